@@ -1,0 +1,171 @@
+"""ctypes binding of libemx.so (C ABI declared in include/emx.h).
+
+The product path has NO fallback: if the shared library is missing or a call is rejected this module
+raises.  ``import torch`` must happen before the library is loaded so that libemx resolves the HIP
+runtime torch already mapped (both carry the soname ``libamdhip64.so.7``), which makes
+``torch.cuda.current_stream().cuda_stream`` a valid ``hipStream_t`` for the kernels here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libemx.so")
+
+EMX_REDUCE_WS = 1024
+MEAN_ABS, MEAN_SQUARE, MEAN_NORM = 0, 1, 2
+VARIANTS = {"mean_abs": MEAN_ABS, "mean_square": MEAN_SQUARE, "mean_norm": MEAN_NORM}
+
+
+class EmxError(RuntimeError):
+    pass
+
+
+_f = C.c_float
+_i = C.c_int
+_l = C.c_int64
+_p = C.c_void_p
+_sz = C.c_size_t
+
+# name -> (restype, argtypes); kept in one table so tests can check it against include/emx.h
+SIGNATURES = {
+    "emx_version": (_i, []),
+    "emx_last_error": (C.c_char_p, []),
+    "emx_target_arch": (C.c_char_p, []),
+    "emx_sketchmap_ws_bytes": (_sz, [_i, _i]),
+    "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
+    "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "emx_periodic_in": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
+    "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
+    "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _i, _i, _p, _p, _p, _p]),
+    "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
+    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libemx.so (once).  Raises EmxError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise EmxError(
+            f"{LIB_PATH} not found: the HIP kernel library has not been built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing -> loud
+        fn.restype = res
+        fn.argtypes = args
+    if lib.emx_version() != 1:
+        raise EmxError(f"libemx.so version {lib.emx_version()} does not match the Python binding (1)")
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise EmxError(f"{what} failed ({rc}): {load().emx_last_error().decode()}")
+
+
+def require_gpu() -> None:
+    if not torch.cuda.is_available():
+        raise EmxError("encodermap_amd needs an AMD GPU (gfx950): torch.cuda.is_available() is False. There is no CPU fallback.")
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "device tensor expected"
+    return t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f32c(t, name):
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        raise EmxError(f"{name}: contiguous float32 device tensor expected, got {t.dtype} contiguous={t.is_contiguous()}")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# thin, shape-checked wrappers (all asynchronous on torch's current stream)
+# ------------------------------------------------------------------------------------------------
+def sketchmap_ws_bytes(B: int, L: int) -> int:
+    return int(load().emx_sketchmap_ws_bytes(B, L))
+
+
+def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws):
+    lib = load()
+    _f32c(Z, "Z"), _f32c(dZ, "dZ")
+    assert X.dtype == torch.float32 and X.stride(1) == 1
+    B, D = X.shape
+    L = Z.shape[1]
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    rc = lib.emx_sketchmap_fwd_bwd(
+        _ptr(X), B, D, X.stride(0), _ptr(Z), L, float(periodicity), sig_arr, float(scale),
+        float(center_scale if center_loss is not None else 0.0), int(row_begin), int(row_end),
+        _ptr(dist_loss), _ptr(center_loss), _ptr(dZ), _ptr(ws), ws.numel() * ws.element_size(), _stream())
+    _check(rc, "emx_sketchmap_fwd_bwd")
+
+
+def pairwise_dist(X, periodicity, out):
+    B, D = X.shape
+    _check(load().emx_pairwise_dist(_ptr(_f32c(X, "X")), B, D, X.stride(0), float(periodicity), _ptr(out), _stream()), "emx_pairwise_dist")
+
+
+def gather_rows(data, idx, periodicity, xb, xin, cursor=None, B=None):
+    N, D = data.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous()
+    B = idx.numel() if B is None else B
+    _check(load().emx_gather_rows(_ptr(_f32c(data, "data")), N, D, _ptr(idx), _ptr(cursor), B, float(periodicity), _ptr(xb), _ptr(xin),
+                                  _stream()), "emx_gather_rows")
+
+
+def periodic_in(x, periodicity, out):
+    B, D = x.shape
+    _check(load().emx_periodic_in(_ptr(x), B, D, x.stride(0), float(periodicity), _ptr(out), out.stride(0), _stream()), "emx_periodic_in")
+
+
+def periodic_out(y, n, off_sin, off_cos, periodicity, out):
+    B = y.shape[0]
+    _check(load().emx_periodic_out(_ptr(y), B, n, y.stride(0), off_sin, off_cos, float(periodicity), _ptr(out), out.stride(0), _stream()),
+           "emx_periodic_out")
+
+
+def periodic_cost_fwd_bwd(y, off_sin, off_cos, periodic_output, target, n, periodicity, variant, coef, row_begin, row_end,
+                          loss, dY, ws, B=None):
+    B = y.shape[0] if B is None else B
+    assert dY.stride(0) == y.stride(0)
+    _check(load().emx_periodic_cost_fwd_bwd(
+        _ptr(y), y.stride(0), off_sin, off_cos, int(bool(periodic_output)), _ptr(target), target.stride(0), B, n,
+        float(periodicity), VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef),
+        int(row_begin), int(row_end), _ptr(loss), _ptr(dY), _ptr(ws), _stream()), "emx_periodic_cost_fwd_bwd")
+
+
+def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):
+    B, L = Z.shape
+    _check(load().emx_center_cost_fwd_bwd(_ptr(_f32c(Z, "Z")), B, L, float(scale), row_begin, row_end, _ptr(loss), _ptr(dZ),
+                                          int(bool(accumulate)), _stream()), "emx_center_cost_fwd_bwd")
+
+
+def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws):
+    _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
+                                float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), _stream()),
+           "emx_adam_step")
+
+
+def step_tick(terms, n_terms, history, term_history, step, cursor=None):
+    cap = history.numel() if history is not None else (term_history.shape[0] if term_history is not None else 0)
+    _check(load().emx_step_tick(_ptr(terms), n_terms, _ptr(history), _ptr(term_history), cap, _ptr(step), _ptr(cursor), _stream()),
+           "emx_step_tick")

@@ -1,0 +1,408 @@
+// Data feed, periodic transforms, row-mean costs, center cost, fused Adam and step bookkeeping (gfx950).
+// Every kernel here is HBM- or launch-latency-bound: rows are walked by whole waves with 16-byte lanes
+// where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
+#include "emx_common.h"
+
+namespace {
+
+using namespace emx;
+
+constexpr float TWO_PI = 6.283185307179586f;
+constexpr int NT = 256;
+
+thread_local char g_err[512] = "";
+
+}  // namespace
+
+namespace emx {
+char* error_buffer() { return g_err; }
+}  // namespace emx
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// K13 + K4: gather rows by index, optionally emit [sin | cos]      autoencoder.py:845-856, models.py:3347-3351
+// one wave per row; lanes stride the feature axis (coalesced 256-B segments of the gathered row)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const float* __restrict__ data, int D, const int64_t* __restrict__ idx,
+                                                         const int64_t* __restrict__ cursor, int B, float ang_scale,
+                                                         float* __restrict__ xb, float* __restrict__ xin) {
+  if (cursor) idx += *cursor * (long)B;
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * NT) >> 6;
+  for (int b = wave; b < B; b += nwaves) {
+    const float* src = data + idx[b] * (long)D;
+    for (int k = lane; k < D; k += 64) {
+      float v = src[k];
+      if (xb) xb[(long)b * D + k] = v;
+      if (xin) {
+        float s, c;
+        sincosf(v * ang_scale, &s, &c);
+        xin[(long)b * 2 * D + k] = s;
+        xin[(long)b * 2 * D + D + k] = c;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(NT) void periodic_in_kernel(const float* __restrict__ x, int B, int D, int ldx, float ang_scale,
+                                                         float* __restrict__ out, int ldo) {
+  long e = (long)blockIdx.x * NT + threadIdx.x;
+  long n = (long)B * D;
+  for (; e < n; e += (long)gridDim.x * NT) {
+    int b = (int)(e / D), k = (int)(e - (long)b * D);
+    float s, c;
+    sincosf(x[(long)b * ldx + k] * ang_scale, &s, &c);
+    out[(long)b * ldo + k] = s;
+    out[(long)b * ldo + D + k] = c;
+  }
+}
+
+__global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restrict__ y, int B, int n, int ldy, int off_sin,
+                                                          int off_cos, float out_scale, float* __restrict__ out, int ldo) {
+  long e = (long)blockIdx.x * NT + threadIdx.x;
+  long tot = (long)B * n;
+  for (; e < tot; e += (long)gridDim.x * NT) {
+    int b = (int)(e / n), k = (int)(e - (long)b * n);
+    const float* row = y + (long)b * ldy;
+    out[(long)b * ldo + k] = atan2f(row[off_sin + k], row[off_cos + k]) * out_scale;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K5: row-mean cost on periodic differences, fused with PeriodicOutput (atan2) forward + backward.
+// one wave per row (two passes over the row for mean_norm); per-block partial -> ws, final sum below.
+// ---------------------------------------------------------------------------------------------------
+struct CostArgs {
+  const float* y;
+  const float* target;
+  float* dY;
+  float* ws;
+  int ldy, ldt, off_sin, off_cos, periodic_output;
+  int n, row_begin, row_end, variant, wrap;
+  float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
+};
+
+__device__ __forceinline__ void cost_elem(const CostArgs& a, const float* yrow, const float* trow, int k, float& pred_s,
+                                          float& pred_c, float& delta, float& ddelta) {
+  float pred;
+  if (a.periodic_output) {
+    pred_s = yrow[a.off_sin + k];
+    pred_c = yrow[a.off_cos + k];
+    pred = atan2f(pred_s, pred_c) * a.out_scale;
+  } else {
+    pred_s = pred_c = 0.f;
+    pred = yrow[a.off_sin + k];
+  }
+  float diff = pred - trow[k];
+  float d = fabsf(diff);
+  float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+  if (a.wrap) {
+    float w = a.period - d;
+    if (d <= w) {
+      delta = d;
+      ddelta = sgn;
+    } else {
+      delta = w;
+      ddelta = -sgn;
+    }
+  } else {
+    delta = d;
+    ddelta = sgn;
+  }
+}
+
+__device__ __forceinline__ void cost_store(const CostArgs& a, float* drow, int k, float g, float s, float c) {
+  if (a.periodic_output) {
+    float inv = a.out_scale / (s * s + c * c);
+    drow[a.off_sin + k] = g * c * inv;
+    drow[a.off_cos + k] = -g * s * inv;
+  } else {
+    drow[a.off_sin + k] = g;
+  }
+}
+
+__global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
+  __shared__ float red[8];
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
+  const int nwaves = (gridDim.x * NT) >> 6;
+  float lsum = 0.f;
+  for (int b = a.row_begin + wave; b < a.row_end; b += nwaves) {
+    const float* yrow = a.y + (long)b * a.ldy;
+    const float* trow = a.target + (long)b * a.ldt;
+    float* drow = a.dY + (long)b * a.ldy;
+    if (a.variant == EMX_MEAN_NORM) {
+      float ss = 0.f;
+      for (int k = lane; k < a.n; k += 64) {
+        float s, c, delta, dd;
+        cost_elem(a, yrow, trow, k, s, c, delta, dd);
+        ss = fmaf(delta, delta, ss);
+      }
+      ss = wave_sum(ss);
+      float nrm = sqrtf(ss);
+      float inv = nrm > 0.f ? 1.f / nrm : 0.f;
+      if (lane == 0) lsum += nrm;
+      for (int k = lane; k < a.n; k += 64) {
+        float s, c, delta, dd;
+        cost_elem(a, yrow, trow, k, s, c, delta, dd);
+        cost_store(a, drow, k, a.gnorm * delta * inv * dd, s, c);
+      }
+    } else {
+      for (int k = lane; k < a.n; k += 64) {
+        float s, c, delta, dd;
+        cost_elem(a, yrow, trow, k, s, c, delta, dd);
+        float g;
+        if (a.variant == EMX_MEAN_ABS) {
+          lsum += fabsf(delta);
+          g = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+        } else {
+          lsum = fmaf(delta, delta, lsum);
+          g = 2.f * delta * dd;
+        }
+        cost_store(a, drow, k, a.gnorm * g, s, c);
+      }
+    }
+  }
+  float t = block_sum<NT>(lsum, red);
+  if (threadIdx.x == 0) a.ws[blockIdx.x] = t;
+}
+
+// *out = scale * sum_{i<n} ws[i], fixed order
+__global__ __launch_bounds__(NT) void final_sum_kernel(const float* __restrict__ ws, int n, float scale, float* __restrict__ out) {
+  __shared__ float red[8];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += NT) s += ws[i];
+  float t = block_sum<NT>(s, red);
+  if (threadIdx.x == 0) *out = t * scale;
+}
+
+__global__ __launch_bounds__(NT) void center_cost_kernel(const float* __restrict__ Z, int L, int row_begin, int row_end,
+                                                         float lscale, float gscale, float* __restrict__ loss,
+                                                         float* __restrict__ dZ, int accumulate) {
+  __shared__ float red[8];
+  const int n = (row_end - row_begin) * L;
+  const long base = (long)row_begin * L;
+  float s = 0.f;
+  for (int e = threadIdx.x; e < n; e += NT) {
+    float z = Z[base + e];
+    s = fmaf(z, z, s);
+    float g = gscale * z;
+    dZ[base + e] = accumulate ? dZ[base + e] + g : g;
+  }
+  float t = block_sum<NT>(s, red);
+  if (threadIdx.x == 0) *loss = t * lscale;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// K11 + K10: fused (L2 gradient) -> clip -> Keras Adam on the flat buffer.  float4 lanes.
+// ---------------------------------------------------------------------------------------------------
+struct AdamArgs {
+  float* w;
+  const float* g;
+  float* m;
+  float* v;
+  const float* l2coef;
+  const int64_t* step;
+  float* ws;
+  long n;
+  float lr, b1, b2, eps, clip;
+};
+
+__device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float l2c, const AdamArgs& a, float alpha,
+                                         float& reg) {
+  reg = fmaf(0.5f * l2c * w, w, reg);
+  g = fmaf(l2c, w, g);
+  if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);
+  m = fmaf(g - m, 1.f - a.b1, m);
+  v = fmaf(fmaf(g, g, -v), 1.f - a.b2, v);
+  w = w - alpha * m / (sqrtf(v) + a.eps);
+}
+
+__global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
+  __shared__ float red[8];
+  const float t = (float)(*a.step + 1);
+  // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step)
+  const float alpha = a.lr * sqrtf(1.f - powf(a.b2, t)) / (1.f - powf(a.b1, t));
+  float reg = 0.f;
+  const long n4 = a.n >> 2;
+  const bool vec = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.m) |
+                     reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef)) & 15) == 0;
+  long start = 0;
+  if (vec) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+      float4 w = reinterpret_cast<float4*>(a.w)[i];
+      float4 g = reinterpret_cast<const float4*>(a.g)[i];
+      float4 m = reinterpret_cast<float4*>(a.m)[i];
+      float4 v = reinterpret_cast<float4*>(a.v)[i];
+      float4 l = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      adam_one(w.x, g.x, m.x, v.x, l.x, a, alpha, reg);
+      adam_one(w.y, g.y, m.y, v.y, l.y, a, alpha, reg);
+      adam_one(w.z, g.z, m.z, v.z, l.z, a, alpha, reg);
+      adam_one(w.w, g.w, m.w, v.w, l.w, a, alpha, reg);
+      reinterpret_cast<float4*>(a.w)[i] = w;
+      reinterpret_cast<float4*>(a.m)[i] = m;
+      reinterpret_cast<float4*>(a.v)[i] = v;
+    }
+    start = n4 << 2;
+  }
+  for (long i = start + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += (long)gridDim.x * NT) {
+    float w = a.w[i], m = a.m[i], v = a.v[i];
+    adam_one(w, a.g[i], m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha, reg);
+    a.w[i] = w;
+    a.m[i] = m;
+    a.v[i] = v;
+  }
+  float tsum = block_sum<NT>(reg, red);
+  if (threadIdx.x == 0) a.ws[blockIdx.x] = tsum;
+}
+
+__global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
+                                 float* __restrict__ term_history, long capacity, int64_t* __restrict__ step,
+                                 int64_t* __restrict__ cursor) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long s = *step;
+  float tot = 0.f;
+  for (int i = 0; i < n_terms; ++i) tot += terms[i];
+  if (s >= 0 && s < capacity) {
+    if (history) history[s] = tot;
+    if (term_history)
+      for (int i = 0; i < n_terms; ++i) term_history[s * n_terms + i] = terms[i];
+  }
+  *step = s + 1;
+  if (cursor) *cursor += 1;
+}
+
+inline int grid_for(long work_items, int per_block) {
+  long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > EMX_REDUCE_WS) g = EMX_REDUCE_WS;
+  return (int)g;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emx_version(void) { return EMX_VERSION; }
+const char* emx_last_error(void) { return g_err; }
+const char* emx_target_arch(void) { return "gfx950"; }
+
+int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B, float periodicity,
+                    float* xb, float* xin, emx_stream_t stream) {
+  EMX_REQUIRE(data && idx && (xb || xin), "emx_gather_rows: null pointer argument");
+  EMX_REQUIRE(N > 0 && D > 0 && B > 0, "emx_gather_rows: bad shape N=%ld D=%d B=%d", (long)N, D, B);
+  EMX_REQUIRE(!xin || (std::isfinite(periodicity) && periodicity > 0.f), "emx_gather_rows: sin/cos output needs a finite periodicity");
+  float ang = xin ? (periodicity == TWO_PI ? 1.f : TWO_PI / periodicity) : 1.f;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, 4)), dim3(NT), 0, (hipStream_t)stream, data, D, idx, cursor, B, ang, xb, xin);
+  return emx::check_launch("gather_rows_kernel");
+}
+
+int emx_periodic_in(const float* x, int B, int D, int ldx, float periodicity, float* out, int ldo, emx_stream_t stream) {
+  EMX_REQUIRE(x && out && B > 0 && D > 0 && ldx >= D && ldo >= 2 * D, "emx_periodic_in: bad arguments");
+  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "emx_periodic_in: needs a finite periodicity");
+  float ang = periodicity == TWO_PI ? 1.f : TWO_PI / periodicity;
+  hipLaunchKernelGGL(periodic_in_kernel, dim3(grid_for((long)B * D, NT)), dim3(NT), 0, (hipStream_t)stream, x, B, D, ldx, ang, out,
+                     ldo);
+  return emx::check_launch("periodic_in_kernel");
+}
+
+int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off_cos, float periodicity, float* out, int ldo,
+                     emx_stream_t stream) {
+  EMX_REQUIRE(y && out && B > 0 && n > 0 && ldo >= n, "emx_periodic_out: bad arguments");
+  EMX_REQUIRE(off_sin >= 0 && off_cos >= 0 && off_sin + n <= ldy && off_cos + n <= ldy, "emx_periodic_out: column window outside the row");
+  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "emx_periodic_out: needs a finite periodicity");
+  float sc = periodicity == TWO_PI ? 1.f : periodicity / TWO_PI;
+  hipLaunchKernelGGL(periodic_out_kernel, dim3(grid_for((long)B * n, NT)), dim3(NT), 0, (hipStream_t)stream, y, B, n, ldy, off_sin,
+                     off_cos, sc, out, ldo);
+  return emx::check_launch("periodic_out_kernel");
+}
+
+int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output, const float* target, int ldt,
+                              int B, int n, float periodicity, int variant, float coef, int row_begin, int row_end, float* loss,
+                              float* dY, float* ws, emx_stream_t stream) {
+  EMX_REQUIRE(y && target && loss && dY && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
+  EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "emx_periodic_cost_fwd_bwd: bad shape");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_periodic_cost_fwd_bwd: bad row block");
+  EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "emx_periodic_cost_fwd_bwd: cost variant %d not available", variant);
+  EMX_REQUIRE(off_sin >= 0 && off_sin + n <= ldy && (!periodic_output || (off_cos >= 0 && off_cos + n <= ldy)),
+              "emx_periodic_cost_fwd_bwd: column window outside the row");
+  EMX_REQUIRE(!periodic_output || std::isfinite(periodicity), "emx_periodic_cost_fwd_bwd: periodic output needs a finite periodicity");
+  CostArgs a;
+  a.y = y;
+  a.target = target;
+  a.dY = dY;
+  a.ws = ws;
+  a.ldy = ldy;
+  a.ldt = ldt;
+  a.off_sin = off_sin;
+  a.off_cos = off_cos;
+  a.periodic_output = periodic_output;
+  a.n = n;
+  a.row_begin = row_begin;
+  a.row_end = row_end;
+  a.variant = variant;
+  a.wrap = std::isfinite(periodicity);
+  a.period = periodicity;
+  a.out_scale = (a.wrap && periodicity != TWO_PI) ? periodicity / TWO_PI : 1.f;
+  const double denom = (variant == EMX_MEAN_NORM) ? (double)B : (double)B * n;
+  a.gnorm = (float)(coef / denom);
+  const int grid = grid_for(row_end - row_begin, 4);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
+  int rc = emx::check_launch("periodic_cost_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, a.gnorm, loss);
+  return emx::check_launch("final_sum_kernel");
+}
+
+int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_begin, int row_end, float* loss, float* dZ,
+                            int accumulate, emx_stream_t stream) {
+  EMX_REQUIRE(Z && loss && dZ && B > 0 && L > 0, "emx_center_cost_fwd_bwd: bad arguments");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_center_cost_fwd_bwd: bad row block");
+  const double bl = (double)B * L;
+  hipLaunchKernelGGL(center_cost_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, Z, L, row_begin, row_end, (float)(scale / bl),
+                     (float)(2.0 * scale / bl), loss, dZ, accumulate);
+  return emx::check_launch("center_cost_kernel");
+}
+
+int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float clip, const int64_t* step, float* reg_loss, float* ws, emx_stream_t stream) {
+  EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
+  EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
+  AdamArgs a;
+  a.w = w;
+  a.g = g;
+  a.m = m;
+  a.v = v;
+  a.l2coef = l2coef;
+  a.step = step;
+  a.ws = ws;
+  a.n = n;
+  a.lr = lr;
+  a.b1 = beta1;
+  a.b2 = beta2;
+  a.eps = eps;
+  a.clip = clip;
+  const int grid = grid_for((n + 3) / 4, NT);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
+  int rc = emx::check_launch("adam_kernel");
+  if (rc) return rc;
+  if (reg_loss) {
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, reg_loss);
+    rc = emx::check_launch("final_sum_kernel");
+  }
+  return rc;
+}
+
+int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity, int64_t* step,
+                  int64_t* cursor, emx_stream_t stream) {
+  EMX_REQUIRE(terms && step && n_terms > 0 && n_terms <= 64, "emx_step_tick: bad arguments");
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, n_terms, history, term_history, (long)capacity,
+                     step, cursor);
+  return emx::check_launch("step_tick_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,528 @@
+// K1/K2: fused sketch-map sigmoid pairwise-distance cost, forward + latent gradient (gfx950).
+//
+// Replaces the TensorFlow op chain of
+//   pairwise_dist / pairwise_dist_periodic / sigmoid   encodermap/misc/distances.py:66-88,144-176,179-255
+//   sigmoid_loss_func                                  encodermap/loss_functions/loss_functions.py:351-367
+// which materialises >= 10 [B,B] (periodic: [B,B,D]) temporaries, by ONE tiled all-pairs kernel plus a
+// small fixed-order reduction kernel.
+//
+// Layout / algorithm
+//   * The B x B pair matrix is cut into TM x TN tiles, one 256-thread workgroup (4 waves) per tile.  With the
+//     full batch owned by this rank only tiles with tj >= ti are launched (i<->j symmetry): an off-diagonal
+//     tile counts twice in the loss and produces both the row sums (gradient of rows in ti) and the column
+//     sums (gradient of rows in tj).  With a data-parallel row block the rectangle rows x [0,B) is launched
+//     and only row sums are produced.
+//   * K loop: 32-wide chunks of the feature axis are staged global -> registers -> LDS (128-B coalesced
+//     row segments, ds_write_b128), the next chunk's global loads are in flight while the current one is
+//     consumed.  LDS rows are padded to 36 floats so that the interleaved row assignment (row = t + 16 r)
+//     reads conflict-free ds_read_b128 fragments.  Each thread owns an RM x RN register micro-tile of
+//     squared-distance accumulators (8x8 for 128-tiles, 4x4 for 64-tiles): per pair-element one v_sub +
+//     one v_fma (Euclidean) or sub, sub|abs|, min, fma (periodic).  FP32 VALU bound, not HBM bound:
+//     algorithmic HBM traffic is 4*B*(D+2L) bytes per launch.
+//   * Epilogue (registers): d^2 -> sigmoid complements E = (1 + c (d/sig)^a)^(-b/a), f = E_l - E_h
+//     (= S_h - S_l without the 1-x cancellation), loss += f^2, g = f * S_l'(d_l)/d_l, row/column gradient
+//     sums.  The default parameter family (a_h=12,b_h=6,a_l=2,b_l=6) needs one v_rsq and one v_rcp per pair;
+//     any other parameters take the exp2/log2 path.
+//   * Per-tile partial sums go to a workspace slot that exactly one tile writes; the finish kernel adds the
+//     slots in index order (no float atomics -> bitwise reproducible), applies the scale and the optional
+//     center cost (loss_functions.py:422-449) and writes dZ.
+//
+// Deviations from the reference arithmetic, all below fp32 resolution of the loss: distances are formed by
+// direct differences instead of the Gram identity (no cancellation); the periodic path omits the +1e-12
+// regularisers of distances.py:169-175 (they only keep TF's sqrt gradient finite; X carries no gradient here).
+#include "emx_common.h"
+
+namespace {
+
+using namespace emx;
+
+constexpr int NT = 256;
+constexpr int KC = 32;       // feature chunk staged per iteration
+constexpr int LS = KC + 4;   // padded LDS row stride (floats)
+
+struct SigDev {
+  float inv_sig2;   // 1/sig^2
+  float c;          // 2^(a/b) - 1
+  float half_a;     // a/2
+  float nba;        // -b/a
+  float half_am2;   // (a-2)/2
+  float vmax;       // clamp on (d/sig)^2 so that v^(a/2) stays finite
+  int a_is_2;
+};
+
+struct SkArgs {
+  const float* X;
+  const float* Z;
+  float* P;          // [nslots][nrows_pad][L]
+  float* tile_loss;  // [ntiles]
+  int B, D, ldx, L;
+  int row0, row_end;  // rows handled: [row0,row_end)
+  int nbr, nbc;       // tile rows / tile columns
+  int nrows_pad;
+  int symm;
+  int vec4;
+  float period;
+  SigDev sh, sl;
+};
+
+template <int N>
+__device__ __forceinline__ float powi(float v) {
+  if constexpr (N == 0) return 1.f;
+  else if constexpr (N == 1) return v;
+  else if constexpr (N % 2 == 0) { float h = powi<N / 2>(v); return h * h; }
+  else return v * powi<N - 1>(v);
+}
+
+// complement of the sketch-map sigmoid, E(v) = (1 + c v^(a/2))^(-b/a), v = (d/sig)^2   (distances.py:86)
+template <bool FAST>
+__device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
+  float v = fminf(d2 * s.inv_sig2, s.vmax);
+  if constexpr (FAST) {  // a = 12, b = 6
+    float q = fmaf(s.c, powi<6>(v), 1.f);
+    return __builtin_amdgcn_rsqf(q);
+  } else {
+    float t = __builtin_amdgcn_exp2f(s.half_a * __builtin_amdgcn_logf(v));
+    float q = fmaf(s.c, t, 1.f);
+    return __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
+  }
+}
+
+// low-d: E and G = S'(d)/d / (b c / sig^2) = v^((a-2)/2) * q^(-b/a-1)
+template <bool FAST>
+__device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, float& G) {
+  float v = fminf(d2 * s.inv_sig2, s.vmax);
+  if constexpr (FAST) {  // a = 2, b = 6
+    float q = fmaf(s.c, v, 1.f);
+    float r = __builtin_amdgcn_rcpf(q);
+    E = r * r * r;
+    G = E * r;
+  } else {
+    float lv = __builtin_amdgcn_logf(v);
+    float t = __builtin_amdgcn_exp2f(s.half_a * lv);
+    float q = fmaf(s.c, t, 1.f);
+    E = __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
+    float um = s.a_is_2 ? 1.f : __builtin_amdgcn_exp2f(s.half_am2 * lv);
+    G = um * E * __builtin_amdgcn_rcpf(q);
+    G = (v > 0.f) ? G : 0.f;  // reference mask: coincident latent points carry no gradient
+  }
+}
+
+template <bool PERIODIC>
+__device__ __forceinline__ float acc4(const float4& a, const float4& b, float acc, float period) {
+  if constexpr (PERIODIC) {
+    float d0 = fabsf(a.x - b.x), d1 = fabsf(a.y - b.y), d2 = fabsf(a.z - b.z), d3 = fabsf(a.w - b.w);
+    d0 = fminf(d0, period - d0);
+    d1 = fminf(d1, period - d1);
+    d2 = fminf(d2, period - d2);
+    d3 = fminf(d3, period - d3);
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  } else {
+    float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long row, int ldx, int k, int D, bool rowvalid,
+                                            bool vec4) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rowvalid && k < D) {
+    const float* p = X + row * (long)ldx + k;
+    if (vec4) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      v.x = p[0];
+      if (k + 1 < D) v.y = p[1];
+      if (k + 2 < D) v.z = p[2];
+      if (k + 3 < D) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+// upper-triangle linear index -> (ti, tj), ti <= tj < nb, row-major
+__device__ __forceinline__ void tri_decode(int t, int nb, int& ti, int& tj) {
+  float fn = 2.f * nb + 1.f;
+  int i = (int)((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
+  i = max(0, min(i, nb - 1));
+  while (i > 0 && (i * nb - i * (i - 1) / 2) > t) --i;
+  while ((i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
+  ti = i;
+  tj = i + (t - (i * nb - i * (i - 1) / 2));
+}
+
+template <int TM, int TN, int LT, bool PERIODIC, bool FASTSIG>
+__global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
+  constexpr int RM = TM / 16, RN = TN / 16;
+  constexpr int LMAX = LT ? LT : 4;
+  constexpr int STAGE = (TM + TN) * LS;
+  constexpr int PART = 16 * (TM + TN) * LMAX;
+  constexpr int SMEM = (STAGE > PART ? STAGE : PART) + 8;
+  __shared__ __align__(16) float smem[SMEM];
+  float* Xi_s = smem;
+  float* Xj_s = smem + TM * LS;
+
+  const int L = LT ? LT : a.L;
+  const int tid = threadIdx.x;
+  const int tx = tid & 15, ty = tid >> 4;
+
+  int ti, tj;
+  if (a.symm) {
+    tri_decode(blockIdx.x, a.nbc, ti, tj);
+  } else {
+    ti = blockIdx.x / a.nbc;
+    tj = blockIdx.x - ti * a.nbc;
+  }
+  const int i0 = a.row0 + ti * TM;
+  const int j0 = tj * TN;
+  const bool offdiag = a.symm && (ti != tj);
+
+  float acc[RM][RN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < RN; ++c) acc[r][c] = 0.f;
+
+  // ---- K loop -------------------------------------------------------------------------------
+  const int kq = tid & 7, rb = tid >> 3;
+  constexpr int QI = TM / 32, QJ = TN / 32;
+  float4 pi[QI], pj[QJ];
+  const bool vec4 = a.vec4 != 0;
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < QI; ++q) {
+      int row = i0 + rb + 32 * q;
+      pi[q] = load_row4(a.X, row, a.ldx, k0 + 4 * kq, a.D, row < a.row_end, vec4);
+    }
+#pragma unroll
+    for (int q = 0; q < QJ; ++q) {
+      int row = j0 + rb + 32 * q;
+      pj[q] = load_row4(a.X, row, a.ldx, k0 + 4 * kq, a.D, row < a.B, vec4);
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < a.D; k0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < QI; ++q) *reinterpret_cast<float4*>(&Xi_s[(rb + 32 * q) * LS + 4 * kq]) = pi[q];
+#pragma unroll
+    for (int q = 0; q < QJ; ++q) *reinterpret_cast<float4*>(&Xj_s[(rb + 32 * q) * LS + 4 * kq]) = pj[q];
+    __syncthreads();
+    if (k0 + KC < a.D) gload(k0 + KC);
+#pragma unroll 2
+    for (int kk = 0; kk < KC; kk += 4) {
+      float4 av[RM];
+#pragma unroll
+      for (int r = 0; r < RM; ++r) av[r] = *reinterpret_cast<const float4*>(&Xi_s[(ty + 16 * r) * LS + kk]);
+#pragma unroll
+      for (int c = 0; c < RN; ++c) {
+        const float4 bv = *reinterpret_cast<const float4*>(&Xj_s[(tx + 16 * c) * LS + kk]);
+#pragma unroll
+        for (int r = 0; r < RM; ++r) acc[r][c] = acc4<PERIODIC>(av[r], bv, acc[r][c], a.period);
+      }
+    }
+  }
+  __syncthreads();  // staging LDS is reused for the partial sums below
+
+  // ---- epilogue -----------------------------------------------------------------------------
+  float zi[RM][LMAX], zj[RN][LMAX], wr[RM], wc[RN];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) {
+    int row = i0 + ty + 16 * r;
+    bool ok = row < a.row_end;
+    wr[r] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) zi[r][l] = (ok && l < L) ? a.Z[(long)row * L + l] : 0.f;
+  }
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    int row = j0 + tx + 16 * c;
+    bool ok = row < a.B;
+    wc[c] = ok ? 1.f : 0.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) zj[c][l] = (ok && l < L) ? a.Z[(long)row * L + l] : 0.f;
+  }
+
+  float* rpart = smem;                       // [TM][LMAX][16]
+  float* cpart = smem + 16 * TM * LMAX;      // [TN][LMAX][16]
+  float gi[RM][LMAX];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gi[r][l] = 0.f;
+  float lsum = 0.f;
+
+#pragma unroll
+  for (int c = 0; c < RN; ++c) {
+    float gj[LMAX];
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      float dz[LMAX];
+      float dl2 = 0.f;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        dz[l] = zi[r][l] - zj[c][l];
+        dl2 = fmaf(dz[l], dz[l], dl2);
+      }
+      float Eh = sig_E_high<FASTSIG>(acc[r][c], a.sh);
+      float El, G;
+      sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+      float f = (El - Eh) * (wr[r] * wc[c]);
+      lsum = fmaf(f, f, lsum);
+      float g = f * G;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        gi[r][l] = fmaf(g, dz[l], gi[r][l]);
+        gj[l] = fmaf(-g, dz[l], gj[l]);
+      }
+    }
+    if (offdiag) {
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) cpart[((tx + 16 * c) * LMAX + l) * 16 + ty] = gj[l];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) rpart[((ty + 16 * r) * LMAX + l) * 16 + tx] = gi[r][l];
+
+  // tile loss: deterministic block reduction (own small LDS area behind the partials)
+  float* red = smem + SMEM - 8;
+  float tl = block_sum<NT>(lsum, red);  // contains __syncthreads -> partials visible
+  if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
+
+  // fold the 16 partials per (row, l) in fixed order and publish to this tile's private slot
+  for (int e = tid; e < TM * LMAX; e += NT) {
+    int rl = e / LMAX, l = e - rl * LMAX;
+    if (l < L) {
+      const float4* p = reinterpret_cast<const float4*>(&rpart[e * 16]);
+      float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+      float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+      int row_local = (i0 - a.row0) + rl;
+      a.P[((long)tj * a.nrows_pad + row_local) * L + l] = s;
+    }
+  }
+  if (offdiag) {
+    for (int e = tid; e < TN * LMAX; e += NT) {
+      int rl = e / LMAX, l = e - rl * LMAX;
+      if (l < L) {
+        const float4* p = reinterpret_cast<const float4*>(&cpart[e * 16]);
+        float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+        float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                  (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+        int row_local = (j0 - a.row0) + rl;  // symm => row0 == 0
+        a.P[((long)ti * a.nrows_pad + row_local) * L + l] = s;
+      }
+    }
+  }
+}
+
+struct FinArgs {
+  const float* P;
+  const float* tile_loss;
+  const float* Z;
+  float* dZ;
+  float* dist_loss;
+  float* center_loss;
+  int B, L, row0, row_end, nrows_pad, nslots, ntiles, symm, tile;
+  float gscale;      // -4 * scale * (b_l c_l / sig_l^2) / B^2
+  float lscale;      // scale / B^2
+  float cgrad;       // 2 * center_scale / (B*L)
+  float cscale;      // center_scale / (B*L)
+};
+
+// grid: ceil(nrows*L/256) blocks for dZ + 1 block for the scalar losses
+__global__ __launch_bounds__(NT) void sk_finish_kernel(const FinArgs a) {
+  __shared__ float red[8];
+  const int nrows = a.row_end - a.row0;
+  const int nelem = nrows * a.L;
+  if (blockIdx.x == gridDim.x - 1) {
+    float s = 0.f;
+    for (int t = threadIdx.x; t < a.ntiles; t += NT) s += a.tile_loss[t];
+    float tot = block_sum<NT>(s, red);
+    if (threadIdx.x == 0) *a.dist_loss = tot * a.lscale;
+    if (a.center_loss) {
+      float c = 0.f;
+      for (int e = threadIdx.x; e < nelem; e += NT) {
+        float z = a.Z[(long)a.row0 * a.L + e];
+        c = fmaf(z, z, c);
+      }
+      float ct = block_sum<NT>(c, red);
+      if (threadIdx.x == 0) *a.center_loss = ct * a.cscale;
+    }
+    return;
+  }
+  int e = blockIdx.x * NT + threadIdx.x;
+  if (e >= nelem) return;
+  int row_local = e / a.L;
+  float s = 0.f;
+  // symmetric launch: slot s of row r was written by tile (min,max) of (r/tile, s) -> every slot is valid
+  for (int sl = 0; sl < a.nslots; ++sl) s += a.P[((long)sl * a.nrows_pad) * a.L + e];
+  (void)row_local;
+  long gidx = (long)a.row0 * a.L + e;
+  float g = a.gscale * s;
+  if (a.center_loss) g = fmaf(a.cgrad, a.Z[gidx], g);
+  a.dZ[gidx] = g;
+}
+
+SigDev make_sig(float sig, float aa, float bb) {
+  SigDev s;
+  s.inv_sig2 = 1.f / (sig * sig);
+  s.c = (float)(std::pow(2.0, (double)aa / bb) - 1.0);
+  s.half_a = 0.5f * aa;
+  s.nba = -bb / aa;
+  s.half_am2 = 0.5f * (aa - 2.f);
+  s.vmax = (float)std::pow(2.0, 100.0 / std::max(0.5 * aa, 1.0));
+  s.a_is_2 = (aa == 2.f);
+  return s;
+}
+
+template <int T, int LT, bool PERIODIC, bool FAST>
+void launch_tiles(const SkArgs& a, int ntiles, hipStream_t st) {
+  hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PERIODIC, FAST>), dim3(ntiles), dim3(NT), 0, st, a);
+}
+
+template <int T, int LT>
+void dispatch2(const SkArgs& a, int ntiles, bool periodic, bool fast, hipStream_t st) {
+  if (periodic) {
+    if (fast) launch_tiles<T, LT, true, true>(a, ntiles, st);
+    else launch_tiles<T, LT, true, false>(a, ntiles, st);
+  } else {
+    if (fast) launch_tiles<T, LT, false, true>(a, ntiles, st);
+    else launch_tiles<T, LT, false, false>(a, ntiles, st);
+  }
+}
+
+int pick_tile(int B, int nrows) {
+  // 128-tiles halve the LDS traffic per flop but quantise badly on 256 CUs when there are few of them
+  long pairs = (long)B * nrows;
+  return (pairs >= (long)8192 * 8192) ? 128 : 64;
+}
+
+__global__ void pairwise_dist_kernel(const float* __restrict__ X, int B, int D, int ldx, float period, int periodic,
+                                     float* __restrict__ out) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  int i = blockIdx.y;
+  if (j >= B) return;
+  float acc = 0.f;
+  for (int k = 0; k < D; ++k) {
+    float d = X[(long)i * ldx + k] - X[(long)j * ldx + k];
+    if (periodic) {
+      d = fabsf(d);
+      d = fminf(d, period - d);
+    }
+    acc = fmaf(d, d, acc);
+  }
+  out[(long)i * B + j] = sqrtf(acc);
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t emx_sketchmap_ws_bytes(int B, int L) {
+  if (B <= 0 || L <= 0) return 0;
+  size_t nb = (size_t)(B + 63) / 64;
+  return (nb * nb * 64 * (size_t)L + nb * nb + 64) * sizeof(float);
+}
+
+int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+                          const float sig[6], float scale, float center_scale, int row_begin, int row_end,
+                          float* dist_loss, float* center_loss, float* dZ, void* ws, size_t ws_bytes,
+                          emx_stream_t stream) {
+  EMX_REQUIRE(X && Z && dist_loss && dZ && ws && sig, "emx_sketchmap_fwd_bwd: null pointer argument");
+  EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "emx_sketchmap_fwd_bwd: bad shape B=%d D=%d ldx=%d", B, D, ldx);
+  if (L < 1 || L > 4)
+    return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_fwd_bwd: latent dimension %d not supported (1..4)", L);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_sketchmap_fwd_bwd: bad row block [%d,%d) of %d",
+              row_begin, row_end, B);
+  EMX_REQUIRE(periodicity > 0.f, "emx_sketchmap_fwd_bwd: periodicity must be > 0 (INFINITY for none)");
+  for (int i = 0; i < 6; ++i) EMX_REQUIRE(sig[i] > 0.f, "emx_sketchmap_fwd_bwd: sigmoid parameters must be > 0");
+  if (ws_bytes < emx_sketchmap_ws_bytes(B, L))
+    return emx::fail(EMX_EWORKSPACE, "emx_sketchmap_fwd_bwd: workspace %zu < %zu bytes", ws_bytes,
+                     emx_sketchmap_ws_bytes(B, L));
+  hipStream_t st = (hipStream_t)stream;
+  const bool symm = (row_begin == 0 && row_end == B);
+  const int nrows = row_end - row_begin;
+  const int T = pick_tile(B, nrows);
+  const bool periodic = std::isfinite(periodicity);
+  const bool fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
+
+  SkArgs a;
+  a.X = X;
+  a.Z = Z;
+  a.B = B;
+  a.D = D;
+  a.ldx = ldx;
+  a.L = L;
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  a.nbr = (nrows + T - 1) / T;
+  a.nbc = (B + T - 1) / T;
+  a.nrows_pad = a.nbr * T;
+  a.symm = symm;
+  a.vec4 = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  a.period = periodicity;
+  a.sh = make_sig(sig[0], sig[1], sig[2]);
+  a.sl = make_sig(sig[3], sig[4], sig[5]);
+  const int ntiles = symm ? a.nbc * (a.nbc + 1) / 2 : a.nbr * a.nbc;
+  const int nslots = a.nbc;
+  float* wsf = static_cast<float*>(ws);
+  a.P = wsf;
+  a.tile_loss = wsf + (size_t)nslots * a.nrows_pad * L;
+
+  if (T == 128) {
+    if (L == 2) dispatch2<128, 2>(a, ntiles, periodic, fast, st);
+    else dispatch2<128, 0>(a, ntiles, periodic, fast, st);
+  } else {
+    if (L == 2) dispatch2<64, 2>(a, ntiles, periodic, fast, st);
+    else dispatch2<64, 0>(a, ntiles, periodic, fast, st);
+  }
+  int rc = emx::check_launch("sk_tile_kernel");
+  if (rc) return rc;
+
+  FinArgs f;
+  f.P = a.P;
+  f.tile_loss = a.tile_loss;
+  f.Z = Z;
+  f.dZ = dZ;
+  f.dist_loss = dist_loss;
+  f.center_loss = center_loss;
+  f.B = B;
+  f.L = L;
+  f.row0 = row_begin;
+  f.row_end = row_end;
+  f.nrows_pad = a.nrows_pad;
+  f.nslots = nslots;
+  f.ntiles = ntiles;
+  f.symm = symm;
+  f.tile = T;
+  const double B2 = (double)B * (double)B;
+  const double gl = (double)sig[5] * (std::pow(2.0, (double)sig[4] / sig[5]) - 1.0) / ((double)sig[3] * sig[3]);
+  f.gscale = (float)(-4.0 * scale * gl / B2);
+  f.lscale = (float)(scale / B2);
+  f.cgrad = (float)(2.0 * center_scale / ((double)B * L));
+  f.cscale = (float)(center_scale / ((double)B * L));
+  const int nblk = (nrows * L + NT - 1) / NT + 1;
+  hipLaunchKernelGGL(sk_finish_kernel, dim3(nblk), dim3(NT), 0, st, f);
+  return emx::check_launch("sk_finish_kernel");
+}
+
+int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream) {
+  EMX_REQUIRE(X && out && B > 0 && D > 0 && ldx >= D, "emx_pairwise_dist: bad arguments");
+  dim3 grid((B + 255) / 256, B);
+  hipLaunchKernelGGL(pairwise_dist_kernel, grid, dim3(256), 0, (hipStream_t)stream, X, B, D, ldx, periodicity,
+                     std::isfinite(periodicity) ? 1 : 0, out);
+  return emx::check_launch("pairwise_dist_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,402 @@
+"""Device engine of the dense (sequential) autoencoder: ONE training step of the reference's
+``SequentialModel.train_step`` (encodermap/models/models.py:3367-3401) as a fixed sequence of HIP kernels
+(libemx, through ctypes) and hipBLASLt GEMMs (through torch), captured once into a hipGraph and replayed.
+
+What a step does (reference call stack: SURVEY.md section 3.2):
+
+  gather rows (+ sin/cos)            emx_gather_rows           autoencoder.py:845-856, models.py:3347-3351
+  encoder / decoder Dense layers     torch.addmm + tanh        models.py:3179-3220 (the only MFMA use)
+  sketch-map distance + center cost  emx_sketchmap_fwd_bwd     loss_functions.py:266-296,351-367,422-449
+  auto cost (+ atan2 output)         emx_periodic_cost_fwd_bwd loss_functions.py:586-626, models.py:3353-3359
+  manual backward through the MLP    torch.mm / sum            (tape.gradient, models.py:3392-3393)
+  [data parallel: one all-reduce of the flat gradient + loss-term buffer]
+  L2 + clip + Adam, regulariser cost emx_adam_step             autoencoder.py:741-743, loss_functions.py:488-506
+  history / counters on the device   emx_step_tick             models.py:3399-3401
+
+The reference evaluates the forward pass once per loss term (4x) plus twice more for the latent
+(SURVEY.md section 3.2); the forward is deterministic, so a single pass gives identical numbers.
+
+Memory layout: parameters, gradients (+ 8 loss-term slots), Adam m and v are four flat float32 buffers
+(``layout.NetLayout``); per-layer kernels/biases are views.  The training set lives in HBM for the whole
+run (N x D float32: 0.5 GB for 1e6 x 128, 4 GB for 2e6 x 512 -- 288 GB per GPU make host staging pointless);
+mini-batches are drawn by a device-side permutation stream and gathered by index.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .layout import NetLayout, build_layout, init_parameters, l2_coefficients, pack_weights, unpack_weights
+
+N_TERMS = 8
+T_AUTO, T_REG, T_CENTER, T_DIST = 0, 1, 2, 3
+TERM_NAMES = ("auto", "reg", "center", "distance")
+INF = float("inf")
+
+
+class DataParallel:
+    """Partition of one step over ranks.  ``mode``:
+
+    ``"rowblock"``  every rank sees the same global batch of ``batch_size`` rows, owns a contiguous row block
+                    and all-reduces (SUM) the flat gradient: bit-for-bit the single-process objective.
+    ``"replica"``   every rank draws its own mini-batch of ``batch_size`` rows and gradients are averaged:
+                    classic data parallelism (weak scaling), the objective is the mean of the per-rank costs.
+    """
+
+    def __init__(self, rank: int = 0, world_size: int = 1, mode: str = "replica", group=None):
+        if mode not in ("rowblock", "replica"):
+            raise ValueError(f"data-parallel mode {mode!r} not available")
+        self.rank, self.world_size, self.mode, self.group = int(rank), int(world_size), mode, group
+
+    @property
+    def active(self) -> bool:
+        return self.world_size > 1
+
+    def row_block(self, batch_size: int):
+        """Rows of the global batch owned by this rank (balanced contiguous blocks)."""
+        if not self.active or self.mode == "replica":
+            return 0, batch_size
+        base, rem = divmod(batch_size, self.world_size)
+        begin = self.rank * base + min(self.rank, rem)
+        return begin, begin + base + (1 if self.rank < rem else 0)
+
+    def all_reduce_(self, flat: torch.Tensor) -> None:
+        """The single collective of a step: gradients and loss terms in one flat buffer."""
+        if not self.active:
+            return
+        import torch.distributed as dist
+
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        if self.mode == "replica":
+            flat.mul_(1.0 / self.world_size)
+
+    def batch_seed(self, seed: Optional[int]) -> Optional[int]:
+        """rowblock: all ranks must draw identical batches; replica: distinct streams per rank."""
+        if seed is None:
+            seed = 0 if self.active else None
+        if seed is None:
+            return None
+        return seed if self.mode == "rowblock" else seed * 1000003 + self.rank
+
+
+class SequentialEngine:
+    """Weights, optimizer state, buffers and the captured step of Autoencoder / EncoderMap."""
+
+    def __init__(self, input_dim: int, p, *, with_distance: bool, device: str = "cuda:0",
+                 weights: Optional[Sequence[np.ndarray]] = None, dp: Optional[DataParallel] = None,
+                 use_graph: bool = True, history_capacity: Optional[int] = None):
+        _lib.require_gpu()
+        _lib.load()
+        self.p = p
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.dp = dp or DataParallel()
+        self.with_distance = bool(with_distance)
+        self.periodicity = float(p.periodicity)
+        self.periodic = self.periodicity < INF
+        self.D = int(input_dim)
+        self.net_dim = 2 * self.D if self.periodic else self.D
+        self.layout: NetLayout = build_layout(p.n_neurons, p.activation_functions, self.net_dim)
+        self.L = self.layout.latent_dim
+        self.B = int(p.batch_size)
+        self.use_graph = bool(use_graph)
+        lay, dev = self.layout, self.device
+        P = lay.n_params
+
+        flat = pack_weights(lay, weights) if weights is not None else init_parameters(lay, p.seed)
+        self.w = torch.from_numpy(flat).to(dev)
+        self.g_ext = torch.zeros(P + N_TERMS, dtype=torch.float32, device=dev)   # gradients | loss terms
+        self.g = self.g_ext[:P]
+        self.terms = self.g_ext[P:]
+        self.m = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(P, dtype=torch.float32, device=dev)
+        self.l2coef = torch.from_numpy(l2_coefficients(lay, p.l2_reg_constant)).to(dev)
+        self.W = [self.w[l.w_off: l.w_off + l.n_in * l.n_out].view(l.n_in, l.n_out) for l in lay.layers]
+        self.b = [self.w[l.b_off: l.b_off + l.n_out] for l in lay.layers]
+        self.gW = [self.g[l.w_off: l.w_off + l.n_in * l.n_out].view(l.n_in, l.n_out) for l in lay.layers]
+        self.gb = [self.g[l.b_off: l.b_off + l.n_out] for l in lay.layers]
+
+        self.step = torch.full((1,), int(p.current_training_step), dtype=torch.int64, device=dev)
+        self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.history_capacity = int(history_capacity or max(int(p.n_steps), 1))
+        self.history = torch.zeros(self.history_capacity, dtype=torch.float32, device=dev)
+        self.term_history = torch.zeros(self.history_capacity, N_TERMS, dtype=torch.float32, device=dev)
+        self._hist_base = int(p.current_training_step)   # history[i] belongs to training step _hist_base + i
+        self.hstep = torch.zeros(1, dtype=torch.int64, device=dev)  # write position in history
+
+        self.rb, self.re = self.dp.row_block(self.B)
+        self._alloc_step_buffers(self.B)
+        self._graph = None
+        self.data = None
+        self.idx_block = None
+        self._gen = None
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc_step_buffers(self, B: int) -> None:
+        lay, dev, f32 = self.layout, self.device, torch.float32
+        nown = self.re - self.rb
+        self.xb = torch.empty(B, self.D, dtype=f32, device=dev)
+        self.xin = torch.empty(B, self.net_dim, dtype=f32, device=dev) if self.periodic else self.xb
+        # activations: encoder on all B rows (row-block DP needs the full latent), decoder on own rows only
+        self.h = [torch.empty(B if i < lay.n_enc else nown, l.n_out, dtype=f32, device=dev) for i, l in enumerate(lay.layers)]
+        self.dh = [torch.empty(nown, l.n_out, dtype=f32, device=dev) for l in lay.layers]
+        self.tmp = [torch.empty(nown, l.n_out, dtype=f32, device=dev) if l.activation else None for l in lay.layers]
+        self.dZ = torch.zeros(B, self.L, dtype=f32, device=dev)
+        self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
+        self.red_ws = torch.empty(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+
+    # -- data feed -------------------------------------------------------------------------------
+    def set_data(self, data) -> None:
+        """Make the training set device-resident (float32 [N, D])."""
+        if isinstance(data, np.ndarray):
+            data = torch.from_numpy(np.ascontiguousarray(data, dtype=np.float32))
+        self.data = data.to(self.device, dtype=torch.float32).contiguous()
+        if self.data.shape[1] != self.D:
+            raise Exception(f"train data has {self.data.shape[1]} features, the model expects {self.D}")
+        seed = self.dp.batch_seed(self.p.seed)
+        self._gen = torch.Generator(device=self.device)
+        if seed is None:
+            self._gen.seed()
+        else:
+            self._gen.manual_seed(int(seed))
+        self._left = torch.empty(0, dtype=torch.int64, device=self.device)
+
+    def draw_index_block(self, n_batches: int) -> torch.Tensor:
+        """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes."""
+        need = n_batches * self.B
+        parts, have = [self._left], self._left.numel()
+        N = self.data.shape[0]
+        while have < need:
+            parts.append(torch.randperm(N, generator=self._gen, device=self.device))
+            have += N
+        allidx = torch.cat(parts)
+        self._left = allidx[need:].clone()
+        return allidx[:need].contiguous()
+
+    # -- forward / backward ------------------------------------------------------------------------
+    def _forward(self) -> None:
+        lay = self.layout
+        rb, re = self.rb, self.re
+        x = self.xin
+        for i, l in enumerate(lay.layers):
+            if i == lay.n_enc:
+                x = x[rb:re]            # decoder (and everything after) on the rows this rank owns
+            torch.addmm(self.b[i], x, self.W[i], out=self.h[i])
+            if l.activation:
+                torch.tanh(self.h[i], out=self.h[i])
+            x = self.h[i]
+
+    def _losses(self) -> None:
+        p, rb, re, B = self.p, self.rb, self.re, self.B
+        lay = self.layout
+        Z = self.h[lay.n_enc - 1]
+        Y = self.h[-1]
+        dY = self.dh[-1]
+        # auto cost on own rows (global 1/B normalisation), gradient straight into dY
+        if p.auto_cost_scale is not None:
+            _lib.periodic_cost_fwd_bwd(
+                _RowView(Y, rb), 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
+                float(p.auto_cost_scale), rb, re, self.terms[T_AUTO:T_AUTO + 1], _RowView(dY, rb), self.red_ws, B=B)
+        else:
+            dY.zero_()
+            self.terms[T_AUTO].zero_()
+        cs = p.center_cost_scale
+        if self.with_distance and p.distance_cost_scale is not None:
+            _lib.sketchmap_fwd_bwd(self.xb, Z, self.periodicity, p.dist_sig_parameters, float(p.distance_cost_scale),
+                                   float(cs) if cs is not None else 0.0, rb, re,
+                                   self.terms[T_DIST:T_DIST + 1], self.terms[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
+        else:
+            self.terms[T_DIST].zero_()
+            _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, rb, re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
+
+    def _backward(self) -> None:
+        lay = self.layout
+        rb, re = self.rb, self.re
+        n = len(lay.layers)
+        for i in range(n - 1, -1, -1):
+            l = lay.layers[i]
+            d = self.dh[i]
+            if i == lay.n_enc - 1:
+                d.add_(self.dZ[rb:re])           # latent: decoder path + distance/center gradients
+            h_own = self.h[i] if i >= lay.n_enc else self.h[i][rb:re]
+            if l.activation:                      # tanh': d *= 1 - h^2
+                torch.mul(h_own, h_own, out=self.tmp[i])
+                torch.addcmul(d, d, self.tmp[i], value=-1.0, out=d)
+            if i == 0:
+                inp = self.xin[rb:re]
+            else:
+                inp = self.h[i - 1] if i - 1 >= lay.n_enc else self.h[i - 1][rb:re]
+            torch.mm(inp.t(), d, out=self.gW[i])
+            torch.sum(d, dim=0, out=self.gb[i])
+            if i > 0:
+                torch.mm(d, self.W[i].t(), out=self.dh[i - 1])
+
+    def _step_body(self) -> None:
+        p = self.p
+        _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
+                         self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
+        self._forward()
+        self._losses()
+        self._backward()
+        self.dp.all_reduce_(self.g_ext)
+        _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
+                       self.terms[T_REG:T_REG + 1], self.red_ws)
+        _lib.step_tick(self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor)
+        self.step.add_(1)
+
+    # -- driver --------------------------------------------------------------------------------------
+    def _capture(self) -> None:
+        """Warm up on a side stream, then capture one step into a hipGraph (torch.cuda.CUDAGraph)."""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream())
+        saved = [t.clone() for t in (self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history)]
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                self._step_body()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        for t, sv in zip((self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history), saved):
+            t.copy_(sv)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._step_body()
+        for t, sv in zip((self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history), saved):
+            t.copy_(sv)
+        self._graph = g
+
+    def run_steps(self, n_steps: int, index_block: Optional[torch.Tensor] = None) -> None:
+        """Enqueue ``n_steps`` training steps (asynchronous).  ``index_block`` ([n_steps*B] int64, device) injects
+        the batch composition; by default it is drawn from the shuffle stream."""
+        if self.data is None:
+            raise Exception("no train data: call set_data() first")
+        if n_steps <= 0:
+            return
+        if int(self.hstep_host()) + n_steps > self.history_capacity:
+            self._grow_history(int(self.hstep_host()) + n_steps)
+        block = index_block if index_block is not None else self.draw_index_block(n_steps)
+        if block.numel() != n_steps * self.B:
+            raise ValueError(f"index block has {block.numel()} entries, expected {n_steps} x {self.B}")
+        cap = self._block_capacity()
+        if self.idx_block is None or self.idx_block.numel() < cap * self.B:
+            self.idx_block = torch.zeros(cap * self.B, dtype=torch.int64, device=self.device)
+            self._graph = None
+        done = 0
+        while done < n_steps:
+            k = min(cap, n_steps - done)
+            self.idx_block[: k * self.B].copy_(block[done * self.B: (done + k) * self.B])
+            self.cursor.zero_()
+            if self.use_graph and not self.dp.active:
+                if self._graph is None:
+                    self._capture()
+                for _ in range(k):
+                    self._graph.replay()
+            else:
+                for _ in range(k):
+                    self._step_body()
+            done += k
+        self._hstep_host += n_steps
+
+    def _block_capacity(self) -> int:
+        return 1024
+
+    _hstep_host = 0
+
+    def hstep_host(self) -> int:
+        return self._hstep_host
+
+    def _grow_history(self, need: int) -> None:
+        cap = max(need, 2 * self.history_capacity)
+        h = torch.zeros(cap, dtype=torch.float32, device=self.device)
+        th = torch.zeros(cap, N_TERMS, dtype=torch.float32, device=self.device)
+        h[: self.history_capacity].copy_(self.history)
+        th[: self.history_capacity].copy_(self.term_history)
+        self.history, self.term_history, self.history_capacity = h, th, cap
+        self._graph = None   # captured pointers are stale
+
+    def losses(self) -> np.ndarray:
+        """Total loss per executed step (synchronises)."""
+        torch.cuda.synchronize(self.device)
+        return self.history[: self._hstep_host].cpu().numpy()
+
+    def loss_terms(self) -> dict:
+        torch.cuda.synchronize(self.device)
+        th = self.term_history[: self._hstep_host].cpu().numpy()
+        return {name: th[:, i] for i, name in enumerate(TERM_NAMES)}
+
+    def current_step(self) -> int:
+        return int(self.step.item())
+
+    # -- inference -----------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, x: np.ndarray, already_transformed: bool = False, chunk: int = 262144) -> np.ndarray:
+        lay = self.layout
+        out = np.empty((x.shape[0], self.L), np.float32)
+        for s in range(0, x.shape[0], chunk):
+            xc = torch.from_numpy(np.ascontiguousarray(x[s: s + chunk], dtype=np.float32)).to(self.device)
+            if self.periodic and not already_transformed:
+                xin = torch.empty(xc.shape[0], self.net_dim, dtype=torch.float32, device=self.device)
+                _lib.periodic_in(xc, self.periodicity, xin)
+                xc = xin
+            for i in range(lay.n_enc):
+                xc = torch.addmm(self.b[i], xc, self.W[i])
+                if lay.layers[i].activation:
+                    xc = torch.tanh(xc)
+            out[s: s + chunk] = xc.cpu().numpy()
+        return out
+
+    @torch.no_grad()
+    def decode(self, z: np.ndarray, chunk: int = 262144) -> np.ndarray:
+        lay = self.layout
+        z = np.asarray(z, np.float32)
+        out = np.empty((z.shape[0], self.D), np.float32)
+        for s in range(0, z.shape[0], chunk):
+            y = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
+            for i in range(lay.n_enc, len(lay.layers)):
+                y = torch.addmm(self.b[i], y, self.W[i])
+                if lay.layers[i].activation:
+                    y = torch.tanh(y)
+            if self.periodic:
+                o = torch.empty(y.shape[0], self.D, dtype=torch.float32, device=self.device)
+                _lib.periodic_out(y, self.D, 0, self.D, self.periodicity, o)
+                y = o
+            out[s: s + chunk] = y.cpu().numpy()
+        return out
+
+    # -- state ---------------------------------------------------------------------------------------
+    def get_weights(self) -> list:
+        return unpack_weights(self.layout, self.w.cpu().numpy())
+
+    def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
+        self.w.copy_(torch.from_numpy(pack_weights(self.layout, arrays)).to(self.device))
+
+    def state_dict(self) -> dict:
+        torch.cuda.synchronize(self.device)
+        return {"w": self.w.cpu().numpy(), "m": self.m.cpu().numpy(), "v": self.v.cpu().numpy(),
+                "step": np.int64(self.step.item())}
+
+    def load_state_dict(self, sd: dict) -> None:
+        for name in ("w", "m", "v"):
+            if name in sd:
+                getattr(self, name).copy_(torch.from_numpy(np.asarray(sd[name], np.float32)).to(self.device))
+        if "step" in sd:
+            self.step.fill_(int(sd["step"]))
+
+
+class _RowView:
+    """Pointer arithmetic helper: presents a tensor that holds rows [row0, row0+n) of a conceptual [B, n] block
+    as if it were the whole block (the C ABI indexes rows globally)."""
+
+    def __init__(self, t: torch.Tensor, row0: int):
+        self.t, self.row0 = t, row0
+        self.is_cuda = t.is_cuda
+        self.shape = t.shape
+
+    def stride(self, i):
+        return self.t.stride(i)
+
+    def data_ptr(self):
+        return self.t.data_ptr() - self.row0 * self.t.stride(0) * self.t.element_size()

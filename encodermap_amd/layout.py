@@ -1,0 +1,166 @@
+"""Host-side description of the dense autoencoder and of its flat parameter buffer.
+
+Pure Python/NumPy (no GPU needed): layer stacking rules of the reference's ``SequentialModel``
+(encodermap/models/models.py:3121-3160), Keras-compatible initialisers (models.py:3184-3186;
+``VarianceScaling()`` / ``RandomNormal(0.1, 0.05)``) and the offsets of every
+kernel/bias inside ONE contiguous float32 buffer -- the layout the fused Adam kernel and the single
+gradient all-reduce operate on.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+_TRUNC_STD = 0.87962566103423978  # std of a unit normal truncated to [-2, 2]
+
+
+@dataclass(frozen=True)
+class DenseSpec:
+    name: str          # Encoder_i / Latent / Decoder_i (models.py:3142-3150)
+    n_in: int
+    n_out: int
+    activation: Optional[str]  # "tanh" or None
+    w_off: int         # offset of the [n_in, n_out] kernel in the flat buffer
+    b_off: int         # offset of the [n_out] bias
+
+
+@dataclass(frozen=True)
+class NetLayout:
+    layers: tuple          # all DenseSpec, encoder first
+    n_enc: int             # number of encoder layers (index of the first decoder layer)
+    net_dim: int           # width the network sees (2*D for periodic input)
+    n_params: int          # floats in the flat buffer (multiple of 4 for 16-byte lanes)
+    n_real: int            # floats that are actual parameters
+
+    @property
+    def encoder(self):
+        return self.layers[: self.n_enc]
+
+    @property
+    def decoder(self):
+        return self.layers[self.n_enc:]
+
+    @property
+    def latent_dim(self) -> int:
+        return self.layers[self.n_enc - 1].n_out
+
+
+def build_layout(n_neurons: Sequence[int], activation_functions: Sequence[str], net_dim: int) -> NetLayout:
+    """[128,128,2] + ['', 'tanh', 'tanh', ''] -> Encoder_0(tanh) Encoder_1(tanh) Latent(linear) |
+    Decoder_0(tanh) Decoder_1(tanh) Decoder_2(linear, net_dim)."""
+    if len(n_neurons) != len(activation_functions) - 1:
+        raise Exception(
+            f"Length of `n_neurons` and `activation_functions` (-1) does not match: {n_neurons}, {activation_functions}")
+    acts = [a if a != "" else None for a in activation_functions]
+    for a in acts:
+        if a not in (None, "tanh"):
+            raise NotImplementedError(f"activation function {a!r} is not available in the HIP engine (tanh or '' only)")
+    units = list(n_neurons) + list(n_neurons[-2::-1]) + [net_dim]
+    layer_acts = acts[1:] + acts[-2::-1] + [None]
+    n_lat = len(n_neurons)
+    bottleneck = units.index(min(units)) + 1
+    layers, off, prev = [], 0, net_dim
+    for i, (u, a) in enumerate(zip(units, layer_acts)):
+        if i < n_lat - 1:
+            name = f"Encoder_{i}"
+        elif i > n_lat - 1:
+            name = f"Decoder_{i - n_lat}"
+        else:
+            name = "Latent"
+        w_off = off
+        off += prev * u
+        b_off = off
+        off += u
+        # keep every tensor 16-byte aligned inside the buffer (float4 lanes in the Adam kernel, GEMM alignment)
+        off = (off + 3) // 4 * 4
+        layers.append(DenseSpec(name, prev, u, a, w_off, b_off))
+        prev = u
+    n_real = sum(l.n_in * l.n_out + l.n_out for l in layers)
+    return NetLayout(tuple(layers), bottleneck, net_dim, off, n_real)
+
+
+def init_parameters(layout: NetLayout, seed: Optional[int]) -> np.ndarray:
+    """Flat float32 buffer initialised like the reference: kernels VarianceScaling() = truncated normal with
+    stddev sqrt(1/fan_in)/0.8796 cut at 2 sigma, biases RandomNormal(0.1, 0.05).  Same distributions, own
+    stream (TensorFlow's Philox streams are not reproducible outside TensorFlow)."""
+    rng = np.random.default_rng(seed)
+    flat = np.zeros(layout.n_params, np.float32)
+    for l in layout.layers:
+        std = np.sqrt(1.0 / l.n_in) / _TRUNC_STD
+        n = l.n_in * l.n_out
+        w = rng.standard_normal(n)
+        bad = np.abs(w) > 2.0
+        while bad.any():
+            w[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(w) > 2.0
+        flat[l.w_off: l.w_off + n] = (w * std).astype(np.float32)
+        flat[l.b_off: l.b_off + l.n_out] = rng.normal(0.1, 0.05, l.n_out).astype(np.float32)
+    return flat
+
+
+def l2_coefficients(layout: NetLayout, l2_reg_constant: float) -> np.ndarray:
+    """Per-element 2*lambda on kernels, 0 on biases/padding: d/dw of Keras ``l2(lambda) = lambda*sum(w^2)``
+    (kernel_regularizer only, models.py:3126,3185)."""
+    c = np.zeros(layout.n_params, np.float32)
+    for l in layout.layers:
+        c[l.w_off: l.w_off + l.n_in * l.n_out] = 2.0 * float(l2_reg_constant)
+    return c
+
+
+def pack_weights(layout: NetLayout, arrays: Sequence[np.ndarray]) -> np.ndarray:
+    """[W0, b0, W1, b1, ...] (Keras ``get_weights`` order) -> flat buffer."""
+    if len(arrays) != 2 * len(layout.layers):
+        raise ValueError(f"expected {2 * len(layout.layers)} arrays (kernel, bias per layer), got {len(arrays)}")
+    flat = np.zeros(layout.n_params, np.float32)
+    for l, W, b in zip(layout.layers, arrays[0::2], arrays[1::2]):
+        W = np.asarray(W, np.float32)
+        b = np.asarray(b, np.float32)
+        if W.shape != (l.n_in, l.n_out) or b.shape != (l.n_out,):
+            raise ValueError(f"{l.name}: expected kernel {(l.n_in, l.n_out)} and bias {(l.n_out,)}, got {W.shape} and {b.shape}")
+        flat[l.w_off: l.w_off + W.size] = W.reshape(-1)
+        flat[l.b_off: l.b_off + b.size] = b
+    return flat
+
+
+def unpack_weights(layout: NetLayout, flat: np.ndarray) -> list:
+    out = []
+    for l in layout.layers:
+        out.append(np.array(flat[l.w_off: l.w_off + l.n_in * l.n_out]).reshape(l.n_in, l.n_out))
+        out.append(np.array(flat[l.b_off: l.b_off + l.n_out]))
+    return out
+
+
+def weights_from_initializer_dict(layout: NetLayout, d: dict) -> np.ndarray:
+    """The reference's initializer-dict convention (models.py:113-248): keys ``dense/kernel``, ``dense/bias``,
+    ``dense_1/kernel`` ... in layer order."""
+    arrays = []
+    for i in range(len(layout.layers)):
+        stem = "dense" if i == 0 else f"dense_{i}"
+        arrays += [d[f"{stem}/kernel"], d[f"{stem}/bias"]]
+    return pack_weights(layout, arrays)
+
+
+class BatchIndexStream:
+    """Row indices for ``Dataset.shuffle(N, reshuffle_each_iteration=True).repeat().batch(B)``
+    (encodermap/autoencoder/autoencoder.py:845-856): a fresh uniform permutation per pass, batches always
+    full and allowed to straddle passes.  Host-side statement used for planning/tests; the engine draws the
+    same stream on the device with ``torch.randperm``."""
+
+    def __init__(self, n_rows: int, batch_size: int, seed: Optional[int] = None):
+        self.n, self.b = int(n_rows), int(batch_size)
+        self.rng = np.random.default_rng(seed)
+        self._left = np.empty(0, np.int64)
+
+    def next_block(self, n_batches: int) -> np.ndarray:
+        need = n_batches * self.b
+        parts = [self._left]
+        have = self._left.size
+        while have < need:
+            p = self.rng.permutation(self.n).astype(np.int64)
+            parts.append(p)
+            have += p.size
+        allidx = np.concatenate(parts)
+        self._left = allidx[need:]
+        return allidx[:need].reshape(n_batches, self.b)

@@ -1,0 +1,141 @@
+/*
+ * emx.h -- C ABI of libemx.so: the hand-written HIP (gfx950 / MI355X) kernels behind
+ * encodermap_amd's training hot path.
+ *
+ * The reference (AG-Peter/encodermap, pure Python on TensorFlow) has no FFI boundary of its own: every
+ * function below replaces a group of TensorFlow op call sites, cited as file:line relative to the upstream
+ * repository @ 2025-05-23.  INTEGRATION.md shows the ctypes stub that binds each symbol.
+ *
+ * Contract (all functions):
+ *   - every pointer is a DEVICE pointer owned by the caller (row-major float32 unless stated), except
+ *     `const float sig[6]` / scalars, which are host values copied at launch;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
+ *     synchronises, allocates or frees, so every entry point is legal inside a hipGraph capture;
+ *   - return value 0 = launched, negative = rejected before any launch (bad argument, unsupported shape);
+ *     emx_last_error() returns the thread-local message of the last rejection;
+ *   - re-entrant, no global mutable state; one host thread per GPU/rank is the intended use;
+ *   - results are deterministic run to run: no float atomics, fixed-order two-pass reductions.
+ *
+ * Row-block arguments (`row_begin`, `row_end`) implement the data-parallel partition of SURVEY.md section
+ * 8e: a rank evaluates only the terms owned by rows [row_begin,row_end) of the GLOBAL batch of `B` rows,
+ * with the global 1/B (or 1/B^2) normalisation, so that a SUM all-reduce over ranks yields the
+ * single-process value.
+ */
+#ifndef EMX_H
+#define EMX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EMX_VERSION 1
+/* scratch floats every two-pass scalar reduction needs (per call, may be shared by calls on one stream) */
+#define EMX_REDUCE_WS 1024
+
+typedef void* emx_stream_t; /* hipStream_t */
+
+/* cost variants of loss_functions.py:598-613 */
+enum { EMX_MEAN_ABS = 0, EMX_MEAN_SQUARE = 1, EMX_MEAN_NORM = 2 };
+
+/* error codes */
+enum { EMX_OK = 0, EMX_EINVAL = -1, EMX_EUNSUPPORTED = -2, EMX_ELAUNCH = -3, EMX_EWORKSPACE = -4 };
+
+int emx_version(void);
+const char* emx_last_error(void);
+/* name of the device the library was built for ("gfx950"); used by the host side to fail loudly */
+const char* emx_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * K1/K2  sketch-map sigmoid pairwise-distance cost, forward + gradient wrt the latent
+ *   replaces: pairwise_dist            encodermap/misc/distances.py:179-255
+ *             pairwise_dist_periodic   encodermap/misc/distances.py:144-176
+ *             sigmoid                  encodermap/misc/distances.py:66-88
+ *             sigmoid_loss_func        encodermap/loss_functions/loss_functions.py:351-367
+ *             distance_loss_func       encodermap/loss_functions/loss_functions.py:266-296 (the x scale)
+ *             center_loss_func         encodermap/loss_functions/loss_functions.py:422-449 (optional fused term)
+ *   X [B, D] (row stride ldx floats) high-d rows (data, no gradient); Z [B, L] latent, L in 1..4.
+ *   periodicity: INFINITY -> Euclidean, else the period of X.
+ *   sig = (sig_h, a_h, b_h, sig_l, a_l, b_l).
+ *   *dist_loss   = scale / B^2 * sum_{i in rows} sum_{j<B} (S_h(dh_ij) - S_l(dl_ij))^2
+ *   *center_loss = center_scale / (B*L) * sum_{i in rows} sum_l z_il^2      (skipped if center_loss == NULL)
+ *   dZ[i,:] (rows in the block only) = d(dist + center)/dz_i of the FULL-batch loss; pairs with dl == 0
+ *   contribute zero gradient (the reference's mask, distances.py:247-253).
+ *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes.
+ * ------------------------------------------------------------------------------------------------ */
+size_t emx_sketchmap_ws_bytes(int B, int L);
+int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L,
+                          float periodicity, const float sig[6], float scale,
+                          float center_scale, int row_begin, int row_end,
+                          float* dist_loss, float* center_loss, float* dZ,
+                          void* ws, size_t ws_bytes, emx_stream_t stream);
+
+/* materialising variants, for parity tests of a2/a3 only (out is [B,B]) */
+int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * K13 + K4  data feed: gather a mini-batch by row index and (optionally) build the sin/cos input
+ *   replaces: tf.data from_tensor_slices/shuffle/repeat/batch   encodermap/autoencoder/autoencoder.py:845-856
+ *             SequentialModel.encoder sin/cos concat             encodermap/models/models.py:3347-3351
+ *             PeriodicInput.call                                 encodermap/models/layers.py:204-215
+ *   data [N, D]; idx int64 row numbers, batch number c occupies idx[c*B .. c*B+B); `cursor` (device int64,
+ *   may be NULL = 0) selects the batch so that a captured graph walks a pre-drawn index block without host
+ *   work (emx_step_tick advances it); xb [B, D] gathered rows (may be NULL);
+ *   xin [B, 2D] = [sin(x*2pi/p) | cos(x*2pi/p)] (may be NULL; periodicity ignored then).
+ * ------------------------------------------------------------------------------------------------ */
+int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B,
+                    float periodicity, float* xb, float* xin, emx_stream_t stream);
+/* PeriodicInput on an already dense [B, D] block (encode()) */
+int emx_periodic_in(const float* x, int B, int D, int ldx, float periodicity, float* out, int ldo, emx_stream_t stream);
+/* PeriodicOutput: out[b, k] = atan2(y[b, off_sin+k], y[b, off_cos+k]) * p/2pi  (models.py:3353-3359, layers.py:1118-1125) */
+int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off_cos, float periodicity,
+                     float* out, int ldo, emx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * K5  row-mean cost on (periodic) differences, forward + gradient wrt the network output
+ *   replaces: periodic_distance + mean_abs/mean_square/mean_norm  encodermap/misc/distances.py:113-141,
+ *             auto_loss_func / dihedral_loss_func / angle_loss_func / side_dihedral_loss_func
+ *             encodermap/loss_functions/loss_functions.py:586-626, 671-706, 832-868, 751-788
+ *             and, fused, PeriodicOutput's atan2 with its backward (models.py:3353-3359)
+ *   target [B, n] (stride ldt).  y (stride ldy): if periodic_output != 0 the prediction is
+ *   atan2(y[:,off_sin+k], y[:,off_cos+k]) * p/2pi and dY receives the gradient for both halves; otherwise
+ *   the prediction is y[:, off_sin+k] itself.  periodicity = INFINITY -> plain |pred - target|.
+ *   *loss = coef * variant(delta) over rows [row_begin,row_end) normalised by the GLOBAL B;
+ *   dY (same layout/stride as y) is WRITTEN for the addressed columns of rows in the block.
+ * ------------------------------------------------------------------------------------------------ */
+int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output,
+                              const float* target, int ldt, int B, int n, float periodicity, int variant,
+                              float coef, int row_begin, int row_end, float* loss, float* dY,
+                              float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
+
+/* center cost alone: mean(z^2)*scale over the global batch (loss_functions.py:422-449); dZ written or accumulated */
+int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_begin, int row_end,
+                            float* loss, float* dZ, int accumulate, emx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * K11 + K10  fused clip -> Adam on the flat parameter buffer, L2 regulariser folded in
+ *   replaces: tf.keras.optimizers.Adam(lr, clipvalue=1.0).apply_gradients  encodermap/autoencoder/autoencoder.py:741-743,
+ *             encodermap/models/models.py:3395 ; regularization_loss_func   loss_functions.py:488-506
+ *   g_total = g + l2coef[i]*w[i]  (l2coef = 2*lambda on kernel elements, 0 on biases; may be NULL)
+ *   g_total = clamp(g_total, -clip, clip)  (clip <= 0 disables)
+ *   m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps),  t = *step + 1
+ *   *reg_loss = sum_i 0.5*l2coef[i]*w[i]^2 evaluated on the weights BEFORE the update (may be NULL).
+ *   `step` is a device int64 holding the number of completed updates; it is NOT modified here (emx_step_tick does).
+ * ------------------------------------------------------------------------------------------------ */
+int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n,
+                  float lr, float beta1, float beta2, float eps, float clip,
+                  const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
+
+/* end-of-step bookkeeping on the device (so a captured graph can be replayed without host round trips):
+ * history[*step] = sum(terms[0..n_terms)), term_history[*step, :] = terms (if not NULL), then ++*step
+ * (and ++*cursor, the batch cursor of emx_gather_rows).
+ * replaces the Keras History / _my_train_counter bookkeeping, encodermap/models/models.py:3399-3401 */
+int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity,
+                  int64_t* step, int64_t* cursor /* may be NULL; ++*cursor */, emx_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EMX_H */

@@ -295,8 +295,8 @@ def train_steps(model: SequentialOracle, data: np.ndarray, batch_indices: Sequen
         total, terms = encodermap_loss(model, xb, p, with_distance)
         grads = torch.autograd.grad(total, model.params)
         opt.apply_gradients(model.params, grads)
-        losses.append(float(total))
-        terms_all.append({k: float(v) for k, v in terms.items()})
+        losses.append(float(total.detach()))
+        terms_all.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in terms.items()})
     return losses, terms_all
 
 

@@ -1,0 +1,281 @@
+"""Parity of every HIP kernel (through the C ABI) against the float64 oracle.  Needs an MI355X.
+
+Tolerances (float32 kernels vs float64 oracle): loss 1e-5 relative (north star: 1e-4), gradients
+2e-5 relative to the largest gradient entry, element-wise transforms 2e-6 absolute on O(1) values.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import direct_ops as D
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+INF = float("inf")
+DEFAULT_SIG = (4.5, 12, 6, 1, 2, 6)
+
+
+@pytest.fixture(scope="module")
+def L():
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    _lib.load()
+    return _lib
+
+
+def dev(a, dtype=torch.float32):
+    return torch.tensor(np.asarray(a), dtype=dtype, device="cuda")
+
+
+def make_xz(rng, B, Dd, Ld, periodicity, spread=1.0):
+    if periodicity == INF:
+        x = rng.normal(0, spread, (B, Dd))
+    else:
+        x = rng.uniform(-periodicity / 2, periodicity / 2, (B, Dd))
+    z = rng.normal(0, 1.0, (B, Ld))
+    return x.astype(np.float32), z.astype(np.float32)
+
+
+def run_sketchmap(L, x, z, periodicity, sig, scale, center_scale, rb, re):
+    B, Ld = z.shape
+    X, Z = dev(x), dev(z)
+    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    dist = torch.zeros(1, device="cuda")
+    cen = torch.zeros(1, device="cuda") if center_scale is not None else None
+    dZ = torch.full((B, Ld), float("nan"), device="cuda")
+    L.sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, rb, re, dist, cen, dZ, ws)
+    torch.cuda.synchronize()
+    return float(dist), (float(cen) if cen is not None else None), dZ.cpu().numpy().astype(np.float64)
+
+
+SK_CASES = [
+    # B, D, L, periodicity, sig
+    (2, 1, 2, INF, DEFAULT_SIG),
+    (3, 2, 2, 2 * PI, DEFAULT_SIG),
+    (64, 10, 2, 2 * PI, DEFAULT_SIG),
+    (256, 51, 2, INF, DEFAULT_SIG),
+    (256, 51, 2, 2 * PI, DEFAULT_SIG),
+    (257, 33, 2, INF, (6.0, 12, 6, 1, 2, 6)),
+    (1000, 128, 2, INF, (16.0, 12, 6, 1, 2, 6)),
+    (1024, 128, 2, 2 * PI, (8.0, 12, 6, 1, 2, 6)),
+    (300, 7, 3, INF, (2.0, 3, 6, 1, 2, 6)),       # general-exponent path, odd D, L=3
+    (200, 12, 1, 360.0, (90.0, 10, 5, 1.5, 4, 2)),  # general path, L=1, period 360
+    (130, 4, 4, INF, (1.5, 12, 6, 1, 2, 6)),      # L=4 runtime-L instantiation
+    (500, 20, 2, INF, (3.0, 2, 2, 1, 1.5, 3)),    # a_l < 2: singular S'/d needs the d==0 mask
+]
+
+
+@pytest.mark.parametrize("B,Dd,Ld,periodicity,sig", SK_CASES)
+def test_sketchmap_full_batch(L, B, Dd, Ld, periodicity, sig):
+    rng = np.random.default_rng(B * 7 + Dd)
+    spread = sig[0] / math.sqrt(2 * Dd) if periodicity == INF else 1.0
+    x, z = make_xz(rng, B, Dd, Ld, periodicity, spread)
+    if B > 8:
+        z[5] = z[7]      # coincident latent points
+        x[2] = x[3]      # coincident high-d points
+    loss_o, g_o = D.sketchmap_fwd_bwd(x, z, periodicity, sig, scale=500.0)
+    cen_o = 1e-4 * np.mean(z.astype(np.float64) ** 2)
+    g_o = g_o + 2e-4 * z.astype(np.float64) / z.size
+    loss, cen, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
+    assert loss == pytest.approx(loss_o, rel=1e-5, abs=1e-9)
+    assert cen == pytest.approx(cen_o, rel=1e-5)
+    np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
+
+
+@pytest.mark.parametrize("B,Dd,periodicity,blocks", [
+    (512, 32, INF, [(0, 128), (128, 512)]),
+    (512, 32, 2 * PI, [(0, 100), (100, 333), (333, 512)]),
+    (1030, 16, INF, [(0, 515), (515, 1030)]),
+])
+def test_sketchmap_row_blocks_sum_to_full(L, B, Dd, periodicity, blocks):
+    rng = np.random.default_rng(3)
+    x, z = make_xz(rng, B, Dd, 2, periodicity, 1.0)
+    sig = (2.0 * math.sqrt(Dd) if periodicity == INF else 4.5, 12, 6, 1, 2, 6)
+    loss_full, _, g_full = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
+    loss_sum, cen_sum = 0.0, 0.0
+    g_sum = np.zeros_like(g_full)
+    for rb, re in blocks:
+        lo_o, g_o = D.sketchmap_fwd_bwd(x, z, periodicity, sig, 500.0, rb, re)
+        lo, ce, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, rb, re)
+        assert lo == pytest.approx(lo_o, rel=1e-5)
+        assert np.all(np.isnan(g[:rb])) and np.all(np.isnan(g[re:]))   # rows outside the block untouched
+        g_o = g_o[rb:re] + 2e-4 * z[rb:re].astype(np.float64) / z.size
+        np.testing.assert_allclose(g[rb:re], g_o, rtol=0, atol=2e-5 * np.abs(g_o).max())
+        loss_sum += lo
+        cen_sum += ce
+        g_sum[rb:re] = g[rb:re]
+    assert loss_sum == pytest.approx(loss_full, rel=2e-6)
+    np.testing.assert_allclose(g_sum, g_full, rtol=0, atol=1e-5 * np.abs(g_full).max())
+
+
+def test_sketchmap_deterministic_and_rejects(L):
+    rng = np.random.default_rng(0)
+    x, z = make_xz(rng, 777, 24, 2, INF, 1.0)
+    a = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
+    b = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
+    assert a[0] == b[0] and np.array_equal(a[2], b[2])           # bitwise reproducible
+    X, Z = dev(x), dev(np.zeros((777, 5), np.float32))
+    ws = torch.empty(1 << 20, device="cuda")
+    with pytest.raises(L.EmxError, match="latent dimension"):
+        L.sketchmap_fwd_bwd(X, Z, INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
+                            torch.zeros(777, 5, device="cuda"), ws)
+    with pytest.raises(L.EmxError, match="workspace"):
+        L.sketchmap_fwd_bwd(X, dev(z), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
+                            torch.zeros(777, 2, device="cuda"), torch.empty(16, device="cuda"))
+
+
+def test_sketchmap_full_size_properties(L):
+    """BASELINE config C2 size (B=4096, D=128): size-independent properties instead of an O(B^2 D) oracle run:
+    (i) row-block partials add up to the full-batch value, (ii) translation invariance of X and Z,
+    (iii) the gradient sums to zero over the batch (Newton's third law of the pair terms),
+    (iv) a 512-row sub-batch embedded twice gives the analytically related loss."""
+    rng = np.random.default_rng(1)
+    B, Dd = 4096, 128
+    x, z = make_xz(rng, B, Dd, 2, INF, 1.0)
+    sig = (16.0, 12, 6, 1, 2, 6)
+    loss, _, g = run_sketchmap(L, x, z, INF, sig, 500.0, None, 0, B)
+    parts = [run_sketchmap(L, x, z, INF, sig, 500.0, None, rb, rb + 1024) for rb in range(0, B, 1024)]
+    assert sum(p[0] for p in parts) == pytest.approx(loss, rel=2e-6)
+    g_parts = np.concatenate([p[2][i * 1024:(i + 1) * 1024] for i, p in enumerate(parts)])
+    np.testing.assert_allclose(g_parts, g, rtol=0, atol=1e-5 * np.abs(g).max())
+    loss_t, _, g_t = run_sketchmap(L, x + np.float32(0.5), z + np.float32(2.0), INF, sig, 500.0, None, 0, B)
+    assert loss_t == pytest.approx(loss, rel=1e-4)
+    np.testing.assert_allclose(g_t, g, rtol=0, atol=1e-3 * np.abs(g).max())
+    assert np.abs(g.sum(0)).max() < 1e-4 * np.abs(g).sum(0).max()
+    # oracle on a 512-row subset, exact
+    sub = slice(0, 512)
+    lo_o, g_o = D.sketchmap_fwd_bwd(x[sub], z[sub], INF, sig, 500.0)
+    lo, _, gg = run_sketchmap(L, x[sub], z[sub], INF, sig, 500.0, None, 0, 512)
+    assert lo == pytest.approx(lo_o, rel=1e-5)
+    np.testing.assert_allclose(gg, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max())
+
+
+@pytest.mark.parametrize("periodicity", [INF, 2 * PI, 360.0])
+def test_pairwise_dist_materialised(L, periodicity):
+    rng = np.random.default_rng(5)
+    x = (rng.uniform(-1, 1, (70, 9)) * (PI if periodicity == INF else periodicity / 2)).astype(np.float32)
+    out = torch.empty(70, 70, device="cuda")
+    L.pairwise_dist(dev(x), periodicity, out)
+    ref = D.pairwise_dist_direct(x) if periodicity == INF else D.pairwise_dist_periodic_direct(x, periodicity)
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=2e-6, atol=1e-5)
+    # literal two-point answers of the reference tests (tests/test_pairwise_distances.py:140-160)
+    pts = dev(np.array([[1 / 8, 1 / 2], [7 / 8, 1 / 2]], np.float32))
+    o2 = torch.empty(2, 2, device="cuda")
+    L.pairwise_dist(pts, 1.0, o2)
+    np.testing.assert_allclose(o2.cpu().numpy(), [[0, 0.25], [0.25, 0]], atol=1e-6)
+    L.pairwise_dist(pts, INF, o2)
+    np.testing.assert_allclose(o2.cpu().numpy(), [[0, 0.75], [0.75, 0]], atol=1e-6)
+
+
+@pytest.mark.parametrize("periodicity", [2 * PI, 360.0])
+def test_gather_and_periodic_transforms(L, periodicity):
+    rng = np.random.default_rng(6)
+    N, Dd, B = 1000, 37, 129
+    data = rng.uniform(-periodicity / 2, periodicity / 2, (N, Dd)).astype(np.float32)
+    idx = rng.integers(0, N, B)
+    xb = torch.empty(B, Dd, device="cuda")
+    xin = torch.empty(B, 2 * Dd, device="cuda")
+    L.gather_rows(dev(data), dev(idx, torch.int64), periodicity, xb, xin)
+    assert np.array_equal(xb.cpu().numpy(), data[idx])                       # gather is bit-exact
+    np.testing.assert_allclose(xin.cpu().numpy(), D.periodic_in(data[idx], periodicity), atol=2e-6)
+    xin2 = torch.empty(B, 2 * Dd, device="cuda")
+    L.periodic_in(xb, periodicity, xin2)
+    assert torch.equal(xin, xin2)
+    y = rng.normal(0, 1, (B, 2 * Dd)).astype(np.float32)
+    out = torch.empty(B, Dd, device="cuda")
+    L.periodic_out(dev(y), Dd, 0, Dd, periodicity, out)
+    np.testing.assert_allclose(out.cpu().numpy(), D.periodic_out(y, periodicity), atol=2e-6 * periodicity)
+    # gather only (non-periodic data): xin absent
+    xb2 = torch.empty(B, Dd, device="cuda")
+    L.gather_rows(dev(data), dev(idx, torch.int64), INF, xb2, None)
+    assert torch.equal(xb, xb2)
+
+
+@pytest.mark.parametrize("variant", ["mean_abs", "mean_square", "mean_norm"])
+@pytest.mark.parametrize("periodicity,periodic_output", [(2 * PI, True), (360.0, True), (INF, False), (2 * PI, False)])
+def test_periodic_cost(L, variant, periodicity, periodic_output):
+    rng = np.random.default_rng(8)
+    B, n = 203, 45
+    lim = PI if periodicity == INF else periodicity / 2
+    target = rng.uniform(-lim, lim, (B, n)).astype(np.float32)
+    width = 2 * n + 3 if periodic_output else n + 3
+    y = rng.normal(0, 1, (B, width)).astype(np.float32)
+    if not periodic_output:
+        y[:, 1:1 + n] = rng.uniform(-lim, lim, (B, n))
+    off_sin, off_cos = (1, 1 + n) if periodic_output else (1, 0)
+    coef = 1.7
+    for rb, re in [(0, B), (50, 120)]:
+        Y = dev(y)
+        dY = torch.full_like(Y, 7.0)
+        loss = torch.zeros(1, device="cuda")
+        ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+        L.periodic_cost_fwd_bwd(Y, off_sin, off_cos, periodic_output, dev(target), n, periodicity, variant, coef, rb, re, loss, dY, ws)
+        # oracle: float64 chain rule through atan2
+        y64 = y.astype(np.float64)
+        if periodic_output:
+            s, c = y64[:, off_sin:off_sin + n], y64[:, off_cos:off_cos + n]
+            sc = periodicity / (2 * PI)
+            pred = np.arctan2(s, c) * sc
+        else:
+            pred = y64[:, off_sin:off_sin + n]
+        lo_full, g_full = D.periodic_cost_fwd_bwd(target[rb:re], pred[rb:re], periodicity, variant, coef)
+        frac = (re - rb) / B
+        assert float(loss) == pytest.approx(lo_full * frac, rel=2e-5, abs=1e-8)
+        g_pred = g_full * frac
+        got = dY.cpu().numpy().astype(np.float64)
+        if periodic_output:
+            r2 = s[rb:re] ** 2 + c[rb:re] ** 2
+            np.testing.assert_allclose(got[rb:re, off_sin:off_sin + n], g_pred * c[rb:re] / r2 * sc, rtol=1e-4, atol=1e-8)
+            np.testing.assert_allclose(got[rb:re, off_cos:off_cos + n], -g_pred * s[rb:re] / r2 * sc, rtol=1e-4, atol=1e-8)
+        else:
+            np.testing.assert_allclose(got[rb:re, off_sin:off_sin + n], g_pred, rtol=1e-4, atol=1e-8)
+        # everything outside the addressed window / row block is untouched
+        mask = np.ones_like(got, bool)
+        mask[rb:re, off_sin:off_sin + n] = False
+        if periodic_output:
+            mask[rb:re, off_cos:off_cos + n] = False
+        assert np.all(got[mask] == 7.0)
+
+
+def test_center_cost(L):
+    rng = np.random.default_rng(9)
+    z = rng.normal(0, 2, (300, 2)).astype(np.float32)
+    loss = torch.zeros(1, device="cuda")
+    dZ = torch.ones(300, 2, device="cuda")
+    L.center_cost_fwd_bwd(dev(z), 1e-4, 0, 300, loss, dZ, True)
+    assert float(loss) == pytest.approx(1e-4 * np.mean(z.astype(np.float64) ** 2), rel=1e-5)
+    np.testing.assert_allclose(dZ.cpu().numpy(), 1 + 2e-4 * z / z.size, rtol=1e-6)
+    # latent == 1 -> cost == center_cost_scale (tests/test_losses.py:815-840)
+    L.center_cost_fwd_bwd(torch.ones(64, 2, device="cuda"), 1e-4, 0, 64, loss, torch.zeros(64, 2, device="cuda"), False)
+    assert float(loss) == pytest.approx(1e-4, rel=1e-6)
+
+
+@pytest.mark.parametrize("n", [5, 1024, 66690])
+def test_adam_and_tick(L, n):
+    rng = np.random.default_rng(n)
+    w = rng.normal(0, 0.3, n)
+    l2 = (rng.random(n) < 0.9) * 2e-3
+    W, M, V = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L2 = dev(l2)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    terms = torch.zeros(4, device="cuda")
+    hist = torch.zeros(8, device="cuda")
+    thist = torch.zeros(8, 4, device="cuda")
+    ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+    wn, m, v = w.copy(), np.zeros(n), np.zeros(n)
+    for t in range(1, 6):
+        g = rng.normal(0, 1.0, n) * (3.0 if t == 2 else 0.3)   # step 2 exercises the clip
+        reg_o = np.sum(0.5 * l2 * wn * wn)
+        L.adam_step(W, dev(g), M, V, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, step, terms[1:2], ws)
+        terms[0] = float(t)
+        L.step_tick(terms, 4, hist, thist, step)
+        wn, m, v = D.keras_adam_step(wn, g, m, v, t, l2coef=l2)
+        torch.cuda.synchronize()
+        assert float(terms[1]) == pytest.approx(reg_o, rel=1e-5)
+        np.testing.assert_allclose(W.cpu().numpy(), wn, rtol=0, atol=2e-6)
+        assert int(step) == t
+        assert float(hist[t - 1]) == pytest.approx(t + reg_o, rel=1e-5)
+    assert np.allclose(thist[:5, 0].cpu().numpy(), [1, 2, 3, 4, 5])
