@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""Headline benchmark: EncoderMap training throughput at B=4096, D=128 (BASELINE.json config C2).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one full training step of ``em.EncoderMap`` (gather a mini-batch, encoder/decoder forward, sketch-map
+distance + auto + center + L2 cost, backward, clip + Adam) on synthetic Gaussian blobs that are resident in HBM
+before the timed region starts.  One JSON line is printed by rank 0:
+
+  value        whole-job samples/s = N_gpus * 4096 * K / (max over ranks of the time for K steps)
+  roofline     the dominant kernel (sk_tile_kernel, the O(B^2 D) all-pairs pass): algorithmic FLOPs per launch
+               (3 per pair-element: SURVEY.md section 8d) / its average duration, measured here with HIP events
+               around K back-to-back launches on live data, against the 157.3 TFLOP/s fp32 peak (vector == matrix
+               on gfx950).  ``traffic`` = HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/.
+  cpu_baseline the reference-formulation CPU path (oracle/reference_ops.py in float32: Gram-matrix distances with
+               B x B temporaries, autograd, per-element clipped Adam) timed on this host for a few steps of the same
+               workload.  N=1 only.  kind "port": TensorFlow itself cannot be installed here.
+
+N > 1: weak scaling -- every rank trains on its own mini-batch of 4096 rows (global batch 4096*N) and the flat
+gradient buffer is averaged by one RCCL all-reduce per step (engine.DataParallel mode "replica").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+B, D, N_ROWS = 4096, 128, 1_000_000
+SIG = (16.0, 12, 6, 1, 2, 6)
+FP32_PEAK = 157.3e12   # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md chip table)
+
+
+def make_blobs(device, n_rows, d, seed):
+    """C2 data: 16 blob centres N(0,4), points = centre + N(0,1)   (SURVEY.md section 8d)."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    centres = torch.randn(16, d, generator=g, device=device) * 4.0
+    k = torch.randint(0, 16, (n_rows,), generator=g, device=device)
+    return centres[k] + torch.randn(n_rows, d, generator=g, device=device)
+
+
+def cpu_baseline(n_steps=12):
+    import numpy as np
+    import torch
+
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+    from encodermap_amd.parameters import Parameters
+    from oracle import reference_ops as R
+
+    rng = np.random.default_rng(1)
+    n_rows = 20000   # the sample: rows actually touched by the timed steps are drawn from this subset
+    centres = rng.normal(0, 4, (16, D))
+    data = (centres[rng.integers(0, 16, n_rows)] + rng.normal(0, 1, (n_rows, D))).astype(np.float32)
+    p = Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG)
+    lay = build_layout(p.n_neurons, p.activation_functions, D)
+    w0 = unpack_weights(lay, init_parameters(lay, 0))
+    model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0, dtype=torch.float32)
+    idx = rng.integers(0, n_rows, (n_steps + 1, B))
+    R.train_steps(model, data, idx[:1], p.to_dict())           # warm-up step
+    t0 = time.perf_counter()
+    R.train_steps(model, data, idx[1:], p.to_dict())
+    dt = time.perf_counter() - t0
+    return {"value": B * n_steps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_steps} training steps at B={B}, D={D} (float32 torch-CPU restatement of the reference formulation, "
+                      f"{dt / n_steps * 1e3:.0f} ms/step)"}
+
+
+def kernel_roofline(eng, launches):
+    """Average duration of the tile kernel alone on the engine's live batch (HIP events on the launch stream)."""
+    import torch
+
+    from encodermap_amd import _lib
+
+    Z = eng.h[eng.layout.n_enc - 1]
+    for _ in range(5):
+        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(launches):
+        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) * 1e-3 / launches
+    W = D * B * (B - 1) / 2           # pair-elements per launch
+    flops = 3.0 * W                   # sub + fma per pair-element (Euclidean), SURVEY.md section 8d
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.isfile(tf):
+        try:
+            traffic = json.load(open(tf)).get("sk_tile_kernel_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
+            "frac": flops / t / FP32_PEAK, "traffic": traffic, "kernel": "sk_tile_kernel", "kernel_us": t * 1e6,
+            "algorithmic_bytes": 4 * B * (D + 2 * 2) + 4,
+            "note": "fp32 VALU kernel; on gfx950 the fp32 vector peak equals the fp32 MFMA peak (157.3 TFLOP/s), "
+                    "algorithmic HBM bytes per launch are ~2 MB so the HBM roof does not bind"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dp-mode", default="replica", choices=["replica", "rowblock"])
+    args = ap.parse_args()
+
+    import torch
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(device)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+
+    import encodermap_amd as em
+    from encodermap_amd.engine import DataParallel
+
+    p = em.Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
+    dp = DataParallel(rank, world, args.dp_mode) if world > 1 else None
+    data = make_blobs(device, N_ROWS, D, seed=1)
+    e = em.EncoderMap(p, __import__("numpy").zeros((B, D), "float32"), read_only=True, device=device, dp=dp)
+    eng = e._engine
+    eng.set_data(data)                      # 512 MB, resident in HBM before the timed region
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    eng.run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    eng.run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    losses = eng.losses()
+    assert all(l == l and abs(l) != float("inf") for l in losses), "non-finite loss in the benchmark run"
+
+    if rank == 0:
+        global_batch = B * world if args.dp_mode == "replica" else B
+        out = {
+            "metric": "train_samples_per_sec", "value": global_batch * args.steps / dt, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "steps_per_sec": args.steps / dt, "higher_is_better": True,
+            "scaling": "weak" if args.dp_mode == "replica" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, batch 4096 per GPU, "
+                                   "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
+                       "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
+                       "hip_graph": True},
+            "loss_first_last": [float(losses[0]), float(losses[-1])],
+        }
+        out["roofline"] = kernel_roofline(eng, max(args.steps, 50))
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -37,6 +37,8 @@ SIGNATURES = {
     "emx_target_arch": (C.c_char_p, []),
     "emx_sketchmap_ws_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p]),
+    "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
     "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
     "emx_periodic_in": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
@@ -117,6 +119,21 @@ def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, ro
         float(center_scale if center_loss is not None else 0.0), int(row_begin), int(row_end),
         _ptr(dist_loss), _ptr(center_loss), _ptr(dZ), _ptr(ws), ws.numel() * ws.element_size(), _stream())
     _check(rc, "emx_sketchmap_fwd_bwd")
+
+
+def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws):
+    B, D = X.shape
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, int(row_begin),
+                                      int(row_end), _ptr(ws), ws.numel() * ws.element_size(), _stream()), "emx_sketchmap_tiles")
+
+
+def sketchmap_finish(B, D, Z, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws):
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    _check(load().emx_sketchmap_finish(B, D, _ptr(Z), Z.shape[1], sig_arr, float(scale),
+                                       float(center_scale if center_loss is not None else 0.0), int(row_begin), int(row_end),
+                                       _ptr(dist_loss), _ptr(center_loss), _ptr(dZ), _ptr(ws), ws.numel() * ws.element_size(),
+                                       _stream()), "emx_sketchmap_finish")
 
 
 def pairwise_dist(X, periodicity, out):

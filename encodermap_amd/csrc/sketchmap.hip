@@ -435,29 +435,36 @@ size_t emx_sketchmap_ws_bytes(int B, int L) {
   return (nb * nb * 64 * (size_t)L + nb * nb + 64) * sizeof(float);
 }
 
-int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
-                          const float sig[6], float scale, float center_scale, int row_begin, int row_end,
-                          float* dist_loss, float* center_loss, float* dZ, void* ws, size_t ws_bytes,
-                          emx_stream_t stream) {
-  EMX_REQUIRE(X && Z && dist_loss && dZ && ws && sig, "emx_sketchmap_fwd_bwd: null pointer argument");
-  EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "emx_sketchmap_fwd_bwd: bad shape B=%d D=%d ldx=%d", B, D, ldx);
-  if (L < 1 || L > 4)
-    return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_fwd_bwd: latent dimension %d not supported (1..4)", L);
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_sketchmap_fwd_bwd: bad row block [%d,%d) of %d",
-              row_begin, row_end, B);
-  EMX_REQUIRE(periodicity > 0.f, "emx_sketchmap_fwd_bwd: periodicity must be > 0 (INFINITY for none)");
-  for (int i = 0; i < 6; ++i) EMX_REQUIRE(sig[i] > 0.f, "emx_sketchmap_fwd_bwd: sigmoid parameters must be > 0");
+}  // extern "C" (ws_bytes)
+
+namespace {
+
+struct SkPlan {
+  SkArgs a;
+  FinArgs f;
+  int ntiles, T, nblk_finish;
+  bool periodic, fast;
+};
+
+int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6],
+              float scale, float center_scale, int row_begin, int row_end, float* dist_loss, float* center_loss,
+              float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who) {
+  EMX_REQUIRE(X && Z && ws && sig, "%s: null pointer argument", who);
+  EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "%s: bad shape B=%d D=%d ldx=%d", who, B, D, ldx);
+  if (L < 1 || L > 4) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..4)", who, L);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "%s: bad row block [%d,%d) of %d", who, row_begin,
+              row_end, B);
+  EMX_REQUIRE(periodicity > 0.f, "%s: periodicity must be > 0 (INFINITY for none)", who);
+  for (int i = 0; i < 6; ++i) EMX_REQUIRE(sig[i] > 0.f, "%s: sigmoid parameters must be > 0", who);
   if (ws_bytes < emx_sketchmap_ws_bytes(B, L))
-    return emx::fail(EMX_EWORKSPACE, "emx_sketchmap_fwd_bwd: workspace %zu < %zu bytes", ws_bytes,
-                     emx_sketchmap_ws_bytes(B, L));
-  hipStream_t st = (hipStream_t)stream;
+    return emx::fail(EMX_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, emx_sketchmap_ws_bytes(B, L));
   const bool symm = (row_begin == 0 && row_end == B);
   const int nrows = row_end - row_begin;
   const int T = pick_tile(B, nrows);
-  const bool periodic = std::isfinite(periodicity);
-  const bool fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
-
-  SkArgs a;
+  pl.T = T;
+  pl.periodic = std::isfinite(periodicity);
+  pl.fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
+  SkArgs& a = pl.a;
   a.X = X;
   a.Z = Z;
   a.B = B;
@@ -474,23 +481,12 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
   a.period = periodicity;
   a.sh = make_sig(sig[0], sig[1], sig[2]);
   a.sl = make_sig(sig[3], sig[4], sig[5]);
-  const int ntiles = symm ? a.nbc * (a.nbc + 1) / 2 : a.nbr * a.nbc;
+  pl.ntiles = symm ? a.nbc * (a.nbc + 1) / 2 : a.nbr * a.nbc;
   const int nslots = a.nbc;
   float* wsf = static_cast<float*>(ws);
   a.P = wsf;
   a.tile_loss = wsf + (size_t)nslots * a.nrows_pad * L;
-
-  if (T == 128) {
-    if (L == 2) dispatch2<128, 2>(a, ntiles, periodic, fast, st);
-    else dispatch2<128, 0>(a, ntiles, periodic, fast, st);
-  } else {
-    if (L == 2) dispatch2<64, 2>(a, ntiles, periodic, fast, st);
-    else dispatch2<64, 0>(a, ntiles, periodic, fast, st);
-  }
-  int rc = emx::check_launch("sk_tile_kernel");
-  if (rc) return rc;
-
-  FinArgs f;
+  FinArgs& f = pl.f;
   f.P = a.P;
   f.tile_loss = a.tile_loss;
   f.Z = Z;
@@ -503,7 +499,7 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
   f.row_end = row_end;
   f.nrows_pad = a.nrows_pad;
   f.nslots = nslots;
-  f.ntiles = ntiles;
+  f.ntiles = pl.ntiles;
   f.symm = symm;
   f.tile = T;
   const double B2 = (double)B * (double)B;
@@ -512,9 +508,63 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
   f.lscale = (float)(scale / B2);
   f.cgrad = (float)(2.0 * center_scale / ((double)B * L));
   f.cscale = (float)(center_scale / ((double)B * L));
-  const int nblk = (nrows * L + NT - 1) / NT + 1;
-  hipLaunchKernelGGL(sk_finish_kernel, dim3(nblk), dim3(NT), 0, st, f);
+  pl.nblk_finish = (nrows * L + NT - 1) / NT + 1;
+  return EMX_OK;
+}
+
+int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
+  const SkArgs& a = pl.a;
+  if (pl.T == 128) {
+    if (a.L == 2) dispatch2<128, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    else dispatch2<128, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
+  } else {
+    if (a.L == 2) dispatch2<64, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    else dispatch2<64, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
+  }
+  return emx::check_launch("sk_tile_kernel");
+}
+
+int launch_finish_plan(const SkPlan& pl, hipStream_t st) {
+  hipLaunchKernelGGL(sk_finish_kernel, dim3(pl.nblk_finish), dim3(NT), 0, st, pl.f);
   return emx::check_launch("sk_finish_kernel");
+}
+
+}  // namespace
+
+extern "C" {
+
+int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+                          const float sig[6], float scale, float center_scale, int row_begin, int row_end,
+                          float* dist_loss, float* center_loss, float* dZ, void* ws, size_t ws_bytes,
+                          emx_stream_t stream) {
+  EMX_REQUIRE(dist_loss && dZ, "emx_sketchmap_fwd_bwd: null pointer argument");
+  SkPlan pl;
+  int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ,
+                     ws, ws_bytes, pl, "emx_sketchmap_fwd_bwd");
+  if (rc) return rc;
+  rc = launch_tiles_plan(pl, (hipStream_t)stream);
+  if (rc) return rc;
+  return launch_finish_plan(pl, (hipStream_t)stream);
+}
+
+int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, emx_stream_t stream) {
+  SkPlan pl;
+  int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, row_begin, row_end, nullptr, nullptr, nullptr, ws, ws_bytes,
+                     pl, "emx_sketchmap_tiles");
+  if (rc) return rc;
+  return launch_tiles_plan(pl, (hipStream_t)stream);
+}
+
+int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6], float scale, float center_scale,
+                         int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ, void* ws,
+                         size_t ws_bytes, emx_stream_t stream) {
+  EMX_REQUIRE(dist_loss && dZ, "emx_sketchmap_finish: null pointer argument");
+  SkPlan pl;
+  int rc = make_plan(Z /* X unused by the finish pass */, B, D, D, Z, L, INFINITY, sig, scale, center_scale, row_begin, row_end,
+                     dist_loss, center_loss, dZ, ws, ws_bytes, pl, "emx_sketchmap_finish");
+  if (rc) return rc;
+  return launch_finish_plan(pl, (hipStream_t)stream);
 }
 
 int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream) {

@@ -70,9 +70,12 @@ class DataParallel:
             return
         import torch.distributed as dist
 
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        if self.mode == "replica":
-            flat.mul_(1.0 / self.world_size)
+        if self.mode == "replica" and flat.is_cuda:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.mode == "replica":
+                flat.mul_(1.0 / self.world_size)
 
     def batch_seed(self, seed: Optional[int]) -> Optional[int]:
         """rowblock: all ranks must draw identical batches; replica: distinct streams per rank."""
@@ -235,38 +238,68 @@ class SequentialEngine:
             if i > 0:
                 torch.mm(d, self.W[i].t(), out=self.dh[i - 1])
 
-    def _step_body(self) -> None:
-        p = self.p
+    def _step_pre(self) -> None:
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
                          self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
         self._forward()
         self._losses()
         self._backward()
-        self.dp.all_reduce_(self.g_ext)
+
+    def _step_post(self) -> None:
+        p = self.p
         _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
                        self.terms[T_REG:T_REG + 1], self.red_ws)
         _lib.step_tick(self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor)
         self.step.add_(1)
 
+    def _step_body(self) -> None:
+        self._step_pre()
+        self.dp.all_reduce_(self.g_ext)
+        self._step_post()
+
     # -- driver --------------------------------------------------------------------------------------
+    def _state_tensors(self):
+        return (self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history)
+
     def _capture(self) -> None:
-        """Warm up on a side stream, then capture one step into a hipGraph (torch.cuda.CUDAGraph)."""
+        """Warm up on a side stream, then capture the step into hipGraphs (torch.cuda.CUDAGraph).  Single GPU: one
+        graph for the whole step.  Data parallel: one graph up to the gradients, the RCCL all-reduce issued eagerly
+        on the same stream, one graph for Adam + bookkeeping."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
-        saved = [t.clone() for t in (self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history)]
+        saved = [t.clone() for t in self._state_tensors()]
         with torch.cuda.stream(s):
             for _ in range(2):
                 self._step_body()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        for t, sv in zip((self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history), saved):
-            t.copy_(sv)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_body()
-        for t, sv in zip((self.w, self.m, self.v, self.step, self.hstep, self.cursor, self.history, self.term_history), saved):
-            t.copy_(sv)
-        self._graph = g
+
+        def restore():
+            for t, sv in zip(self._state_tensors(), saved):
+                t.copy_(sv)
+
+        restore()
+        if self.dp.active:
+            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g1):
+                self._step_pre()
+            with torch.cuda.graph(g2, pool=g1.pool()):
+                self._step_post()
+            self._graph = (g1, g2)
+        else:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body()
+            self._graph = (g,)
+        restore()
+
+    def _replay(self) -> None:
+        if len(self._graph) == 1:
+            self._graph[0].replay()
+        else:
+            self._graph[0].replay()
+            self.dp.all_reduce_(self.g_ext)
+            self._graph[1].replay()
 
     def run_steps(self, n_steps: int, index_block: Optional[torch.Tensor] = None) -> None:
         """Enqueue ``n_steps`` training steps (asynchronous).  ``index_block`` ([n_steps*B] int64, device) injects
@@ -289,11 +322,11 @@ class SequentialEngine:
             k = min(cap, n_steps - done)
             self.idx_block[: k * self.B].copy_(block[done * self.B: (done + k) * self.B])
             self.cursor.zero_()
-            if self.use_graph and not self.dp.active:
+            if self.use_graph:
                 if self._graph is None:
                     self._capture()
                 for _ in range(k):
-                    self._graph.replay()
+                    self._replay()
             else:
                 for _ in range(k):
                     self._step_body()

@@ -72,6 +72,15 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
                           float* dist_loss, float* center_loss, float* dZ,
                           void* ws, size_t ws_bytes, emx_stream_t stream);
 
+/* The two launches of emx_sketchmap_fwd_bwd as separate entry points (per-kernel timing in bench.py, and for
+ * callers that want other work between the O(B^2 D) tile pass and the O(B) reduction).  Same arguments; the
+ * tile pass leaves per-tile partial sums in `ws`, the finish pass reduces them (scale, center cost, dZ). */
+int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, emx_stream_t stream);
+int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6], float scale, float center_scale,
+                         int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ,
+                         void* ws, size_t ws_bytes, emx_stream_t stream);
+
 /* materialising variants, for parity tests of a2/a3 only (out is [B,B]) */
 int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream);
 

@@ -1,0 +1,247 @@
+"""CPU tests of the host side: configuration objects, network layout, data generators, batch index stream,
+checkpoint naming/resume rules, callback cadence, data-parallel partition, and the C-ABI library's exports."""
+import ctypes
+import json
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+import encodermap_amd as em
+from encodermap_amd import checkpoint as ckpt
+from encodermap_amd.callbacks import CheckpointSaver, EncoderMapBaseCallback, ProgressBar
+from encodermap_amd.layout import (BatchIndexStream, build_layout, init_parameters, l2_coefficients, pack_weights,
+                                   unpack_weights, weights_from_initializer_dict)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INF = float("inf")
+
+
+# ---- Parameters / ADCParameters (reference: encodermap/parameters/parameters.py) --------------------------
+def test_parameter_defaults_match_reference_table():
+    p = em.Parameters()
+    # SURVEY.md appendix A (parameters.py:611-639)
+    expect = dict(n_neurons=[128, 128, 2], activation_functions=["", "tanh", "tanh", ""], periodicity=2 * math.pi,
+                  learning_rate=0.001, n_steps=1000, batch_size=256, summary_step=10, checkpoint_step=5000,
+                  dist_sig_parameters=(4.5, 12, 6, 1, 2, 6), distance_cost_scale=500, auto_cost_scale=1,
+                  auto_cost_variant="mean_abs", center_cost_scale=0.0001, l2_reg_constant=0.001, gpu_memory_fraction=0,
+                  analysis_path="", id="", model_api="sequential", loss="emap_cost", training="auto", batched=True,
+                  tensorboard=False, seed=None, current_training_step=0, write_summary=False,
+                  trainable_dense_to_sparse=False, using_hypercube=False)
+    assert p.defaults == expect
+    for k, v in expect.items():
+        assert p[k] == v and getattr(p, k) == v
+    assert p.main_path == os.getcwd()
+    a = em.ADCParameters()
+    assert a.model_api == "functional" and a.auto_cost_scale is None and a.distance_cost_scale is None
+    assert a.dihedral_cost_scale == 1 and a.angle_cost_scale == 0 and a.side_dihedral_cost_scale == 0.5
+    assert a.cartesian_cost_scale_soft_start == (None, None) and a.cartesian_dist_sig_parameters == (4.5, 12, 6, 1, 2, 6)
+    assert set(p.defaults) < set(a.defaults)
+
+
+def test_parameter_behaviour(tmp_path, capsys):
+    p = em.Parameters(batch_size=64, bogus=3, main_path=str(tmp_path))
+    assert "Dropping unknown dict entry" in capsys.readouterr().out and not hasattr(p, "bogus")
+    with pytest.raises(Exception, match="n_epochs"):
+        em.Parameters(n_epochs=5)
+    with pytest.raises(Exception, match="does not match"):
+        em.Parameters(n_neurons=[10, 2], activation_functions=["", "tanh", "tanh", ""])
+    with pytest.raises(Exception, match="tuple of len 2"):
+        em.ADCParameters(cartesian_cost_scale_soft_start=(1, 2, 3))
+    p["center_cost_scale"] = 2.5
+    assert p.center_cost_scale == 2.5
+    p.update(learning_rate=0.1, nonsense=1)
+    assert p.learning_rate == 0.1
+    path = p.save()
+    assert path == str(tmp_path / "parameters.json")
+    d = json.load(open(path))
+    assert d["batch_size"] == 64 and d["main_path"] == str(tmp_path) and list(d) == sorted(d)   # sort_keys
+    p.save()                                                     # second save backs the first one up
+    assert len(list(tmp_path.glob("parameters_back_*.json"))) == 1
+    q = em.Parameters.from_file(path)
+    assert q.batch_size == 64 and q.center_cost_scale == 2.5 and q.dist_sig_parameters == [4.5, 12, 6, 1, 2, 6]
+    moved = tmp_path / "sub"
+    moved.mkdir()
+    os.rename(path, moved / "parameters.json")
+    r = em.Parameters.from_file(moved / "parameters.json")
+    assert r.main_path == str(moved)
+    y = p.save(tmp_path / "p.yaml")
+    assert em.Parameters.load(y).batch_size == 64
+    with pytest.raises(OSError):
+        p.save(tmp_path / "p.txt")
+    legacy = dict(p.to_dict(), n_epochs=3, n_steps_per_epoch=100)
+    del legacy["n_steps"]
+    json.dump(legacy, open(tmp_path / "legacy.json", "w"))
+    lp = em.Parameters.from_file(tmp_path / "legacy.json")
+    assert lp.n_steps == 300 and lp.summary_step == 1000
+    assert "Non-standard value of batch_size" in str(p) and "Parameter" in em.Parameters.defaults_description()
+
+
+# ---- layout (reference: models/models.py:3121-3220) -------------------------------------------------------
+def test_layout_default_and_custom():
+    lay = build_layout([128, 128, 2], ["", "tanh", "tanh", ""], 20)
+    assert [l.name for l in lay.layers] == ["Encoder_0", "Encoder_1", "Latent", "Decoder_0", "Decoder_1", "Decoder_2"]
+    assert [(l.n_in, l.n_out) for l in lay.layers] == [(20, 128), (128, 128), (128, 2), (2, 128), (128, 128), (128, 20)]
+    assert [l.activation for l in lay.layers] == ["tanh", "tanh", None, "tanh", "tanh", None]
+    assert lay.n_enc == 3 and lay.latent_dim == 2 and lay.n_real == 38934            # P = 38 934
+    assert build_layout([128, 128, 2], ["", "tanh", "tanh", ""], 128).n_real == 66690
+    assert all(l.w_off % 4 == 0 for l in lay.layers) and lay.n_params % 4 == 0
+    small = build_layout([64, 3], ["", "tanh", ""], 7)
+    assert [(l.n_in, l.n_out, l.activation) for l in small.layers] == [(7, 64, "tanh"), (64, 3, None), (3, 64, "tanh"), (64, 7, None)]
+    with pytest.raises(NotImplementedError):
+        build_layout([8, 2], ["", "relu", ""], 4)
+
+
+def test_initialisers_and_packing():
+    lay = build_layout([128, 128, 2], ["", "tanh", "tanh", ""], 64)
+    flat = init_parameters(lay, 5)
+    assert np.array_equal(flat, init_parameters(lay, 5)) and not np.array_equal(flat, init_parameters(lay, 6))
+    arrays = unpack_weights(lay, flat)
+    W1, b1 = arrays[2], arrays[3]
+    std = math.sqrt(1 / 128) / 0.87962566103423978
+    assert np.abs(W1).max() <= 2 * std + 1e-7                       # truncated at 2 sigma
+    assert abs(W1.std() - math.sqrt(1 / 128)) < 0.003               # VarianceScaling: var = 1/fan_in after truncation
+    assert abs(b1.mean() - 0.1) < 0.02 and abs(b1.std() - 0.05) < 0.02
+    assert np.array_equal(pack_weights(lay, arrays), flat)
+    c = l2_coefficients(lay, 0.001)
+    assert c.sum() == pytest.approx(0.002 * sum(l.n_in * l.n_out for l in lay.layers), rel=1e-6)
+    d = {}
+    for i in range(6):
+        stem = "dense" if i == 0 else f"dense_{i}"
+        d[f"{stem}/kernel"], d[f"{stem}/bias"] = arrays[2 * i], arrays[2 * i + 1]
+    assert np.array_equal(weights_from_initializer_dict(lay, d), flat)
+    with pytest.raises(ValueError):
+        pack_weights(lay, arrays[:-1])
+
+
+def test_batch_index_stream_semantics():
+    s = BatchIndexStream(10, 4, seed=0)
+    blk = s.next_block(5)                       # 20 indices = exactly two passes
+    assert blk.shape == (5, 4)
+    flat = blk.reshape(-1)
+    assert sorted(flat[:10]) == list(range(10)) and sorted(flat[10:]) == list(range(10))   # one permutation per pass
+    assert set(blk[2]) & set(flat[:10]) and set(blk[2]) & set(flat[10:])                  # batch 2 straddles the passes
+    nxt = s.next_block(1)
+    assert nxt.shape == (1, 4)
+
+
+# ---- misc data generators -----------------------------------------------------------------------------------
+def test_create_n_cube_matches_networkx_edge_order():
+    nx = pytest.importorskip("networkx")
+    from encodermap_amd.misc import _hypercube_edges
+
+    for n in (1, 2, 3, 4, 5):
+        ref = np.array([e for e in nx.hypercube_graph(n).edges]).reshape(-1, 2, n)
+        assert np.array_equal(_hypercube_edges(n), ref)
+    coords, colors = em.create_n_cube(2, sigma=0)
+    assert np.array_equal(coords[0], [0.0, 0.0])                    # misc/misc.py doctest
+    c4, _ = em.create_n_cube(4, seed=3)
+    assert c4.shape == (16000, 4)                                    # autoencoder.py:654-655
+    assert np.array_equal(c4, em.create_n_cube(4, seed=3)[0])
+    pts, ids = em.random_on_cube_edges(5000, sigma=0.0, rng=np.random.default_rng(0))
+    on_edge = ((np.abs(pts) < 1e-12) | (np.abs(pts - 1) < 1e-12)).sum(1) >= 2
+    assert on_edge.all() and set(ids) == set(range(12))
+
+
+# ---- checkpoints ---------------------------------------------------------------------------------------------
+def test_checkpoint_roundtrip_and_rules(tmp_path):
+    lay = build_layout([16, 2], ["", "tanh", ""], 6)
+    arrays = unpack_weights(lay, init_parameters(lay, 1))
+    state = {"m": np.ones(lay.n_params, np.float32), "v": np.full(lay.n_params, 2, np.float32), "step": 20}
+    for s in (10, 20, 5):
+        ckpt.save_checkpoint(ckpt.checkpoint_name(tmp_path, s), arrays, dict(state, step=s), "EncoderMap")
+    assert [ckpt.step_of(f) for f in ckpt.find_checkpoints(tmp_path)] == [5, 10, 20]
+    assert ckpt.resolve(tmp_path).name == "saved_model_20.emx.npz"
+    payload = ckpt.load_checkpoint(ckpt.resolve(tmp_path))
+    assert np.array_equal(payload["dense/kernel"], arrays[0]) and np.array_equal(payload["dense_3/bias"], arrays[7])
+    assert int(payload["adam/iterations"]) == 20 and str(payload["class_name"]) == "EncoderMap"
+    with pytest.raises(Exception, match="has no saved_model"):
+        ckpt.resolve(tmp_path / "..".replace("..", "empty")) if (tmp_path / "empty").mkdir() is None else None
+    p = em.Parameters(main_path=str(tmp_path), current_training_step=20, n_steps=20)
+    p.save()
+    assert ckpt.reconcile_step(tmp_path / "saved_model_20.emx.npz", p, False) is p
+    with pytest.raises(Exception, match="intermediate"):
+        ckpt.reconcile_step(tmp_path / "saved_model_10.emx.npz", p, False)
+    p2 = ckpt.reconcile_step(tmp_path / "saved_model_10.emx.npz", p, True)
+    assert p2.current_training_step == 11 and p2.n_steps == 11
+    assert list(tmp_path.glob("parameters_at_20_*")) and list(tmp_path.glob("saved_model_20_backup_from_10_*"))
+    stamped = ckpt.checkpoint_name(tmp_path, None)
+    assert re.fullmatch(r"saved_model_\d{4}-\d\d-\d\dT.*\.emx\.npz", stamped.name)
+
+
+# ---- callbacks ---------------------------------------------------------------------------------------------------
+def test_callback_cadence():
+    p = em.Parameters(summary_step=10, checkpoint_step=25)
+    log = []
+
+    class CB(EncoderMapBaseCallback):
+        def on_summary_step(self, step, logs=None):
+            log.append(("s", step))
+
+        def on_checkpoint_step(self, step, logs=None):
+            log.append(("c", step))
+
+    cb = CB(p)
+    for b in range(50):
+        cb.on_train_batch_end(b)
+    assert log == [("s", 10), ("s", 20), ("c", 25), ("s", 30), ("s", 40), ("c", 50), ("s", 50)]   # checkpoint before summary
+    assert cb.due_steps(0, 50) == [10, 20, 25, 30, 40, 50] and cb.due_steps(25, 30) == [30]
+    assert CheckpointSaver(p).due_steps(0, 60) == [25, 50]
+    assert ProgressBar(p).due_steps(0, 100) == [] and ProgressBar(p, enabled=True).due_steps(0, 20) == [10, 20]
+
+
+# ---- data-parallel partition -----------------------------------------------------------------
+def test_row_block_partition():
+    from encodermap_amd.engine import DataParallel
+
+    for B, G in [(4096, 8), (4096, 3), (10, 4), (7, 7)]:
+        blocks = [DataParallel(r, G, "rowblock").row_block(B) for r in range(G)]
+        assert blocks[0][0] == 0 and blocks[-1][1] == B
+        assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
+        sizes = [e - b for b, e in blocks]
+        assert max(sizes) - min(sizes) <= 1
+    assert DataParallel(2, 8, "replica").row_block(4096) == (0, 4096)
+    assert DataParallel().row_block(256) == (0, 256) and not DataParallel().active
+    assert DataParallel(0, 2, "rowblock").batch_seed(5) == DataParallel(1, 2, "rowblock").batch_seed(5)
+    assert DataParallel(0, 2, "replica").batch_seed(5) != DataParallel(1, 2, "replica").batch_seed(5)
+    with pytest.raises(ValueError):
+        DataParallel(0, 2, "pipeline")
+
+
+# ---- the product path fails loudly without a GPU / library -----------------------------------------------------------
+def test_no_silent_cpu_fallback():
+    import torch
+
+    from encodermap_amd import _lib
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.EmxError, match="no CPU fallback"):
+        em.EncoderMap(em.Parameters(), np.zeros((300, 3), np.float32), read_only=True)
+    # nothing in the product package imports the oracle
+    pkg = os.path.join(ROOT, "encodermap_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            assert not re.search(r"^\s*(from|import)\s+oracle", open(os.path.join(pkg, fn)).read(), re.M), fn
+
+
+def test_library_exports_every_declared_symbol():
+    from encodermap_amd import _lib
+
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "emx.h")).read(), flags=re.S)
+    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(emx_\w+)\s*\(", header, re.M))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    if not os.path.isfile(_lib.LIB_PATH):
+        pytest.skip("libemx.so not built (run __graft_entry__.build())")
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    loaded = _lib.load()
+    assert loaded.emx_version() == 1 and loaded.emx_target_arch() == b"gfx950"
+    # argument counts of the binding agree with the header
+    for name, (_, args) in _lib.SIGNATURES.items():
+        m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", header, re.S)
+        params = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        assert len(params) == len(args), (name, len(params), len(args))
