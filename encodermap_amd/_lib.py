@@ -47,7 +47,44 @@ SIGNATURES = {
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
     "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p]),
+    "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
+    "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }
+
+EMX_MAX_LAYERS = 8
+
+
+class MlpDesc(C.Structure):
+    """Mirror of ``emx_mlp_desc`` (include/emx.h)."""
+
+    _fields_ = [("n_layers", _i), ("width", _i * (EMX_MAX_LAYERS + 1)), ("act", _i * EMX_MAX_LAYERS),
+                ("w_off", _l * EMX_MAX_LAYERS), ("b_off", _l * EMX_MAX_LAYERS)]
+
+
+class MlpPlan:
+    """Descriptor + pointer tables for one network (built once per engine)."""
+
+    def __init__(self, layout, params, h, delta):
+        n = len(layout.layers)
+        if n > EMX_MAX_LAYERS:
+            raise EmxError(f"{n} dense layers not supported by the fused MLP kernels (max {EMX_MAX_LAYERS})")
+        d = MlpDesc()
+        d.n_layers = n
+        d.width[0] = layout.net_dim
+        for i, lyr in enumerate(layout.layers):
+            d.width[i + 1] = lyr.n_out
+            d.act[i] = 1 if lyr.activation == "tanh" else 0
+            d.w_off[i] = lyr.w_off
+            d.b_off[i] = lyr.b_off
+        self.desc = d
+        self.params = params
+        self.n_params = params.numel()
+        self.keep = (h, delta)
+        PtrArr = _p * EMX_MAX_LAYERS
+        self.h = PtrArr(*[(t.data_ptr() if t is not None else None) for t in h] + [None] * (EMX_MAX_LAYERS - n))
+        self.delta = PtrArr(*[(t.data_ptr() if t is not None else None) for t in delta] + [None] * (EMX_MAX_LAYERS - n))
 
 _lib = None
 
@@ -186,3 +223,23 @@ def step_tick(terms, n_terms, history, term_history, step, cursor=None):
     cap = history.numel() if history is not None else (term_history.shape[0] if term_history is not None else 0)
     _check(load().emx_step_tick(_ptr(terms), n_terms, _ptr(history), _ptr(term_history), cap, _ptr(step), _ptr(cursor), _stream()),
            "emx_step_tick")
+
+
+def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
+    _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(x), x.stride(0), int(row_begin), int(row_end),
+                                  plan.h, _stream()), "emx_mlp_forward")
+
+
+def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end):
+    _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
+                                   int(layer_add), int(row_begin), int(row_end), plan.h, plan.delta, _stream()), "emx_mlp_backward")
+
+
+def mlp_wgrad_ws_floats(n_params, n_rows):
+    return int(load().emx_mlp_wgrad_ws_floats(int(n_params), int(n_rows)))
+
+
+def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws):
+    _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, _ptr(xin), xin.stride(0),
+                                int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(), _stream()),
+           "emx_mlp_wgrad")

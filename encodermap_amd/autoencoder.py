@@ -56,16 +56,7 @@ class ModelView:
 
     def _decoder_raw(self, z):
         # decoder_model in the reference returns the raw last Dense layer (before atan2)
-        import torch
-
-        eng, lay = self.engine, self.engine.layout
-        with torch.no_grad():
-            y = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32)).to(eng.device)
-            for i in range(lay.n_enc, len(lay.layers)):
-                y = torch.addmm(eng.b[i], y, eng.W[i])
-                if lay.layers[i].activation:
-                    y = torch.tanh(y)
-            return y.cpu().numpy()
+        return self.engine.decode_raw(np.asarray(z))
 
     def encoder(self, x, training: bool = False):
         return self.engine.encode(np.asarray(x))

@@ -1,0 +1,519 @@
+// K12: the dense encoder/decoder as fused row-block kernels on the exact-f32 matrix cores (gfx950).
+//
+// Replaces the per-layer Keras Dense ops of SequentialModel (encodermap/models/models.py:3179-3220: y = act(x W + b),
+// W is [in, out]) and their autodiff (tape.gradient, models.py:3392-3393).  The layers are tiny (<= 3e5 parameters)
+// and B is a few thousand rows, so per-layer GEMM launches are launch- and tail-bound (hipBLASLt: ~36 launches,
+// 330 us per step at B=4096, D=128).  Here:
+//
+//   mlp_forward_kernel   one workgroup = 16 batch rows pushed through a RANGE of layers; the activations of the
+//                        row block ping-pong between two LDS images, every layer's output is also stored to HBM
+//                        for the backward pass.  Each wave owns 32 output columns (two 16x16 MFMA tiles);
+//                        v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain, MI355X_MICROARCH.md) with A fragments read
+//                        from LDS as one ds_read_b128 per four MFMAs and B fragments streamed from the L2-resident
+//                        weights (64-B coalesced row segments), software-pipelined one K-step ahead.
+//   mlp_backward_kernel  same row-block structure in reverse: delta_l = dh_l * act'(h_l) is stored for the weight
+//                        gradients, dh_{l-1} = delta_l W_l^T uses 16-byte row loads of W_l (the k index of an MFMA
+//                        may be assigned to lanes freely, so no transposed copy of the weights is needed).
+//   mlp_wgrad_kernel     dW_l = h_{l-1}^T delta_l and db_l for ALL layers in one launch, split over row slices;
+//                        mlp_wgrad_reduce_kernel adds the slice partials in fixed order (deterministic).
+//
+// Lane maps (cdna_hip_programming.md section 3): 16x16x4: A[m = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15],
+// D[row = 4*(lane>>4) + reg][col = lane&15].  k-assignment used here: in K-step q lane group g = lane>>4 supplies
+// k = 16q + 4g + i for the i-th of four consecutive MFMAs, so a lane's four A (or W-row) values are contiguous.
+#include "emx_common.h"
+
+namespace {
+
+using namespace emx;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 256;
+constexpr int R = 16;            // batch rows per workgroup
+constexpr int MAXL = EMX_MAX_LAYERS;
+
+struct MlpDev {
+  int n_layers;
+  int width[MAXL + 1];
+  int act[MAXL];
+  const float* W[MAXL];
+  const float* b[MAXL];
+  float* h[MAXL];        // activations, row stride = width[l+1]
+  float* delta[MAXL];    // d loss / d pre-activation, row stride = width[l+1]
+};
+
+// Clamped (never masked) operand load.  No mask is needed: the other MFMA operand comes from an LDS image that is
+// zero beyond the valid K range, and output columns beyond N are discarded in the epilogue, so out-of-range lanes
+// may read any finite in-bounds value.  (A select on a loaded value makes hipcc emit an exec-masked load followed
+// by s_waitcnt vmcnt(0) per element, which serialises the K loop on memory latency.)
+__device__ __forceinline__ float ld_clamped(const float* __restrict__ p, int r, int c, int nr, int nc, int ld) {
+  return p[(long)min(r, nr - 1) * ld + min(c, nc - 1)];
+}
+
+template <int NQ>
+__device__ __forceinline__ void fwd_chunk(const float* __restrict__ W, const float* src, int pitch, int q0, int m, int g, int n0, int K,
+                                          int N, f32x4& acc0, f32x4& acc1) {
+  float b0[NQ][4], b1[NQ][4];
+  const int c0 = min(n0 + m, N - 1), c1 = min(n0 + 16 + m, N - 1);
+#pragma unroll
+  for (int q = 0; q < NQ; ++q)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* row = W + (long)min(16 * (q0 + q) + 4 * g + i, K - 1) * N;   // clamped, see ld_clamped
+      b0[q][i] = row[c0];
+      b1[q][i] = row[c1];
+    }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * (q0 + q) + 4 * g]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[q][i], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[q][i], acc1, 0, 0, 0);
+    }
+  }
+}
+
+// backward-data chunk: B fragments are 16-byte pieces of W rows (row = input feature j, 4 consecutive outputs k)
+template <int NQ>
+__device__ __forceinline__ void bwd_chunk(const float* __restrict__ W, const float* src, int pitch, int q0, int m, int g, int n0, int Kin,
+                                          int N, bool vec, f32x4& acc0, f32x4& acc1) {
+  f32x4 w0[NQ], w1[NQ];
+  const float* p0 = W + (long)min(n0 + m, Kin - 1) * N;
+  const float* p1 = W + (long)min(n0 + 16 + m, Kin - 1) * N;
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int k = 16 * (q0 + q) + 4 * g;
+    if (vec) {   // wave-uniform: N % 4 == 0
+      const int kk = min(k, N - 4);
+      w0[q] = *reinterpret_cast<const f32x4*>(p0 + kk);
+      w1[q] = *reinterpret_cast<const f32x4*>(p1 + kk);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        w0[q][i] = p0[min(k + i, N - 1)];
+        w1[q][i] = p1[min(k + i, N - 1)];
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * (q0 + q) + 4 * g]);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w0[q][i], acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w1[q][i], acc1, 0, 0, 0);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// forward: layers [l0, l1) on rows [row0, row_end); `in` is [*, width[l0]] with row stride ld_in
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ in, int ld_in,
+                                                         int row0, int row_end, int pitch) {
+  extern __shared__ __align__(16) float lds[];
+  // (LDS images are addressed as lds + offset everywhere: a pointer array would decay to generic pointers and
+  //  flat_load, whose out-of-order return forces s_waitcnt vmcnt(0) in front of every MFMA group)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int r0 = row0 + blockIdx.x * R;
+
+  // stage the input rows (zero padded to the pitch, rows beyond the block zero)
+  {
+    const int K = d.width[l0];
+    for (int e = tid; e < R * pitch; e += NT) {
+      int r = e / pitch, c = e - r * pitch;
+      float v = 0.f;
+      if (c < K && r0 + r < row_end) v = in[(long)(r0 + r) * ld_in + c];
+      lds[e] = v;
+    }
+  }
+  __syncthreads();
+
+  int cur = 0;
+  for (int l = l0; l < l1; ++l) {
+    const int K = d.width[l], N = d.width[l + 1];
+    const int Kq = (K + 15) >> 4;
+    const float* __restrict__ W = d.W[l];
+    const float* __restrict__ bias = d.b[l];
+    const float* src = lds + cur * (R * pitch);
+    float* dst = lds + (cur ^ 1) * (R * pitch);
+    float* hout = d.h[l];
+    const bool act = d.act[l] != 0;
+    for (int n0 = wave * 32; n0 < N; n0 += 128) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      // K loop in chunks of up to 8 K-steps (128 k): all B fragments of a chunk are requested before the first MFMA
+      // of the chunk, so the L2 latency is paid once per chunk instead of once per K-step (one wave per SIMD here,
+      // nothing else hides it).
+      for (int q0 = 0; q0 < Kq;) {
+        const int left = Kq - q0;
+        if (left >= 8) { fwd_chunk<8>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 8; }
+        else if (left >= 4) { fwd_chunk<4>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 4; }
+        else if (left >= 2) { fwd_chunk<2>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 2; }
+        else { fwd_chunk<1>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 1; }
+      }
+      // epilogue: bias, activation, to LDS (next layer's input, zero beyond N) and to HBM
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int col = n0 + 16 * t + m;
+        const float bv = bias[min(col, N - 1)];
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = 4 * g + reg;
+          float v = (t == 0 ? acc0[reg] : acc1[reg]) + bv;
+          if (act) v = tanhf(v);
+          v = col < N ? v : 0.f;
+          if (col < pitch) dst[row * pitch + col] = v;
+          if (col < N && r0 + row < row_end) hout[(long)(r0 + row) * N + col] = v;
+        }
+      }
+    }
+    // columns of the LDS image between the last written tile and the next layer's padded K must be zero
+    {
+      const int written = ((N + 31) >> 5) << 5;
+      const int need = ((N + 15) >> 4) << 4;
+      (void)need;  // need <= written always
+      (void)written;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// backward (data): for l = l1-1 .. l0:  delta_l = dh_l * act'(h_l)  (stored),  dh_{l-1} = delta_l W_l^T.
+// `dtop` [*, width[l1]] (row stride ld_top) is d loss / d h_{l1-1}; `dadd` (may be null) [*, width[ladd+1]] is
+// added to dh_ladd before its activation derivative (the latent gradient of the distance/center costs).
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ dtop, int ld_top,
+                                                          const float* __restrict__ dadd, int ladd, int row0, int row_end,
+                                                          int pitch) {
+  extern __shared__ __align__(16) float lds[];
+  // (LDS images are addressed as lds + offset everywhere: a pointer array would decay to generic pointers and
+  //  flat_load, whose out-of-order return forces s_waitcnt vmcnt(0) in front of every MFMA group)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  const int r0 = row0 + blockIdx.x * R;
+
+  int cur = 0;
+  // dh of the top layer -> LDS
+  {
+    const int N = d.width[l1];
+    for (int e = tid; e < R * pitch; e += NT) {
+      int r = e / pitch, c = e - r * pitch;
+      float v = 0.f;
+      if (c < N && r0 + r < row_end) v = dtop[(long)(r0 + r) * ld_top + c];
+      lds[e] = v;
+    }
+  }
+  __syncthreads();
+
+  for (int l = l1 - 1; l >= l0; --l) {
+    const int Kin = d.width[l], N = d.width[l + 1];  // layer maps Kin -> N
+    float* dh = lds + cur * (R * pitch);
+    // delta_l = (dh_l [+ dadd]) * act'(h_l), in place in LDS, and stored to HBM for the weight gradients
+    {
+      const float* __restrict__ h = d.h[l];
+      float* __restrict__ dl = d.delta[l];
+      const bool act = d.act[l] != 0;
+      const bool add = dadd != nullptr && l == ladd;
+      for (int e = tid; e < R * N; e += NT) {
+        int r = e / N, c = e - r * N;
+        float v = dh[r * pitch + c];
+        const bool ok = r0 + r < row_end;
+        if (ok) {
+          const long gi = (long)(r0 + r) * N + c;
+          if (add) v += dadd[gi];
+          if (act) {
+            float hv = h[gi];
+            v *= fmaf(-hv, hv, 1.f);
+          }
+          dl[gi] = v;
+        } else {
+          v = 0.f;
+        }
+        dh[r * pitch + c] = v;
+      }
+    }
+    __syncthreads();
+    if (l == l0) break;  // no dh needed below the first layer of the range
+    // dh_{l-1}[row][j] = sum_k delta[row][k] W[j][k]  (k over N outputs, j over Kin inputs)
+    const float* __restrict__ W = d.W[l];
+    const int Kq = (N + 15) >> 4;
+    const float* src = lds + cur * (R * pitch);
+    float* dst = lds + (cur ^ 1) * (R * pitch);
+    const bool vec = (N & 3) == 0;
+    for (int n0 = wave * 32; n0 < Kin; n0 += 128) {
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      for (int q0 = 0; q0 < Kq;) {
+        const int left = Kq - q0;
+        if (left >= 8) { bwd_chunk<8>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 8; }
+        else if (left >= 4) { bwd_chunk<4>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 4; }
+        else if (left >= 2) { bwd_chunk<2>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 2; }
+        else { bwd_chunk<1>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 1; }
+      }
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int col = n0 + 16 * t + m;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const int row = 4 * g + reg;
+          float v = t == 0 ? acc0[reg] : acc1[reg];
+          if (col < pitch) dst[row * pitch + col] = col < Kin ? v : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight gradients: partial[slice][l] (+)= X_l^T delta_l over the slice's rows, X_l = (l == lx0 ? x_in : h_{l-1}).
+// grid = (tiles of all layers) x n_slices; one workgroup = one 64x64 output block of one layer (each wave a
+// 32x32 quadrant = 2x2 MFMA tiles), rows [row0 + slice*rows_per_slice, ...).  db is produced by the blocks of
+// the first tile row.  Partials are stored densely per slice in the flat-parameter layout (w_off/b_off).
+// ---------------------------------------------------------------------------------------------------------
+struct WgradDev {
+  MlpDev d;
+  int l0, l1;
+  const float* xin;
+  int ld_xin;
+  long w_off[MAXL], b_off[MAXL];
+  int tile_begin[MAXL + 1];  // prefix sum of 64x64 output blocks per layer (relative to l0)
+  float* partial;            // [n_slices][n_params]
+  long n_params;
+  int row0, row_end, rows_per_slice;
+};
+
+__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int m = lane & 15, g = lane >> 4;
+  // which layer / block
+  int l = a.l0;
+  while (l + 1 < a.l1 && (int)blockIdx.x >= a.tile_begin[l + 1 - a.l0]) ++l;
+  const int tb = blockIdx.x - a.tile_begin[l - a.l0];
+  const int Kin = a.d.width[l], N = a.d.width[l + 1];
+  const int nbn = (N + 63) >> 6;
+  const int bi = tb / nbn, bj = tb - bi * nbn;
+  const int i0 = bi * 64 + (wave >> 1) * 32;   // input-feature offset of this wave's quadrant
+  const int j0 = bj * 64 + (wave & 1) * 32;    // output-feature offset
+  const float* __restrict__ X = (l == a.l0) ? a.xin : a.d.h[l - 1];
+  const int ldx = (l == a.l0) ? a.ld_xin : Kin;
+  const float* __restrict__ Dl = a.d.delta[l];
+  const int rs = a.row0 + blockIdx.y * a.rows_per_slice;
+  const int re = min(rs + a.rows_per_slice, a.row_end);
+  float* __restrict__ out = a.partial + (long)blockIdx.y * a.n_params;
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum[2] = {0.f, 0.f};
+  const bool do_bias = (bi == 0) && ((wave >> 1) == 0);
+
+  // K loop over rows: step = 16 rows (lane group g supplies rows 4g..4g+3 of the step).  Columns beyond the tensor
+  // are clamped (their outputs are discarded); only the ragged last step masks rows, on the delta side.
+  constexpr int US = 4;   // K-steps (16 rows each) whose loads are in flight together
+  for (int r = rs; r < re; r += 16 * US) {
+    float xa[US][2][4], db[US][2][4];
+#pragma unroll
+    for (int s = 0; s < US; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int rr = min(r + 16 * s + 4 * g + i, re - 1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          xa[s][u][i] = X[(long)rr * ldx + min(i0 + 16 * u + m, Kin - 1)];
+          db[s][u][i] = Dl[(long)rr * N + min(j0 + 16 * u + m, N - 1)];
+        }
+      }
+    if (r + 16 * US > re) {   // ragged tail (wave-uniform): rows beyond the slice contribute nothing
+#pragma unroll
+      for (int s = 0; s < US; ++s)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float ok = (r + 16 * s + 4 * g + i < re) ? 1.f : 0.f;
+          db[s][0][i] *= ok;
+          db[s][1][i] *= ok;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < US; ++s)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int v = 0; v < 2; ++v)
+            acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s][u][i], db[s][v][i], acc[u][v], 0, 0, 0);
+        bsum[0] += db[s][0][i];
+        bsum[1] += db[s][1][i];
+      }
+  }
+  // store the quadrant: D[row = 4g + reg][col = m] of tile (u, v) -> dW[i0 + 16u + row][j0 + 16v + col]
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int ii = i0 + 16 * u + 4 * g + reg, jj = j0 + 16 * v + m;
+        if (ii < Kin && jj < N) out[a.w_off[l] + (long)ii * N + jj] = acc[u][v][reg];
+      }
+  if (do_bias) {
+    // column sums: add the 4 lane groups (rows) of each column
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float s = bsum[u];
+      s += __shfl_xor(s, 16, 64);
+      s += __shfl_xor(s, 32, 64);
+      const int jj = j0 + 16 * u + m;
+      if (g == 0 && jj < N) out[a.b_off[l] + jj] = s;
+    }
+  }
+}
+
+// g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
+__global__ __launch_bounds__(NT) void mlp_wgrad_reduce_kernel(const float* __restrict__ partial, long n_params, int n_slices, long lo,
+                                                              long hi, float* __restrict__ g) {
+  long e = lo + (long)blockIdx.x * NT + threadIdx.x;
+  if (e >= hi) return;
+  float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // fixed association -> deterministic
+  int k = 0;
+  for (; k + 8 <= n_slices; k += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) part[u] += partial[(long)(k + u) * n_params + e];
+  }
+  for (int u = 0; k < n_slices; ++k, ++u) part[u] += partial[(long)k * n_params + e];
+  g[e] = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+}
+
+int fill_dev(const emx_mlp_desc* desc, float* params, float* const* h, float* const* delta, MlpDev& d, const char* who) {
+  EMX_REQUIRE(desc && params, "%s: null descriptor or parameter buffer", who);
+  EMX_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= MAXL, "%s: %d layers not supported (1..%d)", who, desc->n_layers, MAXL);
+  d.n_layers = desc->n_layers;
+  for (int l = 0; l <= desc->n_layers; ++l) {
+    EMX_REQUIRE(desc->width[l] >= 1, "%s: layer width must be >= 1", who);
+    d.width[l] = desc->width[l];
+  }
+  for (int l = 0; l < desc->n_layers; ++l) {
+    d.act[l] = desc->act[l];
+    d.W[l] = params + desc->w_off[l];
+    d.b[l] = params + desc->b_off[l];
+    d.h[l] = h ? h[l] : nullptr;
+    d.delta[l] = delta ? delta[l] : nullptr;
+  }
+  return EMX_OK;
+}
+
+int pitch_for(const emx_mlp_desc* desc, int l0, int l1) {
+  int w = 0;
+  for (int l = l0; l <= l1; ++l) w = std::max(w, desc->width[l]);
+  return ((w + 31) / 32) * 32 + 4;   // tiles write up to the next multiple of 32; +4 keeps b128 rows conflict-free
+}
+
+int set_lds(const void* fn, size_t bytes, const char* who) {
+  if (bytes > 160 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: layer width too large for the LDS row block (%zu bytes)", who, bytes);
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, bytes, hipGetErrorString(e));
+  }
+  return EMX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* in, int ld_in,
+                    int row_begin, int row_end, float* const* h, emx_stream_t stream) {
+  MlpDev d;
+  int rc = fill_dev(desc, params, h, nullptr, d, "emx_mlp_forward");
+  if (rc) return rc;
+  EMX_REQUIRE(in && h, "emx_mlp_forward: null pointer argument");
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
+  for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
+  const int pitch = pitch_for(desc, layer_begin, layer_end);
+  const size_t lds = (size_t)2 * R * pitch * sizeof(float);
+  rc = set_lds(reinterpret_cast<const void*>(&mlp_forward_kernel), lds, "emx_mlp_forward");
+  if (rc) return rc;
+  const int grid = (row_end - row_begin + R - 1) / R;
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, d, layer_begin, layer_end, in, ld_in, row_begin,
+                     row_end, pitch);
+  return emx::check_launch("mlp_forward_kernel");
+}
+
+int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
+                     const float* dadd, int layer_add, int row_begin, int row_end, float* const* h, float* const* delta,
+                     emx_stream_t stream) {
+  MlpDev d;
+  int rc = fill_dev(desc, params, h, delta, d, "emx_mlp_backward");
+  if (rc) return rc;
+  EMX_REQUIRE(dtop && h && delta, "emx_mlp_backward: null pointer argument");
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_backward: bad layer range");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "emx_mlp_backward: bad rows / stride");
+  EMX_REQUIRE(!dadd || (layer_add >= layer_begin && layer_add < layer_end), "emx_mlp_backward: layer_add outside the layer range");
+  for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(h[l] && delta[l], "emx_mlp_backward: buffer of layer %d is null", l);
+  const int pitch = pitch_for(desc, layer_begin, layer_end);
+  const size_t lds = (size_t)2 * R * pitch * sizeof(float);
+  rc = set_lds(reinterpret_cast<const void*>(&mlp_backward_kernel), lds, "emx_mlp_backward");
+  if (rc) return rc;
+  const int grid = (row_end - row_begin + R - 1) / R;
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, d, layer_begin, layer_end, dtop, ld_top, dadd,
+                     layer_add, row_begin, row_end, pitch);
+  return emx::check_launch("mlp_backward_kernel");
+}
+
+size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows) {
+  int slices = (n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
+  return (size_t)std::max(slices, 1) * (size_t)n_params;
+}
+
+int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
+                  int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad, float* ws,
+                  size_t ws_floats, emx_stream_t stream) {
+  WgradDev a;
+  int rc = fill_dev(desc, params, h, delta, a.d, "emx_mlp_wgrad");
+  if (rc) return rc;
+  EMX_REQUIRE(xin && h && delta && grad && ws, "emx_mlp_wgrad: null pointer argument");
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_wgrad: bad layer range");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_xin >= desc->width[layer_begin], "emx_mlp_wgrad: bad rows / stride");
+  const int nrows = row_end - row_begin;
+  if (ws_floats < emx_mlp_wgrad_ws_floats(n_params, nrows))
+    return emx::fail(EMX_EWORKSPACE, "emx_mlp_wgrad: workspace %zu < %zu floats", ws_floats, emx_mlp_wgrad_ws_floats(n_params, nrows));
+  a.l0 = layer_begin;
+  a.l1 = layer_end;
+  a.xin = xin;
+  a.ld_xin = ld_xin;
+  int tiles = 0;
+  long lo = -1, hi = 0;
+  for (int l = layer_begin; l < layer_end; ++l) {
+    EMX_REQUIRE(delta[l] && (l == layer_begin || h[l - 1]), "emx_mlp_wgrad: buffer of layer %d is null", l);
+    a.w_off[l] = desc->w_off[l];
+    a.b_off[l] = desc->b_off[l];
+    a.tile_begin[l - layer_begin] = tiles;
+    tiles += ((desc->width[l] + 63) / 64) * ((desc->width[l + 1] + 63) / 64);
+    const long wl = desc->w_off[l], wh = desc->b_off[l] + desc->width[l + 1];
+    lo = (lo < 0) ? wl : std::min(lo, wl);
+    hi = std::max(hi, wh);
+  }
+  a.tile_begin[layer_end - layer_begin] = tiles;
+  a.partial = ws;
+  a.n_params = n_params;
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  a.rows_per_slice = EMX_WGRAD_SLICE_ROWS;
+  const int slices = (nrows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles, slices), dim3(NT), 0, st, a);
+  rc = emx::check_launch("mlp_wgrad_kernel");
+  if (rc) return rc;
+  const long n = hi - lo;
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, ws, (long)n_params, slices, lo, hi, grad);
+  return emx::check_launch("mlp_wgrad_reduce_kernel");
+}
+
+}  // extern "C"

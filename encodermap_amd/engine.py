@@ -1,14 +1,15 @@
 """Device engine of the dense (sequential) autoencoder: ONE training step of the reference's
 ``SequentialModel.train_step`` (encodermap/models/models.py:3367-3401) as a fixed sequence of HIP kernels
-(libemx, through ctypes) and hipBLASLt GEMMs (through torch), captured once into a hipGraph and replayed.
+(libemx, through ctypes; torch only owns the device memory and the stream), captured once into a hipGraph
+and replayed.
 
 What a step does (reference call stack: SURVEY.md section 3.2):
 
   gather rows (+ sin/cos)            emx_gather_rows           autoencoder.py:845-856, models.py:3347-3351
-  encoder / decoder Dense layers     torch.addmm + tanh        models.py:3179-3220 (the only MFMA use)
+  encoder / decoder Dense layers     emx_mlp_forward           models.py:3179-3220 (exact-f32 MFMA, fused over layers)
   sketch-map distance + center cost  emx_sketchmap_fwd_bwd     loss_functions.py:266-296,351-367,422-449
   auto cost (+ atan2 output)         emx_periodic_cost_fwd_bwd loss_functions.py:586-626, models.py:3353-3359
-  manual backward through the MLP    torch.mm / sum            (tape.gradient, models.py:3392-3393)
+  backward through the Dense layers  emx_mlp_backward / _wgrad (tape.gradient, models.py:3392-3393)
   [data parallel: one all-reduce of the flat gradient + loss-term buffer]
   L2 + clip + Adam, regulariser cost emx_adam_step             autoencoder.py:741-743, loss_functions.py:488-506
   history / counters on the device   emx_step_tick             models.py:3399-3401
@@ -141,16 +142,18 @@ class SequentialEngine:
     # ------------------------------------------------------------------------------------------
     def _alloc_step_buffers(self, B: int) -> None:
         lay, dev, f32 = self.layout, self.device, torch.float32
-        nown = self.re - self.rb
         self.xb = torch.empty(B, self.D, dtype=f32, device=dev)
         self.xin = torch.empty(B, self.net_dim, dtype=f32, device=dev) if self.periodic else self.xb
-        # activations: encoder on all B rows (row-block DP needs the full latent), decoder on own rows only
-        self.h = [torch.empty(B if i < lay.n_enc else nown, l.n_out, dtype=f32, device=dev) for i, l in enumerate(lay.layers)]
-        self.dh = [torch.empty(nown, l.n_out, dtype=f32, device=dev) for l in lay.layers]
-        self.tmp = [torch.empty(nown, l.n_out, dtype=f32, device=dev) if l.activation else None for l in lay.layers]
+        # activations h[l] and pre-activation gradients delta[l], [B, n_out]; a row-block rank fills the encoder
+        # activations for all B rows (the all-pairs cost needs the full latent) and everything else for its own rows
+        self.h = [torch.zeros(B, l.n_out, dtype=f32, device=dev) for l in lay.layers]
+        self.delta = [torch.zeros(B, l.n_out, dtype=f32, device=dev) for l in lay.layers]
+        self.dY = torch.zeros(B, self.net_dim, dtype=f32, device=dev)
         self.dZ = torch.zeros(B, self.L, dtype=f32, device=dev)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.red_ws = torch.empty(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
+        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
 
     # -- data feed -------------------------------------------------------------------------------
     def set_data(self, data) -> None:
@@ -182,30 +185,24 @@ class SequentialEngine:
 
     # -- forward / backward ------------------------------------------------------------------------
     def _forward(self) -> None:
-        lay = self.layout
-        rb, re = self.rb, self.re
-        x = self.xin
-        for i, l in enumerate(lay.layers):
-            if i == lay.n_enc:
-                x = x[rb:re]            # decoder (and everything after) on the rows this rank owns
-            torch.addmm(self.b[i], x, self.W[i], out=self.h[i])
-            if l.activation:
-                torch.tanh(self.h[i], out=self.h[i])
-            x = self.h[i]
+        lay, n = self.layout, len(self.layout.layers)
+        if (self.rb, self.re) == (0, self.B):
+            _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B)
+        else:   # row-block rank: encoder on every row, decoder on the rows it owns
+            _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
+            _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
 
     def _losses(self) -> None:
         p, rb, re, B = self.p, self.rb, self.re, self.B
         lay = self.layout
         Z = self.h[lay.n_enc - 1]
         Y = self.h[-1]
-        dY = self.dh[-1]
-        # auto cost on own rows (global 1/B normalisation), gradient straight into dY
+        # auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY
         if p.auto_cost_scale is not None:
-            _lib.periodic_cost_fwd_bwd(
-                _RowView(Y, rb), 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
-                float(p.auto_cost_scale), rb, re, self.terms[T_AUTO:T_AUTO + 1], _RowView(dY, rb), self.red_ws, B=B)
+            _lib.periodic_cost_fwd_bwd(Y, 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
+                                       float(p.auto_cost_scale), rb, re, self.terms[T_AUTO:T_AUTO + 1], self.dY, self.red_ws, B=B)
         else:
-            dY.zero_()
+            self.dY.zero_()
             self.terms[T_AUTO].zero_()
         cs = p.center_cost_scale
         if self.with_distance and p.distance_cost_scale is not None:
@@ -217,26 +214,9 @@ class SequentialEngine:
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, rb, re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
 
     def _backward(self) -> None:
-        lay = self.layout
-        rb, re = self.rb, self.re
-        n = len(lay.layers)
-        for i in range(n - 1, -1, -1):
-            l = lay.layers[i]
-            d = self.dh[i]
-            if i == lay.n_enc - 1:
-                d.add_(self.dZ[rb:re])           # latent: decoder path + distance/center gradients
-            h_own = self.h[i] if i >= lay.n_enc else self.h[i][rb:re]
-            if l.activation:                      # tanh': d *= 1 - h^2
-                torch.mul(h_own, h_own, out=self.tmp[i])
-                torch.addcmul(d, d, self.tmp[i], value=-1.0, out=d)
-            if i == 0:
-                inp = self.xin[rb:re]
-            else:
-                inp = self.h[i - 1] if i - 1 >= lay.n_enc else self.h[i - 1][rb:re]
-            torch.mm(inp.t(), d, out=self.gW[i])
-            torch.sum(d, dim=0, out=self.gb[i])
-            if i > 0:
-                torch.mm(d, self.W[i].t(), out=self.dh[i - 1])
+        lay, n = self.layout, len(self.layout.layers)
+        _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g, self.wg_ws)
 
     def _step_pre(self) -> None:
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
@@ -364,6 +344,16 @@ class SequentialEngine:
         return int(self.step.item())
 
     # -- inference -----------------------------------------------------------------------------------
+    def _infer(self, x_dev: torch.Tensor, l0: int, l1: int) -> torch.Tensor:
+        """Layers [l0, l1) on an arbitrary number of rows (temporary activation buffers)."""
+        lay = self.layout
+        n = x_dev.shape[0]
+        h = [torch.empty(n, l.n_out, dtype=torch.float32, device=self.device) if l0 <= i < l1 else None
+             for i, l in enumerate(lay.layers)]
+        plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers))
+        _lib.mlp_forward(plan, l0, l1, x_dev, 0, n)
+        return h[l1 - 1]
+
     @torch.no_grad()
     def encode(self, x: np.ndarray, already_transformed: bool = False, chunk: int = 262144) -> np.ndarray:
         lay = self.layout
@@ -374,11 +364,18 @@ class SequentialEngine:
                 xin = torch.empty(xc.shape[0], self.net_dim, dtype=torch.float32, device=self.device)
                 _lib.periodic_in(xc, self.periodicity, xin)
                 xc = xin
-            for i in range(lay.n_enc):
-                xc = torch.addmm(self.b[i], xc, self.W[i])
-                if lay.layers[i].activation:
-                    xc = torch.tanh(xc)
-            out[s: s + chunk] = xc.cpu().numpy()
+            out[s: s + chunk] = self._infer(xc, 0, lay.n_enc).cpu().numpy()
+        return out
+
+    @torch.no_grad()
+    def decode_raw(self, z: np.ndarray, chunk: int = 262144) -> np.ndarray:
+        """Output of the last Dense layer (before the atan2 of periodic models)."""
+        lay = self.layout
+        z = np.asarray(z, np.float32)
+        out = np.empty((z.shape[0], self.net_dim), np.float32)
+        for s in range(0, z.shape[0], chunk):
+            zc = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
+            out[s: s + chunk] = self._infer(zc, lay.n_enc, len(lay.layers)).cpu().numpy()
         return out
 
     @torch.no_grad()
@@ -387,11 +384,8 @@ class SequentialEngine:
         z = np.asarray(z, np.float32)
         out = np.empty((z.shape[0], self.D), np.float32)
         for s in range(0, z.shape[0], chunk):
-            y = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
-            for i in range(lay.n_enc, len(lay.layers)):
-                y = torch.addmm(self.b[i], y, self.W[i])
-                if lay.layers[i].activation:
-                    y = torch.tanh(y)
+            zc = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
+            y = self._infer(zc, lay.n_enc, len(lay.layers))
             if self.periodic:
                 o = torch.empty(y.shape[0], self.D, dtype=torch.float32, device=self.device)
                 _lib.periodic_out(y, self.D, 0, self.D, self.periodicity, o)
@@ -417,19 +411,3 @@ class SequentialEngine:
                 getattr(self, name).copy_(torch.from_numpy(np.asarray(sd[name], np.float32)).to(self.device))
         if "step" in sd:
             self.step.fill_(int(sd["step"]))
-
-
-class _RowView:
-    """Pointer arithmetic helper: presents a tensor that holds rows [row0, row0+n) of a conceptual [B, n] block
-    as if it were the whole block (the C ABI indexes rows globally)."""
-
-    def __init__(self, t: torch.Tensor, row0: int):
-        self.t, self.row0 = t, row0
-        self.is_cuda = t.is_cuda
-        self.shape = t.shape
-
-    def stride(self, i):
-        return self.t.stride(i)
-
-    def data_ptr(self):
-        return self.t.data_ptr() - self.row0 * self.t.stride(0) * self.t.element_size()

