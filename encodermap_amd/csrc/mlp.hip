@@ -49,59 +49,130 @@ __device__ __forceinline__ float ld_clamped(const float* __restrict__ p, int r, 
   return p[(long)min(r, nr - 1) * ld + min(c, nc - 1)];
 }
 
-template <int NQ>
-__device__ __forceinline__ void fwd_chunk(const float* __restrict__ W, const float* src, int pitch, int q0, int m, int g, int n0, int K,
-                                          int N, f32x4& acc0, f32x4& acc1) {
-  float b0[NQ][4], b1[NQ][4];
-  const int c0 = min(n0 + m, N - 1), c1 = min(n0 + 16 + m, N - 1);
-#pragma unroll
-  for (int q = 0; q < NQ; ++q)
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float* row = W + (long)min(16 * (q0 + q) + 4 * g + i, K - 1) * N;   // clamped, see ld_clamped
-      b0[q][i] = row[c0];
-      b1[q][i] = row[c1];
+// tanh with |error| <= ~1e-7 (the float32 resolution of the activations): odd polynomial near zero, 1 - 2/(e^{2x}+1)
+// elsewhere.  ~14 VALU instructions instead of the ~50 of the library tanhf, which matters at one wave per SIMD.
+__device__ __forceinline__ float tanh_f32(float x) {
+  const float ax = fabsf(x);
+  const float x2 = x * x;
+  const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * ax);        // e^{2|x|}
+  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  return ax < 0.25f ? p : copysignf(t, x);
+}
+
+constexpr int UQ = 4;   // K-steps (16 k each) per pipeline unit: 32 B-fragment registers in flight per unit
+
+// One pipeline unit = (layer, 32-column pass of this wave, chunk of UQ K-steps).  Units are walked in order across
+// layer boundaries so that the B fragments (weights, independent of the activations) of the NEXT unit are always in
+// flight while the current unit's MFMAs, epilogue and barrier run.
+struct Unit {
+  int l, n0, c;
+  bool valid;
+};
+
+template <bool BWD>
+__device__ __forceinline__ int unit_cols(const MlpDev& d, int l) {   // width of the GEMM's output (N for fwd, Kin for bwd)
+  return BWD ? d.width[l] : d.width[l + 1];
+}
+template <bool BWD>
+__device__ __forceinline__ int unit_kq(const MlpDev& d, int l) {     // K-steps of the GEMM's reduction axis
+  return ((BWD ? d.width[l + 1] : d.width[l]) + 15) >> 4;
+}
+
+// forward walks layers upward, backward walks them downward (and skips the data GEMM of layer lo)
+template <bool BWD>
+__device__ __forceinline__ Unit first_unit(const MlpDev& d, int l, int lo, int hi, int wave) {
+  Unit u{l, wave * 32, 0, false};
+  while (BWD ? (u.l > lo) : (u.l < hi)) {
+    if (u.n0 < unit_cols<BWD>(d, u.l)) {
+      u.valid = true;
+      return u;
     }
+    u.l += BWD ? -1 : 1;
+  }
+  return u;
+}
+template <bool BWD>
+__device__ __forceinline__ Unit next_unit(const MlpDev& d, Unit u, int lo, int hi, int wave) {
+  const int nch = (unit_kq<BWD>(d, u.l) + UQ - 1) / UQ;
+  if (u.c + 1 < nch) return Unit{u.l, u.n0, u.c + 1, true};
+  if (u.n0 + 128 < unit_cols<BWD>(d, u.l)) return Unit{u.l, u.n0 + 128, 0, true};
+  return first_unit<BWD>(d, u.l + (BWD ? -1 : 1), lo, hi, wave);
+}
+
+// B fragments of a forward unit: W[k][n], k = 16(UQ c + q) + 4g + i, n = n0 + 16t + m.  Uniform row base + per-lane
+// offset (-> global_load with an SGPR base); rows are clamped only in the ragged last chunk.
+__device__ __forceinline__ void load_unit_fwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][2][4]) {
+  const int K = d.width[u.l], N = d.width[u.l + 1];
+  const float* __restrict__ W = d.W[u.l];
+  const int off0 = 4 * g * N + min(u.n0 + m, N - 1), off1 = 4 * g * N + min(u.n0 + 16 + m, N - 1);
+  const int k0 = 16 * UQ * u.c;
+  if (k0 + 16 * UQ <= K) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * (q0 + q) + 4 * g]);
+    for (int q = 0; q < UQ; ++q)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b0[q][i], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b1[q][i], acc1, 0, 0, 0);
-    }
+      for (int i = 0; i < 4; ++i) {
+        const float* rb = W + (long)(k0 + 16 * q + i) * N;   // wave-uniform
+        b[q][0][i] = rb[off0];
+        b[q][1][i] = rb[off1];
+      }
+  } else {
+    const int c0 = min(u.n0 + m, N - 1), c1 = min(u.n0 + 16 + m, N - 1);
+#pragma unroll
+    for (int q = 0; q < UQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float* rb = W + (long)min(k0 + 16 * q + 4 * g + i, K - 1) * N;   // clamped: the A side is zero there
+        b[q][0][i] = rb[c0];
+        b[q][1][i] = rb[c1];
+      }
   }
 }
 
-// backward-data chunk: B fragments are 16-byte pieces of W rows (row = input feature j, 4 consecutive outputs k)
-template <int NQ>
-__device__ __forceinline__ void bwd_chunk(const float* __restrict__ W, const float* src, int pitch, int q0, int m, int g, int n0, int Kin,
-                                          int N, bool vec, f32x4& acc0, f32x4& acc1) {
-  f32x4 w0[NQ], w1[NQ];
-  const float* p0 = W + (long)min(n0 + m, Kin - 1) * N;
-  const float* p1 = W + (long)min(n0 + 16 + m, Kin - 1) * N;
+// B fragments of a backward-data unit: 16-byte pieces of W rows: W[j][k..k+3], j = n0 + 16t + m (input feature),
+// k = 16(UQ c + q) + 4g (output feature)
+__device__ __forceinline__ void load_unit_bwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][2][4]) {
+  const int Kin = d.width[u.l], N = d.width[u.l + 1];
+  const float* __restrict__ W = d.W[u.l];
+  const float* p0 = W + (long)min(u.n0 + m, Kin - 1) * N;
+  const float* p1 = W + (long)min(u.n0 + 16 + m, Kin - 1) * N;
+  const int k0 = 16 * UQ * u.c + 4 * g;
+  if ((N & 3) == 0) {   // wave-uniform
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const int k = 16 * (q0 + q) + 4 * g;
-    if (vec) {   // wave-uniform: N % 4 == 0
-      const int kk = min(k, N - 4);
-      w0[q] = *reinterpret_cast<const f32x4*>(p0 + kk);
-      w1[q] = *reinterpret_cast<const f32x4*>(p1 + kk);
-    } else {
+    for (int q = 0; q < UQ; ++q) {
+      const int kk = min(k0 + 16 * q, N - 4);
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p0 + kk);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(p1 + kk);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        w0[q][i] = p0[min(k + i, N - 1)];
-        w1[q][i] = p1[min(k + i, N - 1)];
+        b[q][0][i] = w0[i];
+        b[q][1][i] = w1[i];
       }
     }
+  } else {
+#pragma unroll
+    for (int q = 0; q < UQ; ++q)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int kk = min(k0 + 16 * q + i, N - 1);
+        b[q][0][i] = p0[kk];
+        b[q][1][i] = p1[kk];
+      }
   }
+}
+
+__device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int g, int c, int Kq, const float (&b)[UQ][2][4],
+                                         f32x4& acc0, f32x4& acc1) {
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * (q0 + q) + 4 * g]);
+  for (int q = 0; q < UQ; ++q) {
+    const int kq = UQ * c + q;
+    if (kq < Kq) {   // wave-uniform
+      const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * kq + 4 * g]);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w0[q][i], acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], w1[q][i], acc1, 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][0][i], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][1][i], acc1, 0, 0, 0);
+      }
     }
   }
 }
@@ -118,6 +189,10 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
   const int m = lane & 15, g = lane >> 4;
   const int r0 = row0 + blockIdx.x * R;
 
+  float bcur[UQ][2][4], bnxt[UQ][2][4];
+  Unit cur = first_unit<false>(d, l0, l0, l1, wave);
+  if (cur.valid) load_unit_fwd(d, cur, m, g, bcur);
+
   // stage the input rows (zero padded to the pitch, rows beyond the block zero)
   {
     const int K = d.width[l0];
@@ -130,53 +205,50 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
   }
   __syncthreads();
 
-  int cur = 0;
+  int buf = 0;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int l = l0; l < l1; ++l) {
-    const int K = d.width[l], N = d.width[l + 1];
-    const int Kq = (K + 15) >> 4;
-    const float* __restrict__ W = d.W[l];
-    const float* __restrict__ bias = d.b[l];
-    const float* src = lds + cur * (R * pitch);
-    float* dst = lds + (cur ^ 1) * (R * pitch);
-    float* hout = d.h[l];
-    const bool act = d.act[l] != 0;
-    for (int n0 = wave * 32; n0 < N; n0 += 128) {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      // K loop in chunks of up to 8 K-steps (128 k): all B fragments of a chunk are requested before the first MFMA
-      // of the chunk, so the L2 latency is paid once per chunk instead of once per K-step (one wave per SIMD here,
-      // nothing else hides it).
-      for (int q0 = 0; q0 < Kq;) {
-        const int left = Kq - q0;
-        if (left >= 8) { fwd_chunk<8>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 8; }
-        else if (left >= 4) { fwd_chunk<4>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 4; }
-        else if (left >= 2) { fwd_chunk<2>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 2; }
-        else { fwd_chunk<1>(W, src, pitch, q0, m, g, n0, K, N, acc0, acc1); q0 += 1; }
-      }
-      // epilogue: bias, activation, to LDS (next layer's input, zero beyond N) and to HBM
+    const int N = d.width[l + 1];
+    const int Kq = (d.width[l] + 15) >> 4;
+    const int nch = (Kq + UQ - 1) / UQ;
+    const float* src = lds + buf * (R * pitch);
+    float* dst = lds + (buf ^ 1) * (R * pitch);
+    while (cur.valid && cur.l == l) {
+      const Unit nxt = next_unit<false>(d, cur, l0, l1, wave);
+      if (nxt.valid) load_unit_fwd(d, nxt, m, g, bnxt);
+      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0, acc1);
+      if (cur.c == nch - 1) {
+        // epilogue: bias, activation, to LDS (next layer's input, zero beyond N) and to HBM
+        const float* __restrict__ bias = d.b[l];
+        float* hout = d.h[l];
+        const bool act = d.act[l] != 0;
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int col = n0 + 16 * t + m;
-        const float bv = bias[min(col, N - 1)];
+        for (int t = 0; t < 2; ++t) {
+          const int col = cur.n0 + 16 * t + m;
+          const float bv = bias[min(col, N - 1)];
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = 4 * g + reg;
-          float v = (t == 0 ? acc0[reg] : acc1[reg]) + bv;
-          if (act) v = tanhf(v);
-          v = col < N ? v : 0.f;
-          if (col < pitch) dst[row * pitch + col] = v;
-          if (col < N && r0 + row < row_end) hout[(long)(r0 + row) * N + col] = v;
+          for (int reg = 0; reg < 4; ++reg) {
+            const int row = 4 * g + reg;
+            float v = (t == 0 ? acc0[reg] : acc1[reg]) + bv;
+            if (act) v = tanh_f32(v);
+            v = col < N ? v : 0.f;
+            dst[row * pitch + col] = v;   // col < round32(N) <= pitch - 4
+            if (col < N && r0 + row < row_end) hout[(long)(r0 + row) * N + col] = v;
+          }
         }
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       }
-    }
-    // columns of the LDS image between the last written tile and the next layer's padded K must be zero
-    {
-      const int written = ((N + 31) >> 5) << 5;
-      const int need = ((N + 15) >> 4) << 4;
-      (void)need;  // need <= written always
-      (void)written;
+#pragma unroll
+      for (int q = 0; q < UQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bcur[q][t][i] = bnxt[q][t][i];
+      cur = nxt;
     }
     __syncthreads();
-    cur ^= 1;
+    buf ^= 1;
   }
 }
 
@@ -189,13 +261,14 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
                                                           const float* __restrict__ dadd, int ladd, int row0, int row_end,
                                                           int pitch) {
   extern __shared__ __align__(16) float lds[];
-  // (LDS images are addressed as lds + offset everywhere: a pointer array would decay to generic pointers and
-  //  flat_load, whose out-of-order return forces s_waitcnt vmcnt(0) in front of every MFMA group)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int r0 = row0 + blockIdx.x * R;
 
-  int cur = 0;
+  float bcur[UQ][2][4], bnxt[UQ][2][4];
+  Unit cur = first_unit<true>(d, l1 - 1, l0, l1, wave);
+  if (cur.valid) load_unit_bwd(d, cur, m, g, bcur);
+
   // dh of the top layer -> LDS
   {
     const int N = d.width[l1];
@@ -208,9 +281,11 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
   }
   __syncthreads();
 
+  int buf = 0;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
   for (int l = l1 - 1; l >= l0; --l) {
     const int Kin = d.width[l], N = d.width[l + 1];  // layer maps Kin -> N
-    float* dh = lds + cur * (R * pitch);
+    float* dh = lds + buf * (R * pitch);
     // delta_l = (dh_l [+ dadd]) * act'(h_l), in place in LDS, and stored to HBM for the weight gradients
     {
       const float* __restrict__ h = d.h[l];
@@ -237,34 +312,38 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
     }
     __syncthreads();
     if (l == l0) break;  // no dh needed below the first layer of the range
-    // dh_{l-1}[row][j] = sum_k delta[row][k] W[j][k]  (k over N outputs, j over Kin inputs)
-    const float* __restrict__ W = d.W[l];
+    // dh_{l-1}[row][j] = sum_k delta[row][k] W[j][k]  (k over the N outputs, j over the Kin inputs)
     const int Kq = (N + 15) >> 4;
-    const float* src = lds + cur * (R * pitch);
-    float* dst = lds + (cur ^ 1) * (R * pitch);
-    const bool vec = (N & 3) == 0;
-    for (int n0 = wave * 32; n0 < Kin; n0 += 128) {
-      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      for (int q0 = 0; q0 < Kq;) {
-        const int left = Kq - q0;
-        if (left >= 8) { bwd_chunk<8>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 8; }
-        else if (left >= 4) { bwd_chunk<4>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 4; }
-        else if (left >= 2) { bwd_chunk<2>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 2; }
-        else { bwd_chunk<1>(W, src, pitch, q0, m, g, n0, Kin, N, vec, acc0, acc1); q0 += 1; }
-      }
+    const int nch = (Kq + UQ - 1) / UQ;
+    const float* src = lds + buf * (R * pitch);
+    float* dst = lds + (buf ^ 1) * (R * pitch);
+    while (cur.valid && cur.l == l) {
+      const Unit nxt = next_unit<true>(d, cur, l0, l1, wave);
+      if (nxt.valid) load_unit_bwd(d, nxt, m, g, bnxt);
+      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0, acc1);
+      if (cur.c == nch - 1) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int col = n0 + 16 * t + m;
+        for (int t = 0; t < 2; ++t) {
+          const int col = cur.n0 + 16 * t + m;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = 4 * g + reg;
-          float v = t == 0 ? acc0[reg] : acc1[reg];
-          if (col < pitch) dst[row * pitch + col] = col < Kin ? v : 0.f;
+          for (int reg = 0; reg < 4; ++reg) {
+            const float v = t == 0 ? acc0[reg] : acc1[reg];
+            dst[(4 * g + reg) * pitch + col] = col < Kin ? v : 0.f;
+          }
         }
+        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       }
+#pragma unroll
+      for (int q = 0; q < UQ; ++q)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) bcur[q][t][i] = bnxt[q][t][i];
+      cur = nxt;
     }
     __syncthreads();
-    cur ^= 1;
+    buf ^= 1;
   }
 }
 

@@ -32,6 +32,8 @@
 // regularisers of distances.py:169-175 (they only keep TF's sqrt gradient finite; X carries no gradient here).
 #include "emx_common.h"
 
+#include <cstdlib>
+
 namespace {
 
 using namespace emx;
@@ -76,11 +78,12 @@ __device__ __forceinline__ float powi(float v) {
 // complement of the sketch-map sigmoid, E(v) = (1 + c v^(a/2))^(-b/a), v = (d/sig)^2   (distances.py:86)
 template <bool FAST>
 __device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
-  float v = fminf(d2 * s.inv_sig2, s.vmax);
-  if constexpr (FAST) {  // a = 12, b = 6
+  if constexpr (FAST) {  // a = 12, b = 6; an overflowing v^6 gives q = inf, rsq = 0: the correct limit, no clamp needed
+    const float v = d2 * s.inv_sig2;
     float q = fmaf(s.c, powi<6>(v), 1.f);
     return __builtin_amdgcn_rsqf(q);
   } else {
+    float v = fminf(d2 * s.inv_sig2, s.vmax);
     float t = __builtin_amdgcn_exp2f(s.half_a * __builtin_amdgcn_logf(v));
     float q = fmaf(s.c, t, 1.f);
     return __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
@@ -90,13 +93,14 @@ __device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
 // low-d: E and G = S'(d)/d / (b c / sig^2) = v^((a-2)/2) * q^(-b/a-1)
 template <bool FAST>
 __device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, float& G) {
-  float v = fminf(d2 * s.inv_sig2, s.vmax);
   if constexpr (FAST) {  // a = 2, b = 6
+    const float v = d2 * s.inv_sig2;
     float q = fmaf(s.c, v, 1.f);
     float r = __builtin_amdgcn_rcpf(q);
     E = r * r * r;
     G = E * r;
   } else {
+    float v = fminf(d2 * s.inv_sig2, s.vmax);
     float lv = __builtin_amdgcn_logf(v);
     float t = __builtin_amdgcn_exp2f(s.half_a * lv);
     float q = fmaf(s.c, t, 1.f);
@@ -326,6 +330,200 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Euclidean tiles on the matrix cores: d2_ij = |x_i|^2 + |x_j|^2 - 2 x_i.x_j  -- the reference's own Gram
+// formulation (encodermap/misc/distances.py:216-227) -- with the cross term on v_mfma_f32_32x32x2_f32 (exact
+// f32: bitwise an fmaf chain, same 157 TFLOP/s peak as the VALU but one MFMA covers 2048 multiply-adds and leaves
+// the VALU to the sigmoid epilogue of the co-resident tiles).  Rows are shifted by the first row of the batch
+// before the products (distances are translation invariant; a common offset of the data would otherwise dominate
+// the cancellation), the diagonal is exactly 0 and d2 is clamped at 0 like distances.py:229.
+// 64x64 tile per workgroup, one 32x32 quadrant per wave.  k-assignment: in each group of 8 k the lane half
+// h = lane>>5 supplies k = 8c + 4h + i to the i-th of four MFMAs, so A and B fragments are single ds_read_b128.
+// ---------------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int LT, bool FASTSIG>
+__global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
+  constexpr int T = 64;
+  constexpr int LMAX = LT ? LT : 4;
+  constexpr int STAGE = 2 * T * LS + 2 * T;            // Xi, Xj images + the two norm vectors
+  constexpr int RP = 68;                               // padded row of 64 column-lane partials
+  constexpr int PART = T * LMAX * RP + T * LMAX * 2;   // row partials [row][l][RP] + column partials
+  constexpr int SMEM = (STAGE > PART ? STAGE : PART) + 8;
+  __shared__ __align__(16) float smem[SMEM];
+  float* Xi_s = smem;
+  float* Xj_s = smem + T * LS;
+  float* ni_s = smem + 2 * T * LS;
+  float* nj_s = ni_s + T;
+
+  const int L = LT ? LT : a.L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
+  const int lr = lane & 31, h = lane >> 5;
+
+  int ti, tj;
+  if (a.symm) {
+    tri_decode(blockIdx.x, a.nbc, ti, tj);
+  } else {
+    ti = blockIdx.x / a.nbc;
+    tj = blockIdx.x - ti * a.nbc;
+  }
+  const int i0 = a.row0 + ti * T;
+  const int j0 = tj * T;
+  const bool offdiag = a.symm && (ti != tj);
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // ---- K loop: stage (x - x_ref) chunks, accumulate row norms, MFMA ---------------------------------
+  const int kq = tid & 7, rb = tid >> 3;
+  float4 pi[2], pj[2];
+  float pni[2] = {0.f, 0.f}, pnj[2] = {0.f, 0.f};
+  auto gload = [&](int k0) {
+    const int k = k0 + 4 * kq;
+    const float4 xr = load_row4(a.X, 0, a.ldx, k, a.D, true, true);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      int row = i0 + rb + 32 * q;
+      float4 v = load_row4(a.X, min(row, a.B - 1), a.ldx, k, a.D, true, true);
+      float w = (row < a.row_end && k < a.D) ? 1.f : 0.f;
+      pi[q] = make_float4((v.x - xr.x) * w, (v.y - xr.y) * w, (v.z - xr.z) * w, (v.w - xr.w) * w);
+      row = j0 + rb + 32 * q;
+      v = load_row4(a.X, min(row, a.B - 1), a.ldx, k, a.D, true, true);
+      w = (row < a.B && k < a.D) ? 1.f : 0.f;
+      pj[q] = make_float4((v.x - xr.x) * w, (v.y - xr.y) * w, (v.z - xr.z) * w, (v.w - xr.w) * w);
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < a.D; k0 += KC) {
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      *reinterpret_cast<float4*>(&Xi_s[(rb + 32 * q) * LS + 4 * kq]) = pi[q];
+      *reinterpret_cast<float4*>(&Xj_s[(rb + 32 * q) * LS + 4 * kq]) = pj[q];
+      pni[q] = fmaf(pi[q].x, pi[q].x, fmaf(pi[q].y, pi[q].y, fmaf(pi[q].z, pi[q].z, fmaf(pi[q].w, pi[q].w, pni[q]))));
+      pnj[q] = fmaf(pj[q].x, pj[q].x, fmaf(pj[q].y, pj[q].y, fmaf(pj[q].z, pj[q].z, fmaf(pj[q].w, pj[q].w, pnj[q]))));
+    }
+    __syncthreads();
+    if (k0 + KC < a.D) gload(k0 + KC);
+#pragma unroll
+    for (int c = 0; c < KC / 8; ++c) {
+      const float4 av = *reinterpret_cast<const float4*>(&Xi_s[(wm * 32 + lr) * LS + 8 * c + 4 * h]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Xj_s[(wn * 32 + lr) * LS + 8 * c + 4 * h]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+    }
+  }
+  // row norms: the 8 lanes that share a row (kq = 0..7) add their partials in a fixed order
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    float s = pni[q], t = pnj[q];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      s += __shfl_xor(s, o, 64);
+      t += __shfl_xor(t, o, 64);
+    }
+    if (kq == 0) {
+      ni_s[rb + 32 * q] = s;
+      nj_s[rb + 32 * q] = t;
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
+  const int jl = wn * 32 + lr;
+  const int jg = j0 + jl;
+  const bool jok = jg < a.B;
+  const float nj = nj_s[jl];
+  float zj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) zj[l] = (jok && l < L) ? a.Z[(long)jg * L + l] : 0.f;
+  float ni[16], zi[16][LMAX];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    ni[r] = ni_s[il];
+    const int ig = min(i0 + il, a.B - 1);
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) zi[r][l] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
+  }
+  __syncthreads();   // norms consumed: the staging LDS is reused for the partial sums below
+
+  float* rpart = smem;                      // [T][LMAX][RP]  (RP = 68: conflict-free 16-byte reads in the fold)
+  float* cpart = smem + T * LMAX * RP;      // [T][LMAX][2]
+  float gj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+  float lsum = 0.f;
+  // interior tiles (the vast majority) need no validity masks and no diagonal fix-up
+  const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+  auto pair = [&](int r, bool masked) {
+    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float dz[LMAX];
+    float dl2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      dz[l] = zi[r][l] - zj[l];
+      dl2 = fmaf(dz[l], dz[l], dl2);
+    }
+    float d2 = fmaxf(fmaf(-2.f, acc[r], ni[r] + nj), 0.f);
+    if (masked) d2 = (i0 + il == jg) ? 0.f : d2;
+    const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+    float El, G;
+    sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+    float f = El - Eh;
+    if (masked) f = (i0 + il < a.row_end && jok) ? f : 0.f;
+    lsum = fmaf(f, f, lsum);
+    const float g = f * G;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      rpart[(il * LMAX + l) * RP + jl] = g * dz[l];
+      gj[l] = fmaf(-g, dz[l], gj[l]);
+    }
+  };
+  if (edge) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, true);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, false);
+  }
+  if (offdiag) {
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      float s = gj[l] + __shfl_xor(gj[l], 32, 64);   // the two row halves of the quadrant
+      if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
+    }
+  }
+  float* red = smem + SMEM - 8;
+  float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
+  if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
+
+  for (int e = tid; e < T * LMAX; e += NT) {
+    int rl = e / LMAX, l = e - rl * LMAX;
+    if (l < L) {
+      const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; u += 4) {
+        float4 s0 = p[u], s1 = p[u + 1], s2 = p[u + 2], s3 = p[u + 3];
+        s += (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+             (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+      }
+      a.P[((long)tj * a.nrows_pad + (i0 - a.row0) + rl) * L + l] = s;
+    }
+  }
+  if (offdiag) {
+    for (int e = tid; e < T * LMAX; e += NT) {
+      int rl = e / LMAX, l = e - rl * LMAX;
+      if (l < L) a.P[((long)ti * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+    }
+  }
+}
+
 struct FinArgs {
   const float* P;
   const float* tile_loss;
@@ -411,8 +609,10 @@ void dispatch2(const SkArgs& a, int ntiles, bool periodic, bool fast, hipStream_
   }
 }
 
-int pick_tile(int B, int nrows) {
-  // 128-tiles halve the LDS traffic per flop but quantise badly on 256 CUs when there are few of them
+int pick_tile(int B, int nrows, bool gram) {
+  // the MFMA (Gram) tiles exist as 64x64 only; the VALU tiles: 128-tiles halve the LDS traffic per flop but
+  // quantise badly on 256 CUs when there are few of them
+  if (gram) return 64;
   long pairs = (long)B * nrows;
   return (pairs >= (long)8192 * 8192) ? 128 : 64;
 }
@@ -452,7 +652,7 @@ struct SkPlan {
   SkArgs a;
   FinArgs f;
   int ntiles, T, nblk_finish;
-  bool periodic, fast;
+  bool periodic, fast, gram;
 };
 
 int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6],
@@ -469,9 +669,14 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
     return emx::fail(EMX_EWORKSPACE, "%s: workspace %zu < %zu bytes", who, ws_bytes, emx_sketchmap_ws_bytes(B, L));
   const bool symm = (row_begin == 0 && row_end == B);
   const int nrows = row_end - row_begin;
-  const int T = pick_tile(B, nrows);
-  pl.T = T;
   pl.periodic = std::isfinite(periodicity);
+  {
+    const char* e = getenv("EMX_SKETCHMAP_DIRECT");   // debugging aid: force the direct-difference VALU tiles
+    pl.gram = !(e && e[0] == '1');
+  }
+  const bool vec4ok = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+  const int T = pick_tile(B, nrows, pl.gram && !pl.periodic && vec4ok);
+  pl.T = T;
   pl.fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
   SkArgs& a = pl.a;
   a.X = X;
@@ -523,6 +728,16 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
 
 int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   const SkArgs& a = pl.a;
+  if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram) {
+    if (a.L == 2) {
+      if (pl.fast) hipLaunchKernelGGL((sk_tile_mfma_kernel<2, true>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+      else hipLaunchKernelGGL((sk_tile_mfma_kernel<2, false>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    } else {
+      if (pl.fast) hipLaunchKernelGGL((sk_tile_mfma_kernel<0, true>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+      else hipLaunchKernelGGL((sk_tile_mfma_kernel<0, false>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    }
+    return emx::check_launch("sk_tile_mfma_kernel");
+  }
   if (pl.T == 128) {
     if (a.L == 2) dispatch2<128, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
     else dispatch2<128, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
