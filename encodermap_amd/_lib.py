@@ -43,10 +43,18 @@ SIGNATURES = {
     "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
     "emx_periodic_in": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
-    "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _i, _i, _p, _p, _p, _p]),
+    "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
     "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p]),
+    "emx_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
+    "emx_chain_in_plane_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
+    "emx_chain_in_plane_bwd": (_i, [_p, _p, _i, _p, _i, _i, _p, _i, _p]),
+    "emx_dihedrals_to_cartesian_fwd": (_i, [_p, _i, _f, _p, _i, _i, _p, _p]),
+    "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
+    "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
@@ -198,13 +206,14 @@ def periodic_out(y, n, off_sin, off_cos, periodicity, out):
 
 
 def periodic_cost_fwd_bwd(y, off_sin, off_cos, periodic_output, target, n, periodicity, variant, coef, row_begin, row_end,
-                          loss, dY, ws, B=None):
+                          loss, dY, ws, B=None, coef_scale=None, dpred_add=None):
     B = y.shape[0] if B is None else B
-    assert dY.stride(0) == y.stride(0)
+    assert dY is None or dY.stride(0) == y.stride(0)
+    assert dpred_add is None or (dpred_add.is_contiguous() and dpred_add.shape[1] == n)
     _check(load().emx_periodic_cost_fwd_bwd(
         _ptr(y), y.stride(0), off_sin, off_cos, int(bool(periodic_output)), _ptr(target), target.stride(0), B, n,
-        float(periodicity), VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef),
-        int(row_begin), int(row_end), _ptr(loss), _ptr(dY), _ptr(ws), _stream()), "emx_periodic_cost_fwd_bwd")
+        float(periodicity), VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef), _ptr(coef_scale),
+        _ptr(dpred_add), int(row_begin), int(row_end), _ptr(loss), _ptr(dY), _ptr(ws), _stream()), "emx_periodic_cost_fwd_bwd")
 
 
 def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):
@@ -243,3 +252,48 @@ def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws):
     _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, _ptr(xin), xin.stride(0),
                                 int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(), _stream()),
            "emx_mlp_wgrad")
+
+
+# ---- ADC path ---------------------------------------------------------------------------------------------------
+def colmean(x, out):
+    B, n = x.shape
+    _check(load().emx_colmean(_ptr(x), B, n, x.stride(0), _ptr(out), _stream()), "emx_colmean")
+
+
+def chain_in_plane_fwd(lengths, angles, xyz):
+    B, A = xyz.shape[0], xyz.shape[1]
+    _check(load().emx_chain_in_plane_fwd(_ptr(lengths), _ptr(angles), angles.stride(0), B, A, _ptr(xyz), _stream()), "emx_chain_in_plane_fwd")
+
+
+def chain_in_plane_bwd(lengths, angles, dxyz, dangles):
+    B, A = dxyz.shape[0], dxyz.shape[1]
+    _check(load().emx_chain_in_plane_bwd(_ptr(lengths), _ptr(angles), angles.stride(0), _ptr(dxyz), B, A, _ptr(dangles),
+                                         dangles.stride(0), _stream()), "emx_chain_in_plane_bwd")
+
+
+def dihedrals_to_cartesian_fwd(dihedrals, offset, plane, out):
+    B, A = plane.shape[0], plane.shape[1]
+    _check(load().emx_dihedrals_to_cartesian_fwd(_ptr(dihedrals), dihedrals.stride(0), float(offset), _ptr(plane), B, A, _ptr(out),
+                                                 _stream()), "emx_dihedrals_to_cartesian_fwd")
+
+
+def dihedrals_to_cartesian_bwd(dihedrals, offset, plane, dout, ddihedrals, dplane):
+    B, A = plane.shape[0], plane.shape[1]
+    _check(load().emx_dihedrals_to_cartesian_bwd(_ptr(dihedrals), dihedrals.stride(0), float(offset), _ptr(plane), _ptr(dout), B, A,
+                                                 _ptr(ddihedrals), ddihedrals.stride(0), _ptr(dplane), _stream()),
+           "emx_dihedrals_to_cartesian_bwd")
+
+
+def pdist_flat_fwd(xyz, start, step, C, out):
+    B, A = xyz.shape[0], xyz.shape[1]
+    _check(load().emx_pdist_flat_fwd(_ptr(xyz), B, A, int(start), int(step), int(C), _ptr(out), out.stride(0), _stream()), "emx_pdist_flat_fwd")
+
+
+def pdist_flat_bwd(xyz, dout, start, step, C, dxyz, accumulate=False):
+    B, A = xyz.shape[0], xyz.shape[1]
+    _check(load().emx_pdist_flat_bwd(_ptr(xyz), _ptr(dout), B, A, int(start), int(step), int(C), dout.stride(0), _ptr(dxyz),
+                                     int(bool(accumulate)), _stream()), "emx_pdist_flat_bwd")
+
+
+def soft_start_scale(step, a, b, c, out):
+    _check(load().emx_soft_start_scale(_ptr(step), float(a), float(b), float(c), _ptr(out), _stream()), "emx_soft_start_scale")

@@ -1,0 +1,492 @@
+// ADC path: dihedral <-> Cartesian back-mapping and per-frame pair distances (gfx950).
+//
+//   K8  emx_colmean                    MeanAngles / mean bond lengths     encodermap/models/layers.py:971,1153-1161
+//   K6  emx_chain_in_plane_fwd/bwd     chain_in_plane                     encodermap/encodermap_tf1/backmapping.py:97-119
+//   K7  emx_dihedrals_to_cartesian_*   dihedrals_to_cartesian_tf(_layers) encodermap/encodermap_tf1/backmapping.py:164-214,
+//                                                                         encodermap/misc/backmapping.py:179-309,1873-1912
+//                                      rotation_matrix                    encodermap/encodermap_tf1/misc.py:286-304
+//   K3  emx_pdist_flat_fwd/bwd         PairwiseDistances / pairwise_dist(flat=True)   layers.py:1252-1267, distances.py:235-253
+//
+// K7 algorithm.  The reference twists the planar chain with A/2 sequential steps per direction, each rotating the
+// whole remaining tail about the current bond (O(A^2) per frame, hundreds of tiny launches).  The same result is a
+// composition of rigid transforms along the chain: with the ORIGINAL (planar) coordinates P_k, step i is the rotation
+// N_i by the dihedral d_i about the original bond (P_{i+1}, P_{i+2}) through P_{i+2}, and
+//     out_k = A_{k-3} P_k,   A_i = A_{i-1} o N_i,   A_{-1} = identity            (k >= 3; out_k = P_k for k < 3)
+// (induction: the axis of step i, taken from the already twisted chain, is A_{i-1} applied to the original bond).
+// One thread walks one direction of one frame: O(A) work, nothing materialised.  The reference's row-vector
+// "(x - o) @ R(u, -d)" equals the usual right-handed rotation by +d about u acting on column vectors.
+// The backward pass walks the chain in reverse, recovering A_{i-1} = A_i o N_i^{-1} instead of storing it, and
+// accumulates the adjoints of the transform, of the dihedral and of the planar coordinates.
+#include "emx_common.h"
+
+namespace {
+
+using namespace emx;
+constexpr int NT = 256;
+constexpr float PI_F = 3.14159265358979323846f;
+
+struct V3 {
+  float x, y, z;
+};
+__device__ __forceinline__ V3 ld3(const float* p) { return V3{p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+
+struct M3 {
+  float m[3][3];
+};
+__device__ __forceinline__ V3 mul(const M3& A, V3 v) {
+  return V3{A.m[0][0] * v.x + A.m[0][1] * v.y + A.m[0][2] * v.z, A.m[1][0] * v.x + A.m[1][1] * v.y + A.m[1][2] * v.z,
+            A.m[2][0] * v.x + A.m[2][1] * v.y + A.m[2][2] * v.z};
+}
+__device__ __forceinline__ V3 mulT(const M3& A, V3 v) {  // A^T v
+  return V3{A.m[0][0] * v.x + A.m[1][0] * v.y + A.m[2][0] * v.z, A.m[0][1] * v.x + A.m[1][1] * v.y + A.m[2][1] * v.z,
+            A.m[0][2] * v.x + A.m[1][2] * v.y + A.m[2][2] * v.z};
+}
+__device__ __forceinline__ M3 mul(const M3& A, const M3& B) {
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[0][j] + A.m[i][1] * B.m[1][j] + A.m[i][2] * B.m[2][j];
+  return C;
+}
+__device__ __forceinline__ M3 mulBT(const M3& A, const M3& B) {  // A B^T
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[i][0] * B.m[j][0] + A.m[i][1] * B.m[j][1] + A.m[i][2] * B.m[j][2];
+  return C;
+}
+__device__ __forceinline__ M3 mulAT(const M3& A, const M3& B) {  // A^T B
+  M3 C;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C.m[i][j] = A.m[0][i] * B.m[0][j] + A.m[1][i] * B.m[1][j] + A.m[2][i] * B.m[2][j];
+  return C;
+}
+__device__ __forceinline__ M3 identity() {
+  M3 I;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) I.m[i][j] = (i == j) ? 1.f : 0.f;
+  return I;
+}
+// right-handed rotation by angle (c = cos, s = sin) about the unit axis u (Rodrigues, encodermap_tf1/misc.py:286-304 transposed)
+__device__ __forceinline__ M3 rodrigues(V3 u, float c, float s) {
+  const float t = 1.f - c;
+  M3 Q;
+  Q.m[0][0] = c + t * u.x * u.x;
+  Q.m[0][1] = t * u.x * u.y - s * u.z;
+  Q.m[0][2] = t * u.x * u.z + s * u.y;
+  Q.m[1][0] = t * u.x * u.y + s * u.z;
+  Q.m[1][1] = c + t * u.y * u.y;
+  Q.m[1][2] = t * u.y * u.z - s * u.x;
+  Q.m[2][0] = t * u.x * u.z - s * u.y;
+  Q.m[2][1] = t * u.y * u.z + s * u.x;
+  Q.m[2][2] = c + t * u.z * u.z;
+  return Q;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K8: column mean.  block = 64 columns x 4 row phases; out[k] = mean_b x[b, k]
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void colmean_kernel(const float* __restrict__ x, int B, int n, int ldx, float* __restrict__ out) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < n) {
+    int b = ph;
+    for (; b + 12 < B; b += 16) {   // 4 independent loads in flight per thread
+      s0 += x[(long)b * ldx + c];
+      s1 += x[(long)(b + 4) * ldx + c];
+      s2 += x[(long)(b + 8) * ldx + c];
+      s3 += x[(long)(b + 12) * ldx + c];
+    }
+    for (; b < B; b += 4) s0 += x[(long)b * ldx + c];
+  }
+  part[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (ph == 0 && c < n) out[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)B;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K6: chain_in_plane.  One thread per frame; O(A) recurrence:
+//   P_0 = 0, phi = 0, s = +1;  P_{i+1} = P_i + len_i (cos phi, s sin phi, 0);  phi <- pi - theta_i - phi;  s <- -s
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void chain_fwd_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda, int B,
+                                                       int A, float* __restrict__ xyz) {
+  const int b = blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const float* th = ang + (long)b * lda;
+  float* o = xyz + (long)b * A * 3;
+  float x = 0.f, y = 0.f, phi = 0.f, sg = 1.f;
+  o[0] = 0.f;
+  o[1] = 0.f;
+  o[2] = 0.f;
+  for (int i = 0; i < A - 1; ++i) {
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    x += len[i] * cs;
+    y += len[i] * sn * sg;
+    o[3 * (i + 1)] = x;
+    o[3 * (i + 1) + 1] = y;
+    o[3 * (i + 1) + 2] = 0.f;
+    if (i < A - 2) phi = PI_F - th[i] - phi;
+    sg = -sg;
+  }
+}
+
+// backward: dphi_j/dtheta_i = (-1)^(i+j) (i < j); dL/dphi_j = len_j * (-sin phi_j * GX_{j+1} + s_j cos phi_j * GY_{j+1}),
+// GX/GY = suffix sums of the coordinate gradients.  Reverse sweep, phi recovered by inverting the recurrence.
+__global__ __launch_bounds__(NT) void chain_bwd_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda,
+                                                       const float* __restrict__ dxyz, int B, int A, float* __restrict__ dang, int ldd) {
+  const int b = blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const float* th = ang + (long)b * lda;
+  const float* g = dxyz + (long)b * A * 3;
+  float* d = dang + (long)b * ldd;
+  // phi_{A-2} by running the recurrence forward once (cheap: no trigonometry)
+  float phi = 0.f;
+  for (int i = 0; i < A - 2; ++i) phi = PI_F - th[i] - phi;
+  float sg = ((A - 2) & 1) ? -1.f : 1.f;
+  float GX = 0.f, GY = 0.f, acc = 0.f;   // acc = sum_{j > i} (-1)^(i+j) dL/dphi_j, maintained as acc <- -(acc) + ...
+  for (int j = A - 2; j >= 0; --j) {
+    GX += g[3 * (j + 1)];
+    GY += g[3 * (j + 1) + 1];
+    float sn, cs;
+    sincosf(phi, &sn, &cs);
+    const float dphi = len[j] * (-sn * GX + sg * cs * GY);
+    // for theta_{j-1}: sum_{k >= j} (-1)^{(j-1)+k} dphi_k = -(dphi_j - sum_{k>j} (-1)^{j+k}...)  -> recurrence acc_j = dphi_j - acc_{j+1}
+    acc = dphi - acc;
+    if (j >= 1) {
+      d[j - 1] = -acc;
+      phi = PI_F - th[j - 1] - phi;   // phi_{j-1} = pi - theta_{j-1} - phi_j
+    }
+    sg = -sg;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K7: one thread = one direction (0: right part, 1: left part) of one frame.
+//   split s = A/2.  right: atoms s-1, s, s+1, ... A-1 with dihedrals d[s-1 ...];   left: atoms s+1, s, s-1, ... 0 with
+//   dihedrals d[s-2], d[s-3], ... d[0]   (encodermap_tf1/backmapping.py:176-181; iteration counts models.py:666-671).
+//   Local chain index c = 0.. maps to atom  a(c) = dir ? s + 1 - c : s - 1 + c,  local dihedral i to
+//   dih(i) = dir ? s - 2 - i : s - 1 + i.  Local atoms 0..2 stay in place; the right pass owns atoms s-1..s+1.
+// ---------------------------------------------------------------------------------------------------------
+struct D2C {
+  int s, A;
+  __device__ __forceinline__ int natoms(int dir) const { return dir ? s + 2 : A - (s - 1); }
+  __device__ __forceinline__ int atom(int dir, int c) const { return dir ? s + 1 - c : s - 1 + c; }
+  __device__ __forceinline__ int dih(int dir, int i) const { return dir ? s - 2 - i : s - 1 + i; }
+};
+
+__global__ __launch_bounds__(NT) void d2c_fwd_kernel(const float* __restrict__ dih, int ldd, float offset, const float* __restrict__ plane,
+                                                     int B, int A, float* __restrict__ out) {
+  const int t = blockIdx.x * NT + threadIdx.x;
+  const int b = t >> 1, dir = t & 1;
+  if (b >= B) return;
+  const D2C g{A / 2, A};
+  const float* P = plane + (long)b * A * 3;
+  const float* dd = dih + (long)b * ldd;
+  float* O = out + (long)b * A * 3;
+  const int n = g.natoms(dir);
+  // fixed atoms (the left pass leaves s-1..s+1 to the right pass)
+  if (dir == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      if (c < n) st3(O + 3 * g.atom(0, c), ld3(P + 3 * g.atom(0, c)));
+  }
+  M3 R = identity();
+  V3 tr{0.f, 0.f, 0.f};
+  V3 p1 = n > 1 ? ld3(P + 3 * g.atom(dir, 1)) : V3{0, 0, 0};
+  V3 p2 = n > 2 ? ld3(P + 3 * g.atom(dir, 2)) : V3{0, 0, 0};
+  for (int i = 0; i + 3 < n; ++i) {
+    // N_i: rotation by d_i about u = unit(p2 - p1) through o = p2
+    V3 w = p2 - p1;
+    const float inv = rsqrtf(dot(w, w));
+    const V3 u = inv * w;
+    float sn, cs;
+    sincosf(dd[g.dih(dir, i)] + offset, &sn, &cs);
+    const M3 Q = rodrigues(u, cs, sn);
+    const V3 c = p2 - mul(Q, p2);
+    tr = mul(R, c) + tr;
+    R = mul(R, Q);
+    const V3 p3 = ld3(P + 3 * g.atom(dir, i + 3));
+    st3(O + 3 * g.atom(dir, i + 3), mul(R, p3) + tr);
+    p1 = p2;
+    p2 = p3;
+  }
+}
+
+// backward: gradients wrt the dihedrals and the planar coordinates.  dplane must be zero-initialised by the host
+// wrapper (both directions add into the shared atoms s-1..s+1 -> done by ONE thread per frame walking both directions).
+__global__ __launch_bounds__(NT) void d2c_bwd_kernel(const float* __restrict__ dih, int ldd, float offset, const float* __restrict__ plane,
+                                                     const float* __restrict__ dout, int B, int A, float* __restrict__ ddih, int ldg,
+                                                     float* __restrict__ dplane) {
+  const int b = blockIdx.x * NT + threadIdx.x;
+  if (b >= B) return;
+  const D2C g{A / 2, A};
+  const float* P = plane + (long)b * A * 3;
+  const float* dd = dih + (long)b * ldd;
+  const float* G = dout + (long)b * A * 3;
+  float* DD = ddih + (long)b * ldg;
+  float* DP = dplane + (long)b * A * 3;
+  for (int k = 0; k < A; ++k) st3(DP + 3 * k, V3{0.f, 0.f, 0.f});
+  // atoms s-1, s, s+1 pass straight through
+  for (int c = 0; c < 3; ++c) {
+    const int a = g.atom(0, c);
+    if (a < A && a >= 0) st3(DP + 3 * a, ld3(G + 3 * a));
+  }
+  for (int dir = 0; dir < 2; ++dir) {
+    const int n = g.natoms(dir);
+    const int nd = n - 3;   // number of dihedral steps
+    if (nd <= 0) continue;
+    // forward sweep to the final transform A_{nd-1}
+    M3 R = identity();
+    V3 tr{0.f, 0.f, 0.f};
+    for (int i = 0; i < nd; ++i) {
+      const V3 p1 = ld3(P + 3 * g.atom(dir, i + 1)), p2 = ld3(P + 3 * g.atom(dir, i + 2));
+      V3 w = p2 - p1;
+      const V3 u = rsqrtf(dot(w, w)) * w;
+      float sn, cs;
+      sincosf(dd[g.dih(dir, i)] + offset, &sn, &cs);
+      const M3 Q = rodrigues(u, cs, sn);
+      tr = mul(R, p2 - mul(Q, p2)) + tr;
+      R = mul(R, Q);
+    }
+    // reverse sweep
+    M3 Rb;   // adjoint of R_i
+    V3 tb{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rb.m[r][c] = 0.f;
+    for (int i = nd - 1; i >= 0; --i) {
+      // out_{i+3} = R_i P_{i+3} + t_i
+      const int a3 = g.atom(dir, i + 3);
+      const V3 gk = ld3(G + 3 * a3), p3 = ld3(P + 3 * a3);
+      Rb.m[0][0] += gk.x * p3.x; Rb.m[0][1] += gk.x * p3.y; Rb.m[0][2] += gk.x * p3.z;
+      Rb.m[1][0] += gk.y * p3.x; Rb.m[1][1] += gk.y * p3.y; Rb.m[1][2] += gk.y * p3.z;
+      Rb.m[2][0] += gk.z * p3.x; Rb.m[2][1] += gk.z * p3.y; Rb.m[2][2] += gk.z * p3.z;
+      tb = tb + gk;
+      {
+        const V3 add = mulT(R, gk);
+        float* q = DP + 3 * a3;
+        q[0] += add.x; q[1] += add.y; q[2] += add.z;
+      }
+      // step i: R_i = R_{i-1} Q_i,  t_i = R_{i-1} c_i + t_{i-1},  c_i = o - Q_i o,  o = P_{i+2}
+      const int a1 = g.atom(dir, i + 1), a2 = g.atom(dir, i + 2);
+      const V3 p1 = ld3(P + 3 * a1), o = ld3(P + 3 * a2);
+      V3 w = o - p1;
+      const float inv = rsqrtf(dot(w, w));
+      const V3 u = inv * w;
+      float sn, cs;
+      sincosf(dd[g.dih(dir, i)] + offset, &sn, &cs);
+      const M3 Q = rodrigues(u, cs, sn);
+      const V3 c = o - mul(Q, o);
+      // recover R_{i-1}, t_{i-1}
+      const M3 Rp = mulBT(R, Q);
+      const V3 tp = tr - mul(Rp, c);
+      // adjoints
+      M3 Qb = mulAT(Rp, Rb);           // from R_i = Rp Q
+      const V3 cb = mulT(Rp, tb);      // from t_i = Rp c + tp
+      M3 Rpb = mulBT(Rb, Q);           // Rb Q^T
+      Rpb.m[0][0] += tb.x * c.x; Rpb.m[0][1] += tb.x * c.y; Rpb.m[0][2] += tb.x * c.z;
+      Rpb.m[1][0] += tb.y * c.x; Rpb.m[1][1] += tb.y * c.y; Rpb.m[1][2] += tb.y * c.z;
+      Rpb.m[2][0] += tb.z * c.x; Rpb.m[2][1] += tb.z * c.y; Rpb.m[2][2] += tb.z * c.z;
+      // c = o - Q o
+      V3 ob = cb - mulT(Q, cb);
+      Qb.m[0][0] -= cb.x * o.x; Qb.m[0][1] -= cb.x * o.y; Qb.m[0][2] -= cb.x * o.z;
+      Qb.m[1][0] -= cb.y * o.x; Qb.m[1][1] -= cb.y * o.y; Qb.m[1][2] -= cb.y * o.z;
+      Qb.m[2][0] -= cb.z * o.x; Qb.m[2][1] -= cb.z * o.y; Qb.m[2][2] -= cb.z * o.z;
+      // Q(u, d) = cs I + sn [u]x + (1 - cs) u u^T
+      const float trQ = Qb.m[0][0] + Qb.m[1][1] + Qb.m[2][2];
+      const V3 ax{Qb.m[2][1] - Qb.m[1][2], Qb.m[0][2] - Qb.m[2][0], Qb.m[1][0] - Qb.m[0][1]};   // <Qb, [v]x> = v . ax
+      const V3 Qu = mul(Qb, u), QTu = mulT(Qb, u);
+      const float uQu = dot(u, Qu);
+      DD[g.dih(dir, i)] = -sn * trQ + cs * dot(u, ax) + sn * uQu;
+      V3 ub = sn * ax + (1.f - cs) * (Qu + QTu);
+      // u = w / |w|
+      const V3 wb = inv * (ub - dot(u, ub) * u);
+      ob = ob + wb;
+      {
+        float* q = DP + 3 * a2;
+        q[0] += ob.x; q[1] += ob.y; q[2] += ob.z;
+        float* q1 = DP + 3 * a1;
+        q1[0] -= wb.x; q1[1] -= wb.y; q1[2] -= wb.z;
+      }
+      R = Rp;
+      tr = tp;
+      Rb = Rpb;
+      // tb carries over unchanged (t_i = ... + t_{i-1})
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// K3: per-frame flat pair distances of the selected atoms (start + step * c, c < C), strict upper triangle, row-major
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
+  // p = i*C - i(i+1)/2 + (j - i - 1)
+  float fc = (float)C - 0.5f;
+  int ii = (int)(fc - sqrtf(fmaxf(fc * fc - 2.f * (float)p, 0.f)));
+  ii = max(0, min(ii, C - 2));
+  while (ii > 0 && (long)ii * C - (long)ii * (ii + 1) / 2 > p) --ii;
+  while ((long)(ii + 1) * C - (long)(ii + 1) * (ii + 2) / 2 <= p) ++ii;
+  i = ii;
+  j = (int)(p - ((long)ii * C - (long)ii * (ii + 1) / 2)) + ii + 1;
+}
+
+__global__ __launch_bounds__(NT) void pdist_fwd_kernel(const float* __restrict__ xyz, int A, int start, int step, int C, long P, int ldo,
+                                                       float* __restrict__ out) {
+  extern __shared__ float sx[];   // [C][3]
+  const int b = blockIdx.x;
+  const float* X = xyz + (long)b * A * 3;
+  for (int e = threadIdx.x; e < 3 * C; e += NT) {
+    int c = e / 3, k = e - 3 * c;
+    sx[e] = X[3 * (start + step * c) + k];
+  }
+  __syncthreads();
+  float* o = out + (long)b * ldo;
+  for (long p = threadIdx.x; p < P; p += NT) {
+    int i, j;
+    pair_decode(p, C, i, j);
+    const float dx = sx[3 * i] - sx[3 * j], dy = sx[3 * i + 1] - sx[3 * j + 1], dz = sx[3 * i + 2] - sx[3 * j + 2];
+    o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  for (long p = P + threadIdx.x; p < ldo; p += NT) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
+}
+
+// one thread per selected atom gathers its C-1 pair terms (deterministic, no atomics)
+__global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
+                                                       int step, int C, int ldo, float* __restrict__ dxyz, int accumulate) {
+  extern __shared__ float sx[];
+  const int b = blockIdx.x;
+  const float* X = xyz + (long)b * A * 3;
+  for (int e = threadIdx.x; e < 3 * C; e += NT) {
+    int c = e / 3, k = e - 3 * c;
+    sx[e] = X[3 * (start + step * c) + k];
+  }
+  __syncthreads();
+  const float* g = dout + (long)b * ldo;
+  float* D = dxyz + (long)b * A * 3;
+  if (!accumulate) {
+    // atoms that are not selected receive zero
+    for (int e = threadIdx.x; e < 3 * A; e += NT) {
+      int a = e / 3;
+      bool sel = a >= start && (a - start) % step == 0 && (a - start) / step < C;
+      if (!sel) D[e] = 0.f;
+    }
+  }
+  for (int i = threadIdx.x; i < C; i += NT) {
+    const float xi = sx[3 * i], yi = sx[3 * i + 1], zi = sx[3 * i + 2];
+    float gx = 0.f, gy = 0.f, gz = 0.f;
+    for (int j = 0; j < C; ++j) {
+      if (j == i) continue;
+      const int lo = min(i, j), hi = max(i, j);
+      const long p = (long)lo * C - (long)lo * (lo + 1) / 2 + (hi - lo - 1);
+      const float dx = xi - sx[3 * j], dy = yi - sx[3 * j + 1], dz = zi - sx[3 * j + 2];
+      const float d2 = dx * dx + dy * dy + dz * dz;
+      const float w = d2 > 0.f ? g[p] * rsqrtf(d2) : 0.f;   // reference mask: zero gradient on coincident atoms
+      gx = fmaf(w, dx, gx);
+      gy = fmaf(w, dy, gy);
+      gz = fmaf(w, dz, gz);
+    }
+    float* q = D + 3 * (start + step * i);
+    if (accumulate) {
+      q[0] += gx; q[1] += gy; q[2] += gz;
+    } else {
+      q[0] = gx; q[1] = gy; q[2] = gz;
+    }
+  }
+}
+
+__global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, float b, float c, float* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float sc = c;
+  if (a >= 0.f) {
+    const float t = (float)*step;
+    if (t < a) sc = 0.f;
+    else if (t <= b) sc = c / (b - a) * (t - a);
+  }
+  *out = sc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t stream) {
+  EMX_REQUIRE(x && out && B > 0 && n > 0 && ldx >= n, "emx_colmean: bad arguments");
+  hipLaunchKernelGGL(colmean_kernel, dim3((n + 63) / 64), dim3(NT), 0, (hipStream_t)stream, x, B, n, ldx, out);
+  return emx::check_launch("colmean_kernel");
+}
+
+int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, int B, int A, float* xyz, emx_stream_t stream) {
+  EMX_REQUIRE(lengths && angles && xyz && B > 0 && A >= 3 && lda >= A - 2, "emx_chain_in_plane_fwd: bad arguments (A >= 3)");
+  hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, B, A, xyz);
+  return emx::check_launch("chain_fwd_kernel");
+}
+
+int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, const float* dxyz, int B, int A, float* dangles, int ldd,
+                           emx_stream_t stream) {
+  EMX_REQUIRE(lengths && angles && dxyz && dangles && B > 0 && A >= 3 && lda >= A - 2 && ldd >= A - 2, "emx_chain_in_plane_bwd: bad arguments");
+  hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, dxyz, B, A, dangles,
+                     ldd);
+  return emx::check_launch("chain_bwd_kernel");
+}
+
+int emx_dihedrals_to_cartesian_fwd(const float* dihedrals, int ldd, float dihedral_offset, const float* plane, int B, int A, float* out,
+                                   emx_stream_t stream) {
+  EMX_REQUIRE(dihedrals && plane && out && B > 0 && A >= 4 && ldd >= A - 3, "emx_dihedrals_to_cartesian_fwd: bad arguments (A >= 4)");
+  hipLaunchKernelGGL(d2c_fwd_kernel, dim3((2 * B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, B,
+                     A, out);
+  return emx::check_launch("d2c_fwd_kernel");
+}
+
+int emx_dihedrals_to_cartesian_bwd(const float* dihedrals, int ldd, float dihedral_offset, const float* plane, const float* dout, int B, int A,
+                                   float* ddihedrals, int ldg, float* dplane, emx_stream_t stream) {
+  EMX_REQUIRE(dihedrals && plane && dout && ddihedrals && dplane && B > 0 && A >= 4 && ldd >= A - 3 && ldg >= A - 3,
+              "emx_dihedrals_to_cartesian_bwd: bad arguments (A >= 4)");
+  hipLaunchKernelGGL(d2c_bwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, dout, B,
+                     A, ddihedrals, ldg, dplane);
+  return emx::check_launch("d2c_bwd_kernel");
+}
+
+int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int C, float* out, int ldo, emx_stream_t stream) {
+  EMX_REQUIRE(xyz && out && B > 0 && A > 0 && C >= 2 && step >= 1 && start >= 0, "emx_pdist_flat_fwd: bad arguments");
+  EMX_REQUIRE(start + (long)step * (C - 1) < A, "emx_pdist_flat_fwd: atom selection outside the frame");
+  const long P = (long)C * (C - 1) / 2;
+  EMX_REQUIRE(ldo >= P, "emx_pdist_flat_fwd: output row stride %d < %ld pairs", ldo, P);
+  const size_t lds = (size_t)3 * C * sizeof(float);
+  if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_fwd: %d atoms do not fit the LDS frame buffer", C);
+  hipLaunchKernelGGL(pdist_fwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, A, start, step, C, P, ldo, out);
+  return emx::check_launch("pdist_fwd_kernel");
+}
+
+int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo, float* dxyz, int accumulate,
+                       emx_stream_t stream) {
+  EMX_REQUIRE(xyz && dout && dxyz && B > 0 && A > 0 && C >= 2 && step >= 1 && start >= 0, "emx_pdist_flat_bwd: bad arguments");
+  EMX_REQUIRE(start + (long)step * (C - 1) < A, "emx_pdist_flat_bwd: atom selection outside the frame");
+  EMX_REQUIRE(ldo >= (long)C * (C - 1) / 2, "emx_pdist_flat_bwd: gradient row stride too small");
+  const size_t lds = (size_t)3 * C * sizeof(float);
+  if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_bwd: %d atoms do not fit the LDS frame buffer", C);
+  hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate);
+  return emx::check_launch("pdist_bwd_kernel");
+}
+
+int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream) {
+  EMX_REQUIRE(step && out, "emx_soft_start_scale: null pointer argument");
+  EMX_REQUIRE(soft_a < 0.f || soft_b > soft_a, "emx_soft_start_scale: soft start needs b > a");
+  hipLaunchKernelGGL(soft_start_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, soft_a, soft_b, scale_c, out);
+  return emx::check_launch("soft_start_kernel");
+}
+
+}  // extern "C"

@@ -77,6 +77,8 @@ __global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restric
 struct CostArgs {
   const float* y;
   const float* target;
+  const float* dpred_add;
+  const float* coef_scale;
   float* dY;
   float* ws;
   int ldy, ldt, off_sin, off_cos, periodic_output;
@@ -113,7 +115,9 @@ __device__ __forceinline__ void cost_elem(const CostArgs& a, const float* yrow, 
   }
 }
 
-__device__ __forceinline__ void cost_store(const CostArgs& a, float* drow, int k, float g, float s, float c) {
+__device__ __forceinline__ void cost_store(const CostArgs& a, float* drow, const float* addrow, int k, float g, float s, float c) {
+  if (!drow) return;
+  if (addrow) g += addrow[k];
   if (a.periodic_output) {
     float inv = a.out_scale / (s * s + c * c);
     drow[a.off_sin + k] = g * c * inv;
@@ -132,7 +136,9 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
   for (int b = a.row_begin + wave; b < a.row_end; b += nwaves) {
     const float* yrow = a.y + (long)b * a.ldy;
     const float* trow = a.target + (long)b * a.ldt;
-    float* drow = a.dY + (long)b * a.ldy;
+    float* drow = a.dY ? a.dY + (long)b * a.ldy : nullptr;
+    const float* addrow = a.dpred_add ? a.dpred_add + (long)b * a.n : nullptr;
+    const float gn = a.coef_scale ? a.gnorm * *a.coef_scale : a.gnorm;
     if (a.variant == EMX_MEAN_NORM) {
       float ss = 0.f;
       for (int k = lane; k < a.n; k += 64) {
@@ -147,7 +153,7 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
       for (int k = lane; k < a.n; k += 64) {
         float s, c, delta, dd;
         cost_elem(a, yrow, trow, k, s, c, delta, dd);
-        cost_store(a, drow, k, a.gnorm * delta * inv * dd, s, c);
+        cost_store(a, drow, addrow, k, gn * delta * inv * dd, s, c);
       }
     } else {
       for (int k = lane; k < a.n; k += 64) {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
           lsum = fmaf(delta, delta, lsum);
           g = 2.f * delta * dd;
         }
-        cost_store(a, drow, k, a.gnorm * g, s, c);
+        cost_store(a, drow, addrow, k, gn * g, s, c);
       }
     }
   }
@@ -170,12 +176,13 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
 }
 
 // *out = scale * sum_{i<n} ws[i], fixed order
-__global__ __launch_bounds__(NT) void final_sum_kernel(const float* __restrict__ ws, int n, float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(NT) void final_sum_kernel(const float* __restrict__ ws, int n, float scale, const float* __restrict__ dev_scale,
+                                                       float* __restrict__ out) {
   __shared__ float red[8];
   float s = 0.f;
   for (int i = threadIdx.x; i < n; i += NT) s += ws[i];
   float t = block_sum<NT>(s, red);
-  if (threadIdx.x == 0) *out = t * scale;
+  if (threadIdx.x == 0) *out = t * scale * (dev_scale ? *dev_scale : 1.f);
 }
 
 __global__ __launch_bounds__(NT) void center_cost_kernel(const float* __restrict__ Z, int L, int row_begin, int row_end,
@@ -320,9 +327,10 @@ int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off
 }
 
 int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output, const float* target, int ldt,
-                              int B, int n, float periodicity, int variant, float coef, int row_begin, int row_end, float* loss,
-                              float* dY, float* ws, emx_stream_t stream) {
-  EMX_REQUIRE(y && target && loss && dY && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
+                              int B, int n, float periodicity, int variant, float coef, const float* coef_scale,
+                              const float* dpred_add, int row_begin, int row_end, float* loss, float* dY, float* ws,
+                              emx_stream_t stream) {
+  EMX_REQUIRE(y && target && loss && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
   EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "emx_periodic_cost_fwd_bwd: bad shape");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_periodic_cost_fwd_bwd: bad row block");
   EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "emx_periodic_cost_fwd_bwd: cost variant %d not available", variant);
@@ -332,6 +340,8 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   CostArgs a;
   a.y = y;
   a.target = target;
+  a.dpred_add = dpred_add;
+  a.coef_scale = coef_scale;
   a.dY = dY;
   a.ws = ws;
   a.ldy = ldy;
@@ -353,7 +363,7 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
   int rc = emx::check_launch("periodic_cost_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, a.gnorm, loss);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, a.gnorm, coef_scale, loss);
   return emx::check_launch("final_sum_kernel");
 }
 
@@ -391,7 +401,7 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   if (reg_loss) {
-    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, reg_loss);
+    hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, (const float*)nullptr, reg_loss);
     rc = emx::check_launch("final_sum_kernel");
   }
   return rc;

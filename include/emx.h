@@ -112,11 +112,17 @@ int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off
  *   atan2(y[:,off_sin+k], y[:,off_cos+k]) * p/2pi and dY receives the gradient for both halves; otherwise
  *   the prediction is y[:, off_sin+k] itself.  periodicity = INFINITY -> plain |pred - target|.
  *   *loss = coef * variant(delta) over rows [row_begin,row_end) normalised by the GLOBAL B;
- *   dY (same layout/stride as y) is WRITTEN for the addressed columns of rows in the block.
+ *   dY (same layout/stride as y) is WRITTEN for the addressed columns of rows in the block (NULL: forward only).
+ *   `coef_scale` (device float, e.g. the soft-start scale of callbacks.py:584-606) multiplies coef on the device so
+ *   that a captured graph follows the step counter; `dpred_add` lets the back-mapping path (cartesian cost) join
+ *   the gradient before the atan2 backward.  The same entry point serves cartesian_loss
+ *   (loss_functions.py:1020-1065): periodic_output = 0, periodicity = INFINITY, y = out_pair, target = inp_pair.
  * ------------------------------------------------------------------------------------------------ */
 int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output,
                               const float* target, int ldt, int B, int n, float periodicity, int variant,
-                              float coef, int row_begin, int row_end, float* loss, float* dY,
+                              float coef, const float* coef_scale /* device scalar multiplied into coef, may be NULL */,
+                              const float* dpred_add /* [B, n] gradient wrt the prediction from other paths, may be NULL */,
+                              int row_begin, int row_end, float* loss, float* dY,
                               float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
 
 /* center cost alone: mean(z^2)*scale over the global batch (loss_functions.py:422-449); dZ written or accumulated */
@@ -181,6 +187,41 @@ size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
                   int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad, float* ws,
                   size_t ws_floats, emx_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------ *
+ * ADC path (AngleDihedralCartesianEncoderMap): back-mapping and per-frame pair distances
+ * ------------------------------------------------------------------------------------------------ */
+/* K8  column mean over the batch: out[k] = mean_b x[b,k]     MeanAngles / mean bond lengths, layers.py:971,1153-1161 */
+int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t stream);
+
+/* K6  chain_in_plane   encodermap/encodermap_tf1/backmapping.py:97-119
+ *   lengths [A-1] (already the batch mean), angles [B, A-2] (stride lda) -> xyz [B, A, 3] (z = 0)
+ *   bwd: dxyz [B,A,3] -> dangles [B, A-2] (stride ldd), WRITTEN.  (lengths are data: no gradient) */
+int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, int B, int A, float* xyz, emx_stream_t stream);
+int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, const float* dxyz, int B, int A,
+                           float* dangles, int ldd, emx_stream_t stream);
+
+/* K7  dihedrals_to_cartesian (two-way, split at A/2)   encodermap/encodermap_tf1/backmapping.py:164-214,
+ *     encodermap/misc/backmapping.py:179-309,1873-1912 ; rotation_matrix encodermap/encodermap_tf1/misc.py:286-304
+ *   dihedrals [B, A-3] (stride ldd; `dihedral_offset` (= pi in BackMapLayer, layers.py:979) is added inside),
+ *   plane [B, A, 3] -> out [B, A, 3].   bwd: dout -> ddihedrals [B, A-3] (stride ldg) and dplane [B, A, 3], WRITTEN. */
+int emx_dihedrals_to_cartesian_fwd(const float* dihedrals, int ldd, float dihedral_offset, const float* plane,
+                                   int B, int A, float* out, emx_stream_t stream);
+int emx_dihedrals_to_cartesian_bwd(const float* dihedrals, int ldd, float dihedral_offset, const float* plane,
+                                   const float* dout, int B, int A, float* ddihedrals, int ldg, float* dplane,
+                                   emx_stream_t stream);
+
+/* K3  per-frame flat pairwise distances of atoms start, start+step, ... (C atoms)   PairwiseDistances, layers.py:1252-1267
+ *     with pairwise_dist(flat=True) distances.py:235-253.  xyz [B, A, 3]; out [B, ldo] holds the C(C-1)/2 distances of
+ *     the strict upper triangle, row-major, followed by zeros up to ldo (so the block can feed the all-pairs kernel
+ *     with a 16-byte aligned row).  bwd: dxyz WRITTEN (accumulate = 0; unselected atoms get 0) or ADDED to. */
+int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int C, float* out, int ldo, emx_stream_t stream);
+int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo,
+                       float* dxyz, int accumulate, emx_stream_t stream);
+
+/* soft start of the cartesian cost (callbacks/callbacks.py:584-606) evaluated on the device from the step counter:
+ * *out = 0 (t < a), c (t - a)/(b - a) (a <= t <= b), c (t > b); a < 0 -> constant c.   t = *step */
+int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream);
 
 #ifdef __cplusplus
 }

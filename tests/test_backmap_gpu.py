@@ -1,0 +1,166 @@
+"""ADC-path kernels (column mean, chain_in_plane, dihedrals_to_cartesian, flat pair distances, soft start) against
+the float64 oracle (oracle/reference_ops.py follows encodermap_tf1/backmapping.py and misc/distances.py; gradients by
+torch autograd, as tf.GradientTape does for the reference).  Needs an MI355X.
+Tolerances: coordinates 2e-5 * chain extent (float32 composition over up to ~230 rotations), gradients 1e-4 relative
+to the largest entry."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import direct_ops as D
+from oracle import reference_ops as R
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+
+
+@pytest.fixture(scope="module")
+def L():
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    _lib.load()
+    return _lib
+
+
+def dev(a):
+    return torch.tensor(np.asarray(a), dtype=torch.float32, device="cuda")
+
+
+def t64(a, grad=False):
+    return torch.tensor(np.asarray(a), dtype=torch.float64, requires_grad=grad)
+
+
+def make_chain(rng, B, A):
+    lengths = rng.normal(1.4, 0.05, (B, A - 1)).astype(np.float32)
+    angles = rng.normal(2.0, 0.1, (B, A - 2)).astype(np.float32)
+    dih = rng.uniform(-PI, PI, (B, A - 3)).astype(np.float32)
+    return lengths, angles, dih
+
+
+def test_colmean(L):
+    rng = np.random.default_rng(0)
+    for B, n in [(256, 227), (1000, 3), (7, 130)]:
+        x = rng.normal(1, 2, (B, n)).astype(np.float32)
+        out = torch.empty(n, device="cuda")
+        L.colmean(dev(x), out)
+        np.testing.assert_allclose(out.cpu().numpy(), x.astype(np.float64).mean(0), rtol=2e-6, atol=2e-6)
+
+
+@pytest.mark.parametrize("B,A", [(5, 4), (33, 7), (64, 24), (256, 228), (16, 457)])
+def test_chain_in_plane_and_backmapping(L, B, A):
+    rng = np.random.default_rng(A)
+    lengths, angles, dih = make_chain(rng, B, A)
+    mean_len = lengths.astype(np.float64).mean(0).astype(np.float32)
+    # ---- oracle
+    ang_t, dih_t = t64(angles, True), t64(dih, True)
+    plane_o = R.chain_in_plane(t64(mean_len)[None, :], ang_t)
+    xyz_o = R.dihedrals_to_cartesian(dih_t + PI, plane_o)
+    gout = rng.normal(0, 1, (B, A, 3))
+    (xyz_o * t64(gout)).sum().backward()
+    extent = float(xyz_o.detach().abs().max()) + 1.0
+    # ---- kernels
+    LEN, ANG, DIH = dev(mean_len), dev(angles), dev(dih)
+    plane = torch.full((B, A, 3), float("nan"), device="cuda")
+    L.chain_in_plane_fwd(LEN, ANG, plane)
+    np.testing.assert_allclose(plane.cpu().numpy(), plane_o.detach().numpy(), atol=2e-5 * extent)
+    assert torch.all(plane[..., 2] == 0)                                  # tests/test_losses.py:643-648
+    xyz = torch.full((B, A, 3), float("nan"), device="cuda")
+    L.dihedrals_to_cartesian_fwd(DIH, PI, plane, xyz)
+    np.testing.assert_allclose(xyz.cpu().numpy(), xyz_o.detach().numpy(), atol=3e-5 * extent)
+    # round trip: the mdtraj-convention dihedrals of the back-mapped chain are the inputs (test_backmapping_em1_em2.py:643-669)
+    back = R.dihedrals_mdtraj_convention(xyz.cpu().double())
+    diff = R.periodic_distance(back, t64(dih), 2 * PI)
+    assert float(diff.max()) < 2e-3
+    # ---- backward
+    G = dev(gout)
+    ddih = torch.full((B, A - 3), float("nan"), device="cuda")
+    dplane = torch.full((B, A, 3), float("nan"), device="cuda")
+    L.dihedrals_to_cartesian_bwd(DIH, PI, plane, G, ddih, dplane)
+    dang = torch.full((B, A - 2), float("nan"), device="cuda")
+    L.chain_in_plane_bwd(LEN, ANG, dplane, dang)
+    gd, ga = dih_t.grad.numpy(), ang_t.grad.numpy()
+    np.testing.assert_allclose(ddih.cpu().numpy(), gd, rtol=0, atol=1e-4 * np.abs(gd).max())
+    np.testing.assert_allclose(dang.cpu().numpy(), ga, rtol=0, atol=1e-4 * np.abs(ga).max())
+
+
+def test_backmapping_helix_table(L):
+    """33x3 helix table of the reference (tests/test_dihedral_to_cartesian.py:98-148): the two-way map reproduces its
+    intra-frame distances (it equals the one-way map up to a rigid motion)."""
+    import json
+    import os
+
+    T = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat_tables.json")))
+    tab = np.array(T["helix_33x3"])
+    phi = (T["helix_phi_deg"] / 180) * PI + PI
+    psi = (T["helix_psi_deg"] / 180) * PI + PI
+    dih = np.array([[phi, psi, 0.0] * 10] * 3, np.float32)
+    chain = np.repeat(R.straight_tetrahedral_chain(33)[None], 3, 0)
+    out = torch.empty(3, 33, 3, device="cuda")
+    L.dihedrals_to_cartesian_fwd(dev(dih), 0.0, dev(chain), out)
+    np.testing.assert_allclose(D.pdist_flat(out.cpu().numpy().astype(np.float64))[0], D.pdist_flat(tab[None])[0], atol=2e-4)
+
+
+@pytest.mark.parametrize("A,start,step,C", [(228, 1, 3, 76), (24, 0, 1, 24), (30, 2, 4, 7), (10, 0, 1, 2)])
+def test_pdist_flat(L, A, start, step, C):
+    rng = np.random.default_rng(C)
+    B = 37
+    xyz = rng.normal(0, 3, (B, A, 3)).astype(np.float32)
+    xyz[:, start + step] = xyz[:, start]           # coincident atoms: exact 0 and zero gradient (distances.py:247-253)
+    P = C * (C - 1) // 2
+    ldo = (P + 3) // 4 * 4
+    out = torch.full((B, ldo), float("nan"), device="cuda")
+    X = dev(xyz)
+    L.pdist_flat_fwd(X, start, step, C, out)
+    sel = xyz[:, start: start + step * C: step].astype(np.float64)
+    ref = D.pdist_flat(sel)
+    np.testing.assert_allclose(out[:, :P].cpu().numpy(), ref, rtol=2e-6, atol=1e-6)
+    assert torch.all(out[:, P:] == 0)
+    assert float(out[0, 0]) == 0.0
+    gout = rng.normal(0, 1, (B, ldo)).astype(np.float32)
+    dx = torch.full((B, A, 3), float("nan"), device="cuda")
+    L.pdist_flat_bwd(X, dev(gout), start, step, C, dx, False)
+    g_sel = D.pdist_flat_bwd(sel, gout[:, :P].astype(np.float64))
+    ref_full = np.zeros((B, A, 3))
+    ref_full[:, start: start + step * C: step] = g_sel
+    np.testing.assert_allclose(dx.cpu().numpy(), ref_full, rtol=0, atol=2e-5 * np.abs(ref_full).max())
+    dx2 = torch.ones(B, A, 3, device="cuda")
+    L.pdist_flat_bwd(X, dev(gout), start, step, C, dx2, True)
+    np.testing.assert_allclose(dx2.cpu().numpy(), 1 + ref_full, rtol=0, atol=2e-5 * np.abs(ref_full).max())
+    # literal of the reference: flat distances of [[0,0],[1,0],[0,1]] are [1, 1, sqrt(2)]  (tests/test_pairwise_distances.py:163-168)
+    tri = dev(np.array([[[0, 0, 0], [1, 0, 0], [0, 1, 0]]], np.float32))
+    o3 = torch.empty(1, 4, device="cuda")
+    L.pdist_flat_fwd(tri, 0, 1, 3, o3)
+    np.testing.assert_allclose(o3.cpu().numpy()[0, :3], [1, 1, 2 ** 0.5], rtol=1e-6)
+
+
+def test_soft_start_and_scaled_cost(L):
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    out = torch.zeros(1, device="cuda")
+    for t, want in [(0, 0.0), (9, 0.5), (12, 1.0), (100, 1.0)]:      # tests/test_losses.py:918-962
+        step.fill_(t)
+        L.soft_start_scale(step, 6, 12, 1.0, out)
+        assert float(out) == pytest.approx(want)
+    step.fill_(3)
+    L.soft_start_scale(step, -1, -1, 2.0, out)                      # (None, None) -> constant scale
+    assert float(out) == 2.0
+    # cartesian cost = coef * scale(device) * mean|inp - out| with the gradient wrt out, plus an external gradient joined in
+    rng = np.random.default_rng(1)
+    B, P = 50, 28
+    inp, outp = rng.normal(0, 1, (B, P)).astype(np.float32), rng.normal(0, 1, (B, P)).astype(np.float32)
+    extra = rng.normal(0, 1, (B, P)).astype(np.float32)
+    step.fill_(9)
+    L.soft_start_scale(step, 6, 12, 1.0, out)
+    loss = torch.zeros(1, device="cuda")
+    dY = torch.zeros(B, P, device="cuda")
+    ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+    L.periodic_cost_fwd_bwd(dev(outp), 0, 0, False, dev(inp), P, float("inf"), "mean_abs", 1.0 / 3.0, 0, B, loss, dY, ws,
+                            coef_scale=out, dpred_add=dev(extra))
+    lo, g = D.periodic_cost_fwd_bwd(inp, outp, float("inf"), "mean_abs", 0.5 / 3.0)
+    assert float(loss) == pytest.approx(lo, rel=1e-5)
+    np.testing.assert_allclose(dY.cpu().numpy(), g + extra, atol=1e-6)
+    # forward only (dY = NULL): train_for_references uses this
+    L.periodic_cost_fwd_bwd(dev(outp), 0, 0, False, dev(inp), P, float("inf"), "mean_square", 2.0, 0, B, loss, None, ws)
+    assert float(loss) == pytest.approx(2.0 * np.mean((inp.astype(np.float64) - outp) ** 2), rel=1e-5)
