@@ -11,10 +11,11 @@ helpers are plain Python); constructing a model does, and fails loudly without t
 from .parameters import ADCParameters, Parameters
 from .misc import create_n_cube, random_on_cube_edges
 from .autoencoder import Autoencoder, DihedralEncoderMap, EncoderMap
+from .adc import AngleDihedralCartesianEncoderMap
 from .callbacks import CheckpointSaver, EarlyStop, EncoderMapBaseCallback, History, ProgressBar
 
 __all__ = [
-    "Parameters", "ADCParameters", "Autoencoder", "EncoderMap", "DihedralEncoderMap",
+    "Parameters", "ADCParameters", "Autoencoder", "EncoderMap", "DihedralEncoderMap", "AngleDihedralCartesianEncoderMap",
     "create_n_cube", "random_on_cube_edges", "EncoderMapBaseCallback", "ProgressBar", "CheckpointSaver",
     "EarlyStop", "History",
 ]

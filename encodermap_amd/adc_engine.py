@@ -1,0 +1,320 @@
+"""Device engine of ``AngleDihedralCartesianEncoderMap``: one ``ADCFunctionalModel.train_step``
+(encodermap/models/models.py:2260-2521, model graph ``gen_functional_model`` :385-1060) as a captured sequence of
+HIP kernels.
+
+Inputs per frame (reference contract, autoencoder.py:1613-1621): central_angles [A-2], central_dihedrals [A-3],
+central_cartesians [A,3], central_distances [A-1], side_dihedrals [S] (A = 3 x residues backbone atoms).
+
+Step:
+  gather the mini-batch (angular features | distances in one block, cartesians in another)
+  encoder input  = [sin|cos] blocks of (angles if use_backbone_angles) | dihedrals | (side dihedrals if use_sidechains)
+  dense layers   = emx_mlp_forward, the decoder output is split back into the same blocks           models.py:1499-1541
+  predictions    = atan2 per block (PeriodicOutput); angles = batch-mean input angles otherwise (MeanAngles)
+  back-mapping   = batch-mean bond lengths -> chain_in_plane -> dihedrals_to_cartesian(dih + pi)     layers.py:957-986
+  pair distances = flat upper triangle of atoms start:stop:step, input and back-mapped               layers.py:1252-1267
+  costs          = dihedral + angle + cartesian (soft start) + distance + cartesian_distance + center + L2 (+ side)
+  backward       = cartesian cost -> pair distances -> back-mapping -> joins the angle/dihedral cost gradients before
+                   the atan2 backward; both sketch-map costs and the center cost meet at the latent; dense backward,
+                   weight gradients, [all-reduce], Adam.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import INF, N_TERMS, DataParallel, SequentialEngine
+
+T_DIH, T_ANG, T_CART, T_DIST, T_CDIST, T_CENTER, T_REG, T_SIDE = range(8)
+ADC_TERM_NAMES = ("dihedral", "angle", "cartesian", "distance", "cartesian_distance", "center", "reg", "side_dihedral")
+
+
+def _round4(n: int) -> int:
+    return (n + 3) // 4 * 4
+
+
+class ADCEngine(SequentialEngine):
+    TERM_NAMES = ADC_TERM_NAMES
+
+    def __init__(self, n_atoms: int, n_side: int, p, *, device: str = "cuda:0", weights: Optional[Sequence[np.ndarray]] = None,
+                 dp: Optional[DataParallel] = None, use_graph: bool = True, history_capacity: Optional[int] = None):
+        if p.periodicity == INF:
+            raise Exception("AngleDihedralCartesianEncoderMap needs a finite periodicity (angles in radians: 2*pi)")
+        if p.use_sidechains and not p.use_backbone_angles:
+            raise Exception("Cannot train model with central dihedrals and side dihedrals only. Backbone angles are required.")
+        if p.reconstruct_sidechains or p.multimer_training is not None:
+            raise NotImplementedError("reconstruct_sidechains / multimer training are experimental in the reference and out of scope here")
+        if dp is not None and dp.active and dp.mode != "replica":
+            raise NotImplementedError("the ADC engine supports data-parallel mode 'replica' (batch statistics are per rank)")
+        self.A = int(n_atoms)
+        if self.A < 4:
+            raise Exception("at least 4 backbone atoms are needed for a dihedral")
+        self.S = int(n_side) if p.use_sidechains else 0
+        self.n_ang, self.n_dih, self.n_len = self.A - 2, self.A - 3, self.A - 1
+        self.use_ang = bool(p.use_backbone_angles)
+        self.periodicity = float(p.periodicity)
+        self.periodic = True
+        self.with_distance = True
+        # feature block: [angles | dihedrals | side | distances]; the encoder sees the first blocks that are switched on
+        self.off_ang, self.off_dih = 0, self.n_ang
+        self.off_side = self.n_ang + self.n_dih
+        self.off_len = self.off_side + self.S
+        self.F = self.off_len + self.n_len
+        parts = []   # (feature column offset, width, column offset of the sin half inside the network input/output)
+        col = 0
+        for on, off, n in ((self.use_ang, self.off_ang, self.n_ang), (True, self.off_dih, self.n_dih), (self.S > 0, self.off_side, self.S)):
+            if on:
+                parts.append((off, n, col))
+                col += 2 * n
+        self.parts = parts
+        self.D = self.F
+        # atoms entering the pair distances (cartesian_pwd_start:stop:step)
+        sel = range(self.A)[slice(p.cartesian_pwd_start, p.cartesian_pwd_stop, p.cartesian_pwd_step)]
+        if len(sel) < 2:
+            raise Exception("cartesian_pwd_start/stop/step select fewer than 2 atoms")
+        self.pw_start, self.pw_step, self.C = sel.start, sel.step, len(sel)
+        self.P = self.C * (self.C - 1) // 2
+        self.ldp = _round4(self.P)
+        self._init_common(col, p, device, weights, dp, use_graph, history_capacity)
+
+    # ------------------------------------------------------------------------------------------
+    def _alloc_step_buffers(self, B: int) -> None:
+        lay, dev, f32 = self.layout, self.device, torch.float32
+        z = lambda *shape: torch.zeros(*shape, dtype=f32, device=dev)
+        self.feat = z(B, self.F)
+        self.cart = z(B, self.A, 3)
+        self.xin = z(B, self.net_dim)
+        self.xb = self.feat
+        self.h = [z(B, l.n_out) for l in lay.layers]
+        self.delta = [z(B, l.n_out) for l in lay.layers]
+        self.dY = z(B, self.net_dim)
+        self.dZ, self.dZ2 = z(B, self.L), z(B, self.L)
+        self.ang_pred = z(B, self.n_ang) if self.use_ang else z(1, self.n_ang)
+        self.dih_pred = z(B, self.n_dih)
+        self.mean_len = z(self.n_len)
+        self.plane, self.xyz = z(B, self.A, 3), z(B, self.A, 3)
+        self.dxyz, self.dplane = z(B, self.A, 3), z(B, self.A, 3)
+        self.inp_pair, self.out_pair, self.dpair = z(B, self.ldp), z(B, self.ldp), z(B, self.ldp)
+        self.ddih_cart, self.dang_cart = z(B, self.n_dih), z(B, self.n_ang)
+        self.cart_scale = z(1)
+        dmax = max(self.ldp, self.F)
+        self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
+        self.red_ws = torch.empty(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
+        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
+
+    # -- data ------------------------------------------------------------------------------------------
+    def set_data(self, angles, dihedrals, cartesians, distances, side_dihedrals=None) -> None:
+        A = self.A
+        angles, dihedrals, distances = (np.asarray(a, np.float32) for a in (angles, dihedrals, distances))
+        cartesians = np.asarray(cartesians, np.float32)
+        N = dihedrals.shape[0]
+        if cartesians.ndim == 2:
+            cartesians = cartesians.reshape(N, -1, 3)
+        for name, arr, want in (("central_angles", angles, (N, A - 2)), ("central_dihedrals", dihedrals, (N, A - 3)),
+                                ("central_cartesians", cartesians, (N, A, 3)), ("central_distances", distances, (N, A - 1))):
+            if arr.shape != want:     # shape asserts of the reference: models.py:1385-1389
+                raise Exception(f"{name} has shape {arr.shape}, expected {want}")
+        blocks = [angles, dihedrals]
+        if self.S:
+            if side_dihedrals is None or np.asarray(side_dihedrals).shape != (N, self.S):
+                raise Exception(f"side_dihedrals of shape {(N, self.S)} are required with use_sidechains=True")
+            blocks.append(np.asarray(side_dihedrals, np.float32))
+        blocks.append(distances)
+        feats = np.concatenate(blocks, axis=1)
+        if np.isnan(feats).any() or np.isnan(cartesians).any():
+            raise NotImplementedError("input contains NaNs; the sparse ADC model is not part of the HIP engine")
+        self.data = torch.from_numpy(np.ascontiguousarray(feats)).to(self.device)
+        self.data_cart = torch.from_numpy(np.ascontiguousarray(cartesians.reshape(N, 3 * A))).to(self.device)
+        self._init_batch_stream()
+
+    # -- one step ----------------------------------------------------------------------------------------
+    def _encoder_input(self, feat: torch.Tensor, xin: torch.Tensor) -> None:
+        for off, n, col in self.parts:
+            _lib.periodic_in(feat[:, off: off + n], self.periodicity, xin[:, col: col + 2 * n])
+
+    def _backmap(self, Y: torch.Tensor, feat: torch.Tensor, B: int, ang_pred, dih_pred, mean_len, plane, xyz) -> None:
+        """PeriodicOutput -> BackMapLayer (layers.py:957-986)."""
+        for off, n, col in self.parts:
+            if off == self.off_ang and self.use_ang:
+                _lib.periodic_out(Y, n, col, col + n, self.periodicity, ang_pred)
+            elif off == self.off_dih:
+                _lib.periodic_out(Y, n, col, col + n, self.periodicity, dih_pred)
+        if not self.use_ang:
+            _lib.colmean(feat[:, self.off_ang: self.off_ang + self.n_ang], ang_pred.view(-1))
+        _lib.colmean(feat[:, self.off_len: self.off_len + self.n_len], mean_len)
+        _lib.chain_in_plane_fwd(mean_len, _Bcast(ang_pred) if not self.use_ang else ang_pred, plane)
+        _lib.dihedrals_to_cartesian_fwd(dih_pred, math.pi, plane, xyz)
+
+    def _step_pre(self) -> None:
+        p, B, per = self.p, self.B, self.periodicity
+        lay, n = self.layout, len(self.layout.layers)
+        t = self.terms
+        _lib.gather_rows(self.data, self.idx_block, INF, self.feat, None, cursor=self.cursor, B=B)
+        _lib.gather_rows(self.data_cart, self.idx_block, INF, self.cart.view(B, -1), None, cursor=self.cursor, B=B)
+        self._encoder_input(self.feat, self.xin)
+        _lib.mlp_forward(self.plan, 0, n, self.xin, 0, B)
+        Y, Z = self.h[-1], self.h[lay.n_enc - 1]
+        self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
+        _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
+        _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
+
+        # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
+        a, b = p.cartesian_cost_scale_soft_start if p.cartesian_cost_scale_soft_start is not None else (None, None)
+        c = p.cartesian_cost_scale
+        _lib.soft_start_scale(self.step, -1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b,
+                              0.0 if c is None else float(c), self.cart_scale)
+        _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
+                                   1.0 / float(p.cartesian_cost_reference), 0, B, t[T_CART:T_CART + 1], self.dpair, self.red_ws,
+                                   coef_scale=self.cart_scale)
+        _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
+        _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
+        if self.use_ang:
+            _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
+
+        # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward)
+        for off, nn, col in self.parts:
+            tgt = self.feat[:, off: off + nn]
+            if off == self.off_dih:
+                sc, var, ref, slot, extra = p.dihedral_cost_scale, p.dihedral_cost_variant, p.dihedral_cost_reference, T_DIH, self.ddih_cart
+            elif off == self.off_ang:
+                sc, var, ref, slot, extra = p.angle_cost_scale, p.angle_cost_variant, p.angle_cost_reference, T_ANG, self.dang_cart
+            else:
+                sc, var, ref, slot, extra = p.side_dihedral_cost_scale, p.side_dihedral_cost_variant, p.side_dihedral_cost_reference, T_SIDE, None
+            coef = 0.0 if sc is None else float(sc) / float(ref)
+            _lib.periodic_cost_fwd_bwd(Y, col, col + nn, True, tgt, nn, per, var, coef, 0, B, t[slot:slot + 1], self.dY, self.red_ws,
+                                       dpred_add=extra)
+        if not self.use_ang:   # mean angles carry no gradient, the cost is still reported (models.py:2383)
+            sc = p.angle_cost_scale
+            _lib.periodic_cost_fwd_bwd(_Bcast(self.ang_pred), 0, 0, False, self.feat[:, self.off_ang: self.off_ang + self.n_ang], self.n_ang,
+                                       per, p.angle_cost_variant, 0.0 if sc is None else float(sc) / float(p.angle_cost_reference), 0, B,
+                                       t[T_ANG:T_ANG + 1], None, self.red_ws, B=B)
+        if not self.S:
+            t[T_SIDE].zero_()
+
+        # latent costs: cartesian distance cost (Euclidean, high-d = input pair distances) with the center cost fused,
+        # and the periodic distance cost on the angular inputs when it is switched on
+        cs = p.center_cost_scale
+        cdc = p.cartesian_distance_cost_scale
+        if cdc is not None:
+            _lib.sketchmap_fwd_bwd(self.inp_pair, Z, INF, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0,
+                                   0, B, t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
+        else:
+            t[T_CDIST].zero_()
+            _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, 0, B, t[T_CENTER:T_CENTER + 1], self.dZ, False)
+        if p.distance_cost_scale is not None:
+            lo = self.off_ang if self.use_ang else self.off_dih
+            hi = self.off_side + self.S if self.use_ang else self.off_dih + self.n_dih
+            _lib.sketchmap_fwd_bwd(self.feat[:, lo:hi], Z, per, p.dist_sig_parameters, float(p.distance_cost_scale), 0.0, 0, B,
+                                   t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws)
+            self.dZ.add_(self.dZ2)
+        else:
+            t[T_DIST].zero_()
+        _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
+        _lib.mlp_wgrad(self.plan, 0, n, self.xin, 0, B, self.g, self.wg_ws)
+
+    def _step_post(self) -> None:
+        p = self.p
+        _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
+                       self.terms[T_REG:T_REG + 1], self.red_ws)
+        _lib.step_tick(self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor)
+        self.step.add_(1)
+
+    # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
+    @torch.no_grad()
+    def reference_costs(self, n_batches: int, mean_ang: np.ndarray, mean_dih: np.ndarray, mean_len: np.ndarray) -> dict:
+        """Costs of the trivial model that always answers with the data-set means, per batch: dihedral cost, angle cost
+        and cartesian cost (pair distances of the mean structure vs the batch), all mean_abs with scale 1 / reference 1
+        and periodicity 2 pi as a fresh ``ADCParameters()`` defines them."""
+        dev, B = self.device, self.B
+        f = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32).reshape(1, -1)).to(dev)
+        m_ang, m_dih, m_len = f(mean_ang), f(mean_dih), f(mean_len).view(-1)
+        plane = torch.empty(1, self.A, 3, dtype=torch.float32, device=dev)
+        xyz = torch.empty_like(plane)
+        pd_mean = torch.zeros(1, self.ldp, dtype=torch.float32, device=dev)
+        _lib.chain_in_plane_fwd(m_len, m_ang, plane)
+        _lib.dihedrals_to_cartesian_fwd(m_dih, math.pi, plane, xyz)
+        _lib.pdist_flat_fwd(xyz, self.pw_start, self.pw_step, self.C, pd_mean)
+        block = self.draw_index_block(n_batches)
+        out = torch.zeros(n_batches, 3, dtype=torch.float32, device=dev)
+        two_pi = 2 * math.pi
+        for i in range(n_batches):
+            idx = block[i * B: (i + 1) * B]
+            _lib.gather_rows(self.data, idx, INF, self.feat, None)
+            _lib.gather_rows(self.data_cart, idx, INF, self.cart.view(B, -1), None)
+            _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
+            _lib.periodic_cost_fwd_bwd(_Bcast(m_dih), 0, 0, False, self.feat[:, self.off_dih: self.off_dih + self.n_dih], self.n_dih, two_pi,
+                                       "mean_abs", 1.0, 0, B, out[i, 0:1], None, self.red_ws, B=B)
+            _lib.periodic_cost_fwd_bwd(_Bcast(m_ang), 0, 0, False, self.feat[:, self.off_ang: self.off_ang + self.n_ang], self.n_ang, two_pi,
+                                       "mean_abs", 1.0, 0, B, out[i, 1:2], None, self.red_ws, B=B)
+            _lib.periodic_cost_fwd_bwd(_Bcast(pd_mean), 0, 0, False, self.inp_pair, self.P, INF, "mean_abs", 1.0, 0, B, out[i, 2:3], None,
+                                       self.red_ws, B=B)
+        o = out.cpu().numpy()
+        return {"dihedral_cost": o[:, 0], "angle_cost": o[:, 1], "cartesian_cost": o[:, 2]}
+
+    # -- inference -------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def encode(self, arrays: Sequence[np.ndarray], chunk: int = 131072) -> np.ndarray:
+        """arrays: the encoder inputs in order (angles if use_backbone_angles, dihedrals, side dihedrals if use_sidechains)."""
+        if len(arrays) != len(self.parts):
+            raise Exception(f"the encoder takes {len(self.parts)} arrays, got {len(arrays)}")
+        N = arrays[0].shape[0]
+        out = np.empty((N, self.L), np.float32)
+        for s in range(0, N, chunk):
+            xin = torch.empty(min(chunk, N - s), self.net_dim, dtype=torch.float32, device=self.device)
+            for (off, n, col), a in zip(self.parts, arrays):
+                if a.shape[1] != n:
+                    raise Exception(f"The shape of the provided data ({a.shape}) does not match the expected shape (None, {n}).")
+                ac = torch.from_numpy(np.ascontiguousarray(a[s: s + chunk], dtype=np.float32)).to(self.device)
+                _lib.periodic_in(ac, self.periodicity, xin[:, col: col + 2 * n])
+            out[s: s + chunk] = self._infer(xin, 0, self.layout.n_enc).cpu().numpy()
+        return out
+
+    @torch.no_grad()
+    def decode(self, z: np.ndarray, chunk: int = 131072) -> list:
+        """Latent points -> list of angle arrays, one per decoder block (angles?, dihedrals, side dihedrals?)."""
+        z = np.asarray(z, np.float32)
+        outs = [np.empty((z.shape[0], n), np.float32) for _, n, _ in self.parts]
+        for s in range(0, z.shape[0], chunk):
+            zc = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
+            y = self._infer(zc, self.layout.n_enc, len(self.layout.layers))
+            for (off, n, col), o in zip(self.parts, outs):
+                t = torch.empty(y.shape[0], n, dtype=torch.float32, device=self.device)
+                _lib.periodic_out(y, n, col, col + n, self.periodicity, t)
+                o[s: s + chunk] = t.cpu().numpy()
+        return outs
+
+    @torch.no_grad()
+    def backmap(self, angles: np.ndarray, dihedrals: np.ndarray, mean_lengths: np.ndarray) -> np.ndarray:
+        """chain_in_plane + dihedrals_to_cartesian(dih + pi) for arbitrary frames (generate())."""
+        n = dihedrals.shape[0]
+        dev = self.device
+        ang = torch.from_numpy(np.ascontiguousarray(angles, dtype=np.float32)).to(dev)
+        dih = torch.from_numpy(np.ascontiguousarray(dihedrals, dtype=np.float32)).to(dev)
+        ml = torch.from_numpy(np.ascontiguousarray(mean_lengths, dtype=np.float32).reshape(-1)).to(dev)
+        plane = torch.empty(n, self.A, 3, dtype=torch.float32, device=dev)
+        xyz = torch.empty_like(plane)
+        _lib.chain_in_plane_fwd(ml, ang if ang.shape[0] == n else _Bcast(ang), plane)
+        _lib.dihedrals_to_cartesian_fwd(dih, math.pi, plane, xyz)
+        return xyz.cpu().numpy()
+
+
+class _Bcast:
+    """Presents a single row as a [B, n] block with row stride 0 (broadcast) to the C ABI."""
+
+    def __init__(self, t: torch.Tensor):
+        self.t = t
+        self.is_cuda = t.is_cuda
+        self.shape = (1, t.shape[-1])
+
+    def stride(self, i):
+        return 0 if i == 0 else 1
+
+    def data_ptr(self):
+        return self.t.data_ptr()
+
+    def is_contiguous(self):
+        return True

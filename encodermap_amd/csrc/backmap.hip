@@ -430,14 +430,14 @@ int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t 
 }
 
 int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, int B, int A, float* xyz, emx_stream_t stream) {
-  EMX_REQUIRE(lengths && angles && xyz && B > 0 && A >= 3 && lda >= A - 2, "emx_chain_in_plane_fwd: bad arguments (A >= 3)");
+  EMX_REQUIRE(lengths && angles && xyz && B > 0 && A >= 3 && (lda >= A - 2 || lda == 0), "emx_chain_in_plane_fwd: bad arguments (A >= 3)");
   hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, B, A, xyz);
   return emx::check_launch("chain_fwd_kernel");
 }
 
 int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, const float* dxyz, int B, int A, float* dangles, int ldd,
                            emx_stream_t stream) {
-  EMX_REQUIRE(lengths && angles && dxyz && dangles && B > 0 && A >= 3 && lda >= A - 2 && ldd >= A - 2, "emx_chain_in_plane_bwd: bad arguments");
+  EMX_REQUIRE(lengths && angles && dxyz && dangles && B > 0 && A >= 3 && (lda >= A - 2 || lda == 0) && ldd >= A - 2, "emx_chain_in_plane_bwd: bad arguments");
   hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, dxyz, B, A, dangles,
                      ldd);
   return emx::check_launch("chain_bwd_kernel");

@@ -334,7 +334,9 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "emx_periodic_cost_fwd_bwd: bad shape");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_periodic_cost_fwd_bwd: bad row block");
   EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "emx_periodic_cost_fwd_bwd: cost variant %d not available", variant);
-  EMX_REQUIRE(off_sin >= 0 && off_sin + n <= ldy && (!periodic_output || (off_cos >= 0 && off_cos + n <= ldy)),
+  // ldy == 0 broadcasts one prediction row to every batch row (forward only: the batch-mean angles of MeanAngles)
+  EMX_REQUIRE(ldy > 0 || !dY, "emx_periodic_cost_fwd_bwd: a broadcast prediction (ldy == 0) cannot receive a gradient");
+  EMX_REQUIRE(off_sin >= 0 && (ldy == 0 || off_sin + n <= ldy) && (!periodic_output || (off_cos >= 0 && (ldy == 0 || off_cos + n <= ldy))),
               "emx_periodic_cost_fwd_bwd: column window outside the row");
   EMX_REQUIRE(!periodic_output || std::isfinite(periodicity), "emx_periodic_cost_fwd_bwd: periodic output needs a finite periodicity");
   CostArgs a;

@@ -90,20 +90,26 @@ class DataParallel:
 class SequentialEngine:
     """Weights, optimizer state, buffers and the captured step of Autoencoder / EncoderMap."""
 
+    TERM_NAMES = TERM_NAMES
+
     def __init__(self, input_dim: int, p, *, with_distance: bool, device: str = "cuda:0",
                  weights: Optional[Sequence[np.ndarray]] = None, dp: Optional[DataParallel] = None,
                  use_graph: bool = True, history_capacity: Optional[int] = None):
+        self.with_distance = bool(with_distance)
+        self.periodicity = float(p.periodicity)
+        self.periodic = self.periodicity < INF
+        self.D = int(input_dim)
+        self._init_common(2 * self.D if self.periodic else self.D, p, device, weights, dp, use_graph, history_capacity)
+
+    def _init_common(self, net_dim: int, p, device, weights, dp, use_graph, history_capacity) -> None:
+        """Flat parameter/optimizer buffers, counters, history -- shared by the sequential and the ADC engine."""
         _lib.require_gpu()
         _lib.load()
         self.p = p
         self.device = torch.device(device)
         torch.cuda.set_device(self.device)
         self.dp = dp or DataParallel()
-        self.with_distance = bool(with_distance)
-        self.periodicity = float(p.periodicity)
-        self.periodic = self.periodicity < INF
-        self.D = int(input_dim)
-        self.net_dim = 2 * self.D if self.periodic else self.D
+        self.net_dim = int(net_dim)
         self.layout: NetLayout = build_layout(p.n_neurons, p.activation_functions, self.net_dim)
         self.L = self.layout.latent_dim
         self.B = int(p.batch_size)
@@ -121,15 +127,12 @@ class SequentialEngine:
         self.l2coef = torch.from_numpy(l2_coefficients(lay, p.l2_reg_constant)).to(dev)
         self.W = [self.w[l.w_off: l.w_off + l.n_in * l.n_out].view(l.n_in, l.n_out) for l in lay.layers]
         self.b = [self.w[l.b_off: l.b_off + l.n_out] for l in lay.layers]
-        self.gW = [self.g[l.w_off: l.w_off + l.n_in * l.n_out].view(l.n_in, l.n_out) for l in lay.layers]
-        self.gb = [self.g[l.b_off: l.b_off + l.n_out] for l in lay.layers]
 
         self.step = torch.full((1,), int(p.current_training_step), dtype=torch.int64, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
         self.history_capacity = int(history_capacity or max(int(p.n_steps), 1))
         self.history = torch.zeros(self.history_capacity, dtype=torch.float32, device=dev)
         self.term_history = torch.zeros(self.history_capacity, N_TERMS, dtype=torch.float32, device=dev)
-        self._hist_base = int(p.current_training_step)   # history[i] belongs to training step _hist_base + i
         self.hstep = torch.zeros(1, dtype=torch.int64, device=dev)  # write position in history
 
         self.rb, self.re = self.dp.row_block(self.B)
@@ -163,6 +166,9 @@ class SequentialEngine:
         self.data = data.to(self.device, dtype=torch.float32).contiguous()
         if self.data.shape[1] != self.D:
             raise Exception(f"train data has {self.data.shape[1]} features, the model expects {self.D}")
+        self._init_batch_stream()
+
+    def _init_batch_stream(self) -> None:
         seed = self.dp.batch_seed(self.p.seed)
         self._gen = torch.Generator(device=self.device)
         if seed is None:
@@ -338,7 +344,7 @@ class SequentialEngine:
     def loss_terms(self) -> dict:
         torch.cuda.synchronize(self.device)
         th = self.term_history[: self._hstep_host].cpu().numpy()
-        return {name: th[:, i] for i, name in enumerate(TERM_NAMES)}
+        return {name: th[:, i] for i, name in enumerate(self.TERM_NAMES)}
 
     def current_step(self) -> int:
         return int(self.step.item())

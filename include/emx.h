@@ -195,7 +195,8 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t stream);
 
 /* K6  chain_in_plane   encodermap/encodermap_tf1/backmapping.py:97-119
- *   lengths [A-1] (already the batch mean), angles [B, A-2] (stride lda) -> xyz [B, A, 3] (z = 0)
+ *   lengths [A-1] (already the batch mean), angles [B, A-2] (stride lda; lda = 0 broadcasts one row of
+ *   batch-mean angles to every frame, MeanAngles layers.py:1153-1161) -> xyz [B, A, 3] (z = 0)
  *   bwd: dxyz [B,A,3] -> dangles [B, A-2] (stride ldd), WRITTEN.  (lengths are data: no gradient) */
 int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, int B, int A, float* xyz, emx_stream_t stream);
 int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, const float* dxyz, int B, int A,

@@ -424,3 +424,111 @@ def dihedrals_mdtraj_convention(xyz: torch.Tensor) -> torch.Tensor:
     p1 = (b1 * c1).sum(-1) * torch.linalg.norm(b2, dim=-1)
     p2 = (c1 * c2).sum(-1)
     return torch.atan2(p1, p2)
+
+
+# --------------------------------------------------------------------------- #
+# a21: ADC functional model -- models/models.py:385-1060 (graph), :2260-2521 (get_loss / train_step)
+# --------------------------------------------------------------------------- #
+class ADCOracle:
+    """gen_functional_model as plain tensors.  ``params`` = [W0, b0, ...] over encoder then decoder Dense layers."""
+
+    def __init__(self, n_atoms: int, n_side: int, p: dict, params: Sequence[np.ndarray], dtype=torch.float64):
+        self.p = p
+        self.A = n_atoms
+        self.use_ang = bool(p.get("use_backbone_angles", False))
+        self.use_side = bool(p.get("use_sidechains", False))
+        self.periodicity = float(p.get("periodicity", 2 * PI))
+        widths = ([n_atoms - 2] if self.use_ang else []) + [n_atoms - 3] + ([n_side] if self.use_side else [])
+        self.splits = [2 * w for w in widths]                      # models.py:1980-2002
+        net_dim = sum(self.splits)
+        enc, dec = layer_plan(p["n_neurons"], p["activation_functions"], net_dim)
+        self.enc_acts = [a for _, a in enc]
+        self.dec_acts = [a for _, a in dec]
+        self.n_enc = len(enc)
+        self.params = [torch.tensor(np.asarray(q), dtype=dtype).requires_grad_(True) for q in params]
+        self.dtype = dtype
+
+    def encoder(self, inputs: Sequence[torch.Tensor]) -> torch.Tensor:
+        x = torch.cat([periodic_input(a, self.periodicity) for a in inputs], dim=1)   # PeriodicInput + Concatenate, :625-630,872-878
+        W, b = self.params[0::2], self.params[1::2]
+        return dense_stack(x, W[: self.n_enc], b[: self.n_enc], self.enc_acts)
+
+    def decoder(self, z: torch.Tensor):
+        W, b = self.params[0::2], self.params[1::2]
+        y = dense_stack(z, W[self.n_enc:], b[self.n_enc:], self.dec_acts)
+        return [periodic_output(part, self.periodicity) for part in torch.split(y, self.splits, dim=1)]   # :1499-1541
+
+    def kernels(self):
+        return self.params[0::2]
+
+
+def adc_loss(model: ADCOracle, angles, dihedrals, cartesians, distances, side, step: int):
+    """ADCFunctionalModel.get_loss (models.py:2260-2460); returns (total, dict of terms)."""
+    p = model.p
+    per = model.periodicity
+    enc_in = ([angles] if model.use_ang else []) + [dihedrals] + ([side] if model.use_side else [])
+    latent = model.encoder(enc_in)
+    outs = model.decoder(latent)
+    if model.use_ang:
+        out_angles, out_dihedrals = outs[0], outs[1]
+        out_side = outs[2] if model.use_side else None
+    else:
+        out_angles, out_dihedrals, out_side = mean_angles_layer(angles), outs[0], None
+    back = backmap_layer(out_angles, out_dihedrals, distances)
+    sl = (p.get("cartesian_pwd_start"), p.get("cartesian_pwd_stop"), p.get("cartesian_pwd_step"))
+    inp_pair = pairwise_distances_layer(cartesians, *sl)
+    out_pair = pairwise_distances_layer(back, *sl)
+    terms = {
+        "dihedral": angle_like_cost(dihedrals, out_dihedrals, per, p.get("dihedral_cost_variant", "mean_abs"),
+                                    p.get("dihedral_cost_reference", 1), p.get("dihedral_cost_scale", 1)),
+        "angle": angle_like_cost(angles, out_angles, per, p.get("angle_cost_variant", "mean_abs"),
+                                 p.get("angle_cost_reference", 1), p.get("angle_cost_scale", 0)),
+        "cartesian": cartesian_cost(inp_pair, out_pair, p.get("cartesian_cost_variant", "mean_abs"), p.get("cartesian_cost_reference", 1),
+                                    soft_start_scale(step, p.get("cartesian_cost_scale_soft_start", (None, None)), p.get("cartesian_cost_scale", 1))),
+        "distance": distance_cost(torch.cat(enc_in[:3], dim=1) if len(enc_in) > 1 else dihedrals, latent, per,
+                                  p.get("dist_sig_parameters", (4.5, 12, 6, 1, 2, 6)), p.get("distance_cost_scale")),
+        "cartesian_distance": (sigmoid_loss(inp_pair, latent, float("inf"), p.get("cartesian_dist_sig_parameters", (4.5, 12, 6, 1, 2, 6)))
+                               * p["cartesian_distance_cost_scale"]) if p.get("cartesian_distance_cost_scale", 1) is not None else latent.new_zeros(()),
+        "center": center_cost(latent, p.get("center_cost_scale", 1e-4)),
+        "reg": regularization_cost(model.kernels(), p.get("l2_reg_constant", 0.001)),
+        "side_dihedral": angle_like_cost(side, out_side, per, p.get("side_dihedral_cost_variant", "mean_abs"),
+                                         p.get("side_dihedral_cost_reference", 1), p.get("side_dihedral_cost_scale", 0.5))
+        if model.use_side else latent.new_zeros(()),
+    }
+    return sum(terms.values()), terms
+
+
+def adc_train_steps(model: ADCOracle, data: dict, batch_indices, start_step: int = 0):
+    """Oracle ADC training loop with injected weights and batch indices (Adam with clipvalue 1 as autoencoder.py:1664-1666)."""
+    opt = KerasAdam(model.params, learning_rate=model.p.get("learning_rate", 1e-3), clipvalue=1.0)
+    t = {k: torch.tensor(np.asarray(v), dtype=model.dtype) for k, v in data.items()}
+    losses, terms_all = [], []
+    for n, idx in enumerate(batch_indices):
+        ii = torch.as_tensor(np.asarray(idx), dtype=torch.long)
+        total, terms = adc_loss(model, t["central_angles"][ii], t["central_dihedrals"][ii], t["central_cartesians"][ii],
+                                t["central_distances"][ii], t["side_dihedrals"][ii] if "side_dihedrals" in t else None, start_step + n)
+        grads = torch.autograd.grad(total, model.params)
+        opt.apply_gradients(model.params, grads)
+        losses.append(float(total.detach()))
+        terms_all.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in terms.items()})
+    return losses, terms_all
+
+
+def synthetic_backbone(rng: np.random.Generator, n_frames: int, n_residues: int, n_side: int = 0) -> dict:
+    """Synthetic protein-like backbone: dihedrals around two basins, angles N(2.0, 0.05),
+    bond lengths N(1.4, 0.02) (arbitrary length unit); central_cartesians are built with THIS file's
+    chain_in_plane + dihedrals_to_cartesian so that the inputs are self-consistent."""
+    A = 3 * n_residues
+    basin = rng.integers(0, 2, (n_frames, 1))
+    centers = np.where(basin == 0, -1.0, 2.4)
+    dih = centers + rng.normal(0, 0.35, (n_frames, A - 3))
+    dih = (dih + PI) % (2 * PI) - PI
+    ang = rng.normal(2.0, 0.05, (n_frames, A - 2))
+    length = rng.normal(1.4, 0.02, (n_frames, A - 1))
+    plane = chain_in_plane(torch.tensor(length), torch.tensor(ang))
+    xyz = dihedrals_to_cartesian(torch.tensor(dih) + PI, plane).numpy()
+    out = {"central_angles": ang.astype(np.float32), "central_dihedrals": dih.astype(np.float32),
+           "central_cartesians": xyz.astype(np.float32), "central_distances": length.astype(np.float32)}
+    if n_side:
+        out["side_dihedrals"] = rng.uniform(-PI, PI, (n_frames, n_side)).astype(np.float32)
+    return out

