@@ -46,7 +46,9 @@ SIGNATURES = {
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
-    "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p]),
+    "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p]),
+    "emx_mlp_wgrad_slices": (_i, [_i]),
+    "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
     "emx_chain_in_plane_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
     "emx_chain_in_plane_bwd": (_i, [_p, _p, _i, _p, _i, _i, _p, _i, _p]),
@@ -56,7 +58,7 @@ SIGNATURES = {
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
-    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }
@@ -228,10 +230,23 @@ def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, w
            "emx_adam_step")
 
 
-def step_tick(terms, n_terms, history, term_history, step, cursor=None):
+def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
+              term_history, hstep, cursor, ws):
+    n = w.numel()
+    _check(load().emx_adam_tick(_ptr(w), _ptr(g), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
+                                float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(opt_step),
+                                _ptr(terms), int(n_terms), int(reg_slot), _ptr(history), _ptr(term_history), history.numel(),
+                                _ptr(hstep), _ptr(cursor), _ptr(ws), _stream()), "emx_adam_tick")
+
+
+def mlp_wgrad_slices(n_rows):
+    return int(load().emx_mlp_wgrad_slices(int(n_rows)))
+
+
+def step_tick(terms, n_terms, history, term_history, step, cursor=None, counter2=None):
     cap = history.numel() if history is not None else (term_history.shape[0] if term_history is not None else 0)
-    _check(load().emx_step_tick(_ptr(terms), n_terms, _ptr(history), _ptr(term_history), cap, _ptr(step), _ptr(cursor), _stream()),
-           "emx_step_tick")
+    _check(load().emx_step_tick(_ptr(terms), n_terms, _ptr(history), _ptr(term_history), cap, _ptr(step), _ptr(cursor), _ptr(counter2),
+                                _stream()), "emx_step_tick")
 
 
 def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
@@ -239,9 +254,10 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
                                   plan.h, _stream()), "emx_mlp_forward")
 
 
-def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end):
+def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None):
     _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
-                                   int(layer_add), int(row_begin), int(row_end), plan.h, plan.delta, _stream()), "emx_mlp_backward")
+                                   int(layer_add), _ptr(dbelow), int(row_begin), int(row_end), plan.h, plan.delta, _stream()),
+           "emx_mlp_backward")
 
 
 def mlp_wgrad_ws_floats(n_params, n_rows):
@@ -249,6 +265,7 @@ def mlp_wgrad_ws_floats(n_params, n_rows):
 
 
 def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws):
+    """grad=None leaves the per-slice partials in ws (consumed by adam_tick)."""
     _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, _ptr(xin), xin.stride(0),
                                 int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(), _stream()),
            "emx_mlp_wgrad")

@@ -38,6 +38,7 @@ def _round4(n: int) -> int:
 
 class ADCEngine(SequentialEngine):
     TERM_NAMES = ADC_TERM_NAMES
+    _reg_slot = T_REG
 
     def __init__(self, n_atoms: int, n_side: int, p, *, device: str = "cuda:0", weights: Optional[Sequence[np.ndarray]] = None,
                  dp: Optional[DataParallel] = None, use_graph: bool = True, history_capacity: Optional[int] = None):
@@ -92,6 +93,7 @@ class ADCEngine(SequentialEngine):
         self.delta = [z(B, l.n_out) for l in lay.layers]
         self.dY = z(B, self.net_dim)
         self.dZ, self.dZ2 = z(B, self.L), z(B, self.L)
+        self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.ang_pred = z(B, self.n_ang) if self.use_ang else z(1, self.n_ang)
         self.dih_pred = z(B, self.n_dih)
         self.mean_len = z(self.n_len)
@@ -102,7 +104,7 @@ class ADCEngine(SequentialEngine):
         self.cart_scale = z(1)
         dmax = max(self.ldp, self.F)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
-        self.red_ws = torch.empty(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
 
@@ -214,14 +216,7 @@ class ADCEngine(SequentialEngine):
         else:
             t[T_DIST].zero_()
         _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
-        _lib.mlp_wgrad(self.plan, 0, n, self.xin, 0, B, self.g, self.wg_ws)
-
-    def _step_post(self) -> None:
-        p = self.p
-        _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
-                       self.terms[T_REG:T_REG + 1], self.red_ws)
-        _lib.step_tick(self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor)
-        self.step.add_(1)
+        self._wgrad()
 
     # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
     @torch.no_grad()

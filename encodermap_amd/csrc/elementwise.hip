@@ -81,6 +81,7 @@ struct CostArgs {
   const float* coef_scale;
   float* dY;
   float* ws;
+  float* loss;
   int ldy, ldt, off_sin, off_cos, periodic_output;
   int n, row_begin, row_end, variant, wrap;
   float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
@@ -208,6 +209,9 @@ __global__ __launch_bounds__(NT) void center_cost_kernel(const float* __restrict
 struct AdamArgs {
   float* w;
   const float* g;
+  const float* gpart;   // optional: gradient = sum over n_slices slices of gpart[s * gstride + i] (fixed order)
+  long gstride;
+  int n_slices;
   float* m;
   float* v;
   const float* l2coef;
@@ -227,6 +231,28 @@ __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, 
   w = w - alpha * m / (sqrtf(v) + a.eps);
 }
 
+__device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
+  if (!a.gpart) return reinterpret_cast<const float4*>(a.g)[i4];
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;   // 4 loads in flight, fixed association
+  int s = 0;
+  for (; s + 4 <= a.n_slices; s += 4) {
+    const float4 q0 = reinterpret_cast<const float4*>(a.gpart + (long)s * a.gstride)[i4];
+    const float4 q1 = reinterpret_cast<const float4*>(a.gpart + (long)(s + 1) * a.gstride)[i4];
+    const float4 q2 = reinterpret_cast<const float4*>(a.gpart + (long)(s + 2) * a.gstride)[i4];
+    const float4 q3 = reinterpret_cast<const float4*>(a.gpart + (long)(s + 3) * a.gstride)[i4];
+    p0.x += q0.x; p0.y += q0.y; p0.z += q0.z; p0.w += q0.w;
+    p1.x += q1.x; p1.y += q1.y; p1.z += q1.z; p1.w += q1.w;
+    p2.x += q2.x; p2.y += q2.y; p2.z += q2.z; p2.w += q2.w;
+    p3.x += q3.x; p3.y += q3.y; p3.z += q3.z; p3.w += q3.w;
+  }
+  for (; s < a.n_slices; ++s) {
+    const float4 q0 = reinterpret_cast<const float4*>(a.gpart + (long)s * a.gstride)[i4];
+    p0.x += q0.x; p0.y += q0.y; p0.z += q0.z; p0.w += q0.w;
+  }
+  return make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z),
+                     (p0.w + p1.w) + (p2.w + p3.w));
+}
+
 __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   __shared__ float red[8];
   const float t = (float)(*a.step + 1);
@@ -235,12 +261,13 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   float reg = 0.f;
   const long n4 = a.n >> 2;
   const bool vec = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.m) |
-                     reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef)) & 15) == 0;
+                     reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef) | reinterpret_cast<uintptr_t>(a.gpart) |
+                     (uintptr_t)(a.gstride * 4)) & 15) == 0;
   long start = 0;
   if (vec) {
     for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
       float4 w = reinterpret_cast<float4*>(a.w)[i];
-      float4 g = reinterpret_cast<const float4*>(a.g)[i];
+      float4 g = grad4(a, i);
       float4 m = reinterpret_cast<float4*>(a.m)[i];
       float4 v = reinterpret_cast<float4*>(a.v)[i];
       float4 l = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -256,7 +283,14 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   }
   for (long i = start + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += (long)gridDim.x * NT) {
     float w = a.w[i], m = a.m[i], v = a.v[i];
-    adam_one(w, a.g[i], m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha, reg);
+    float g;
+    if (a.gpart) {
+      g = 0.f;
+      for (int s = 0; s < a.n_slices; ++s) g += a.gpart[(long)s * a.gstride + i];
+    } else {
+      g = a.g[i];
+    }
+    adam_one(w, g, m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha, reg);
     a.w[i] = w;
     a.m[i] = m;
     a.v[i] = v;
@@ -267,7 +301,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
 
 __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
                                  float* __restrict__ term_history, long capacity, int64_t* __restrict__ step,
-                                 int64_t* __restrict__ cursor) {
+                                 int64_t* __restrict__ cursor, int64_t* __restrict__ counter2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long s = *step;
   float tot = 0.f;
@@ -279,6 +313,7 @@ __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, f
   }
   *step = s + 1;
   if (cursor) *cursor += 1;
+  if (counter2) *counter2 += 1;
 }
 
 inline int grid_for(long work_items, int per_block) {
@@ -344,6 +379,7 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   a.target = target;
   a.dpred_add = dpred_add;
   a.coef_scale = coef_scale;
+  a.loss = loss;
   a.dY = dY;
   a.ws = ws;
   a.ldy = ldy;
@@ -379,13 +415,15 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
   return emx::check_launch("center_cost_kernel");
 }
 
-int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float clip, const int64_t* step, float* reg_loss, float* ws, emx_stream_t stream) {
-  EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
-  EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
+namespace {
+AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
+                   int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws) {
   AdamArgs a;
   a.w = w;
   a.g = g;
+  a.gpart = gpart;
+  a.gstride = gstride;
+  a.n_slices = n_slices;
   a.m = m;
   a.v = v;
   a.l2coef = l2coef;
@@ -397,6 +435,15 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   a.b2 = beta2;
   a.eps = eps;
   a.clip = clip;
+  return a;
+}
+}  // namespace
+
+int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float clip, const int64_t* step, float* reg_loss, float* ws, emx_stream_t stream) {
+  EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
+  EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
+  const AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws);
   const int grid = grid_for((n + 3) / 4, NT);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
@@ -409,11 +456,35 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   return rc;
 }
 
+int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
+                  const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
+                  float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
+                  int64_t* cursor, float* ws, emx_stream_t stream) {
+  EMX_REQUIRE(w && m && v && opt_step && terms && hstep && ws, "emx_adam_tick: null pointer argument");
+  EMX_REQUIRE((g != nullptr) != (g_partials != nullptr), "emx_adam_tick: pass either the gradient or its slice partials");
+  EMX_REQUIRE(!g_partials || (n_slices > 0 && partial_stride >= n), "emx_adam_tick: bad slice layout");
+  EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && reg_slot >= 0 && reg_slot < n_terms, "emx_adam_tick: bad sizes");
+  const AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws);
+  // Three plain launches on the stream.  (An in-kernel hand-off -- last workgroup finishes -- was measured slower: its
+  // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
+  const int grid = grid_for((n + 3) / 4, NT);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
+  int rc = emx::check_launch("adam_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, (const float*)nullptr, terms + reg_slot);
+  rc = emx::check_launch("final_sum_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, st, terms, n_terms, history, term_history, (long)capacity, hstep, cursor,
+                     opt_step);
+  return emx::check_launch("step_tick_kernel");
+}
+
 int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity, int64_t* step,
-                  int64_t* cursor, emx_stream_t stream) {
+                  int64_t* cursor, int64_t* counter2, emx_stream_t stream) {
   EMX_REQUIRE(terms && step && n_terms > 0 && n_terms <= 64, "emx_step_tick: bad arguments");
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, terms, n_terms, history, term_history, (long)capacity,
-                     step, cursor);
+                     step, cursor, counter2);
   return emx::check_launch("step_tick_kernel");
 }
 

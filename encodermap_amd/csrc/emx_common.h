@@ -57,4 +57,5 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= NT/64 floa
   return r;
 }
 
+
 }  // namespace emx

@@ -7,7 +7,7 @@
 //
 //   mlp_forward_kernel   one workgroup = 16 batch rows pushed through a RANGE of layers; the activations of the
 //                        row block ping-pong between two LDS images, every layer's output is also stored to HBM
-//                        for the backward pass.  Each wave owns 32 output columns (two 16x16 MFMA tiles);
+//                        for the backward pass.  Eight waves (two per SIMD) own one 16-column MFMA tile each;
 //                        v_mfma_f32_16x16x4_f32 (bitwise an fmaf chain, MI355X_MICROARCH.md) with A fragments read
 //                        from LDS as one ds_read_b128 per four MFMAs and B fragments streamed from the L2-resident
 //                        weights (64-B coalesced row segments), software-pipelined one K-step ahead.
@@ -27,7 +27,8 @@ namespace {
 using namespace emx;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int NT = 256;
+constexpr int NT = 256;           // weight-gradient kernels
+constexpr int NTC = 512;          // row-block chain kernels: 8 waves, two per SIMD, one 16-column MFMA tile each
 constexpr int R = 16;            // batch rows per workgroup
 constexpr int MAXL = EMX_MAX_LAYERS;
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ float tanh_f32(float x) {
   return ax < 0.25f ? p : copysignf(t, x);
 }
 
-constexpr int UQ = 4;   // K-steps (16 k each) per pipeline unit: 32 B-fragment registers in flight per unit
+constexpr int UQ = 8;   // K-steps (16 k each) per pipeline unit: 32 B-fragment registers in flight per unit
 
 // One pipeline unit = (layer, 32-column pass of this wave, chunk of UQ K-steps).  Units are walked in order across
 // layer boundaries so that the B fragments (weights, independent of the activations) of the NEXT unit are always in
@@ -82,7 +83,7 @@ __device__ __forceinline__ int unit_kq(const MlpDev& d, int l) {     // K-steps 
 // forward walks layers upward, backward walks them downward (and skips the data GEMM of layer lo)
 template <bool BWD>
 __device__ __forceinline__ Unit first_unit(const MlpDev& d, int l, int lo, int hi, int wave) {
-  Unit u{l, wave * 32, 0, false};
+  Unit u{l, wave * 16, 0, false};
   while (BWD ? (u.l > lo) : (u.l < hi)) {
     if (u.n0 < unit_cols<BWD>(d, u.l)) {
       u.valid = true;
@@ -102,10 +103,10 @@ __device__ __forceinline__ Unit next_unit(const MlpDev& d, Unit u, int lo, int h
 
 // B fragments of a forward unit: W[k][n], k = 16(UQ c + q) + 4g + i, n = n0 + 16t + m.  Uniform row base + per-lane
 // offset (-> global_load with an SGPR base); rows are clamped only in the ragged last chunk.
-__device__ __forceinline__ void load_unit_fwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][2][4]) {
+__device__ __forceinline__ void load_unit_fwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][4]) {
   const int K = d.width[u.l], N = d.width[u.l + 1];
   const float* __restrict__ W = d.W[u.l];
-  const int off0 = 4 * g * N + min(u.n0 + m, N - 1), off1 = 4 * g * N + min(u.n0 + 16 + m, N - 1);
+  const int off0 = 4 * g * N + min(u.n0 + m, N - 1);
   const int k0 = 16 * UQ * u.c;
   if (k0 + 16 * UQ <= K) {
 #pragma unroll
@@ -113,40 +114,35 @@ __device__ __forceinline__ void load_unit_fwd(const MlpDev& d, const Unit u, int
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* rb = W + (long)(k0 + 16 * q + i) * N;   // wave-uniform
-        b[q][0][i] = rb[off0];
-        b[q][1][i] = rb[off1];
+        b[q][i] = rb[off0];
       }
   } else {
-    const int c0 = min(u.n0 + m, N - 1), c1 = min(u.n0 + 16 + m, N - 1);
+    const int c0 = min(u.n0 + m, N - 1);
 #pragma unroll
     for (int q = 0; q < UQ; ++q)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const float* rb = W + (long)min(k0 + 16 * q + 4 * g + i, K - 1) * N;   // clamped: the A side is zero there
-        b[q][0][i] = rb[c0];
-        b[q][1][i] = rb[c1];
+        b[q][i] = rb[c0];
       }
   }
 }
 
 // B fragments of a backward-data unit: 16-byte pieces of W rows: W[j][k..k+3], j = n0 + 16t + m (input feature),
 // k = 16(UQ c + q) + 4g (output feature)
-__device__ __forceinline__ void load_unit_bwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][2][4]) {
+__device__ __forceinline__ void load_unit_bwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][4]) {
   const int Kin = d.width[u.l], N = d.width[u.l + 1];
   const float* __restrict__ W = d.W[u.l];
   const float* p0 = W + (long)min(u.n0 + m, Kin - 1) * N;
-  const float* p1 = W + (long)min(u.n0 + 16 + m, Kin - 1) * N;
   const int k0 = 16 * UQ * u.c + 4 * g;
   if ((N & 3) == 0) {   // wave-uniform
 #pragma unroll
     for (int q = 0; q < UQ; ++q) {
       const int kk = min(k0 + 16 * q, N - 4);
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(p0 + kk);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(p1 + kk);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        b[q][0][i] = w0[i];
-        b[q][1][i] = w1[i];
+        b[q][i] = w0[i];
       }
     }
   } else {
@@ -155,14 +151,12 @@ __device__ __forceinline__ void load_unit_bwd(const MlpDev& d, const Unit u, int
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int kk = min(k0 + 16 * q + i, N - 1);
-        b[q][0][i] = p0[kk];
-        b[q][1][i] = p1[kk];
+        b[q][i] = p0[kk];
       }
   }
 }
 
-__device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int g, int c, int Kq, const float (&b)[UQ][2][4],
-                                         f32x4& acc0, f32x4& acc1) {
+__device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int g, int c, int Kq, const float (&b)[UQ][4], f32x4& acc0) {
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
     const int kq = UQ * c + q;
@@ -170,8 +164,7 @@ __device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int
       const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * kq + 4 * g]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][0][i], acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][1][i], acc1, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][i], acc0, 0, 0, 0);
       }
     }
   }
@@ -180,7 +173,7 @@ __device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int
 // ---------------------------------------------------------------------------------------------------------
 // forward: layers [l0, l1) on rows [row0, row_end); `in` is [*, width[l0]] with row stride ld_in
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ in, int ld_in,
+__global__ __launch_bounds__(NTC) void mlp_forward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ in, int ld_in,
                                                          int row0, int row_end, int pitch) {
   extern __shared__ __align__(16) float lds[];
   // (LDS images are addressed as lds + offset everywhere: a pointer array would decay to generic pointers and
@@ -189,14 +182,14 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
   const int m = lane & 15, g = lane >> 4;
   const int r0 = row0 + blockIdx.x * R;
 
-  float bcur[UQ][2][4], bnxt[UQ][2][4];
+  float bcur[UQ][4], bnxt[UQ][4];
   Unit cur = first_unit<false>(d, l0, l0, l1, wave);
   if (cur.valid) load_unit_fwd(d, cur, m, g, bcur);
 
   // stage the input rows (zero padded to the pitch, rows beyond the block zero)
   {
     const int K = d.width[l0];
-    for (int e = tid; e < R * pitch; e += NT) {
+    for (int e = tid; e < R * pitch; e += NTC) {
       int r = e / pitch, c = e - r * pitch;
       float v = 0.f;
       if (c < K && r0 + r < row_end) v = in[(long)(r0 + r) * ld_in + c];
@@ -206,7 +199,7 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
   __syncthreads();
 
   int buf = 0;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
   for (int l = l0; l < l1; ++l) {
     const int N = d.width[l + 1];
     const int Kq = (d.width[l] + 15) >> 4;
@@ -216,35 +209,31 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
     while (cur.valid && cur.l == l) {
       const Unit nxt = next_unit<false>(d, cur, l0, l1, wave);
       if (nxt.valid) load_unit_fwd(d, nxt, m, g, bnxt);
-      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0, acc1);
+      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0);
       if (cur.c == nch - 1) {
         // epilogue: bias, activation, to LDS (next layer's input, zero beyond N) and to HBM
         const float* __restrict__ bias = d.b[l];
         float* hout = d.h[l];
         const bool act = d.act[l] != 0;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = cur.n0 + 16 * t + m;
+        {
+          const int col = cur.n0 + m;
           const float bv = bias[min(col, N - 1)];
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int row = 4 * g + reg;
-            float v = (t == 0 ? acc0[reg] : acc1[reg]) + bv;
+            float v = acc0[reg] + bv;
             if (act) v = tanh_f32(v);
             v = col < N ? v : 0.f;
-            dst[row * pitch + col] = v;   // col < round32(N) <= pitch - 4
+            dst[row * pitch + col] = v;   // col < round16(N) <= pitch - 4
             if (col < N && r0 + row < row_end) hout[(long)(r0 + row) * N + col] = v;
           }
         }
         acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int q = 0; q < UQ; ++q)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bcur[q][t][i] = bnxt[q][t][i];
+        for (int i = 0; i < 4; ++i) bcur[q][i] = bnxt[q][i];
       cur = nxt;
     }
     __syncthreads();
@@ -257,22 +246,23 @@ __global__ __launch_bounds__(NT) void mlp_forward_kernel(const MlpDev d, int l0,
 // `dtop` [*, width[l1]] (row stride ld_top) is d loss / d h_{l1-1}; `dadd` (may be null) [*, width[ladd+1]] is
 // added to dh_ladd before its activation derivative (the latent gradient of the distance/center costs).
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ dtop, int ld_top,
-                                                          const float* __restrict__ dadd, int ladd, int row0, int row_end,
-                                                          int pitch) {
+__global__ __launch_bounds__(NTC) void mlp_backward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ dtop, int ld_top,
+                                                          const float* __restrict__ dadd, int ladd, float* __restrict__ dbelow,
+                                                          int row0, int row_end, int pitch) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   const int r0 = row0 + blockIdx.x * R;
 
-  float bcur[UQ][2][4], bnxt[UQ][2][4];
-  Unit cur = first_unit<true>(d, l1 - 1, l0, l1, wave);
+  float bcur[UQ][4], bnxt[UQ][4];
+  const int lo = dbelow ? l0 - 1 : l0;   // with `dbelow` the data GEMM of layer l0 runs too (dh below the range is stored)
+  Unit cur = first_unit<true>(d, l1 - 1, lo, l1, wave);
   if (cur.valid) load_unit_bwd(d, cur, m, g, bcur);
 
   // dh of the top layer -> LDS
   {
     const int N = d.width[l1];
-    for (int e = tid; e < R * pitch; e += NT) {
+    for (int e = tid; e < R * pitch; e += NTC) {
       int r = e / pitch, c = e - r * pitch;
       float v = 0.f;
       if (c < N && r0 + r < row_end) v = dtop[(long)(r0 + r) * ld_top + c];
@@ -282,7 +272,7 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
   __syncthreads();
 
   int buf = 0;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
   for (int l = l1 - 1; l >= l0; --l) {
     const int Kin = d.width[l], N = d.width[l + 1];  // layer maps Kin -> N
     float* dh = lds + buf * (R * pitch);
@@ -292,7 +282,7 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
       float* __restrict__ dl = d.delta[l];
       const bool act = d.act[l] != 0;
       const bool add = dadd != nullptr && l == ladd;
-      for (int e = tid; e < R * N; e += NT) {
+      for (int e = tid; e < R * N; e += NTC) {
         int r = e / N, c = e - r * N;
         float v = dh[r * pitch + c];
         const bool ok = r0 + r < row_end;
@@ -311,35 +301,32 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
       }
     }
     __syncthreads();
-    if (l == l0) break;  // no dh needed below the first layer of the range
+    if (l == l0 && !dbelow) break;  // no dh needed below the first layer of the range
     // dh_{l-1}[row][j] = sum_k delta[row][k] W[j][k]  (k over the N outputs, j over the Kin inputs)
     const int Kq = (N + 15) >> 4;
     const int nch = (Kq + UQ - 1) / UQ;
     const float* src = lds + buf * (R * pitch);
     float* dst = lds + (buf ^ 1) * (R * pitch);
     while (cur.valid && cur.l == l) {
-      const Unit nxt = next_unit<true>(d, cur, l0, l1, wave);
+      const Unit nxt = next_unit<true>(d, cur, lo, l1, wave);
       if (nxt.valid) load_unit_bwd(d, nxt, m, g, bnxt);
-      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0, acc1);
+      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0);
       if (cur.c == nch - 1) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          const int col = cur.n0 + 16 * t + m;
+        {
+          const int col = cur.n0 + m;
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const float v = t == 0 ? acc0[reg] : acc1[reg];
+            const float v = acc0[reg];
             dst[(4 * g + reg) * pitch + col] = col < Kin ? v : 0.f;
+            if (l == l0 && col < Kin && r0 + 4 * g + reg < row_end) dbelow[(long)(r0 + 4 * g + reg) * Kin + col] = v;
           }
         }
         acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-        acc1 = f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int q = 0; q < UQ; ++q)
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int i = 0; i < 4; ++i) bcur[q][t][i] = bnxt[q][t][i];
+        for (int i = 0; i < 4; ++i) bcur[q][i] = bnxt[q][i];
       cur = nxt;
     }
     __syncthreads();
@@ -349,8 +336,8 @@ __global__ __launch_bounds__(NT) void mlp_backward_kernel(const MlpDev d, int l0
 
 // ---------------------------------------------------------------------------------------------------------
 // weight gradients: partial[slice][l] (+)= X_l^T delta_l over the slice's rows, X_l = (l == lx0 ? x_in : h_{l-1}).
-// grid = (tiles of all layers) x n_slices; one workgroup = one 64x64 output block of one layer (each wave a
-// 32x32 quadrant = 2x2 MFMA tiles), rows [row0 + slice*rows_per_slice, ...).  db is produced by the blocks of
+// grid = (blocks of all layers) x n_slices; one workgroup = one 128x128 output block of one layer (each wave a
+// 64x64 quadrant = 4x4 MFMA tiles), rows [row0 + slice*rows_per_slice, ...).  db is produced by the blocks of
 // the first tile row.  Partials are stored densely per slice in the flat-parameter layout (w_off/b_off).
 // ---------------------------------------------------------------------------------------------------------
 struct WgradDev {
@@ -359,24 +346,27 @@ struct WgradDev {
   const float* xin;
   int ld_xin;
   long w_off[MAXL], b_off[MAXL];
-  int tile_begin[MAXL + 1];  // prefix sum of 64x64 output blocks per layer (relative to l0)
+  int tile_begin[MAXL + 1];  // prefix sum of 128x128 output blocks per layer (relative to l0)
   float* partial;            // [n_slices][n_params]
   long n_params;
   int row0, row_end, rows_per_slice;
 };
 
 __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
+  // One workgroup = one 128x128 block of one layer's dW over one row slice; each wave a 64x64 quadrant = 4x4 MFMA
+  // tiles.  The MFMA's m/n indices are free labels: lane slot m of tile u stands for feature 4m + u (n, v likewise), so
+  // ONE 16-byte load per operand and row feeds all four tiles of that operand (2 loads per 16 MFMAs), and the four
+  // tiles (u, v = 0..3) of a slot pair form a float4 of adjacent output columns for the store.
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
-  // which layer / block
   int l = a.l0;
   while (l + 1 < a.l1 && (int)blockIdx.x >= a.tile_begin[l + 1 - a.l0]) ++l;
   const int tb = blockIdx.x - a.tile_begin[l - a.l0];
   const int Kin = a.d.width[l], N = a.d.width[l + 1];
-  const int nbn = (N + 63) >> 6;
+  const int nbn = (N + 127) >> 7;
   const int bi = tb / nbn, bj = tb - bi * nbn;
-  const int i0 = bi * 64 + (wave >> 1) * 32;   // input-feature offset of this wave's quadrant
-  const int j0 = bj * 64 + (wave & 1) * 32;    // output-feature offset
+  const int i0 = bi * 128 + (wave >> 1) * 64;   // input-feature offset of this wave's quadrant
+  const int j0 = bj * 128 + (wave & 1) * 64;    // output-feature offset
   const float* __restrict__ X = (l == a.l0) ? a.xin : a.d.h[l - 1];
   const int ldx = (l == a.l0) ? a.ld_xin : Kin;
   const float* __restrict__ Dl = a.d.delta[l];
@@ -384,72 +374,97 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
   const int re = min(rs + a.rows_per_slice, a.row_end);
   float* __restrict__ out = a.partial + (long)blockIdx.y * a.n_params;
 
-  f32x4 acc[2][2];
+  f32x4 acc[4][4];
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+  for (int u = 0; u < 4; ++u)
 #pragma unroll
-    for (int v = 0; v < 2; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum[2] = {0.f, 0.f};
+    for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
   const bool do_bias = (bi == 0) && ((wave >> 1) == 0);
+  const bool quad_active = i0 < Kin && j0 < N;   // wave-uniform
 
-  // K loop over rows: step = 16 rows (lane group g supplies rows 4g..4g+3 of the step).  Columns beyond the tensor
-  // are clamped (their outputs are discarded); only the ragged last step masks rows, on the delta side.
-  constexpr int US = 4;   // K-steps (16 rows each) whose loads are in flight together
-  for (int r = rs; r < re; r += 16 * US) {
-    float xa[US][2][4], db[US][2][4];
+  // 16-byte operand loads need 4 | width and an aligned row stride; otherwise four clamped scalar loads
+  const bool vx = ((ldx & 3) == 0) && ((Kin & 3) == 0), vd = (N & 3) == 0;
+  const int cx = i0 + 4 * m, cd = j0 + 4 * m;
+  auto ldrow = [&](const float* __restrict__ base, int ld, int width, int col, bool vec, int row) -> f32x4 {
+    const float* p = base + (long)row * ld;
+    f32x4 v;
+    if (vec) {
+      v = *reinterpret_cast<const f32x4*>(p + min(col, width - 4));   // clamped: out-of-range slots are discarded at the store
+    } else {
 #pragma unroll
-    for (int s = 0; s < US; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int rr = min(r + 16 * s + 4 * g + i, re - 1);
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          xa[s][u][i] = X[(long)rr * ldx + min(i0 + 16 * u + m, Kin - 1)];
-          db[s][u][i] = Dl[(long)rr * N + min(j0 + 16 * u + m, N - 1)];
-        }
-      }
-    if (r + 16 * US > re) {   // ragged tail (wave-uniform): rows beyond the slice contribute nothing
-#pragma unroll
-      for (int s = 0; s < US; ++s)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float ok = (r + 16 * s + 4 * g + i < re) ? 1.f : 0.f;
-          db[s][0][i] *= ok;
-          db[s][1][i] *= ok;
-        }
+      for (int i = 0; i < 4; ++i) v[i] = p[min(col + i, width - 1)];
     }
+    return v;
+  };
+  constexpr int US = 4;   // 4-row steps per batch; the next batch's loads are issued before this batch's 64 MFMAs
+  if (quad_active) {
+    f32x4 xa[US], db[US], xn[US], dn[US];
+    auto load_batch = [&](int r, f32x4 (&xo)[US], f32x4 (&dout)[US]) {
 #pragma unroll
-    for (int s = 0; s < US; ++s)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-#pragma unroll
-          for (int v = 0; v < 2; ++v)
-            acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s][u][i], db[s][v][i], acc[u][v], 0, 0, 0);
-        bsum[0] += db[s][0][i];
-        bsum[1] += db[s][1][i];
+      for (int s2 = 0; s2 < US; ++s2) {
+        const int row = min(r + 4 * s2 + g, re - 1);
+        xo[s2] = ldrow(X, ldx, Kin, cx, vx, row);
+        dout[s2] = ldrow(Dl, N, N, cd, vd, row);
       }
-  }
-  // store the quadrant: D[row = 4g + reg][col = m] of tile (u, v) -> dW[i0 + 16u + row][j0 + 16v + col]
+    };
+    load_batch(rs, xn, dn);
+    for (int r = rs; r < re; r += 4 * US) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u)
+      for (int s2 = 0; s2 < US; ++s2) {
+        xa[s2] = xn[s2];
+        db[s2] = dn[s2];
+      }
+      if (r + 4 * US < re) load_batch(r + 4 * US, xn, dn);
+      if (r + 4 * US > re) {   // ragged tail (wave-uniform): rows beyond the slice contribute nothing
 #pragma unroll
-    for (int v = 0; v < 2; ++v)
+        for (int s2 = 0; s2 < US; ++s2) {
+          const float ok = (r + 4 * s2 + g < re) ? 1.f : 0.f;
+          db[s2] *= ok;
+        }
+      }
+#pragma unroll
+      for (int s2 = 0; s2 < US; ++s2) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s2][u], db[s2][v], acc[u][v], 0, 0, 0);
+        bsum += db[s2];
+      }
+    }
+    // store: tile (u, v), D[row slot 4g + reg][col slot m] -> dW[i0 + 4(4g + reg) + u][j0 + 4m + v]
+    const bool vst = (N & 3) == 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int ii = i0 + 16 * u + 4 * g + reg, jj = j0 + 16 * v + m;
-        if (ii < Kin && jj < N) out[a.w_off[l] + (long)ii * N + jj] = acc[u][v][reg];
-      }
-  if (do_bias) {
-    // column sums: add the 4 lane groups (rows) of each column
+        const int ii = i0 + 4 * (4 * g + reg) + u, jj = j0 + 4 * m;
+        if (ii < Kin && jj < N) {
+          float* q = out + a.w_off[l] + (long)ii * N + jj;
+          if (vst && ((a.w_off[l] & 3) == 0)) {
+            *reinterpret_cast<f32x4*>(q) = f32x4{acc[u][0][reg], acc[u][1][reg], acc[u][2][reg], acc[u][3][reg]};
+          } else {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      float s = bsum[u];
-      s += __shfl_xor(s, 16, 64);
-      s += __shfl_xor(s, 32, 64);
-      const int jj = j0 + 16 * u + m;
-      if (g == 0 && jj < N) out[a.b_off[l] + jj] = s;
+            for (int v = 0; v < 4; ++v)
+              if (jj + v < N) q[v] = acc[u][v][reg];
+          }
+        }
+      }
+  }
+  if (do_bias && j0 < N) {
+    // column sums: lane (m, g) holds the sums of columns j0 + 4m .. + 3 over the rows of its lane group
+    f32x4 sfull = bsum;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      float t = sfull[v];
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      sfull[v] = t;
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (cd + v < N) out[a.b_off[l] + cd + v] = sfull[v];
     }
   }
 }
@@ -490,7 +505,7 @@ int fill_dev(const emx_mlp_desc* desc, float* params, float* const* h, float* co
 int pitch_for(const emx_mlp_desc* desc, int l0, int l1) {
   int w = 0;
   for (int l = l0; l <= l1; ++l) w = std::max(w, desc->width[l]);
-  return ((w + 31) / 32) * 32 + 4;   // tiles write up to the next multiple of 32; +4 keeps b128 rows conflict-free
+  return ((w + 15) / 16) * 16 + 4;   // tiles write up to the next multiple of 16; +4 keeps b128 rows conflict-free
 }
 
 int set_lds(const void* fn, size_t bytes, const char* who) {
@@ -520,14 +535,14 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, in
   rc = set_lds(reinterpret_cast<const void*>(&mlp_forward_kernel), lds, "emx_mlp_forward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, d, layer_begin, layer_end, in, ld_in, row_begin,
+  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, d, layer_begin, layer_end, in, ld_in, row_begin,
                      row_end, pitch);
   return emx::check_launch("mlp_forward_kernel");
 }
 
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, int row_begin, int row_end, float* const* h, float* const* delta,
-                     emx_stream_t stream) {
+                     const float* dadd, int layer_add, float* dbelow, int row_begin, int row_end, float* const* h,
+                     float* const* delta, emx_stream_t stream) {
   MlpDev d;
   int rc = fill_dev(desc, params, h, delta, d, "emx_mlp_backward");
   if (rc) return rc;
@@ -541,10 +556,12 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, i
   rc = set_lds(reinterpret_cast<const void*>(&mlp_backward_kernel), lds, "emx_mlp_backward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid), dim3(NT), lds, (hipStream_t)stream, d, layer_begin, layer_end, dtop, ld_top, dadd,
-                     layer_add, row_begin, row_end, pitch);
+  hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, d, layer_begin, layer_end, dtop, ld_top, dadd,
+                     layer_add, dbelow, row_begin, row_end, pitch);
   return emx::check_launch("mlp_backward_kernel");
 }
+
+int emx_mlp_wgrad_slices(int n_rows) { return std::max((n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS, 1); }
 
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows) {
   int slices = (n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
@@ -557,7 +574,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   WgradDev a;
   int rc = fill_dev(desc, params, h, delta, a.d, "emx_mlp_wgrad");
   if (rc) return rc;
-  EMX_REQUIRE(xin && h && delta && grad && ws, "emx_mlp_wgrad: null pointer argument");
+  EMX_REQUIRE(xin && h && delta && ws, "emx_mlp_wgrad: null pointer argument");
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_wgrad: bad layer range");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_xin >= desc->width[layer_begin], "emx_mlp_wgrad: bad rows / stride");
   const int nrows = row_end - row_begin;
@@ -574,7 +591,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
     a.w_off[l] = desc->w_off[l];
     a.b_off[l] = desc->b_off[l];
     a.tile_begin[l - layer_begin] = tiles;
-    tiles += ((desc->width[l] + 63) / 64) * ((desc->width[l + 1] + 63) / 64);
+    tiles += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
     const long wl = desc->w_off[l], wh = desc->b_off[l] + desc->width[l + 1];
     lo = (lo < 0) ? wl : std::min(lo, wl);
     hi = std::max(hi, wh);
@@ -590,6 +607,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles, slices), dim3(NT), 0, st, a);
   rc = emx::check_launch("mlp_wgrad_kernel");
   if (rc) return rc;
+  if (!grad) return EMX_OK;   // the caller sums the slices itself (emx_adam_tick)
   const long n = hi - lo;
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, st, ws, (long)n_params, slices, lo, hi, grad);
   return emx::check_launch("mlp_wgrad_reduce_kernel");

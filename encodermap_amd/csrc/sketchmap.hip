@@ -343,18 +343,25 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int LT, bool FASTSIG>
-__global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_tile_mfma_kernel(const SkArgs a) {
+  // Resource budget: <= 64 VGPRs and <= 20 KB LDS per workgroup so that 8 tiles (8 waves per SIMD) are resident per
+  // CU: a tile alternates an MFMA phase (K loop) and a VALU phase (sigmoid epilogue), and only co-resident tiles in
+  // different phases keep both pipes busy (measured: 4 resident tiles leave MFMA at 30 % and VALU at 40 %).
   constexpr int T = 64;
   constexpr int LMAX = LT ? LT : 4;
-  constexpr int STAGE = 2 * T * LS + 2 * T;            // Xi, Xj images + the two norm vectors
-  constexpr int RP = 68;                               // padded row of 64 column-lane partials
-  constexpr int PART = T * LMAX * RP + T * LMAX * 2;   // row partials [row][l][RP] + column partials
-  constexpr int SMEM = (STAGE > PART ? STAGE : PART) + 8;
+  constexpr int RP = 36;                                // 32 pre-reduced column-lane partials per (row, l) + pad
+  constexpr int STAGE = 2 * T * LS;                     // Xi, Xj images
+  constexpr int PART = T * LMAX * RP;                   // row partials (reuse the staging area)
+  constexpr int MAIN = STAGE > PART ? STAGE : PART;
+  constexpr int SMEM = MAIN + 2 * T + T * LMAX + T * LMAX * 2 + 8;   // + norms + latent rows of the tile + column partials
   __shared__ __align__(16) float smem[SMEM];
   float* Xi_s = smem;
   float* Xj_s = smem + T * LS;
-  float* ni_s = smem + 2 * T * LS;
+  float* ni_s = smem + MAIN;
   float* nj_s = ni_s + T;
+  float* zi_s = nj_s + T;                               // [T][LMAX]
+  float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
+  float* red = cpart + T * LMAX * 2;
 
   const int L = LT ? LT : a.L;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -375,6 +382,13 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // latent rows of the tile's i side -> LDS (read back as broadcasts in the epilogue instead of living in registers)
+  for (int e = tid; e < T * LMAX; e += NT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const int ig = min(i0 + rl, a.B - 1);
+    zi_s[e] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
+  }
 
   // ---- K loop: stage (x - x_ref) chunks, accumulate row norms, MFMA ---------------------------------
   const int kq = tid & 7, rb = tid >> 3;
@@ -431,7 +445,7 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
       nj_s[rb + 32 * q] = t;
     }
   }
-  __syncthreads();
+  __syncthreads();   // norms visible; all MFMA operand reads done: the staging area becomes the row-partial area
 
   // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
   const int jl = wn * 32 + lr;
@@ -441,19 +455,8 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
   float zj[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) zj[l] = (jok && l < L) ? a.Z[(long)jg * L + l] : 0.f;
-  float ni[16], zi[16][LMAX];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-    ni[r] = ni_s[il];
-    const int ig = min(i0 + il, a.B - 1);
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) zi[r][l] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
-  }
-  __syncthreads();   // norms consumed: the staging LDS is reused for the partial sums below
 
-  float* rpart = smem;                      // [T][LMAX][RP]  (RP = 68: conflict-free 16-byte reads in the fold)
-  float* cpart = smem + T * LMAX * RP;      // [T][LMAX][2]
+  float* rpart = smem;   // [T][LMAX][RP]
   float gj[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
@@ -466,10 +469,10 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
     float dl2 = 0.f;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-      dz[l] = zi[r][l] - zj[l];
+      dz[l] = zi_s[il * LMAX + l] - zj[l];
       dl2 = fmaf(dz[l], dz[l], dl2);
     }
-    float d2 = fmaxf(fmaf(-2.f, acc[r], ni[r] + nj), 0.f);
+    float d2 = fmaxf(fmaf(-2.f, acc[r], ni_s[il] + nj), 0.f);
     if (masked) d2 = (i0 + il == jg) ? 0.f : d2;
     const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
     float El, G;
@@ -480,8 +483,10 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
     const float g = f * G;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-      rpart[(il * LMAX + l) * RP + jl] = g * dz[l];
-      gj[l] = fmaf(-g, dz[l], gj[l]);
+      float v = g * dz[l];
+      gj[l] -= v;
+      v += __shfl_xor(v, 1, 64);                       // neighbouring columns pre-reduced in registers
+      if ((lr & 1) == 0) rpart[(il * LMAX + l) * RP + (jl >> 1)] = v;
     }
   };
   if (edge) {
@@ -498,7 +503,6 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
       if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
     }
   }
-  float* red = smem + SMEM - 8;
   float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
   if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
 
@@ -508,7 +512,7 @@ __global__ __launch_bounds__(NT) void sk_tile_mfma_kernel(const SkArgs a) {
       const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
       float s = 0.f;
 #pragma unroll
-      for (int u = 0; u < 16; u += 4) {
+      for (int u = 0; u < 8; u += 4) {
         float4 s0 = p[u], s1 = p[u + 1], s2 = p[u + 2], s3 = p[u + 3];
         s += (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
              (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));

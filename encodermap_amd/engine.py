@@ -25,6 +25,7 @@ mini-batches are drawn by a device-side permutation stream and gathered by index
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -91,6 +92,7 @@ class SequentialEngine:
     """Weights, optimizer state, buffers and the captured step of Autoencoder / EncoderMap."""
 
     TERM_NAMES = TERM_NAMES
+    _reg_slot = T_REG
 
     def __init__(self, input_dim: int, p, *, with_distance: bool, device: str = "cuda:0",
                  weights: Optional[Sequence[np.ndarray]] = None, dp: Optional[DataParallel] = None,
@@ -136,6 +138,8 @@ class SequentialEngine:
         self.hstep = torch.zeros(1, dtype=torch.int64, device=dev)  # write position in history
 
         self.rb, self.re = self.dp.row_block(self.B)
+        self._side_stream = torch.cuda.Stream(device=self.device)
+        self._fork = os.environ.get("EMX_FORK_STREAMS", "1") != "0"   # fork/join of the two post-forward branches
         self._alloc_step_buffers(self.B)
         self._graph = None
         self.data = None
@@ -153,8 +157,10 @@ class SequentialEngine:
         self.delta = [torch.zeros(B, l.n_out, dtype=f32, device=dev) for l in lay.layers]
         self.dY = torch.zeros(B, self.net_dim, dtype=f32, device=dev)
         self.dZ = torch.zeros(B, self.L, dtype=f32, device=dev)
+        self.dlat = torch.zeros(B, self.L, dtype=f32, device=dev)   # dh at the latent coming down from the decoder
+        self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
-        self.red_ws = torch.empty(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
 
@@ -198,18 +204,21 @@ class SequentialEngine:
             _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
             _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
 
-    def _losses(self) -> None:
-        p, rb, re, B = self.p, self.rb, self.re, self.B
-        lay = self.layout
-        Z = self.h[lay.n_enc - 1]
-        Y = self.h[-1]
-        # auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY
+    def _auto_cost(self) -> None:
+        """auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY"""
+        p = self.p
         if p.auto_cost_scale is not None:
-            _lib.periodic_cost_fwd_bwd(Y, 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
-                                       float(p.auto_cost_scale), rb, re, self.terms[T_AUTO:T_AUTO + 1], self.dY, self.red_ws, B=B)
+            _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
+                                       float(p.auto_cost_scale), self.rb, self.re, self.terms[T_AUTO:T_AUTO + 1], self.dY, self.red_ws,
+                                       B=self.B)
         else:
             self.dY.zero_()
             self.terms[T_AUTO].zero_()
+
+    def _latent_costs(self) -> None:
+        """sketch-map distance cost with the center cost fused (or the center cost alone): gradient wrt the latent"""
+        p, rb, re = self.p, self.rb, self.re
+        Z = self.h[self.layout.n_enc - 1]
         cs = p.center_cost_scale
         if self.with_distance and p.distance_cost_scale is not None:
             _lib.sketchmap_fwd_bwd(self.xb, Z, self.periodicity, p.dist_sig_parameters, float(p.distance_cost_scale),
@@ -219,24 +228,43 @@ class SequentialEngine:
             self.terms[T_DIST].zero_()
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, rb, re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
 
-    def _backward(self) -> None:
-        lay, n = self.layout, len(self.layout.layers)
-        _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, self.rb, self.re)
-        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g, self.wg_ws)
-
     def _step_pre(self) -> None:
+        """Everything up to the gradients.  After the forward pass the work forks: the all-pairs kernel (which only
+        needs X and the latent) runs on the main stream while the auto cost and the decoder's backward pass run on a side
+        stream; they join at the latent layer.  Both branches are captured into the same hipGraph."""
+        lay, n = self.layout, len(self.layout.layers)
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
                          self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
         self._forward()
-        self._losses()
-        self._backward()
+        if self._fork:
+            main = torch.cuda.current_stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._auto_cost()
+                _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
+            self._latent_costs()
+            main.wait_stream(side)
+        else:
+            self._auto_cost()
+            _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
+            self._latent_costs()
+        _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        self._wgrad()
+
+    def _wgrad(self) -> None:
+        """Weight gradients.  Single GPU: the slice partials stay in the workspace and the Adam kernel adds them up
+        itself; data parallel: reduced into the flat gradient buffer for the all-reduce."""
+        n = len(self.layout.layers)
+        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws)
 
     def _step_post(self) -> None:
+        """clip + L2 + Adam, regulariser cost, history and counters: one launch."""
         p = self.p
-        _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
-                       self.terms[T_REG:T_REG + 1], self.red_ws)
-        _lib.step_tick(self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor)
-        self.step.add_(1)
+        part = None if self.dp.active else self.wg_ws
+        _lib.adam_tick(self.w, self.g if self.dp.active else None, part, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v,
+                       self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.terms, N_TERMS, self._reg_slot,
+                       self.history, self.term_history, self.hstep, self.cursor, self.red_ws2)
 
     def _step_body(self) -> None:
         self._step_pre()

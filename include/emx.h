@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define EMX_VERSION 1
-/* scratch floats every two-pass scalar reduction needs (per call, may be shared by calls on one stream) */
+/* scratch floats every two-pass scalar reduction needs (per call, may be shared by calls ordered on one stream) */
 #define EMX_REDUCE_WS 1024
 
 typedef void* emx_stream_t; /* hipStream_t */
@@ -143,12 +143,23 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
                   float lr, float beta1, float beta2, float eps, float clip,
                   const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
 
+/* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
+ * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
+ * reduction pass is needed on a single GPU.  terms[reg_slot] receives the regulariser cost; then
+ * history[*hstep] = sum(terms), term_history row, ++*hstep, ++*cursor (may be NULL), ++*opt_step.
+ * ws: EMX_REDUCE_WS floats. */
+int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
+                  const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
+                  float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
+                  int64_t* cursor, float* ws, emx_stream_t stream);
+
 /* end-of-step bookkeeping on the device (so a captured graph can be replayed without host round trips):
  * history[*step] = sum(terms[0..n_terms)), term_history[*step, :] = terms (if not NULL), then ++*step
  * (and ++*cursor, the batch cursor of emx_gather_rows).
  * replaces the Keras History / _my_train_counter bookkeeping, encodermap/models/models.py:3399-3401 */
 int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity,
-                  int64_t* step, int64_t* cursor /* may be NULL; ++*cursor */, emx_stream_t stream);
+                  int64_t* step, int64_t* cursor /* may be NULL; ++*cursor */,
+                  int64_t* counter2 /* may be NULL; ++*counter2: the optimizer's update counter */, emx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ *
  * K12  dense encoder/decoder, fused over layers, on the exact-f32 matrix cores
@@ -175,18 +186,22 @@ typedef struct {
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* in, int ld_in,
                     int row_begin, int row_end, float* const* h, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
- *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL. */
+ *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
+ *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and
+ *   the encoder can be back-propagated by separate launches (the decoder's overlaps the all-pairs kernel). */
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, int row_begin, int row_end, float* const* h, float* const* delta,
-                     emx_stream_t stream);
+                     const float* dadd, int layer_add, float* dbelow, int row_begin, int row_end, float* const* h,
+                     float* const* delta, emx_stream_t stream);
 /* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
  * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials
  * (EMX_WGRAD_SLICE_ROWS rows each) into ws, then a fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)
  * floats, ZERO-INITIALISED ONCE by the caller (alignment padding between tensors is never written). */
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
-                  int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad, float* ws,
-                  size_t ws_floats, emx_stream_t stream);
+                  int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad /* NULL: leave
+                  the slice partials in ws for emx_adam_tick */, float* ws, size_t ws_floats, emx_stream_t stream);
+/* number of row slices emx_mlp_wgrad leaves in ws for n_rows rows (slice s starts at ws + s * n_params) */
+int emx_mlp_wgrad_slices(int n_rows);
 
 /* ------------------------------------------------------------------------------------------------ *
  * ADC path (AngleDihedralCartesianEncoderMap): back-mapping and per-frame pair distances

@@ -155,7 +155,7 @@ def test_soft_start_and_scaled_cost(L):
     L.soft_start_scale(step, 6, 12, 1.0, out)
     loss = torch.zeros(1, device="cuda")
     dY = torch.zeros(B, P, device="cuda")
-    ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+    ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
     L.periodic_cost_fwd_bwd(dev(outp), 0, 0, False, dev(inp), P, float("inf"), "mean_abs", 1.0 / 3.0, 0, B, loss, dY, ws,
                             coef_scale=out, dpred_add=dev(extra))
     lo, g = D.periodic_cost_fwd_bwd(inp, outp, float("inf"), "mean_abs", 0.5 / 3.0)

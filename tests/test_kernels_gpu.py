@@ -211,7 +211,7 @@ def test_periodic_cost(L, variant, periodicity, periodic_output):
         Y = dev(y)
         dY = torch.full_like(Y, 7.0)
         loss = torch.zeros(1, device="cuda")
-        ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+        ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
         L.periodic_cost_fwd_bwd(Y, off_sin, off_cos, periodic_output, dev(target), n, periodicity, variant, coef, rb, re, loss, dY, ws)
         # oracle: float64 chain rule through atan2
         y64 = y.astype(np.float64)
@@ -264,7 +264,7 @@ def test_adam_and_tick(L, n):
     terms = torch.zeros(4, device="cuda")
     hist = torch.zeros(8, device="cuda")
     thist = torch.zeros(8, 4, device="cuda")
-    ws = torch.empty(L.EMX_REDUCE_WS, device="cuda")
+    ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
     wn, m, v = w.copy(), np.zeros(n), np.zeros(n)
     for t in range(1, 6):
         g = rng.normal(0, 1.0, n) * (3.0 if t == 2 else 0.3)   # step 2 exercises the clip
@@ -279,3 +279,46 @@ def test_adam_and_tick(L, n):
         assert int(step) == t
         assert float(hist[t - 1]) == pytest.approx(t + reg_o, rel=1e-5)
     assert np.allclose(thist[:5, 0].cpu().numpy(), [1, 2, 3, 4, 5])
+
+
+def test_adam_tick_fused_equals_separate(L):
+    """emx_adam_tick (one launch: slice sum + clip + L2 + Adam + regulariser cost + bookkeeping, behind one entry
+    point) gives the same result as emx_adam_step + emx_step_tick on the reduced gradient."""
+    rng = np.random.default_rng(3)
+    n, S = 66692, 32
+    w = rng.normal(0, 0.3, n).astype(np.float32)
+    l2 = ((rng.random(n) < 0.9) * 2e-3).astype(np.float32)
+    parts = rng.normal(0, 0.05, (S, n)).astype(np.float32)
+    P = dev(parts)
+    # reference path: fixed-order slice sum as mlp_wgrad_reduce does it (8 accumulators), then the separate kernels
+    W1, M1, V1 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    W2, M2, V2 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L2 = dev(l2)
+    s1 = torch.zeros(1, dtype=torch.int64, device="cuda"); h1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s2 = torch.zeros(1, dtype=torch.int64, device="cuda"); h2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    cur = torch.zeros(1, dtype=torch.int64, device="cuda")
+    t1 = torch.tensor([1.0, 0.0, 2.0, 3.0], device="cuda"); t2 = t1.clone()
+    hist1 = torch.zeros(8, device="cuda"); hist2 = torch.zeros(8, device="cuda")
+    th1 = torch.zeros(8, 4, device="cuda"); th2 = torch.zeros(8, 4, device="cuda")
+    ws1 = torch.zeros(L.EMX_REDUCE_WS, device="cuda"); ws2 = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
+    for step in range(3):
+        g = P.double().sum(0).float()          # float64 sum: the fused kernel's float32 slice sum must agree to rounding
+        L.adam_step(W1, g, M1, V1, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s1, t1[1:2], ws1)
+        L.step_tick(t1, 4, hist1, th1, h1, None, s1)
+        L.adam_tick(W2, None, P, S, M2, V2, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s2, t2, 4, 1, hist2, th2, h2, cur, ws2)
+        torch.cuda.synchronize()
+        diff = np.abs(W2.cpu().numpy() - W1.cpu().numpy())     # Adam amplifies rounding of near-zero gradients to ~lr
+        assert (diff > 3e-6).mean() < 2e-3 and diff.max() < 2.1e-3
+        assert int(s2) == step + 1 and int(h2) == step + 1 and int(cur) == step + 1
+        assert float(t2[1]) == pytest.approx(float(t1[1]), rel=1e-5)
+        assert float(hist2[step]) == pytest.approx(float(hist1[step]), rel=1e-5)
+    # with the gradient given directly the two paths are bitwise identical
+    W3, M3, V3 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    W4, M4, V4 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    s3 = torch.zeros(1, dtype=torch.int64, device="cuda"); s4 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    h4 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    g = dev(rng.normal(0, 1, n))
+    L.adam_step(W3, g, M3, V3, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s3, t1[1:2], ws1)
+    L.adam_tick(W4, g, None, 0, M4, V4, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s4, t2, 4, 1, hist2, th2, h4, None, ws2)
+    torch.cuda.synchronize()
+    assert torch.equal(W3, W4) and torch.equal(M3, M4) and torch.equal(V3, V4) and float(t1[1]) == float(t2[1])

@@ -93,6 +93,15 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
     for i in range(n):
         ref = deltas[i]
         np.testing.assert_allclose(delta[i].cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"delta {i}")
+    # decoder and encoder back-propagated by separate launches (dh below the decoder handed over through `dbelow`)
+    delta2 = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
+    plan3 = L.MlpPlan(lay, params, h, delta2)
+    dlat = torch.full((B, lay.latent_dim), float("nan"), device=dev)
+    L.mlp_backward(plan3, lay.n_enc, n, DT, None, 0, 0, B, dbelow=dlat)
+    L.mlp_backward(plan3, 0, lay.n_enc, dlat, DA, ladd, 0, B)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert torch.equal(delta2[i], delta[i]), f"split backward differs at layer {i}"
     g = torch.full((lay.n_params,), float("nan"), device=dev)
     ws = torch.zeros(L.mlp_wgrad_ws_floats(lay.n_params, B), device=dev)
     L.mlp_wgrad(plan, 0, n, X, 0, B, g, ws)

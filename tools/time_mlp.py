@@ -32,3 +32,6 @@ for l in range(n):
 for l in range(1, n):
     print(f"backward layers [{l},{l+1}) us", timeit(lambda: _lib.mlp_backward(plan, l, l + 1, h[l], None, 0, 0, B)))
     print(f"backward layers [{l-1},{l+1}) us", timeit(lambda: _lib.mlp_backward(plan, l - 1, l + 1, h[l], None, 0, 0, B)))
+for l in range(n):
+    src = x if l == 0 else h[l - 1]
+    print(f"wgrad layer {l} us", timeit(lambda: _lib.mlp_wgrad(plan, l, l + 1, src, 0, B, g, ws)))
