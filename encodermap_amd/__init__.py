@@ -12,11 +12,12 @@ from .parameters import ADCParameters, Parameters
 from .misc import create_n_cube, random_on_cube_edges
 from .autoencoder import Autoencoder, DihedralEncoderMap, EncoderMap
 from .adc import AngleDihedralCartesianEncoderMap
+from .features import featurize_backbone
 from .callbacks import CheckpointSaver, EarlyStop, EncoderMapBaseCallback, History, ProgressBar
 
 __all__ = [
     "Parameters", "ADCParameters", "Autoencoder", "EncoderMap", "DihedralEncoderMap", "AngleDihedralCartesianEncoderMap",
-    "create_n_cube", "random_on_cube_edges", "EncoderMapBaseCallback", "ProgressBar", "CheckpointSaver",
+    "create_n_cube", "random_on_cube_edges", "featurize_backbone", "EncoderMapBaseCallback", "ProgressBar", "CheckpointSaver",
     "EarlyStop", "History",
 ]
 __version__ = "0.1.0"

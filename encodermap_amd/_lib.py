@@ -56,6 +56,7 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p]),
@@ -314,3 +315,8 @@ def pdist_flat_bwd(xyz, dout, start, step, C, dxyz, accumulate=False):
 
 def soft_start_scale(step, a, b, c, out):
     _check(load().emx_soft_start_scale(_ptr(step), float(a), float(b), float(c), _ptr(out), _stream()), "emx_soft_start_scale")
+
+
+def backbone_features(xyz, distances, angles, dihedrals):
+    N, A = xyz.shape[0], xyz.shape[1]
+    _check(load().emx_backbone_features(_ptr(xyz), N, A, _ptr(distances), _ptr(angles), _ptr(dihedrals), _stream()), "emx_backbone_features")

@@ -193,6 +193,14 @@ class AngleDihedralCartesianEncoderMap(Autoencoder):
         return self._engine.backmap(angles, dihedrals, d["central_distances"].mean(0))
 
     @classmethod
+    def from_cartesians(cls, central_cartesians: np.ndarray, parameters: Optional[ADCParameters] = None, **kw):
+        """Builds the model from raw backbone coordinates [N, A, 3]: lengths, angles and dihedrals are computed on the
+        device (``features.featurize_backbone``)."""
+        from .features import featurize_backbone
+
+        return cls(featurize_backbone(central_cartesians, device=kw.get("device") or "cuda:0"), parameters, **kw)
+
+    @classmethod
     def from_checkpoint(cls, trajs, checkpoint_path: Union[str, Path], dataset=None, use_previous_model: bool = False,
                         compat: bool = False, **engine_kw):
         file = ckpt.resolve(checkpoint_path)

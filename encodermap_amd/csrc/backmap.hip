@@ -408,6 +408,44 @@ __global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Featurisation of a backbone chain ("next" row 2): bond lengths, bond angles and dihedrals of
+// consecutive atoms, the quantities the reference obtains from mdtraj's C kernels (encodermap/loading/features.py:
+// 150-156, 1133, 1394) and feeds to the ADC model.  Formulas: lengths encodermap_tf1/moldata.py:270-271, dihedral
+// atan2(|b2| b1.(b2 x b3), (b1 x b2).(b2 x b3)) encodermap/misc/backmapping.py:344-352.
+// One thread per (frame, atom): coalesced across atoms within a frame.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ V3 cross(V3 a, V3 b) { return V3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+
+__global__ __launch_bounds__(NT) void featurize_kernel(const float* __restrict__ xyz, long N, int A, float* __restrict__ dist,
+                                                       float* __restrict__ ang, float* __restrict__ dih) {
+  const long e = (long)blockIdx.x * NT + threadIdx.x;
+  if (e >= N * A) return;
+  const long f = e / A;
+  const int i = (int)(e - f * A);
+  const float* P = xyz + f * A * 3;
+  if (i + 1 < A) {
+    const V3 p0 = ld3(P + 3 * i), p1 = ld3(P + 3 * (i + 1));
+    const V3 b1 = p1 - p0;
+    if (dist) dist[f * (A - 1) + i] = sqrtf(dot(b1, b1));
+    if (i + 2 < A) {
+      const V3 p2 = ld3(P + 3 * (i + 2));
+      const V3 b2 = p2 - p1;
+      if (ang) {
+        const V3 u = p0 - p1;
+        const float c = dot(u, b2) * rsqrtf(dot(u, u) * dot(b2, b2));
+        ang[f * (A - 2) + i] = acosf(fminf(fmaxf(c, -1.f), 1.f));
+      }
+      if (i + 3 < A && dih) {
+        const V3 p3 = ld3(P + 3 * (i + 3));
+        const V3 b3 = p3 - p2;
+        const V3 c1 = cross(b2, b3), c2 = cross(b1, b2);
+        dih[f * (A - 3) + i] = atan2f(dot(b1, c1) * sqrtf(dot(b2, b2)), dot(c1, c2));
+      }
+    }
+  }
+}
+
 __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, float b, float c, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float sc = c;
@@ -480,6 +518,14 @@ int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int st
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_bwd: %d atoms do not fit the LDS frame buffer", C);
   hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate);
   return emx::check_launch("pdist_bwd_kernel");
+}
+
+int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, float* angles, float* dihedrals, emx_stream_t stream) {
+  EMX_REQUIRE(xyz && N > 0 && A >= 2 && (distances || angles || dihedrals), "emx_backbone_features: bad arguments");
+  const long n = (long)N * A;
+  hipLaunchKernelGGL(featurize_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, xyz, (long)N, A, distances, angles,
+                     dihedrals);
+  return emx::check_launch("featurize_kernel");
 }
 
 int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream) {

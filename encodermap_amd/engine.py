@@ -72,7 +72,7 @@ class DataParallel:
             return
         import torch.distributed as dist
 
-        if self.mode == "replica" and flat.is_cuda:
+        if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)

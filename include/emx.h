@@ -235,6 +235,13 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo,
                        float* dxyz, int accumulate, emx_stream_t stream);
 
+/* Featurisation of a backbone chain: xyz [N, A, 3] -> bond lengths [N, A-1], bond angles
+ * [N, A-2] (rad) and dihedrals [N, A-3] (rad, mdtraj convention) of consecutive atoms -- the ADC model's inputs, which the
+ * reference obtains through mdtraj's C kernels (encodermap/loading/features.py:150-156,1133,1394; formulas restated at
+ * encodermap/misc/backmapping.py:328-352, encodermap_tf1/moldata.py:270-271).  Any output may be NULL. */
+int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, float* angles, float* dihedrals,
+                          emx_stream_t stream);
+
 /* soft start of the cartesian cost (callbacks/callbacks.py:584-606) evaluated on the device from the step counter:
  * *out = 0 (t < a), c (t - a)/(b - a) (a <= t <= b), c (t > b); a < 0 -> constant c.   t = *step */
 int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream);

@@ -164,3 +164,40 @@ def test_soft_start_and_scaled_cost(L):
     # forward only (dY = NULL): train_for_references uses this
     L.periodic_cost_fwd_bwd(dev(outp), 0, 0, False, dev(inp), P, float("inf"), "mean_square", 2.0, 0, B, loss, None, ws)
     assert float(loss) == pytest.approx(2.0 * np.mean((inp.astype(np.float64) - outp) ** 2), rel=1e-5)
+
+
+def test_backbone_featurisation(L):
+    """emx_backbone_features against (i) the reference's known_angles fixture (tests/data/known_angles.pdb +
+    known_angles_{dists,angles,dihedrals}.npy) and (ii) the round trip through the back-mapping kernels."""
+    import json
+    import os
+
+    import encodermap_amd as em
+
+    T = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat_tables.json")))
+    xyz = np.array(T["known_angles_xyz_angstrom"], np.float32) / 10.0          # PDB Angstrom -> nm
+    f = em.featurize_backbone(xyz)
+    np.testing.assert_allclose(f["central_distances"], np.array(T["known_angles_dists"]), atol=2e-4)
+    np.testing.assert_allclose(np.rad2deg(f["central_angles"]), np.array(T["known_angles_angles"]), atol=1e-2)
+    np.testing.assert_allclose(np.abs(np.rad2deg(f["central_dihedrals"])), np.abs(np.array(T["known_angles_dihedrals"])), atol=1e-2)
+    # round trip: features of a back-mapped chain are the inputs of the back-mapping
+    rng = np.random.default_rng(2)
+    B, A = 40, 60
+    lengths, angles, dih = make_chain(rng, B, A)
+    ml = lengths.mean(0)
+    plane = torch.empty(B, A, 3, device="cuda")
+    out = torch.empty(B, A, 3, device="cuda")
+    L.chain_in_plane_fwd(dev(ml), dev(angles), plane)
+    L.dihedrals_to_cartesian_fwd(dev(dih), PI, plane, out)
+    g = em.featurize_backbone(out.cpu().numpy())
+    np.testing.assert_allclose(g["central_distances"], np.repeat(ml[None], B, 0), atol=2e-5)
+    np.testing.assert_allclose(g["central_angles"], angles, atol=1e-4)
+    d = np.abs(g["central_dihedrals"] - dih)
+    assert np.minimum(d, 2 * PI - d).max() < 1e-3
+    # oracle formula (misc/backmapping.py:344-352)
+    ref = R.dihedrals_mdtraj_convention(out.cpu().double()).numpy()
+    d = np.abs(g["central_dihedrals"] - ref)
+    assert np.minimum(d, 2 * PI - d).max() < 1e-4
+    # and the ADC class can be fed from coordinates alone
+    e = em.AngleDihedralCartesianEncoderMap.from_cartesians(out.cpu().numpy(), em.ADCParameters(batch_size=16, n_steps=3), read_only=True)
+    assert e.encode().shape == (B, 2)

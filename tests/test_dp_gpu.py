@@ -1,0 +1,79 @@
+"""Data-parallel engine path on the GPU: two ranks (processes) share the one GPU of the test box and reduce through
+gloo (RCCL refuses two ranks on one device; the collective is a single ``all_reduce`` of the flat buffer either way).
+Exercises exactly what ``bench.py --gpus N`` runs: the step captured as two hipGraphs around the eager all-reduce.
+
+* rowblock mode reproduces the single-process loss trajectory (exact partition of the objective)
+* replica mode: both ranks hold identical weights after every step and the reported loss is the mean of their batches
+"""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+PI = np.pi
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _data():
+    rng = np.random.default_rng(0)
+    return rng.uniform(-PI, PI, (3000, 12)).astype(np.float32)
+
+
+def _weights(p):
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+
+    lay = build_layout(p.n_neurons, p.activation_functions, 24)
+    return unpack_weights(lay, init_parameters(lay, 2))
+
+
+def _worker(rank, world, port, mode, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import encodermap_amd as em
+    from encodermap_amd.engine import DataParallel
+
+    data = _data()
+    p = em.Parameters(n_steps=6, batch_size=256, seed=11)
+    e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=DataParallel(rank, world, mode))
+    if mode == "rowblock":
+        idx = np.random.default_rng(5).integers(0, 3000, (6, 256))
+        e._engine.run_steps(6, torch.from_numpy(idx.reshape(-1)).cuda())
+    else:
+        e._engine.run_steps(6)
+    np.savez(os.path.join(out_dir, f"{mode}_{rank}.npz"), loss=e._engine.losses(), w=e._engine.w.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["rowblock", "replica"])
+def test_two_ranks_on_one_gpu(mode, tmp_path):
+    import torch.multiprocessing as mp
+
+    import encodermap_amd as em
+
+    mp.spawn(_worker, args=(2, _free_port(), mode, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (np.load(tmp_path / f"{mode}_{r}.npz") for r in range(2))
+    np.testing.assert_array_equal(r0["w"], r1["w"])                 # replicated optimizer: identical weights on every rank
+    np.testing.assert_array_equal(r0["loss"], r1["loss"])
+    assert np.isfinite(r0["loss"]).all()
+    if mode == "rowblock":
+        data = _data()
+        p = em.Parameters(n_steps=6, batch_size=256, seed=11)
+        e = em.EncoderMap(p, data, model=_weights(p), read_only=True)
+        idx = np.random.default_rng(5).integers(0, 3000, (6, 256))
+        e._engine.run_steps(6, torch.from_numpy(idx.reshape(-1)).cuda())
+        np.testing.assert_allclose(r0["loss"], e._engine.losses(), rtol=2e-5)
+        diff = np.abs(r0["w"] - e._engine.w.cpu().numpy())
+        assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3
