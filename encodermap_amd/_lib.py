@@ -39,6 +39,7 @@ SIGNATURES = {
     "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p]),
     "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_sketchmap_describe": (_i, [_i, _i, _i, _p, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _sz, _p]),
     "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
     "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
     "emx_periodic_in": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
@@ -46,8 +47,10 @@ SIGNATURES = {
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
+    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
+    "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
     "emx_chain_in_plane_fwd": (_i, [_p, _p, _i, _i, _i, _p, _p]),
@@ -59,12 +62,31 @@ SIGNATURES = {
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
-    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _i, _i, _p, _p, _p]),
+    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }
 
 EMX_MAX_LAYERS = 8
+EMX_MAX_SUM_JOBS = 8
+
+
+class LatentGrad(C.Structure):
+    """Mirror of ``emx_latent_grad``."""
+
+    _fields_ = [("partials", _p), ("Z", _p), ("slot_stride", _l), ("n_slots", _i), ("row_base", _i), ("gscale", _f), ("center_grad", _f)]
+
+
+class SketchmapPartials(C.Structure):
+    """Mirror of ``emx_sketchmap_partials``."""
+
+    _fields_ = [("grad", LatentGrad), ("tile_loss", _p), ("n_tiles", _i), ("loss_scale", _f), ("center_loss_scale", _f)]
+
+
+class SumJob(C.Structure):
+    """Mirror of ``emx_sum_job``."""
+
+    _fields_ = [("src", _p), ("n", _l), ("scale", _f), ("dev_scale", _p), ("slot", _i), ("square", _i)]
 
 
 class MlpDesc(C.Structure):
@@ -231,6 +253,13 @@ def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, w
            "emx_adam_step")
 
 
+def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws):
+    n = w.numel()
+    _check(load().emx_adam_step_slices(_ptr(w), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
+                                       float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step),
+                                       _ptr(ws), _stream()), "emx_adam_step_slices")
+
+
 def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
               term_history, hstep, cursor, ws):
     n = w.numel()
@@ -255,10 +284,35 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
                                   plan.h, _stream()), "emx_mlp_forward")
 
 
-def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None):
+def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None):
     _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
-                                   int(layer_add), _ptr(dbelow), int(row_begin), int(row_end), plan.h, plan.delta, _stream()),
-           "emx_mlp_backward")
+                                   int(layer_add), C.byref(latent) if latent is not None else None, _ptr(dbelow), int(row_begin),
+                                   int(row_end), plan.h, plan.delta, _stream()), "emx_mlp_backward")
+
+
+def sketchmap_describe(X, Z, periodicity, sig, scale, center_scale, row_begin, row_end, ws) -> SketchmapPartials:
+    B, D = X.shape
+    out = SketchmapPartials()
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    _check(load().emx_sketchmap_describe(B, D, X.stride(0), _ptr(X), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, float(scale),
+                                         float(center_scale), int(row_begin), int(row_end), _ptr(ws), ws.numel() * ws.element_size(),
+                                         C.byref(out)), "emx_sketchmap_describe")
+    return out
+
+
+def finish_step(jobs, terms, n_terms, history=None, term_history=None, hstep=None, cursor=None, counter2=None):
+    """jobs: list of (src_ptr_or_tensor, n, scale, dev_scale_tensor_or_None, slot, square)."""
+    arr = (SumJob * max(len(jobs), 1))()
+    for j, (src, n, scale, dsc, slot, sq) in enumerate(jobs):
+        arr[j].src = src if isinstance(src, int) else _ptr(src)
+        arr[j].n = int(n)
+        arr[j].scale = float(scale)
+        arr[j].dev_scale = _ptr(dsc)
+        arr[j].slot = int(slot)
+        arr[j].square = int(bool(sq))
+    cap = history.numel() if history is not None else 0
+    _check(load().emx_finish_step(arr, len(jobs), _ptr(terms), int(n_terms), _ptr(history), _ptr(term_history), cap, _ptr(hstep),
+                                  _ptr(cursor), _ptr(counter2), _stream()), "emx_finish_step")
 
 
 def mlp_wgrad_ws_floats(n_params, n_rows):

@@ -40,6 +40,12 @@ class ADCEngine(SequentialEngine):
     TERM_NAMES = ADC_TERM_NAMES
     _reg_slot = T_REG
 
+    def _jobs_pre(self) -> list:
+        return []      # every ADC cost kernel writes its term itself
+
+    def _use_sketchmap(self) -> bool:
+        return False   # the ADC step reduces its two all-pairs costs with emx_sketchmap_fwd_bwd
+
     def __init__(self, n_atoms: int, n_side: int, p, *, device: str = "cuda:0", weights: Optional[Sequence[np.ndarray]] = None,
                  dp: Optional[DataParallel] = None, use_graph: bool = True, history_capacity: Optional[int] = None):
         if p.periodicity == INF:
@@ -217,6 +223,8 @@ class ADCEngine(SequentialEngine):
             t[T_DIST].zero_()
         _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
         self._wgrad()
+        if self.dp.active:
+            pass
 
     # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
     @torch.no_grad()

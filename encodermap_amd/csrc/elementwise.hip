@@ -83,7 +83,7 @@ struct CostArgs {
   float* ws;
   float* loss;
   int ldy, ldt, off_sin, off_cos, periodic_output;
-  int n, row_begin, row_end, variant, wrap;
+  int n, row_begin, row_end, variant, wrap, prescale;
   float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
 };
 
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
     }
   }
   float t = block_sum<NT>(lsum, red);
-  if (threadIdx.x == 0) a.ws[blockIdx.x] = t;
+  if (threadIdx.x == 0) a.ws[blockIdx.x] = a.prescale ? t * a.gnorm * (a.coef_scale ? *a.coef_scale : 1.f) : t;
+  if (a.prescale && blockIdx.x == 0)   // unused scratch entries read as zero by the summing job
+    for (int i = gridDim.x + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
 }
 
 // *out = scale * sum_{i<n} ws[i], fixed order
@@ -297,6 +299,8 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   }
   float tsum = block_sum<NT>(reg, red);
   if (threadIdx.x == 0) a.ws[blockIdx.x] = tsum;
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
 }
 
 __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
@@ -314,6 +318,65 @@ __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, f
   *step = s + 1;
   if (cursor) *cursor += 1;
   if (counter2) *counter2 += 1;
+}
+
+struct FinishArgs {
+  emx_sum_job jobs[EMX_MAX_SUM_JOBS];
+  int n_jobs;
+  float* terms;
+  int n_terms;
+  float* history;
+  float* term_history;
+  long capacity;
+  int64_t* hstep;
+  int64_t* cursor;
+  int64_t* counter2;
+};
+
+// one workgroup: the jobs' sums (fixed order), then the bookkeeping of step_tick_kernel
+__global__ __launch_bounds__(NT) void finish_step_kernel(const FinishArgs a) {
+  __shared__ float red[8];
+  for (int j = 0; j < a.n_jobs; ++j) {
+    const emx_sum_job job = a.jobs[j];
+    // up to 16 independent loads in flight per thread: the whole job is one or two memory round trips
+    float acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
+    long i = threadIdx.x;
+    for (; i + 15 * NT < job.n; i += 16 * NT) {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = job.src[i + u * NT];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += job.square ? v[u] * v[u] : v[u];
+    }
+    {
+      float v[16];
+#pragma unroll
+      for (int u = 0; u < 16; ++u) v[u] = (i + u * NT < job.n) ? job.src[min(i + (long)u * NT, job.n - 1)] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 16; ++u) acc[u] += job.square ? v[u] * v[u] : v[u];
+    }
+    const float s0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    const float s1 = ((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15]));
+    const float s2 = 0.f, s3 = 0.f;
+    const float tot = block_sum<NT>((s0 + s1) + (s2 + s3), red);
+    if (threadIdx.x == 0) a.terms[job.slot] = tot * job.scale * (job.dev_scale ? *job.dev_scale : 1.f);
+  }
+  if (a.hstep && threadIdx.x == 0) {
+    __threadfence_block();
+    const long s = *a.hstep;
+    float tot = 0.f;
+    for (int i = 0; i < a.n_terms; ++i) tot += a.terms[i];
+    if (s >= 0 && s < a.capacity) {
+      if (a.history) a.history[s] = tot;
+      if (a.term_history)
+        for (int i = 0; i < a.n_terms; ++i) a.term_history[s * a.n_terms + i] = a.terms[i];
+    }
+    *a.hstep = s + 1;
+    if (a.cursor) *a.cursor += 1;
+    if (a.counter2) *a.counter2 += 1;
+  }
 }
 
 inline int grid_for(long work_items, int per_block) {
@@ -365,7 +428,7 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
                               int B, int n, float periodicity, int variant, float coef, const float* coef_scale,
                               const float* dpred_add, int row_begin, int row_end, float* loss, float* dY, float* ws,
                               emx_stream_t stream) {
-  EMX_REQUIRE(y && target && loss && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
+  EMX_REQUIRE(y && target && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
   EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "emx_periodic_cost_fwd_bwd: bad shape");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_periodic_cost_fwd_bwd: bad row block");
   EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "emx_periodic_cost_fwd_bwd: cost variant %d not available", variant);
@@ -392,6 +455,7 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   a.row_end = row_end;
   a.variant = variant;
   a.wrap = std::isfinite(periodicity);
+  a.prescale = loss ? 0 : 1;
   a.period = periodicity;
   a.out_scale = (a.wrap && periodicity != TWO_PI) ? periodicity / TWO_PI : 1.f;
   const double denom = (variant == EMX_MEAN_NORM) ? (double)B : (double)B * n;
@@ -400,7 +464,7 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
   int rc = emx::check_launch("periodic_cost_kernel");
-  if (rc) return rc;
+  if (rc || !loss) return rc;
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, a.gnorm, coef_scale, loss);
   return emx::check_launch("final_sum_kernel");
 }
@@ -456,6 +520,16 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   return rc;
 }
 
+int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
+                         int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
+                         emx_stream_t stream) {
+  EMX_REQUIRE(w && g_partials && m && v && step && ws, "emx_adam_step_slices: null pointer argument");
+  EMX_REQUIRE(n > 0 && n_slices > 0 && partial_stride >= n, "emx_adam_step_slices: bad slice layout");
+  const AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("adam_kernel");
+}
+
 int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
                   const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
                   float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
@@ -478,6 +552,28 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
   hipLaunchKernelGGL(step_tick_kernel, dim3(1), dim3(64), 0, st, terms, n_terms, history, term_history, (long)capacity, hstep, cursor,
                      opt_step);
   return emx::check_launch("step_tick_kernel");
+}
+
+int emx_finish_step(const emx_sum_job* jobs, int n_jobs, float* terms, int n_terms, float* history, float* term_history,
+                    int64_t capacity, int64_t* hstep, int64_t* cursor, int64_t* counter2, emx_stream_t stream) {
+  EMX_REQUIRE(terms && n_terms > 0 && n_terms <= 64 && n_jobs >= 0 && n_jobs <= EMX_MAX_SUM_JOBS && (n_jobs == 0 || jobs),
+              "emx_finish_step: bad arguments");
+  FinishArgs a;
+  for (int j = 0; j < n_jobs; ++j) {
+    EMX_REQUIRE(jobs[j].src && jobs[j].n >= 0 && jobs[j].slot >= 0 && jobs[j].slot < n_terms, "emx_finish_step: bad job %d", j);
+    a.jobs[j] = jobs[j];
+  }
+  a.n_jobs = n_jobs;
+  a.terms = terms;
+  a.n_terms = n_terms;
+  a.history = history;
+  a.term_history = term_history;
+  a.capacity = (long)capacity;
+  a.hstep = hstep;
+  a.cursor = cursor;
+  a.counter2 = counter2;
+  hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("finish_step_kernel");
 }
 
 int emx_step_tick(const float* terms, int n_terms, float* history, float* term_history, int64_t capacity, int64_t* step,

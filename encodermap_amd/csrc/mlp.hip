@@ -247,8 +247,8 @@ __global__ __launch_bounds__(NTC) void mlp_forward_kernel(const MlpDev d, int l0
 // added to dh_ladd before its activation derivative (the latent gradient of the distance/center costs).
 // ---------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NTC) void mlp_backward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ dtop, int ld_top,
-                                                          const float* __restrict__ dadd, int ladd, float* __restrict__ dbelow,
-                                                          int row0, int row_end, int pitch) {
+                                                          const float* __restrict__ dadd, int ladd, const emx_latent_grad lg,
+                                                          float* __restrict__ dbelow, int row0, int row_end, int pitch) {
   extern __shared__ __align__(16) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
@@ -289,6 +289,19 @@ __global__ __launch_bounds__(NTC) void mlp_backward_kernel(const MlpDev d, int l
         if (ok) {
           const long gi = (long)(r0 + r) * N + c;
           if (add) v += dadd[gi];
+          if (lg.partials != nullptr && l == ladd) {
+            // latent gradient of the all-pairs cost: fixed-order sum of the per-tile slots (8 loads in flight)
+            const float* __restrict__ P = lg.partials + (long)(r0 + r - lg.row_base) * N + c;
+            float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            int sidx = 0;
+            for (; sidx + 8 <= lg.n_slots; sidx += 8) {
+#pragma unroll
+              for (int u = 0; u < 8; ++u) part[u] += P[(long)(sidx + u) * lg.slot_stride];
+            }
+            for (int u = 0; sidx < lg.n_slots; ++sidx, ++u) part[u] += P[(long)sidx * lg.slot_stride];
+            const float ssum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
+            v += fmaf(lg.center_grad, lg.Z[gi], lg.gscale * ssum);
+          }
           if (act) {
             float hv = h[gi];
             v *= fmaf(-hv, hv, 1.f);
@@ -541,15 +554,20 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, in
 }
 
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, float* dbelow, int row_begin, int row_end, float* const* h,
-                     float* const* delta, emx_stream_t stream) {
+                     const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin, int row_end,
+                     float* const* h, float* const* delta, emx_stream_t stream) {
   MlpDev d;
   int rc = fill_dev(desc, params, h, delta, d, "emx_mlp_backward");
   if (rc) return rc;
   EMX_REQUIRE(dtop && h && delta, "emx_mlp_backward: null pointer argument");
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_backward: bad layer range");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "emx_mlp_backward: bad rows / stride");
-  EMX_REQUIRE(!dadd || (layer_add >= layer_begin && layer_add < layer_end), "emx_mlp_backward: layer_add outside the layer range");
+  EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "emx_mlp_backward: layer_add outside the layer range");
+  emx_latent_grad lg{};
+  if (latent) {
+    lg = *latent;
+    EMX_REQUIRE(lg.partials && lg.Z && lg.n_slots > 0, "emx_mlp_backward: incomplete latent gradient descriptor");
+  }
   for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(h[l] && delta[l], "emx_mlp_backward: buffer of layer %d is null", l);
   const int pitch = pitch_for(desc, layer_begin, layer_end);
   const size_t lds = (size_t)2 * R * pitch * sizeof(float);
@@ -557,7 +575,7 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, i
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
   hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, d, layer_begin, layer_end, dtop, ld_top, dadd,
-                     layer_add, dbelow, row_begin, row_end, pitch);
+                     layer_add, lg, dbelow, row_begin, row_end, pitch);
   return emx::check_launch("mlp_backward_kernel");
 }
 

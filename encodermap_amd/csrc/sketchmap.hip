@@ -795,6 +795,28 @@ int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6]
   return launch_finish_plan(pl, (hipStream_t)stream);
 }
 
+int emx_sketchmap_describe(int B, int D, int ldx, const float* X, const float* Z, int L, float periodicity, const float sig[6],
+                           float scale, float center_scale, int row_begin, int row_end, void* ws, size_t ws_bytes,
+                           emx_sketchmap_partials* out) {
+  EMX_REQUIRE(out, "emx_sketchmap_describe: null output");
+  SkPlan pl;
+  int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, scale, center_scale, row_begin, row_end, nullptr, nullptr, nullptr, ws, ws_bytes,
+                     pl, "emx_sketchmap_describe");
+  if (rc) return rc;
+  out->grad.partials = pl.f.P;
+  out->grad.Z = Z;
+  out->grad.slot_stride = (int64_t)pl.f.nrows_pad * L;
+  out->grad.n_slots = pl.f.nslots;
+  out->grad.row_base = row_begin;
+  out->grad.gscale = pl.f.gscale;
+  out->grad.center_grad = pl.f.cgrad;
+  out->tile_loss = pl.f.tile_loss;
+  out->n_tiles = pl.ntiles;
+  out->loss_scale = pl.f.lscale;
+  out->center_loss_scale = pl.f.cscale;
+  return EMX_OK;
+}
+
 int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream) {
   EMX_REQUIRE(X && out && B > 0 && D > 0 && ldx >= D, "emx_pairwise_dist: bad arguments");
   dim3 grid((B + 255) / 256, B);

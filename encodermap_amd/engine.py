@@ -139,7 +139,10 @@ class SequentialEngine:
 
         self.rb, self.re = self.dp.row_block(self.B)
         self._side_stream = torch.cuda.Stream(device=self.device)
-        self._fork = os.environ.get("EMX_FORK_STREAMS", "1") != "0"   # fork/join of the two post-forward branches
+        # Optional fork/join of the two post-forward branches (all-pairs kernel || auto cost + decoder backward).  Off by
+        # default: on this stack every cross-stream dependency inside a hipGraph costs 5-12 us (measured, rocprofv3
+        # timeline), more than the ~19 us of work the overlap hides.
+        self._fork = os.environ.get("EMX_FORK_STREAMS", "0") == "1"
         self._alloc_step_buffers(self.B)
         self._graph = None
         self.data = None
@@ -163,6 +166,7 @@ class SequentialEngine:
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
+        self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
 
     # -- data feed -------------------------------------------------------------------------------
     def set_data(self, data) -> None:
@@ -205,33 +209,50 @@ class SequentialEngine:
             _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
 
     def _auto_cost(self) -> None:
-        """auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY"""
+        """auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY; the cost's
+        per-workgroup partials stay in ``red_ws`` and are summed by the step's single scalar epilogue"""
         p = self.p
         if p.auto_cost_scale is not None:
             _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
-                                       float(p.auto_cost_scale), self.rb, self.re, self.terms[T_AUTO:T_AUTO + 1], self.dY, self.red_ws,
-                                       B=self.B)
+                                       float(p.auto_cost_scale), self.rb, self.re, None, self.dY, self.red_ws, B=self.B)
         else:
             self.dY.zero_()
-            self.terms[T_AUTO].zero_()
+            self.red_ws.zero_()
+
+    def _use_sketchmap(self) -> bool:
+        return self.with_distance and self.p.distance_cost_scale is not None
 
     def _latent_costs(self) -> None:
-        """sketch-map distance cost with the center cost fused (or the center cost alone): gradient wrt the latent"""
-        p, rb, re = self.p, self.rb, self.re
+        """all-pairs tile pass of the sketch-map cost (its O(B) reduction is folded into the encoder's backward kernel and
+        the scalar epilogue), or the center cost alone"""
+        p = self.p
         Z = self.h[self.layout.n_enc - 1]
-        cs = p.center_cost_scale
-        if self.with_distance and p.distance_cost_scale is not None:
-            _lib.sketchmap_fwd_bwd(self.xb, Z, self.periodicity, p.dist_sig_parameters, float(p.distance_cost_scale),
-                                   float(cs) if cs is not None else 0.0, rb, re,
-                                   self.terms[T_DIST:T_DIST + 1], self.terms[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
+        if self._use_sketchmap():
+            _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws)
         else:
-            self.terms[T_DIST].zero_()
-            _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, rb, re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
+            cs = p.center_cost_scale
+            _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, self.rb, self.re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
+
+    def _describe_sketchmap(self):
+        p = self.p
+        cs = p.center_cost_scale
+        return _lib.sketchmap_describe(self.xb, self.h[self.layout.n_enc - 1], self.periodicity, p.dist_sig_parameters,
+                                       float(p.distance_cost_scale), float(cs) if cs is not None else 0.0, self.rb, self.re, self.sk_ws)
+
+    def _jobs_pre(self) -> list:
+        """scalar sums that must be final before a data-parallel all-reduce: (src, n, scale, dev_scale, slot, square)"""
+        jobs = [(self.red_ws, _lib.EMX_REDUCE_WS, 1.0, None, T_AUTO, False)]
+        if self._use_sketchmap():
+            sk = self._sk
+            Z = self.h[self.layout.n_enc - 1]
+            jobs.append((sk.tile_loss, sk.n_tiles, sk.loss_scale, None, T_DIST, False))
+            jobs.append((Z.data_ptr() + self.rb * self.L * 4, (self.re - self.rb) * self.L, sk.center_loss_scale, None, T_CENTER, True))
+        return jobs
 
     def _step_pre(self) -> None:
-        """Everything up to the gradients.  After the forward pass the work forks: the all-pairs kernel (which only
-        needs X and the latent) runs on the main stream while the auto cost and the decoder's backward pass run on a side
-        stream; they join at the latent layer.  Both branches are captured into the same hipGraph."""
+        """Everything up to the gradients.  After the forward pass there are two independent branches -- the all-pairs
+        kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at the latent layer; they
+        run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
         lay, n = self.layout, len(self.layout.layers)
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
                          self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
@@ -249,8 +270,13 @@ class SequentialEngine:
             self._auto_cost()
             _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
             self._latent_costs()
-        _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        if self._use_sketchmap():
+            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
+        else:
+            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         self._wgrad()
+        if self.dp.active:      # the loss terms travel in the same all-reduce as the gradients
+            _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
 
     def _wgrad(self) -> None:
         """Weight gradients.  Single GPU: the slice partials stay in the workspace and the Adam kernel adds them up
@@ -259,12 +285,18 @@ class SequentialEngine:
         _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws)
 
     def _step_post(self) -> None:
-        """clip + L2 + Adam, regulariser cost, history and counters: one launch."""
+        """clip + L2 + Adam, then ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost,
+        history and counters."""
         p = self.p
-        part = None if self.dp.active else self.wg_ws
-        _lib.adam_tick(self.w, self.g if self.dp.active else None, part, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v,
-                       self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.terms, N_TERMS, self._reg_slot,
-                       self.history, self.term_history, self.hstep, self.cursor, self.red_ws2)
+        reg_job = (self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)
+        if self.dp.active:
+            _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2)
+            jobs = [reg_job]
+        else:
+            _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
+                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2)
+            jobs = self._jobs_pre() + [reg_job]
+        _lib.finish_step(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
 
     def _step_body(self) -> None:
         self._step_pre()

@@ -81,6 +81,30 @@ int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6]
                          int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ,
                          void* ws, size_t ws_bytes, emx_stream_t stream);
 
+/* Where emx_sketchmap_tiles leaves its results, for callers that fold the O(B) reduction into kernels they launch anyway
+ * (emx_mlp_backward adds the latent gradient while it forms delta; emx_finish_step sums the cost):
+ *   d cost / d z[row, c] = gscale * sum_{s < n_slots} partials[s * slot_stride + (row - row_base) * L + c] + center_grad * z[row, c]
+ *   distance cost = loss_scale * sum(tile_loss[0 .. n_tiles));  center cost = center_loss_scale * sum_{own rows} z^2 */
+typedef struct {
+  const float* partials;
+  const float* Z;
+  int64_t slot_stride;
+  int n_slots;
+  int row_base;
+  float gscale;
+  float center_grad;
+} emx_latent_grad;
+typedef struct {
+  emx_latent_grad grad;
+  const float* tile_loss;
+  int n_tiles;
+  float loss_scale;
+  float center_loss_scale;
+} emx_sketchmap_partials;
+int emx_sketchmap_describe(int B, int D, int ldx, const float* X, const float* Z, int L, float periodicity, const float sig[6],
+                           float scale, float center_scale, int row_begin, int row_end, void* ws, size_t ws_bytes,
+                           emx_sketchmap_partials* out);
+
 /* materialising variants, for parity tests of a2/a3 only (out is [B,B]) */
 int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream);
 
@@ -113,6 +137,8 @@ int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off
  *   the prediction is y[:, off_sin+k] itself.  periodicity = INFINITY -> plain |pred - target|.
  *   *loss = coef * variant(delta) over rows [row_begin,row_end) normalised by the GLOBAL B;
  *   dY (same layout/stride as y) is WRITTEN for the addressed columns of rows in the block (NULL: forward only).
+ *   loss == NULL: no final sum is launched; ws[0 .. EMX_REDUCE_WS) then holds per-workgroup partials that already carry
+ *   coef (and *coef_scale) and add up to the cost (emx_finish_step sums them).
  *   `coef_scale` (device float, e.g. the soft-start scale of callbacks.py:584-606) multiplies coef on the device so
  *   that a captured graph follows the step counter; `dpred_add` lets the back-mapping path (cartesian cost) join
  *   the gradient before the atan2 backward.  The same entry point serves cartesian_loss
@@ -136,12 +162,20 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
  *   g_total = g + l2coef[i]*w[i]  (l2coef = 2*lambda on kernel elements, 0 on biases; may be NULL)
  *   g_total = clamp(g_total, -clip, clip)  (clip <= 0 disables)
  *   m += (g-m)(1-b1); v += (g^2-v)(1-b2); w -= lr*sqrt(1-b2^t)/(1-b1^t) * m/(sqrt(v)+eps),  t = *step + 1
- *   *reg_loss = sum_i 0.5*l2coef[i]*w[i]^2 evaluated on the weights BEFORE the update (may be NULL).
+ *   *reg_loss = sum_i 0.5*l2coef[i]*w[i]^2 evaluated on the weights BEFORE the update (may be NULL: then ws[0 ..
+ *   EMX_REDUCE_WS) holds partials that add up to it).
  *   `step` is a device int64 holding the number of completed updates; it is NOT modified here (emx_step_tick does).
  * ------------------------------------------------------------------------------------------------ */
 int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n,
                   float lr, float beta1, float beta2, float eps, float clip,
                   const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
+
+/* emx_adam_step on the weight-gradient slice partials left by emx_mlp_wgrad (gradient = fixed-order sum over n_slices slices of
+ * g_partials[s * partial_stride + i]); no separate reduction pass.  ws[0 .. EMX_REDUCE_WS) receives partials of the regulariser
+ * cost (summed by emx_finish_step). */
+int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
+                         int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
+                         emx_stream_t stream);
 
 /* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
  * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
@@ -152,6 +186,21 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
                   const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
                   float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
                   int64_t* cursor, float* ws, emx_stream_t stream);
+
+/* Scalar epilogue of a step in ONE single-workgroup launch: every job adds `n` floats (or their squares) in a fixed order
+ * and stores scale * (*dev_scale) * sum into terms[slot]; with hstep != NULL the bookkeeping of emx_step_tick follows
+ * (history[*hstep] = sum(terms), ++counters).  Replaces the per-cost final-sum launches. */
+typedef struct {
+  const float* src;
+  int64_t n;
+  float scale;
+  const float* dev_scale; /* may be NULL */
+  int slot;
+  int square;
+} emx_sum_job;
+#define EMX_MAX_SUM_JOBS 8
+int emx_finish_step(const emx_sum_job* jobs, int n_jobs, float* terms, int n_terms, float* history, float* term_history,
+                    int64_t capacity, int64_t* hstep, int64_t* cursor, int64_t* counter2, emx_stream_t stream);
 
 /* end-of-step bookkeeping on the device (so a captured graph can be replayed without host round trips):
  * history[*step] = sum(terms[0..n_terms)), term_history[*step, :] = terms (if not NULL), then ++*step
@@ -190,8 +239,8 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, in
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and
  *   the encoder can be back-propagated by separate launches (the decoder's overlaps the all-pairs kernel). */
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, float* dbelow, int row_begin, int row_end, float* const* h,
-                     float* const* delta, emx_stream_t stream);
+                     const float* dadd, int layer_add, const emx_latent_grad* latent /* may be NULL; joins at layer_add */,
+                     float* dbelow, int row_begin, int row_end, float* const* h, float* const* delta, emx_stream_t stream);
 /* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
  * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials
  * (EMX_WGRAD_SLICE_ROWS rows each) into ws, then a fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)

@@ -322,3 +322,30 @@ def test_adam_tick_fused_equals_separate(L):
     L.adam_tick(W4, g, None, 0, M4, V4, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s4, t2, 4, 1, hist2, th2, h4, None, ws2)
     torch.cuda.synchronize()
     assert torch.equal(W3, W4) and torch.equal(M3, M4) and torch.equal(V3, V4) and float(t1[1]) == float(t2[1])
+
+
+@pytest.mark.parametrize("B,Dd,periodicity,sig", [
+    (8192, 512, 2 * PI, (28.0, 12, 6, 1, 2, 6)),      # BASELINE config C4 batch shape (periodic dihedrals)
+    (16384, 256, INF, (22.6, 12, 6, 1, 2, 6)),        # BASELINE config C5 batch shape (Euclidean stress)
+])
+def test_sketchmap_baseline_stress_sizes(L, B, Dd, periodicity, sig):
+    """The large BASELINE batch shapes through size-independent properties: row-block partials (the data-parallel
+    rectangles) add up to the symmetric full-batch launch, the gradient has zero net force, the result is bitwise
+    reproducible, and a 384-row sub-batch agrees with the float64 oracle."""
+    rng = np.random.default_rng(B)
+    x, z = make_xz(rng, B, Dd, 2, periodicity, 1.0)
+    loss, _, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, None, 0, B)
+    loss2, _, g2 = run_sketchmap(L, x, z, periodicity, sig, 500.0, None, 0, B)
+    assert loss == loss2 and np.array_equal(g, g2)
+    nblk = 4
+    step = B // nblk
+    parts = [run_sketchmap(L, x, z, periodicity, sig, 500.0, None, rb, rb + step) for rb in range(0, B, step)]
+    assert sum(p[0] for p in parts) == pytest.approx(loss, rel=5e-6)
+    g_parts = np.concatenate([p[2][i * step:(i + 1) * step] for i, p in enumerate(parts)])
+    np.testing.assert_allclose(g_parts, g, rtol=0, atol=2e-5 * np.abs(g).max())
+    assert np.abs(g.sum(0)).max() < 1e-4 * np.abs(g).sum(0).max()
+    sub = slice(100, 484)
+    lo_o, g_o = D.sketchmap_fwd_bwd(x[sub], z[sub], periodicity, sig, 500.0)
+    lo, _, gg = run_sketchmap(L, x[sub], z[sub], periodicity, sig, 500.0, None, 0, 384)
+    assert lo == pytest.approx(lo_o, rel=1e-5)
+    np.testing.assert_allclose(gg, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max())
