@@ -46,9 +46,9 @@ SIGNATURES = {
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
-    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p]),
-    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p]),
-    "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p]),
+    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
     "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _p]),
@@ -61,8 +61,10 @@ SIGNATURES = {
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
-    "emx_mlp_forward": (_i, [_p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
-    "emx_mlp_backward": (_i, [_p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "emx_mlp_mirror_floats": (_sz, [_p]),
+    "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
+    "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
 }
@@ -99,7 +101,7 @@ class MlpDesc(C.Structure):
 class MlpPlan:
     """Descriptor + pointer tables for one network (built once per engine)."""
 
-    def __init__(self, layout, params, h, delta):
+    def __init__(self, layout, params, h, delta, mirror=None):
         n = len(layout.layers)
         if n > EMX_MAX_LAYERS:
             raise EmxError(f"{n} dense layers not supported by the fused MLP kernels (max {EMX_MAX_LAYERS})")
@@ -118,6 +120,17 @@ class MlpPlan:
         PtrArr = _p * EMX_MAX_LAYERS
         self.h = PtrArr(*[(t.data_ptr() if t is not None else None) for t in h] + [None] * (EMX_MAX_LAYERS - n))
         self.delta = PtrArr(*[(t.data_ptr() if t is not None else None) for t in delta] + [None] * (EMX_MAX_LAYERS - n))
+        # W^T copy read by the forward kernel (include/emx.h, emx_mlp_mirror); shared between plans over the same weights
+        if mirror is None:
+            import torch
+            mirror = torch.zeros(load().emx_mlp_mirror_floats(C.byref(d)), dtype=torch.float32, device=params.device)
+            self.mirror = mirror
+            self.refresh_mirror()
+        self.mirror = mirror
+
+    def refresh_mirror(self):
+        """Rebuild the mirror after `params` was written by anything other than emx_adam_step*."""
+        _check(load().emx_mlp_mirror(C.byref(self.desc), _ptr(self.params), _ptr(self.mirror), _stream()), "emx_mlp_mirror")
 
 _lib = None
 
@@ -247,26 +260,36 @@ def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):
                                           int(bool(accumulate)), _stream()), "emx_center_cost_fwd_bwd")
 
 
-def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws):
+def _mirror_args(plan):
+    """(descriptor, operand store) of the network whose kernels live in the parameter buffer, or (NULL, NULL)."""
+    if plan is None:
+        return None, None
+    return C.byref(plan.desc), _ptr(plan.mirror)
+
+
+def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws, plan=None):
+    md, mp = _mirror_args(plan)
     _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
-                                float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), _stream()),
-           "emx_adam_step")
+                                float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), md, mp,
+                                _stream()), "emx_adam_step")
 
 
-def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws):
+def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None):
     n = w.numel()
+    md, mp = _mirror_args(plan)
     _check(load().emx_adam_step_slices(_ptr(w), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
                                        float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step),
-                                       _ptr(ws), _stream()), "emx_adam_step_slices")
+                                       _ptr(ws), md, mp, _stream()), "emx_adam_step_slices")
 
 
 def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
-              term_history, hstep, cursor, ws):
+              term_history, hstep, cursor, ws, plan=None):
     n = w.numel()
+    md, mp = _mirror_args(plan)
     _check(load().emx_adam_tick(_ptr(w), _ptr(g), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
                                 float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(opt_step),
                                 _ptr(terms), int(n_terms), int(reg_slot), _ptr(history), _ptr(term_history), history.numel(),
-                                _ptr(hstep), _ptr(cursor), _ptr(ws), _stream()), "emx_adam_tick")
+                                _ptr(hstep), _ptr(cursor), _ptr(ws), md, mp, _stream()), "emx_adam_tick")
 
 
 def mlp_wgrad_slices(n_rows):
@@ -280,12 +303,12 @@ def step_tick(terms, n_terms, history, term_history, step, cursor=None, counter2
 
 
 def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
-    _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(x), x.stride(0), int(row_begin), int(row_end),
+    _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin), int(row_end),
                                   plan.h, _stream()), "emx_mlp_forward")
 
 
 def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None):
-    _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
+    _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
                                    int(layer_add), C.byref(latent) if latent is not None else None, _ptr(dbelow), int(row_begin),
                                    int(row_end), plan.h, plan.delta, _stream()), "emx_mlp_backward")
 

@@ -2,6 +2,7 @@
 // Every kernel here is HBM- or launch-latency-bound: rows are walked by whole waves with 16-byte lanes
 // where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
 #include "emx_common.h"
+#include "mirror.h"
 
 namespace {
 
@@ -221,6 +222,8 @@ struct AdamArgs {
   float* ws;
   long n;
   float lr, b1, b2, eps, clip;
+  float* mirror;        // optional: operand store of the dense layers, rewritten with the new weights (mirror.h)
+  MirrorArgs mir;
 };
 
 __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float l2c, const AdamArgs& a, float alpha,
@@ -280,6 +283,12 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
       reinterpret_cast<float4*>(a.w)[i] = w;
       reinterpret_cast<float4*>(a.m)[i] = m;
       reinterpret_cast<float4*>(a.v)[i] = v;
+      if (a.mirror) {
+        mirror_scatter(a.mir, a.mirror, 4 * i, w.x);
+        mirror_scatter(a.mir, a.mirror, 4 * i + 1, w.y);
+        mirror_scatter(a.mir, a.mirror, 4 * i + 2, w.z);
+        mirror_scatter(a.mir, a.mirror, 4 * i + 3, w.w);
+      }
     }
     start = n4 << 2;
   }
@@ -296,6 +305,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     a.w[i] = w;
     a.m[i] = m;
     a.v[i] = v;
+    if (a.mirror) mirror_scatter(a.mir, a.mirror, i, w);
   }
   float tsum = block_sum<NT>(reg, red);
   if (threadIdx.x == 0) a.ws[blockIdx.x] = tsum;
@@ -481,8 +491,11 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 
 namespace {
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
-                   int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws) {
-  AdamArgs a;
+                   int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
+                   const emx_mlp_desc* mirror_desc, float* mirror) {
+  AdamArgs a{};
+  a.mirror = (mirror_desc && mirror) ? mirror : nullptr;
+  if (a.mirror) fill_mirror_args(mirror_desc, a.mir);
   a.w = w;
   a.g = g;
   a.gpart = gpart;
@@ -504,10 +517,12 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
 }  // namespace
 
 int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
-                  float eps, float clip, const int64_t* step, float* reg_loss, float* ws, emx_stream_t stream) {
+                  float eps, float clip, const int64_t* step, float* reg_loss, float* ws, const emx_mlp_desc* mirror_desc, float* mirror,
+                  emx_stream_t stream) {
   EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
+  EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
-  const AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws);
+  const AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror);
   const int grid = grid_for((n + 3) / 4, NT);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
@@ -522,10 +537,11 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
 
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         emx_stream_t stream) {
+                         const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream) {
   EMX_REQUIRE(w && g_partials && m && v && step && ws, "emx_adam_step_slices: null pointer argument");
+  EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step_slices: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0 && n_slices > 0 && partial_stride >= n, "emx_adam_step_slices: bad slice layout");
-  const AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws);
+  const AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
 }
@@ -533,12 +549,13 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
 int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
                   const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
                   float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
-                  int64_t* cursor, float* ws, emx_stream_t stream) {
+                  int64_t* cursor, float* ws, const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream) {
   EMX_REQUIRE(w && m && v && opt_step && terms && hstep && ws, "emx_adam_tick: null pointer argument");
+  EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_tick: mirror without a valid descriptor");
   EMX_REQUIRE((g != nullptr) != (g_partials != nullptr), "emx_adam_tick: pass either the gradient or its slice partials");
   EMX_REQUIRE(!g_partials || (n_slices > 0 && partial_stride >= n), "emx_adam_tick: bad slice layout");
   EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && reg_slot >= 0 && reg_slot < n_terms, "emx_adam_tick: bad sizes");
-  const AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws);
+  const AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws, mirror_desc, mirror);
   // Three plain launches on the stream.  (An in-kernel hand-off -- last workgroup finishes -- was measured slower: its
   // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
   const int grid = grid_for((n + 3) / 4, NT);

@@ -21,6 +21,7 @@
 // D[row = 4*(lane>>4) + reg][col = lane&15].  k-assignment used here: in K-step q lane group g = lane>>4 supplies
 // k = 16q + 4g + i for the i-th of four consecutive MFMAs, so a lane's four A (or W-row) values are contiguous.
 #include "emx_common.h"
+#include "mirror.h"
 
 namespace {
 
@@ -50,301 +51,346 @@ __device__ __forceinline__ float ld_clamped(const float* __restrict__ p, int r, 
   return p[(long)min(r, nr - 1) * ld + min(c, nc - 1)];
 }
 
-// tanh with |error| <= ~1e-7 (the float32 resolution of the activations): odd polynomial near zero, 1 - 2/(e^{2x}+1)
-// elsewhere.  ~14 VALU instructions instead of the ~50 of the library tanhf, which matters at one wave per SIMD.
+// tanh(x) = 1 - 2 / (e^{2x} + 1): two transcendental + three plain VALU instructions, absolute error <= ~1.5e-7 over the
+// whole range (v_exp_f32 and v_rcp_f32 are 1-ulp; e = inf gives rcp = 0 -> 1, e = 0 gives -1), which is the float32
+// resolution of the activations.  The epilogue of a layer is VALU-bound (two waves per SIMD finish their MFMAs together),
+// so the ~50-instruction library tanhf would cost more than the layer's MFMAs.
 __device__ __forceinline__ float tanh_f32(float x) {
-  const float ax = fabsf(x);
-  const float x2 = x * x;
-  const float p = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 62.f / 2835.f, -17.f / 315.f), 2.f / 15.f), -1.f / 3.f), 1.f);
-  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * ax);        // e^{2|x|}
-  const float t = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
-  return ax < 0.25f ? p : copysignf(t, x);
+  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);        // e^{2x}
+  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
 }
 
-constexpr int UQ = 8;   // K-steps (16 k each) per pipeline unit: 32 B-fragment registers in flight per unit
+// ---------------------------------------------------------------------------------------------------------
+// Row-block chain kernel (forward and backward-data share it).
+//
+// One workgroup = 16 batch rows pushed through a range of layers; the row block's activations (forward) or deltas
+// (backward) ping-pong between two LDS images.  Eight waves, two per SIMD, one 16-column MFMA tile each
+// (v_mfma_f32_16x16x4_f32: A = 16 rows x 4 k from LDS, B = 4 k x 16 columns of weights).
+//
+// The weights are the only HBM/L2 stream and every workgroup needs all of them (64 KB per 128x128 layer and CU), so
+// the kernel is built around that stream:
+//   * operand store ("mirror", emx_mlp_mirror): per layer and direction the weights are kept in the exact order the
+//     waves consume them -- 1-KB blocks (tile of 16 output columns, K-step of 16), lane (g, m) owning the 16 bytes
+//     {B[16q + 4g + i][16t + m], i < 4} -- so one global_load_dwordx4 per wave fetches eight whole 128-B lines
+//     (the [in, out] kernel itself is read with half-used lines in either direction);
+//   * measured load-to-use time of that stream with 256 workgroups pulling the same lines is 5-8 thousand cycles
+//     (profiles/r01_chain_timeline.txt), a multiple of one layer's MFMA time (2048 cycles per SIMD).  The host
+//     therefore flattens the layer range into UNITS (layer, pass of 128 columns, chunk of 128 k; one unit = up to
+//     32 MFMAs per wave) and the kernel keeps the operands of NB - 1 units in flight in a register ring;
+//   * vmcnt is one in-order counter for loads AND stores, so everything a unit will need from memory (operand
+//     pieces, bias or h values for its epilogue) travels in one package NB - 1 units ahead, results are stored one
+//     unit late (from registers, at the head of the next request burst), and no other vector-memory instruction
+//     exists in the loop: every wait is for the OLDEST package only.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int MAXU = 40;   // units per launch
+constexpr int NB = 4;      // operand ring depth
 
-// One pipeline unit = (layer, 32-column pass of this wave, chunk of UQ K-steps).  Units are walked in order across
-// layer boundaries so that the B fragments (weights, independent of the activations) of the NEXT unit are always in
-// flight while the current unit's MFMAs, epilogue and barrier run.
-struct Unit {
-  int l, n0, c;
-  bool valid;
+struct UnitLoad {       // what a request burst needs to fetch a unit's package (32 B, one s_load_dwordx8)
+  int op_off;           // float offset of the operand block (first tile of the pass, first K-step of the chunk)
+  int Q;                // K-steps per tile of this operand (tile pitch in 256-float blocks)
+  int kq;               // K-steps in this chunk, 1..8
+  int tiles;            // tiles of this pass that exist, 1..8 (waves beyond them re-read the last one)
+  int col0;             // first output column of the pass
+  int n;                // row length of aux
+  const float* aux;     // forward: the layer's bias; backward: h rows for the activation derivative (any readable [*, n] otherwise)
+};
+struct UnitExec {       // what the MFMA phase and the epilogue need (32 B)
+  int kq_cols;          // kq | valid output columns of this pass << 8
+  int src_off;          // column offset of the chunk in the source LDS image
+  int dst_off;          // column offset of the pass in the destination image and in the output rows
+  int flags;            // U_* | S_* << 8
+  float* out;           // [*, n] result rows (h_l forward; delta_{l-1} or dbelow backward)
+  int n;
+  int pad;
+};
+enum { U_FIRST = 1, U_LAST = 2, U_LAYER_END = 4 };
+enum { S_ACT = 1, S_JOIN = 2 };
+
+struct ChainArgs {
+  UnitLoad ul[MAXU];
+  UnitExec ux[MAXU];
+  int nu;
+  int pitch;
+  const float* mbase;   // operand store
+  const float* in;      // forward: input rows; backward: d loss / d h_top
+  int ld_in, in_cols;
+  int row0, row_end;
+  // backward only: the top of the range becomes delta_top = (in [+ join]) * act'(h_top), stored to top_out
+  const float* top_h;
+  float* top_out;
+  int top_flags;
+  // join: rows added to dh of one layer (S_JOIN): dadd and / or the latent gradient of the all-pairs cost
+  const float* dadd;
+  emx_latent_grad lg;
+  int join_n;           // width of the joined layer (0: no join)
+};
+
+#ifdef EMX_CHAIN_TIMING   // in-kernel timeline (tools/abl_timing.py); stamps go to LDS so that they do not touch vmcnt
+__device__ long long emx_dbg[8192];
+#define TSTAMP(slot) do { if (!BWD && lane == 0) dbg_lds[wave * 64 + (slot)] = clock64(); } while (0)
+#else
+#define TSTAMP(slot)
+#endif
+
+template <int V>
+struct IC {
+  static constexpr int value = V;
 };
 
 template <bool BWD>
-__device__ __forceinline__ int unit_cols(const MlpDev& d, int l) {   // width of the GEMM's output (N for fwd, Kin for bwd)
-  return BWD ? d.width[l] : d.width[l + 1];
-}
-template <bool BWD>
-__device__ __forceinline__ int unit_kq(const MlpDev& d, int l) {     // K-steps of the GEMM's reduction axis
-  return ((BWD ? d.width[l + 1] : d.width[l]) + 15) >> 4;
-}
-
-// forward walks layers upward, backward walks them downward (and skips the data GEMM of layer lo)
-template <bool BWD>
-__device__ __forceinline__ Unit first_unit(const MlpDev& d, int l, int lo, int hi, int wave) {
-  Unit u{l, wave * 16, 0, false};
-  while (BWD ? (u.l > lo) : (u.l < hi)) {
-    if (u.n0 < unit_cols<BWD>(d, u.l)) {
-      u.valid = true;
-      return u;
-    }
-    u.l += BWD ? -1 : 1;
-  }
-  return u;
-}
-template <bool BWD>
-__device__ __forceinline__ Unit next_unit(const MlpDev& d, Unit u, int lo, int hi, int wave) {
-  const int nch = (unit_kq<BWD>(d, u.l) + UQ - 1) / UQ;
-  if (u.c + 1 < nch) return Unit{u.l, u.n0, u.c + 1, true};
-  if (u.n0 + 128 < unit_cols<BWD>(d, u.l)) return Unit{u.l, u.n0 + 128, 0, true};
-  return first_unit<BWD>(d, u.l + (BWD ? -1 : 1), lo, hi, wave);
-}
-
-// B fragments of a forward unit: W[k][n], k = 16(UQ c + q) + 4g + i, n = n0 + 16t + m.  Uniform row base + per-lane
-// offset (-> global_load with an SGPR base); rows are clamped only in the ragged last chunk.
-__device__ __forceinline__ void load_unit_fwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][4]) {
-  const int K = d.width[u.l], N = d.width[u.l + 1];
-  const float* __restrict__ W = d.W[u.l];
-  const int off0 = 4 * g * N + min(u.n0 + m, N - 1);
-  const int k0 = 16 * UQ * u.c;
-  if (k0 + 16 * UQ <= K) {
-#pragma unroll
-    for (int q = 0; q < UQ; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* rb = W + (long)(k0 + 16 * q + i) * N;   // wave-uniform
-        b[q][i] = rb[off0];
-      }
-  } else {
-    const int c0 = min(u.n0 + m, N - 1);
-#pragma unroll
-    for (int q = 0; q < UQ; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float* rb = W + (long)min(k0 + 16 * q + 4 * g + i, K - 1) * N;   // clamped: the A side is zero there
-        b[q][i] = rb[c0];
-      }
-  }
-}
-
-// B fragments of a backward-data unit: 16-byte pieces of W rows: W[j][k..k+3], j = n0 + 16t + m (input feature),
-// k = 16(UQ c + q) + 4g (output feature)
-__device__ __forceinline__ void load_unit_bwd(const MlpDev& d, const Unit u, int m, int g, float (&b)[UQ][4]) {
-  const int Kin = d.width[u.l], N = d.width[u.l + 1];
-  const float* __restrict__ W = d.W[u.l];
-  const float* p0 = W + (long)min(u.n0 + m, Kin - 1) * N;
-  const int k0 = 16 * UQ * u.c + 4 * g;
-  if ((N & 3) == 0) {   // wave-uniform
-#pragma unroll
-    for (int q = 0; q < UQ; ++q) {
-      const int kk = min(k0 + 16 * q, N - 4);
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(p0 + kk);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        b[q][i] = w0[i];
-      }
-    }
-  } else {
-#pragma unroll
-    for (int q = 0; q < UQ; ++q)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int kk = min(k0 + 16 * q + i, N - 1);
-        b[q][i] = p0[kk];
-      }
-  }
-}
-
-__device__ __forceinline__ void mma_unit(const float* src, int pitch, int m, int g, int c, int Kq, const float (&b)[UQ][4], f32x4& acc0) {
-#pragma unroll
-  for (int q = 0; q < UQ; ++q) {
-    const int kq = UQ * c + q;
-    if (kq < Kq) {   // wave-uniform
-      const f32x4 a = *reinterpret_cast<const f32x4*>(&src[m * pitch + 16 * kq + 4 * g]);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[q][i], acc0, 0, 0, 0);
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// forward: layers [l0, l1) on rows [row0, row_end); `in` is [*, width[l0]] with row stride ld_in
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTC) void mlp_forward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ in, int ld_in,
-                                                         int row0, int row_end, int pitch) {
+__global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   extern __shared__ __align__(16) float lds[];
-  // (LDS images are addressed as lds + offset everywhere: a pointer array would decay to generic pointers and
-  //  flat_load, whose out-of-order return forces s_waitcnt vmcnt(0) in front of every MFMA group)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef EMX_CHAIN_TIMING
+  __shared__ long long dbg_lds[512];
+#endif
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int m = lane & 15, g = lane >> 4;
-  const int r0 = row0 + blockIdx.x * R;
+  const int n0 = wave * 16;
+  const int r0 = a.row0 + blockIdx.x * R;
+  const int pitch = a.pitch;
+  const int img = R * pitch;
+  const int nu = a.nu;
+  float* lat = lds + 2 * img;   // [R][join_n] rows joined into one layer's dh (backward)
+  constexpr int NE = BWD ? 4 : 1;
+  TSTAMP(0);
 
-  float bcur[UQ][4], bnxt[UQ][4];
-  Unit cur = first_unit<false>(d, l0, l0, l1, wave);
-  if (cur.valid) load_unit_fwd(d, cur, m, g, bcur);
+  float b[NB][8][4];
+  float e[NB][NE];
 
-  // stage the input rows (zero padded to the pitch, rows beyond the block zero)
-  {
-    const int K = d.width[l0];
-    for (int e = tid; e < R * pitch; e += NTC) {
-      int r = e / pitch, c = e - r * pitch;
-      float v = 0.f;
-      if (c < K && r0 + r < row_end) v = in[(long)(r0 + r) * ld_in + c];
-      lds[e] = v;
+  // one unit's package: its epilogue operands + 8 operand pieces.  Addresses are clamped, never masked or branched
+  // around, so that every package is the same instruction sequence.
+  auto piece_ptr = [&](const UnitLoad& L) { return a.mbase + L.op_off + (long)(min(wave, L.tiles - 1) * L.Q) * 256 + lane * 4; };
+  auto request_piece = [&](const UnitLoad& L, const float* __restrict__ p, int q, float (&bq)[4]) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + min(q, L.kq - 1) * 256);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) bq[i] = v[i];
+  };
+  auto request_epi = [&](const UnitLoad& L, float (&ee)[NE]) {
+    const int ccol = min(L.col0 + n0 + m, L.n - 1);
+    if (!BWD) {
+      ee[0] = L.aux[ccol];
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < NE; ++reg) ee[reg] = L.aux[(long)min(r0 + 4 * g + reg, a.row_end - 1) * L.n + ccol];
     }
-  }
-  __syncthreads();
+  };
 
-  int buf = 0;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-  for (int l = l0; l < l1; ++l) {
-    const int N = d.width[l + 1];
-    const int Kq = (d.width[l] + 15) >> 4;
-    const int nch = (Kq + UQ - 1) / UQ;
-    const float* src = lds + buf * (R * pitch);
-    float* dst = lds + (buf ^ 1) * (R * pitch);
-    while (cur.valid && cur.l == l) {
-      const Unit nxt = next_unit<false>(d, cur, l0, l1, wave);
-      if (nxt.valid) load_unit_fwd(d, nxt, m, g, bnxt);
-      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0);
-      if (cur.c == nch - 1) {
-        // epilogue: bias, activation, to LDS (next layer's input, zero beyond N) and to HBM
-        const float* __restrict__ bias = d.b[l];
-        float* hout = d.h[l];
-        const bool act = d.act[l] != 0;
-        {
-          const int col = cur.n0 + m;
-          const float bv = bias[min(col, N - 1)];
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const int row = 4 * g + reg;
-            float v = acc0[reg] + bv;
-            if (act) v = tanh_f32(v);
-            v = col < N ? v : 0.f;
-            dst[row * pitch + col] = v;   // col < round16(N) <= pitch - 4
-            if (col < N && r0 + row < row_end) hout[(long)(r0 + row) * N + col] = v;
-          }
+  if (BWD && a.join_n > 0) {
+    // rows joined into dh of one layer: dadd and / or the latent gradient of the all-pairs cost (one wave per element,
+    // lanes over the per-tile slots, fixed order)
+    const int N = a.join_n;
+    if (a.lg.partials != nullptr) {
+      for (int el = wave; el < R * N; el += NTC / 64) {
+        const int r = el / N, c = el - r * N;
+        const bool rok = r0 + r < a.row_end;
+        float v = 0.f;
+        if (rok) {
+          const float* __restrict__ P = a.lg.partials + (long)(r0 + r - a.lg.row_base) * N + c;
+          for (int sidx = lane; sidx < a.lg.n_slots; sidx += 64) v += P[(long)sidx * a.lg.slot_stride];
         }
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        v = wave_sum(v);
+        if (lane == 0) {
+          float t = 0.f;
+          if (rok) {
+            const long gi = (long)(r0 + r) * N + c;
+            t = fmaf(a.lg.center_grad, a.lg.Z[gi], a.lg.gscale * v);
+            if (a.dadd != nullptr) t += a.dadd[gi];
+          }
+          lat[el] = t;
+        }
       }
-#pragma unroll
-      for (int q = 0; q < UQ; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bcur[q][i] = bnxt[q][i];
-      cur = nxt;
+    } else {
+      for (int el = tid; el < R * N; el += NTC) {
+        const int r = el / N, c = el - r * N;
+        lat[el] = r0 + r < a.row_end ? a.dadd[(long)(r0 + r) * N + c] : 0.f;
+      }
     }
     __syncthreads();
-    buf ^= 1;
   }
-}
 
-// ---------------------------------------------------------------------------------------------------------
-// backward (data): for l = l1-1 .. l0:  delta_l = dh_l * act'(h_l)  (stored),  dh_{l-1} = delta_l W_l^T.
-// `dtop` [*, width[l1]] (row stride ld_top) is d loss / d h_{l1-1}; `dadd` (may be null) [*, width[ladd+1]] is
-// added to dh_ladd before its activation derivative (the latent gradient of the distance/center costs).
-// ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTC) void mlp_backward_kernel(const MlpDev d, int l0, int l1, const float* __restrict__ dtop, int ld_top,
-                                                          const float* __restrict__ dadd, int ladd, const emx_latent_grad lg,
-                                                          float* __restrict__ dbelow, int row0, int row_end, int pitch) {
-  extern __shared__ __align__(16) float lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int m = lane & 15, g = lane >> 4;
-  const int r0 = row0 + blockIdx.x * R;
-
-  float bcur[UQ][4], bnxt[UQ][4];
-  const int lo = dbelow ? l0 - 1 : l0;   // with `dbelow` the data GEMM of layer l0 runs too (dh below the range is stored)
-  Unit cur = first_unit<true>(d, l1 - 1, lo, l1, wave);
-  if (cur.valid) load_unit_bwd(d, cur, m, g, bcur);
-
-  // dh of the top layer -> LDS
-  {
-    const int N = d.width[l1];
-    for (int e = tid; e < R * pitch; e += NTC) {
-      int r = e / pitch, c = e - r * pitch;
-      float v = 0.f;
-      if (c < N && r0 + r < row_end) v = dtop[(long)(r0 + r) * ld_top + c];
-      lds[e] = v;
+  // stage the row block: thread -> (row = tid / 32, columns 4 (tid % 32) + 128 i), zero beyond the input width.
+  // The first 128 columns are requested before the operand packages and written to LDS after them.
+  const int sr = tid >> 5, sK = a.in_cols;
+  const bool srok = r0 + sr < a.row_end;
+  const long sgrow = (long)min(r0 + sr, a.row_end - 1);
+  auto stage_load = [&](int c, float (&v)[4]) {
+    const float* __restrict__ src = a.in + sgrow * a.ld_in;
+    if ((((a.ld_in | sK) & 3) == 0) && c < sK) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(src + c);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = t[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = src[min(c + i, sK - 1)];
     }
-  }
-  __syncthreads();
+    if (BWD) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cc = min(c + i, sK - 1);
+        if (a.top_flags & S_JOIN) v[i] += lat[sr * sK + cc];
+        if (a.top_flags & S_ACT) {
+          const float hv = a.top_h[sgrow * sK + cc];
+          v[i] *= fmaf(-hv, hv, 1.f);
+        }
+      }
+    }
+  };
+  auto stage_store = [&](int c, const float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = srok && c + i < sK;
+      if (BWD && ok) a.top_out[sgrow * sK + c + i] = v[i];
+      lds[sr * pitch + c + i] = ok ? v[i] : 0.f;   // pitch % 4 == 0
+    }
+  };
+  const int sc0 = 4 * (tid & 31);
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};
 
   int buf = 0;
-  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f};
-  for (int l = l1 - 1; l >= l0; --l) {
-    const int Kin = d.width[l], N = d.width[l + 1];  // layer maps Kin -> N
-    float* dh = lds + buf * (R * pitch);
-    // delta_l = (dh_l [+ dadd]) * act'(h_l), in place in LDS, and stored to HBM for the weight gradients
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  // results of the previous epilogue, stored at the head of the next iteration through a buffer resource whose bounds
+  // check drops the lanes and rows that do not exist (no exec-masked branch around a vector-memory instruction)
+  float pend[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* pend_base = a.ux[0].out;
+  int pend_bytes = 0, pend_n = 0;
+  unsigned pend_voff = 0x80000000u;
+  UnitExec X = a.ux[0];
+  UnitLoad Lq = a.ul[0];
+
+  // Iteration ui requests the package of unit ui + NB - 1 into ring slot r and executes unit ui from slot r + 1; the
+  // first NB - 1 iterations (ui < 0) only request.  Every iteration issues the SAME sequence of vector-memory
+  // instructions (4 stores, NE epilogue operands, 8 pieces, the pieces one per MFMA group), with scalar branches only
+  // around code that has none -- that is what lets the compiler's s_waitcnt insertion count exactly, so that the wait in
+  // front of an MFMA group is for that group's piece of the OLDEST package and nothing younger.
+  auto unit = [&](auto RC, const int ui) {
+    constexpr int r = decltype(RC)::value;
+    constexpr int rx = (r + 1) % NB;
+    const bool run = ui >= 0 && ui < nu;
+    const bool req = ui + NB - 1 < nu;
+    const int kq = run ? (X.kq_cols & 0xff) : 0, cols = X.kq_cols >> 8;
+    const bool mine = n0 < cols;
+
     {
-      const float* __restrict__ h = d.h[l];
-      float* __restrict__ dl = d.delta[l];
-      const bool act = d.act[l] != 0;
-      const bool add = dadd != nullptr && l == ladd;
-      for (int e = tid; e < R * N; e += NTC) {
-        int r = e / N, c = e - r * N;
-        float v = dh[r * pitch + c];
-        const bool ok = r0 + r < row_end;
-        if (ok) {
-          const long gi = (long)(r0 + r) * N + c;
-          if (add) v += dadd[gi];
-          if (lg.partials != nullptr && l == ladd) {
-            // latent gradient of the all-pairs cost: fixed-order sum of the per-tile slots (8 loads in flight)
-            const float* __restrict__ P = lg.partials + (long)(r0 + r - lg.row_base) * N + c;
-            float part[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            int sidx = 0;
-            for (; sidx + 8 <= lg.n_slots; sidx += 8) {
+      __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend_base), 0, pend_bytes, 0x00020000);
 #pragma unroll
-              for (int u = 0; u < 8; ++u) part[u] += P[(long)(sidx + u) * lg.slot_stride];
-            }
-            for (int u = 0; sidx < lg.n_slots; ++sidx, ++u) part[u] += P[(long)sidx * lg.slot_stride];
-            const float ssum = ((part[0] + part[1]) + (part[2] + part[3])) + ((part[4] + part[5]) + (part[6] + part[7]));
-            v += fmaf(lg.center_grad, lg.Z[gi], lg.gscale * ssum);
-          }
-          if (act) {
-            float hv = h[gi];
-            v *= fmaf(-hv, hv, 1.f);
-          }
-          dl[gi] = v;
+      for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
+      pend_bytes = 0;
+    }
+    if (ui == -(NB - 1)) {
+      if (sc0 < pitch) stage_load(sc0, sv);   // the row block itself travels ahead of the first package
+      TSTAMP(1);
+    }
+    request_epi(Lq, e[r]);
+    // beyond the last unit the pieces degenerate to one shared line
+    const float* __restrict__ pp = req ? piece_ptr(Lq) : a.mbase;
+    const float* src = lds + buf * img + X.src_off + m * pitch + 4 * g;
+    if (run && (X.flags & U_FIRST)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (run) TSTAMP(3 + 5 * ui);
+    f32x4 av = *reinterpret_cast<const f32x4*>(src);   // A pieces are read one group ahead (any in-image address is readable)
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const f32x4 avn = *reinterpret_cast<const f32x4*>(src + 16 * (q < 7 ? q + 1 : 7));
+      if (mine && q < kq) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], b[rx][q][i], acc, 0, 0, 0);
+      }
+      request_piece(Lq, pp, q, b[r][q]);
+      __builtin_amdgcn_sched_barrier(0);
+      av = avn;
+    }
+    // the next iteration's records: scalar loads issued here land behind the epilogue (issued at the top of the iteration,
+    // their s_waitcnt lgkmcnt(0) -- scalar loads return out of order -- would sit in front of the first ds_read)
+    const UnitLoad Ln = a.ul[max(0, min(ui + NB, nu - 1))];
+    const UnitExec Xn = a.ux[max(0, min(ui + 1, nu - 1))];
+    Lq = Ln;
+
+    if (ui == -(NB - 1)) {
+      if (sc0 < pitch) stage_store(sc0, sv);
+      for (int c = sc0 + 128; c < pitch; c += 128) {
+        float v[4];
+        stage_load(c, v);
+        stage_store(c, v);
+      }
+      __syncthreads();
+      TSTAMP(2);
+    }
+    if (!run) return;
+    TSTAMP(5 + 5 * ui);
+
+    // ---- epilogue (every wave: the whole 128-column pass of the destination image is written, zeros where the
+    //      layer is narrower, because it is the next layer's A operand)
+    if (X.flags & U_LAST) {
+      const int sflags = X.flags >> 8;
+      const int col = X.dst_off + n0 + m;
+      const bool cok = n0 + m < cols;
+      float* dst = lds + (buf ^ 1) * img + col;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int row = 4 * g + reg;
+        float v = acc[reg];
+        if (!BWD) {
+          v += e[rx][0];
+          if (sflags & S_ACT) v = tanh_f32(v);
         } else {
-          v = 0.f;
+          if (sflags & S_JOIN) v += lat[row * X.n + min(col, X.n - 1)];
+          if (sflags & S_ACT) v *= fmaf(-e[rx][reg % NE], e[rx][reg % NE], 1.f);
         }
-        dh[r * pitch + c] = v;
+        v = (cok && r0 + row < a.row_end) ? v : 0.f;
+        dst[row * pitch] = v;
+        pend[reg] = v;
       }
+      pend_base = X.out + (long)r0 * X.n;
+      pend_n = X.n;
+      pend_bytes = max(0, min(R, a.row_end - r0)) * X.n * 4;
+      pend_voff = cok ? (unsigned)((4 * g * X.n + col) * 4) : 0x80000000u;
     }
-    __syncthreads();
-    if (l == l0 && !dbelow) break;  // no dh needed below the first layer of the range
-    // dh_{l-1}[row][j] = sum_k delta[row][k] W[j][k]  (k over the N outputs, j over the Kin inputs)
-    const int Kq = (N + 15) >> 4;
-    const int nch = (Kq + UQ - 1) / UQ;
-    const float* src = lds + buf * (R * pitch);
-    float* dst = lds + (buf ^ 1) * (R * pitch);
-    while (cur.valid && cur.l == l) {
-      const Unit nxt = next_unit<true>(d, cur, lo, l1, wave);
-      if (nxt.valid) load_unit_bwd(d, nxt, m, g, bnxt);
-      mma_unit(src, pitch, m, g, cur.c, Kq, bcur, acc0);
-      if (cur.c == nch - 1) {
-        {
-          const int col = cur.n0 + m;
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            const float v = acc0[reg];
-            dst[(4 * g + reg) * pitch + col] = col < Kin ? v : 0.f;
-            if (l == l0 && col < Kin && r0 + 4 * g + reg < row_end) dbelow[(long)(r0 + 4 * g + reg) * Kin + col] = v;
-          }
-        }
-        acc0 = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int q = 0; q < UQ; ++q)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bcur[q][i] = bnxt[q][i];
-      cur = nxt;
+    TSTAMP(6 + 5 * ui);
+    if (X.flags & U_LAYER_END) {
+      __syncthreads();
+      buf ^= 1;
     }
-    __syncthreads();
-    buf ^= 1;
+    TSTAMP(7 + 5 * ui);
+    X = Xn;
+  };
+
+  for (int ui = -(NB - 1); ui < nu; ui += NB) {
+    unit(IC<0>{}, ui);
+    unit(IC<1>{}, ui + 1);
+    unit(IC<2>{}, ui + 2);
+    unit(IC<3>{}, ui + 3);
   }
+  {
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend_base), 0, pend_bytes, 0x00020000);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
+  }
+#ifdef EMX_CHAIN_TIMING
+  __syncthreads();
+  if (!BWD && (blockIdx.x == 0 || blockIdx.x == 100)) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
+#endif
+}
+
+// gather form of mirror.h's layout (the scatter form lives in the Adam kernel)
+__global__ __launch_bounds__(256) void mlp_mirror_kernel(const MirrorArgs ma, const float* __restrict__ params, float* __restrict__ mirror) {
+  const long el = (long)blockIdx.x * 256 + threadIdx.x;
+  if (el >= ma.begin[ma.n_layers]) return;
+  int l = 0;
+  while (el >= ma.begin[l + 1]) ++l;
+  const int K = ma.width[l], N = ma.width[l + 1];
+  long rel = el - ma.begin[l];
+  const long blk = operand_block(K, N);
+  const int dir = rel >= blk;
+  rel -= dir * blk;
+  const int nout = dir ? K : N, kred = dir ? N : K;
+  const int Q = (kred + 15) / 16;
+  const int block = (int)(rel >> 8), in = (int)(rel & 255);
+  const int t = block / Q, q = block - t * Q;
+  const int ln = in >> 2, i = in & 3;
+  const int j = 16 * t + (ln & 15), k = 16 * q + 4 * (ln >> 4) + i;
+  float v = 0.f;
+  if (j < nout && k < kred) v = dir ? params[ma.w_off[l] + (long)j * N + k] : params[ma.w_off[l] + (long)k * N + j];
+  mirror[el] = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -518,7 +564,7 @@ int fill_dev(const emx_mlp_desc* desc, float* params, float* const* h, float* co
 int pitch_for(const emx_mlp_desc* desc, int l0, int l1) {
   int w = 0;
   for (int l = l0; l <= l1; ++l) w = std::max(w, desc->width[l]);
-  return ((w + 15) / 16) * 16 + 4;   // tiles write up to the next multiple of 16; +4 keeps b128 rows conflict-free
+  return ((w + 127) / 128) * 128 + 4;   // whole 128-column passes are written; +4 keeps b128 rows conflict-free
 }
 
 int set_lds(const void* fn, size_t bytes, const char* who) {
@@ -530,53 +576,141 @@ int set_lds(const void* fn, size_t bytes, const char* who) {
   return EMX_OK;
 }
 
+int check_desc(const emx_mlp_desc* desc, const char* who) {
+  EMX_REQUIRE(desc, "%s: null descriptor", who);
+  EMX_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= MAXL, "%s: %d layers not supported (1..%d)", who, desc->n_layers, MAXL);
+  for (int l = 0; l <= desc->n_layers; ++l) EMX_REQUIRE(desc->width[l] >= 1, "%s: layer width must be >= 1", who);
+  return EMX_OK;
+}
+
+// float offset of layer l's operand blocks in the operand store (forward block first, backward block second)
+long mirror_begin(const emx_mlp_desc* desc, int l) {
+  long o = 0;
+  for (int i = 0; i < l; ++i) o += 2 * operand_block(desc->width[i], desc->width[i + 1]);
+  return o;
+}
+
+// Appends the units of one GEMM: `kred` reduction indices, `nout` output columns, operand block at float offset `op`.
+int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, float* out, int sflags, const char* who) {
+  const int Q = (kred + 15) / 16, T = (nout + 15) / 16;
+  const int P = (nout + 127) / 128, Cn = (kred + 127) / 128;
+  for (int p = 0; p < P; ++p)
+    for (int c = 0; c < Cn; ++c) {
+      if (a.nu >= MAXU) return emx::fail(EMX_EUNSUPPORTED, "%s: layer range needs more than %d 128x128 units", who, MAXU);
+      const long off = op + ((long)(8 * p) * Q + 8 * c) * 256;
+      if (off + 8L * Q * 256 > 0x7fffffffL) return emx::fail(EMX_EUNSUPPORTED, "%s: operand store too large", who);
+      const int kq = std::min(8, Q - 8 * c);
+      UnitLoad& ul = a.ul[a.nu];
+      ul = UnitLoad{(int)off, Q, kq, std::min(8, T - 8 * p), 128 * p, nout, aux};
+      UnitExec& ux = a.ux[a.nu];
+      ux = UnitExec{kq | (std::min(128, nout - 128 * p) << 8), 128 * c, 128 * p,
+                    (c == 0 ? U_FIRST : 0) | (c == Cn - 1 ? U_LAST : 0) | (c == Cn - 1 && p == P - 1 ? U_LAYER_END : 0) | (sflags << 8), out, nout, 0};
+      ++a.nu;
+    }
+  return EMX_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
-int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* in, int ld_in,
-                    int row_begin, int row_end, float* const* h, emx_stream_t stream) {
-  MlpDev d;
-  int rc = fill_dev(desc, params, h, nullptr, d, "emx_mlp_forward");
-  if (rc) return rc;
-  EMX_REQUIRE(in && h, "emx_mlp_forward: null pointer argument");
-  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
-  for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
-  const int pitch = pitch_for(desc, layer_begin, layer_end);
-  const size_t lds = (size_t)2 * R * pitch * sizeof(float);
-  rc = set_lds(reinterpret_cast<const void*>(&mlp_forward_kernel), lds, "emx_mlp_forward");
-  if (rc) return rc;
-  const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(mlp_forward_kernel, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, d, layer_begin, layer_end, in, ld_in, row_begin,
-                     row_end, pitch);
-  return emx::check_launch("mlp_forward_kernel");
+size_t emx_mlp_mirror_floats(const emx_mlp_desc* desc) {
+  if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL) return 0;
+  return (size_t)mirror_begin(desc, desc->n_layers);
 }
 
-int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin, int row_end,
-                     float* const* h, float* const* delta, emx_stream_t stream) {
-  MlpDev d;
-  int rc = fill_dev(desc, params, h, delta, d, "emx_mlp_backward");
+int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror, emx_stream_t stream) {
+  int rc = check_desc(desc, "emx_mlp_mirror");
   if (rc) return rc;
-  EMX_REQUIRE(dtop && h && delta, "emx_mlp_backward: null pointer argument");
+  EMX_REQUIRE(params && mirror, "emx_mlp_mirror: null pointer argument");
+  MirrorArgs ma{};
+  fill_mirror_args(desc, ma);
+  const long n = ma.begin[desc->n_layers];
+  hipLaunchKernelGGL(mlp_mirror_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ma, params, mirror);
+  return emx::check_launch("mlp_mirror_kernel");
+}
+
+int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                    int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream) {
+  int rc = check_desc(desc, "emx_mlp_forward");
+  if (rc) return rc;
+  EMX_REQUIRE(params && mirror && in && h, "emx_mlp_forward: null pointer argument");
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
+  ChainArgs a{};
+  for (int l = layer_begin; l < layer_end; ++l) {
+    EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
+    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], h[l], desc->act[l] ? S_ACT : 0,
+                   "emx_mlp_forward");
+    if (rc) return rc;
+  }
+  a.pitch = pitch_for(desc, layer_begin, layer_end);
+  a.mbase = mirror;
+  a.in = in;
+  a.ld_in = ld_in;
+  a.in_cols = desc->width[layer_begin];
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  const size_t lds = (size_t)2 * R * a.pitch * sizeof(float);
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<false>), lds, "emx_mlp_forward");
+  if (rc) return rc;
+  const int grid = (row_end - row_begin + R - 1) / R;
+  hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
+  return emx::check_launch("mlp chain kernel (forward)");
+}
+
+int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
+                     int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin,
+                     int row_end, float* const* h, float* const* delta, emx_stream_t stream) {
+  int rc = check_desc(desc, "emx_mlp_backward");
+  if (rc) return rc;
+  EMX_REQUIRE(params && mirror && dtop && h && delta, "emx_mlp_backward: null pointer argument");
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_backward: bad layer range");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "emx_mlp_backward: bad rows / stride");
   EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "emx_mlp_backward: layer_add outside the layer range");
-  emx_latent_grad lg{};
+  ChainArgs a{};
+  const bool join = dadd || latent;
   if (latent) {
-    lg = *latent;
-    EMX_REQUIRE(lg.partials && lg.Z && lg.n_slots > 0, "emx_mlp_backward: incomplete latent gradient descriptor");
+    a.lg = *latent;
+    EMX_REQUIRE(a.lg.partials && a.lg.Z && a.lg.n_slots > 0, "emx_mlp_backward: incomplete latent gradient descriptor");
   }
+  if (join) a.join_n = desc->width[layer_add + 1];
+  a.dadd = dadd;
   for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(h[l] && delta[l], "emx_mlp_backward: buffer of layer %d is null", l);
-  const int pitch = pitch_for(desc, layer_begin, layer_end);
-  const size_t lds = (size_t)2 * R * pitch * sizeof(float);
-  rc = set_lds(reinterpret_cast<const void*>(&mlp_backward_kernel), lds, "emx_mlp_backward");
+  auto sflags = [&](int l) { return (desc->act[l] ? S_ACT : 0) | ((join && l == layer_add) ? S_JOIN : 0); };
+  // top of the range: delta_top from dtop
+  const int top = layer_end - 1;
+  a.top_h = h[top];
+  a.top_out = delta[top];
+  a.top_flags = sflags(top);
+  // GEMM of layer l: delta_l W_l^T -> dh_{l-1} -> delta_{l-1} (or dbelow at the bottom of the range)
+  const int lo = dbelow ? layer_begin : layer_begin + 1;
+  for (int l = top; l >= lo; --l) {
+    const int Kin = desc->width[l], N = desc->width[l + 1];
+    const long op = mirror_begin(desc, l) + operand_block(Kin, N);
+    if (l > layer_begin)
+      rc = add_units(a, op, N, Kin, desc->act[l - 1] ? h[l - 1] : delta[l - 1], delta[l - 1], sflags(l - 1), "emx_mlp_backward");
+    else
+      rc = add_units(a, op, N, Kin, dbelow, dbelow, 0, "emx_mlp_backward");
+    if (rc) return rc;
+  }
+  if (a.nu == 0) {   // a one-layer range without dbelow: only delta_top is formed; the kernel still wants one readable record
+    a.ul[0] = UnitLoad{0, 1, 1, 1, 0, 1, mirror};
+    a.ux[0] = UnitExec{1 | (1 << 8), 0, 0, 0, delta[top], 1, 0};
+  }
+  a.pitch = pitch_for(desc, layer_begin, layer_end);
+  a.mbase = mirror;
+  a.in = dtop;
+  a.ld_in = ld_top;
+  a.in_cols = desc->width[layer_end];
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  const size_t lds = ((size_t)2 * R * a.pitch + (size_t)R * a.join_n) * sizeof(float);
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<true>), lds, "emx_mlp_backward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(mlp_backward_kernel, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, d, layer_begin, layer_end, dtop, ld_top, dadd,
-                     layer_add, lg, dbelow, row_begin, row_end, pitch);
-  return emx::check_launch("mlp_backward_kernel");
+  hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
+  return emx::check_launch("mlp chain kernel (backward)");
 }
 
 int emx_mlp_wgrad_slices(int n_rows) { return std::max((n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS, 1); }
@@ -632,3 +766,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 }
 
 }  // extern "C"
+
+#ifdef EMX_CHAIN_TIMING
+extern "C" int emx_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg), sizeof(emx_dbg)); }
+#endif

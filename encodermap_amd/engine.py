@@ -290,11 +290,12 @@ class SequentialEngine:
         p = self.p
         reg_job = (self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)
         if self.dp.active:
-            _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2)
+            _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2,
+                           plan=self.plan)
             jobs = [reg_job]
         else:
             _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
-                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2)
+                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan)
             jobs = self._jobs_pre() + [reg_job]
         _lib.finish_step(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
 
@@ -323,6 +324,7 @@ class SequentialEngine:
         def restore():
             for t, sv in zip(self._state_tensors(), saved):
                 t.copy_(sv)
+            self.plan.refresh_mirror()
 
         restore()
         if self.dp.active:
@@ -416,7 +418,7 @@ class SequentialEngine:
         n = x_dev.shape[0]
         h = [torch.empty(n, l.n_out, dtype=torch.float32, device=self.device) if l0 <= i < l1 else None
              for i, l in enumerate(lay.layers)]
-        plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers))
+        plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers), mirror=self.plan.mirror)
         _lib.mlp_forward(plan, l0, l1, x_dev, 0, n)
         return h[l1 - 1]
 
@@ -465,6 +467,7 @@ class SequentialEngine:
 
     def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
         self.w.copy_(torch.from_numpy(pack_weights(self.layout, arrays)).to(self.device))
+        self.plan.refresh_mirror()
 
     def state_dict(self) -> dict:
         torch.cuda.synchronize(self.device)
@@ -475,5 +478,7 @@ class SequentialEngine:
         for name in ("w", "m", "v"):
             if name in sd:
                 getattr(self, name).copy_(torch.from_numpy(np.asarray(sd[name], np.float32)).to(self.device))
+        if "w" in sd:
+            self.plan.refresh_mirror()
         if "step" in sd:
             self.step.fill_(int(sd["step"]))

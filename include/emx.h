@@ -155,6 +155,18 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
 int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_begin, int row_end,
                             float* loss, float* dZ, int accumulate, emx_stream_t stream);
 
+/* description of the dense network (see K12 below); declared here because the optimizer keeps the operand store of the
+ * dense-layer kernels current */
+#define EMX_MAX_LAYERS 8
+#define EMX_WGRAD_SLICE_ROWS 128
+typedef struct {
+  int n_layers;
+  int width[EMX_MAX_LAYERS + 1];
+  int act[EMX_MAX_LAYERS];
+  int64_t w_off[EMX_MAX_LAYERS];
+  int64_t b_off[EMX_MAX_LAYERS];
+} emx_mlp_desc;
+
 /* ------------------------------------------------------------------------------------------------ *
  * K11 + K10  fused clip -> Adam on the flat parameter buffer, L2 regulariser folded in
  *   replaces: tf.keras.optimizers.Adam(lr, clipvalue=1.0).apply_gradients  encodermap/autoencoder/autoencoder.py:741-743,
@@ -168,14 +180,16 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
  * ------------------------------------------------------------------------------------------------ */
 int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n,
                   float lr, float beta1, float beta2, float eps, float clip,
-                  const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
+                  const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */,
+                  const emx_mlp_desc* mirror_desc /* may be NULL */, float* mirror /* may be NULL: operand store (emx_mlp_mirror) rewritten
+                  with the new kernels */, emx_stream_t stream);
 
 /* emx_adam_step on the weight-gradient slice partials left by emx_mlp_wgrad (gradient = fixed-order sum over n_slices slices of
  * g_partials[s * partial_stride + i]); no separate reduction pass.  ws[0 .. EMX_REDUCE_WS) receives partials of the regulariser
  * cost (summed by emx_finish_step). */
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         emx_stream_t stream);
+                         const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream);
 
 /* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
  * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
@@ -185,7 +199,7 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
 int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
                   const float* l2coef, int64_t n, float lr, float beta1, float beta2, float eps, float clip, int64_t* opt_step,
                   float* terms, int n_terms, int reg_slot, float* history, float* term_history, int64_t capacity, int64_t* hstep,
-                  int64_t* cursor, float* ws, emx_stream_t stream);
+                  int64_t* cursor, float* ws, const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream);
 
 /* Scalar epilogue of a step in ONE single-workgroup launch: every job adds `n` floats (or their squares) in a fixed order
  * and stores scale * (*dev_scale) * sum into terms[slot]; with hstep != NULL the bookkeeping of emx_step_tick follows
@@ -221,25 +235,24 @@ int emx_step_tick(const float* terms, int n_terms, float* history, float* term_h
  *   d loss / d pre-activation of layer l.  Layer ranges let a data-parallel rank run the encoder on all rows and
  *   the decoder on its own row block.
  * ------------------------------------------------------------------------------------------------ */
-#define EMX_MAX_LAYERS 8
-#define EMX_WGRAD_SLICE_ROWS 128
-typedef struct {
-  int n_layers;
-  int width[EMX_MAX_LAYERS + 1];
-  int act[EMX_MAX_LAYERS];
-  int64_t w_off[EMX_MAX_LAYERS];
-  int64_t b_off[EMX_MAX_LAYERS];
-} emx_mlp_desc;
+
+/* Operand store ("mirror"): a second flat buffer holding, per layer, the kernel in the order the row-block kernels stream
+ * it -- for the forward pass (B[k = in][j = out]) and for the backward-data pass (B[k = out][j = in]) -- as 1-KB blocks
+ * [tile of 16 j][step of 16 k][lane = 16 g + m][i < 4] = B[16 q + 4 g + i][16 t + m], zero padded; the [in, out] kernel
+ * itself would be read with half-used cache lines in either direction.  emx_mlp_mirror_floats floats; emx_mlp_mirror
+ * builds it from `params`, emx_adam_step* keep it current when they are handed the descriptor. */
+size_t emx_mlp_mirror_floats(const emx_mlp_desc* desc);
+int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror, emx_stream_t stream);
 
 /* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
-int emx_mlp_forward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* in, int ld_in,
-                    int row_begin, int row_end, float* const* h, emx_stream_t stream);
+int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                    int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and
  *   the encoder can be back-propagated by separate launches (the decoder's overlaps the all-pairs kernel). */
-int emx_mlp_backward(const emx_mlp_desc* desc, float* params, int layer_begin, int layer_end, const float* dtop, int ld_top,
-                     const float* dadd, int layer_add, const emx_latent_grad* latent /* may be NULL; joins at layer_add */,
+int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
+                     int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent /* may be NULL; joins at layer_add */,
                      float* dbelow, int row_begin, int row_end, float* const* h, float* const* delta, emx_stream_t stream);
 /* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
  * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials

@@ -142,3 +142,32 @@ def test_mlp_rejects_bad_arguments(L):
         L.mlp_forward(plan, 2, 1, x, 0, 4)
     with pytest.raises(L.EmxError, match="workspace"):
         L.mlp_wgrad(plan, 0, 4, x, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net_dim,n_neurons", [(128, [128, 128, 2]), (37, [50, 3]), (300, [136, 20, 2])])
+def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
+    """The optimizer rewrites every kernel element at its two places in the operand store of the dense-layer kernels
+    (include/emx.h, emx_mlp_mirror): after an update the store must equal a fresh emx_mlp_mirror of the new weights."""
+    from encodermap_amd.layout import build_layout, init_parameters
+
+    afs = [""] + ["tanh"] * (len(n_neurons) - 1) + [""]
+    lay = build_layout(n_neurons, afs, net_dim)
+    params = torch.from_numpy(init_parameters(lay, 3)).cuda()
+    bufs = [torch.zeros(4, l.n_out, device="cuda") for l in lay.layers]
+    plan = L.MlpPlan(lay, params, bufs, bufs)
+    g = torch.randn_like(params)
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
+    before = plan.mirror.clone()
+    for _ in range(2):
+        L.adam_step(params, g, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, plan=plan)
+    fresh = L.MlpPlan(lay, params, bufs, bufs)
+    assert not torch.equal(before, plan.mirror)
+    assert torch.equal(fresh.mirror, plan.mirror)
+    # slice-partial form
+    parts = torch.randn(3, params.numel(), device="cuda")
+    L.adam_step_slices(params, parts, 3, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, ws, plan=plan)
+    fresh = L.MlpPlan(lay, params, bufs, bufs)
+    assert torch.equal(fresh.mirror, plan.mirror)

@@ -1,0 +1,32 @@
+"""Reads the in-kernel timestamps of an ABL_TIMING build of mlp_forward_kernel (kernel experiments)."""
+import sys, os, ctypes
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from encodermap_amd import _lib
+_lib.LIB_PATH = os.path.abspath(sys.argv[1])
+from encodermap_amd.layout import build_layout, init_parameters
+lib = _lib.load()
+B, D = 4096, 128
+lay = build_layout([128, 128, 2], ["", "tanh", "tanh", ""], D)
+n = len(lay.layers)
+params = torch.from_numpy(init_parameters(lay, 0)).cuda()
+h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+dl = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+plan = _lib.MlpPlan(lay, params, h, dl)
+x = torch.randn(B, D, device="cuda")
+for _ in range(20): _lib.mlp_forward(plan, 0, n, x, 0, B)
+torch.cuda.synchronize()
+buf = np.zeros(8192, dtype=np.int64)
+lib.emx_debug_read.argtypes = [ctypes.c_void_p]
+assert lib.emx_debug_read(buf.ctypes.data) == 0
+for blk in (0, 1):
+    clk = buf[blk * 2048: blk * 2048 + 512].reshape(8, 64); wall = clk * 0
+    nslot = 3 + 5 * n
+    for w in (0, 3, 7):
+        c = clk[w, :nslot] - clk[w, 0]; t = c * 0
+        print(f"block {blk*100} wave {w}: total {c[-1]} clk, {t[-1]} ns -> {c[-1]/max(t[-1],1):.2f} GHz")
+        print("  clk  pre:", c[1], c[2], "| per layer [issue loads, mma, epilogue+copy, barrier]:")
+        for l in range(n):
+            s3, s5, s6, s7 = (c[3 + 5 * l], c[5 + 5 * l], c[6 + 5 * l], c[7 + 5 * l])
+            prev = c[2] if l == 0 else c[7 + 5 * (l - 1)]
+            print(f"   u{l}: start {prev:6d}  head {s3-prev:5d}  mfma+requests {s5-s3:5d}  epilogue {s6-s5:5d}  barrier {s7-s6:5d}")
