@@ -64,6 +64,8 @@ SIGNATURES = {
     "emx_mlp_mirror_floats": (_sz, [_p]),
     "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "emx_mlp_row_blocks": (_i, [_i]),
+    "emx_mlp_forward_fused": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
@@ -77,6 +79,34 @@ class LatentGrad(C.Structure):
     """Mirror of ``emx_latent_grad``."""
 
     _fields_ = [("partials", _p), ("Z", _p), ("slot_stride", _l), ("n_slots", _i), ("row_base", _i), ("gscale", _f), ("center_grad", _f)]
+
+
+class Feed(C.Structure):
+    """Mirror of ``emx_feed``: the data feed folded into the forward launch."""
+
+    _fields_ = [("data", _p), ("n_rows", _l), ("D", _i), ("idx", _p), ("cursor", _p), ("B", _i), ("periodicity", _f), ("xb", _p), ("xin", _p)]
+
+
+class AutoCost(C.Structure):
+    """Mirror of ``emx_auto_cost``: the auto cost folded into the forward launch."""
+
+    _fields_ = [("target", _p), ("ldt", _i), ("n", _i), ("off_sin", _i), ("off_cos", _i), ("periodic_output", _i), ("periodicity", _f),
+                ("variant", _i), ("coef", _f), ("B", _i), ("dY", _p), ("ws", _p)]
+
+
+def make_feed(data, idx, cursor, B, periodicity, xb, xin) -> Feed:
+    N, D = data.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and data.is_contiguous()
+    f = Feed(_ptr(data), N, D, _ptr(idx), _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin))
+    f.keep = (data, idx, cursor, xb, xin)
+    return f
+
+
+def make_auto_cost(target, n, off_sin, off_cos, periodic_output, periodicity, variant, coef, B, dY, ws) -> AutoCost:
+    c = AutoCost(_ptr(target), target.stride(0), int(n), int(off_sin), int(off_cos), int(bool(periodic_output)), float(periodicity),
+                 VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef), int(B), _ptr(dY), _ptr(ws))
+    c.keep = (target, dY, ws)
+    return c
 
 
 class SketchmapPartials(C.Structure):
@@ -302,9 +332,21 @@ def step_tick(terms, n_terms, history, term_history, step, cursor=None, counter2
                                 _stream()), "emx_step_tick")
 
 
-def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end):
-    _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin), int(row_end),
-                                  plan.h, _stream()), "emx_mlp_forward")
+def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, feed: "Feed" = None, cost: "AutoCost" = None):
+    """Layers [l0, l1) on rows [row_begin, row_end).  ``feed`` gathers the rows from the resident data set instead of
+    reading ``x`` (which may then be None); ``cost`` evaluates the auto cost on the last layer's rows in the same launch."""
+    if feed is None and cost is None:
+        _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
+                                      int(row_end), plan.h, _stream()), "emx_mlp_forward")
+        return
+    _check(load().emx_mlp_forward_fused(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1,
+                                        C.byref(feed) if feed is not None else None, _ptr(x), x.stride(0) if x is not None else 0,
+                                        int(row_begin), int(row_end), plan.h, C.byref(cost) if cost is not None else None, _stream()),
+           "emx_mlp_forward_fused")
+
+
+def mlp_row_blocks(n_rows):
+    return int(load().emx_mlp_row_blocks(int(n_rows)))
 
 
 def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None):

@@ -2,6 +2,7 @@
 // Every kernel here is HBM- or launch-latency-bound: rows are walked by whole waves with 16-byte lanes
 // where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
 #include "emx_common.h"
+#include "cost.h"
 #include "mirror.h"
 
 namespace {
@@ -75,60 +76,6 @@ __global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restric
 // K5: row-mean cost on periodic differences, fused with PeriodicOutput (atan2) forward + backward.
 // one wave per row (two passes over the row for mean_norm); per-block partial -> ws, final sum below.
 // ---------------------------------------------------------------------------------------------------
-struct CostArgs {
-  const float* y;
-  const float* target;
-  const float* dpred_add;
-  const float* coef_scale;
-  float* dY;
-  float* ws;
-  float* loss;
-  int ldy, ldt, off_sin, off_cos, periodic_output;
-  int n, row_begin, row_end, variant, wrap, prescale;
-  float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
-};
-
-__device__ __forceinline__ void cost_elem(const CostArgs& a, const float* yrow, const float* trow, int k, float& pred_s,
-                                          float& pred_c, float& delta, float& ddelta) {
-  float pred;
-  if (a.periodic_output) {
-    pred_s = yrow[a.off_sin + k];
-    pred_c = yrow[a.off_cos + k];
-    pred = atan2f(pred_s, pred_c) * a.out_scale;
-  } else {
-    pred_s = pred_c = 0.f;
-    pred = yrow[a.off_sin + k];
-  }
-  float diff = pred - trow[k];
-  float d = fabsf(diff);
-  float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
-  if (a.wrap) {
-    float w = a.period - d;
-    if (d <= w) {
-      delta = d;
-      ddelta = sgn;
-    } else {
-      delta = w;
-      ddelta = -sgn;
-    }
-  } else {
-    delta = d;
-    ddelta = sgn;
-  }
-}
-
-__device__ __forceinline__ void cost_store(const CostArgs& a, float* drow, const float* addrow, int k, float g, float s, float c) {
-  if (!drow) return;
-  if (addrow) g += addrow[k];
-  if (a.periodic_output) {
-    float inv = a.out_scale / (s * s + c * c);
-    drow[a.off_sin + k] = g * c * inv;
-    drow[a.off_cos + k] = -g * s * inv;
-  } else {
-    drow[a.off_sin + k] = g;
-  }
-}
-
 __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
   __shared__ float red[8];
   const int lane = threadIdx.x & 63;
@@ -455,21 +402,10 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   a.loss = loss;
   a.dY = dY;
   a.ws = ws;
-  a.ldy = ldy;
-  a.ldt = ldt;
-  a.off_sin = off_sin;
-  a.off_cos = off_cos;
-  a.periodic_output = periodic_output;
-  a.n = n;
+  fill_cost_scalars(a, B, n, ldy, ldt, off_sin, off_cos, periodic_output, periodicity, variant, coef);
   a.row_begin = row_begin;
   a.row_end = row_end;
-  a.variant = variant;
-  a.wrap = std::isfinite(periodicity);
   a.prescale = loss ? 0 : 1;
-  a.period = periodicity;
-  a.out_scale = (a.wrap && periodicity != TWO_PI) ? periodicity / TWO_PI : 1.f;
-  const double denom = (variant == EMX_MEAN_NORM) ? (double)B : (double)B * n;
-  a.gnorm = (float)(coef / denom);
   const int grid = grid_for(row_end - row_begin, 4);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);

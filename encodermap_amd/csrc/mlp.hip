@@ -20,6 +20,7 @@
 // Lane maps (cdna_hip_programming.md section 3): 16x16x4: A[m = lane&15][k = lane>>4], B[k = lane>>4][n = lane&15],
 // D[row = 4*(lane>>4) + reg][col = lane&15].  k-assignment used here: in K-step q lane group g = lane>>4 supplies
 // k = 16q + 4g + i for the i-th of four consecutive MFMAs, so a lane's four A (or W-row) values are contiguous.
+#include "cost.h"
 #include "emx_common.h"
 #include "mirror.h"
 
@@ -123,6 +124,18 @@ struct ChainArgs {
   const float* dadd;
   emx_latent_grad lg;
   int join_n;           // width of the joined layer (0: no join)
+  // forward only, optional data feed (replaces emx_gather_rows in front of the first layer): the row block is gathered by
+  // index from the resident data set, expanded to [sin | cos] for periodic data, and also written out (xb raw, xin expanded)
+  const float* feed_data;   // null: rows come from `in`
+  const int64_t* feed_idx;
+  const int64_t* feed_cursor;
+  int feed_D, feed_B, feed_periodic;
+  float feed_ang;
+  float* feed_xb;
+  float* feed_xin;
+  // forward only, optional auto cost on the rows of the last layer (replaces emx_periodic_cost_fwd_bwd behind it):
+  // cost.dY receives d cost / d output, cost.ws[workgroup] the workgroup's share of the cost
+  CostArgs cost;
 };
 
 #ifdef EMX_CHAIN_TIMING   // in-kernel timeline (tools/abl_timing.py); stamps go to LDS so that they do not touch vmcnt
@@ -214,7 +227,30 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int sr = tid >> 5, sK = a.in_cols;
   const bool srok = r0 + sr < a.row_end;
   const long sgrow = (long)min(r0 + sr, a.row_end - 1);
+  long feed_row = 0;
+  if (!BWD && a.feed_data != nullptr) feed_row = a.feed_idx[(a.feed_cursor ? *a.feed_cursor : 0) * (long)a.feed_B + sgrow];
   auto stage_load = [&](int c, float (&v)[4]) {
+    if (!BWD && a.feed_data != nullptr) {
+      const int D = a.feed_D;
+      const float* __restrict__ src = a.feed_data + feed_row * D;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int k = min(c + i, sK - 1);
+        const float raw = src[k < D ? k : k - D];
+        float val = raw;
+        if (a.feed_periodic) {
+          float sn, cs;
+          sincosf(raw * a.feed_ang, &sn, &cs);
+          val = k < D ? sn : cs;
+        }
+        v[i] = val;
+        if (srok && c + i < sK) {
+          if (a.feed_xb != nullptr && k < D) a.feed_xb[sgrow * D + k] = raw;
+          if (a.feed_xin != nullptr) a.feed_xin[sgrow * sK + k] = val;
+        }
+      }
+      return;
+    }
     const float* __restrict__ src = a.in + sgrow * a.ld_in;
     if ((((a.ld_in | sK) & 3) == 0) && c < sK) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(src + c);
@@ -277,8 +313,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
       pend_bytes = 0;
     }
-    if (ui == -(NB - 1)) {
-      if (sc0 < pitch) stage_load(sc0, sv);   // the row block itself travels ahead of the first package
+    if (ui == -(NB - 2)) {
+      // the row block itself: behind the first package (whose request must not wait for the gather index), ahead of the rest
+      if (sc0 < pitch) stage_load(sc0, sv);
       TSTAMP(1);
     }
     request_epi(Lq, e[r]);
@@ -305,7 +342,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const UnitExec Xn = a.ux[max(0, min(ui + 1, nu - 1))];
     Lq = Ln;
 
-    if (ui == -(NB - 1)) {
+    if (ui == -1) {
       if (sc0 < pitch) stage_store(sc0, sv);
       for (int c = sc0 + 128; c < pitch; c += 128) {
         float v[4];
@@ -364,6 +401,52 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend_base), 0, pend_bytes, 0x00020000);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
+  }
+  if (!BWD && a.cost.dY != nullptr) {
+    // auto cost on the last layer's rows, which are complete in the current LDS image: 32 threads per row
+    __shared__ float cred[NTC / 64];
+    const CostArgs& cst = a.cost;
+    const int row = tid >> 5, l32 = tid & 31;
+    const bool rok = r0 + row < a.row_end;
+    const long grow = (long)min(r0 + row, a.row_end - 1);
+    const float* yrow = lds + buf * img + row * pitch;
+    const float* trow = cst.target + grow * cst.ldt;
+    float* drow = rok ? cst.dY + grow * cst.ldy : nullptr;
+    float lsum = 0.f;
+    if (cst.variant == EMX_MEAN_NORM) {
+      float ss = 0.f;
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        ss = fmaf(delta, delta, ss);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's 32 lanes
+      const float nrm = sqrtf(ss);
+      const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
+      if (l32 == 0 && rok) lsum = nrm;
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        cost_store(cst, drow, nullptr, k, cst.gnorm * delta * inv * dd, sn, cs);
+      }
+    } else {
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        float gq;
+        if (cst.variant == EMX_MEAN_ABS) {
+          if (rok) lsum += fabsf(delta);
+          gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+        } else {
+          if (rok) lsum = fmaf(delta, delta, lsum);
+          gq = 2.f * delta * dd;
+        }
+        cost_store(cst, drow, nullptr, k, cst.gnorm * gq, sn, cs);
+      }
+    }
+    const float tsum = block_sum<NTC>(lsum, cred);
+    if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   }
 #ifdef EMX_CHAIN_TIMING
   __syncthreads();
@@ -630,25 +713,60 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
   return emx::check_launch("mlp_mirror_kernel");
 }
 
-int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
-                    int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream) {
+int emx_mlp_row_blocks(int n_rows) { return std::max((n_rows + R - 1) / R, 1); }
+
+int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const emx_feed* feed,
+                          const float* in, int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost,
+                          emx_stream_t stream) {
   int rc = check_desc(desc, "emx_mlp_forward");
   if (rc) return rc;
-  EMX_REQUIRE(params && mirror && in && h, "emx_mlp_forward: null pointer argument");
+  EMX_REQUIRE(params && mirror && h && (in || feed), "emx_mlp_forward: null pointer argument");
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "emx_mlp_forward: bad rows");
   ChainArgs a{};
+  const int in_cols = desc->width[layer_begin];
+  if (feed) {
+    const bool periodic = std::isfinite(feed->periodicity);
+    EMX_REQUIRE(feed->data && feed->idx && feed->n_rows > 0 && feed->D > 0 && feed->B >= row_end, "emx_mlp_forward: incomplete data feed");
+    EMX_REQUIRE(!periodic || feed->periodicity > 0.f, "emx_mlp_forward: periodic feed needs a positive periodicity");
+    EMX_REQUIRE(in_cols == (periodic ? 2 : 1) * feed->D, "emx_mlp_forward: feed of %d columns (%s) does not match the input width %d", feed->D,
+                periodic ? "periodic" : "plain", in_cols);
+    a.feed_data = feed->data;
+    a.feed_idx = feed->idx;
+    a.feed_cursor = feed->cursor;
+    a.feed_D = feed->D;
+    a.feed_B = feed->B;
+    a.feed_periodic = periodic;
+    a.feed_ang = periodic ? (feed->periodicity == COST_TWO_PI ? 1.f : COST_TWO_PI / feed->periodicity) : 1.f;
+    a.feed_xb = feed->xb;
+    a.feed_xin = feed->xin;
+  } else {
+    EMX_REQUIRE(ld_in >= in_cols, "emx_mlp_forward: bad input stride");
+  }
   for (int l = layer_begin; l < layer_end; ++l) {
     EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
     rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], h[l], desc->act[l] ? S_ACT : 0,
                    "emx_mlp_forward");
     if (rc) return rc;
   }
+  if (cost) {
+    const int wout = desc->width[layer_end];
+    EMX_REQUIRE(cost->target && cost->dY && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0, "emx_mlp_forward: incomplete cost description");
+    EMX_REQUIRE(cost->variant >= EMX_MEAN_ABS && cost->variant <= EMX_MEAN_NORM, "emx_mlp_forward: cost variant %d not available", cost->variant);
+    EMX_REQUIRE(cost->off_sin >= 0 && cost->off_sin + cost->n <= wout &&
+                    (!cost->periodic_output || (cost->off_cos >= 0 && cost->off_cos + cost->n <= wout && std::isfinite(cost->periodicity))),
+                "emx_mlp_forward: cost column window outside the output row");
+    a.cost.target = cost->target;
+    a.cost.dY = cost->dY;
+    a.cost.ws = cost->ws;
+    fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
+                      cost->variant, cost->coef);
+  }
   a.pitch = pitch_for(desc, layer_begin, layer_end);
   a.mbase = mirror;
   a.in = in;
   a.ld_in = ld_in;
-  a.in_cols = desc->width[layer_begin];
+  a.in_cols = in_cols;
   a.row0 = row_begin;
   a.row_end = row_end;
   const size_t lds = (size_t)2 * R * a.pitch * sizeof(float);
@@ -657,6 +775,12 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror
   const int grid = (row_end - row_begin + R - 1) / R;
   hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
   return emx::check_launch("mlp chain kernel (forward)");
+}
+
+int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                    int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream) {
+  EMX_REQUIRE(in, "emx_mlp_forward: null pointer argument");
+  return emx_mlp_forward_fused(desc, params, mirror, layer_begin, layer_end, nullptr, in, ld_in, row_begin, row_end, h, nullptr, stream);
 }
 
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,

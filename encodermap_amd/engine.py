@@ -164,6 +164,7 @@ class SequentialEngine:
         self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.cost_ws = torch.zeros(_lib.mlp_row_blocks(self.re - self.rb), dtype=f32, device=dev)   # auto cost per row block (zero: no auto cost)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
         self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
@@ -201,23 +202,21 @@ class SequentialEngine:
 
     # -- forward / backward ------------------------------------------------------------------------
     def _forward(self) -> None:
-        lay, n = self.layout, len(self.layout.layers)
-        if (self.rb, self.re) == (0, self.B):
-            _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B)
-        else:   # row-block rank: encoder on every row, decoder on the rows it owns
-            _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
-            _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
-
-    def _auto_cost(self) -> None:
-        """auto cost on own rows (global 1/B normalisation), gradient wrt the decoder output straight into dY; the cost's
-        per-workgroup partials stay in ``red_ws`` and are summed by the step's single scalar epilogue"""
-        p = self.p
+        """Data feed, forward pass and auto cost in ONE launch (two for a row-block rank: encoder on every row, decoder and
+        cost on the rows it owns).  The gathered rows, the activations and d cost / d output go to HBM for the kernels
+        that follow; the cost's per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue."""
+        lay, n, p = self.layout, len(self.layout.layers), self.p
+        feed = _lib.make_feed(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
+                              self.xin if self.periodic else None)
+        cost = None
         if p.auto_cost_scale is not None:
-            _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self.periodicity, p.auto_cost_variant,
-                                       float(p.auto_cost_scale), self.rb, self.re, None, self.dY, self.red_ws, B=self.B)
+            cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
+                                       float(p.auto_cost_scale), self.B, self.dY, self.cost_ws)
+        if (self.rb, self.re) == (0, self.B):
+            _lib.mlp_forward(self.plan, 0, n, None, 0, self.B, feed=feed, cost=cost)
         else:
-            self.dY.zero_()
-            self.red_ws.zero_()
+            _lib.mlp_forward(self.plan, 0, lay.n_enc, None, 0, self.B, feed=feed)
+            _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
 
     def _use_sketchmap(self) -> bool:
         return self.with_distance and self.p.distance_cost_scale is not None
@@ -241,7 +240,7 @@ class SequentialEngine:
 
     def _jobs_pre(self) -> list:
         """scalar sums that must be final before a data-parallel all-reduce: (src, n, scale, dev_scale, slot, square)"""
-        jobs = [(self.red_ws, _lib.EMX_REDUCE_WS, 1.0, None, T_AUTO, False)]
+        jobs = [(self.cost_ws, self.cost_ws.numel(), 1.0, None, T_AUTO, False)]
         if self._use_sketchmap():
             sk = self._sk
             Z = self.h[self.layout.n_enc - 1]
@@ -254,20 +253,16 @@ class SequentialEngine:
         kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at the latent layer; they
         run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
         lay, n = self.layout, len(self.layout.layers)
-        _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
-                         self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
         self._forward()
         if self._fork:
             main = torch.cuda.current_stream()
             side = self._side_stream
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                self._auto_cost()
                 _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
             self._latent_costs()
             main.wait_stream(side)
         else:
-            self._auto_cost()
             _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
             self._latent_costs()
         if self._use_sketchmap():

@@ -247,6 +247,44 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
 /* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream);
+/* emx_mlp_forward with the step's neighbours folded into the same launch (their own kernels are a few microseconds of
+ * launch and first-touch latency each):
+ *   feed (may be NULL): the row block is gathered straight from the resident data set -- batch row r is
+ *     data[idx[*cursor * B + r]] -- and expanded to [sin | cos] when `periodicity` is finite, exactly as emx_gather_rows
+ *     does (encodermap/autoencoder/autoencoder.py:845-856, models.py:3347-3351); xb / xin (may be NULL) receive the raw and
+ *     the expanded rows for the kernels that need them later.  `in` is ignored when a feed is given.
+ *   cost (may be NULL): the auto cost of emx_periodic_cost_fwd_bwd evaluated on the rows of layer layer_end-1 while they are
+ *     still on chip: dY [*, width[layer_end]] receives d cost / d output; ws[g], g < emx_mlp_row_blocks(row_end - row_begin),
+ *     the row blocks' shares of the cost, already scaled by coef / (B n) (or coef / B for EMX_MEAN_NORM) -- their
+ *     fixed-order sum (emx_finish_step) is the cost. */
+typedef struct {
+  const float* data;      /* [n_rows, D] resident data set */
+  int64_t n_rows;
+  int D;
+  const int64_t* idx;     /* gather index block */
+  const int64_t* cursor;  /* may be NULL (= 0): device scalar, index of the current batch inside idx */
+  int B;                  /* batch size: rows of idx per cursor step */
+  float periodicity;      /* INFINITY: plain rows */
+  float* xb;              /* may be NULL: [B, D] */
+  float* xin;             /* may be NULL: [B, 2 D], periodic only */
+} emx_feed;
+typedef struct {
+  const float* target;    /* [*, ldt] */
+  int ldt;
+  int n;                  /* compared columns */
+  int off_sin, off_cos;   /* column windows of the prediction inside the output row (off_cos only for periodic_output) */
+  int periodic_output;    /* the output row holds [sin | cos] pairs that are turned into angles first */
+  float periodicity;      /* INFINITY: plain differences */
+  int variant;            /* EMX_MEAN_ABS / EMX_MEAN_SQUARE / EMX_MEAN_NORM */
+  float coef;
+  int B;                  /* global batch size of the normalisation */
+  float* dY;
+  float* ws;
+} emx_auto_cost;
+int emx_mlp_row_blocks(int n_rows);
+int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const emx_feed* feed,
+                          const float* in, int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost,
+                          emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and

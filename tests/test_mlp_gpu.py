@@ -171,3 +171,53 @@ def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
     L.adam_step_slices(params, parts, 3, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, ws, plan=plan)
     fresh = L.MlpPlan(lay, params, bufs, bufs)
     assert torch.equal(fresh.mirror, plan.mirror)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodicity,variant,D,B", [(float("inf"), "mean_square", 128, 4096), (2 * np.pi, "mean_abs", 10, 256),
+                                                     (360.0, "mean_norm", 37, 100), (float("inf"), "mean_norm", 70, 50)])
+def test_forward_with_feed_and_cost_equals_separate_kernels(L, periodicity, variant, D, B):
+    """emx_mlp_forward_fused (data feed + dense layers + auto cost in one launch) against the three stand-alone entry
+    points it replaces (emx_gather_rows, emx_mlp_forward, emx_periodic_cost_fwd_bwd): same rows, same activations, same
+    cost and the same gradient with respect to the output."""
+    from encodermap_amd.layout import build_layout, init_parameters
+
+    periodic = np.isfinite(periodicity)
+    net_dim = 2 * D if periodic else D
+    lay = build_layout([64, 48, 2], ["", "tanh", "tanh", ""], net_dim)
+    n = len(lay.layers)
+    params = torch.from_numpy(init_parameters(lay, 5)).cuda()
+    g = torch.Generator().manual_seed(0)
+    N = 1000
+    data = ((torch.rand(N, D, generator=g) - 0.5) * (periodicity if periodic else 6.0)).cuda()
+    idx = torch.randint(0, N, (3 * B,), generator=g).cuda()
+    cursor = torch.tensor([2], dtype=torch.int64, device="cuda")
+    coef = 0.7
+
+    def buffers():
+        return ([torch.zeros(B, l.n_out, device="cuda") for l in lay.layers], torch.zeros(B, D, device="cuda"),
+                torch.zeros(B, net_dim, device="cuda") if periodic else None, torch.zeros(B, net_dim, device="cuda"))
+
+    # separate kernels
+    h1, xb1, xin1, dY1 = buffers()
+    plan1 = L.MlpPlan(lay, params, h1, h1)
+    L.gather_rows(data, idx, periodicity, xb1, xin1, cursor=cursor, B=B)
+    L.mlp_forward(plan1, 0, n, xin1 if periodic else xb1, 0, B)
+    loss1 = torch.zeros(1, device="cuda")
+    ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
+    L.periodic_cost_fwd_bwd(h1[-1], 0, D, periodic, xb1, D, periodicity, variant, coef, 0, B, loss1, dY1, ws, B=B)
+    # one launch
+    h2, xb2, xin2, dY2 = buffers()
+    plan2 = L.MlpPlan(lay, params, h2, h2)
+    cost_ws = torch.zeros(L.mlp_row_blocks(B), device="cuda")
+    feed = L.make_feed(data, idx, cursor, B, periodicity, xb2, xin2)
+    cost = L.make_auto_cost(xb2, D, 0, D, periodic, periodicity, variant, coef, B, dY2, cost_ws)
+    L.mlp_forward(plan2, 0, n, None, 0, B, feed=feed, cost=cost)
+    torch.cuda.synchronize()
+    assert torch.equal(xb1, xb2)
+    if periodic:
+        assert torch.equal(xin1, xin2)
+    for a, b in zip(h1, h2):
+        assert torch.equal(a, b)
+    np.testing.assert_allclose(dY2.cpu().numpy(), dY1.cpu().numpy(), rtol=1e-6, atol=1e-9)
+    assert float(cost_ws.double().sum()) == pytest.approx(float(loss1), rel=1e-5)
