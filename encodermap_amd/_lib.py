@@ -46,8 +46,8 @@ SIGNATURES = {
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
-    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
-    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
+    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
+    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
     "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
@@ -65,7 +65,7 @@ SIGNATURES = {
     "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "emx_mlp_row_blocks": (_i, [_i]),
-    "emx_mlp_forward_fused": (_i, [_p, _p, _p, _i, _i, _p, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
@@ -81,10 +81,19 @@ class LatentGrad(C.Structure):
     _fields_ = [("partials", _p), ("Z", _p), ("slot_stride", _l), ("n_slots", _i), ("row_base", _i), ("gscale", _f), ("center_grad", _f)]
 
 
-class Feed(C.Structure):
-    """Mirror of ``emx_feed``: the data feed folded into the forward launch."""
+class NextBatch(C.Structure):
+    """Mirror of ``emx_next_batch``: the rows of batch cursor + 1, gathered beside the optimizer."""
 
-    _fields_ = [("data", _p), ("n_rows", _l), ("D", _i), ("idx", _p), ("cursor", _p), ("B", _i), ("periodicity", _f), ("xb", _p), ("xin", _p)]
+    _fields_ = [("data", _p), ("n_rows", _l), ("D", _i), ("idx", _p), ("n_batches", _i), ("cursor", _p), ("B", _i), ("periodicity", _f),
+                ("xb", _p), ("xin", _p)]
+
+
+def make_next_batch(data, idx, cursor, B, periodicity, xb, xin) -> NextBatch:
+    N, D = data.shape
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and data.is_contiguous() and idx.numel() % B == 0
+    nb = NextBatch(_ptr(data), N, D, _ptr(idx), idx.numel() // B, _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin))
+    nb.keep = (data, idx, cursor, xb, xin)
+    return nb
 
 
 class AutoCost(C.Structure):
@@ -92,14 +101,6 @@ class AutoCost(C.Structure):
 
     _fields_ = [("target", _p), ("ldt", _i), ("n", _i), ("off_sin", _i), ("off_cos", _i), ("periodic_output", _i), ("periodicity", _f),
                 ("variant", _i), ("coef", _f), ("B", _i), ("dY", _p), ("ws", _p)]
-
-
-def make_feed(data, idx, cursor, B, periodicity, xb, xin) -> Feed:
-    N, D = data.shape
-    assert idx.dtype == torch.int64 and idx.is_contiguous() and data.is_contiguous()
-    f = Feed(_ptr(data), N, D, _ptr(idx), _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin))
-    f.keep = (data, idx, cursor, xb, xin)
-    return f
 
 
 def make_auto_cost(target, n, off_sin, off_cos, periodic_output, periodicity, variant, coef, B, dY, ws) -> AutoCost:
@@ -297,19 +298,21 @@ def _mirror_args(plan):
     return C.byref(plan.desc), _ptr(plan.mirror)
 
 
-def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws, plan=None):
+def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws, plan=None, next_batch=None):
     md, mp = _mirror_args(plan)
+    nb = C.byref(next_batch) if next_batch is not None else None
     _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
                                 float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), md, mp,
-                                _stream()), "emx_adam_step")
+                                nb, _stream()), "emx_adam_step")
 
 
-def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None):
+def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None, next_batch=None):
     n = w.numel()
     md, mp = _mirror_args(plan)
+    nb = C.byref(next_batch) if next_batch is not None else None
     _check(load().emx_adam_step_slices(_ptr(w), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
                                        float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step),
-                                       _ptr(ws), md, mp, _stream()), "emx_adam_step_slices")
+                                       _ptr(ws), md, mp, nb, _stream()), "emx_adam_step_slices")
 
 
 def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
@@ -332,17 +335,10 @@ def step_tick(terms, n_terms, history, term_history, step, cursor=None, counter2
                                 _stream()), "emx_step_tick")
 
 
-def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, feed: "Feed" = None, cost: "AutoCost" = None):
-    """Layers [l0, l1) on rows [row_begin, row_end).  ``feed`` gathers the rows from the resident data set instead of
-    reading ``x`` (which may then be None); ``cost`` evaluates the auto cost on the last layer's rows in the same launch."""
-    if feed is None and cost is None:
-        _check(load().emx_mlp_forward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
-                                      int(row_end), plan.h, _stream()), "emx_mlp_forward")
-        return
-    _check(load().emx_mlp_forward_fused(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1,
-                                        C.byref(feed) if feed is not None else None, _ptr(x), x.stride(0) if x is not None else 0,
-                                        int(row_begin), int(row_end), plan.h, C.byref(cost) if cost is not None else None, _stream()),
-           "emx_mlp_forward_fused")
+def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" = None):
+    """Layers [l0, l1) on rows [row_begin, row_end); ``cost`` evaluates the auto cost on the last layer's rows in the same launch."""
+    _check(load().emx_mlp_forward_cost(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
+                                       int(row_end), plan.h, C.byref(cost) if cost is not None else None, _stream()), "emx_mlp_forward")
 
 
 def mlp_row_blocks(n_rows):

@@ -37,6 +37,8 @@ def _round4(n: int) -> int:
 
 
 class ADCEngine(SequentialEngine):
+    _prefetch = False   # the feature block is assembled inside the step (gather + featurisation)
+
     TERM_NAMES = ADC_TERM_NAMES
     _reg_slot = T_REG
 

@@ -26,26 +26,45 @@ namespace {
 // K13 + K4: gather rows by index, optionally emit [sin | cos]      autoencoder.py:845-856, models.py:3347-3351
 // one wave per row; lanes stride the feature axis (coalesced 256-B segments of the gathered row)
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void gather_rows_kernel(const float* __restrict__ data, int D, const int64_t* __restrict__ idx,
-                                                         const int64_t* __restrict__ cursor, int B, float ang_scale,
-                                                         float* __restrict__ xb, float* __restrict__ xin) {
-  if (cursor) idx += *cursor * (long)B;
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * NT) >> 6;
-  for (int b = wave; b < B; b += nwaves) {
-    const float* src = data + idx[b] * (long)D;
+struct GatherArgs {
+  const float* data;
+  int D;
+  const int64_t* idx;
+  const int64_t* cursor;
+  int B;
+  int batch_step;     // gather batch *cursor + batch_step ...
+  int n_batches;      // ... unless that is >= n_batches (0: no bound)
+  float ang_scale;
+  float* xb;
+  float* xin;
+};
+
+// rows b = wave, wave + nwaves, ... of the batch
+__device__ __forceinline__ void gather_rows_body(const GatherArgs& g, int wave, int nwaves, int lane) {
+  const int64_t* __restrict__ idx = g.idx;
+  if (g.cursor) {
+    const long batch = *g.cursor + g.batch_step;
+    if (g.n_batches > 0 && batch >= g.n_batches) return;
+    idx += batch * (long)g.B;
+  }
+  const int D = g.D;
+  for (int b = wave; b < g.B; b += nwaves) {
+    const float* __restrict__ src = g.data + idx[b] * (long)D;
     for (int k = lane; k < D; k += 64) {
-      float v = src[k];
-      if (xb) xb[(long)b * D + k] = v;
-      if (xin) {
+      const float v = src[k];
+      if (g.xb) g.xb[(long)b * D + k] = v;
+      if (g.xin) {
         float s, c;
-        sincosf(v * ang_scale, &s, &c);
-        xin[(long)b * 2 * D + k] = s;
-        xin[(long)b * 2 * D + D + k] = c;
+        sincos_bounded(v * g.ang_scale, &s, &c);
+        g.xin[(long)b * 2 * D + k] = s;
+        g.xin[(long)b * 2 * D + D + k] = c;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(NT) void gather_rows_kernel(const GatherArgs g) {
+  gather_rows_body(g, (blockIdx.x * NT + threadIdx.x) >> 6, (gridDim.x * NT) >> 6, threadIdx.x & 63);
 }
 
 __global__ __launch_bounds__(NT) void periodic_in_kernel(const float* __restrict__ x, int B, int D, int ldx, float ang_scale,
@@ -55,7 +74,7 @@ __global__ __launch_bounds__(NT) void periodic_in_kernel(const float* __restrict
   for (; e < n; e += (long)gridDim.x * NT) {
     int b = (int)(e / D), k = (int)(e - (long)b * D);
     float s, c;
-    sincosf(x[(long)b * ldx + k] * ang_scale, &s, &c);
+    sincos_bounded(x[(long)b * ldx + k] * ang_scale, &s, &c);
     out[(long)b * ldo + k] = s;
     out[(long)b * ldo + D + k] = c;
   }
@@ -171,6 +190,8 @@ struct AdamArgs {
   float lr, b1, b2, eps, clip;
   float* mirror;        // optional: operand store of the dense layers, rewritten with the new weights (mirror.h)
   MirrorArgs mir;
+  int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
+  GatherArgs next;
 };
 
 __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float l2c, const AdamArgs& a, float alpha,
@@ -207,6 +228,14 @@ __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
 
 __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   __shared__ float red[8];
+  if ((int)blockIdx.x >= a.adam_blocks) {
+    // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
+    // beside it, on other CUs, instead of in a launch of their own at the head of the next step
+    const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks;
+    gather_rows_body(a.next, (gb * NT + threadIdx.x) >> 6, (ngb * NT) >> 6, threadIdx.x & 63);
+    return;
+  }
+  const int nblk = a.adam_blocks;
   const float t = (float)(*a.step + 1);
   // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step)
   const float alpha = a.lr * sqrtf(1.f - powf(a.b2, t)) / (1.f - powf(a.b1, t));
@@ -217,7 +246,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
                      (uintptr_t)(a.gstride * 4)) & 15) == 0;
   long start = 0;
   if (vec) {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)nblk * NT) {
       float4 w = reinterpret_cast<float4*>(a.w)[i];
       float4 g = grad4(a, i);
       float4 m = reinterpret_cast<float4*>(a.m)[i];
@@ -239,7 +268,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     }
     start = n4 << 2;
   }
-  for (long i = start + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += (long)gridDim.x * NT) {
+  for (long i = start + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += (long)nblk * NT) {
     float w = a.w[i], m = a.m[i], v = a.v[i];
     float g;
     if (a.gpart) {
@@ -257,7 +286,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   float tsum = block_sum<NT>(reg, red);
   if (threadIdx.x == 0) a.ws[blockIdx.x] = tsum;
   if (blockIdx.x == 0)
-    for (int i = gridDim.x + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
+    for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
 }
 
 __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
@@ -356,8 +385,8 @@ int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, con
   EMX_REQUIRE(data && idx && (xb || xin), "emx_gather_rows: null pointer argument");
   EMX_REQUIRE(N > 0 && D > 0 && B > 0, "emx_gather_rows: bad shape N=%ld D=%d B=%d", (long)N, D, B);
   EMX_REQUIRE(!xin || (std::isfinite(periodicity) && periodicity > 0.f), "emx_gather_rows: sin/cos output needs a finite periodicity");
-  float ang = xin ? (periodicity == TWO_PI ? 1.f : TWO_PI / periodicity) : 1.f;
-  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, 4)), dim3(NT), 0, (hipStream_t)stream, data, D, idx, cursor, B, ang, xb, xin);
+  GatherArgs g{data, D, idx, cursor, B, 0, 0, xin ? (periodicity == TWO_PI ? 1.f : TWO_PI / periodicity) : 1.f, xb, xin};
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, 4)), dim3(NT), 0, (hipStream_t)stream, g);
   return emx::check_launch("gather_rows_kernel");
 }
 
@@ -426,10 +455,23 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 }
 
 namespace {
+int check_next(const emx_next_batch* next, const char* who) {
+  if (!next) return EMX_OK;
+  EMX_REQUIRE(next->data && next->idx && next->cursor && (next->xb || next->xin), "%s: incomplete next-batch description", who);
+  EMX_REQUIRE(next->n_rows > 0 && next->D > 0 && next->B > 0 && next->n_batches > 0, "%s: bad next-batch shape", who);
+  EMX_REQUIRE(!next->xin || (std::isfinite(next->periodicity) && next->periodicity > 0.f), "%s: sin/cos rows need a finite periodicity", who);
+  return EMX_OK;
+}
+
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
                    int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                   const emx_mlp_desc* mirror_desc, float* mirror) {
+                   const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next = nullptr) {
   AdamArgs a{};
+  if (next) {
+    const bool periodic = next->xin != nullptr;
+    a.next = GatherArgs{next->data, next->D, next->idx, next->cursor, next->B, 1, next->n_batches,
+                        periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin};
+  }
   a.mirror = (mirror_desc && mirror) ? mirror : nullptr;
   if (a.mirror) fill_mirror_args(mirror_desc, a.mir);
   a.w = w;
@@ -454,14 +496,17 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
 
 int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
                   float eps, float clip, const int64_t* step, float* reg_loss, float* ws, const emx_mlp_desc* mirror_desc, float* mirror,
-                  emx_stream_t stream) {
+                  const emx_next_batch* next, emx_stream_t stream) {
+  int rcn = check_next(next, "emx_adam_step");
+  if (rcn) return rcn;
   EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
-  const AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror);
+  AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
   const int grid = grid_for((n + 3) / 4, NT);
+  a.adam_blocks = grid;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid + (next ? grid_for(next->B, 4) : 0)), dim3(NT), 0, st, a);
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   if (reg_loss) {
@@ -473,12 +518,16 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
 
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream) {
+                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, emx_stream_t stream) {
+  int rcn = check_next(next, "emx_adam_step_slices");
+  if (rcn) return rcn;
   EMX_REQUIRE(w && g_partials && m && v && step && ws, "emx_adam_step_slices: null pointer argument");
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step_slices: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0 && n_slices > 0 && partial_stride >= n, "emx_adam_step_slices: bad slice layout");
-  const AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc,
+                         mirror, next);
+  a.adam_blocks = grid_for((n + 3) / 4, NT);
+  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + (next ? grid_for(next->B, 4) : 0)), dim3(NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
 }
 
@@ -491,7 +540,8 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
   EMX_REQUIRE((g != nullptr) != (g_partials != nullptr), "emx_adam_tick: pass either the gradient or its slice partials");
   EMX_REQUIRE(!g_partials || (n_slices > 0 && partial_stride >= n), "emx_adam_tick: bad slice layout");
   EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && reg_slot >= 0 && reg_slot < n_terms, "emx_adam_tick: bad sizes");
-  const AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws, mirror_desc, mirror);
+  AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws, mirror_desc, mirror);
+  a.adam_blocks = grid_for((n + 3) / 4, NT);
   // Three plain launches on the stream.  (An in-kernel hand-off -- last workgroup finishes -- was measured slower: its
   // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
   const int grid = grid_for((n + 3) / 4, NT);

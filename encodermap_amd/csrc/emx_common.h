@@ -57,5 +57,22 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= NT/64 floa
   return r;
 }
 
+// sin and cos of an angle of moderate size (|x| up to a few thousand: data angles are within a few periods): three-term
+// Cody-Waite reduction by pi/2 and the classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4], ~1.5 ulp.  The
+// library sincosf carries a Payne-Hanek path for huge arguments that costs ~3 KB of scratch per lane in every kernel that
+// merely contains it.
+__device__ __forceinline__ void sincos_bounded(float x, float* s, float* c) {
+  const float q = rintf(x * 0.63661977236758134f);
+  float r = fmaf(q, -1.57079601287841796875f, x);
+  r = fmaf(q, -3.1391647326017846353e-7f, r);
+  r = fmaf(q, -5.3903025299577647655e-15f, r);
+  const int n = (int)q;
+  const float r2 = r * r;
+  const float sp = fmaf(r * r2, fmaf(r2, fmaf(r2, -1.95152959e-4f, 8.33216087e-3f), -1.66666546e-1f), r);
+  const float cp = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.44331571e-5f, -1.38873163e-3f), 4.16666457e-2f), -0.5f), 1.f);
+  const float a = (n & 1) ? cp : sp, b = (n & 1) ? sp : cp;
+  *s = (n & 2) ? -a : a;
+  *c = ((n + 1) & 2) ? -b : b;
+}
 
 }  // namespace emx

@@ -124,15 +124,6 @@ struct ChainArgs {
   const float* dadd;
   emx_latent_grad lg;
   int join_n;           // width of the joined layer (0: no join)
-  // forward only, optional data feed (replaces emx_gather_rows in front of the first layer): the row block is gathered by
-  // index from the resident data set, expanded to [sin | cos] for periodic data, and also written out (xb raw, xin expanded)
-  const float* feed_data;   // null: rows come from `in`
-  const int64_t* feed_idx;
-  const int64_t* feed_cursor;
-  int feed_D, feed_B, feed_periodic;
-  float feed_ang;
-  float* feed_xb;
-  float* feed_xin;
   // forward only, optional auto cost on the rows of the last layer (replaces emx_periodic_cost_fwd_bwd behind it):
   // cost.dY receives d cost / d output, cost.ws[workgroup] the workgroup's share of the cost
   CostArgs cost;
@@ -165,6 +156,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int img = R * pitch;
   const int nu = a.nu;
   float* lat = lds + 2 * img;   // [R][join_n] rows joined into one layer's dh (backward)
+  float* tgt = lds + 2 * img;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
   constexpr int NE = BWD ? 4 : 1;
   TSTAMP(0);
 
@@ -227,30 +219,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int sr = tid >> 5, sK = a.in_cols;
   const bool srok = r0 + sr < a.row_end;
   const long sgrow = (long)min(r0 + sr, a.row_end - 1);
-  long feed_row = 0;
-  if (!BWD && a.feed_data != nullptr) feed_row = a.feed_idx[(a.feed_cursor ? *a.feed_cursor : 0) * (long)a.feed_B + sgrow];
   auto stage_load = [&](int c, float (&v)[4]) {
-    if (!BWD && a.feed_data != nullptr) {
-      const int D = a.feed_D;
-      const float* __restrict__ src = a.feed_data + feed_row * D;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int k = min(c + i, sK - 1);
-        const float raw = src[k < D ? k : k - D];
-        float val = raw;
-        if (a.feed_periodic) {
-          float sn, cs;
-          sincosf(raw * a.feed_ang, &sn, &cs);
-          val = k < D ? sn : cs;
-        }
-        v[i] = val;
-        if (srok && c + i < sK) {
-          if (a.feed_xb != nullptr && k < D) a.feed_xb[sgrow * D + k] = raw;
-          if (a.feed_xin != nullptr) a.feed_xin[sgrow * sK + k] = val;
-        }
-      }
-      return;
-    }
     const float* __restrict__ src = a.in + sgrow * a.ld_in;
     if ((((a.ld_in | sK) & 3) == 0) && c < sK) {
       const f32x4 t = *reinterpret_cast<const f32x4*>(src + c);
@@ -282,6 +251,17 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   };
   const int sc0 = 4 * (tid & 31);
   float sv[4] = {0.f, 0.f, 0.f, 0.f};
+  float tv[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool tgt_global = !BWD && a.cost.dY != nullptr;
+  auto target_load = [&](int c, float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = a.cost.target[sgrow * a.cost.ldt + min(c + i, a.cost.n - 1)];
+  };
+  auto target_store = [&](int c, const float (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (c + i < a.cost.n) tgt[sr * a.cost.n + c + i] = v[i];
+  };
 
   int buf = 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -313,9 +293,10 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
       pend_bytes = 0;
     }
-    if (ui == -(NB - 2)) {
-      // the row block itself: behind the first package (whose request must not wait for the gather index), ahead of the rest
+    if (ui == -(NB - 1)) {
+      // the row block itself travels ahead of the first package and reaches LDS behind it
       if (sc0 < pitch) stage_load(sc0, sv);
+      if (tgt_global && sc0 < a.cost.n) target_load(sc0, tv);
       TSTAMP(1);
     }
     request_epi(Lq, e[r]);
@@ -342,12 +323,20 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const UnitExec Xn = a.ux[max(0, min(ui + 1, nu - 1))];
     Lq = Ln;
 
-    if (ui == -1) {
+    if (ui == -(NB - 1)) {
       if (sc0 < pitch) stage_store(sc0, sv);
       for (int c = sc0 + 128; c < pitch; c += 128) {
         float v[4];
         stage_load(c, v);
         stage_store(c, v);
+      }
+      if (tgt_global) {
+        if (sc0 < a.cost.n) target_store(sc0, tv);
+        for (int c = sc0 + 128; c < a.cost.n; c += 128) {
+          float v[4];
+          target_load(c, v);
+          target_store(c, v);
+        }
       }
       __syncthreads();
       TSTAMP(2);
@@ -391,17 +380,24 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     X = Xn;
   };
 
-  for (int ui = -(NB - 1); ui < nu; ui += NB) {
+  // (left by `break` right behind the last unit: an iteration that only requests would still wait for the registers it
+  //  overwrites, a full load latency for nothing)
+  for (int ui = -(NB - 1);; ui += NB) {
     unit(IC<0>{}, ui);
+    if (ui + 1 >= nu) break;
     unit(IC<1>{}, ui + 1);
+    if (ui + 2 >= nu) break;
     unit(IC<2>{}, ui + 2);
+    if (ui + 3 >= nu) break;
     unit(IC<3>{}, ui + 3);
+    if (ui + 4 >= nu) break;
   }
   {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend_base), 0, pend_bytes, 0x00020000);
 #pragma unroll
     for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
   }
+  TSTAMP(60);
   if (!BWD && a.cost.dY != nullptr) {
     // auto cost on the last layer's rows, which are complete in the current LDS image: 32 threads per row
     __shared__ float cred[NTC / 64];
@@ -410,7 +406,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const bool rok = r0 + row < a.row_end;
     const long grow = (long)min(r0 + row, a.row_end - 1);
     const float* yrow = lds + buf * img + row * pitch;
-    const float* trow = cst.target + grow * cst.ldt;
+    const float* trow = tgt + row * cst.n;
     float* drow = rok ? cst.dY + grow * cst.ldy : nullptr;
     float lsum = 0.f;
     if (cst.variant == EMX_MEAN_NORM) {
@@ -448,6 +444,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const float tsum = block_sum<NTC>(lsum, cred);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   }
+  TSTAMP(61);
 #ifdef EMX_CHAIN_TIMING
   __syncthreads();
   if (!BWD && (blockIdx.x == 0 || blockIdx.x == 100)) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
@@ -715,34 +712,14 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
 
 int emx_mlp_row_blocks(int n_rows) { return std::max((n_rows + R - 1) / R, 1); }
 
-int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const emx_feed* feed,
-                          const float* in, int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost,
-                          emx_stream_t stream) {
+int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, emx_stream_t stream) {
   int rc = check_desc(desc, "emx_mlp_forward");
   if (rc) return rc;
-  EMX_REQUIRE(params && mirror && h && (in || feed), "emx_mlp_forward: null pointer argument");
+  EMX_REQUIRE(params && mirror && h && in, "emx_mlp_forward: null pointer argument");
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "emx_mlp_forward: bad rows");
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
   ChainArgs a{};
-  const int in_cols = desc->width[layer_begin];
-  if (feed) {
-    const bool periodic = std::isfinite(feed->periodicity);
-    EMX_REQUIRE(feed->data && feed->idx && feed->n_rows > 0 && feed->D > 0 && feed->B >= row_end, "emx_mlp_forward: incomplete data feed");
-    EMX_REQUIRE(!periodic || feed->periodicity > 0.f, "emx_mlp_forward: periodic feed needs a positive periodicity");
-    EMX_REQUIRE(in_cols == (periodic ? 2 : 1) * feed->D, "emx_mlp_forward: feed of %d columns (%s) does not match the input width %d", feed->D,
-                periodic ? "periodic" : "plain", in_cols);
-    a.feed_data = feed->data;
-    a.feed_idx = feed->idx;
-    a.feed_cursor = feed->cursor;
-    a.feed_D = feed->D;
-    a.feed_B = feed->B;
-    a.feed_periodic = periodic;
-    a.feed_ang = periodic ? (feed->periodicity == COST_TWO_PI ? 1.f : COST_TWO_PI / feed->periodicity) : 1.f;
-    a.feed_xb = feed->xb;
-    a.feed_xin = feed->xin;
-  } else {
-    EMX_REQUIRE(ld_in >= in_cols, "emx_mlp_forward: bad input stride");
-  }
   for (int l = layer_begin; l < layer_end; ++l) {
     EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
     rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], h[l], desc->act[l] ? S_ACT : 0,
@@ -766,10 +743,10 @@ int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* 
   a.mbase = mirror;
   a.in = in;
   a.ld_in = ld_in;
-  a.in_cols = in_cols;
+  a.in_cols = desc->width[layer_begin];
   a.row0 = row_begin;
   a.row_end = row_end;
-  const size_t lds = (size_t)2 * R * a.pitch * sizeof(float);
+  const size_t lds = ((size_t)2 * R * a.pitch + (cost ? (size_t)R * cost->n : 0)) * sizeof(float);
   rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<false>), lds, "emx_mlp_forward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
@@ -779,8 +756,7 @@ int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* 
 
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream) {
-  EMX_REQUIRE(in, "emx_mlp_forward: null pointer argument");
-  return emx_mlp_forward_fused(desc, params, mirror, layer_begin, layer_end, nullptr, in, ld_in, row_begin, row_end, h, nullptr, stream);
+  return emx_mlp_forward_cost(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, nullptr, stream);
 }
 
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,

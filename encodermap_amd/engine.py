@@ -201,21 +201,27 @@ class SequentialEngine:
         return allidx[:need].contiguous()
 
     # -- forward / backward ------------------------------------------------------------------------
+    _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
+
+    def _gather_current(self) -> None:
+        """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
+        step gathers the next batch)."""
+        _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
+                         self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
+
     def _forward(self) -> None:
-        """Data feed, forward pass and auto cost in ONE launch (two for a row-block rank: encoder on every row, decoder and
-        cost on the rows it owns).  The gathered rows, the activations and d cost / d output go to HBM for the kernels
-        that follow; the cost's per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue."""
+        """Forward pass and auto cost in ONE launch (two for a row-block rank: encoder on every row, decoder and cost on the
+        rows it owns).  The activations and d cost / d output go to HBM for the kernels that follow; the cost's
+        per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue."""
         lay, n, p = self.layout, len(self.layout.layers), self.p
-        feed = _lib.make_feed(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
-                              self.xin if self.periodic else None)
         cost = None
         if p.auto_cost_scale is not None:
             cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
                                        float(p.auto_cost_scale), self.B, self.dY, self.cost_ws)
         if (self.rb, self.re) == (0, self.B):
-            _lib.mlp_forward(self.plan, 0, n, None, 0, self.B, feed=feed, cost=cost)
+            _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B, cost=cost)
         else:
-            _lib.mlp_forward(self.plan, 0, lay.n_enc, None, 0, self.B, feed=feed)
+            _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
             _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
 
     def _use_sketchmap(self) -> bool:
@@ -284,13 +290,17 @@ class SequentialEngine:
         history and counters."""
         p = self.p
         reg_job = (self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)
+        nxt = None
+        if self._prefetch:
+            nxt = _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
+                                       self.xin if self.periodic else None)
         if self.dp.active:
             _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2,
-                           plan=self.plan)
+                           plan=self.plan, next_batch=nxt)
             jobs = [reg_job]
         else:
             _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
-                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan)
+                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt)
             jobs = self._jobs_pre() + [reg_job]
         _lib.finish_step(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
 
@@ -311,6 +321,8 @@ class SequentialEngine:
         s.wait_stream(torch.cuda.current_stream())
         saved = [t.clone() for t in self._state_tensors()]
         with torch.cuda.stream(s):
+            if self._prefetch:
+                self._gather_current()
             for _ in range(2):
                 self._step_body()
         torch.cuda.current_stream().wait_stream(s)
@@ -320,6 +332,8 @@ class SequentialEngine:
             for t, sv in zip(self._state_tensors(), saved):
                 t.copy_(sv)
             self.plan.refresh_mirror()
+            if self._prefetch:
+                self._gather_current()
 
         restore()
         if self.dp.active:
@@ -365,6 +379,8 @@ class SequentialEngine:
             k = min(cap, n_steps - done)
             self.idx_block[: k * self.B].copy_(block[done * self.B: (done + k) * self.B])
             self.cursor.zero_()
+            if self._prefetch:
+                self._gather_current()
             if self.use_graph:
                 if self._graph is None:
                     self._capture()

@@ -167,6 +167,22 @@ typedef struct {
   int64_t b_off[EMX_MAX_LAYERS];
 } emx_mlp_desc;
 
+/* The rows of the NEXT batch, gathered beside the optimizer (the same rows emx_gather_rows would produce for batch
+ * *cursor + 1, skipped when that is >= n_batches): the optimizer is a short latency-bound stream over ~1e5 parameters, the
+ * gather runs on other CUs meanwhile, and the next step starts with its rows already in xb / xin. */
+typedef struct {
+  const float* data;      /* [n_rows, D] resident data set */
+  int64_t n_rows;
+  int D;
+  const int64_t* idx;     /* gather index block, n_batches x B */
+  int n_batches;
+  const int64_t* cursor;  /* device scalar: the CURRENT batch */
+  int B;
+  float periodicity;      /* used when xin != NULL */
+  float* xb;              /* may be NULL: [B, D] raw rows */
+  float* xin;             /* may be NULL: [B, 2 D] = [sin | cos] */
+} emx_next_batch;
+
 /* ------------------------------------------------------------------------------------------------ *
  * K11 + K10  fused clip -> Adam on the flat parameter buffer, L2 regulariser folded in
  *   replaces: tf.keras.optimizers.Adam(lr, clipvalue=1.0).apply_gradients  encodermap/autoencoder/autoencoder.py:741-743,
@@ -182,14 +198,14 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
                   float lr, float beta1, float beta2, float eps, float clip,
                   const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */,
                   const emx_mlp_desc* mirror_desc /* may be NULL */, float* mirror /* may be NULL: operand store (emx_mlp_mirror) rewritten
-                  with the new kernels */, emx_stream_t stream);
+                  with the new kernels */, const emx_next_batch* next /* may be NULL */, emx_stream_t stream);
 
 /* emx_adam_step on the weight-gradient slice partials left by emx_mlp_wgrad (gradient = fixed-order sum over n_slices slices of
  * g_partials[s * partial_stride + i]); no separate reduction pass.  ws[0 .. EMX_REDUCE_WS) receives partials of the regulariser
  * cost (summed by emx_finish_step). */
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         const emx_mlp_desc* mirror_desc, float* mirror, emx_stream_t stream);
+                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, emx_stream_t stream);
 
 /* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
  * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
@@ -247,27 +263,11 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
 /* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream);
-/* emx_mlp_forward with the step's neighbours folded into the same launch (their own kernels are a few microseconds of
- * launch and first-touch latency each):
- *   feed (may be NULL): the row block is gathered straight from the resident data set -- batch row r is
- *     data[idx[*cursor * B + r]] -- and expanded to [sin | cos] when `periodicity` is finite, exactly as emx_gather_rows
- *     does (encodermap/autoencoder/autoencoder.py:845-856, models.py:3347-3351); xb / xin (may be NULL) receive the raw and
- *     the expanded rows for the kernels that need them later.  `in` is ignored when a feed is given.
- *   cost (may be NULL): the auto cost of emx_periodic_cost_fwd_bwd evaluated on the rows of layer layer_end-1 while they are
- *     still on chip: dY [*, width[layer_end]] receives d cost / d output; ws[g], g < emx_mlp_row_blocks(row_end - row_begin),
- *     the row blocks' shares of the cost, already scaled by coef / (B n) (or coef / B for EMX_MEAN_NORM) -- their
- *     fixed-order sum (emx_finish_step) is the cost. */
-typedef struct {
-  const float* data;      /* [n_rows, D] resident data set */
-  int64_t n_rows;
-  int D;
-  const int64_t* idx;     /* gather index block */
-  const int64_t* cursor;  /* may be NULL (= 0): device scalar, index of the current batch inside idx */
-  int B;                  /* batch size: rows of idx per cursor step */
-  float periodicity;      /* INFINITY: plain rows */
-  float* xb;              /* may be NULL: [B, D] */
-  float* xin;             /* may be NULL: [B, 2 D], periodic only */
-} emx_feed;
+/* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch
+ * latency for a few hundred kilobytes): the cost of emx_periodic_cost_fwd_bwd is evaluated on the rows of layer
+ * layer_end-1 while they are still on chip.  dY [*, width[layer_end]] receives d cost / d output; ws[g],
+ * g < emx_mlp_row_blocks(row_end - row_begin), the row blocks' shares of the cost, already scaled by coef / (B n) (or
+ * coef / B for EMX_MEAN_NORM) -- their fixed-order sum (emx_finish_step) is the cost.  cost == NULL: emx_mlp_forward. */
 typedef struct {
   const float* target;    /* [*, ldt] */
   int ldt;
@@ -282,9 +282,8 @@ typedef struct {
   float* ws;
 } emx_auto_cost;
 int emx_mlp_row_blocks(int n_rows);
-int emx_mlp_forward_fused(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const emx_feed* feed,
-                          const float* in, int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost,
-                          emx_stream_t stream);
+int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and

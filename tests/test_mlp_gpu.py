@@ -175,11 +175,12 @@ def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("periodicity,variant,D,B", [(float("inf"), "mean_square", 128, 4096), (2 * np.pi, "mean_abs", 10, 256),
-                                                     (360.0, "mean_norm", 37, 100), (float("inf"), "mean_norm", 70, 50)])
-def test_forward_with_feed_and_cost_equals_separate_kernels(L, periodicity, variant, D, B):
-    """emx_mlp_forward_fused (data feed + dense layers + auto cost in one launch) against the three stand-alone entry
-    points it replaces (emx_gather_rows, emx_mlp_forward, emx_periodic_cost_fwd_bwd): same rows, same activations, same
-    cost and the same gradient with respect to the output."""
+                                                     (360.0, "mean_norm", 37, 100), (float("inf"), "mean_norm", 70, 50),
+                                                     (float("inf"), "mean_abs", 300, 40)])
+def test_forward_with_cost_equals_separate_kernels(L, periodicity, variant, D, B):
+    """emx_mlp_forward_cost (dense layers + auto cost in one launch) against the two stand-alone entry points it
+    replaces (emx_mlp_forward, emx_periodic_cost_fwd_bwd): same activations, same cost and the same gradient with
+    respect to the output."""
     from encodermap_amd.layout import build_layout, init_parameters
 
     periodic = np.isfinite(periodicity)
@@ -188,36 +189,67 @@ def test_forward_with_feed_and_cost_equals_separate_kernels(L, periodicity, vari
     n = len(lay.layers)
     params = torch.from_numpy(init_parameters(lay, 5)).cuda()
     g = torch.Generator().manual_seed(0)
-    N = 1000
-    data = ((torch.rand(N, D, generator=g) - 0.5) * (periodicity if periodic else 6.0)).cuda()
-    idx = torch.randint(0, N, (3 * B,), generator=g).cuda()
-    cursor = torch.tensor([2], dtype=torch.int64, device="cuda")
+    xb = ((torch.rand(B, D, generator=g) - 0.5) * (periodicity if periodic else 6.0)).cuda()
+    xin = torch.zeros(B, net_dim, device="cuda")
+    if periodic:
+        L.periodic_in(xb, periodicity, xin)
+    else:
+        xin = xb
     coef = 0.7
-
-    def buffers():
-        return ([torch.zeros(B, l.n_out, device="cuda") for l in lay.layers], torch.zeros(B, D, device="cuda"),
-                torch.zeros(B, net_dim, device="cuda") if periodic else None, torch.zeros(B, net_dim, device="cuda"))
-
     # separate kernels
-    h1, xb1, xin1, dY1 = buffers()
+    h1 = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+    dY1 = torch.zeros(B, net_dim, device="cuda")
     plan1 = L.MlpPlan(lay, params, h1, h1)
-    L.gather_rows(data, idx, periodicity, xb1, xin1, cursor=cursor, B=B)
-    L.mlp_forward(plan1, 0, n, xin1 if periodic else xb1, 0, B)
+    L.mlp_forward(plan1, 0, n, xin, 0, B)
     loss1 = torch.zeros(1, device="cuda")
     ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
-    L.periodic_cost_fwd_bwd(h1[-1], 0, D, periodic, xb1, D, periodicity, variant, coef, 0, B, loss1, dY1, ws, B=B)
+    L.periodic_cost_fwd_bwd(h1[-1], 0, D, periodic, xb, D, periodicity, variant, coef, 0, B, loss1, dY1, ws, B=B)
     # one launch
-    h2, xb2, xin2, dY2 = buffers()
+    h2 = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+    dY2 = torch.zeros(B, net_dim, device="cuda")
     plan2 = L.MlpPlan(lay, params, h2, h2)
     cost_ws = torch.zeros(L.mlp_row_blocks(B), device="cuda")
-    feed = L.make_feed(data, idx, cursor, B, periodicity, xb2, xin2)
-    cost = L.make_auto_cost(xb2, D, 0, D, periodic, periodicity, variant, coef, B, dY2, cost_ws)
-    L.mlp_forward(plan2, 0, n, None, 0, B, feed=feed, cost=cost)
+    cost = L.make_auto_cost(xb, D, 0, D, periodic, periodicity, variant, coef, B, dY2, cost_ws)
+    L.mlp_forward(plan2, 0, n, xin, 0, B, cost=cost)
     torch.cuda.synchronize()
-    assert torch.equal(xb1, xb2)
-    if periodic:
-        assert torch.equal(xin1, xin2)
     for a, b in zip(h1, h2):
         assert torch.equal(a, b)
     np.testing.assert_allclose(dY2.cpu().numpy(), dY1.cpu().numpy(), rtol=1e-6, atol=1e-9)
     assert float(cost_ws.double().sum()) == pytest.approx(float(loss1), rel=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodicity,D", [(float("inf"), 128), (2 * np.pi, 10), (360.0, 33)])
+def test_adam_gathers_the_next_batch(L, periodicity, D):
+    """emx_adam_step(next) leaves the rows of batch cursor + 1 in xb / xin exactly as emx_gather_rows would, skips the gather
+    beyond the last batch of the index block, and still performs the same update."""
+    B, N, nb = 96, 500, 3
+    periodic = np.isfinite(periodicity)
+    g = torch.Generator().manual_seed(1)
+    data = ((torch.rand(N, D, generator=g) - 0.5) * (periodicity if periodic else 4.0)).cuda()
+    idx = torch.randint(0, N, (nb * B,), generator=g).cuda()
+    n = 1000
+    w = torch.randn(n, generator=g).cuda()
+    grad = torch.randn(n, generator=g).cuda()
+    step = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
+    for cur in range(nb):
+        cursor = torch.tensor([cur], dtype=torch.int64, device="cuda")
+        xb = torch.full((B, D), -7.0, device="cuda")
+        xin = torch.full((B, 2 * D), -7.0, device="cuda") if periodic else None
+        nxt = L.make_next_batch(data, idx, cursor, B, periodicity, xb, xin)
+        w1, m1, v1 = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        w2, m2, v2 = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        L.adam_step(w1, grad, m1, v1, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, next_batch=nxt)
+        L.adam_step(w2, grad, m2, v2, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws)
+        assert torch.equal(w1, w2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+        if cur + 1 < nb:
+            xb_ref = torch.zeros(B, D, device="cuda")
+            xin_ref = torch.zeros(B, 2 * D, device="cuda") if periodic else None
+            L.gather_rows(data, idx, periodicity, xb_ref, xin_ref, cursor=torch.tensor([cur + 1], device="cuda"), B=B)
+            assert torch.equal(xb, xb_ref)
+            assert torch.equal(xb, data[idx[(cur + 1) * B:(cur + 2) * B]])
+            if periodic:
+                assert torch.equal(xin, xin_ref)
+        else:
+            assert float(xb.max()) == -7.0   # nothing gathered behind the last batch

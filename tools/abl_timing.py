@@ -14,7 +14,16 @@ h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
 dl = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
 plan = _lib.MlpPlan(lay, params, h, dl)
 x = torch.randn(B, D, device="cuda")
-for _ in range(20): _lib.mlp_forward(plan, 0, n, x, 0, B)
+fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
+if fused:
+    N = 1000000
+    data = torch.randn(N, D, device="cuda"); idx = torch.randint(0, N, (4 * B,), device="cuda"); cursor = torch.tensor([1], device="cuda")
+    xb = torch.zeros(B, D, device="cuda"); dY = torch.zeros(B, D, device="cuda"); cws = torch.zeros(_lib.mlp_row_blocks(B), device="cuda")
+    feed = _lib.make_feed(data, idx, cursor, B, float("inf"), xb, None)
+    cost = _lib.make_auto_cost(xb, D, 0, D, False, float("inf"), "mean_square", 1.0, B, dY, cws)
+    for _ in range(20): _lib.mlp_forward(plan, 0, n, None, 0, B, feed=feed, cost=cost)
+else:
+    for _ in range(20): _lib.mlp_forward(plan, 0, n, x, 0, B)
 torch.cuda.synchronize()
 buf = np.zeros(8192, dtype=np.int64)
 lib.emx_debug_read.argtypes = [ctypes.c_void_p]
@@ -25,7 +34,8 @@ for blk in (0, 1):
     for w in (0, 3, 7):
         c = clk[w, :nslot] - clk[w, 0]; t = c * 0
         print(f"block {blk*100} wave {w}: total {c[-1]} clk, {t[-1]} ns -> {c[-1]/max(t[-1],1):.2f} GHz")
-        print("  clk  pre:", c[1], c[2], "| per layer [issue loads, mma, epilogue+copy, barrier]:")
+        cc = clk[w] - clk[w, 0]
+        print("  clk  stage loads issued:", c[1], " staged + barrier:", c[2], " loop end:", cc[60], " cost phase end:", cc[61])
         for l in range(n):
             s3, s5, s6, s7 = (c[3 + 5 * l], c[5 + 5 * l], c[6 + 5 * l], c[7 + 5 * l])
             prev = c[2] if l == 0 else c[7 + 5 * (l - 1)]
