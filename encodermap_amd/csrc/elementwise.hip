@@ -206,8 +206,22 @@ __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, 
 
 __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
   if (!a.gpart) return reinterpret_cast<const float4*>(a.g)[i4];
-  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;   // 4 loads in flight, fixed association
+  // fixed association (slice s goes to partial s % 4); 16 loads in flight -- the optimizer is a latency-bound stream, with 4
+  // in flight the 32 slices of a 4096-row batch were eight dependent round trips
+  float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
   int s = 0;
+  for (; s + 16 <= a.n_slices; s += 16) {
+    float4 q[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) q[u] = reinterpret_cast<const float4*>(a.gpart + (long)(s + u) * a.gstride)[i4];
+#pragma unroll
+    for (int u = 0; u < 16; u += 4) {
+      p0.x += q[u].x; p0.y += q[u].y; p0.z += q[u].z; p0.w += q[u].w;
+      p1.x += q[u + 1].x; p1.y += q[u + 1].y; p1.z += q[u + 1].z; p1.w += q[u + 1].w;
+      p2.x += q[u + 2].x; p2.y += q[u + 2].y; p2.z += q[u + 2].z; p2.w += q[u + 2].w;
+      p3.x += q[u + 3].x; p3.y += q[u + 3].y; p3.z += q[u + 3].z; p3.w += q[u + 3].w;
+    }
+  }
   for (; s + 4 <= a.n_slices; s += 4) {
     const float4 q0 = reinterpret_cast<const float4*>(a.gpart + (long)s * a.gstride)[i4];
     const float4 q1 = reinterpret_cast<const float4*>(a.gpart + (long)(s + 1) * a.gstride)[i4];
@@ -317,51 +331,114 @@ struct FinishArgs {
   int64_t* hstep;
   int64_t* cursor;
   int64_t* counter2;
+  const float* terms_base;   // 16-byte aligned, >= 16 readable bytes
 };
 
-// one workgroup: the jobs' sums (fixed order), then the bookkeeping of step_tick_kernel
+// One workgroup, one memory round trip for all the step's scalars: every job's first 8192 elements are requested (16-byte
+// loads, four jobs at a time) before anything is added, one block-wide reduction serves all jobs, and the bookkeeping of
+// step_tick_kernel works from values fetched at kernel entry.  A single workgroup is bound by round trips (~2.7 us each
+// here: freshly written lines of other XCDs, cold TLB) and by its own instruction count, not by bandwidth; job after job,
+// each with its own reduction and a serial tail, was 9 us.  Fixed order throughout.
+#ifdef EMX_CHAIN_TIMING
+__device__ long long emx_dbg_fin[64];
+#define FSTAMP(k) do { if (threadIdx.x == 0) emx_dbg_fin[k] = clock64(); } while (0)
+#else
+#define FSTAMP(k)
+#endif
+constexpr int FQ = 8;   // 16-byte loads per thread and job in the common round
+
 __global__ __launch_bounds__(NT) void finish_step_kernel(const FinishArgs a) {
-  __shared__ float red[8];
-  for (int j = 0; j < a.n_jobs; ++j) {
-    const emx_sum_job job = a.jobs[j];
-    // up to 16 independent loads in flight per thread: the whole job is one or two memory round trips
-    float acc[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) acc[u] = 0.f;
-    long i = threadIdx.x;
-    for (; i + 15 * NT < job.n; i += 16 * NT) {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = job.src[i + u * NT];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] += job.square ? v[u] * v[u] : v[u];
-    }
-    {
-      float v[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) v[u] = (i + u * NT < job.n) ? job.src[min(i + (long)u * NT, job.n - 1)] : 0.f;
-#pragma unroll
-      for (int u = 0; u < 16; ++u) acc[u] += job.square ? v[u] * v[u] : v[u];
-    }
-    const float s0 = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-    const float s1 = ((acc[8] + acc[9]) + (acc[10] + acc[11])) + ((acc[12] + acc[13]) + (acc[14] + acc[15]));
-    const float s2 = 0.f, s3 = 0.f;
-    const float tot = block_sum<NT>((s0 + s1) + (s2 + s3), red);
-    if (threadIdx.x == 0) a.terms[job.slot] = tot * job.scale * (job.dev_scale ? *job.dev_scale : 1.f);
+  __shared__ float red[EMX_MAX_SUM_JOBS][NT / 64];
+  __shared__ float tl[64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  FSTAMP(0);
+  // scalars of the bookkeeping, requested up front
+  long hs = 0, cur = 0, cnt = 0;
+  if (tid == 0) {
+    if (a.hstep) hs = *a.hstep;
+    if (a.cursor) cur = *a.cursor;
+    if (a.counter2) cnt = *a.counter2;
   }
-  if (a.hstep && threadIdx.x == 0) {
-    __threadfence_block();
-    const long s = *a.hstep;
-    float tot = 0.f;
-    for (int i = 0; i < a.n_terms; ++i) tot += a.terms[i];
-    if (s >= 0 && s < a.capacity) {
-      if (a.history) a.history[s] = tot;
-      if (a.term_history)
-        for (int i = 0; i < a.n_terms; ++i) a.term_history[s * a.n_terms + i] = a.terms[i];
+  if (tid < a.n_terms) tl[tid] = a.terms[tid];
+  float dsc[EMX_MAX_SUM_JOBS];
+#pragma unroll
+  for (int j = 0; j < EMX_MAX_SUM_JOBS; ++j) dsc[j] = (j < a.n_jobs && a.jobs[j].dev_scale && tid == 0) ? *a.jobs[j].dev_scale : 1.f;
+
+  float part[EMX_MAX_SUM_JOBS];
+#pragma unroll
+  for (int g0 = 0; g0 < EMX_MAX_SUM_JOBS; g0 += 4) {
+    if (g0 >= a.n_jobs) {   // uniform
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) part[g0 + jj] = 0.f;
+      continue;
     }
-    *a.hstep = s + 1;
-    if (a.cursor) *a.cursor += 1;
-    if (a.counter2) *a.counter2 += 1;
+    float4 v[4][FQ];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = g0 + jj;
+      // absent and unaligned jobs re-read the first 16 bytes of `terms` with weight 0: no branch around any load
+      const bool vec = j < a.n_jobs && (reinterpret_cast<uintptr_t>(a.jobs[j].src) & 15) == 0;
+      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(vec ? a.jobs[j].src : a.terms_base);
+      const long n4 = vec ? a.jobs[j].n >> 2 : 0;
+#pragma unroll
+      for (int u = 0; u < FQ; ++u) v[jj][u] = src4[min((long)tid + u * NT, max(n4, 1L) - 1)];
+    }
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int j = g0 + jj;
+      const bool live = j < a.n_jobs;
+      const emx_sum_job job = a.jobs[live ? j : 0];
+      const bool vec = live && (reinterpret_cast<uintptr_t>(job.src) & 15) == 0;
+      const long n = live ? job.n : 0, n4 = vec ? n >> 2 : 0;
+      const bool sq = job.square != 0;
+      float acc[FQ];
+#pragma unroll
+      for (int u = 0; u < FQ; ++u) {
+        const float4 x = v[jj][u];
+        const float wq = (long)tid + u * NT < n4 ? 1.f : 0.f;
+        acc[u] = (sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w)) * wq;
+      }
+      float p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      for (long i = (long)tid + FQ * NT; i < n4; i += NT) {   // long jobs: the rest, strided
+        const float4 x = reinterpret_cast<const float4*>(job.src)[i];
+        p += sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w);
+      }
+      for (long i = 4 * n4 + tid; i < n; i += NT) {             // tail (or an unaligned job)
+        const float x = job.src[i];
+        p += sq ? x * x : x;
+      }
+      part[j] = wave_sum(p);
+    }
+  }
+  FSTAMP(2);
+  if (lane == 0) {
+#pragma unroll
+    for (int j = 0; j < EMX_MAX_SUM_JOBS; ++j) red[j][wave] = part[j];
+  }
+  __syncthreads();
+  FSTAMP(3);
+  if (tid == 0) {
+    for (int j = 0; j < a.n_jobs; ++j) {
+      float tot = 0.f;
+      for (int w = 0; w < NT / 64; ++w) tot += red[j][w];
+      tot *= a.jobs[j].scale * dsc[j];
+      a.terms[a.jobs[j].slot] = tot;
+      tl[a.jobs[j].slot] = tot;
+    }
+    FSTAMP(4);
+    if (a.hstep) {
+      float tot = 0.f;
+      for (int i = 0; i < a.n_terms; ++i) tot += tl[i];
+      if (hs >= 0 && hs < a.capacity) {
+        if (a.history) a.history[hs] = tot;
+        if (a.term_history)
+          for (int i = 0; i < a.n_terms; ++i) a.term_history[hs * a.n_terms + i] = tl[i];
+      }
+      *a.hstep = hs + 1;
+      if (a.cursor) *a.cursor = cur + 1;
+      if (a.counter2) *a.counter2 = cnt + 1;
+    }
+    FSTAMP(5);
   }
 }
 
@@ -562,9 +639,13 @@ int emx_finish_step(const emx_sum_job* jobs, int n_jobs, float* terms, int n_ter
   EMX_REQUIRE(terms && n_terms > 0 && n_terms <= 64 && n_jobs >= 0 && n_jobs <= EMX_MAX_SUM_JOBS && (n_jobs == 0 || jobs),
               "emx_finish_step: bad arguments");
   FinishArgs a;
+  a.jobs[0] = emx_sum_job{terms, 0, 1.f, nullptr, 0, 0};
+  EMX_REQUIRE((reinterpret_cast<uintptr_t>(terms) & 15) == 0 && n_terms >= 4, "emx_finish_step: terms must be 16-byte aligned, >= 4 entries");
+  a.terms_base = terms;
   for (int j = 0; j < n_jobs; ++j) {
-    EMX_REQUIRE(jobs[j].src && jobs[j].n >= 0 && jobs[j].slot >= 0 && jobs[j].slot < n_terms, "emx_finish_step: bad job %d", j);
+    EMX_REQUIRE((jobs[j].src || jobs[j].n == 0) && jobs[j].n >= 0 && jobs[j].slot >= 0 && jobs[j].slot < n_terms, "emx_finish_step: bad job %d", j);
     a.jobs[j] = jobs[j];
+    if (jobs[j].n == 0) a.jobs[j].src = terms;
   }
   a.n_jobs = n_jobs;
   a.terms = terms;
@@ -588,3 +669,7 @@ int emx_step_tick(const float* terms, int n_terms, float* history, float* term_h
 }
 
 }  // extern "C"
+
+#ifdef EMX_CHAIN_TIMING
+extern "C" int emx_debug_read_fin(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_fin), sizeof(emx_dbg_fin)); }
+#endif

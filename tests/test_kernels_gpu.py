@@ -349,3 +349,44 @@ def test_sketchmap_baseline_stress_sizes(L, B, Dd, periodicity, sig):
     lo, _, gg = run_sketchmap(L, x[sub], z[sub], periodicity, sig, 500.0, None, 0, 384)
     assert lo == pytest.approx(lo_o, rel=1e-5)
     np.testing.assert_allclose(gg, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max())
+
+
+@pytest.mark.gpu
+def test_finish_step_sums_and_bookkeeping(L):
+    """emx_finish_step: every job's fixed-order sum (plain / squares, aligned / unaligned sources, lengths around the
+    16-byte and the one-round boundaries, device-side scale) lands in its slot; the bookkeeping then records the total
+    of ALL terms and advances the three counters -- against float64 sums."""
+    g = torch.Generator().manual_seed(3)
+    n_terms = 8
+    lens = [1, 3, 4, 255, 2080, 8192, 8193 + 4096, 0]
+    base = torch.randn(sum(lens) + 64, generator=g).cuda()
+    dsc = torch.tensor([0.25], device="cuda")
+    for n_jobs in (0, 1, 3, 4, 5, 8):
+        terms = torch.arange(1, n_terms + 1, dtype=torch.float32, device="cuda") * 0.5
+        want = terms.double().clone()
+        jobs, off = [], 1   # off = 1: the first source is not 16-byte aligned
+        for j in range(n_jobs):
+            n = lens[j]
+            src = base[off: off + n]
+            sq = j % 2 == 1
+            scale = 0.5 + j
+            dev = dsc if j == 2 else None
+            jobs.append((src.data_ptr(), n, scale, dev, j, sq))
+            v = src.double()
+            want[j] = float(((v * v) if sq else v).sum()) * scale * (0.25 if j == 2 else 1.0)
+            off += n + (3 if j % 3 == 0 else 4 - (off + n) % 4)   # mixes aligned and unaligned starts
+        hist = torch.zeros(16, device="cuda")
+        thist = torch.zeros(16, n_terms, device="cuda")
+        hstep = torch.tensor([5], dtype=torch.int64, device="cuda")
+        cursor = torch.tensor([2], dtype=torch.int64, device="cuda")
+        counter = torch.tensor([9], dtype=torch.int64, device="cuda")
+        L.finish_step(jobs, terms, n_terms, hist, thist, hstep, cursor, counter)
+        got = terms.double().cpu().numpy()
+        scale_abs = np.maximum(1.0, np.abs(want.cpu().numpy()))
+        assert np.all(np.abs(got - want.cpu().numpy()) <= 2e-5 * scale_abs * 30), (n_jobs, got, want)
+        assert (int(hstep), int(cursor), int(counter)) == (6, 3, 10)
+        assert float(hist[5]) == pytest.approx(float(terms.double().sum()), rel=1e-6)
+        assert torch.equal(thist[5], terms)
+        # sums only (no bookkeeping): counters untouched
+        L.finish_step(jobs, terms, n_terms)
+        assert (int(hstep), int(cursor), int(counter)) == (6, 3, 10)
