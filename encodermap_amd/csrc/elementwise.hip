@@ -26,6 +26,13 @@ namespace {
 // K13 + K4: gather rows by index, optionally emit [sin | cos]      autoencoder.py:845-856, models.py:3347-3351
 // one wave per row; lanes stride the feature axis (coalesced 256-B segments of the gathered row)
 // ---------------------------------------------------------------------------------------------------
+#ifdef EMX_CHAIN_TIMING   // in-kernel timelines of the two scalar-ish kernels of a step (tools/abl_finish.py)
+__device__ long long emx_dbg_fin[64];
+#define FSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) emx_dbg_fin[k] = clock64(); } while (0)
+#else
+#define FSTAMP(k)
+#endif
+
 struct GatherArgs {
   const float* data;
   int D;
@@ -188,6 +195,7 @@ struct AdamArgs {
   float* ws;
   long n;
   float lr, b1, b2, eps, clip;
+  float log2_b1, log2_b2;
   float* mirror;        // optional: operand store of the dense layers, rewritten with the new weights (mirror.h)
   MirrorArgs mir;
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
@@ -206,10 +214,23 @@ __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, 
 
 __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
   if (!a.gpart) return reinterpret_cast<const float4*>(a.g)[i4];
-  // fixed association (slice s goes to partial s % 4); 16 loads in flight -- the optimizer is a latency-bound stream, with 4
-  // in flight the 32 slices of a 4096-row batch were eight dependent round trips
+  // fixed association (slice s goes to partial s % 4); 32 loads in flight -- the optimizer is a latency-bound stream (a
+  // round trip costs ~2.7 us behind the weight-gradient kernel's fresh lines); with 4 in flight the 32 slices of a
+  // 4096-row batch were eight dependent round trips
   float4 p0 = make_float4(0.f, 0.f, 0.f, 0.f), p1 = p0, p2 = p0, p3 = p0;
   int s = 0;
+  for (; s + 32 <= a.n_slices; s += 32) {
+    float4 q[32];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) q[u] = reinterpret_cast<const float4*>(a.gpart + (long)(s + u) * a.gstride)[i4];
+#pragma unroll
+    for (int u = 0; u < 32; u += 4) {
+      p0.x += q[u].x; p0.y += q[u].y; p0.z += q[u].z; p0.w += q[u].w;
+      p1.x += q[u + 1].x; p1.y += q[u + 1].y; p1.z += q[u + 1].z; p1.w += q[u + 1].w;
+      p2.x += q[u + 2].x; p2.y += q[u + 2].y; p2.z += q[u + 2].z; p2.w += q[u + 2].w;
+      p3.x += q[u + 3].x; p3.y += q[u + 3].y; p3.z += q[u + 3].z; p3.w += q[u + 3].w;
+    }
+  }
   for (; s + 16 <= a.n_slices; s += 16) {
     float4 q[16];
 #pragma unroll
@@ -240,19 +261,28 @@ __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
                      (p0.w + p1.w) + (p2.w + p3.w));
 }
 
+// Launched with one wave per workgroup: the update of ~1e5 parameters reads 36 streams (32 gradient slices, w, m, v,
+// l2coef), ~150 KB per 1024 parameters, and a CU takes 64 B/clk -- on 65 CUs (256-thread workgroups) the loads alone were
+// 2300+ cycles of L1 fill per CU; one wave per workgroup spreads them over every CU.
 __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
-  __shared__ float red[8];
+  __shared__ float red[NT / 64];
+  const int nt = blockDim.x;
   if ((int)blockIdx.x >= a.adam_blocks) {
     // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
     // beside it, on other CUs, instead of in a launch of their own at the head of the next step
     const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks;
-    gather_rows_body(a.next, (gb * NT + threadIdx.x) >> 6, (ngb * NT) >> 6, threadIdx.x & 63);
+    gather_rows_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     return;
   }
   const int nblk = a.adam_blocks;
-  const float t = (float)(*a.step + 1);
-  // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step)
-  const float alpha = a.lr * sqrtf(1.f - powf(a.b2, t)) / (1.f - powf(a.b1, t));
+  FSTAMP(16);
+  const long step_now = *a.step;   // requested first, consumed behind the parameter loads (one round trip, not two)
+  // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step); b^t = 2^(t log2 b) on the hardware
+  // exp2 (the library powf is several hundred instructions in front of the first load of a latency-bound kernel)
+  auto alpha_of = [&](long st) {
+    const float t = (float)(st + 1);
+    return a.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.log2_b1));
+  };
   float reg = 0.f;
   const long n4 = a.n >> 2;
   const bool vec = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.m) |
@@ -260,12 +290,14 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
                      (uintptr_t)(a.gstride * 4)) & 15) == 0;
   long start = 0;
   if (vec) {
-    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)nblk * NT) {
+    for (long i = (long)blockIdx.x * nt + threadIdx.x; i < n4; i += (long)nblk * nt) {
       float4 w = reinterpret_cast<float4*>(a.w)[i];
-      float4 g = grad4(a, i);
       float4 m = reinterpret_cast<float4*>(a.m)[i];
       float4 v = reinterpret_cast<float4*>(a.v)[i];
       float4 l = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 g = grad4(a, i);
+      const float alpha = alpha_of(step_now);
+      FSTAMP(17);
       adam_one(w.x, g.x, m.x, v.x, l.x, a, alpha, reg);
       adam_one(w.y, g.y, m.y, v.y, l.y, a, alpha, reg);
       adam_one(w.z, g.z, m.z, v.z, l.z, a, alpha, reg);
@@ -273,16 +305,12 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
       reinterpret_cast<float4*>(a.w)[i] = w;
       reinterpret_cast<float4*>(a.m)[i] = m;
       reinterpret_cast<float4*>(a.v)[i] = v;
-      if (a.mirror) {
-        mirror_scatter(a.mir, a.mirror, 4 * i, w.x);
-        mirror_scatter(a.mir, a.mirror, 4 * i + 1, w.y);
-        mirror_scatter(a.mir, a.mirror, 4 * i + 2, w.z);
-        mirror_scatter(a.mir, a.mirror, 4 * i + 3, w.w);
-      }
+      FSTAMP(18);
+      if (a.mirror) mirror_scatter4(a.mir, a.mirror, 4 * i, w.x, w.y, w.z, w.w);
     }
     start = n4 << 2;
   }
-  for (long i = start + (long)blockIdx.x * NT + threadIdx.x; i < a.n; i += (long)nblk * NT) {
+  for (long i = start + (long)blockIdx.x * nt + threadIdx.x; i < a.n; i += (long)nblk * nt) {
     float w = a.w[i], m = a.m[i], v = a.v[i];
     float g;
     if (a.gpart) {
@@ -291,16 +319,24 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     } else {
       g = a.g[i];
     }
-    adam_one(w, g, m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha, reg);
+    adam_one(w, g, m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha_of(step_now), reg);
     a.w[i] = w;
     a.m[i] = m;
     a.v[i] = v;
     if (a.mirror) mirror_scatter(a.mir, a.mirror, i, w);
   }
-  float tsum = block_sum<NT>(reg, red);
-  if (threadIdx.x == 0) a.ws[blockIdx.x] = tsum;
+  FSTAMP(19);
+  reg = wave_sum(reg);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = reg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float tsum = 0.f;
+    for (int wv = 0; wv < nt / 64; ++wv) tsum += red[wv];
+    a.ws[blockIdx.x] = tsum;
+  }
+  FSTAMP(20);
   if (blockIdx.x == 0)
-    for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
+    for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += nt) a.ws[i] = 0.f;
 }
 
 __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
@@ -339,12 +375,6 @@ struct FinishArgs {
 // step_tick_kernel works from values fetched at kernel entry.  A single workgroup is bound by round trips (~2.7 us each
 // here: freshly written lines of other XCDs, cold TLB) and by its own instruction count, not by bandwidth; job after job,
 // each with its own reduction and a serial tail, was 9 us.  Fixed order throughout.
-#ifdef EMX_CHAIN_TIMING
-__device__ long long emx_dbg_fin[64];
-#define FSTAMP(k) do { if (threadIdx.x == 0) emx_dbg_fin[k] = clock64(); } while (0)
-#else
-#define FSTAMP(k)
-#endif
 constexpr int FQ = 8;   // 16-byte loads per thread and job in the common round
 
 __global__ __launch_bounds__(NT) void finish_step_kernel(const FinishArgs a) {
@@ -532,6 +562,9 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 }
 
 namespace {
+constexpr int ADAM_NT = 64;   // one wave per workgroup (see adam_kernel)
+inline int gather_blocks(const emx_next_batch* next) { return next ? (int)std::min<long>(next->B, 8192) : 0; }   // one row per wave
+
 int check_next(const emx_next_batch* next, const char* who) {
   if (!next) return EMX_OK;
   EMX_REQUIRE(next->data && next->idx && next->cursor && (next->xb || next->xin), "%s: incomplete next-batch description", who);
@@ -565,6 +598,8 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
   a.lr = lr;
   a.b1 = beta1;
   a.b2 = beta2;
+  a.log2_b1 = (float)std::log2((double)beta1);
+  a.log2_b2 = (float)std::log2((double)beta2);
   a.eps = eps;
   a.clip = clip;
   return a;
@@ -580,10 +615,10 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
   AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
-  const int grid = grid_for((n + 3) / 4, NT);
+  const int grid = grid_for((n + 3) / 4, ADAM_NT);
   a.adam_blocks = grid;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid + (next ? grid_for(next->B, 4) : 0)), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid + gather_blocks(next)), dim3(ADAM_NT), 0, st, a);
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   if (reg_loss) {
@@ -603,8 +638,8 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
   EMX_REQUIRE(n > 0 && n_slices > 0 && partial_stride >= n, "emx_adam_step_slices: bad slice layout");
   AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc,
                          mirror, next);
-  a.adam_blocks = grid_for((n + 3) / 4, NT);
-  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + (next ? grid_for(next->B, 4) : 0)), dim3(NT), 0, (hipStream_t)stream, a);
+  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next)), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
 }
 
@@ -618,12 +653,12 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
   EMX_REQUIRE(!g_partials || (n_slices > 0 && partial_stride >= n), "emx_adam_tick: bad slice layout");
   EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && reg_slot >= 0 && reg_slot < n_terms, "emx_adam_tick: bad sizes");
   AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws, mirror_desc, mirror);
-  a.adam_blocks = grid_for((n + 3) / 4, NT);
+  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
   // Three plain launches on the stream.  (An in-kernel hand-off -- last workgroup finishes -- was measured slower: its
   // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
-  const int grid = grid_for((n + 3) / 4, NT);
+  const int grid = a.adam_blocks;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(ADAM_NT), 0, st, a);
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, (const float*)nullptr, terms + reg_slot);

@@ -53,4 +53,33 @@ __device__ __forceinline__ void mirror_scatter(const MirrorArgs& ma, float* __re
   }
 }
 
+// four consecutive parameters i0 .. i0+3 (i0 % 4 == 0): when they are four consecutive output columns of one kernel row
+// whose width is a multiple of 4 (the usual case) the backward operand takes them as ONE 16-byte store and the row / layer
+// search runs once; otherwise element by element
+__device__ __forceinline__ void mirror_scatter4(const MirrorArgs& ma, float* __restrict__ mirror, long i0, float w0, float w1, float w2,
+                                                float w3) {
+#pragma unroll
+  for (int l = 0; l < EMX_MAX_LAYERS; ++l) {
+    if (l >= ma.n_layers) break;
+    const int K = ma.width[l], N = ma.width[l + 1];
+    const long rel = i0 - ma.w_off[l];
+    if ((N & 3) == 0 && (ma.w_off[l] & 3) == 0 && rel >= 0 && rel < (long)K * N) {
+      const int k = (int)(rel / N), n = (int)(rel - (long)k * N);   // n % 4 == 0
+      float* fwd = mirror + ma.begin[l];
+      const long f0 = operand_index(n, k, (K + 15) >> 4);           // j = n .. n+3 -> lanes m .. m+3: 4 floats apart
+      fwd[f0] = w0;
+      fwd[f0 + 4] = w1;
+      fwd[f0 + 8] = w2;
+      fwd[f0 + 12] = w3;
+      float4* bwd = reinterpret_cast<float4*>(fwd + operand_block(K, N) + operand_index(k, n, (N + 15) >> 4));   // k index n .. n+3 = i
+      *bwd = make_float4(w0, w1, w2, w3);
+      return;
+    }
+  }
+  mirror_scatter(ma, mirror, i0, w0);
+  mirror_scatter(ma, mirror, i0 + 1, w1);
+  mirror_scatter(ma, mirror, i0 + 2, w2);
+  mirror_scatter(ma, mirror, i0 + 3, w3);
+}
+
 }  // namespace emx

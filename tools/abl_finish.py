@@ -16,3 +16,4 @@ buf = np.zeros(64, dtype=np.int64)
 lib.emx_debug_read_fin.argtypes = [ctypes.c_void_p]
 assert lib.emx_debug_read_fin(buf.ctypes.data) == 0
 print("finish_step stamps (clk since entry):", (buf[:6] - buf[0]).tolist())
+print("adam block 0 stamps [entry, grads summed, w/m/v stored, mirror written, reg partial written]:", (buf[16:21] - buf[16]).tolist())
