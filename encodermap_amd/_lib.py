@@ -37,11 +37,13 @@ SIGNATURES = {
     "emx_target_arch": (C.c_char_p, []),
     "emx_sketchmap_ws_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
-    "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p]),
+    "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p, _p]),
+    "emx_sketchmap_split_bytes": (_sz, [_i, _i]),
+    "emx_sketchmap_split": (_i, [_p, _i, _i, _i, _p, _p]),
     "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_sketchmap_describe": (_i, [_i, _i, _i, _p, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _sz, _p]),
     "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
-    "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p]),
+    "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p, _p]),
     "emx_periodic_in": (_i, [_p, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
@@ -85,14 +87,15 @@ class NextBatch(C.Structure):
     """Mirror of ``emx_next_batch``: the rows of batch cursor + 1, gathered beside the optimizer."""
 
     _fields_ = [("data", _p), ("n_rows", _l), ("D", _i), ("idx", _p), ("n_batches", _i), ("cursor", _p), ("B", _i), ("periodicity", _f),
-                ("xb", _p), ("xin", _p)]
+                ("xb", _p), ("xin", _p), ("split_ws", _p)]
 
 
-def make_next_batch(data, idx, cursor, B, periodicity, xb, xin) -> NextBatch:
+def make_next_batch(data, idx, cursor, B, periodicity, xb, xin, split_ws=None) -> NextBatch:
     N, D = data.shape
     assert idx.dtype == torch.int64 and idx.is_contiguous() and data.is_contiguous() and idx.numel() % B == 0
-    nb = NextBatch(_ptr(data), N, D, _ptr(idx), idx.numel() // B, _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin))
-    nb.keep = (data, idx, cursor, xb, xin)
+    nb = NextBatch(_ptr(data), N, D, _ptr(idx), idx.numel() // B, _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin),
+                   _ptr(split_ws))
+    nb.keep = (data, idx, cursor, xb, xin, split_ws)
     return nb
 
 
@@ -235,11 +238,23 @@ def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, ro
     _check(rc, "emx_sketchmap_fwd_bwd")
 
 
-def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws):
+def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws, split_ws=None):
+    """``split_ws`` (from sketchmap_split / gather_rows / the optimizer's next-batch gather): Gram products on the bf16 cores."""
     B, D = X.shape
     sig_arr = (_f * 6)(*[float(s) for s in sig])
     _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, int(row_begin),
-                                      int(row_end), _ptr(ws), ws.numel() * ws.element_size(), _stream()), "emx_sketchmap_tiles")
+                                      int(row_end), _ptr(ws), ws.numel() * ws.element_size(), _ptr(split_ws), _stream()),
+           "emx_sketchmap_tiles")
+
+
+def sketchmap_split_bytes(B, D):
+    return int(load().emx_sketchmap_split_bytes(int(B), int(D)))
+
+
+def sketchmap_split(X, split_ws):
+    B, D = X.shape
+    assert split_ws.numel() * split_ws.element_size() >= sketchmap_split_bytes(B, D)
+    _check(load().emx_sketchmap_split(_ptr(X), B, D, X.stride(0), _ptr(split_ws), _stream()), "emx_sketchmap_split")
 
 
 def sketchmap_finish(B, D, Z, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws):
@@ -255,12 +270,12 @@ def pairwise_dist(X, periodicity, out):
     _check(load().emx_pairwise_dist(_ptr(_f32c(X, "X")), B, D, X.stride(0), float(periodicity), _ptr(out), _stream()), "emx_pairwise_dist")
 
 
-def gather_rows(data, idx, periodicity, xb, xin, cursor=None, B=None):
+def gather_rows(data, idx, periodicity, xb, xin, cursor=None, B=None, split_ws=None):
     N, D = data.shape
     assert idx.dtype == torch.int64 and idx.is_contiguous()
     B = idx.numel() if B is None else B
     _check(load().emx_gather_rows(_ptr(_f32c(data, "data")), N, D, _ptr(idx), _ptr(cursor), B, float(periodicity), _ptr(xb), _ptr(xin),
-                                  _stream()), "emx_gather_rows")
+                                  _ptr(split_ws), _stream()), "emx_gather_rows")
 
 
 def periodic_in(x, periodicity, out):

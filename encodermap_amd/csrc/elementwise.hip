@@ -4,6 +4,7 @@
 #include "emx_common.h"
 #include "cost.h"
 #include "mirror.h"
+#include "split.h"
 
 namespace {
 
@@ -44,6 +45,7 @@ struct GatherArgs {
   float ang_scale;
   float* xb;
   float* xin;
+  SplitRows split;    // optional (planes != null): bf16 planes + norms of (row - row 0 of the batch) for the all-pairs kernel
 };
 
 // rows b = wave, wave + nwaves, ... of the batch
@@ -55,8 +57,10 @@ __device__ __forceinline__ void gather_rows_body(const GatherArgs& g, int wave, 
     idx += batch * (long)g.B;
   }
   const int D = g.D;
+  const float* __restrict__ ref = g.split.planes ? g.data + idx[0] * (long)D : nullptr;
   for (int b = wave; b < g.B; b += nwaves) {
     const float* __restrict__ src = g.data + idx[b] * (long)D;
+    if (g.split.planes) split_row(g.split, src, ref, D, b, lane);
     for (int k = lane; k < D; k += 64) {
       const float v = src[k];
       if (g.xb) g.xb[(long)b * D + k] = v;
@@ -488,11 +492,12 @@ const char* emx_last_error(void) { return g_err; }
 const char* emx_target_arch(void) { return "gfx950"; }
 
 int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B, float periodicity,
-                    float* xb, float* xin, emx_stream_t stream) {
+                    float* xb, float* xin, void* split_ws, emx_stream_t stream) {
   EMX_REQUIRE(data && idx && (xb || xin), "emx_gather_rows: null pointer argument");
   EMX_REQUIRE(N > 0 && D > 0 && B > 0, "emx_gather_rows: bad shape N=%ld D=%d B=%d", (long)N, D, B);
   EMX_REQUIRE(!xin || (std::isfinite(periodicity) && periodicity > 0.f), "emx_gather_rows: sin/cos output needs a finite periodicity");
-  GatherArgs g{data, D, idx, cursor, B, 0, 0, xin ? (periodicity == TWO_PI ? 1.f : TWO_PI / periodicity) : 1.f, xb, xin};
+  GatherArgs g{data, D, idx, cursor, B, 0, 0, xin ? (periodicity == TWO_PI ? 1.f : TWO_PI / periodicity) : 1.f, xb, xin, SplitRows{}};
+  if (split_ws) g.split = split_view(split_ws, B, D);
   hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, 4)), dim3(NT), 0, (hipStream_t)stream, g);
   return emx::check_launch("gather_rows_kernel");
 }
@@ -580,7 +585,8 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
   if (next) {
     const bool periodic = next->xin != nullptr;
     a.next = GatherArgs{next->data, next->D, next->idx, next->cursor, next->B, 1, next->n_batches,
-                        periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin};
+                        periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin, SplitRows{}};
+    if (next->split_ws) a.next.split = split_view(next->split_ws, next->B, next->D);
   }
   a.mirror = (mirror_desc && mirror) ? mirror : nullptr;
   if (a.mirror) fill_mirror_args(mirror_desc, a.mir);

@@ -31,6 +31,7 @@
 // direct differences instead of the Gram identity (no cancellation); the periodic path omits the +1e-12
 // regularisers of distances.py:169-175 (they only keep TF's sqrt gradient finite; X carries no gradient here).
 #include "emx_common.h"
+#include "split.h"
 
 #include <cstdlib>
 
@@ -65,6 +66,7 @@ struct SkArgs {
   int vec4;
   float period;
   SigDev sh, sl;
+  SplitRows split;   // optional bf16 planes + norms of the rows (split.h): selects the bf16 Gram kernel
 };
 
 template <int N>
@@ -342,6 +344,14 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
 // ---------------------------------------------------------------------------------------------------------
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef EMX_CHAIN_TIMING   // per-workgroup timeline of the all-pairs kernel (tools/abl_tiles.py)
+__device__ long long emx_dbg_sk[4 * 32 + 3 * 4096];
+#define KSTAMP(k) do { if (threadIdx.x == 0) { if ((blockIdx.x & 511) == 0 && blockIdx.x < 2048) emx_dbg_sk[(blockIdx.x >> 9) * 32 + (k)] = clock64(); \
+    if (blockIdx.x < 4096 && ((k) == 0 || (k) == 23)) { emx_dbg_sk[128 + 3 * blockIdx.x + ((k) ? 1 : 0)] = wall_clock64(); if (k) emx_dbg_sk[128 + 3 * blockIdx.x + 2] = __builtin_amdgcn_s_getreg(0x1804 /* HW_ID... */); } } } while (0)
+#else
+#define KSTAMP(k)
+#endif
+
 template <int LT, bool FASTSIG>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_tile_mfma_kernel(const SkArgs a) {
   // Resource budget: <= 64 VGPRs and <= 20 KB LDS per workgroup so that 8 tiles (8 waves per SIMD) are resident per
@@ -379,6 +389,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
   const int j0 = tj * T;
   const bool offdiag = a.symm && (ti != tj);
 
+  KSTAMP(0);
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -410,6 +421,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
     }
   };
   gload(0);
+  KSTAMP(1);
   for (int k0 = 0; k0 < a.D; k0 += KC) {
     __syncthreads();
 #pragma unroll
@@ -420,7 +432,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
       pnj[q] = fmaf(pj[q].x, pj[q].x, fmaf(pj[q].y, pj[q].y, fmaf(pj[q].z, pj[q].z, fmaf(pj[q].w, pj[q].w, pnj[q]))));
     }
     __syncthreads();
-    if (k0 + KC < a.D) gload(k0 + KC);
+    KSTAMP(2 + 2 * (k0 / KC));
+    gload(k0 + KC < a.D ? k0 + KC : k0);   // unconditional: see sk_tile_f16_kernel
 #pragma unroll
     for (int c = 0; c < KC / 8; ++c) {
       const float4 av = *reinterpret_cast<const float4*>(&Xi_s[(wm * 32 + lr) * LS + 8 * c + 4 * h]);
@@ -430,6 +443,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
     }
+    KSTAMP(3 + 2 * (k0 / KC));
   }
   // row norms: the 8 lanes that share a row (kq = 0..7) add their partials in a fixed order
 #pragma unroll
@@ -446,6 +460,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
     }
   }
   __syncthreads();   // norms visible; all MFMA operand reads done: the staging area becomes the row-partial area
+  KSTAMP(20);
 
   // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
   const int jl = wn * 32 + lr;
@@ -503,7 +518,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
       if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
     }
   }
+  KSTAMP(21);
   float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
+  KSTAMP(22);
   if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
 
   for (int e = tid; e < T * LMAX; e += NT) {
@@ -526,6 +543,204 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
       if (l < L) a.P[((long)ti * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
     }
   }
+  KSTAMP(23);
+}
+
+// The same tile with the Gram product on the 16-bit matrix cores (split.h): operands are the pre-split f16 planes of the rows.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint4 is a struct: an array of them stays in scratch memory)
+
+// NCH > 0: the number of 32-feature chunks is a compile-time constant and the K loop is fully unrolled -- with a rolled loop
+// the prefetched pieces are loop-carried registers, the compiler loads into temporaries and copies them into place at the
+// loop's end, and that copy waits for the data one instruction after it was requested.
+template <int LT, bool FASTSIG, int NCH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void sk_tile_f16_kernel(const SkArgs a) {
+  // (the compiler sizes its register budget for the occupancy a 64-KB LDS would allow; gfx950 has 160 KB, so the target
+  //  is stated: >= 5 tiles resident per CU)
+  constexpr int T = 64;
+  constexpr int LMAX = LT ? LT : 4;
+  constexpr int RP = 36;                                // 32 pre-reduced column-lane partials per (row, l) + pad
+  constexpr int STAGE = 1024 * 4;                       // 2 sides x 2 planes x 64 rows x 32 k f16, as 16-byte pieces
+  constexpr int PART = T * LMAX * RP;                   // row partials (reuse the staging area)
+  constexpr int MAIN = STAGE > PART ? STAGE : PART;
+  constexpr int SMEM = MAIN + 4 * T + T * LMAX + T * LMAX * 2 + 8;   // + (norm, 1/scale) of 2 T rows + latent rows of the tile + column partials
+  __shared__ __align__(16) float smem[SMEM];
+  float2* nr_s = reinterpret_cast<float2*>(smem + MAIN);   // [2 T] (|x|^2, 1/s): rows of the i side, then of the j side
+  float* zi_s = smem + MAIN + 4 * T;                    // [T][LMAX]
+  float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
+  float* red = cpart + T * LMAX * 2;
+
+  const int L = LT ? LT : a.L;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
+  const int lr = lane & 31, h = lane >> 5;
+
+  int ti, tj;
+  if (a.symm) {
+    tri_decode(blockIdx.x, a.nbc, ti, tj);
+  } else {
+    ti = blockIdx.x / a.nbc;
+    tj = blockIdx.x - ti * a.nbc;
+  }
+  const int i0 = a.row0 + ti * T;
+  const int j0 = tj * T;
+  const bool offdiag = a.symm && (ti != tj);
+
+  KSTAMP(0);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  // latent rows of the tile's i side -> LDS (read back as broadcasts in the epilogue instead of living in registers)
+  for (int e = tid; e < T * LMAX; e += NT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const int ig = min(i0 + rl, a.B - 1);
+    zi_s[e] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
+  }
+
+  // ---- K loop: 32 reduction indices per chunk; the four operand planes of the tile's 64 + 64 rows are staged as 16-byte
+  //      pieces (8 f16) -- one contiguous 4-KB block per side and plane in the chunk-major planes -- through an LDS image
+  //      that is XOR-swizzled so that the ds_read_b128 of 16 consecutive rows covers all 64 banks; 2 x 3 MFMAs per chunk
+  const SplitRows sp = a.split;
+  const uint16_t* gp[4];
+  int lo[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + NT * u;                       // piece: side (i / j), plane, row, quarter q
+    const int side = e >> 9, plane = (e >> 8) & 1, row = (e & 255) >> 2, q = e & 3;
+    const int grow = min((side ? j0 : i0) + row, a.B - 1);
+    gp[u] = sp.planes + plane * sp.plane_stride + (long)grow * SPLIT_KC + 8 * q;
+    lo[u] = ((side * 2 + plane) * 64 + row) * 4 + (q ^ ((row >> 2) & 3));
+  }
+  u32x4 pre[4];
+  const long chunk_stride = (long)sp.B * SPLIT_KC;
+  const int nch = NCH > 0 ? NCH : sp.ld / SPLIT_KC;
+  const int ra = wm * 32 + lr, rbj = wn * 32 + lr;
+  u32x4* buf = reinterpret_cast<u32x4*>(smem);
+  // (no lambdas around `pre`: captured by reference it stays an addressable array, i.e. in scratch memory)
+#define SK_GLOAD(cc)                                                                                       \
+  {                                                                                                        \
+    const long goff = (long)min((cc), nch - 1) * chunk_stride;                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const u32x4*>(gp[u] + goff); \
+  }
+#define SK_CHUNK(cc, more)                                                                                              \
+  {                                                                                                                     \
+    __syncthreads();                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[lo[u]] = pre[u];                                                  \
+    __syncthreads();                                                                                                    \
+    if ((cc) < 4) KSTAMP(2 + 2 * (cc));                                                                                 \
+    if (more) SK_GLOAD((cc) + 1)                                                                                        \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+      const int qa = (2 * t + h) ^ ((ra >> 2) & 3), qb = (2 * t + h) ^ ((rbj >> 2) & 3);                                \
+      const f16x8 ah = __builtin_bit_cast(f16x8, buf[ra * 4 + qa]), al = __builtin_bit_cast(f16x8, buf[(64 + ra) * 4 + qa]);          \
+      const f16x8 bh = __builtin_bit_cast(f16x8, buf[(128 + rbj) * 4 + qb]), bl = __builtin_bit_cast(f16x8, buf[(192 + rbj) * 4 + qb]); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0); /* small products first */                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);                                               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);                                               \
+    }                                                                                                                   \
+    if ((cc) < 4) KSTAMP(3 + 2 * (cc));                                                                                 \
+  }
+  SK_GLOAD(0)   // ahead of the small prologue loads
+  KSTAMP(1);
+  for (int e = tid; e < 2 * T; e += NT) {             // (norm, 1/scale) of both sides' rows
+    const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
+    nr_s[e] = make_float2(sp.norms[grow], sp.rscale[grow]);
+  }
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) SK_CHUNK(c, c + 1 < NCH)
+  } else {
+    for (int c = 0; c < nch; ++c) SK_CHUNK(c, true)   // (the last request re-reads its own chunk)
+  }
+#undef SK_CHUNK
+#undef SK_GLOAD
+  __syncthreads();   // norms visible; all MFMA operand reads done: the staging area becomes the row-partial area
+  KSTAMP(20);
+
+  // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
+  const int jl = wn * 32 + lr;
+  const int jg = j0 + jl;
+  const bool jok = jg < a.B;
+  const float2 nrj = nr_s[T + jl];
+  const float nj = nrj.x, cj = -2.f * nrj.y;
+  float zj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) zj[l] = (jok && l < L) ? a.Z[(long)jg * L + l] : 0.f;
+
+  float* rpart = smem;   // [T][LMAX][RP]
+  float gj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+  float lsum = 0.f;
+  // interior tiles (the vast majority) need no validity masks and no diagonal fix-up
+  const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+  auto pair = [&](int r, bool masked) {
+    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float dz[LMAX];
+    float dl2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      dz[l] = zi_s[il * LMAX + l] - zj[l];
+      dl2 = fmaf(dz[l], dz[l], dl2);
+    }
+    const float2 nri = nr_s[il];
+    float d2 = fmaxf(fmaf(acc[r] * nri.y, cj, nri.x + nj), 0.f);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
+    if (masked) d2 = (i0 + il == jg) ? 0.f : d2;
+    const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+    float El, G;
+    sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+    float f = El - Eh;
+    if (masked) f = (i0 + il < a.row_end && jok) ? f : 0.f;
+    lsum = fmaf(f, f, lsum);
+    const float g = f * G;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      float v = g * dz[l];
+      gj[l] -= v;
+      v += __shfl_xor(v, 1, 64);                       // neighbouring columns pre-reduced in registers
+      if ((lr & 1) == 0) rpart[(il * LMAX + l) * RP + (jl >> 1)] = v;
+    }
+  };
+  if (edge) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, true);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, false);
+  }
+  if (offdiag) {
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      float s = gj[l] + __shfl_xor(gj[l], 32, 64);   // the two row halves of the quadrant
+      if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
+    }
+  }
+  KSTAMP(21);
+  float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
+  KSTAMP(22);
+  if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
+
+  for (int e = tid; e < T * LMAX; e += NT) {
+    int rl = e / LMAX, l = e - rl * LMAX;
+    if (l < L) {
+      const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; u += 4) {
+        float4 s0 = p[u], s1 = p[u + 1], s2 = p[u + 2], s3 = p[u + 3];
+        s += (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+             (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+      }
+      a.P[((long)tj * a.nrows_pad + (i0 - a.row0) + rl) * L + l] = s;
+    }
+  }
+  if (offdiag) {
+    for (int e = tid; e < T * LMAX; e += NT) {
+      int rl = e / LMAX, l = e - rl * LMAX;
+      if (l < L) a.P[((long)ti * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+    }
+  }
+  KSTAMP(23);
 }
 
 struct FinArgs {
@@ -661,7 +876,7 @@ struct SkPlan {
 
 int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6],
               float scale, float center_scale, int row_begin, int row_end, float* dist_loss, float* center_loss,
-              float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who) {
+              float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who, void* split_ws = nullptr) {
   EMX_REQUIRE(X && Z && ws && sig, "%s: null pointer argument", who);
   EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "%s: bad shape B=%d D=%d ldx=%d", who, B, D, ldx);
   if (L < 1 || L > 4) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..4)", who, L);
@@ -679,7 +894,8 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
     pl.gram = !(e && e[0] == '1');
   }
   const bool vec4ok = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-  const int T = pick_tile(B, nrows, pl.gram && !pl.periodic && vec4ok);
+  const bool split_ok = split_ws != nullptr && pl.gram && !pl.periodic;
+  const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok);
   pl.T = T;
   pl.fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
   SkArgs& a = pl.a;
@@ -695,6 +911,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.nbc = (B + T - 1) / T;
   a.nrows_pad = a.nbr * T;
   a.symm = symm;
+  a.split = split_ok ? split_view(split_ws, B, D) : SplitRows{};
   a.vec4 = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   a.period = periodicity;
   a.sh = make_sig(sig[0], sig[1], sig[2]);
@@ -732,6 +949,17 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
 
 int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   const SkArgs& a = pl.a;
+  if (a.split.planes != nullptr && pl.T == 64) {
+    const int nch = a.split.ld / SPLIT_KC;
+    if (a.L == 2 && pl.fast && nch == 4) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 4>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else if (a.L == 2 && pl.fast && nch == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 2>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else if (a.L == 2 && pl.fast && nch == 1) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 1>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    return emx::check_launch("sk_tile_f16_kernel");
+  }
   if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram) {
     if (a.L == 2) {
       if (pl.fast) hipLaunchKernelGGL((sk_tile_mfma_kernel<2, true>), dim3(pl.ntiles), dim3(NT), 0, st, a);
@@ -759,7 +987,23 @@ int launch_finish_plan(const SkPlan& pl, hipStream_t st) {
 
 }  // namespace
 
+__global__ __launch_bounds__(NT) void sk_split_kernel(const float* __restrict__ X, int B, int D, int ldx, const SplitRows sp) {
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6, nwaves = (gridDim.x * NT) >> 6;
+  for (int b = wave; b < B; b += nwaves) split_row(sp, X + (long)b * ldx, X, D, b, lane);
+}
+
 extern "C" {
+
+size_t emx_sketchmap_split_bytes(int B, int D) { return (B > 0 && D > 0) ? split_bytes(B, D) : 0; }
+
+int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, emx_stream_t stream) {
+  EMX_REQUIRE(X && split_ws && B > 0 && D > 0 && ldx >= D, "emx_sketchmap_split: bad arguments");
+  EMX_REQUIRE((reinterpret_cast<uintptr_t>(split_ws) & 15) == 0, "emx_sketchmap_split: workspace must be 16-byte aligned");
+  const SplitRows sp = split_view(split_ws, B, D);
+  hipLaunchKernelGGL(sk_split_kernel, dim3((unsigned)std::min((B + 3) / 4, 4096)), dim3(NT), 0, (hipStream_t)stream, X, B, D, ldx, sp);
+  return emx::check_launch("sk_split_kernel");
+}
 
 int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
                           const float sig[6], float scale, float center_scale, int row_begin, int row_end,
@@ -776,10 +1020,11 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
 }
 
 int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
-                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, emx_stream_t stream) {
+                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, void* split_ws,
+                        emx_stream_t stream) {
   SkPlan pl;
   int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, row_begin, row_end, nullptr, nullptr, nullptr, ws, ws_bytes,
-                     pl, "emx_sketchmap_tiles");
+                     pl, "emx_sketchmap_tiles", split_ws);
   if (rc) return rc;
   return launch_tiles_plan(pl, (hipStream_t)stream);
 }
@@ -826,3 +1071,7 @@ int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, 
 }
 
 }  // extern "C"
+
+#ifdef EMX_CHAIN_TIMING
+extern "C" int emx_debug_read_sk(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_sk), sizeof(emx_dbg_sk)); }
+#endif

@@ -164,6 +164,10 @@ class SequentialEngine:
         self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        # bf16 planes + norms of the batch rows for the all-pairs kernel (Euclidean data only), made beside the gather
+        self.split_ws = None
+        if self._prefetch and not self.periodic and self.with_distance and self.p.distance_cost_scale is not None:
+            self.split_ws = torch.zeros(_lib.sketchmap_split_bytes(B, self.D), dtype=torch.uint8, device=dev)
         self.cost_ws = torch.zeros(_lib.mlp_row_blocks(self.re - self.rb), dtype=f32, device=dev)   # auto cost per row block (zero: no auto cost)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
@@ -207,7 +211,7 @@ class SequentialEngine:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
         step gathers the next batch)."""
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
-                         self.xin if self.periodic else None, cursor=self.cursor, B=self.B)
+                         self.xin if self.periodic else None, cursor=self.cursor, B=self.B, split_ws=self.split_ws)
 
     def _forward(self) -> None:
         """Forward pass and auto cost in ONE launch (two for a row-block rank: encoder on every row, decoder and cost on the
@@ -233,7 +237,7 @@ class SequentialEngine:
         p = self.p
         Z = self.h[self.layout.n_enc - 1]
         if self._use_sketchmap():
-            _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws)
+            _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws, self.split_ws)
         else:
             cs = p.center_cost_scale
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, self.rb, self.re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
@@ -293,7 +297,7 @@ class SequentialEngine:
         nxt = None
         if self._prefetch:
             nxt = _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
-                                       self.xin if self.periodic else None)
+                                       self.xin if self.periodic else None, self.split_ws)
         if self.dp.active:
             _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2,
                            plan=self.plan, next_batch=nxt)

@@ -76,7 +76,16 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
  * callers that want other work between the O(B^2 D) tile pass and the O(B) reduction).  Same arguments; the
  * tile pass leaves per-tile partial sums in `ws`, the finish pass reduces them (scale, center cost, dZ). */
 int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
-                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, emx_stream_t stream);
+                        const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes,
+                        void* split_ws /* may be NULL; Euclidean distances only */, emx_stream_t stream);
+/* Split rows for emx_sketchmap_tiles: x - x_0 (row 0 of the batch) as three bf16 planes whose sum is the float32 value
+ * exactly, plus the squared row norms.  With them the tile pass forms its Gram products on the bf16 matrix cores (six
+ * v_mfma_f32_32x32x16_bf16 per 16 features, every partial product exact in the f32 accumulator: the accuracy class of the
+ * f32 instruction at 0.37x its cycles, and -- unlike the f32 matrix instruction -- without holding the VALU that the
+ * sigmoid epilogues of the other waves need).  emx_gather_rows and emx_next_batch produce them beside the gather;
+ * emx_sketchmap_split makes them from a dense [B, D] block.  split_ws: emx_sketchmap_split_bytes(B, D) bytes, 16-byte aligned. */
+size_t emx_sketchmap_split_bytes(int B, int D);
+int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, emx_stream_t stream);
 int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6], float scale, float center_scale,
                          int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ,
                          void* ws, size_t ws_bytes, emx_stream_t stream);
@@ -119,7 +128,8 @@ int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, 
  *   xin [B, 2D] = [sin(x*2pi/p) | cos(x*2pi/p)] (may be NULL; periodicity ignored then).
  * ------------------------------------------------------------------------------------------------ */
 int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B,
-                    float periodicity, float* xb, float* xin, emx_stream_t stream);
+                    float periodicity, float* xb, float* xin, void* split_ws /* may be NULL: emx_sketchmap_split of the gathered rows */,
+                    emx_stream_t stream);
 /* PeriodicInput on an already dense [B, D] block (encode()) */
 int emx_periodic_in(const float* x, int B, int D, int ldx, float periodicity, float* out, int ldo, emx_stream_t stream);
 /* PeriodicOutput: out[b, k] = atan2(y[b, off_sin+k], y[b, off_cos+k]) * p/2pi  (models.py:3353-3359, layers.py:1118-1125) */
@@ -181,6 +191,7 @@ typedef struct {
   float periodicity;      /* used when xin != NULL */
   float* xb;              /* may be NULL: [B, D] raw rows */
   float* xin;             /* may be NULL: [B, 2 D] = [sin | cos] */
+  void* split_ws;         /* may be NULL: emx_sketchmap_split_bytes(B, D) bytes, the split rows of emx_sketchmap_split */
 } emx_next_batch;
 
 /* ------------------------------------------------------------------------------------------------ *

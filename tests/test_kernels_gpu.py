@@ -390,3 +390,72 @@ def test_finish_step_sums_and_bookkeeping(L):
         # sums only (no bookkeeping): counters untouched
         L.finish_step(jobs, terms, n_terms)
         assert (int(hstep), int(cursor), int(counter)) == (6, 3, 10)
+
+
+def split_planes(ws, B, Dd):
+    """(h + l) / s per element, norms and 1/s of an emx_sketchmap_split workspace (include/emx.h)."""
+    ld = (Dd + 31) // 32 * 32
+    raw = ws.cpu().numpy()
+    planes = raw[: 2 * B * ld * 2].view(np.float16).reshape(2, ld // 32, B, 32).transpose(0, 2, 1, 3).reshape(2, B, ld)   # chunk-major
+    tail = raw[2 * B * ld * 2: 2 * B * ld * 2 + 8 * B].view(np.float32)
+    return planes.astype(np.float64), tail[:B], tail[B:], ld
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Dd", [(64, 128), (257, 33), (100, 7), (5, 1)])
+def test_split_rows_reproduce_the_rows(L, B, Dd):
+    """emx_sketchmap_split and the split made beside emx_gather_rows: the two f16 planes, scaled back, reproduce
+    float32(x - x_0) to float32 accuracy whatever the magnitude of the data (per-row power-of-two scale, no f16
+    overflow), the padding columns are zero, and the norms are the squared lengths of those rows."""
+    rng = np.random.default_rng(B + Dd)
+    x = (rng.normal(0, 3.0, (B, Dd)) * np.exp(rng.normal(0, 4.0, (B, 1)))).astype(np.float32)   # row scales over ~7 decades
+    ws = torch.zeros(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
+    L.sketchmap_split(dev(x), ws)
+
+    def check(ws, rows):
+        planes, norms, rscale, ld = split_planes(ws, B, Dd)
+        shifted = (rows - rows[0:1]).astype(np.float32).astype(np.float64)
+        assert np.all(np.isfinite(planes)) and np.all(np.abs(planes[0]) <= 2.0 ** 14 + 1)
+        assert np.all(np.log2(rscale) == np.round(np.log2(rscale)))          # powers of two
+        rec = planes.sum(0)[:, :Dd] * rscale[:, None].astype(np.float64)
+        rowmax = np.abs(shifted).max(1, keepdims=True)
+        assert np.all(np.abs(rec - shifted) <= 2.0 ** -23 * np.abs(shifted) + 2.0 ** -38 * rowmax)
+        assert np.all(planes[:, :, Dd:] == 0)
+        np.testing.assert_allclose(norms, (shifted ** 2).sum(1), rtol=2e-6)
+
+    check(ws, x)
+    idx = rng.permutation(B).astype(np.int64)
+    ws2 = torch.zeros_like(ws)
+    xb = torch.zeros(B, Dd, device="cuda")
+    L.gather_rows(dev(x), dev(idx, torch.int64), INF, xb, None, split_ws=ws2)
+    check(ws2, x[idx])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Dd,Ld,sig,rb,re", [
+    (256, 51, 2, DEFAULT_SIG, 0, 256), (257, 33, 2, (6.0, 12, 6, 1, 2, 6), 0, 257), (1000, 128, 2, (16.0, 12, 6, 1, 2, 6), 0, 1000),
+    (300, 7, 3, (2.0, 3, 6, 1, 2, 6), 0, 300), (130, 4, 4, (1.5, 12, 6, 1, 2, 6), 0, 130), (1030, 16, 2, (8.0, 12, 6, 1, 2, 6), 515, 1030),
+    (4096, 128, 2, (16.0, 12, 6, 1, 2, 6), 0, 4096)])
+def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
+    """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct
+    formulas -- same tolerances as the float32 path -- on data far from the origin, where the row-0 shift and the
+    accuracy of the split matter."""
+    rng = np.random.default_rng(B + Dd)
+    spread = sig[0] / math.sqrt(2 * Dd)
+    x, z = make_xz(rng, B, Dd, Ld, INF, spread)
+    x += 40.0 * spread          # far from the origin
+    x[2] = x[3]
+    z[5] = z[7]
+    X, Z = dev(x), dev(z)
+    split = torch.zeros(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
+    L.sketchmap_split(X, split)
+    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    dist, cen = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    dZ = torch.full((B, Ld), float("nan"), device="cuda")
+    L.sketchmap_tiles(X, Z, INF, sig, rb, re, ws, split)
+    L.sketchmap_finish(B, Dd, Z, sig, 500.0, 1e-4, rb, re, dist, cen, dZ, ws)
+    loss_o, g_o = D.sketchmap_fwd_bwd(x, z, INF, sig, 500.0, rb, re)
+    g_o = g_o[rb:re] + 2e-4 * z[rb:re].astype(np.float64) / z.size
+    g = dZ.cpu().numpy().astype(np.float64)[rb:re]
+    assert float(dist) == pytest.approx(loss_o, rel=1e-5, abs=1e-9)
+    np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
