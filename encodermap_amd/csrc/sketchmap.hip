@@ -554,12 +554,12 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint
 // the prefetched pieces are loop-carried registers, the compiler loads into temporaries and copies them into place at the
 // loop's end, and that copy waits for the data one instruction after it was requested.
 template <int LT, bool FASTSIG, int NCH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void sk_tile_f16_kernel(const SkArgs a) {
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void sk_tile_f16_kernel(const SkArgs a) {
   // (the compiler sizes its register budget for the occupancy a 64-KB LDS would allow; gfx950 has 160 KB, so the target
-  //  is stated: >= 5 tiles resident per CU)
+  //  is stated: 8 tiles resident per CU: <= 64 VGPRs, <= 20 KB LDS)
   constexpr int T = 64;
   constexpr int LMAX = LT ? LT : 4;
-  constexpr int RP = 36;                                // 32 pre-reduced column-lane partials per (row, l) + pad
+  constexpr int RP = 20;                                // 16 pre-reduced column-lane partials per (row, l) + pad
   constexpr int STAGE = 1024 * 4;                       // 2 sides x 2 planes x 64 rows x 32 k f16, as 16-byte pieces
   constexpr int PART = T * LMAX * RP;                   // row partials (reuse the staging area)
   constexpr int MAIN = STAGE > PART ? STAGE : PART;
@@ -674,31 +674,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
   float lsum = 0.f;
   // interior tiles (the vast majority) need no validity masks and no diagonal fix-up
   const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+  // Row r of this lane is wm*32 + 4h + ro(r), ro(r) = (r & 3) + 8 (r >> 2): one base address per array, the pair's row
+  // as an immediate offset.
+  const int ib = wm * 32 + 4 * h;
+  const float2* nr_b = nr_s + ib;
+  const float* zi_b = zi_s + ib * LMAX;
+  float* rp_b = rpart + ib * LMAX * RP + (jl >> 2);
   auto pair = [&](int r, bool masked) {
-    const int il = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    const int ro = (r & 3) + 8 * (r >> 2);
     float dz[LMAX];
     float dl2 = 0.f;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-      dz[l] = zi_s[il * LMAX + l] - zj[l];
+      dz[l] = zi_b[ro * LMAX + l] - zj[l];
       dl2 = fmaf(dz[l], dz[l], dl2);
     }
-    const float2 nri = nr_s[il];
+    const float2 nri = nr_b[ro];
     float d2 = fmaxf(fmaf(acc[r] * nri.y, cj, nri.x + nj), 0.f);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
-    if (masked) d2 = (i0 + il == jg) ? 0.f : d2;
+    if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
     const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
     float El, G;
     sig_E_low<FASTSIG>(dl2, a.sl, El, G);
     float f = El - Eh;
-    if (masked) f = (i0 + il < a.row_end && jok) ? f : 0.f;
+    if (masked) f = (i0 + ib + ro < a.row_end && jok) ? f : 0.f;
     lsum = fmaf(f, f, lsum);
     const float g = f * G;
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
       float v = g * dz[l];
       gj[l] -= v;
-      v += __shfl_xor(v, 1, 64);                       // neighbouring columns pre-reduced in registers
-      if ((lr & 1) == 0) rpart[(il * LMAX + l) * RP + (jl >> 1)] = v;
+      // four neighbouring columns pre-reduced in registers: DPP quad permutations (lane ^ 1, lane ^ 2), not LDS
+      // bpermutes; the four lanes of a quad then hold the same sum and all store it to the same word -- no exec mask, no branch
+      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+      rp_b[(ro * LMAX + l) * RP] = v;
     }
   };
   if (edge) {
@@ -724,13 +733,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     int rl = e / LMAX, l = e - rl * LMAX;
     if (l < L) {
       const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
-      float s = 0.f;
-#pragma unroll
-      for (int u = 0; u < 8; u += 4) {
-        float4 s0 = p[u], s1 = p[u + 1], s2 = p[u + 2], s3 = p[u + 3];
-        s += (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
-             (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-      }
+      const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+      const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                      (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
       a.P[((long)tj * a.nrows_pad + (i0 - a.row0) + rl) * L + l] = s;
     }
   }
