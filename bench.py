@@ -10,10 +10,13 @@ distance + auto + center + L2 cost, backward, clip + Adam) on synthetic Gaussian
 before the timed region starts.  One JSON line is printed by rank 0:
 
   value        whole-job samples/s = N_gpus * 4096 * K / (max over ranks of the time for K steps)
-  roofline     the dominant kernel (sk_tile_kernel, the O(B^2 D) all-pairs pass): algorithmic FLOPs per launch
+  roofline     the dominant kernel (sk_tile_f16_kernel, the O(B^2 D) all-pairs pass): algorithmic FLOPs per launch
                (2 per pair-element for the Gram tiles) / its average duration, measured here with HIP events
-               around K back-to-back launches on live data, against the 157.3 TFLOP/s fp32 peak (vector == matrix
-               on gfx950).  ``traffic`` = HBM bytes per launch from the rocprofv3 PMC passes kept under profiles/.
+               around K back-to-back launches on live data, against the 157.3 TFLOP/s fp32 matrix peak -- the precision the
+               path delivers (the Gram products run as three f16 matrix instructions per float32 product on split rows,
+               csrc/split.h; priced against the f16 peak the executed 6 W FLOPs would be a few per cent: the kernel is bound
+               by the VALU work of its sigmoid epilogue).  ``traffic`` = HBM bytes per launch from the rocprofv3 PMC
+               passes kept under profiles/.
   cpu_baseline the reference-formulation CPU path (oracle/reference_ops.py in float32: Gram-matrix distances with
                B x B temporaries, autograd, per-element clipped Adam) timed on this host for a few steps of the same
                workload.  N=1 only.  kind "port": TensorFlow itself cannot be installed here.
@@ -95,12 +98,12 @@ def kernel_roofline(eng, launches):
 
     Z = eng.h[eng.layout.n_enc - 1]
     for _ in range(5):
-        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws)
+        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws, eng.split_ws)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(launches):
-        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws)
+        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws, eng.split_ws)
     e1.record()
     torch.cuda.synchronize()
     t = e0.elapsed_time(e1) * 1e-3 / launches
@@ -115,10 +118,12 @@ def kernel_roofline(eng, launches):
         except Exception:
             traffic = None
     return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": flops / t / FP32_PEAK, "traffic": traffic, "kernel": "sk_tile_mfma_kernel", "kernel_us": t * 1e6,
-            "algorithmic_bytes": 4 * B * (D + 2 * 2) + 4,
-            "note": "exact-f32 MFMA (v_mfma_f32_32x32x2_f32) Gram tiles + VALU sigmoid epilogue; 2 FLOP per pair-element over the "
-                    "upper triangle; algorithmic HBM bytes per launch are ~2 MB so the HBM roof does not bind"}
+            "frac": flops / t / FP32_PEAK, "traffic": traffic, "kernel": "sk_tile_f16_kernel", "kernel_us": t * 1e6,
+            "algorithmic_bytes": 4 * B * (D + 2 * 2 + 2) + 4,
+            "note": "Gram tiles as 3 v_mfma_f32_32x32x16_f16 per float32 product on rows split into two f16 planes (float32-accurate), "
+                    "VALU sigmoid epilogue; 2 FLOP per pair-element over the upper triangle, priced against the fp32 matrix peak (the "
+                    "delivered precision); algorithmic HBM bytes per launch are ~2 MB so the HBM roof does not bind; the kernel is "
+                    "VALU-issue bound (epilogue ~40 instructions per pair)"}
 
 
 def main():

@@ -17,10 +17,14 @@ else:
     sig = (per * (D ** 0.5) * 0.2, 12, 6, 1, 2, 6)
 Z = torch.randn(B, 2, generator=g, device="cuda")
 ws = torch.empty(_lib.sketchmap_ws_bytes(B, 2) // 4, device="cuda")
+split = None
+if per == float("inf") and os.environ.get("EMX_TIME_SK_F32", "0") != "1":   # the engine's path: Gram products on the f16 cores
+    split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")
+    _lib.sketchmap_split(X, split)
 reps = 30
-for _ in range(3): _lib.sketchmap_tiles(X, Z, per, sig, 0, B, ws)
+for _ in range(3): _lib.sketchmap_tiles(X, Z, per, sig, 0, B, ws, split)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
-for _ in range(reps): _lib.sketchmap_tiles(X, Z, per, sig, 0, B, ws)
+for _ in range(reps): _lib.sketchmap_tiles(X, Z, per, sig, 0, B, ws, split)
 e1.record(); torch.cuda.synchronize()
 print("B", B, "D", D, "per", per, "tile kernel us", e0.elapsed_time(e1) / reps * 1e3)
