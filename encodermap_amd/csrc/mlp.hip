@@ -485,27 +485,43 @@ struct WgradDev {
   const float* xin;
   int ld_xin;
   long w_off[MAXL], b_off[MAXL];
-  int tile_begin[MAXL + 1];  // prefix sum of 128x128 output blocks per layer (relative to l0)
+  int tile_begin[MAXL + 1];  // prefix sum of 64x64 output blocks per layer (relative to l0)
   float* partial;            // [n_slices][n_params]
   long n_params;
   int row0, row_end, rows_per_slice;
 };
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef EMX_CHAIN_TIMING   // per-workgroup timeline of the weight-gradient kernel (tools/abl_wgrad.py)
+__device__ long long emx_dbg_wg[3 * 1024 + 64];
+#define WSTAMP(k) do { if (threadIdx.x == 0) { const int bid_ = blockIdx.y * gridDim.x + blockIdx.x; \
+    if (bid_ < 1024 && ((k) == 0 || (k) == 9)) emx_dbg_wg[64 + 3 * bid_ + ((k) ? 1 : 0)] = wall_clock64(); \
+    if (bid_ == 0) emx_dbg_wg[k] = clock64(); } } while (0)
+#else
+#define WSTAMP(k)
+#endif
+
 __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
-  // One workgroup = one 128x128 block of one layer's dW over one row slice; each wave a 64x64 quadrant = 4x4 MFMA
-  // tiles.  The MFMA's m/n indices are free labels: lane slot m of tile u stands for feature 4m + u (n, v likewise), so
-  // ONE 16-byte load per operand and row feeds all four tiles of that operand (2 loads per 16 MFMAs), and the four
-  // tiles (u, v = 0..3) of a slot pair form a float4 of adjacent output columns for the store.
+  // One workgroup = one 64x64 block of one layer's dW over one row slice (128 rows); each wave a 32x32 quadrant = 2x2
+  // MFMA tiles.  The MFMA's m/n indices are free labels: lane slot m of tile u stands for feature 2m + u (n, v likewise),
+  // so ONE 8-byte load per operand and 4-row step feeds both tiles of that operand, and the two tiles v = 0, 1 of a slot
+  // pair form a float2 of adjacent output columns for the store.
+  // (Decomposition: parallelism = blocks x slices, partial traffic = slices x parameters.  The kernel is bound by the
+  //  latency of its operand loads -- the activations and deltas were written by the previous kernels on other XCDs --
+  //  so it wants several workgroups per CU: 64x64 blocks x 32 slices = 640 workgroups, 128 MFMAs per wave; measured
+  //  15.8 us against 20.1 us for 64x64 x 16 slices (320 workgroups) and 17.5 us for 128x128 x 32 slices (192 workgroups).)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
+  WSTAMP(0);
   int l = a.l0;
   while (l + 1 < a.l1 && (int)blockIdx.x >= a.tile_begin[l + 1 - a.l0]) ++l;
   const int tb = blockIdx.x - a.tile_begin[l - a.l0];
   const int Kin = a.d.width[l], N = a.d.width[l + 1];
-  const int nbn = (N + 127) >> 7;
+  const int nbn = (N + 63) >> 6;
   const int bi = tb / nbn, bj = tb - bi * nbn;
-  const int i0 = bi * 128 + (wave >> 1) * 64;   // input-feature offset of this wave's quadrant
-  const int j0 = bj * 128 + (wave & 1) * 64;    // output-feature offset
+  const int i0 = bi * 64 + (wave >> 1) * 32;   // input-feature offset of this wave's quadrant
+  const int j0 = bj * 64 + (wave & 1) * 32;    // output-feature offset
   const float* __restrict__ X = (l == a.l0) ? a.xin : a.d.h[l - 1];
   const int ldx = (l == a.l0) ? a.ld_xin : Kin;
   const float* __restrict__ Dl = a.d.delta[l];
@@ -513,88 +529,89 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
   const int re = min(rs + a.rows_per_slice, a.row_end);
   float* __restrict__ out = a.partial + (long)blockIdx.y * a.n_params;
 
-  f32x4 acc[4][4];
+  f32x4 acc[2][2];
 #pragma unroll
-  for (int u = 0; u < 4; ++u)
+  for (int u = 0; u < 2; ++u)
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    for (int v = 0; v < 2; ++v) acc[u][v] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x2 bsum = {0.f, 0.f};
   const bool do_bias = (bi == 0) && ((wave >> 1) == 0);
   const bool quad_active = i0 < Kin && j0 < N;   // wave-uniform
 
-  // 16-byte operand loads need 4 | width and an aligned row stride; otherwise four clamped scalar loads
-  const bool vx = ((ldx & 3) == 0) && ((Kin & 3) == 0), vd = (N & 3) == 0;
-  const int cx = i0 + 4 * m, cd = j0 + 4 * m;
-  auto ldrow = [&](const float* __restrict__ base, int ld, int width, int col, bool vec, int row) -> f32x4 {
-    const float* p = base + (long)row * ld;
-    f32x4 v;
-    if (vec) {
-      v = *reinterpret_cast<const f32x4*>(p + min(col, width - 4));   // clamped: out-of-range slots are discarded at the store
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) v[i] = p[min(col + i, width - 1)];
-    }
-    return v;
+  // 8-byte operand loads need 2 | width and an even row stride; otherwise two clamped scalar loads.  The decision is made
+  // ONCE around the whole row loop: decided per load, the two variants write the same registers from different branches
+  // and the compiler fences every load with a wait for the previous ones.
+  const bool vx = ((ldx & 1) == 0) && ((Kin & 1) == 0), vd = (N & 1) == 0;
+  const int cx = i0 + 2 * m, cd = j0 + 2 * m;
+  auto ldvec = [&](const float* __restrict__ base, int ld, int width, int col, int row) -> f32x2 {
+    return *reinterpret_cast<const f32x2*>(base + (long)row * ld + min(col, width - 2));   // clamped: out-of-range slots are discarded at the store
   };
-  constexpr int US = 4;   // 4-row steps per batch; the next batch's loads are issued before this batch's 64 MFMAs
+  auto ldsca = [&](const float* __restrict__ base, int ld, int width, int col, int row) -> f32x2 {
+    const float* p = base + (long)row * ld;
+    return f32x2{p[min(col, width - 1)], p[min(col + 1, width - 1)]};
+  };
+  constexpr int US = 8;   // 4-row steps per batch: 32 MFMAs behind 16 operand loads
   if (quad_active) {
-    f32x4 xa[US], db[US], xn[US], dn[US];
-    auto load_batch = [&](int r, f32x4 (&xo)[US], f32x4 (&dout)[US]) {
-#pragma unroll
-      for (int s2 = 0; s2 < US; ++s2) {
-        const int row = min(r + 4 * s2 + g, re - 1);
-        xo[s2] = ldrow(X, ldx, Kin, cx, vx, row);
-        dout[s2] = ldrow(Dl, N, N, cd, vd, row);
-      }
-    };
-    load_batch(rs, xn, dn);
-    for (int r = rs; r < re; r += 4 * US) {
-#pragma unroll
-      for (int s2 = 0; s2 < US; ++s2) {
-        xa[s2] = xn[s2];
-        db[s2] = dn[s2];
-      }
-      if (r + 4 * US < re) load_batch(r + 4 * US, xn, dn);
-      if (r + 4 * US > re) {   // ragged tail (wave-uniform): rows beyond the slice contribute nothing
-#pragma unroll
-        for (int s2 = 0; s2 < US; ++s2) {
-          const float ok = (r + 4 * s2 + g < re) ? 1.f : 0.f;
-          db[s2] *= ok;
-        }
-      }
-#pragma unroll
-      for (int s2 = 0; s2 < US; ++s2) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v) acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[s2][u], db[s2][v], acc[u][v], 0, 0, 0);
-        bsum += db[s2];
-      }
+    // Two register sets, two batches per loop iteration: set A is the only loop-carried one and is reloaded (for the
+    // batch after next) right behind the MFMAs that consumed it, set B is loaded and consumed inside the iteration.  All
+    // loads are unconditional with clamped rows; rows beyond the slice are zeroed in the delta operand.
+    f32x2 xA[US], dA[US], xB[US], dB[US];
+#define WG_LOAD(LD, xo, dout, r)                                                              \
+  _Pragma("unroll") for (int s2 = 0; s2 < US; ++s2) {                                        \
+    const int row_ = (r) + 4 * s2 + g;                                                        \
+    const int rowc_ = min(row_, re - 1);                                                      \
+    xo[s2] = LD(X, ldx, Kin, cx, rowc_);                                                      \
+    dout[s2] = LD(Dl, N, N, cd, rowc_) * (row_ < re ? 1.f : 0.f);                             \
+  }
+#define WG_MMA(xi, di)                                                                        \
+  _Pragma("unroll") for (int s2 = 0; s2 < US; ++s2) {                                        \
+    _Pragma("unroll") for (int u = 0; u < 2; ++u)                                            \
+      _Pragma("unroll") for (int v = 0; v < 2; ++v)                                          \
+        acc[u][v] = __builtin_amdgcn_mfma_f32_16x16x4f32(xi[s2][u], di[s2][v], acc[u][v], 0, 0, 0); \
+    bsum += di[s2];                                                                           \
+  }
+#define WG_ROWS(LD)                                   \
+  WG_LOAD(LD, xA, dA, rs)                             \
+  WSTAMP(1);                                          \
+  for (int r = rs; r < re; r += 8 * US) {             \
+    WG_LOAD(LD, xB, dB, r + 4 * US)                   \
+    WG_MMA(xA, dA)                                    \
+    WG_LOAD(LD, xA, dA, r + 8 * US)                   \
+    WG_MMA(xB, dB)                                    \
+    if (r == rs) WSTAMP(2);                           \
+  }                                                   \
+  WSTAMP(3);
+    if (vx && vd) {
+      WG_ROWS(ldvec)
+    } else {
+      WG_ROWS(ldsca)
     }
-    // store: tile (u, v), D[row slot 4g + reg][col slot m] -> dW[i0 + 4(4g + reg) + u][j0 + 4m + v]
-    const bool vst = (N & 3) == 0;
+#undef WG_ROWS
+#undef WG_LOAD
+#undef WG_MMA
+    // store: tile (u, v), D[row slot 4g + reg][col slot m] -> dW[i0 + 2(4g + reg) + u][j0 + 2m + v]
+    const bool vst = (N & 1) == 0 && ((a.w_off[l] & 1) == 0);
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
-        const int ii = i0 + 4 * (4 * g + reg) + u, jj = j0 + 4 * m;
+        const int ii = i0 + 2 * (4 * g + reg) + u, jj = j0 + 2 * m;
         if (ii < Kin && jj < N) {
           float* q = out + a.w_off[l] + (long)ii * N + jj;
-          if (vst && ((a.w_off[l] & 3) == 0)) {
-            *reinterpret_cast<f32x4*>(q) = f32x4{acc[u][0][reg], acc[u][1][reg], acc[u][2][reg], acc[u][3][reg]};
+          if (vst) {
+            *reinterpret_cast<f32x2*>(q) = f32x2{acc[u][0][reg], acc[u][1][reg]};
           } else {
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-              if (jj + v < N) q[v] = acc[u][v][reg];
+            q[0] = acc[u][0][reg];
+            if (jj + 1 < N) q[1] = acc[u][1][reg];
           }
         }
       }
   }
   if (do_bias && j0 < N) {
-    // column sums: lane (m, g) holds the sums of columns j0 + 4m .. + 3 over the rows of its lane group
-    f32x4 sfull = bsum;
+    // column sums: lane (m, g) holds the sums of columns j0 + 2m, + 1 over the rows of its lane group
+    f32x2 sfull = bsum;
 #pragma unroll
-    for (int v = 0; v < 4; ++v) {
+    for (int v = 0; v < 2; ++v) {
       float t = sfull[v];
       t += __shfl_xor(t, 16, 64);
       t += __shfl_xor(t, 32, 64);
@@ -602,10 +619,11 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
     }
     if (g == 0) {
 #pragma unroll
-      for (int v = 0; v < 4; ++v)
+      for (int v = 0; v < 2; ++v)
         if (cd + v < N) out[a.b_off[l] + cd + v] = sfull[v];
     }
   }
+  WSTAMP(9);
 }
 
 // g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
@@ -843,7 +861,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
     a.w_off[l] = desc->w_off[l];
     a.b_off[l] = desc->b_off[l];
     a.tile_begin[l - layer_begin] = tiles;
-    tiles += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
+    tiles += ((desc->width[l] + 63) / 64) * ((desc->width[l + 1] + 63) / 64);
     const long wl = desc->w_off[l], wh = desc->b_off[l] + desc->width[l + 1];
     lo = (lo < 0) ? wl : std::min(lo, wl);
     hi = std::max(hi, wh);
@@ -869,4 +887,8 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 
 #ifdef EMX_CHAIN_TIMING
 extern "C" int emx_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg), sizeof(emx_dbg)); }
+#endif
+
+#ifdef EMX_CHAIN_TIMING
+extern "C" int emx_debug_read_wg(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_wg), sizeof(emx_dbg_wg)); }
 #endif
