@@ -33,7 +33,7 @@ for blk in (0, 1):
     nslot = 3 + 5 * n
     for w in (0, 3, 7):
         c = clk[w, :nslot] - clk[w, 0]; t = c * 0
-        print(f"block {blk*100} wave {w}: total {c[-1]} clk, {t[-1]} ns -> {c[-1]/max(t[-1],1):.2f} GHz")
+        print(f"block {blk*100} wave {w}: last unit's barrier passed at {c[-1]} clk after kernel entry")
         cc = clk[w] - clk[w, 0]
         print("  clk  stage loads issued:", c[1], " staged + barrier:", c[2], " loop end:", cc[60], " cost phase end:", cc[61])
         for l in range(n):
