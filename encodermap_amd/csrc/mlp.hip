@@ -83,8 +83,11 @@ __device__ __forceinline__ float tanh_f32(float x) {
 //     unit late (from registers, at the head of the next request burst), and no other vector-memory instruction
 //     exists in the loop: every wait is for the OLDEST package only.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef EMX_CHAIN_NB
+#define EMX_CHAIN_NB 3
+#endif
 constexpr int MAXU = 40;   // units per launch
-constexpr int NB = 4;      // operand ring depth
+constexpr int NB = EMX_CHAIN_NB;      // operand ring depth: packages of NB - 1 units ahead in flight (measured at C2: 3 is 3 % faster than 4 or 2)
 
 struct UnitLoad {       // what a request burst needs to fetch a unit's package (32 B, one s_load_dwordx8)
   int op_off;           // float offset of the operand block (first tile of the pass, first K-step of the chunk)
@@ -387,10 +390,14 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     if (ui + 1 >= nu) break;
     unit(IC<1>{}, ui + 1);
     if (ui + 2 >= nu) break;
-    unit(IC<2>{}, ui + 2);
-    if (ui + 3 >= nu) break;
-    unit(IC<3>{}, ui + 3);
-    if (ui + 4 >= nu) break;
+    if constexpr (NB >= 3) {
+      unit(IC<2>{}, ui + 2);
+      if (ui + 3 >= nu) break;
+    }
+    if constexpr (NB >= 4) {
+      unit(IC<3>{}, ui + 3);
+      if (ui + 4 >= nu) break;
+    }
   }
   {
     __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend_base), 0, pend_bytes, 0x00020000);
