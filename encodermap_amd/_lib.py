@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libemx.so")
+LIB_PATH = os.environ.get("EMX_LIB_PATH") or os.path.join(_HERE, "libemx.so")   # EMX_LIB_PATH: A/B runs of two builds on one box
 
 EMX_REDUCE_WS = 1024
 MEAN_ABS, MEAN_SQUARE, MEAN_NORM = 0, 1, 2
@@ -68,6 +68,7 @@ SIGNATURES = {
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "emx_mlp_row_blocks": (_i, [_i]),
     "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
@@ -354,6 +355,13 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" =
     """Layers [l0, l1) on rows [row_begin, row_end); ``cost`` evaluates the auto cost on the last layer's rows in the same launch."""
     _check(load().emx_mlp_forward_cost(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
                                        int(row_end), plan.h, C.byref(cost) if cost is not None else None, _stream()), "emx_mlp_forward")
+
+
+def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None):
+    """Forward [l0, l1), auto cost, backward-data through [bwd_begin, l1) in one launch (delta[l1 - 1] = d cost / d output)."""
+    _check(load().emx_mlp_forward_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
+                                           int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, _ptr(dbelow),
+                                           _stream()), "emx_mlp_forward_backward")
 
 
 def mlp_row_blocks(n_rows):

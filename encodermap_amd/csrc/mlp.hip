@@ -92,11 +92,11 @@ constexpr int NB = EMX_CHAIN_NB;      // operand ring depth: packages of NB - 1 
 struct UnitLoad {       // what a request burst needs to fetch a unit's package (32 B, one s_load_dwordx8)
   int op_off;           // float offset of the operand block (first tile of the pass, first K-step of the chunk)
   int Q;                // K-steps per tile of this operand (tile pitch in 256-float blocks)
-  int kq;               // K-steps in this chunk, 1..8
-  int tiles;            // tiles of this pass that exist, 1..8 (waves beyond them re-read the last one)
+  int kq_tiles;         // K-steps in this chunk, 1..8 | tiles of this pass that exist, 1..8 (waves beyond them re-read the last one) << 8
   int col0;             // first output column of the pass
-  int n;                // row length of aux
-  const float* aux;     // forward: the layer's bias; backward: h rows for the activation derivative (any readable [*, n] otherwise)
+  int n;                // number of columns of aux (clamp bound)
+  int rstride;          // row stride of aux: 0 = one broadcast row (a bias), n = one value per batch row (h rows)
+  const float* aux;     // epilogue operand: the layer's bias (forward), h rows for the activation derivative (backward)
 };
 struct UnitExec {       // what the MFMA phase and the epilogue need (32 B)
   int kq_cols;          // kq | valid output columns of this pass << 8
@@ -105,9 +105,9 @@ struct UnitExec {       // what the MFMA phase and the epilogue need (32 B)
   int flags;            // U_* | S_* << 8
   float* out;           // [*, n] result rows (h_l forward; delta_{l-1} or dbelow backward)
   int n;
-  int pad;
+  int imgs;             // LDS images: source | destination << 8 | (image of h for the activation derivative + 1) << 16 (0: from aux)
 };
-enum { U_FIRST = 1, U_LAST = 2, U_LAYER_END = 4 };
+enum { U_FIRST = 1, U_LAST = 2, U_LAYER_END = 4, U_BWD = 8 };
 enum { S_ACT = 1, S_JOIN = 2 };
 
 struct ChainArgs {
@@ -130,11 +130,16 @@ struct ChainArgs {
   // forward only, optional auto cost on the rows of the last layer (replaces emx_periodic_cost_fwd_bwd behind it):
   // cost.dY receives d cost / d output, cost.ws[workgroup] the workgroup's share of the cost
   CostArgs cost;
+  int n_img;            // LDS images of R x pitch floats (2 ping-pong images; fused mode: one per forward layer + 2)
+  int cost_img;         // image that holds the rows the cost is evaluated on
+  // fused mode (forward, cost, backward through the upper layers in one launch): the cost runs behind unit cost_at and
+  // leaves d cost / d output in image top_img, the source of the first backward unit
+  int cost_at, top_img;
 };
 
 #ifdef EMX_CHAIN_TIMING   // in-kernel timeline (tools/abl_timing.py); stamps go to LDS so that they do not touch vmcnt
 __device__ long long emx_dbg[8192];
-#define TSTAMP(slot) do { if (!BWD && lane == 0) dbg_lds[wave * 64 + (slot)] = clock64(); } while (0)
+#define TSTAMP(slot) do { if (MODE != CHAIN_BWD && lane == 0 && (slot) < 64) dbg_lds[wave * 64 + (slot)] = clock64(); } while (0)
 #else
 #define TSTAMP(slot)
 #endif
@@ -144,9 +149,13 @@ struct IC {
   static constexpr int value = V;
 };
 
-template <bool BWD>
+enum { CHAIN_FWD = 0, CHAIN_BWD = 1, CHAIN_FUSED = 2 };
+
+template <int MODE>
 __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
+  constexpr bool BWD = MODE == CHAIN_BWD;
   extern __shared__ __align__(16) float lds[];
+  __shared__ float cred[NTC / 64];
 #ifdef EMX_CHAIN_TIMING
   __shared__ long long dbg_lds[512];
 #endif
@@ -158,9 +167,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int pitch = a.pitch;
   const int img = R * pitch;
   const int nu = a.nu;
-  float* lat = lds + 2 * img;   // [R][join_n] rows joined into one layer's dh (backward)
-  float* tgt = lds + 2 * img;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
-  constexpr int NE = BWD ? 4 : 1;
+  float* lat = lds + a.n_img * img;   // [R][join_n] rows joined into one layer's dh (backward)
+  float* tgt = lds + a.n_img * img;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
+  constexpr int NE = MODE == CHAIN_FWD ? 1 : 4;
   TSTAMP(0);
 
   float b[NB][8][4];
@@ -168,20 +177,16 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
 
   // one unit's package: its epilogue operands + 8 operand pieces.  Addresses are clamped, never masked or branched
   // around, so that every package is the same instruction sequence.
-  auto piece_ptr = [&](const UnitLoad& L) { return a.mbase + L.op_off + (long)(min(wave, L.tiles - 1) * L.Q) * 256 + lane * 4; };
+  auto piece_ptr = [&](const UnitLoad& L) { return a.mbase + L.op_off + (long)(min(wave, (L.kq_tiles >> 8) - 1) * L.Q) * 256 + lane * 4; };
   auto request_piece = [&](const UnitLoad& L, const float* __restrict__ p, int q, float (&bq)[4]) {
-    const f32x4 v = *reinterpret_cast<const f32x4*>(p + min(q, L.kq - 1) * 256);
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + min(q, (L.kq_tiles & 0xff) - 1) * 256);
 #pragma unroll
     for (int i = 0; i < 4; ++i) bq[i] = v[i];
   };
   auto request_epi = [&](const UnitLoad& L, float (&ee)[NE]) {
     const int ccol = min(L.col0 + n0 + m, L.n - 1);
-    if (!BWD) {
-      ee[0] = L.aux[ccol];
-    } else {
 #pragma unroll
-      for (int reg = 0; reg < NE; ++reg) ee[reg] = L.aux[(long)min(r0 + 4 * g + reg, a.row_end - 1) * L.n + ccol];
-    }
+    for (int reg = 0; reg < NE; ++reg) ee[reg] = L.aux[(long)min(r0 + 4 * g + reg, a.row_end - 1) * L.rstride + ccol];
   };
 
   if (BWD && a.join_n > 0) {
@@ -256,6 +261,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   float sv[4] = {0.f, 0.f, 0.f, 0.f};
   float tv[4] = {0.f, 0.f, 0.f, 0.f};
   const bool tgt_global = !BWD && a.cost.dY != nullptr;
+  if (MODE == CHAIN_FUSED) {   // the image that receives d cost / d output is the A operand of the first backward unit: zero padded
+    for (int el = tid; el < img; el += NTC) lds[a.top_img * img + el] = 0.f;
+  }
   auto target_load = [&](int c, float (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = a.cost.target[sgrow * a.cost.ldt + min(c + i, a.cost.n - 1)];
@@ -266,7 +274,6 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       if (c + i < a.cost.n) tgt[sr * a.cost.n + c + i] = v[i];
   };
 
-  int buf = 0;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // results of the previous epilogue, stored at the head of the next iteration through a buffer resource whose bounds
   // check drops the lanes and rows that do not exist (no exec-masked branch around a vector-memory instruction)
@@ -276,6 +283,56 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   unsigned pend_voff = 0x80000000u;
   UnitExec X = a.ux[0];
   UnitLoad Lq = a.ul[0];
+
+  // auto cost on the last forward layer's rows, which are complete in LDS image cost_img: 32 threads per row.
+  // to_lds: d cost / d output also goes to image top_img (the source of the fused backward units).
+  auto cost_phase = [&](const bool to_lds) {
+    const CostArgs& cst = a.cost;
+    const int row = tid >> 5, l32 = tid & 31;
+    const bool rok = r0 + row < a.row_end;
+    const long grow = (long)min(r0 + row, a.row_end - 1);
+    const float* yrow = lds + a.cost_img * img + row * pitch;
+    const float* trow = tgt + row * cst.n;
+    float* drow = rok ? cst.dY + grow * cst.ldy : nullptr;
+    float* lrow = (to_lds && rok) ? lds + a.top_img * img + row * pitch : nullptr;   // rows beyond the block stay zero
+    float lsum = 0.f;
+    if (cst.variant == EMX_MEAN_NORM) {
+      float ss = 0.f;
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        ss = fmaf(delta, delta, ss);
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's 32 lanes
+      const float nrm = sqrtf(ss);
+      const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
+      if (l32 == 0 && rok) lsum = nrm;
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        cost_store(cst, drow, nullptr, k, cst.gnorm * delta * inv * dd, sn, cs);
+        cost_store(cst, lrow, nullptr, k, cst.gnorm * delta * inv * dd, sn, cs);
+      }
+    } else {
+      for (int k = l32; k < cst.n; k += 32) {
+        float sn, cs, delta, dd;
+        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        float gq;
+        if (cst.variant == EMX_MEAN_ABS) {
+          if (rok) lsum += fabsf(delta);
+          gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+        } else {
+          if (rok) lsum = fmaf(delta, delta, lsum);
+          gq = 2.f * delta * dd;
+        }
+        cost_store(cst, drow, nullptr, k, cst.gnorm * gq, sn, cs);
+        cost_store(cst, lrow, nullptr, k, cst.gnorm * gq, sn, cs);
+      }
+    }
+    const float tsum = block_sum<NTC>(lsum, cred);
+    if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
+  };
 
   // Iteration ui requests the package of unit ui + NB - 1 into ring slot r and executes unit ui from slot r + 1; the
   // first NB - 1 iterations (ui < 0) only request.  Every iteration issues the SAME sequence of vector-memory
@@ -305,7 +362,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     request_epi(Lq, e[r]);
     // beyond the last unit the pieces degenerate to one shared line
     const float* __restrict__ pp = req ? piece_ptr(Lq) : a.mbase;
-    const float* src = lds + buf * img + X.src_off + m * pitch + 4 * g;
+    const float* src = lds + (X.imgs & 0xff) * img + X.src_off + m * pitch + 4 * g;
     if (run && (X.flags & U_FIRST)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (run) TSTAMP(3 + 5 * ui);
     f32x4 av = *reinterpret_cast<const f32x4*>(src);   // A pieces are read one group ahead (any in-image address is readable)
@@ -353,17 +410,22 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       const int sflags = X.flags >> 8;
       const int col = X.dst_off + n0 + m;
       const bool cok = n0 + m < cols;
-      float* dst = lds + (buf ^ 1) * img + col;
+      const bool ubwd = MODE == CHAIN_BWD || (MODE == CHAIN_FUSED && (X.flags & U_BWD));
+      const int himg = (X.imgs >> 16) & 0xff;   // 0: activations from the epilogue operands, else LDS image himg - 1
+      float* dst = lds + ((X.imgs >> 8) & 0xff) * img + col;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = 4 * g + reg;
         float v = acc[reg];
-        if (!BWD) {
+        if (!ubwd) {
           v += e[rx][0];
           if (sflags & S_ACT) v = tanh_f32(v);
         } else {
           if (sflags & S_JOIN) v += lat[row * X.n + min(col, X.n - 1)];
-          if (sflags & S_ACT) v *= fmaf(-e[rx][reg % NE], e[rx][reg % NE], 1.f);
+          if (sflags & S_ACT) {
+            const float hv = (MODE == CHAIN_FUSED && himg) ? lds[(himg - 1) * img + row * pitch + col] : e[rx][reg % NE];
+            v *= fmaf(-hv, hv, 1.f);
+          }
         }
         v = (cok && r0 + row < a.row_end) ? v : 0.f;
         dst[row * pitch] = v;
@@ -375,9 +437,10 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       pend_voff = cok ? (unsigned)((4 * g * X.n + col) * 4) : 0x80000000u;
     }
     TSTAMP(6 + 5 * ui);
-    if (X.flags & U_LAYER_END) {
+    if (X.flags & U_LAYER_END) __syncthreads();
+    if (MODE == CHAIN_FUSED && ui == a.cost_at) {   // the forward part is complete: cost, d cost / d output -> HBM and image top_img
+      cost_phase(true);
       __syncthreads();
-      buf ^= 1;
     }
     TSTAMP(7 + 5 * ui);
     X = Xn;
@@ -405,56 +468,11 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend[reg]), rs, pend_voff + reg * pend_n * 4, 0, 0);
   }
   TSTAMP(60);
-  if (!BWD && a.cost.dY != nullptr) {
-    // auto cost on the last layer's rows, which are complete in the current LDS image: 32 threads per row
-    __shared__ float cred[NTC / 64];
-    const CostArgs& cst = a.cost;
-    const int row = tid >> 5, l32 = tid & 31;
-    const bool rok = r0 + row < a.row_end;
-    const long grow = (long)min(r0 + row, a.row_end - 1);
-    const float* yrow = lds + buf * img + row * pitch;
-    const float* trow = tgt + row * cst.n;
-    float* drow = rok ? cst.dY + grow * cst.ldy : nullptr;
-    float lsum = 0.f;
-    if (cst.variant == EMX_MEAN_NORM) {
-      float ss = 0.f;
-      for (int k = l32; k < cst.n; k += 32) {
-        float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
-        ss = fmaf(delta, delta, ss);
-      }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's 32 lanes
-      const float nrm = sqrtf(ss);
-      const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
-      if (l32 == 0 && rok) lsum = nrm;
-      for (int k = l32; k < cst.n; k += 32) {
-        float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
-        cost_store(cst, drow, nullptr, k, cst.gnorm * delta * inv * dd, sn, cs);
-      }
-    } else {
-      for (int k = l32; k < cst.n; k += 32) {
-        float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
-        float gq;
-        if (cst.variant == EMX_MEAN_ABS) {
-          if (rok) lsum += fabsf(delta);
-          gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
-        } else {
-          if (rok) lsum = fmaf(delta, delta, lsum);
-          gq = 2.f * delta * dd;
-        }
-        cost_store(cst, drow, nullptr, k, cst.gnorm * gq, sn, cs);
-      }
-    }
-    const float tsum = block_sum<NTC>(lsum, cred);
-    if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
-  }
+  if (MODE == CHAIN_FWD && a.cost.dY != nullptr) cost_phase(false);
   TSTAMP(61);
 #ifdef EMX_CHAIN_TIMING
   __syncthreads();
-  if (!BWD && (blockIdx.x == 0 || blockIdx.x == 100)) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
+  if (MODE != CHAIN_BWD && (blockIdx.x == 0 || blockIdx.x == 100)) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
 #endif
 }
 
@@ -695,8 +713,11 @@ long mirror_begin(const emx_mlp_desc* desc, int l) {
   return o;
 }
 
-// Appends the units of one GEMM: `kred` reduction indices, `nout` output columns, operand block at float offset `op`.
-int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, float* out, int sflags, const char* who) {
+// Appends the units of one GEMM: `kred` reduction indices, `nout` output columns, operand block at float offset `op`;
+// `aux` with row stride `rstride` (0: a bias row) feeds the epilogue; LDS images src -> dst, himg + 1 = image of the
+// activations for the derivative (0: they come through aux).
+int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, int rstride, float* out, int sflags, int uflags, int src_img,
+              int dst_img, int himg1, const char* who) {
   const int Q = (kred + 15) / 16, T = (nout + 15) / 16;
   const int P = (nout + 127) / 128, Cn = (kred + 127) / 128;
   for (int p = 0; p < P; ++p)
@@ -705,11 +726,10 @@ int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, float
       const long off = op + ((long)(8 * p) * Q + 8 * c) * 256;
       if (off + 8L * Q * 256 > 0x7fffffffL) return emx::fail(EMX_EUNSUPPORTED, "%s: operand store too large", who);
       const int kq = std::min(8, Q - 8 * c);
-      UnitLoad& ul = a.ul[a.nu];
-      ul = UnitLoad{(int)off, Q, kq, std::min(8, T - 8 * p), 128 * p, nout, aux};
-      UnitExec& ux = a.ux[a.nu];
-      ux = UnitExec{kq | (std::min(128, nout - 128 * p) << 8), 128 * c, 128 * p,
-                    (c == 0 ? U_FIRST : 0) | (c == Cn - 1 ? U_LAST : 0) | (c == Cn - 1 && p == P - 1 ? U_LAYER_END : 0) | (sflags << 8), out, nout, 0};
+      a.ul[a.nu] = UnitLoad{(int)off, Q, kq | (std::min(8, T - 8 * p) << 8), 128 * p, nout, rstride, aux};
+      a.ux[a.nu] = UnitExec{kq | (std::min(128, nout - 128 * p) << 8), 128 * c, 128 * p,
+                            (c == 0 ? U_FIRST : 0) | (c == Cn - 1 ? U_LAST : 0) | (c == Cn - 1 && p == P - 1 ? U_LAYER_END : 0) | uflags | (sflags << 8), out,
+                            nout, src_img | (dst_img << 8) | (himg1 << 16)};
       ++a.nu;
     }
   return EMX_OK;
@@ -747,10 +767,13 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   ChainArgs a{};
   for (int l = layer_begin; l < layer_end; ++l) {
     EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
-    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], h[l], desc->act[l] ? S_ACT : 0,
-                   "emx_mlp_forward");
+    const int st = l - layer_begin;
+    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0,
+                   st & 1, (st + 1) & 1, 0, "emx_mlp_forward");
     if (rc) return rc;
   }
+  a.n_img = 2;
+  a.cost_img = (layer_end - layer_begin) & 1;
   if (cost) {
     const int wout = desc->width[layer_end];
     EMX_REQUIRE(cost->target && cost->dY && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0, "emx_mlp_forward: incomplete cost description");
@@ -772,10 +795,10 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   a.row0 = row_begin;
   a.row_end = row_end;
   const size_t lds = ((size_t)2 * R * a.pitch + (cost ? (size_t)R * cost->n : 0)) * sizeof(float);
-  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<false>), lds, "emx_mlp_forward");
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_FWD>), lds, "emx_mlp_forward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(chain_kernel<false>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(chain_kernel<CHAIN_FWD>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
   return emx::check_launch("mlp chain kernel (forward)");
 }
 
@@ -813,16 +836,19 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   for (int l = top; l >= lo; --l) {
     const int Kin = desc->width[l], N = desc->width[l + 1];
     const long op = mirror_begin(desc, l) + operand_block(Kin, N);
+    const int st = top - l;
     if (l > layer_begin)
-      rc = add_units(a, op, N, Kin, desc->act[l - 1] ? h[l - 1] : delta[l - 1], delta[l - 1], sflags(l - 1), "emx_mlp_backward");
+      rc = add_units(a, op, N, Kin, desc->act[l - 1] ? h[l - 1] : delta[l - 1], Kin, delta[l - 1], sflags(l - 1), U_BWD, st & 1, (st + 1) & 1, 0,
+                     "emx_mlp_backward");
     else
-      rc = add_units(a, op, N, Kin, dbelow, dbelow, 0, "emx_mlp_backward");
+      rc = add_units(a, op, N, Kin, dbelow, Kin, dbelow, 0, U_BWD, st & 1, (st + 1) & 1, 0, "emx_mlp_backward");
     if (rc) return rc;
   }
   if (a.nu == 0) {   // a one-layer range without dbelow: only delta_top is formed; the kernel still wants one readable record
-    a.ul[0] = UnitLoad{0, 1, 1, 1, 0, 1, mirror};
-    a.ux[0] = UnitExec{1 | (1 << 8), 0, 0, 0, delta[top], 1, 0};
+    a.ul[0] = UnitLoad{0, 1, 1 | (1 << 8), 0, 1, 0, mirror};
+    a.ux[0] = UnitExec{1 | (1 << 8), 0, 0, 0, delta[top], 1, 0 | (1 << 8)};
   }
+  a.n_img = 2;
   a.pitch = pitch_for(desc, layer_begin, layer_end);
   a.mbase = mirror;
   a.in = dtop;
@@ -831,11 +857,77 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   a.row0 = row_begin;
   a.row_end = row_end;
   const size_t lds = ((size_t)2 * R * a.pitch + (size_t)R * a.join_n) * sizeof(float);
-  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<true>), lds, "emx_mlp_backward");
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_BWD>), lds, "emx_mlp_backward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(chain_kernel<true>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(chain_kernel<CHAIN_BWD>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
   return emx::check_launch("mlp chain kernel (backward)");
+}
+
+int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                             int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                             float* const* delta, float* dbelow, emx_stream_t stream) {
+  const char* who = "emx_mlp_forward_backward";
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  EMX_REQUIRE(params && mirror && h && in && cost && delta, "%s: null pointer argument", who);
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "%s: bad layer range", who);
+  EMX_REQUIRE(layer_begin <= bwd_begin && bwd_begin < layer_end, "%s: backward range [%d, %d) outside the forward range", who, bwd_begin, layer_end);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "%s: bad rows / stride", who);
+  const int top = layer_end - 1, wout = desc->width[layer_end];
+  EMX_REQUIRE(!desc->act[top], "%s: the fused launch needs a linear top layer (d cost / d output is its delta)", who);
+  EMX_REQUIRE(cost->target && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0, "%s: incomplete cost description", who);
+  EMX_REQUIRE(cost->variant >= EMX_MEAN_ABS && cost->variant <= EMX_MEAN_NORM, "%s: cost variant %d not available", who, cost->variant);
+  EMX_REQUIRE(cost->off_sin >= 0 && cost->off_sin + cost->n <= wout &&
+                  (!cost->periodic_output || (cost->off_cos >= 0 && cost->off_cos + cost->n <= wout && std::isfinite(cost->periodicity))),
+              "%s: cost column window outside the output row", who);
+  EMX_REQUIRE(cost->dY == delta[top] || cost->dY == nullptr, "%s: d cost / d output is delta[layer_end - 1]; pass that buffer (or NULL) as cost->dY", who);
+  ChainArgs a{};
+  const int nf = layer_end - layer_begin;           // forward layers: images 0 .. nf (image i = input of forward layer i)
+  for (int l = layer_begin; l < layer_end; ++l) {
+    EMX_REQUIRE(h[l], "%s: activation buffer of layer %d is null", who, l);
+    const int st = l - layer_begin;
+    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0, st,
+                   st + 1, 0, who);
+    if (rc) return rc;
+  }
+  a.cost_at = a.nu - 1;
+  a.cost_img = nf;
+  a.top_img = nf + 1;                                // d cost / d output; the backward units ping-pong between nf + 1 and nf + 2
+  a.n_img = nf + 3;
+  for (int l = top; l >= bwd_begin; --l) {
+    EMX_REQUIRE(delta[l], "%s: delta buffer of layer %d is null", who, l);
+    const int Kin = desc->width[l], N = desc->width[l + 1];
+    const long op = mirror_begin(desc, l) + operand_block(Kin, N);
+    const int st = top - l, src = nf + 1 + (st & 1), dst = nf + 1 + ((st + 1) & 1);
+    if (l > bwd_begin) {
+      // delta_{l-1} = (delta_l W_l^T) * act'(h_{l-1}); h_{l-1} is still in LDS image (l - 1 - layer_begin) + 1
+      // (the epilogue operand slot of these units is not used: any readable row, here the head of the operand store)
+      rc = add_units(a, op, N, Kin, mirror, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, U_BWD, src, dst, (l - layer_begin) + 1, who);
+    } else {
+      if (!dbelow) break;
+      rc = add_units(a, op, N, Kin, mirror, 0, dbelow, 0, U_BWD, src, dst, 0, who);
+    }
+    if (rc) return rc;
+  }
+  a.cost.target = cost->target;
+  a.cost.dY = delta[top];
+  a.cost.ws = cost->ws;
+  fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
+                    cost->variant, cost->coef);
+  a.pitch = pitch_for(desc, layer_begin, layer_end);
+  a.mbase = mirror;
+  a.in = in;
+  a.ld_in = ld_in;
+  a.in_cols = desc->width[layer_begin];
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  const size_t lds = ((size_t)a.n_img * R * a.pitch + (size_t)R * cost->n) * sizeof(float);
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_FUSED>), lds, who);
+  if (rc) return rc;
+  const int grid = (row_end - row_begin + R - 1) / R;
+  hipLaunchKernelGGL(chain_kernel<CHAIN_FUSED>, dim3(grid), dim3(NTC), lds, (hipStream_t)stream, a);
+  return emx::check_launch("mlp chain kernel (forward + cost + backward)");
 }
 
 int emx_mlp_wgrad_slices(int n_rows) { return std::max((n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS, 1); }

@@ -206,6 +206,7 @@ class SequentialEngine:
 
     # -- forward / backward ------------------------------------------------------------------------
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
+    _fuse_decoder = os.environ.get("EMX_FUSE_DECODER", "1") != "0"   # forward + auto cost + decoder backward in one launch
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -213,20 +214,37 @@ class SequentialEngine:
         _lib.gather_rows(self.data, self.idx_block, self.periodicity if self.periodic else INF, self.xb,
                          self.xin if self.periodic else None, cursor=self.cursor, B=self.B, split_ws=self.split_ws)
 
-    def _forward(self) -> None:
-        """Forward pass and auto cost in ONE launch (two for a row-block rank: encoder on every row, decoder and cost on the
-        rows it owns).  The activations and d cost / d output go to HBM for the kernels that follow; the cost's
-        per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue."""
+    def _forward(self) -> bool:
+        """Forward pass, auto cost and the decoder's backward pass in ONE launch (two for a row-block rank: encoder on
+        every row first).  The activations, the decoder's deltas and the latent gradient of the auto cost (``dlat``) go to
+        HBM for the kernels that follow; the cost's per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue.
+        Returns False when the decoder's backward pass still has to be launched (no auto cost, a non-linear output layer,
+        layers too wide for the LDS images of the fused launch, or forked streams)."""
         lay, n, p = self.layout, len(self.layout.layers), self.p
+        full = (self.rb, self.re) == (0, self.B)
+        fuse = p.auto_cost_scale is not None and self._fuse_decoder and not self._fork
         cost = None
         if p.auto_cost_scale is not None:
             cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
-                                       float(p.auto_cost_scale), self.B, self.dY, self.cost_ws)
-        if (self.rb, self.re) == (0, self.B):
+                                       float(p.auto_cost_scale), self.B, self.delta[-1] if fuse else self.dY, self.cost_ws)
+        if fuse:
+            try:
+                if full:
+                    _lib.mlp_forward_backward(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, dbelow=self.dlat)
+                else:
+                    _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
+                    _lib.mlp_forward_backward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost, lay.n_enc,
+                                              dbelow=self.dlat)
+                return True
+            except _lib.EmxError:
+                self._fuse_decoder = False     # e.g. layers too wide for one LDS image per layer: two launches from now on
+                return self._forward()
+        if full:
             _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B, cost=cost)
         else:
             _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
             _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
+        return False
 
     def _use_sketchmap(self) -> bool:
         return self.with_distance and self.p.distance_cost_scale is not None
@@ -263,8 +281,10 @@ class SequentialEngine:
         kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at the latent layer; they
         run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
         lay, n = self.layout, len(self.layout.layers)
-        self._forward()
-        if self._fork:
+        decoder_done = self._forward()
+        if decoder_done:
+            self._latent_costs()
+        elif self._fork:
             main = torch.cuda.current_stream()
             side = self._side_stream
             side.wait_stream(main)

@@ -295,6 +295,16 @@ typedef struct {
 int emx_mlp_row_blocks(int n_rows);
 int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                          int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, emx_stream_t stream);
+/* Forward pass, auto cost and the backward-data pass through the upper layers [bwd_begin, layer_end) in ONE launch: the
+ * row block never leaves the CU between them (its activations stay in LDS images, one per layer), which saves the second
+ * launch's start-up (the weights' first-touch latency, ~4 us) and the HBM round trip of d cost / d output.
+ *   h[l] (all forward layers) and delta[l] (bwd_begin <= l < layer_end) are still written for the weight gradients;
+ *   delta[layer_end - 1] = d cost / d output (the top layer must be linear); dbelow (may be NULL) receives dh below
+ *   layer bwd_begin -- exactly what emx_mlp_forward_cost followed by emx_mlp_backward(bwd_begin, layer_end, dtop = dY,
+ *   dbelow) produce.  EMX_EUNSUPPORTED when the layers' LDS images do not fit (then use the two calls). */
+int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                             int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                             float* const* delta, float* dbelow, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and

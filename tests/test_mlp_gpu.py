@@ -253,3 +253,52 @@ def test_adam_gathers_the_next_batch(L, periodicity, D):
                 assert torch.equal(xin, xin_ref)
         else:
             assert float(xb.max()) == -7.0   # nothing gathered behind the last batch
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("periodicity,variant,D,B,n_neurons", [
+    (float("inf"), "mean_square", 128, 4096, [128, 128, 2]), (2 * np.pi, "mean_abs", 10, 256, [128, 128, 2]),
+    (360.0, "mean_norm", 37, 100, [64, 48, 3]), (float("inf"), "mean_abs", 150, 40, [136, 20, 2])])
+def test_forward_backward_in_one_launch_equals_two(L, periodicity, variant, D, B, n_neurons):
+    """emx_mlp_forward_backward (forward, auto cost, decoder backward in one launch, activations kept in LDS) against
+    emx_mlp_forward_cost followed by emx_mlp_backward: the same activations, deltas, latent gradient and cost."""
+    from encodermap_amd.layout import build_layout, init_parameters
+
+    periodic = np.isfinite(periodicity)
+    net_dim = 2 * D if periodic else D
+    afs = [""] + ["tanh"] * (len(n_neurons) - 1) + [""]
+    lay = build_layout(n_neurons, afs, net_dim)
+    n = len(lay.layers)
+    params = torch.from_numpy(init_parameters(lay, 9)).cuda()
+    g = torch.Generator().manual_seed(2)
+    xb = ((torch.rand(B, D, generator=g) - 0.5) * (periodicity if periodic else 6.0)).cuda()
+    xin = torch.zeros(B, net_dim, device="cuda")
+    if periodic:
+        L.periodic_in(xb, periodicity, xin)
+    else:
+        xin = xb
+    Ld = lay.layers[lay.n_enc - 1].n_out
+
+    def run(fused):
+        h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+        dl = [torch.full((B, l.n_out), float("nan"), device="cuda") for l in lay.layers]
+        dlat = torch.full((B, Ld), float("nan"), device="cuda")
+        plan = L.MlpPlan(lay, params, h, dl)
+        cost_ws = torch.zeros(L.mlp_row_blocks(B), device="cuda")
+        cost = L.make_auto_cost(xb, D, 0, D, periodic, periodicity, variant, 0.7, B, dl[-1], cost_ws)
+        if fused:
+            L.mlp_forward_backward(plan, 0, n, xin, 0, B, cost, lay.n_enc, dbelow=dlat)
+        else:
+            L.mlp_forward(plan, 0, n, xin, 0, B, cost=cost)
+            L.mlp_backward(plan, lay.n_enc, n, dl[-1], None, 0, 0, B, dbelow=dlat)
+        torch.cuda.synchronize()
+        return h, dl, dlat, cost_ws
+
+    h1, d1, z1, c1 = run(False)
+    h2, d2, z2, c2 = run(True)
+    for a, b in zip(h1, h2):
+        assert torch.equal(a, b)
+    assert torch.equal(c1, c2)
+    for l in range(lay.n_enc, n):
+        np.testing.assert_allclose(d2[l].cpu().numpy(), d1[l].cpu().numpy(), rtol=1e-6, atol=1e-12)
+    np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), rtol=1e-6, atol=1e-12)
