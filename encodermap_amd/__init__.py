@@ -2,8 +2,7 @@
 
 Drop-in for the training hot path of AG-Peter/encodermap (``em.Parameters`` / ``em.EncoderMap(...)`` /
 ``train()`` / ``encode()`` / ``generate()``): Python host code, hand-written HIP kernels behind a C ABI
-(``libemx.so``, ``include/emx.h``), hipBLASLt GEMMs through torch for the dense layers, one RCCL all-reduce per
-step for data parallelism.  ``import encodermap_amd as em``.
+(``libemx.so``, ``include/emx.h``), one RCCL all-reduce per step for data parallelism.  ``import encodermap_amd as em``.
 
 Importing the package needs neither a GPU nor the built library (parameters, data generators and checkpoint
 helpers are plain Python); constructing a model does, and fails loudly without them -- there is no CPU path.
@@ -13,11 +12,12 @@ from .misc import create_n_cube, random_on_cube_edges
 from .autoencoder import Autoencoder, DihedralEncoderMap, EncoderMap
 from .adc import AngleDihedralCartesianEncoderMap
 from .features import featurize_backbone
-from .callbacks import CheckpointSaver, EarlyStop, EncoderMapBaseCallback, History, ProgressBar
+from . import callbacks
+from .callbacks import ADCClashMetric, ADCRMSDMetric, CheckpointSaver, EarlyStop, EncoderMapBaseCallback, History, ProgressBar
 
 __all__ = [
     "Parameters", "ADCParameters", "Autoencoder", "EncoderMap", "DihedralEncoderMap", "AngleDihedralCartesianEncoderMap",
     "create_n_cube", "random_on_cube_edges", "featurize_backbone", "EncoderMapBaseCallback", "ProgressBar", "CheckpointSaver",
-    "EarlyStop", "History",
+    "EarlyStop", "History", "ADCClashMetric", "ADCRMSDMetric", "callbacks",
 ]
 __version__ = "0.1.0"

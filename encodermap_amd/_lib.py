@@ -68,6 +68,9 @@ SIGNATURES = {
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
     "emx_mlp_row_blocks": (_i, [_i]),
     "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_clash_count": (_i, [_p, _i, _i, _f, _p, _p]),
+    "emx_kabsch_rmsd": (_i, [_p, _p, _i, _i, C.POINTER(_f), _i, _p, _p]),
+    "emx_metric_tick": (_i, [_p, _p, _i, _p, _p, _l, _p, _p]),
     "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
@@ -362,6 +365,27 @@ def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "Au
     _check(load().emx_mlp_forward_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
                                            int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, _ptr(dbelow),
                                            _stream()), "emx_mlp_forward_backward")
+
+
+def clash_count(xyz, clash_distance, counts):
+    """xyz [B, A, 3] float32 (contiguous), counts [B] int64."""
+    B, A = xyz.shape[0], xyz.shape[1]
+    assert xyz.is_contiguous() and counts.dtype == torch.int64
+    _check(load().emx_clash_count(_ptr(xyz), B, A, float(clash_distance), _ptr(counts), _stream()), "emx_clash_count")
+
+
+def kabsch_rmsd(a, b, weights3, translate, out):
+    """a, b [B, A, 3] float32 (contiguous), out [B] float32."""
+    B, A = a.shape[0], a.shape[1]
+    assert a.is_contiguous() and b.is_contiguous() and a.shape == b.shape
+    w = (_f * 3)(*[float(x) for x in weights3])
+    _check(load().emx_kabsch_rmsd(_ptr(a), _ptr(b), B, A, w, int(bool(translate)), _ptr(out), _stream()), "emx_kabsch_rmsd")
+
+
+def metric_tick(counts, rmsd, B, clash_hist, rmsd_hist, hstep):
+    cap = (clash_hist if clash_hist is not None else rmsd_hist).numel()
+    _check(load().emx_metric_tick(_ptr(counts), _ptr(rmsd), int(B), _ptr(clash_hist), _ptr(rmsd_hist), cap, _ptr(hstep), _stream()),
+           "emx_metric_tick")
 
 
 def mlp_row_blocks(n_rows):

@@ -159,6 +159,47 @@ class ADCEngine(SequentialEngine):
         _lib.chain_in_plane_fwd(mean_len, _Bcast(ang_pred) if not self.use_ang else ang_pred, plane)
         _lib.dihedrals_to_cartesian_fwd(dih_pred, math.pi, plane, xyz)
 
+    # -- training metrics (ADCClashMetric / ADCRMSDMetric, callbacks/metrics.py:470-581) ------------------------------
+    METRIC_WEIGHTS = (14.0067, 24.305, 24.305)   # metrics.py:63
+
+    def _metrics(self) -> None:
+        """Clashes of the back-mapped batch and its Kabsch RMSD against the input frames, one value per step like a Keras
+        metric (p.track_clashes / p.track_RMSD, autoencoder.py:2255-2258); part of the captured step."""
+        p = self.p
+        clash = bool(getattr(p, "track_clashes", False))
+        rmsd = bool(getattr(p, "track_RMSD", False)) and self.A % 3 == 0
+        if not (clash or rmsd):
+            return
+        if getattr(self, "clash_hist", None) is None or self.clash_hist.numel() != self.history_capacity:
+            dev, cap = self.device, self.history_capacity
+            old = (getattr(self, "clash_hist", None), getattr(self, "rmsd_hist", None))
+            self.clash_hist = torch.zeros(cap, dtype=torch.float32, device=dev)
+            self.rmsd_hist = torch.zeros(cap, dtype=torch.float32, device=dev)
+            if old[0] is not None:
+                self.clash_hist[: old[0].numel()].copy_(old[0])
+                self.rmsd_hist[: old[1].numel()].copy_(old[1])
+            self.clash_counts = torch.zeros(self.B, dtype=torch.int64, device=dev)
+            self.rmsd_rows = torch.zeros(self.B, dtype=torch.float32, device=dev)
+        if clash:
+            _lib.clash_count(self.xyz, 0.1, self.clash_counts)      # distance_unit "nm" (autoencoder.py:2256)
+        if rmsd:
+            _lib.kabsch_rmsd(self.cart, self.xyz, self.METRIC_WEIGHTS, True, self.rmsd_rows)
+        _lib.metric_tick(self.clash_counts if clash else None, self.rmsd_rows if rmsd else None, self.B, self.clash_hist, self.rmsd_hist,
+                         self.hstep)
+
+    def metric_history(self) -> dict:
+        """{"ADCClashMetric": [...], "ADCRMSDMetric": [...]} for the steps run so far (only the tracked ones)."""
+        out = {}
+        if getattr(self, "clash_hist", None) is None:
+            return out
+        torch.cuda.synchronize(self.device)
+        k = self._hstep_host
+        if getattr(self.p, "track_clashes", False):
+            out["ADCClashMetric"] = self.clash_hist[:k].cpu().numpy()
+        if getattr(self.p, "track_RMSD", False) and self.A % 3 == 0:
+            out["ADCRMSDMetric"] = self.rmsd_hist[:k].cpu().numpy()
+        return out
+
     def _step_pre(self) -> None:
         p, B, per = self.p, self.B, self.periodicity
         lay, n = self.layout, len(self.layout.layers)
@@ -169,6 +210,7 @@ class ADCEngine(SequentialEngine):
         _lib.mlp_forward(self.plan, 0, n, self.xin, 0, B)
         Y, Z = self.h[-1], self.h[lay.n_enc - 1]
         self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
+        self._metrics()
         _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
         _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
 

@@ -289,7 +289,10 @@ class Autoencoder:
         if not self.read_only:
             self.p.save()
         self.save()
-        return History(losses, terms, params={"epochs": total, "steps": 1})
+        metrics = {}
+        if hasattr(eng, "metric_history"):
+            metrics = {k: v[start_hist:] for k, v in eng.metric_history().items()}
+        return History(losses, terms, params={"epochs": total, "steps": 1}, metrics=metrics)
 
     @staticmethod
     def _assert_finite(loss: float) -> None:

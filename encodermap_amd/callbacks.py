@@ -118,10 +118,85 @@ class EarlyStop(EncoderMapBaseCallback):
 class History:
     """Stand-in for ``tf.keras.callbacks.History``: ``.history['loss']`` holds one float per step."""
 
-    def __init__(self, losses, terms=None, params=None) -> None:
+    def __init__(self, losses, terms=None, params=None, metrics=None) -> None:
         self.history = {"loss": [float(v) for v in losses]}
         if terms:
             for k, v in terms.items():
                 self.history[f"{k}_cost"] = [float(x) for x in v]
+        if metrics:
+            for k, v in metrics.items():   # Keras logs every metric's result() under the metric's name
+                self.history[k] = [float(x) for x in v]
         self.epoch = list(range(len(self.history["loss"])))
         self.params = params or {}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Training metrics of the ADC model (encodermap/callbacks/metrics.py:470-581 of the reference).  During training the
+# engine evaluates them inside the captured step (ADCParameters.track_clashes / track_RMSD); the classes below keep the
+# reference's stand-alone interface -- update_state(y_true, y_pred) / result() -- on the same HIP kernels.
+# ---------------------------------------------------------------------------------------------------------------------
+def _frames(y):
+    """[B, A, 3] float32 CUDA tensor from an array, a tensor, or the model's output tuple (frames are entry 2)."""
+    import numpy as np
+    import torch
+
+    if isinstance(y, (list, tuple)):
+        y = y[2]
+    t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(y, dtype=np.float32)))
+    return t.to("cuda", torch.float32).contiguous()
+
+
+class ADCClashMetric:
+    """Number of atom pairs closer than 0.1 nm / 1 Angstrom in the reconstructed backbone, averaged over the batch
+    (metrics.py:470-525; the mean of the int64 counts is truncated like ``tf.reduce_mean``)."""
+
+    def __init__(self, distance_unit: str, name: str = "ADCClashMetric", parameters=None, **kwargs) -> None:
+        if distance_unit == "nm":
+            self.clash_distance = 0.1
+        elif distance_unit == "ang":
+            self.clash_distance = 1
+        else:
+            raise Exception(f"Argument `distance_unit` must be either 'nm' or 'ang'. You provided {distance_unit=}.")
+        self.name = name
+        self.p = parameters
+        self.clashes = 0
+
+    def update_state(self, y_true, y_pred, sample_weight=None) -> None:
+        import torch
+
+        from . import _lib
+
+        _lib.require_gpu()
+        xyz = _frames(y_pred)
+        counts = torch.zeros(xyz.shape[0], dtype=torch.int64, device=xyz.device)
+        _lib.clash_count(xyz, self.clash_distance, counts)
+        self.counts = counts.cpu().numpy()
+        self.clashes = int(self.counts.sum() // len(self.counts))
+
+    def result(self):
+        return self.clashes
+
+
+class ADCRMSDMetric:
+    """Weighted Kabsch RMSD of the output frames against the input frames, one value per batch row (metrics.py:528-581)."""
+
+    WEIGHTS = (14.0067, 24.305, 24.305)   # metrics.py:63
+
+    def __init__(self, name: str = "ADCRMSDMetric", parameters=None, **kwargs) -> None:
+        self.name = name
+        self.p = parameters
+        self.rmsd = None
+
+    def update_state(self, y_true, y_pred, sample_weight=None) -> None:
+        import torch
+
+        from . import _lib
+
+        _lib.require_gpu()
+        a, b = _frames(y_true), _frames(y_pred)
+        out = torch.zeros(a.shape[0], dtype=torch.float32, device=a.device)
+        _lib.kabsch_rmsd(a, b, self.WEIGHTS, True, out)
+        self.rmsd = out.cpu().numpy()
+
+    def result(self):
+        return self.rmsd

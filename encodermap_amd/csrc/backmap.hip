@@ -459,6 +459,179 @@ __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, flo
 
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------
+// Training metrics of the ADC model
+// ---------------------------------------------------------------------------------------------------------
+// clashes: number of atom pairs i < j of a frame closer than `thr`                     callbacks/metrics.py:505-522
+//   (count_nonzero(pairwise_dist(y, flat=True) < d, axis=1)); one workgroup per frame, the frame in LDS
+__global__ __launch_bounds__(NT) void clash_count_kernel(const float* __restrict__ xyz, int A, float thr2, long long* __restrict__ counts) {
+  extern __shared__ float fr[];   // [A][3]
+  __shared__ int red[NT / 64];
+  const float* __restrict__ f = xyz + (long)blockIdx.x * A * 3;
+  for (int e = threadIdx.x; e < 3 * A; e += NT) fr[e] = f[e];
+  __syncthreads();
+  int c = 0;
+  for (int i = 0; i < A - 1; ++i) {
+    const float xi = fr[3 * i], yi = fr[3 * i + 1], zi = fr[3 * i + 2];
+    for (int j = i + 1 + threadIdx.x; j < A; j += NT) {
+      const float dx = fr[3 * j] - xi, dy = fr[3 * j + 1] - yi, dz = fr[3 * j + 2] - zi;
+      c += fmaf(dx, dx, fmaf(dy, dy, dz * dz)) < thr2 ? 1 : 0;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int t = 0;
+    for (int w = 0; w < NT / 64; ++w) t += red[w];
+    counts[blockIdx.x] = t;
+  }
+}
+
+// eigenvalues of a symmetric positive semi-definite 3x3 matrix (cyclic Jacobi, float64: the work is negligible)
+__device__ inline void eig3_psd(double m[3][3], double ev[3]) {
+  for (int sweep = 0; sweep < 12; ++sweep) {
+    const double off = fabs(m[0][1]) + fabs(m[0][2]) + fabs(m[1][2]);
+    if (off < 1e-300) break;
+    for (int p = 0; p < 2; ++p)
+      for (int q = p + 1; q < 3; ++q) {
+        if (fabs(m[p][q]) < 1e-300) continue;
+        const double theta = (m[q][q] - m[p][p]) / (2.0 * m[p][q]);
+        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
+        for (int k = 0; k < 3; ++k) {   // columns p, q
+          const double a = m[k][p], b = m[k][q];
+          m[k][p] = cs * a - sn * b;
+          m[k][q] = sn * a + cs * b;
+        }
+        for (int k = 0; k < 3; ++k) {   // rows p, q
+          const double a = m[p][k], b = m[q][k];
+          m[p][k] = cs * a - sn * b;
+          m[q][k] = sn * a + cs * b;
+        }
+      }
+  }
+  ev[0] = m[0][0];
+  ev[1] = m[1][1];
+  ev[2] = m[2][2];
+}
+
+// weighted Kabsch RMSD of frame pairs, one wave per pair                               callbacks/metrics.py:71-153 (kabsch_weighted, rmsd)
+//   weights = tile(w3, A / 3); translate: every ATOM is shifted by the mean of its own three coordinates (the
+//   reference's `a -= mean(a, axis=-1)`, metrics.py:149-151); msd = (PSQ + QSQ) iw - 2 (s1 + s2 +- s3), the sign of the
+//   smallest singular value following det(C) (= det(V) det(W^T) of the SVD)
+__global__ __launch_bounds__(NT) void kabsch_rmsd_kernel(const float* __restrict__ a, const float* __restrict__ b, int B, int A, float w0,
+                                                         float w1, float w2, int translate, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int fidx = (blockIdx.x * NT + threadIdx.x) >> 6;
+  if (fidx >= B) return;
+  const float* __restrict__ P = a + (long)fidx * A * 3;
+  const float* __restrict__ Q = b + (long)fidx * A * 3;
+  // float64 sums: msd is a small difference of large sums (identical frames must give 0, not sqrt(eps) * size)
+  double C[3][3] = {{0., 0., 0.}, {0., 0., 0.}, {0., 0., 0.}}, cp[3] = {0., 0., 0.}, cq[3] = {0., 0., 0.};
+  double psq = 0., qsq = 0., wsum = 0.;
+  auto wsumd = [](double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  };
+  for (int j = lane; j < A; j += 64) {
+    const int r3 = j % 3;
+    const double w = r3 == 0 ? w0 : (r3 == 1 ? w1 : w2);
+    double p[3] = {P[3 * j], P[3 * j + 1], P[3 * j + 2]}, q[3] = {Q[3 * j], Q[3 * j + 1], Q[3 * j + 2]};
+    if (translate) {
+      const double mp = (p[0] + p[1] + p[2]) / 3., mq = (q[0] + q[1] + q[2]) / 3.;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        p[i] -= mp;
+        q[i] -= mq;
+      }
+    }
+    wsum += w;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      cp[i] = fma(p[i], w, cp[i]);
+      cq[i] = fma(q[i], w, cq[i]);
+      psq = fma(p[i] * p[i], w, psq);
+      qsq = fma(q[i] * q[i], w, qsq);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) C[i][k] = fma(p[i] * q[k], w, C[i][k]);
+    }
+  }
+  wsum = wsumd(wsum);
+  psq = wsumd(psq);
+  qsq = wsumd(qsq);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    cp[i] = wsumd(cp[i]);
+    cq[i] = wsumd(cq[i]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) C[i][k] = wsumd(C[i][k]);
+  }
+  if (lane != 0) return;
+  const double iw = 1.0 / wsum;   // 3 / sum of the [A, 3] weight array
+  double Cd[3][3], M[3][3];
+  double PSQ = psq, QSQ = qsq;
+  for (int i = 0; i < 3; ++i) {
+    PSQ -= cp[i] * cp[i] * iw;
+    QSQ -= cq[i] * cq[i] * iw;
+    for (int k = 0; k < 3; ++k) Cd[i][k] = (C[i][k] - cp[i] * cq[k] * iw) * iw;
+  }
+  for (int i = 0; i < 3; ++i)
+    for (int k = 0; k < 3; ++k) M[i][k] = Cd[0][i] * Cd[0][k] + Cd[1][i] * Cd[1][k] + Cd[2][i] * Cd[2][k];   // C^T C
+  double ev[3];
+  eig3_psd(M, ev);
+  double s[3] = {sqrt(fmax(ev[0], 0.0)), sqrt(fmax(ev[1], 0.0)), sqrt(fmax(ev[2], 0.0))};
+  const double det = Cd[0][0] * (Cd[1][1] * Cd[2][2] - Cd[1][2] * Cd[2][1]) - Cd[0][1] * (Cd[1][0] * Cd[2][2] - Cd[1][2] * Cd[2][0]) +
+                     Cd[0][2] * (Cd[1][0] * Cd[2][1] - Cd[1][1] * Cd[2][0]);
+  const double smin = fmin(s[0], fmin(s[1], s[2]));
+  double ssum = s[0] + s[1] + s[2];
+  if (det < 0.0) ssum -= 2.0 * smin;
+  const double msd = (PSQ + QSQ) * iw - 2.0 * ssum;
+  out[fidx] = (float)sqrt(fmax(msd, 0.0));
+}
+
+
+// per-step record of the two metrics (Keras logs a metric's result() every epoch = step): mean clashes -- truncated like
+// tf.reduce_mean of an int64 tensor, metrics.py:521 -- and mean RMSD, written at index *hstep (before the step's
+// bookkeeping advances it)
+__global__ __launch_bounds__(NT) void metric_tick_kernel(const long long* __restrict__ counts, const float* __restrict__ rmsd, int B,
+                                                         float* __restrict__ clash_hist, float* __restrict__ rmsd_hist, long capacity,
+                                                         const int64_t* __restrict__ hstep) {
+  __shared__ float redf[NT / 64];
+  __shared__ long long redi[NT / 64];
+  long long c = 0;
+  float r = 0.f;
+  for (int i = threadIdx.x; i < B; i += NT) {
+    if (counts) c += counts[i];
+    if (rmsd) r += rmsd[i];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    c += __shfl_xor(c, o, 64);
+    r += __shfl_xor(r, o, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    redi[threadIdx.x >> 6] = c;
+    redf[threadIdx.x >> 6] = r;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    long long ct = 0;
+    float rt = 0.f;
+    for (int w = 0; w < NT / 64; ++w) {
+      ct += redi[w];
+      rt += redf[w];
+    }
+    const long s = *hstep;
+    if (s >= 0 && s < capacity) {
+      if (counts && clash_hist) clash_hist[s] = (float)(ct / B);
+      if (rmsd && rmsd_hist) rmsd_hist[s] = rt / (float)B;
+    }
+  }
+}
+
 extern "C" {
 
 int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t stream) {
@@ -533,6 +706,32 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
   EMX_REQUIRE(soft_a < 0.f || soft_b > soft_a, "emx_soft_start_scale: soft start needs b > a");
   hipLaunchKernelGGL(soft_start_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, soft_a, soft_b, scale_c, out);
   return emx::check_launch("soft_start_kernel");
+}
+
+int emx_clash_count(const float* xyz, int B, int A, float clash_distance, int64_t* counts, emx_stream_t stream) {
+  EMX_REQUIRE(xyz && counts && B > 0 && A >= 2 && clash_distance >= 0.f, "emx_clash_count: bad arguments");
+  const size_t lds = (size_t)3 * A * sizeof(float);
+  if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_clash_count: %d atoms do not fit the LDS frame buffer", A);
+  hipLaunchKernelGGL(clash_count_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, A, clash_distance * clash_distance,
+                     reinterpret_cast<long long*>(counts));
+  return emx::check_launch("clash_count_kernel");
+}
+
+int emx_kabsch_rmsd(const float* a, const float* b, int B, int A, const float weights3[3], int translate, float* rmsd, emx_stream_t stream) {
+  EMX_REQUIRE(a && b && rmsd && weights3 && B > 0 && A >= 3, "emx_kabsch_rmsd: bad arguments");
+  EMX_REQUIRE(A % 3 == 0, "emx_kabsch_rmsd: the weights repeat over N, CA, C -- the number of atoms must be a multiple of 3 (got %d)", A);
+  hipLaunchKernelGGL(kabsch_rmsd_kernel, dim3((unsigned)((B + 3) / 4)), dim3(NT), 0, (hipStream_t)stream, a, b, B, A, weights3[0], weights3[1],
+                     weights3[2], translate, rmsd);
+  return emx::check_launch("kabsch_rmsd_kernel");
+}
+
+int emx_metric_tick(const int64_t* counts, const float* rmsd, int B, float* clash_hist, float* rmsd_hist, int64_t capacity, const int64_t* hstep,
+                    emx_stream_t stream) {
+  EMX_REQUIRE(B > 0 && hstep && (counts || rmsd), "emx_metric_tick: bad arguments");
+  EMX_REQUIRE((!counts || clash_hist) && (!rmsd || rmsd_hist), "emx_metric_tick: a metric without its history buffer");
+  hipLaunchKernelGGL(metric_tick_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, reinterpret_cast<const long long*>(counts), rmsd, B, clash_hist,
+                     rmsd_hist, (long)capacity, hstep);
+  return emx::check_launch("metric_tick_kernel");
 }
 
 }  // extern "C"

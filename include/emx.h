@@ -355,6 +355,20 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo,
                        float* dxyz, int accumulate, emx_stream_t stream);
 
+/* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
+ *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,
+ *                    count_nonzero(pairwise_dist(y_pred, flat=True) < d, axis=1)      encodermap/callbacks/metrics.py:505-522
+ *   emx_kabsch_rmsd  rmsd[f] of frame f of a against frame f of b after the optimal rotation, weights tile(weights3, A/3) --
+ *                    kabsch_weighted / rmsd / ADCRMSDMetric (metrics.py:71-153, 229-243, 570-581), including the
+ *                    reference's `translate` step (every atom shifted by the mean of its own three coordinates). */
+int emx_clash_count(const float* xyz, int B, int A, float clash_distance, int64_t* counts, emx_stream_t stream);
+int emx_kabsch_rmsd(const float* a, const float* b, int B, int A, const float weights3[3], int translate, float* rmsd, emx_stream_t stream);
+/* per-step record inside a captured step (Keras logs every metric's result() each epoch = step):
+ * clash_hist[*hstep] = mean(counts) truncated like tf.reduce_mean of int64 (metrics.py:521), rmsd_hist[*hstep] = mean(rmsd);
+ * either metric may be NULL; call before emx_finish_step advances *hstep. */
+int emx_metric_tick(const int64_t* counts, const float* rmsd, int B, float* clash_hist, float* rmsd_hist, int64_t capacity,
+                    const int64_t* hstep, emx_stream_t stream);
+
 /* Featurisation of a backbone chain: xyz [N, A, 3] -> bond lengths [N, A-1], bond angles
  * [N, A-2] (rad) and dihedrals [N, A-3] (rad, mdtraj convention) of consecutive atoms -- the ADC model's inputs, which the
  * reference obtains through mdtraj's C kernels (encodermap/loading/features.py:150-156,1133,1394; formulas restated at

@@ -133,3 +133,46 @@ def test_adc_facade_train_and_references(em, tmp_path):
     with pytest.raises(Exception, match="Backbone angles are required"):
         em.AngleDihedralCartesianEncoderMap(dict(data, side_dihedrals=np.zeros((1200, 3), np.float32)),
                                             em.ADCParameters(use_sidechains=True), read_only=True)
+
+
+def test_adc_tracked_metrics(em, tmp_path):
+    """p.track_clashes / p.track_RMSD (autoencoder.py:2255-2258): one value per step in the History under the metric's
+    name, equal to the numpy restatement of ADCClashMetric / ADCRMSDMetric on that step's batch (input frames vs the
+    frames the model back-maps), and the stand-alone metric classes give the same numbers."""
+    from oracle import metrics_ops as M
+
+    rng = np.random.default_rng(4)
+    data = R.synthetic_backbone(rng, 600, 12)            # 36 atoms: a multiple of 3
+    p = em.ADCParameters(n_steps=6, batch_size=64, main_path=str(tmp_path), cartesian_pwd_start=1, cartesian_pwd_step=3,
+                         track_clashes=True, track_RMSD=True, seed=5, dihedral_cost_reference=0.5, angle_cost_reference=0.5,
+                         cartesian_cost_reference=0.5)
+    e = em.AngleDihedralCartesianEncoderMap(data, p, read_only=True)
+    eng = e._engine
+    idx = rng.integers(0, 600, (6, 64))
+    clash, rmsd = [], []
+    for t in range(6):
+        eng.run_steps(1, torch.from_numpy(idx[t]).to("cuda:0"))
+        torch.cuda.synchronize()
+        xyz = eng.xyz.cpu().numpy()
+        cart = eng.cart.cpu().numpy()
+        np.testing.assert_allclose(cart, data["central_cartesians"][idx[t]], rtol=0, atol=0)
+        clash.append(int(M.clash_counts(xyz, 0.1).sum() // 64))
+        rmsd.append(float(M.rmsd_numpy(cart, xyz).mean()))
+    got = eng.metric_history()
+    assert np.abs(got["ADCClashMetric"] - np.array(clash)).max() <= 1      # a pair within rounding of the threshold
+    np.testing.assert_allclose(got["ADCRMSDMetric"], rmsd, rtol=2e-4)
+    # stand-alone classes (reference interface)
+    mc = em.callbacks.ADCClashMetric(distance_unit="nm", parameters=p)
+    mc.update_state(None, [None, None, xyz])
+    assert abs(mc.result() - clash[-1]) <= 1
+    mr = em.ADCRMSDMetric(parameters=p)
+    mr.update_state(cart, xyz)
+    np.testing.assert_allclose(mr.result(), M.rmsd_numpy(cart, xyz), rtol=2e-4, atol=1e-6)
+    with pytest.raises(Exception, match="distance_unit"):
+        em.ADCClashMetric(distance_unit="m")
+    # through the facade: the History carries the series
+    p2 = em.ADCParameters(n_steps=5, batch_size=64, main_path=str(tmp_path), cartesian_pwd_start=1, cartesian_pwd_step=3, track_clashes=True,
+                          track_RMSD=True, seed=5, dihedral_cost_reference=0.5, angle_cost_reference=0.5, cartesian_cost_reference=0.5)
+    h = em.AngleDihedralCartesianEncoderMap(data, p2, read_only=True).train()
+    assert len(h.history["ADCClashMetric"]) == 5 and len(h.history["ADCRMSDMetric"]) == 5
+    assert np.isfinite(h.history["ADCRMSDMetric"]).all() and min(h.history["ADCRMSDMetric"]) > 0

@@ -309,3 +309,26 @@ def test_adam_statements_agree():
     np.testing.assert_allclose(wn, p[0].detach().numpy(), rtol=1e-12)
     # first step of Adam with clipped unit gradient moves by ~lr
     assert abs(abs(w[0] - D.keras_adam_step(w, np.full(50, 5.0), np.zeros(50), np.zeros(50), 1)[0][0]) - 1e-3) < 1e-8
+
+
+def test_metric_known_answers():
+    """tests/test_autoencoder.py:412-480 of the reference: the literal coordinate sets of ``test_metrics`` -- mean clashes
+    1.0 and 2.0 at 0.1 nm (the commented assertions), rmsd(c, c) = 0 within 1e-3, rmsd(c, c2) != 0."""
+    from oracle import metrics_ops as M
+
+    c = np.array([[[0.0, 0.0, 0.0], [0.01, 0.0, 0.0], [2.0, 0.0, 0.0]],
+                  [[3.0, 0.0, 0.0], [3.01, 0.0, 0.0], [5.0, 0.0, 0.0]]], np.float32)
+    c2 = np.array([[[0.0, 0.0, 0.0], [0.01, 0.0, 0.0], [0.02, 0.0, 0.0]],
+                   [[1.0, 0.0, 0.0], [0.99, 0.0, 0.0], [5.0, 0.0, 0.0]]], np.float32)
+    assert M.clash_counts(c, 0.1).mean() == 1.0
+    assert M.clash_counts(c2, 0.1).mean() == 2.0
+    np.testing.assert_allclose(M.rmsd_numpy(c, c), [0.0, 0.0], atol=1e-3)
+    assert not np.allclose(M.rmsd_numpy(c, c2), [0.0, 0.0], atol=1e-3)
+    # a rigid rotation + translation of a frame leaves the (centroid-free) Kabsch distance at zero; a mirror image does not
+    rng = np.random.default_rng(0)
+    P = rng.normal(size=(30, 3))
+    th = 0.7
+    Rm = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    w = np.tile(M.WEIGHTS, 10)
+    assert M.kabsch_weighted_rmsd(P, P @ Rm.T + 3.0, w) < 1e-6
+    assert M.kabsch_weighted_rmsd(P, P * np.array([1.0, 1.0, -1.0]), w) > 1e-2
