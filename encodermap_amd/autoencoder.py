@@ -1,7 +1,7 @@
 """User-facing classes ``Autoencoder``, ``EncoderMap``, ``DihedralEncoderMap`` -- same constructor arguments,
 methods, side effects and error behaviour as the reference's ``encodermap/autoencoder/autoencoder.py``
 (``Autoencoder`` :573-1229, ``EncoderMap`` :1232-1307, ``DihedralEncoderMap`` :1310-1400), backed by
-``engine.SequentialEngine`` (HIP kernels + hipBLASLt GEMMs on an MI355X) instead of Keras.
+``engine.SequentialEngine`` (hand-written HIP kernels on an MI355X, include/emx.h) instead of Keras.
 
 Not carried over (out of the hot-path scope): sparse/NaN input, ``tf.data.Dataset`` input,
 TensorBoard, user-supplied Keras models and loss closures -- each raises ``NotImplementedError`` with a message
