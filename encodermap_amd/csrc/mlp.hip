@@ -169,7 +169,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int nu = a.nu;
   float* lat = lds + a.n_img * img;   // [R][join_n] rows joined into one layer's dh (backward)
   float* tgt = lds + a.n_img * img;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
-  constexpr int NE = MODE == CHAIN_FWD ? 1 : 4;
+  constexpr int NE = MODE == CHAIN_BWD ? 4 : 1;   // epilogue operands per lane: h values of 4 rows (backward) or one bias (the fused
+                                                  // launch's backward units take h from the LDS images)
   TSTAMP(0);
 
   float b[NB][8][4];
