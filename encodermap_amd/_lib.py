@@ -48,8 +48,9 @@ SIGNATURES = {
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
-    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _p]),
-    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p]),
+    "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
+    "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
+    "emx_l2_partials": (_i, [_p, _p, _l, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
     "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
@@ -74,7 +75,7 @@ SIGNATURES = {
     "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
-    "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
 }
 
 EMX_MAX_LAYERS = 8
@@ -127,6 +128,34 @@ class SumJob(C.Structure):
     """Mirror of ``emx_sum_job``."""
 
     _fields_ = [("src", _p), ("n", _l), ("scale", _f), ("dev_scale", _p), ("slot", _i), ("square", _i)]
+
+
+class FinishDesc(C.Structure):
+    """Mirror of ``emx_finish_desc``: the arguments of emx_finish_step for launches that carry it along."""
+
+    _fields_ = [("jobs", _p), ("n_jobs", _i), ("terms", _p), ("n_terms", _i), ("history", _p), ("term_history", _p), ("capacity", _l),
+                ("hstep", _p), ("cursor", _p), ("counter2", _p)]
+
+
+def _job_array(jobs):
+    arr = (SumJob * max(len(jobs), 1))()
+    for j, (src, n, scale, dsc, slot, sq) in enumerate(jobs):
+        arr[j].src = src if isinstance(src, int) else _ptr(src)
+        arr[j].n = int(n)
+        arr[j].scale = float(scale)
+        arr[j].dev_scale = _ptr(dsc)
+        arr[j].slot = int(slot)
+        arr[j].square = int(bool(sq))
+    return arr
+
+
+def make_finish_desc(jobs, terms, n_terms, history=None, term_history=None, hstep=None, cursor=None, counter2=None) -> FinishDesc:
+    """jobs: list of (src_ptr_or_tensor, n, scale, dev_scale_tensor_or_None, slot, square), as for finish_step."""
+    arr = _job_array(jobs)
+    d = FinishDesc(C.cast(arr, C.c_void_p), len(jobs), _ptr(terms), int(n_terms), _ptr(history), _ptr(term_history),
+                   history.numel() if history is not None else 0, _ptr(hstep), _ptr(cursor), _ptr(counter2))
+    d.keep = (arr, jobs, terms, history, term_history, hstep, cursor, counter2)
+    return d
 
 
 class MlpDesc(C.Structure):
@@ -317,21 +346,26 @@ def _mirror_args(plan):
     return C.byref(plan.desc), _ptr(plan.mirror)
 
 
-def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws, plan=None, next_batch=None):
+def l2_partials(w, l2coef, ws):
+    _check(load().emx_l2_partials(_ptr(w), _ptr(l2coef), w.numel(), _ptr(ws), _stream()), "emx_l2_partials")
+
+
+def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, ws, plan=None, next_batch=None, bookkeeping_done=False):
     md, mp = _mirror_args(plan)
     nb = C.byref(next_batch) if next_batch is not None else None
     _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
                                 float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), md, mp,
-                                nb, _stream()), "emx_adam_step")
+                                nb, int(bool(bookkeeping_done)), _stream()), "emx_adam_step")
 
 
-def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None, next_batch=None):
+def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None, next_batch=None,
+                     bookkeeping_done=False):
     n = w.numel()
     md, mp = _mirror_args(plan)
     nb = C.byref(next_batch) if next_batch is not None else None
     _check(load().emx_adam_step_slices(_ptr(w), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
                                        float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step),
-                                       _ptr(ws), md, mp, nb, _stream()), "emx_adam_step_slices")
+                                       _ptr(ws), md, mp, nb, int(bool(bookkeeping_done)), _stream()), "emx_adam_step_slices")
 
 
 def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
@@ -410,14 +444,7 @@ def sketchmap_describe(X, Z, periodicity, sig, scale, center_scale, row_begin, r
 
 def finish_step(jobs, terms, n_terms, history=None, term_history=None, hstep=None, cursor=None, counter2=None):
     """jobs: list of (src_ptr_or_tensor, n, scale, dev_scale_tensor_or_None, slot, square)."""
-    arr = (SumJob * max(len(jobs), 1))()
-    for j, (src, n, scale, dsc, slot, sq) in enumerate(jobs):
-        arr[j].src = src if isinstance(src, int) else _ptr(src)
-        arr[j].n = int(n)
-        arr[j].scale = float(scale)
-        arr[j].dev_scale = _ptr(dsc)
-        arr[j].slot = int(slot)
-        arr[j].square = int(bool(sq))
+    arr = _job_array(jobs)
     cap = history.numel() if history is not None else 0
     _check(load().emx_finish_step(arr, len(jobs), _ptr(terms), int(n_terms), _ptr(history), _ptr(term_history), cap, _ptr(hstep),
                                   _ptr(cursor), _ptr(counter2), _stream()), "emx_finish_step")
@@ -427,11 +454,12 @@ def mlp_wgrad_ws_floats(n_params, n_rows):
     return int(load().emx_mlp_wgrad_ws_floats(int(n_params), int(n_rows)))
 
 
-def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws):
-    """grad=None leaves the per-slice partials in ws (consumed by adam_tick)."""
+def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws, finish: "FinishDesc" = None):
+    """grad=None leaves the per-slice partials in ws (consumed by adam_step_slices); ``finish``: the step's scalar epilogue
+    rides along as one extra workgroup."""
     _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, _ptr(xin), xin.stride(0),
-                                int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(), _stream()),
-           "emx_mlp_wgrad")
+                                int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(),
+                                C.byref(finish) if finish is not None else None, _stream()), "emx_mlp_wgrad")
 
 
 # ---- ADC path ---------------------------------------------------------------------------------------------------

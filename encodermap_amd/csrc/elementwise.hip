@@ -30,9 +30,11 @@ namespace {
 #ifdef EMX_CHAIN_TIMING   // in-kernel timelines of the two scalar-ish kernels of a step (tools/abl_finish.py)
 __device__ long long emx_dbg_fin[64];
 #define FSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) emx_dbg_fin[k] = clock64(); } while (0)
-#else
-#define FSTAMP(k)
 #endif
+
+}  // namespace
+#include "finish.h"   // (after FSTAMP)
+namespace {
 
 struct GatherArgs {
   const float* data;
@@ -200,6 +202,9 @@ struct AdamArgs {
   long n;
   float lr, b1, b2, eps, clip;
   float log2_b1, log2_b2;
+  int late;             // the step's bookkeeping already ran (emx_finish_desc of emx_mlp_wgrad): t = *step, the regulariser shares are
+                        // those of the NEW weights (the next step's cost), the next batch is the one under *cursor
+
   float* mirror;        // optional: operand store of the dense layers, rewritten with the new weights (mirror.h)
   MirrorArgs mir;
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
@@ -208,12 +213,13 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float l2c, const AdamArgs& a, float alpha,
                                          float& reg) {
-  reg = fmaf(0.5f * l2c * w, w, reg);
+  if (!a.late) reg = fmaf(0.5f * l2c * w, w, reg);
   g = fmaf(l2c, w, g);
   if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);
   m = fmaf(g - m, 1.f - a.b1, m);
   v = fmaf(fmaf(g, g, -v), 1.f - a.b2, v);
   w = w - alpha * m / (sqrtf(v) + a.eps);
+  if (a.late) reg = fmaf(0.5f * l2c * w, w, reg);
 }
 
 __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
@@ -284,7 +290,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step); b^t = 2^(t log2 b) on the hardware
   // exp2 (the library powf is several hundred instructions in front of the first load of a latency-bound kernel)
   auto alpha_of = [&](long st) {
-    const float t = (float)(st + 1);
+    const float t = (float)(st + (a.late ? 0 : 1));
     return a.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.log2_b1));
   };
   float reg = 0.f;
@@ -343,6 +349,26 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += nt) a.ws[i] = 0.f;
 }
 
+// regulariser shares of the CURRENT weights in the layout the optimizer leaves them in (ws[block], zeros up to
+// EMX_REDUCE_WS): the start-up of the late-bookkeeping scheme (emx_l2_partials)
+__global__ __launch_bounds__(NT) void l2_partials_kernel(const float* __restrict__ w, const float* __restrict__ l2coef, long n, float* __restrict__ ws) {
+  __shared__ float red[NT / 64];
+  const int nt = blockDim.x;
+  float reg = 0.f;
+  if (l2coef)
+    for (long i = (long)blockIdx.x * nt + threadIdx.x; i < n; i += (long)gridDim.x * nt) reg = fmaf(0.5f * l2coef[i] * w[i], w[i], reg);
+  reg = wave_sum(reg);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = reg;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int wv = 0; wv < nt / 64; ++wv) t += red[wv];
+    ws[blockIdx.x] = t;
+  }
+  if (blockIdx.x == 0)
+    for (int i = gridDim.x + threadIdx.x; i < EMX_REDUCE_WS; i += nt) ws[i] = 0.f;
+}
+
 __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, float* __restrict__ history,
                                  float* __restrict__ term_history, long capacity, int64_t* __restrict__ step,
                                  int64_t* __restrict__ cursor, int64_t* __restrict__ counter2) {
@@ -360,120 +386,10 @@ __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, f
   if (counter2) *counter2 += 1;
 }
 
-struct FinishArgs {
-  emx_sum_job jobs[EMX_MAX_SUM_JOBS];
-  int n_jobs;
-  float* terms;
-  int n_terms;
-  float* history;
-  float* term_history;
-  long capacity;
-  int64_t* hstep;
-  int64_t* cursor;
-  int64_t* counter2;
-  const float* terms_base;   // 16-byte aligned, >= 16 readable bytes
-};
-
-// One workgroup, one memory round trip for all the step's scalars: every job's first 8192 elements are requested (16-byte
-// loads, four jobs at a time) before anything is added, one block-wide reduction serves all jobs, and the bookkeeping of
-// step_tick_kernel works from values fetched at kernel entry.  A single workgroup is bound by round trips (~2.7 us each
-// here: freshly written lines of other XCDs, cold TLB) and by its own instruction count, not by bandwidth; job after job,
-// each with its own reduction and a serial tail, was 9 us.  Fixed order throughout.
-constexpr int FQ = 8;   // 16-byte loads per thread and job in the common round
-
-__global__ __launch_bounds__(NT) void finish_step_kernel(const FinishArgs a) {
-  __shared__ float red[EMX_MAX_SUM_JOBS][NT / 64];
+__global__ __launch_bounds__(FIN_NT) void finish_step_kernel(const FinishArgs a) {
+  __shared__ float red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
   __shared__ float tl[64];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  FSTAMP(0);
-  // scalars of the bookkeeping, requested up front
-  long hs = 0, cur = 0, cnt = 0;
-  if (tid == 0) {
-    if (a.hstep) hs = *a.hstep;
-    if (a.cursor) cur = *a.cursor;
-    if (a.counter2) cnt = *a.counter2;
-  }
-  if (tid < a.n_terms) tl[tid] = a.terms[tid];
-  float dsc[EMX_MAX_SUM_JOBS];
-#pragma unroll
-  for (int j = 0; j < EMX_MAX_SUM_JOBS; ++j) dsc[j] = (j < a.n_jobs && a.jobs[j].dev_scale && tid == 0) ? *a.jobs[j].dev_scale : 1.f;
-
-  float part[EMX_MAX_SUM_JOBS];
-#pragma unroll
-  for (int g0 = 0; g0 < EMX_MAX_SUM_JOBS; g0 += 4) {
-    if (g0 >= a.n_jobs) {   // uniform
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) part[g0 + jj] = 0.f;
-      continue;
-    }
-    float4 v[4][FQ];
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = g0 + jj;
-      // absent and unaligned jobs re-read the first 16 bytes of `terms` with weight 0: no branch around any load
-      const bool vec = j < a.n_jobs && (reinterpret_cast<uintptr_t>(a.jobs[j].src) & 15) == 0;
-      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(vec ? a.jobs[j].src : a.terms_base);
-      const long n4 = vec ? a.jobs[j].n >> 2 : 0;
-#pragma unroll
-      for (int u = 0; u < FQ; ++u) v[jj][u] = src4[min((long)tid + u * NT, max(n4, 1L) - 1)];
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int j = g0 + jj;
-      const bool live = j < a.n_jobs;
-      const emx_sum_job job = a.jobs[live ? j : 0];
-      const bool vec = live && (reinterpret_cast<uintptr_t>(job.src) & 15) == 0;
-      const long n = live ? job.n : 0, n4 = vec ? n >> 2 : 0;
-      const bool sq = job.square != 0;
-      float acc[FQ];
-#pragma unroll
-      for (int u = 0; u < FQ; ++u) {
-        const float4 x = v[jj][u];
-        const float wq = (long)tid + u * NT < n4 ? 1.f : 0.f;
-        acc[u] = (sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w)) * wq;
-      }
-      float p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
-      for (long i = (long)tid + FQ * NT; i < n4; i += NT) {   // long jobs: the rest, strided
-        const float4 x = reinterpret_cast<const float4*>(job.src)[i];
-        p += sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w);
-      }
-      for (long i = 4 * n4 + tid; i < n; i += NT) {             // tail (or an unaligned job)
-        const float x = job.src[i];
-        p += sq ? x * x : x;
-      }
-      part[j] = wave_sum(p);
-    }
-  }
-  FSTAMP(2);
-  if (lane == 0) {
-#pragma unroll
-    for (int j = 0; j < EMX_MAX_SUM_JOBS; ++j) red[j][wave] = part[j];
-  }
-  __syncthreads();
-  FSTAMP(3);
-  if (tid == 0) {
-    for (int j = 0; j < a.n_jobs; ++j) {
-      float tot = 0.f;
-      for (int w = 0; w < NT / 64; ++w) tot += red[j][w];
-      tot *= a.jobs[j].scale * dsc[j];
-      a.terms[a.jobs[j].slot] = tot;
-      tl[a.jobs[j].slot] = tot;
-    }
-    FSTAMP(4);
-    if (a.hstep) {
-      float tot = 0.f;
-      for (int i = 0; i < a.n_terms; ++i) tot += tl[i];
-      if (hs >= 0 && hs < a.capacity) {
-        if (a.history) a.history[hs] = tot;
-        if (a.term_history)
-          for (int i = 0; i < a.n_terms; ++i) a.term_history[hs * a.n_terms + i] = tl[i];
-      }
-      *a.hstep = hs + 1;
-      if (a.cursor) *a.cursor = cur + 1;
-      if (a.counter2) *a.counter2 = cnt + 1;
-    }
-    FSTAMP(5);
-  }
+  finish_step_body(a, red, tl);
 }
 
 inline int grid_for(long work_items, int per_block) {
@@ -614,15 +530,18 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
 
 int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
                   float eps, float clip, const int64_t* step, float* reg_loss, float* ws, const emx_mlp_desc* mirror_desc, float* mirror,
-                  const emx_next_batch* next, emx_stream_t stream) {
+                  const emx_next_batch* next, int bookkeeping_done, emx_stream_t stream) {
   int rcn = check_next(next, "emx_adam_step");
   if (rcn) return rcn;
+  EMX_REQUIRE(!bookkeeping_done || !reg_loss, "emx_adam_step: with bookkeeping_done the regulariser shares belong to the next step (reg_loss must be NULL)");
   EMX_REQUIRE(w && g && m && v && step && ws, "emx_adam_step: null pointer argument");
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
   AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
   const int grid = grid_for((n + 3) / 4, ADAM_NT);
   a.adam_blocks = grid;
+  a.late = bookkeeping_done ? 1 : 0;
+  if (a.late) a.next.batch_step = 0;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(adam_kernel, dim3(grid + gather_blocks(next)), dim3(ADAM_NT), 0, st, a);
   int rc = emx::check_launch("adam_kernel");
@@ -636,7 +555,8 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
 
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, emx_stream_t stream) {
+                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, int bookkeeping_done,
+                         emx_stream_t stream) {
   int rcn = check_next(next, "emx_adam_step_slices");
   if (rcn) return rcn;
   EMX_REQUIRE(w && g_partials && m && v && step && ws, "emx_adam_step_slices: null pointer argument");
@@ -645,8 +565,16 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
   AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc,
                          mirror, next);
   a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  a.late = bookkeeping_done ? 1 : 0;
+  if (a.late) a.next.batch_step = 0;
   hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next)), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
+}
+
+int emx_l2_partials(const float* w, const float* l2coef, int64_t n, float* ws, emx_stream_t stream) {
+  EMX_REQUIRE(w && ws && n > 0, "emx_l2_partials: bad arguments");
+  hipLaunchKernelGGL(l2_partials_kernel, dim3(grid_for((n + 3) / 4, ADAM_NT)), dim3(ADAM_NT), 0, (hipStream_t)stream, w, l2coef, (long)n, ws);
+  return emx::check_launch("l2_partials_kernel");
 }
 
 int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v,
@@ -677,27 +605,10 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
 
 int emx_finish_step(const emx_sum_job* jobs, int n_jobs, float* terms, int n_terms, float* history, float* term_history,
                     int64_t capacity, int64_t* hstep, int64_t* cursor, int64_t* counter2, emx_stream_t stream) {
-  EMX_REQUIRE(terms && n_terms > 0 && n_terms <= 64 && n_jobs >= 0 && n_jobs <= EMX_MAX_SUM_JOBS && (n_jobs == 0 || jobs),
-              "emx_finish_step: bad arguments");
   FinishArgs a;
-  a.jobs[0] = emx_sum_job{terms, 0, 1.f, nullptr, 0, 0};
-  EMX_REQUIRE((reinterpret_cast<uintptr_t>(terms) & 15) == 0 && n_terms >= 4, "emx_finish_step: terms must be 16-byte aligned, >= 4 entries");
-  a.terms_base = terms;
-  for (int j = 0; j < n_jobs; ++j) {
-    EMX_REQUIRE((jobs[j].src || jobs[j].n == 0) && jobs[j].n >= 0 && jobs[j].slot >= 0 && jobs[j].slot < n_terms, "emx_finish_step: bad job %d", j);
-    a.jobs[j] = jobs[j];
-    if (jobs[j].n == 0) a.jobs[j].src = terms;
-  }
-  a.n_jobs = n_jobs;
-  a.terms = terms;
-  a.n_terms = n_terms;
-  a.history = history;
-  a.term_history = term_history;
-  a.capacity = (long)capacity;
-  a.hstep = hstep;
-  a.cursor = cursor;
-  a.counter2 = counter2;
-  hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, a);
+  int rc = fill_finish_args(a, jobs, n_jobs, terms, n_terms, history, term_history, capacity, hstep, cursor, counter2, "emx_finish_step");
+  if (rc) return rc;
+  hipLaunchKernelGGL(finish_step_kernel, dim3(1), dim3(FIN_NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("finish_step_kernel");
 }
 

@@ -22,6 +22,7 @@
 // k = 16q + 4g + i for the i-th of four consecutive MFMAs, so a lane's four A (or W-row) values are contiguous.
 #include "cost.h"
 #include "emx_common.h"
+#include "finish.h"
 #include "mirror.h"
 
 namespace {
@@ -515,6 +516,8 @@ struct WgradDev {
   float* partial;            // [n_slices][n_params]
   long n_params;
   int row0, row_end, rows_per_slice;
+  int has_fin;               // the last blockIdx.x column is not a dW block: its y = 0 workgroup runs the step's scalar epilogue
+  FinishArgs fin;
 };
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -537,6 +540,16 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
   //  latency of its operand loads -- the activations and deltas were written by the previous kernels on other XCDs --
   //  so it wants several workgroups per CU: 64x64 blocks x 32 slices = 640 workgroups, 128 MFMAs per wave; measured
   //  15.8 us against 20.1 us for 64x64 x 16 slices (320 workgroups) and 17.5 us for 128x128 x 32 slices (192 workgroups).)
+  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
+  __shared__ float fin_tl[64];
+  if (a.has_fin && blockIdx.x == gridDim.x - 1) {
+    // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs -- the
+    // cost shares of the forward launch, the tile sums of the all-pairs launch, the regulariser shares the previous
+    // optimizer launch left for the current weights -- are complete before this launch starts, and a launch of its own
+    // costs ~6.5 us of a ~95 us step.
+    if (blockIdx.y == 0) finish_step_body(a.fin, fin_red, fin_tl);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int m = lane & 15, g = lane >> 4;
   WSTAMP(0);
@@ -940,8 +953,15 @@ size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows) {
 
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
                   int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad, float* ws,
-                  size_t ws_floats, emx_stream_t stream) {
+                  size_t ws_floats, const emx_finish_desc* finish, emx_stream_t stream) {
   WgradDev a;
+  a.has_fin = 0;
+  if (finish) {
+    int rcf = fill_finish_args(a.fin, finish->jobs, finish->n_jobs, finish->terms, finish->n_terms, finish->history, finish->term_history,
+                               finish->capacity, finish->hstep, finish->cursor, finish->counter2, "emx_mlp_wgrad (finish)");
+    if (rcf) return rcf;
+    a.has_fin = 1;
+  }
   int rc = fill_dev(desc, params, h, delta, a.d, "emx_mlp_wgrad");
   if (rc) return rc;
   EMX_REQUIRE(xin && h && delta && ws, "emx_mlp_wgrad: null pointer argument");
@@ -974,7 +994,8 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   a.rows_per_slice = EMX_WGRAD_SLICE_ROWS;
   const int slices = (nrows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles, slices), dim3(NT), 0, st, a);
+  static_assert(FIN_NT == NT, "the scalar epilogue shares the weight-gradient kernel's workgroup size");
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.has_fin, slices), dim3(NT), 0, st, a);
   rc = emx::check_launch("mlp_wgrad_kernel");
   if (rc) return rc;
   if (!grad) return EMX_OK;   // the caller sums the slices itself (emx_adam_tick)

@@ -144,6 +144,7 @@ class SequentialEngine:
         # timeline), more than the ~19 us of work the overlap hides.
         self._fork = os.environ.get("EMX_FORK_STREAMS", "0") == "1"
         self._alloc_step_buffers(self.B)
+        self._sync_derived_state()
         self._graph = None
         self.data = None
         self.idx_block = None
@@ -207,6 +208,7 @@ class SequentialEngine:
     # -- forward / backward ------------------------------------------------------------------------
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
     _fuse_decoder = os.environ.get("EMX_FUSE_DECODER", "1") != "0"   # forward + auto cost + decoder backward in one launch
+    _fold_finish = os.environ.get("EMX_FOLD_FINISH", "1") != "0"     # scalar epilogue inside the weight-gradient launch
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -303,21 +305,36 @@ class SequentialEngine:
         if self.dp.active:      # the loss terms travel in the same all-reduce as the gradients
             _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
 
+    def _late_bookkeeping(self) -> bool:
+        """Single process: the step's scalar epilogue rides along with the weight-gradient launch (its inputs are complete
+        by then: the regulariser shares of the CURRENT weights were left by the previous optimizer launch, or by
+        emx_l2_partials at the start), and the optimizer runs last with ``bookkeeping_done``."""
+        return not self.dp.active and self._fold_finish
+
     def _wgrad(self) -> None:
         """Weight gradients.  Single GPU: the slice partials stay in the workspace and the Adam kernel adds them up
         itself; data parallel: reduced into the flat gradient buffer for the all-reduce."""
         n = len(self.layout.layers)
-        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws)
+        fin = None
+        if self._late_bookkeeping():
+            jobs = self._jobs_pre() + [(self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)]
+            fin = _lib.make_finish_desc(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws, finish=fin)
 
     def _step_post(self) -> None:
-        """clip + L2 + Adam, then ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost,
-        history and counters."""
+        """clip + L2 + Adam (+ operand store, + the next batch), and -- unless it rode along with the weight gradients --
+        ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost, history and counters."""
         p = self.p
         reg_job = (self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)
         nxt = None
         if self._prefetch:
             nxt = _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
                                        self.xin if self.periodic else None, self.split_ws)
+        if self._late_bookkeeping():
+            _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
+                                  p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt,
+                                  bookkeeping_done=True)
+            return
         if self.dp.active:
             _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2,
                            plan=self.plan, next_batch=nxt)
@@ -327,6 +344,12 @@ class SequentialEngine:
                                   p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt)
             jobs = self._jobs_pre() + [reg_job]
         _lib.finish_step(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+
+    def _sync_derived_state(self) -> None:
+        """After the weights were written by anything but the optimizer: operand store and regulariser shares."""
+        self.plan.refresh_mirror()
+        if self._late_bookkeeping():
+            _lib.l2_partials(self.w, self.l2coef, self.red_ws2)
 
     def _step_body(self) -> None:
         self._step_pre()
@@ -355,7 +378,7 @@ class SequentialEngine:
         def restore():
             for t, sv in zip(self._state_tensors(), saved):
                 t.copy_(sv)
-            self.plan.refresh_mirror()
+            self._sync_derived_state()
             if self._prefetch:
                 self._gather_current()
 
@@ -502,7 +525,7 @@ class SequentialEngine:
 
     def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
         self.w.copy_(torch.from_numpy(pack_weights(self.layout, arrays)).to(self.device))
-        self.plan.refresh_mirror()
+        self._sync_derived_state()
 
     def state_dict(self) -> dict:
         torch.cuda.synchronize(self.device)
@@ -514,6 +537,6 @@ class SequentialEngine:
             if name in sd:
                 getattr(self, name).copy_(torch.from_numpy(np.asarray(sd[name], np.float32)).to(self.device))
         if "w" in sd:
-            self.plan.refresh_mirror()
+            self._sync_derived_state()
         if "step" in sd:
             self.step.fill_(int(sd["step"]))

@@ -209,14 +209,22 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
                   float lr, float beta1, float beta2, float eps, float clip,
                   const int64_t* step, float* reg_loss, float* ws /* >= EMX_REDUCE_WS floats */,
                   const emx_mlp_desc* mirror_desc /* may be NULL */, float* mirror /* may be NULL: operand store (emx_mlp_mirror) rewritten
-                  with the new kernels */, const emx_next_batch* next /* may be NULL */, emx_stream_t stream);
+                  with the new kernels */, const emx_next_batch* next /* may be NULL */,
+                  int bookkeeping_done /* see below */, emx_stream_t stream);
 
 /* emx_adam_step on the weight-gradient slice partials left by emx_mlp_wgrad (gradient = fixed-order sum over n_slices slices of
  * g_partials[s * partial_stride + i]); no separate reduction pass.  ws[0 .. EMX_REDUCE_WS) receives partials of the regulariser
  * cost (summed by emx_finish_step). */
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,
                          int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
-                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, emx_stream_t stream);
+                         const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next, int bookkeeping_done,
+                         emx_stream_t stream);
+/* bookkeeping_done != 0: the step's emx_finish_step has ALREADY run when the optimizer launches (it rode along with
+ * emx_mlp_wgrad, emx_finish_desc), so *step already counts this update (t = *step), the batch under *cursor already is the
+ * next one, and ws receives the regulariser shares of the NEW weights -- the regulariser term of the NEXT step's cost
+ * (0.5 sum l2coef w^2 is a function of the weights the next forward pass uses).  emx_l2_partials provides those shares
+ * for the weights a run starts from. */
+int emx_l2_partials(const float* w, const float* l2coef, int64_t n, float* ws /* EMX_REDUCE_WS floats */, emx_stream_t stream);
 
 /* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
  * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
@@ -240,6 +248,18 @@ typedef struct {
   int square;
 } emx_sum_job;
 #define EMX_MAX_SUM_JOBS 8
+typedef struct {   /* the arguments of emx_finish_step, for launches that carry it along (emx_mlp_wgrad) */
+  const emx_sum_job* jobs;
+  int n_jobs;
+  float* terms;
+  int n_terms;
+  float* history;
+  float* term_history;
+  int64_t capacity;
+  int64_t* hstep;
+  int64_t* cursor;
+  int64_t* counter2;
+} emx_finish_desc;
 int emx_finish_step(const emx_sum_job* jobs, int n_jobs, float* terms, int n_terms, float* history, float* term_history,
                     int64_t capacity, int64_t* hstep, int64_t* cursor, int64_t* counter2, emx_stream_t stream);
 
@@ -319,7 +339,9 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
                   int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad /* NULL: leave
-                  the slice partials in ws for emx_adam_tick */, float* ws, size_t ws_floats, emx_stream_t stream);
+                  the slice partials in ws for emx_adam_step_slices */, float* ws, size_t ws_floats,
+                  const emx_finish_desc* finish /* may be NULL: emx_finish_step with these arguments, run by one extra
+                  workgroup of this launch */, emx_stream_t stream);
 /* number of row slices emx_mlp_wgrad leaves in ws for n_rows rows (slice s starts at ws + s * n_params) */
 int emx_mlp_wgrad_slices(int n_rows);
 

@@ -281,6 +281,37 @@ def test_adam_and_tick(L, n):
     assert np.allclose(thist[:5, 0].cpu().numpy(), [1, 2, 3, 4, 5])
 
 
+def test_adam_after_the_bookkeeping(L):
+    """``bookkeeping_done``: the optimizer launch runs AFTER the step's scalar epilogue advanced the counter, so it takes
+    t from the counter as it stands and leaves the regulariser shares of the weights it has just written (the NEXT step's
+    regulariser cost); emx_l2_partials produces the same shares for weights written by anything else."""
+    rng = np.random.default_rng(11)
+    n = 33412
+    w = rng.normal(0, 0.3, n).astype(np.float32)
+    l2 = ((rng.random(n) < 0.9) * 2e-3).astype(np.float32)
+    W1, M1, V1 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    W2, M2, V2 = dev(w), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    L2 = dev(l2)
+    s1 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    s2 = torch.zeros(1, dtype=torch.int64, device="cuda")
+    ws1, ws2, ws3 = (torch.zeros(L.EMX_REDUCE_WS, device="cuda") for _ in range(3))
+    reg = torch.zeros(4, device="cuda")
+    for t in range(1, 5):
+        g = dev(rng.normal(0, 1.0, n) * (3.0 if t == 2 else 0.3))
+        L.adam_step(W1, g, M1, V1, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s1, None, ws1)       # t = counter + 1 ...
+        s1 += 1                                                                           # ... the epilogue counts afterwards
+        s2 += 1                                                                           # here it already has
+        L.adam_step(W2, g, M2, V2, L2, 1e-3, 0.9, 0.999, 1e-7, 1.0, s2, None, ws2, bookkeeping_done=True)
+        L.l2_partials(W2, L2, ws3)
+        torch.cuda.synchronize()
+        assert int(s1) == t and int(s2) == t
+        assert torch.equal(W1, W2) and torch.equal(M1, M2) and torch.equal(V1, V2)
+        assert float(ws2.double().sum()) == pytest.approx(float(ws3.double().sum()), rel=1e-6)   # (the slots partition differently)
+        want = float((0.5 * L2.double() * W2.double() ** 2).sum())
+        L.finish_step([(ws2, L.EMX_REDUCE_WS, 1.0, None, 0, False)], reg, 4)
+        assert float(reg[0]) == pytest.approx(want, rel=1e-5)
+
+
 def test_adam_tick_fused_equals_separate(L):
     """emx_adam_tick (one launch: slice sum + clip + L2 + Adam + regulariser cost + bookkeeping, behind one entry
     point) gives the same result as emx_adam_step + emx_step_tick on the reduced gradient."""

@@ -128,6 +128,27 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
     L.mlp_wgrad(plan, 0, n, X, 0, B, g2, ws)
     torch.cuda.synchronize()
     assert torch.equal(g[lo:hi], g2[lo:hi])
+    # the step's scalar epilogue riding along as one extra workgroup: same gradients, same sums and bookkeeping as the
+    # separate emx_finish_step launch
+    src = torch.from_numpy(rng.normal(0, 1, 5000).astype(np.float32)).to(dev)
+    jobs = [(src, 5000, 0.5, None, 0, False), (src[1:], 777, 2.0, None, 2, True)]
+    outs = []
+    for fold in (False, True):
+        terms = torch.tensor([9.0, 0.25, 9.0, 0.0], device=dev)
+        hist, thist = torch.zeros(4, device=dev), torch.zeros(4, 4, device=dev)
+        cnt = [torch.tensor([1], dtype=torch.int64, device=dev) for _ in range(3)]
+        g3 = torch.empty_like(g)
+        fin = L.make_finish_desc(jobs, terms, 4, hist, thist, *cnt)
+        L.mlp_wgrad(plan, 0, n, X, 0, B, g3, ws, finish=fin if fold else None)
+        if not fold:
+            L.finish_step(jobs, terms, 4, hist, thist, *cnt)
+        torch.cuda.synchronize()
+        assert torch.equal(g3[lo:hi], g[lo:hi])
+        assert [int(c) for c in cnt] == [2, 2, 2]
+        outs.append((terms.clone(), hist.clone(), thist.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert float(outs[0][1][1]) == pytest.approx(float(outs[0][0].sum()), rel=1e-6) and float(outs[0][0][1]) == 0.25
 
 
 def test_mlp_rejects_bad_arguments(L):
