@@ -12,12 +12,13 @@ from .misc import create_n_cube, random_on_cube_edges
 from .autoencoder import Autoencoder, DihedralEncoderMap, EncoderMap
 from .adc import AngleDihedralCartesianEncoderMap
 from .features import featurize_backbone
-from . import callbacks
+from . import backmapping, callbacks
+from .backmapping import AllAtomTopology, TorsionTable, allatom_backmap
 from .callbacks import ADCClashMetric, ADCRMSDMetric, CheckpointSaver, EarlyStop, EncoderMapBaseCallback, History, ProgressBar
 
 __all__ = [
     "Parameters", "ADCParameters", "Autoencoder", "EncoderMap", "DihedralEncoderMap", "AngleDihedralCartesianEncoderMap",
     "create_n_cube", "random_on_cube_edges", "featurize_backbone", "EncoderMapBaseCallback", "ProgressBar", "CheckpointSaver",
-    "EarlyStop", "History", "ADCClashMetric", "ADCRMSDMetric", "callbacks",
+    "EarlyStop", "History", "ADCClashMetric", "ADCRMSDMetric", "callbacks", "backmapping", "AllAtomTopology", "TorsionTable", "allatom_backmap",
 ]
 __version__ = "0.1.0"

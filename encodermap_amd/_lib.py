@@ -64,6 +64,8 @@ SIGNATURES = {
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
+    "emx_allatom_mask_words": (_i, [_i]),
+    "emx_allatom_backmap": (_i, [_p, _l, _l, _i, _p, _p, _i, _p, _l, _p, _p]),
     "emx_mlp_mirror_floats": (_sz, [_p]),
     "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
@@ -505,6 +507,19 @@ def pdist_flat_bwd(xyz, dout, start, step, C, dxyz, accumulate=False):
 
 def soft_start_scale(step, a, b, c, out):
     _check(load().emx_soft_start_scale(_ptr(step), float(a), float(b), float(c), _ptr(out), _stream()), "emx_soft_start_scale")
+
+
+def allatom_mask_words(A):
+    return int(load().emx_allatom_mask_words(int(A)))
+
+
+def allatom_backmap(xyz0, quads, far_mask, targets, out):
+    """xyz0 [A, 3] (one template for all frames) or [n, A, 3]; quads int32 [J, 4]; far_mask int32 [J, W, 64]; targets [n, J]."""
+    n, A = out.shape[0], out.shape[1]
+    J = quads.shape[0]
+    stride = 0 if xyz0.dim() == 2 else xyz0.stride(0)
+    _check(load().emx_allatom_backmap(_ptr(xyz0), stride, n, A, _ptr(quads), _ptr(far_mask), J, _ptr(targets), targets.stride(0) if J else 0,
+                                      _ptr(out), _stream()), "emx_allatom_backmap")
 
 
 def backbone_features(xyz, distances, angles, dihedrals):

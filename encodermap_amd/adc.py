@@ -179,12 +179,27 @@ class AngleDihedralCartesianEncoderMap(Autoencoder):
         return out if len(out) > 1 else out[0]
 
     def generate(self, points: np.ndarray, top=None, backend=None, progbar=None) -> np.ndarray:
-        """Back-maps latent points to backbone (central) Cartesians [n, A, 3]: decoded dihedrals (and angles when they are
-        learned, the data-set mean angles otherwise) with the data-set mean bond lengths.  Building MDTraj/MDAnalysis
-        objects from a topology (``top``) is out of scope (autoencoder.py:2467-2576)."""
-        if top is not None:
-            raise NotImplementedError("back-mapping onto a topology needs mdtraj/MDAnalysis (out of scope); the Cartesians are returned as an array")
+        """Back-maps latent points to Cartesians (autoencoder.py:2467-2576).
+
+        ``top=None``: backbone (central) Cartesians [n, A, 3] from the decoded dihedrals (and angles when they are learned,
+        the data-set mean angles otherwise) with the data-set mean bond lengths.
+        ``top=AllAtomTopology``: all-atom conformations [n, A_all, 3]: the template frame with every central (and
+        side-chain) torsion set to the decoded value, as ``mdtraj_backmapping`` does (misc/backmapping.py:1060-1787).
+        Building MDTraj/MDAnalysis objects from topology files is out of scope; arrays are returned."""
         out = self._engine.decode(np.asarray(points, np.float32))
+        if top is not None:
+            from .backmapping import AllAtomTopology
+
+            if not isinstance(top, AllAtomTopology):
+                raise ValueError(f"Type of argument `top` must be AllAtomTopology (topology files need mdtraj/MDAnalysis: out of scope). "
+                                 f"You provided {type(top)}.")
+            if len(out) == 1:
+                dihedrals, side = out[0], None
+            elif len(out) == 2:
+                dihedrals, side = out[1], None
+            else:
+                dihedrals, side = out[1], out[2]
+            return top.backmap(dihedrals, side if top.n_side else None, device=str(self._engine.device))
         d = self.inp_CV_data
         if self.p.use_backbone_angles:
             angles, dihedrals = out[0], out[1]

@@ -446,6 +446,79 @@ __global__ __launch_bounds__(NT) void featurize_kernel(const float* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// All-atom back-mapping: set every torsion of every frame to its target by rotating the
+// atoms on the far side of the torsion's central bond -- the serial loops of encodermap/misc/backmapping.py:1668-1690
+// (central dihedrals) and :1722-1745 (side chains), whose numba variant is `parallel_rotation_application` :383-405.
+// The torsions of one frame depend on each other (each rotation moves the atoms later torsions are measured on), the
+// frames do not: ONE WAVE PER FRAME, the frame in LDS, torsion after torsion.  The far sides arrive as a lane-major bit
+// table, far_mask[j][w][lane] bit k <-> atom (32 w + k) 64 + lane: one coalesced 256-byte load per torsion and wave
+// (requested one torsion ahead), no index lists, and lane l only ever touches atoms l, l + 64, ... of the LDS frame.
+//   current = atan2(|b2| b1.(b2 x b3), (b1 x b2).(b2 x b3))                      misc/rotate.py:547-581 (its sin / cos only)
+//   p' = pivot + R (p - pivot),  R = cos a I + (1 - cos a) d d^T + sin a [d]_x   transformations.rotation_matrix, as
+//   called at backmapping.py:1683-1684 with a = target - current, d = unit(x[q2] - x[q1]), pivot = x[q1]
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AA_NT = 64;
+
+__global__ __launch_bounds__(AA_NT) void allatom_rotate_kernel(const float* __restrict__ tmpl, long tmpl_stride, int A,
+                                                               const int* __restrict__ quads, const unsigned* __restrict__ far_mask, int W,
+                                                               int J, const float* __restrict__ targets, long ldt, float* __restrict__ out) {
+  extern __shared__ float fr[];   // [A][3]
+  const int lane = threadIdx.x;
+  const long f = blockIdx.x;
+  const float* __restrict__ src = tmpl + f * tmpl_stride;
+  for (int e = lane; e < 3 * A; e += AA_NT) fr[e] = src[e];
+  __syncthreads();
+  const float* __restrict__ tg = targets + f * ldt;
+  const unsigned* __restrict__ mrow = far_mask + lane;
+  __shared__ float tsin[AA_NT], tcos[AA_NT];   // sin / cos of the next 64 targets, one per lane
+  unsigned m_next = J > 0 ? mrow[0] : 0u;
+  for (int j = 0; j < J; ++j) {
+    if ((j & (AA_NT - 1)) == 0) {
+      float s_, c_;
+      emx::sincos_bounded(tg[min(j + lane, J - 1)], &s_, &c_);
+      tsin[lane] = s_;
+      tcos[lane] = c_;
+      __syncthreads();
+    }
+    const unsigned m0 = m_next;
+    m_next = mrow[(long)min(j + 1, J - 1) * W * AA_NT];
+    const float st = tsin[j & (AA_NT - 1)], ct = tcos[j & (AA_NT - 1)];
+    const int q0 = quads[4 * j], q1 = quads[4 * j + 1], q2 = quads[4 * j + 2], q3 = quads[4 * j + 3];
+    const V3 p0 = ld3(fr + 3 * q0), p1 = ld3(fr + 3 * q1), p2 = ld3(fr + 3 * q2), p3 = ld3(fr + 3 * q3);
+    const V3 b1 = p1 - p0, b2 = p2 - p1, b3 = p3 - p2;
+    const V3 c1 = cross(b2, b3), c2 = cross(b1, b2);
+    const float l2 = dot(b2, b2);
+    // current = atan2(y, x) is never formed: only sin / cos of (target - current) are needed, and
+    // (cos, sin)(current) = (x, y) / hypot(x, y)   [atan2(0, 0) = 0]
+    const float y = dot(b1, c1) * sqrtf(l2), x = dot(c1, c2);
+    const float h2 = fmaf(x, x, y * y);
+    const float rh = rsqrtf(h2);
+    const float cc = h2 > 0.f ? x * rh : 1.f, sc = h2 > 0.f ? y * rh : 0.f;
+    const float sa = fmaf(st, cc, -ct * sc), ca = fmaf(ct, cc, st * sc);
+    const V3 d = rsqrtf(l2) * b2;
+    const float oc = 1.f - ca;
+    // rows of R
+    const V3 r0{fmaf(oc * d.x, d.x, ca), fmaf(oc * d.x, d.y, -sa * d.z), fmaf(oc * d.x, d.z, sa * d.y)};
+    const V3 r1{fmaf(oc * d.y, d.x, sa * d.z), fmaf(oc * d.y, d.y, ca), fmaf(oc * d.y, d.z, -sa * d.x)};
+    const V3 r2{fmaf(oc * d.z, d.x, -sa * d.y), fmaf(oc * d.z, d.y, sa * d.x), fmaf(oc * d.z, d.z, ca)};
+    for (int w = 0; w < W; ++w) {
+      unsigned m = w == 0 ? m0 : mrow[((long)j * W + w) * AA_NT];
+      const int base = w * 32 * AA_NT + lane;
+      while (m) {
+        const int k = __builtin_ctz(m);
+        m &= m - 1;
+        float* a = fr + 3 * (base + k * AA_NT);
+        const V3 v = ld3(a) - p1;
+        st3(a, V3{p1.x + dot(r0, v), p1.y + dot(r1, v), p1.z + dot(r2, v)});
+      }
+    }
+    __syncthreads();
+  }
+  float* __restrict__ dst = out + f * (long)A * 3;
+  for (int e = lane; e < 3 * A; e += AA_NT) dst[e] = fr[e];
+}
+
 __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, float b, float c, float* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   float sc = c;
@@ -699,6 +772,21 @@ int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, 
   hipLaunchKernelGGL(featurize_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, xyz, (long)N, A, distances, angles,
                      dihedrals);
   return emx::check_launch("featurize_kernel");
+}
+
+int emx_allatom_mask_words(int A) { return A > 0 ? ((A + 2047) / 2048) * 64 : 0; }
+
+int emx_allatom_backmap(const float* xyz0, int64_t frame_stride, int64_t n_frames, int A, const int32_t* quads, const uint32_t* far_mask,
+                        int J, const float* targets, int64_t ldt, float* out, emx_stream_t stream) {
+  EMX_REQUIRE(xyz0 && out && n_frames > 0 && A >= 4 && J >= 0, "emx_allatom_backmap: bad arguments");
+  EMX_REQUIRE(J == 0 || (quads && far_mask && targets && ldt >= J), "emx_allatom_backmap: %d torsions without their tables", J);
+  EMX_REQUIRE(frame_stride == 0 || frame_stride >= (int64_t)3 * A, "emx_allatom_backmap: frame stride %lld < 3 A", (long long)frame_stride);
+  const size_t lds = (size_t)3 * A * sizeof(float);
+  if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_allatom_backmap: %d atoms do not fit the LDS frame buffer", A);
+  EMX_REQUIRE(n_frames <= 0x7fffffffLL, "emx_allatom_backmap: too many frames for one launch");
+  hipLaunchKernelGGL(allatom_rotate_kernel, dim3((unsigned)n_frames), dim3(AA_NT), lds, (hipStream_t)stream, xyz0, (long)frame_stride, A, quads,
+                     far_mask, (A + 2047) / 2048, J, targets, (long)ldt, out);
+  return emx::check_launch("allatom_rotate_kernel");
 }
 
 int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream) {

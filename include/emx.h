@@ -398,6 +398,23 @@ int emx_metric_tick(const int64_t* counts, const float* rmsd, int B, float* clas
 int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, float* angles, float* dihedrals,
                           emx_stream_t stream);
 
+/* All-atom back-mapping: every frame starts as a copy of xyz0 (frame_stride 0: one template
+ * frame for all, as encodermap/misc/backmapping.py:1607-1613 joins copies of frame 0; otherwise frame f starts from
+ * xyz0 + f * frame_stride) and has its torsions set one after the other: for j = 0 .. J-1 the atoms on the far side of the
+ * bond quads[j][1] - quads[j][2] are rotated about that bond by targets[f][j] minus the current dihedral of quads[j]
+ * (rad; backmapping.py:1668-1690 central dihedrals, :1722-1745 side-chain dihedrals -- the caller lists them after the
+ * central ones; numba variant `parallel_rotation_application` :383-405).
+ *   quads    int32 [J, 4]                     atom indices of each torsion
+ *   far_mask uint32 [J, W, 64], W = ceil(A / 2048) (W * 64 = emx_allatom_mask_words(A)): bit k of far_mask[j][w][l] is set
+ *            iff atom (32 w + k) * 64 + l lies on the far side of torsion j (the side of quads[j][2]; the reference finds it
+ *            by cutting the bond graph, misc/rotate.py:409-511)
+ *   targets  float [n_frames, ldt >= J]       requested dihedrals, rad
+ *   out      float [n_frames, A, 3]
+ * A is limited to 5461 atoms (the frame lives in LDS). */
+int emx_allatom_mask_words(int A);
+int emx_allatom_backmap(const float* xyz0, int64_t frame_stride, int64_t n_frames, int A, const int32_t* quads, const uint32_t* far_mask,
+                        int J, const float* targets, int64_t ldt, float* out, emx_stream_t stream);
+
 /* soft start of the cartesian cost (callbacks/callbacks.py:584-606) evaluated on the device from the step counter:
  * *out = 0 (t < a), c (t - a)/(b - a) (a <= t <= b), c (t > b); a < 0 -> constant c.   t = *step */
 int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream);

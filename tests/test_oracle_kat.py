@@ -332,3 +332,65 @@ def test_metric_known_answers():
     w = np.tile(M.WEIGHTS, 10)
     assert M.kabsch_weighted_rmsd(P, P @ Rm.T + 3.0, w) < 1e-6
     assert M.kabsch_weighted_rmsd(P, P * np.array([1.0, 1.0, -1.0]), w) > 1e-2
+
+
+# ---- all-atom back-mapping ----------------------------------------------------------
+def test_rotation_matrix_published_known_answers():
+    """``transformations.rotation_matrix`` (third-party, un-vendored; called at encodermap/misc/backmapping.py:1683): the
+    known answers of that package's own docstring."""
+    import math
+
+    from oracle import allatom_ops as O
+
+    R = O.rotation_matrix(math.pi / 2, [0, 0, 1], [1, 0, 0])
+    assert np.allclose(R.dot([0, 0, 0, 1]), [1, -1, 0, 1])
+    rng = np.random.default_rng(0)
+    angle = (rng.random() - 0.5) * 2 * math.pi
+    direc, point = rng.random(3) - 0.5, rng.random(3) - 0.5
+    assert np.allclose(O.rotation_matrix(angle, direc, point), O.rotation_matrix(angle - 2 * math.pi, direc, point))
+    assert np.allclose(O.rotation_matrix(angle, direc, point), O.rotation_matrix(-angle, -direc, point))
+    assert np.allclose(np.identity(4), O.rotation_matrix(2 * math.pi, direc))
+    assert np.allclose(2.0, np.trace(O.rotation_matrix(math.pi / 2, direc, point)))
+
+
+def test_allatom_dihedral_on_the_known_angles_frames():
+    """tests/test_backmapping_em1_em2.py:2096-2113 (every dihedral of known_angles lies in (-pi, pi]) and the committed
+    known_angles dihedral table (tests/data/known_angles_dihedrals.npy, degrees)."""
+    import json
+    import os
+
+    from oracle import allatom_ops as O
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat_tables.json")) as f:
+        G = json.load(f)
+    xyz = np.array(G["known_angles_xyz_angstrom"], np.float64)
+    want = np.array(G["known_angles_dihedrals"], np.float64).reshape(-1)
+    for frame, w in zip(xyz, want):
+        d = O.dihedral(frame, [0, 1, 2, 3])
+        assert -np.pi < d <= np.pi
+        dd = abs(np.rad2deg(d) - w) % 360
+        assert min(dd, 360 - dd) < 0.05
+
+
+def test_allatom_oracle_realises_the_requested_dihedrals():
+    """The reference's ``verify_every_rotation`` check (backmapping.py:1687-1690) on the oracle itself, plus the far-side
+    rule of misc/rotate.py:483-497 (the far side holds the bond's second atom, never its first)."""
+    from molecules import dihedrals_of, random_molecule
+    from oracle import allatom_ops as O
+
+    xyz, bonds, cq, sq = random_molecule(14, 2)
+    far_c = [O.far_side(len(xyz), bonds, q[1:3]) for q in cq]
+    far_s = [O.far_side(len(xyz), bonds, q[1:3]) for q in sq]
+    for q, f in zip(np.concatenate([cq, sq]), far_c + far_s):
+        assert q[2] in f and q[3] in f and q[1] not in f and q[0] not in f
+    rng = np.random.default_rng(3)
+    d = rng.uniform(-np.pi, np.pi, (3, len(cq))).astype(np.float32)
+    s = rng.uniform(-np.pi, np.pi, (3, len(sq))).astype(np.float32)
+    out = O.allatom_backmap(xyz, cq, far_c, d, sq, far_s, s)
+    w = lambda x: (x + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(w(dihedrals_of(out, cq) - d)).max() < 1e-3 and np.abs(w(dihedrals_of(out, sq) - s)).max() < 1e-3
+    with pytest.raises(Exception, match="not part of the bond graph"):
+        O.far_side(len(xyz), bonds, [cq[0][0], cq[0][3]])
+    ring = np.concatenate([bonds, [[cq[0][0], cq[0][3]]]])
+    with pytest.raises(Exception, match="components"):
+        O.far_side(len(xyz), ring, cq[0][1:3])
