@@ -99,14 +99,34 @@ struct UnitLoad {       // what a request burst needs to fetch a unit's package 
   int rstride;          // row stride of aux: 0 = one broadcast row (a bias), n = one value per batch row (h rows)
   const float* aux;     // epilogue operand: the layer's bias (forward), h rows for the activation derivative (backward)
 };
-struct UnitExec {       // what the MFMA phase and the epilogue need (32 B)
+struct UnitExec {       // what the MFMA phase and the epilogue need (48 B)
   int kq_cols;          // kq | valid output columns of this pass << 8
-  int src_off;          // column offset of the chunk in the source LDS image
+  int src_off;          // LDS float offset of the chunk's first column in row 0 of the source image
   int dst_off;          // column offset of the pass in the destination image and in the output rows
   int flags;            // U_* | S_* << 8
   float* out;           // [*, n] result rows (h_l forward; delta_{l-1} or dbelow backward)
   int n;
-  int imgs;             // LDS images: source | destination << 8 | (image of h for the activation derivative + 1) << 16 (0: from aux)
+  int src_pitch;        // row pitch of the source image
+  int dst_base, dst_pitch;   // destination image: LDS float offset of row 0, row pitch
+  int h_base1, h_pitch;      // image of h for the activation derivative: offset + 1 (0: h comes through aux), row pitch
+};
+// LDS images: R rows each, every image as wide as the widest layer it ever holds (whole 128-column passes + 4: the
+// passes are written whole, and +4 keeps b128 rows conflict-free).  Image 0 starts at offset 0 and receives the row block.
+constexpr int MAXIMG = 12;
+struct ImgGeom {
+  int n = 0, width[MAXIMG] = {}, pitch[MAXIMG] = {}, base[MAXIMG] = {}, total = 0;
+  void need(int i, int w) {
+    n = std::max(n, i + 1);
+    width[i] = std::max(width[i], w);
+  }
+  void layout() {
+    total = 0;
+    for (int i = 0; i < n; ++i) {
+      pitch[i] = ((std::max(width[i], 1) + 127) / 128) * 128 + 4;
+      base[i] = total;
+      total += R * pitch[i];
+    }
+  }
 };
 enum { U_FIRST = 1, U_LAST = 2, U_LAYER_END = 4, U_BWD = 8 };
 enum { S_ACT = 1, S_JOIN = 2 };
@@ -115,7 +135,7 @@ struct ChainArgs {
   UnitLoad ul[MAXU];
   UnitExec ux[MAXU];
   int nu;
-  int pitch;
+  int pitch;            // row pitch of image 0
   const float* mbase;   // operand store
   const float* in;      // forward: input rows; backward: d loss / d h_top
   int ld_in, in_cols;
@@ -131,11 +151,11 @@ struct ChainArgs {
   // forward only, optional auto cost on the rows of the last layer (replaces emx_periodic_cost_fwd_bwd behind it):
   // cost.dY receives d cost / d output, cost.ws[workgroup] the workgroup's share of the cost
   CostArgs cost;
-  int n_img;            // LDS images of R x pitch floats (2 ping-pong images; fused mode: one per forward layer + 2)
-  int cost_img;         // image that holds the rows the cost is evaluated on
+  int img_floats;       // floats of all LDS images (2 ping-pong images; fused mode: one per forward layer + 2)
+  int cost_base, cost_pitch;   // image that holds the rows the cost is evaluated on
   // fused mode (forward, cost, backward through the upper layers in one launch): the cost runs behind unit cost_at and
-  // leaves d cost / d output in image top_img, the source of the first backward unit
-  int cost_at, top_img;
+  // leaves d cost / d output in the image at top_base, the source of the first backward unit
+  int cost_at, top_base, top_pitch;
 };
 
 #ifdef EMX_CHAIN_TIMING   // in-kernel timeline (tools/abl_timing.py); stamps go to LDS so that they do not touch vmcnt
@@ -166,10 +186,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int n0 = wave * 16;
   const int r0 = a.row0 + blockIdx.x * R;
   const int pitch = a.pitch;
-  const int img = R * pitch;
   const int nu = a.nu;
-  float* lat = lds + a.n_img * img;   // [R][join_n] rows joined into one layer's dh (backward)
-  float* tgt = lds + a.n_img * img;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
+  float* lat = lds + a.img_floats;   // [R][join_n] rows joined into one layer's dh (backward)
+  float* tgt = lds + a.img_floats;   // [R][cost.n] target rows of the auto cost (forward), fetched with the row block
   constexpr int NE = MODE == CHAIN_BWD ? 4 : 1;   // epilogue operands per lane: h values of 4 rows (backward) or one bias (the fused
                                                   // launch's backward units take h from the LDS images)
   TSTAMP(0);
@@ -264,7 +283,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   float tv[4] = {0.f, 0.f, 0.f, 0.f};
   const bool tgt_global = !BWD && a.cost.dY != nullptr;
   if (MODE == CHAIN_FUSED) {   // the image that receives d cost / d output is the A operand of the first backward unit: zero padded
-    for (int el = tid; el < img; el += NTC) lds[a.top_img * img + el] = 0.f;
+    for (int el = tid; el < R * a.top_pitch; el += NTC) lds[a.top_base + el] = 0.f;
   }
   auto target_load = [&](int c, float (&v)[4]) {
 #pragma unroll
@@ -293,10 +312,10 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const int row = tid >> 5, l32 = tid & 31;
     const bool rok = r0 + row < a.row_end;
     const long grow = (long)min(r0 + row, a.row_end - 1);
-    const float* yrow = lds + a.cost_img * img + row * pitch;
+    const float* yrow = lds + a.cost_base + row * a.cost_pitch;
     const float* trow = tgt + row * cst.n;
     float* drow = rok ? cst.dY + grow * cst.ldy : nullptr;
-    float* lrow = (to_lds && rok) ? lds + a.top_img * img + row * pitch : nullptr;   // rows beyond the block stay zero
+    float* lrow = (to_lds && rok) ? lds + a.top_base + row * a.top_pitch : nullptr;   // rows beyond the block stay zero
     float lsum = 0.f;
     if (cst.variant == EMX_MEAN_NORM) {
       float ss = 0.f;
@@ -364,7 +383,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     request_epi(Lq, e[r]);
     // beyond the last unit the pieces degenerate to one shared line
     const float* __restrict__ pp = req ? piece_ptr(Lq) : a.mbase;
-    const float* src = lds + (X.imgs & 0xff) * img + X.src_off + m * pitch + 4 * g;
+    const float* src = lds + X.src_off + m * X.src_pitch + 4 * g;
     if (run && (X.flags & U_FIRST)) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     if (run) TSTAMP(3 + 5 * ui);
     f32x4 av = *reinterpret_cast<const f32x4*>(src);   // A pieces are read one group ahead (any in-image address is readable)
@@ -413,8 +432,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       const int col = X.dst_off + n0 + m;
       const bool cok = n0 + m < cols;
       const bool ubwd = MODE == CHAIN_BWD || (MODE == CHAIN_FUSED && (X.flags & U_BWD));
-      const int himg = (X.imgs >> 16) & 0xff;   // 0: activations from the epilogue operands, else LDS image himg - 1
-      float* dst = lds + ((X.imgs >> 8) & 0xff) * img + col;
+      const int hb1 = X.h_base1;   // 0: activations from the epilogue operands, else from the LDS image at hb1 - 1
+      float* dst = lds + X.dst_base + col;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
         const int row = 4 * g + reg;
@@ -425,12 +444,12 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
         } else {
           if (sflags & S_JOIN) v += lat[row * X.n + min(col, X.n - 1)];
           if (sflags & S_ACT) {
-            const float hv = (MODE == CHAIN_FUSED && himg) ? lds[(himg - 1) * img + row * pitch + col] : e[rx][reg % NE];
+            const float hv = (MODE == CHAIN_FUSED && hb1) ? lds[hb1 - 1 + row * X.h_pitch + col] : e[rx][reg % NE];
             v *= fmaf(-hv, hv, 1.f);
           }
         }
         v = (cok && r0 + row < a.row_end) ? v : 0.f;
-        dst[row * pitch] = v;
+        dst[row * X.dst_pitch] = v;
         pend[reg] = v;
       }
       pend_base = X.out + (long)r0 * X.n;
@@ -698,12 +717,6 @@ int fill_dev(const emx_mlp_desc* desc, float* params, float* const* h, float* co
   return EMX_OK;
 }
 
-int pitch_for(const emx_mlp_desc* desc, int l0, int l1) {
-  int w = 0;
-  for (int l = l0; l <= l1; ++l) w = std::max(w, desc->width[l]);
-  return ((w + 127) / 128) * 128 + 4;   // whole 128-column passes are written; +4 keeps b128 rows conflict-free
-}
-
 int set_lds(const void* fn, size_t bytes, const char* who) {
   if (bytes > 160 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: layer width too large for the LDS row block (%zu bytes)", who, bytes);
   if (bytes > 64 * 1024) {
@@ -730,8 +743,12 @@ long mirror_begin(const emx_mlp_desc* desc, int l) {
 // Appends the units of one GEMM: `kred` reduction indices, `nout` output columns, operand block at float offset `op`;
 // `aux` with row stride `rstride` (0: a bias row) feeds the epilogue; LDS images src -> dst, himg + 1 = image of the
 // activations for the derivative (0: they come through aux).
-int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, int rstride, float* out, int sflags, int uflags, int src_img,
-              int dst_img, int himg1, const char* who) {
+int add_units(ChainArgs& a, ImgGeom& G, long op, int kred, int nout, const float* aux, int rstride, float* out, int sflags, int uflags,
+              int src_img, int dst_img, int himg1, const char* who) {
+  if (std::max(std::max(src_img, dst_img), himg1 - 1) >= MAXIMG) return emx::fail(EMX_EUNSUPPORTED, "%s: more than %d LDS images", who, MAXIMG);
+  G.need(src_img, kred);
+  G.need(dst_img, nout);
+  if (himg1) G.need(himg1 - 1, nout);
   const int Q = (kred + 15) / 16, T = (nout + 15) / 16;
   const int P = (nout + 127) / 128, Cn = (kred + 127) / 128;
   for (int p = 0; p < P; ++p)
@@ -743,10 +760,27 @@ int add_units(ChainArgs& a, long op, int kred, int nout, const float* aux, int r
       a.ul[a.nu] = UnitLoad{(int)off, Q, kq | (std::min(8, T - 8 * p) << 8), 128 * p, nout, rstride, aux};
       a.ux[a.nu] = UnitExec{kq | (std::min(128, nout - 128 * p) << 8), 128 * c, 128 * p,
                             (c == 0 ? U_FIRST : 0) | (c == Cn - 1 ? U_LAST : 0) | (c == Cn - 1 && p == P - 1 ? U_LAYER_END : 0) | uflags | (sflags << 8), out,
-                            nout, src_img | (dst_img << 8) | (himg1 << 16)};
+                            nout, src_img, dst_img, 0, himg1, 0};   // image ids until finish_images() turns them into offsets and pitches
       ++a.nu;
     }
   return EMX_OK;
+}
+
+// Lays the images out and turns the image ids of the unit records into LDS offsets and row pitches.
+void finish_images(ChainArgs& a, ImgGeom& G) {
+  G.layout();
+  for (int u = 0; u < std::max(a.nu, 1); ++u) {
+    UnitExec& x = a.ux[u];
+    const int si = x.src_pitch, di = x.dst_base, hi1 = x.h_base1;
+    x.src_off += G.base[si];
+    x.src_pitch = G.pitch[si];
+    x.dst_base = G.base[di];
+    x.dst_pitch = G.pitch[di];
+    x.h_base1 = hi1 ? G.base[hi1 - 1] + 1 : 0;
+    x.h_pitch = hi1 ? G.pitch[hi1 - 1] : 0;
+  }
+  a.pitch = G.pitch[0];
+  a.img_floats = G.total;
 }
 
 }  // namespace
@@ -779,15 +813,19 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "emx_mlp_forward: bad layer range");
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "emx_mlp_forward: bad rows / stride");
   ChainArgs a{};
+  ImgGeom G;
   for (int l = layer_begin; l < layer_end; ++l) {
     EMX_REQUIRE(h[l], "emx_mlp_forward: activation buffer of layer %d is null", l);
     const int st = l - layer_begin;
-    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0,
+    rc = add_units(a, G, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0,
                    st & 1, (st + 1) & 1, 0, "emx_mlp_forward");
     if (rc) return rc;
   }
-  a.n_img = 2;
-  a.cost_img = (layer_end - layer_begin) & 1;
+  G.need(1, 1);
+  finish_images(a, G);
+  const int cimg = (layer_end - layer_begin) & 1;
+  a.cost_base = G.base[cimg];
+  a.cost_pitch = G.pitch[cimg];
   if (cost) {
     const int wout = desc->width[layer_end];
     EMX_REQUIRE(cost->target && cost->dY && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0, "emx_mlp_forward: incomplete cost description");
@@ -801,14 +839,13 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
     fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
                       cost->variant, cost->coef);
   }
-  a.pitch = pitch_for(desc, layer_begin, layer_end);
   a.mbase = mirror;
   a.in = in;
   a.ld_in = ld_in;
   a.in_cols = desc->width[layer_begin];
   a.row0 = row_begin;
   a.row_end = row_end;
-  const size_t lds = ((size_t)2 * R * a.pitch + (cost ? (size_t)R * cost->n : 0)) * sizeof(float);
+  const size_t lds = ((size_t)a.img_floats + (cost ? (size_t)R * cost->n : 0)) * sizeof(float);
   rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_FWD>), lds, "emx_mlp_forward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
@@ -831,6 +868,7 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "emx_mlp_backward: bad rows / stride");
   EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "emx_mlp_backward: layer_add outside the layer range");
   ChainArgs a{};
+  ImgGeom G;
   const bool join = dadd || latent;
   if (latent) {
     a.lg = *latent;
@@ -852,25 +890,26 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
     const long op = mirror_begin(desc, l) + operand_block(Kin, N);
     const int st = top - l;
     if (l > layer_begin)
-      rc = add_units(a, op, N, Kin, desc->act[l - 1] ? h[l - 1] : delta[l - 1], Kin, delta[l - 1], sflags(l - 1), U_BWD, st & 1, (st + 1) & 1, 0,
+      rc = add_units(a, G, op, N, Kin, desc->act[l - 1] ? h[l - 1] : delta[l - 1], Kin, delta[l - 1], sflags(l - 1), U_BWD, st & 1, (st + 1) & 1, 0,
                      "emx_mlp_backward");
     else
-      rc = add_units(a, op, N, Kin, dbelow, Kin, dbelow, 0, U_BWD, st & 1, (st + 1) & 1, 0, "emx_mlp_backward");
+      rc = add_units(a, G, op, N, Kin, dbelow, Kin, dbelow, 0, U_BWD, st & 1, (st + 1) & 1, 0, "emx_mlp_backward");
     if (rc) return rc;
   }
   if (a.nu == 0) {   // a one-layer range without dbelow: only delta_top is formed; the kernel still wants one readable record
     a.ul[0] = UnitLoad{0, 1, 1 | (1 << 8), 0, 1, 0, mirror};
-    a.ux[0] = UnitExec{1 | (1 << 8), 0, 0, 0, delta[top], 1, 0 | (1 << 8)};
+    a.ux[0] = UnitExec{1 | (1 << 8), 0, 0, 0, delta[top], 1, 0, 1, 0, 0, 0};
   }
-  a.n_img = 2;
-  a.pitch = pitch_for(desc, layer_begin, layer_end);
+  G.need(0, desc->width[layer_end]);   // the row block of dtop
+  G.need(1, 1);
+  finish_images(a, G);
   a.mbase = mirror;
   a.in = dtop;
   a.ld_in = ld_top;
   a.in_cols = desc->width[layer_end];
   a.row0 = row_begin;
   a.row_end = row_end;
-  const size_t lds = ((size_t)2 * R * a.pitch + (size_t)R * a.join_n) * sizeof(float);
+  const size_t lds = ((size_t)a.img_floats + (size_t)R * a.join_n) * sizeof(float);
   rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_BWD>), lds, "emx_mlp_backward");
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
@@ -897,18 +936,20 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
               "%s: cost column window outside the output row", who);
   EMX_REQUIRE(cost->dY == delta[top] || cost->dY == nullptr, "%s: d cost / d output is delta[layer_end - 1]; pass that buffer (or NULL) as cost->dY", who);
   ChainArgs a{};
+  ImgGeom G;
   const int nf = layer_end - layer_begin;           // forward layers: images 0 .. nf (image i = input of forward layer i)
   for (int l = layer_begin; l < layer_end; ++l) {
     EMX_REQUIRE(h[l], "%s: activation buffer of layer %d is null", who, l);
     const int st = l - layer_begin;
-    rc = add_units(a, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0, st,
+    rc = add_units(a, G, mirror_begin(desc, l), desc->width[l], desc->width[l + 1], params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, 0, st,
                    st + 1, 0, who);
     if (rc) return rc;
   }
   a.cost_at = a.nu - 1;
-  a.cost_img = nf;
-  a.top_img = nf + 1;                                // d cost / d output; the backward units ping-pong between nf + 1 and nf + 2
-  a.n_img = nf + 3;
+  const int cost_img = nf, top_img = nf + 1;         // d cost / d output; the backward units ping-pong between nf + 1 and nf + 2
+  EMX_REQUIRE(nf + 3 <= MAXIMG, "%s: too many layers for one launch", who);
+  G.need(top_img, wout);
+  G.need(nf + 2, 1);
   for (int l = top; l >= bwd_begin; --l) {
     EMX_REQUIRE(delta[l], "%s: delta buffer of layer %d is null", who, l);
     const int Kin = desc->width[l], N = desc->width[l + 1];
@@ -917,10 +958,10 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
     if (l > bwd_begin) {
       // delta_{l-1} = (delta_l W_l^T) * act'(h_{l-1}); h_{l-1} is still in LDS image (l - 1 - layer_begin) + 1
       // (the epilogue operand slot of these units is not used: any readable row, here the head of the operand store)
-      rc = add_units(a, op, N, Kin, mirror, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, U_BWD, src, dst, (l - layer_begin) + 1, who);
+      rc = add_units(a, G, op, N, Kin, mirror, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, U_BWD, src, dst, (l - layer_begin) + 1, who);
     } else {
       if (!dbelow) break;
-      rc = add_units(a, op, N, Kin, mirror, 0, dbelow, 0, U_BWD, src, dst, 0, who);
+      rc = add_units(a, G, op, N, Kin, mirror, 0, dbelow, 0, U_BWD, src, dst, 0, who);
     }
     if (rc) return rc;
   }
@@ -929,14 +970,18 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
   a.cost.ws = cost->ws;
   fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
                     cost->variant, cost->coef);
-  a.pitch = pitch_for(desc, layer_begin, layer_end);
+  finish_images(a, G);
+  a.cost_base = G.base[cost_img];
+  a.cost_pitch = G.pitch[cost_img];
+  a.top_base = G.base[top_img];
+  a.top_pitch = G.pitch[top_img];
   a.mbase = mirror;
   a.in = in;
   a.ld_in = ld_in;
   a.in_cols = desc->width[layer_begin];
   a.row0 = row_begin;
   a.row_end = row_end;
-  const size_t lds = ((size_t)a.n_img * R * a.pitch + (size_t)R * cost->n) * sizeof(float);
+  const size_t lds = ((size_t)a.img_floats + (size_t)R * cost->n) * sizeof(float);
   rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<CHAIN_FUSED>), lds, who);
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;

@@ -113,14 +113,30 @@ __device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, f
   }
 }
 
+__device__ __forceinline__ float abs_minus(float x, float h) {   // |x| - h
+  float r;
+  asm("v_sub_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(h));
+  return r;
+}
+__device__ __forceinline__ float minus_abs(float h, float x) {   // h - |x|
+  float r;
+  asm("v_sub_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+
 template <bool PERIODIC>
 __device__ __forceinline__ float acc4(const float4& a, const float4& b, float acc, float period) {
   if constexpr (PERIODIC) {
-    float d0 = fabsf(a.x - b.x), d1 = fabsf(a.y - b.y), d2 = fabsf(a.z - b.z), d3 = fabsf(a.w - b.w);
-    d0 = fminf(d0, period - d0);
-    d1 = fminf(d1, period - d1);
-    d2 = fminf(d2, period - d2);
-    d3 = fminf(d3, period - d3);
+    // min(|d|, p - |d|) = p/2 - | |d| - p/2 |: three subtractions, two of them with a |.| source modifier, instead of two
+    // and a v_min_f32, which issues at half the rate of v_sub_f32 on gfx950 (profiles/r01_valu_issue_rates.txt).  Written
+    // as instructions: left to itself the compiler pairs the subtractions into v_pk_add_f32, which has no source
+    // modifiers, and spends a v_and_b32 per |.|.
+    const float h = 0.5f * period;
+    float d0 = abs_minus(a.x - b.x, h), d1 = abs_minus(a.y - b.y, h), d2 = abs_minus(a.z - b.z, h), d3 = abs_minus(a.w - b.w, h);
+    d0 = minus_abs(h, d0);
+    d1 = minus_abs(h, d1);
+    d2 = minus_abs(h, d2);
+    d3 = minus_abs(h, d3);
     acc = fmaf(d0, d0, acc);
     acc = fmaf(d1, d1, acc);
     acc = fmaf(d2, d2, acc);
@@ -834,11 +850,13 @@ void dispatch2(const SkArgs& a, int ntiles, bool periodic, bool fast, hipStream_
 }
 
 int pick_tile(int B, int nrows, bool gram) {
-  // the MFMA (Gram) tiles exist as 64x64 only; the VALU tiles: 128-tiles halve the LDS traffic per flop but
-  // quantise badly on 256 CUs when there are few of them
-  if (gram) return 64;
-  long pairs = (long)B * nrows;
-  return (pairs >= (long)8192 * 8192) ? 128 : 64;
+  // 64x64 everywhere.  The MFMA (Gram) tiles exist in that size only, and the VALU kernel's 128x128 instantiation (half the
+  // LDS traffic per pair-element) needs 256 VGPRs + 12 AGPRs: one wave per SIMD, where the VALU issues 0.15 instructions
+  // per clock instead of 0.35 at four waves -- measured at B = 8192, D = 512 periodic: 2.19 ms against 1.40 ms.
+  (void)B;
+  (void)nrows;
+  (void)gram;
+  return 64;
 }
 
 __global__ void pairwise_dist_kernel(const float* __restrict__ X, int B, int D, int ldx, float period, int periodic,
@@ -975,9 +993,8 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     }
     return emx::check_launch("sk_tile_mfma_kernel");
   }
-  if (pl.T == 128) {
-    if (a.L == 2) dispatch2<128, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
-    else dispatch2<128, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
+  if (pl.T != 64) {
+    return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_tiles: no %d x %d tile kernel", pl.T, pl.T);
   } else {
     if (a.L == 2) dispatch2<64, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
     else dispatch2<64, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);

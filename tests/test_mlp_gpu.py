@@ -197,7 +197,9 @@ def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
 @pytest.mark.gpu
 @pytest.mark.parametrize("periodicity,variant,D,B", [(float("inf"), "mean_square", 128, 4096), (2 * np.pi, "mean_abs", 10, 256),
                                                      (360.0, "mean_norm", 37, 100), (float("inf"), "mean_norm", 70, 50),
-                                                     (float("inf"), "mean_abs", 300, 40)])
+                                                     (float("inf"), "mean_abs", 300, 40),
+                                                     (2 * np.pi, "mean_abs", 512, 200),          # C4: 1024-wide ends
+                                                     (float("inf"), "mean_square", 1100, 40)])
 def test_forward_with_cost_equals_separate_kernels(L, periodicity, variant, D, B):
     """emx_mlp_forward_cost (dense layers + auto cost in one launch) against the two stand-alone entry points it
     replaces (emx_mlp_forward, emx_periodic_cost_fwd_bwd): same activations, same cost and the same gradient with

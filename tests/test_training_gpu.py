@@ -57,6 +57,13 @@ CASES = [
     ("norm_variant_small_net", dict(periodicity=INF, auto_cost_variant="mean_norm", n_neurons=[64, 3], activation_functions=["", "tanh", ""],
                                     batch_size=200, dist_sig_parameters=(2.0, 3, 6, 1, 2, 6)),
      lambda r: r.normal(0, 1, (2000, 7)).astype(np.float32)),
+    # C4's shape (BASELINE.json configs[3]): 512 periodic features -> 1024-wide input and output layers, at a batch the
+    # float64 oracle's [B, B, D] temporaries can hold
+    ("c4_shape_wide_periodic", dict(batch_size=192, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6)),
+     lambda r: r.uniform(-np.pi, np.pi, (1500, 512)).astype(np.float32)),
+    # C5's shape (configs[4]): 256 Euclidean features
+    ("c5_shape_euclid_256", dict(periodicity=INF, batch_size=384, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)),
+     lambda r: (r.normal(0, 4, (16, 256))[r.integers(0, 16, 4000)] + r.normal(0, 1, (4000, 256))).astype(np.float32)),
 ]
 
 
@@ -67,12 +74,27 @@ def test_encodermap_loss_trajectory(em, name, kw, maker):
     p = em.Parameters(n_steps=12, **kw)
     e, model, got, want, terms, want_terms = run_both(em, em.EncoderMap, p, data, 12)
     np.testing.assert_allclose(got, want, rtol=1e-4)
+    wide = name == "c4_shape_wide_periodic"
+    # The 300k-weight model of the C4 shape amplifies float32 rounding much faster than the small ones: the reference
+    # formulation itself, run in float32 instead of float64 on the CPU (oracle, same weights and batches), leaves the
+    # float64 auto cost by 1e-5 at step 3 and by 1e-4 .. 1e-3 from step 6 on.  So: tight over the first three steps (they
+    # pin forward, every gradient and the Adam update), the drift band afterwards.
     for k in ("auto", "reg", "center", "distance"):
-        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+        w = np.array([t[k] for t in want_terms])
+        np.testing.assert_allclose(terms[k][:3], w[:3], rtol=2e-5 if wide else 2e-4, atol=1e-9)
+        np.testing.assert_allclose(terms[k], w, rtol=3e-3 if wide else 2e-4, atol=1e-9)
     # weights after 12 Adam steps
     # (Adam normalises every element's update to ~lr, so an element whose gradient is at float32 rounding level can
     # legitimately move differently: require the bulk within 2e-5 and every element within a few percent of 12*lr)
-    for a, b in zip(e._engine.get_weights(), model.params):
+    if wide:
+        # the weights are compared where the trajectories still coincide, after the first update (after three steps the
+        # float32 run of the reference formulation is already 1.5e-3 / 39 % away from the float64 one in the decoder's
+        # 128x128 kernel; this engine 3.4e-4 / 14 %)
+        e3, model3 = run_both(em, em.EncoderMap, p, data, 1)[:2]
+        pairs = zip(e3._engine.get_weights(), model3.params)
+    else:
+        pairs = zip(e._engine.get_weights(), model.params)
+    for a, b in pairs:
         diff = np.abs(a - b.detach().numpy())
         assert (diff > 2e-5).mean() < 0.03 and diff.max() < 5e-4, (diff.max(), (diff > 2e-5).mean())
     # encode / decode / generate arrays, on identical weights (isolates the inference path from Adam's sensitivity)
