@@ -169,7 +169,8 @@ class SequentialEngine:
         self.split_ws = None
         if self._prefetch and not self.periodic and self.with_distance and self.p.distance_cost_scale is not None:
             self.split_ws = torch.zeros(_lib.sketchmap_split_bytes(B, self.D), dtype=torch.uint8, device=dev)
-        self.cost_ws = torch.zeros(_lib.mlp_row_blocks(self.re - self.rb), dtype=f32, device=dev)   # auto cost per row block (zero: no auto cost)
+        # auto cost per row block (zero: no auto cost); at least EMX_REDUCE_WS long for the stand-alone cost kernel's shares
+        self.cost_ws = torch.zeros(max(_lib.mlp_row_blocks(self.re - self.rb), _lib.EMX_REDUCE_WS), dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
         self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
@@ -209,6 +210,7 @@ class SequentialEngine:
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
     _fuse_decoder = os.environ.get("EMX_FUSE_DECODER", "1") != "0"   # forward + auto cost + decoder backward in one launch
     _fold_finish = os.environ.get("EMX_FOLD_FINISH", "1") != "0"     # scalar epilogue inside the weight-gradient launch
+    _cost_in_forward = True                                          # auto cost inside the forward launch (False: layers too wide)
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -241,11 +243,26 @@ class SequentialEngine:
             except _lib.EmxError:
                 self._fuse_decoder = False     # e.g. layers too wide for one LDS image per layer: two launches from now on
                 return self._forward()
+        if self._cost_in_forward or cost is None:
+            try:
+                if full:
+                    _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B, cost=cost)
+                else:
+                    _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
+                    _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
+                return False
+            except _lib.EmxError:
+                if cost is None:
+                    raise
+                self._cost_in_forward = False   # output rows too wide to keep their targets in LDS next to the images
+        # widest nets: plain forward launch, the auto cost as its own kernel (its workgroup shares land in cost_ws as well)
         if full:
-            _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B, cost=cost)
+            _lib.mlp_forward(self.plan, 0, n, self.xin, 0, self.B)
         else:
             _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
-            _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
+            _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
+        _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self.periodicity if self.periodic else INF,
+                                   p.auto_cost_variant, float(p.auto_cost_scale), self.rb, self.re, None, self.dY, self.cost_ws, B=self.B)
         return False
 
     def _use_sketchmap(self) -> bool:

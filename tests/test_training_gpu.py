@@ -228,3 +228,18 @@ def test_facade_defaults_and_errors(em, tmp_path):
     h = e5.train()
     assert [s for s, _ in seen] == [10, 20]
     assert seen[0][1] == pytest.approx(h.history["loss"][9])
+
+
+def test_widest_nets_fall_back_to_separate_launches(em):
+    """1000 periodic features (2000-wide input and output layers): the output rows no longer fit into LDS together with
+    their targets, so the engine runs the plain forward launch and the stand-alone cost kernel -- same numbers."""
+    rng = np.random.default_rng(5)
+    data = rng.uniform(-np.pi, np.pi, (400, 1000)).astype(np.float32)
+    p = em.Parameters(n_steps=3, batch_size=64, dist_sig_parameters=(40.0, 12, 6, 1, 2, 6))
+    e, model, got, want, terms, want_terms = run_both(em, em.EncoderMap, p, data, 3)
+    assert not e._engine._cost_in_forward and not e._engine._fuse_decoder
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=1e-4, atol=1e-9)
+    with pytest.raises(Exception, match="emx_mlp_forward: (layer width too large|layer range needs more than)"):   # loud beyond ~2400 columns
+        em.EncoderMap(em.Parameters(batch_size=32), rng.uniform(-3, 3, (64, 1300)).astype(np.float32), read_only=True).train()
