@@ -989,11 +989,21 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
   return emx::check_launch("mlp chain kernel (forward + cost + backward)");
 }
 
-int emx_mlp_wgrad_slices(int n_rows) { return std::max((n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS, 1); }
+// rows per slice: EMX_WGRAD_SLICE_ROWS, doubled until at most EMX_WGRAD_MAX_SLICES slices remain -- every slice costs a
+// write and a read of the whole gradient (partials), so their number must not grow with the batch
+static int wgrad_slice_rows(int n_rows) {
+  int r = EMX_WGRAD_SLICE_ROWS;
+  while ((long)r * EMX_WGRAD_MAX_SLICES < n_rows) r *= 2;
+  return r;
+}
+
+int emx_mlp_wgrad_slices(int n_rows) {
+  const int r = wgrad_slice_rows(n_rows);
+  return std::max((n_rows + r - 1) / r, 1);
+}
 
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows) {
-  int slices = (n_rows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
-  return (size_t)std::max(slices, 1) * (size_t)n_params;
+  return (size_t)emx_mlp_wgrad_slices(n_rows) * (size_t)n_params;
 }
 
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
@@ -1036,8 +1046,8 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   a.n_params = n_params;
   a.row0 = row_begin;
   a.row_end = row_end;
-  a.rows_per_slice = EMX_WGRAD_SLICE_ROWS;
-  const int slices = (nrows + EMX_WGRAD_SLICE_ROWS - 1) / EMX_WGRAD_SLICE_ROWS;
+  a.rows_per_slice = wgrad_slice_rows(nrows);
+  const int slices = emx_mlp_wgrad_slices(nrows);
   hipStream_t st = (hipStream_t)stream;
   static_assert(FIN_NT == NT, "the scalar epilogue shares the weight-gradient kernel's workgroup size");
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.has_fin, slices), dim3(NT), 0, st, a);

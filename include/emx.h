@@ -168,7 +168,8 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 /* description of the dense network (see K12 below); declared here because the optimizer keeps the operand store of the
  * dense-layer kernels current */
 #define EMX_MAX_LAYERS 8
-#define EMX_WGRAD_SLICE_ROWS 128
+#define EMX_WGRAD_SLICE_ROWS 128   /* rows per weight-gradient slice; doubled until ... */
+#define EMX_WGRAD_MAX_SLICES 32    /* ... at most this many slices remain (emx_mlp_wgrad_slices) */
 typedef struct {
   int n_layers;
   int width[EMX_MAX_LAYERS + 1];
@@ -334,7 +335,8 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
                      float* dbelow, int row_begin, int row_end, float* const* h, float* const* delta, emx_stream_t stream);
 /* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
  * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials
- * (EMX_WGRAD_SLICE_ROWS rows each) into ws, then a fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)
+ * (EMX_WGRAD_SLICE_ROWS rows each, more for batches beyond EMX_WGRAD_SLICE_ROWS * EMX_WGRAD_MAX_SLICES rows) into ws, then a
+ * fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)
  * floats, ZERO-INITIALISED ONCE by the caller (alignment padding between tensors is never written). */
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
 int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,

@@ -48,6 +48,7 @@ CASES = [
     (1024, [128, 128, 2], ["", "tanh", "tanh", ""], 300),
     (33, [50, 17, 4], ["", "tanh", "tanh", "tanh"], 77),
     (6, [8, 2], ["", "tanh", ""], 5),
+    (40, [32, 2], ["", "tanh", ""], 9000),     # more than 32 x 128 rows: the weight-gradient slices grow to 512 rows, ragged end
 ]
 
 
