@@ -319,8 +319,6 @@ class SequentialEngine:
         else:
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         self._wgrad()
-        if self.dp.active:      # the loss terms travel in the same all-reduce as the gradients
-            _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
 
     def _late_bookkeeping(self) -> bool:
         """Single process: the step's scalar epilogue rides along with the weight-gradient launch (its inputs are complete
@@ -336,7 +334,13 @@ class SequentialEngine:
         if self._late_bookkeeping():
             jobs = self._jobs_pre() + [(self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)]
             fin = _lib.make_finish_desc(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+        elif self.dp.active and self._fold_finish and self._jobs_pre():
+            # the rank's shares of the cost terms, summed by the extra workgroup: they travel in the same all-reduce as the
+            # gradients (no history row, no counters here: those follow the optimizer)
+            fin = _lib.make_finish_desc(self._jobs_pre(), self.terms, N_TERMS)
         _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws, finish=fin)
+        if fin is None and self.dp.active and self._jobs_pre():
+            _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
 
     def _step_post(self) -> None:
         """clip + L2 + Adam (+ operand store, + the next batch), and -- unless it rode along with the weight gradients --
