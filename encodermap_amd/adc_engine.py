@@ -112,6 +112,7 @@ class ADCEngine(SequentialEngine):
         self.cart_scale = z(1)
         dmax = max(self.ldp, self.F)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
+        self.split_pair = torch.zeros(_lib.sketchmap_split_bytes(B, self.P), dtype=torch.uint8, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
@@ -252,8 +253,12 @@ class ADCEngine(SequentialEngine):
         cs = p.center_cost_scale
         cdc = p.cartesian_distance_cost_scale
         if cdc is not None:
-            _lib.sketchmap_fwd_bwd(self.inp_pair, Z, INF, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0,
-                                   0, B, t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
+            # the high-d "points" are the frames' pair-distance vectors (thousands of features, few rows): Gram products on the
+            # f16 matrix cores from the split rows
+            _lib.sketchmap_split(self.inp_pair[:, :self.P], self.split_pair)
+            _lib.sketchmap_tiles(self.inp_pair[:, :self.P], Z, INF, p.cartesian_dist_sig_parameters, 0, B, self.sk_ws, self.split_pair)
+            _lib.sketchmap_finish(B, self.P, Z, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0, 0, B,
+                                  t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
         else:
             t[T_CDIST].zero_()
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, 0, B, t[T_CENTER:T_CENTER + 1], self.dZ, False)

@@ -331,6 +331,250 @@ __global__ __launch_bounds__(NT) void d2c_bwd_kernel(const float* __restrict__ d
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// K7, one workgroup per frame (two waves: wave 0 = right part, wave 1 = left part), the frame and every per-step
+// quantity in LDS.  The chain is a product of rigid transforms whose FACTORS do not depend on each other -- step i turns
+// about an axis of the PLANAR input chain -- so only the 3x3 / 3-vector recurrences are serial:
+//   phase A (lanes over the steps)  Q_i, c_i from the planar atoms and the dihedral (sin/cos, Rodrigues)
+//   phase B (one lane, LDS only)    R_i = R_{i-1} Q_i, t_i = R_{i-1} c_i + t_{i-1};  backward also, independent of it and
+//                                   interleaved with it, the adjoint recurrence  Rb_{i-1} = Rb_i Q_i^T + tb_i (x) c_i + g (x) p
+//   phase C (lanes over the steps)  out_{i+3} = R_i P_{i+3} + t_i;  backward: the step's local adjoints (d dihedral, and the
+//                                   step's three contributions to d plane, kept per step)
+//   phase D (lanes over the atoms)  backward: every atom adds the contributions it receives in a fixed order
+// The thread-per-frame kernels above (global loads and library sincosf inside the serial loop, 256 threads on the
+// whole chip) took 97 us forward and 667 us backward at B = 256, A = 228; they remain for frames that do not fit LDS.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int FR_NT_FWD = 128, FR_NT_BWD = 256;   // backward: waves 2, 3 run the adjoint recurrence of the two parts
+
+__device__ __forceinline__ void lds_put9(float* d, const M3& m) {
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) d[3 * r + c] = m.m[r][c];
+}
+__device__ __forceinline__ M3 lds_get9(const float* d) {
+  M3 m;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m.m[r][c] = d[3 * r + c];
+  return m;
+}
+__device__ __forceinline__ M3 outer(V3 a, V3 b) {
+  M3 m;
+  m.m[0][0] = a.x * b.x; m.m[0][1] = a.x * b.y; m.m[0][2] = a.x * b.z;
+  m.m[1][0] = a.y * b.x; m.m[1][1] = a.y * b.y; m.m[1][2] = a.y * b.z;
+  m.m[2][0] = a.z * b.x; m.m[2][1] = a.z * b.y; m.m[2][2] = a.z * b.z;
+  return m;
+}
+__device__ __forceinline__ M3 add(const M3& a, const M3& b) {
+  M3 m;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m.m[r][c] = a.m[r][c] + b.m[r][c];
+  return m;
+}
+
+// LDS floats of the per-frame kernels: the frame (and its gradient), then 12 (forward) / 36 (backward) per step
+__host__ __device__ inline long d2c_frame_floats(int A, bool bwd) { return (long)(bwd ? 6 : 3) * A + (long)(bwd ? 36 : 12) * (A > 4 ? A - 2 : 2); }
+
+template <bool BWD>
+__global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(const float* __restrict__ dih, int ldd, float offset, const float* __restrict__ plane,
+                                                          const float* __restrict__ dout, int A, float* __restrict__ out,
+                                                          float* __restrict__ ddih, int ldg, float* __restrict__ dplane) {
+  extern __shared__ float sm[];
+  constexpr int FR_NT = BWD ? FR_NT_BWD : FR_NT_FWD;
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int dir = wave & 1, role = wave >> 1;   // role 1 (backward only): the adjoint recurrence in phase B
+  constexpr int LSTEP = BWD ? 128 : 64;         // lanes that share one part's steps in phases A and C
+  const int slane = lane + 64 * role;
+  const D2C g{A / 2, A};
+  const float* __restrict__ P = plane + (long)b * A * 3;
+  const float* __restrict__ dd = dih + (long)b * ldd;
+  float* Pf = sm;                        // [A][3] planar chain
+  float* Gf = sm + 3 * A;                // [A][3] d loss / d out (backward)
+  float* S = sm + (BWD ? 6 : 3) * A;     // per step: [Q 9 | c 3] ([R 9 | t 3] after phase B), backward + [R 9 | tb 3] + [Rb 9 | -]
+  constexpr int SW = BWD ? 36 : 12;
+  const int n = g.natoms(dir), nd = max(n - 3, 0);
+  const int nd0 = max(g.natoms(0) - 3, 0);
+  float* Sd = S + (long)(dir ? nd0 : 0) * SW;
+  for (int e = tid; e < 3 * A; e += FR_NT) {
+    Pf[e] = P[e];
+    if (BWD) Gf[e] = dout[(long)b * A * 3 + e];
+  }
+  __syncthreads();
+  // ---- phase A
+  for (int i = slane; i < nd; i += LSTEP) {
+    const V3 p1 = ld3(Pf + 3 * g.atom(dir, i + 1)), p2 = ld3(Pf + 3 * g.atom(dir, i + 2));
+    const V3 w = p2 - p1;
+    const V3 u = rsqrtf(dot(w, w)) * w;
+    float sn, cs;
+    emx::sincos_bounded(dd[g.dih(dir, i)] + offset, &sn, &cs);
+    const M3 Q = rodrigues(u, cs, sn);
+    lds_put9(Sd + (long)i * SW, Q);
+    st3(Sd + (long)i * SW + 9, p2 - mul(Q, p2));
+  }
+  __syncthreads();
+  // ---- phase B: the serial part, LDS only (every lane runs it, lane 0 writes)
+  {
+    M3 R = identity();
+    V3 tr{0.f, 0.f, 0.f};
+    M3 Rb;
+    V3 tb{0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Rb.m[r][c] = 0.f;
+    for (int k = 0; k < nd; ++k) {
+      if (role == 0) {   // ascending: step k
+        float* q = Sd + (long)k * SW;
+        const M3 Q = lds_get9(q);
+        const V3 c = ld3(q + 9);
+        tr = mul(R, c) + tr;
+        R = mul(R, Q);
+        if (BWD) {
+          if (lane == 0) lds_put9(q + 12, R);
+        } else if (lane == 0) {
+          lds_put9(q, R);
+          st3(q + 9, tr);
+        }
+      }
+      if (BWD && role == 1) {   // descending: step j
+        const int j = nd - 1 - k;
+        float* q = Sd + (long)j * SW;
+        const int a3 = g.atom(dir, j + 3);
+        const V3 gk = ld3(Gf + 3 * a3), p3 = ld3(Pf + 3 * a3);
+        Rb = add(Rb, outer(gk, p3));
+        tb = tb + gk;
+        if (lane == 0) {
+          lds_put9(q + 24, Rb);
+          st3(q + 21, tb);
+        }
+        const M3 Q = lds_get9(q);
+        const V3 c = ld3(q + 9);
+        Rb = add(mulBT(Rb, Q), outer(tb, c));
+      }
+    }
+  }
+  __syncthreads();
+  // ---- phase C
+  if (!BWD) {
+    float* O = out + (long)b * A * 3;
+    if (dir == 0 && lane < 3 && lane < n) st3(O + 3 * g.atom(0, lane), ld3(Pf + 3 * g.atom(0, lane)));
+    for (int i = lane; i < nd; i += 64) {
+      const float* q = Sd + (long)i * SW;
+      const M3 R = lds_get9(q);
+      const int a3 = g.atom(dir, i + 3);
+      st3(O + 3 * a3, mul(R, ld3(Pf + 3 * a3)) + ld3(q + 9));
+    }
+    return;
+  }
+  for (int i = slane; i < nd; i += LSTEP) {
+    float* q = Sd + (long)i * SW;
+    const M3 Q = lds_get9(q);
+    const V3 c = ld3(q + 9);
+    const M3 Ri = lds_get9(q + 12);
+    const M3 Rp = i > 0 ? lds_get9(q - SW + 12) : identity();
+    const M3 Rb = lds_get9(q + 24);
+    const V3 tb = ld3(q + 21);
+    const int a1 = g.atom(dir, i + 1), a2 = g.atom(dir, i + 2), a3 = g.atom(dir, i + 3);
+    const V3 gk = ld3(Gf + 3 * a3);
+    const V3 p1 = ld3(Pf + 3 * a1), o = ld3(Pf + 3 * a2);
+    const V3 w = o - p1;
+    const float inv = rsqrtf(dot(w, w));
+    const V3 u = inv * w;
+    float sn, cs;
+    emx::sincos_bounded(dd[g.dih(dir, i)] + offset, &sn, &cs);
+    M3 Qb = mulAT(Rp, Rb);           // from R_i = Rp Q
+    const V3 cb = mulT(Rp, tb);      // from t_i = Rp c + tp
+    V3 ob = cb - mulT(Q, cb);        // c = o - Q o
+    Qb.m[0][0] -= cb.x * o.x; Qb.m[0][1] -= cb.x * o.y; Qb.m[0][2] -= cb.x * o.z;
+    Qb.m[1][0] -= cb.y * o.x; Qb.m[1][1] -= cb.y * o.y; Qb.m[1][2] -= cb.y * o.z;
+    Qb.m[2][0] -= cb.z * o.x; Qb.m[2][1] -= cb.z * o.y; Qb.m[2][2] -= cb.z * o.z;
+    // Q(u, d) = cs I + sn [u]x + (1 - cs) u u^T
+    const float trQ = Qb.m[0][0] + Qb.m[1][1] + Qb.m[2][2];
+    const V3 ax{Qb.m[2][1] - Qb.m[1][2], Qb.m[0][2] - Qb.m[2][0], Qb.m[1][0] - Qb.m[0][1]};   // <Qb, [v]x> = v . ax
+    const V3 Qu = mul(Qb, u), QTu = mulT(Qb, u);
+    const float uQu = dot(u, Qu);
+    ddih[(long)b * ldg + g.dih(dir, i)] = -sn * trQ + cs * dot(u, ax) + sn * uQu;
+    const V3 ub = sn * ax + (1.f - cs) * (Qu + QTu);
+    const V3 wb = inv * (ub - dot(u, ub) * u);   // u = w / |w|
+    ob = ob + wb;
+    (void)c;
+    // the step's contributions to d plane, in the slot of Q: [to atom i+3 | to atom i+2 | to atom i+1]
+    st3(q, mulT(Ri, gk));
+    st3(q + 3, ob);
+    st3(q + 6, V3{-wb.x, -wb.y, -wb.z});
+  }
+  __syncthreads();
+  // ---- phase D: every atom collects what it receives: pass-through (atoms s-1 .. s+1), then right part, then left part
+  float* DP = dplane + (long)b * A * 3;
+  const int nd1 = max(g.natoms(1) - 3, 0);
+  for (int a = tid; a < A; a += FR_NT) {
+    V3 acc{0.f, 0.f, 0.f};
+    if (a >= g.s - 1 && a <= g.s + 1) acc = ld3(Gf + 3 * a);
+#pragma unroll
+    for (int d = 0; d < 2; ++d) {
+      const int cidx = d ? g.s + 1 - a : a - (g.s - 1);   // local chain index of the atom in this direction
+      const int ndd = d ? nd1 : nd0;
+      const float* Sx = S + (long)(d ? nd0 : 0) * SW;
+      if (cidx < 0) continue;
+#pragma unroll
+      for (int r = 3; r >= 1; --r) {   // as step (cidx - r)'s contribution number (3 - r)
+        const int i = cidx - r;
+        if (i >= 0 && i < ndd) acc = acc + ld3(Sx + (long)i * SW + 3 * (3 - r));
+      }
+    }
+    st3(DP + 3 * a, acc);
+  }
+}
+
+// K6, one wave per frame: the angle recurrence is one subtraction per step (serial, LDS), sin/cos and the partial sums of
+// the steps run over the lanes (a wave-wide inclusive scan per 64 steps).
+__global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda, int A,
+                                                         float* __restrict__ xyz) {
+  extern __shared__ float sm[];   // [A] phi
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* __restrict__ th = ang + (long)b * lda;
+  float* o = xyz + (long)b * A * 3;
+  for (int i = lane; i < A - 2; i += 64) sm[i + 1] = PI_F - th[i];
+  __syncthreads();
+  if (lane == 0) {
+    float phi = 0.f;
+    sm[0] = 0.f;
+    for (int i = 1; i < A - 1; ++i) {
+      phi = sm[i] - phi;
+      sm[i] = phi;
+    }
+  }
+  __syncthreads();
+  if (lane == 0) st3(o, V3{0.f, 0.f, 0.f});
+  float cx = 0.f, cy = 0.f;   // carry of the partial sums
+  for (int i0 = 0; i0 < A - 1; i0 += 64) {
+    const int i = i0 + lane;
+    float dx = 0.f, dy = 0.f;
+    if (i < A - 1) {
+      float sn, cs;
+      emx::sincos_bounded(sm[i], &sn, &cs);
+      dx = len[i] * cs;
+      dy = (i & 1) ? -len[i] * sn : len[i] * sn;
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float ux = __shfl_up(dx, off, 64), uy = __shfl_up(dy, off, 64);
+      if (lane >= off) {
+        dx += ux;
+        dy += uy;
+      }
+    }
+    if (i < A - 1) st3(o + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
+    cx += __shfl(dx, 63, 64);
+    cy += __shfl(dy, 63, 64);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // K3: per-frame flat pair distances of the selected atoms (start + step * c, c < C), strict upper triangle, row-major
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
@@ -715,6 +959,10 @@ int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t 
 
 int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, int B, int A, float* xyz, emx_stream_t stream) {
   EMX_REQUIRE(lengths && angles && xyz && B > 0 && A >= 3 && (lda >= A - 2 || lda == 0), "emx_chain_in_plane_fwd: bad arguments (A >= 3)");
+  if ((size_t)A * sizeof(float) <= 48 * 1024) {
+    hipLaunchKernelGGL(chain_frame_kernel, dim3(B), dim3(64), (size_t)A * sizeof(float), (hipStream_t)stream, lengths, angles, lda, A, xyz);
+    return emx::check_launch("chain_frame_kernel");
+  }
   hipLaunchKernelGGL(chain_fwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, B, A, xyz);
   return emx::check_launch("chain_fwd_kernel");
 }
@@ -730,6 +978,13 @@ int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, c
 int emx_dihedrals_to_cartesian_fwd(const float* dihedrals, int ldd, float dihedral_offset, const float* plane, int B, int A, float* out,
                                    emx_stream_t stream) {
   EMX_REQUIRE(dihedrals && plane && out && B > 0 && A >= 4 && ldd >= A - 3, "emx_dihedrals_to_cartesian_fwd: bad arguments (A >= 4)");
+  if (const size_t lds = (size_t)d2c_frame_floats(A, false) * sizeof(float); lds <= 160 * 1024) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&d2c_frame_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return emx::fail(EMX_ELAUNCH, "emx_dihedrals_to_cartesian_fwd: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(d2c_frame_kernel<false>, dim3(B), dim3(FR_NT_FWD), lds, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, nullptr, A,
+                       out, nullptr, 0, nullptr);
+    return emx::check_launch("d2c_frame_kernel (forward)");
+  }
   hipLaunchKernelGGL(d2c_fwd_kernel, dim3((2 * B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, B,
                      A, out);
   return emx::check_launch("d2c_fwd_kernel");
@@ -739,6 +994,13 @@ int emx_dihedrals_to_cartesian_bwd(const float* dihedrals, int ldd, float dihedr
                                    float* ddihedrals, int ldg, float* dplane, emx_stream_t stream) {
   EMX_REQUIRE(dihedrals && plane && dout && ddihedrals && dplane && B > 0 && A >= 4 && ldd >= A - 3 && ldg >= A - 3,
               "emx_dihedrals_to_cartesian_bwd: bad arguments (A >= 4)");
+  if (const size_t lds = (size_t)d2c_frame_floats(A, true) * sizeof(float); lds <= 160 * 1024) {
+    if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&d2c_frame_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return emx::fail(EMX_ELAUNCH, "emx_dihedrals_to_cartesian_bwd: cannot reserve %zu bytes of LDS", lds);
+    hipLaunchKernelGGL(d2c_frame_kernel<true>, dim3(B), dim3(FR_NT_BWD), lds, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, dout, A,
+                       nullptr, ddihedrals, ldg, dplane);
+    return emx::check_launch("d2c_frame_kernel (backward)");
+  }
   hipLaunchKernelGGL(d2c_bwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, dihedrals, ldd, dihedral_offset, plane, dout, B,
                      A, ddihedrals, ldg, dplane);
   return emx::check_launch("d2c_bwd_kernel");

@@ -49,7 +49,7 @@ def test_colmean(L):
         np.testing.assert_allclose(out.cpu().numpy(), x.astype(np.float64).mean(0), rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,A", [(5, 4), (33, 7), (64, 24), (256, 228), (16, 457)])
+@pytest.mark.parametrize("B,A", [(5, 4), (33, 7), (64, 24), (256, 228), (16, 457), (3, 1100)])   # 1100: beyond the LDS frame kernels
 def test_chain_in_plane_and_backmapping(L, B, A):
     rng = np.random.default_rng(A)
     lengths, angles, dih = make_chain(rng, B, A)
@@ -61,6 +61,7 @@ def test_chain_in_plane_and_backmapping(L, B, A):
     gout = rng.normal(0, 1, (B, A, 3))
     (xyz_o * t64(gout)).sum().backward()
     extent = float(xyz_o.detach().abs().max()) + 1.0
+    chain = max(1.0, A / 457)     # float32 rounding of the chained rotations grows with their number
     # ---- kernels
     LEN, ANG, DIH = dev(mean_len), dev(angles), dev(dih)
     plane = torch.full((B, A, 3), float("nan"), device="cuda")
@@ -69,11 +70,11 @@ def test_chain_in_plane_and_backmapping(L, B, A):
     assert torch.all(plane[..., 2] == 0)                                  # tests/test_losses.py:643-648
     xyz = torch.full((B, A, 3), float("nan"), device="cuda")
     L.dihedrals_to_cartesian_fwd(DIH, PI, plane, xyz)
-    np.testing.assert_allclose(xyz.cpu().numpy(), xyz_o.detach().numpy(), atol=3e-5 * extent)
+    np.testing.assert_allclose(xyz.cpu().numpy(), xyz_o.detach().numpy(), atol=3e-5 * extent * chain)
     # round trip: the mdtraj-convention dihedrals of the back-mapped chain are the inputs (test_backmapping_em1_em2.py:643-669)
     back = R.dihedrals_mdtraj_convention(xyz.cpu().double())
     diff = R.periodic_distance(back, t64(dih), 2 * PI)
-    assert float(diff.max()) < 2e-3
+    assert float(diff.max()) < 2e-3 * chain
     # ---- backward
     G = dev(gout)
     ddih = torch.full((B, A - 3), float("nan"), device="cuda")
@@ -82,8 +83,8 @@ def test_chain_in_plane_and_backmapping(L, B, A):
     dang = torch.full((B, A - 2), float("nan"), device="cuda")
     L.chain_in_plane_bwd(LEN, ANG, dplane, dang)
     gd, ga = dih_t.grad.numpy(), ang_t.grad.numpy()
-    np.testing.assert_allclose(ddih.cpu().numpy(), gd, rtol=0, atol=1e-4 * np.abs(gd).max())
-    np.testing.assert_allclose(dang.cpu().numpy(), ga, rtol=0, atol=1e-4 * np.abs(ga).max())
+    np.testing.assert_allclose(ddih.cpu().numpy(), gd, rtol=0, atol=1e-4 * chain * np.abs(gd).max())
+    np.testing.assert_allclose(dang.cpu().numpy(), ga, rtol=0, atol=1e-4 * chain * np.abs(ga).max())
 
 
 def test_backmapping_helix_table(L):
