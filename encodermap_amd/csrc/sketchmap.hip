@@ -67,6 +67,7 @@ struct SkArgs {
   float period;
   SigDev sh, sl;
   SplitRows split;   // optional bf16 planes + norms of the rows (split.h): selects the bf16 Gram kernel
+  int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
 };
 
 template <int N>
@@ -177,6 +178,37 @@ __device__ __forceinline__ void tri_decode(int t, int nb, int& ti, int& tj) {
   while ((i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
   ti = i;
   tj = i + (t - (i * nb - i * (i - 1) / 2));
+}
+
+// XCD-aware order of the upper-triangle tiles.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one,
+// observed, speed only -- nothing below depends on it for correctness), each XCD has its own L2, and a tile needs the
+// planes of its row panel and of its column panel.  In row-major triangle order every XCD ends up pulling ALL panels
+// through the fabric (8 x 2 MB at C2, while all 2048 resident tiles stage at once).  Here the panels form four groups
+// and the triangle ten group pairs: the six off-diagonal pairs (nbg^2 tiles each) go to the blocks with b % 8 = 0..5, the
+// four diagonal ones (nbg (nbg + 1) / 2 tiles each) two by two to b % 8 = 6, 7 -- every XCD touches half of the panels,
+// 256 / 272 tiles at C2.  Blocks beyond an XCD's share (and tiles beyond a ragged last group) leave at once.
+// Returns false for such a block; t = the tile's index in row-major triangle order (its tile_loss slot).
+__device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int& tj, int& t) {
+  const int x = bid & 7, k = bid >> 3;
+  int gi, gj, li, lj;
+  if (x < 6) {
+    gi = x < 3 ? 0 : (x < 5 ? 1 : 2);
+    gj = x < 3 ? x + 1 : (x < 5 ? x - 1 : 3);
+    if (k >= nbg * nbg) return false;
+    li = k / nbg;
+    lj = k - li * nbg;
+  } else {
+    const int T2 = nbg * (nbg + 1) / 2;
+    if (k >= 2 * T2) return false;
+    const int second = k >= T2 ? 1 : 0;
+    gi = gj = 2 * (x - 6) + second;
+    tri_decode(k - second * T2, nbg, li, lj);
+  }
+  ti = gi * nbg + li;
+  tj = gj * nbg + lj;
+  if (ti >= nbc || tj >= nbc) return false;
+  t = ti * nbc - ti * (ti - 1) / 2 + (tj - ti);
+  return true;
 }
 
 template <int TM, int TN, int LT, bool PERIODIC, bool FASTSIG>
@@ -591,8 +623,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
 
-  int ti, tj;
-  if (a.symm) {
+  int ti, tj, tslot = blockIdx.x;
+  if (a.xcd_nbg > 0) {
+    if (!xcd_tile(blockIdx.x, a.xcd_nbg, a.nbc, ti, tj, tslot)) return;
+  } else if (a.symm) {
     tri_decode(blockIdx.x, a.nbc, ti, tj);
   } else {
     ti = blockIdx.x / a.nbc;
@@ -743,7 +777,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   KSTAMP(21);
   float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
   KSTAMP(22);
-  if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
+  if (tid == 0) a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
 
   for (int e = tid; e < T * LMAX; e += NT) {
     int rl = e / LMAX, l = e - rl * LMAX;
@@ -934,6 +968,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.nbc = (B + T - 1) / T;
   a.nrows_pad = a.nbr * T;
   a.symm = symm;
+  a.xcd_nbg = 0;
   a.split = split_ok ? split_view(split_ws, B, D) : SplitRows{};
   a.vec4 = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   a.period = periodicity;
@@ -974,13 +1009,21 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   const SkArgs& a = pl.a;
   if (a.split.planes != nullptr && pl.T == 64) {
     const int nch = a.split.ld / SPLIT_KC;
-    if (a.L == 2 && pl.fast && nch == 4) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 4>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else if (a.L == 2 && pl.fast && nch == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 2>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else if (a.L == 2 && pl.fast && nch == 1) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 1>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
-    else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), dim3(pl.ntiles), dim3(NT), 0, st, a);
+    SkArgs b = a;
+    b.xcd_nbg = 0;
+    int grid = pl.ntiles;
+    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    if (a.symm && a.nbc >= 16 && xcd_order) {   // XCD-aware tile order (xcd_tile): 8 x the largest share, the surplus blocks leave at once
+      b.xcd_nbg = (a.nbc + 3) / 4;
+      grid = 8 * b.xcd_nbg * (b.xcd_nbg + 1);
+    }
+    if (a.L == 2 && pl.fast && nch == 4) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 4>), dim3(grid), dim3(NT), 0, st, b);
+    else if (a.L == 2 && pl.fast && nch == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 2>), dim3(grid), dim3(NT), 0, st, b);
+    else if (a.L == 2 && pl.fast && nch == 1) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 1>), dim3(grid), dim3(NT), 0, st, b);
+    else if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), dim3(grid), dim3(NT), 0, st, b);
+    else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), dim3(grid), dim3(NT), 0, st, b);
+    else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), dim3(grid), dim3(NT), 0, st, b);
+    else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), dim3(grid), dim3(NT), 0, st, b);
     return emx::check_launch("sk_tile_f16_kernel");
   }
   if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram) {
