@@ -24,6 +24,7 @@ mini-batches are drawn by a device-side permutation stream and gathered by index
 """
 from __future__ import annotations
 
+import gc
 import math
 import os
 from typing import Optional, Sequence
@@ -211,6 +212,8 @@ class SequentialEngine:
     _fuse_decoder = os.environ.get("EMX_FUSE_DECODER", "1") != "0"   # forward + auto cost + decoder backward in one launch
     _fold_finish = os.environ.get("EMX_FOLD_FINISH", "1") != "0"     # scalar epilogue inside the weight-gradient launch
     _cost_in_forward = True                                          # auto cost inside the forward launch (False: layers too wide)
+    _graph_steps = max(1, int(os.environ.get("EMX_GRAPH_STEPS", "8")))   # steps per replay of the multi-step graph (1: single-step graph only)
+    _graph_multi = None
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -385,6 +388,7 @@ class SequentialEngine:
         """Warm up on a side stream, then capture the step into hipGraphs (torch.cuda.CUDAGraph).  Single GPU: one
         graph for the whole step.  Data parallel: one graph up to the gradients, the RCCL all-reduce issued eagerly
         on the same stream, one graph for Adam + bookkeeping."""
+        self._graph_multi = None
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         saved = [t.clone() for t in self._state_tensors()]
@@ -404,18 +408,36 @@ class SequentialEngine:
                 self._gather_current()
 
         restore()
-        if self.dp.active:
-            g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g1):
-                self._step_pre()
-            with torch.cuda.graph(g2, pool=g1.pool()):
-                self._step_post()
-            self._graph = (g1, g2)
-        else:
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._step_body()
-            self._graph = (g,)
+        # no garbage collection while a stream is capturing: a collected object that owns device resources (an engine of
+        # an earlier model with its graphs, an event) would destroy them in the middle of the capture and abort it
+        gc_was_on = gc.isenabled()
+        gc.collect()
+        gc.disable()
+        try:
+            if self.dp.active:
+                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g1):
+                    self._step_pre()
+                with torch.cuda.graph(g2, pool=g1.pool()):
+                    self._step_post()
+                self._graph = (g1, g2)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._step_body()
+                self._graph = (g,)
+                # the same step several times over in one graph: every kernel reads the device-side counters, so replaying
+                # it is the same as replaying the single-step graph that often, minus the launch gaps between graphs
+                if self._graph_steps > 1:
+                    restore()
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm, pool=g.pool()):
+                        for _ in range(self._graph_steps):
+                            self._step_body()
+                    self._graph_multi = gm
+        finally:
+            if gc_was_on:
+                gc.enable()
         restore()
 
     def _replay(self) -> None:
@@ -452,7 +474,12 @@ class SequentialEngine:
             if self.use_graph:
                 if self._graph is None:
                     self._capture()
-                for _ in range(k):
+                r = k
+                if len(self._graph) == 1 and self._graph_multi is not None:
+                    while r >= self._graph_steps:
+                        self._graph_multi.replay()
+                        r -= self._graph_steps
+                for _ in range(r):
                     self._replay()
             else:
                 for _ in range(k):

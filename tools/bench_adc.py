@@ -22,7 +22,7 @@ step = rng.normal(size=(N, A, 3))
 step /= np.linalg.norm(step, axis=2, keepdims=True)
 xyz = np.cumsum(1.4 * step, axis=1).astype(np.float32)
 cv = featurize_backbone(xyz)
-p = em.ADCParameters(n_steps=1, batch_size=B, cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5),
+p = em.ADCParameters(n_steps=4000, batch_size=B, cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5),
                      dihedral_cost_reference=1.5, angle_cost_reference=0.3, cartesian_cost_reference=8.0, track_clashes="--metrics" in sys.argv,
                      track_RMSD="--metrics" in sys.argv)
 m = em.AngleDihedralCartesianEncoderMap(cv, p, read_only=True)

@@ -29,7 +29,7 @@ for name in which:
     else:
         cen = rng.normal(0, 4, (16, c["D"]))
         data = (cen[rng.integers(0, 16, c["N"])] + rng.normal(0, 1, (c["N"], c["D"]))).astype(np.float32)
-    p = em.Parameters(n_steps=1, **c["kw"])
+    p = em.Parameters(n_steps=4000, **c["kw"])
     eng = SequentialEngine(c["D"], p, with_distance=True, device="cuda:0")
     eng.set_data(data)
     eng.run_steps(20)
