@@ -389,7 +389,7 @@ __global__ void step_tick_kernel(const float* __restrict__ terms, int n_terms, f
 __global__ __launch_bounds__(FIN_NT) void finish_step_kernel(const FinishArgs a) {
   __shared__ float red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
   __shared__ float tl[64];
-  finish_step_body(a, red, tl);
+  finish_step_body<emx::FQ>(a, red, tl);
 }
 
 inline int grid_for(long work_items, int per_block) {

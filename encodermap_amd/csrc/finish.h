@@ -30,10 +30,13 @@ struct FinishArgs {
 // step_tick_kernel works from values fetched at kernel entry.  A single workgroup is bound by round trips (~2.7 us each
 // here: freshly written lines of other XCDs, cold TLB) and by its own instruction count, not by bandwidth; job after job,
 // each with its own reduction and a serial tail, was 9 us.  Fixed order throughout.
-constexpr int FQ = 8;   // 16-byte loads per thread and job in the common round
+constexpr int FQ = 8;   // 16-byte loads per thread and job in the common round (stand-alone launch: everything in flight at once)
+constexpr int FQ_EMBEDDED = 2;   // ... when it rides along with the weight gradients: its latency hides behind them, its
+                                 // registers count against every workgroup of that launch (4 x FQ float4 per thread)
 
 // the body of finish_step_kernel, for one workgroup of FIN_NT threads (also run by one extra workgroup of the
 // weight-gradient kernel, so that a single-GPU step needs no launch of its own for it)
+template <int FQ>
 __device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&red)[EMX_MAX_SUM_JOBS][FIN_NT / 64], float (&tl)[64]) {
   constexpr int NT = FIN_NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -84,7 +87,14 @@ __device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&re
         const float wq = (long)tid + u * NT < n4 ? 1.f : 0.f;
         acc[u] = (sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w)) * wq;
       }
-      float p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      float p;
+      if constexpr (FQ == 8) {
+        p = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+      } else {
+        p = 0.f;
+#pragma unroll
+        for (int u = 0; u < FQ; ++u) p += acc[u];
+      }
       for (long i = (long)tid + FQ * NT; i < n4; i += NT) {   // long jobs: the rest, strided
         const float4 x = reinterpret_cast<const float4*>(job.src)[i];
         p += sq ? (x.x * x.x + x.y * x.y) + (x.z * x.z + x.w * x.w) : (x.x + x.y) + (x.z + x.w);

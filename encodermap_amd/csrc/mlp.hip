@@ -550,7 +550,9 @@ __device__ long long emx_dbg_wg[3 * 1024 + 64];
 #define WSTAMP(k)
 #endif
 
-__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
+// three waves per SIMD: 640 workgroups x 4 waves must all be resident at once (2.5 per SIMD); the scalar epilogue that rides
+// along would otherwise raise the allocation to 198 registers = two waves (16 -> 22 us)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void mlp_wgrad_kernel(const WgradDev a) {
   // One workgroup = one 64x64 block of one layer's dW over one row slice (128 rows); each wave a 32x32 quadrant = 2x2
   // MFMA tiles.  The MFMA's m/n indices are free labels: lane slot m of tile u stands for feature 2m + u (n, v likewise),
   // so ONE 8-byte load per operand and 4-row step feeds both tiles of that operand, and the two tiles v = 0, 1 of a slot
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
     // cost shares of the forward launch, the tile sums of the all-pairs launch, the regulariser shares the previous
     // optimizer launch left for the current weights -- are complete before this launch starts, and a launch of its own
     // costs ~6.5 us of a ~95 us step.
-    if (blockIdx.y == 0) finish_step_body(a.fin, fin_red, fin_tl);
+    if (blockIdx.y == 0) finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

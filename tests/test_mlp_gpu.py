@@ -147,8 +147,8 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
         assert torch.equal(g3[lo:hi], g[lo:hi])
         assert [int(c) for c in cnt] == [2, 2, 2]
         outs.append((terms.clone(), hist.clone(), thist.clone()))
-    for a, b in zip(*outs):
-        assert torch.equal(a, b)
+    for a, b in zip(*outs):     # (the embedded epilogue keeps fewer loads in flight: same sums, another association)
+        torch.testing.assert_close(a, b, rtol=2e-6, atol=1e-7)
     assert float(outs[0][1][1]) == pytest.approx(float(outs[0][0].sum()), rel=1e-6) and float(outs[0][0][1]) == 0.25
 
 
