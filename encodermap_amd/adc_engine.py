@@ -43,7 +43,9 @@ class ADCEngine(SequentialEngine):
     _reg_slot = T_REG
 
     def _jobs_pre(self) -> list:
-        return []      # every ADC cost kernel writes its term itself
+        """The row-mean costs leave their workgroup shares in ``cost_ws`` (one row per term); the step's scalar epilogue adds
+        them up.  The all-pairs costs write their terms themselves."""
+        return [(self.cost_ws_rows[k], _lib.EMX_REDUCE_WS, 1.0, None, slot, False) for k, slot in self._cost_rows]
 
     def _use_sketchmap(self) -> bool:
         return False   # the ADC step reduces its two all-pairs costs with emx_sketchmap_fwd_bwd
@@ -114,6 +116,10 @@ class ADCEngine(SequentialEngine):
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.split_pair = torch.zeros(_lib.sketchmap_split_bytes(B, self.P), dtype=torch.uint8, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        # workgroup shares of the row-mean costs, one row per term: cartesian, dihedral, angle, side dihedral
+        self.cost_ws_rows = torch.zeros(4, _lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self._row_of = {T_CART: 0, T_DIH: 1, T_ANG: 2, T_SIDE: 3}
+        self._cost_rows = [(0, T_CART), (1, T_DIH), (2, T_ANG)] + ([(3, T_SIDE)] if self.S else [])
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
 
@@ -221,7 +227,7 @@ class ADCEngine(SequentialEngine):
         _lib.soft_start_scale(self.step, -1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b,
                               0.0 if c is None else float(c), self.cart_scale)
         _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
-                                   1.0 / float(p.cartesian_cost_reference), 0, B, t[T_CART:T_CART + 1], self.dpair, self.red_ws,
+                                   1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
                                    coef_scale=self.cart_scale)
         _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
         _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
@@ -238,15 +244,13 @@ class ADCEngine(SequentialEngine):
             else:
                 sc, var, ref, slot, extra = p.side_dihedral_cost_scale, p.side_dihedral_cost_variant, p.side_dihedral_cost_reference, T_SIDE, None
             coef = 0.0 if sc is None else float(sc) / float(ref)
-            _lib.periodic_cost_fwd_bwd(Y, col, col + nn, True, tgt, nn, per, var, coef, 0, B, t[slot:slot + 1], self.dY, self.red_ws,
+            _lib.periodic_cost_fwd_bwd(Y, col, col + nn, True, tgt, nn, per, var, coef, 0, B, None, self.dY, self.cost_ws_rows[self._row_of[slot]],
                                        dpred_add=extra)
         if not self.use_ang:   # mean angles carry no gradient, the cost is still reported (models.py:2383)
             sc = p.angle_cost_scale
             _lib.periodic_cost_fwd_bwd(_Bcast(self.ang_pred), 0, 0, False, self.feat[:, self.off_ang: self.off_ang + self.n_ang], self.n_ang,
                                        per, p.angle_cost_variant, 0.0 if sc is None else float(sc) / float(p.angle_cost_reference), 0, B,
-                                       t[T_ANG:T_ANG + 1], None, self.red_ws, B=B)
-        if not self.S:
-            t[T_SIDE].zero_()
+                                       None, None, self.cost_ws_rows[self._row_of[T_ANG]], B=B)
 
         # latent costs: cartesian distance cost (Euclidean, high-d = input pair distances) with the center cost fused,
         # and the periodic distance cost on the angular inputs when it is switched on
@@ -259,8 +263,7 @@ class ADCEngine(SequentialEngine):
             _lib.sketchmap_tiles(self.inp_pair[:, :self.P], Z, INF, p.cartesian_dist_sig_parameters, 0, B, self.sk_ws, self.split_pair)
             _lib.sketchmap_finish(B, self.P, Z, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0, 0, B,
                                   t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
-        else:
-            t[T_CDIST].zero_()
+        else:       # (the slot of a cost that is switched off is never written: it stays at its initial 0)
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, 0, B, t[T_CENTER:T_CENTER + 1], self.dZ, False)
         if p.distance_cost_scale is not None:
             lo = self.off_ang if self.use_ang else self.off_dih
@@ -268,12 +271,8 @@ class ADCEngine(SequentialEngine):
             _lib.sketchmap_fwd_bwd(self.feat[:, lo:hi], Z, per, p.dist_sig_parameters, float(p.distance_cost_scale), 0.0, 0, B,
                                    t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws)
             self.dZ.add_(self.dZ2)
-        else:
-            t[T_DIST].zero_()
         _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
         self._wgrad()
-        if self.dp.active:
-            pass
 
     # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
     @torch.no_grad()
