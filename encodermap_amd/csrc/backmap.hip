@@ -416,44 +416,73 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
     st3(Sd + (long)i * SW + 9, p2 - mul(Q, p2));
   }
   __syncthreads();
-  // ---- phase B: the serial part, LDS only (every lane runs it, lane 0 writes)
+  // ---- phase B: the serial part, out of LDS.  The state of a recurrence is a 3 x 4 matrix, [R | t] or [Rb | tb]; lane
+  //      4 r + c of the wave's first three quads holds element (r, c), and a step is  state <- state x (4 x 4 step matrix):
+  //      four FMAs per lane whose left factors are the row's elements, broadcast inside the quad (DPP quad_perm), and whose
+  //      right factors are one column of the step matrix, fetched from LDS one step ahead.  ~50 dependent cycles per step
+  //      instead of the ~40 FMAs of a whole 3 x 3 product issued for one useful lane.
   {
-    M3 R = identity();
-    V3 tr{0.f, 0.f, 0.f};
-    M3 Rb;
-    V3 tb{0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 3; ++r)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) Rb.m[r][c] = 0.f;
-    for (int k = 0; k < nd; ++k) {
-      if (role == 0) {   // ascending: step k
+    const int qc = lane & 3, qr = min(lane >> 2, 2);
+    const bool keep = lane < 12, mat = qc < 3;
+    auto step_product = [](float val, const float (&Bv)[4]) {
+      const int iv = __builtin_bit_cast(int, val);
+      const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x00, 0xF, 0xF, true));
+      const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x55, 0xF, 0xF, true));
+      const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xF, 0xF, true));
+      const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0xFF, 0xF, 0xF, true));
+      return fmaf(a3, Bv[3], fmaf(a2, Bv[2], fmaf(a1, Bv[1], a0 * Bv[0])));
+    };
+    if (role == 0) {
+      // ascending:  [R | t] <- [R | t] [[Q, c], [0, 1]]   (R_i = R_{i-1} Q_i,  t_i = R_{i-1} c_i + t_{i-1})
+      const int o0 = mat ? qc : 9, o1 = mat ? 3 + qc : 10, o2 = mat ? 6 + qc : 11;
+      const float b3 = mat ? 0.f : 1.f;
+      float val = (mat && qc == (lane >> 2)) ? 1.f : 0.f;
+      float Bn[4] = {0.f, 0.f, 0.f, b3};
+      if (nd > 0) {
+        Bn[0] = Sd[o0];
+        Bn[1] = Sd[o1];
+        Bn[2] = Sd[o2];
+      }
+      for (int k = 0; k < nd; ++k) {
         float* q = Sd + (long)k * SW;
-        const M3 Q = lds_get9(q);
-        const V3 c = ld3(q + 9);
-        tr = mul(R, c) + tr;
-        R = mul(R, Q);
-        if (BWD) {
-          if (lane == 0) lds_put9(q + 12, R);
-        } else if (lane == 0) {
-          lds_put9(q, R);
-          st3(q + 9, tr);
+        const float Bv[4] = {Bn[0], Bn[1], Bn[2], b3};
+        const float* qn = Sd + (long)min(k + 1, nd - 1) * SW;
+        Bn[0] = qn[o0];
+        Bn[1] = qn[o1];
+        Bn[2] = qn[o2];
+        val = step_product(val, Bv);
+        if (keep) {
+          if (BWD) {
+            if (mat) q[12 + 3 * qr + qc] = val;
+          } else {
+            q[mat ? 3 * qr + qc : 9 + qr] = val;
+          }
         }
       }
-      if (BWD && role == 1) {   // descending: step j
-        const int j = nd - 1 - k;
-        float* q = Sd + (long)j * SW;
+    } else if (BWD) {
+      // descending:  [Rb | tb] += g (x) [p | 1]  (kept for phase C), then  [Rb | tb] <- [Rb | tb] [[Q^T, 0], [c^T, 1]]
+      const int o0 = mat ? 3 * qc : 0, o1 = o0 + 1, o2 = o0 + 2, o3 = mat ? 9 + qc : 0;
+      float val = 0.f;
+      auto fetch = [&](int j, float (&Bv)[4], float& gr, float& pp) {
+        const float* q = Sd + (long)j * SW;
         const int a3 = g.atom(dir, j + 3);
-        const V3 gk = ld3(Gf + 3 * a3), p3 = ld3(Pf + 3 * a3);
-        Rb = add(Rb, outer(gk, p3));
-        tb = tb + gk;
-        if (lane == 0) {
-          lds_put9(q + 24, Rb);
-          st3(q + 21, tb);
-        }
-        const M3 Q = lds_get9(q);
-        const V3 c = ld3(q + 9);
-        Rb = add(mulBT(Rb, Q), outer(tb, c));
+        gr = Gf[3 * a3 + qr];
+        pp = mat ? Pf[3 * a3 + qc] : 1.f;
+        Bv[0] = mat ? q[o0] : 0.f;
+        Bv[1] = mat ? q[o1] : 0.f;
+        Bv[2] = mat ? q[o2] : 0.f;
+        Bv[3] = mat ? q[o3] : 1.f;
+      };
+      float Bn[4] = {0.f, 0.f, 0.f, 0.f}, gn = 0.f, pn = 0.f;
+      if (nd > 0) fetch(nd - 1, Bn, gn, pn);
+      for (int j = nd - 1; j >= 0; --j) {
+        float* q = Sd + (long)j * SW;
+        const float Bv[4] = {Bn[0], Bn[1], Bn[2], Bn[3]};
+        const float gr = gn, pp = pn;
+        fetch(max(j - 1, 0), Bn, gn, pn);
+        val = fmaf(gr, pp, val);
+        if (keep) q[mat ? 24 + 3 * qr + qc : 21 + qr] = val;
+        val = step_product(val, Bv);
       }
     }
   }
