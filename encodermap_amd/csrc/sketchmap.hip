@@ -40,6 +40,8 @@ namespace {
 using namespace emx;
 
 constexpr int NT = 256;
+constexpr int KSPLIT_MAX_NB = 10;      // batches of up to 640 rows may split the reduction of a tile over several workgroups
+constexpr int KSPLIT_BLOCKS = 512;     // ... over at most this many in total
 constexpr int KC = 32;       // feature chunk staged per iteration
 constexpr int LS = KC + 4;   // padded LDS row stride (floats)
 
@@ -68,6 +70,11 @@ struct SkArgs {
   SigDev sh, sl;
   SplitRows split;   // optional bf16 planes + norms of the rows (split.h): selects the bf16 Gram kernel
   int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
+  // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of a first launch
+  // (kmode 1: Gram partial of its chunks -> kpart), a second launch (kmode 2) adds them up in a fixed order and runs the
+  // epilogue.  kmode 0: one workgroup per tile does both.
+  int ksplit, kmode;
+  float* kpart;      // [tiles][ksplit][4 waves][16][64]
 };
 
 template <int N>
@@ -623,14 +630,16 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
 
-  int ti, tj, tslot = blockIdx.x;
+  const int kmode = NCH == 0 ? a.kmode : 0;
+  const int tile_id = kmode == 1 ? (int)blockIdx.x / a.ksplit : (int)blockIdx.x;
+  int ti, tj, tslot = tile_id;
   if (a.xcd_nbg > 0) {
     if (!xcd_tile(blockIdx.x, a.xcd_nbg, a.nbc, ti, tj, tslot)) return;
   } else if (a.symm) {
-    tri_decode(blockIdx.x, a.nbc, ti, tj);
+    tri_decode(tile_id, a.nbc, ti, tj);
   } else {
-    ti = blockIdx.x / a.nbc;
-    tj = blockIdx.x - ti * a.nbc;
+    ti = tile_id / a.nbc;
+    tj = tile_id - ti * a.nbc;
   }
   const int i0 = a.row0 + ti * T;
   const int j0 = tj * T;
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     }                                                                                                                   \
     if ((cc) < 4) KSTAMP(3 + 2 * (cc));                                                                                 \
   }
-  SK_GLOAD(0)   // ahead of the small prologue loads
+  if (kmode == 0) SK_GLOAD(0)   // ahead of the small prologue loads
   KSTAMP(1);
   for (int e = tid; e < 2 * T; e += NT) {             // (norm, 1/scale) of both sides' rows
     const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
@@ -699,8 +708,26 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if constexpr (NCH > 0) {
 #pragma unroll
     for (int c = 0; c < NCH; ++c) SK_CHUNK(c, c + 1 < NCH)
-  } else {
+  } else if (kmode == 0) {
     for (int c = 0; c < nch; ++c) SK_CHUNK(c, true)   // (the last request re-reads its own chunk)
+  } else if (kmode == 1) {
+    // this workgroup's share of the chunks; its Gram partial goes to kpart and the workgroup is done
+    const int sidx = (int)blockIdx.x - tile_id * a.ksplit;
+    const int c0 = (int)((long)sidx * nch / a.ksplit), c1 = (int)((long)(sidx + 1) * nch / a.ksplit);
+    if (c0 < c1) {
+      SK_GLOAD(c0)
+      for (int c = c0; c < c1; ++c) SK_CHUNK(c, true)
+    }
+    float* dst = a.kpart + ((long)blockIdx.x * 4 + wave) * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
+    return;
+  } else {
+    // the partials of the first launch, added in the order of the chunks
+    const float* src = a.kpart + ((long)tile_id * a.ksplit * 4 + wave) * 1024 + lane;
+    for (int sidx = 0; sidx < a.ksplit; ++sidx)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += src[(long)sidx * 4096 + 64 * r];
   }
 #undef SK_CHUNK
 #undef SK_GLOAD
@@ -917,7 +944,8 @@ extern "C" {
 size_t emx_sketchmap_ws_bytes(int B, int L) {
   if (B <= 0 || L <= 0) return 0;
   size_t nb = (size_t)(B + 63) / 64;
-  return (nb * nb * 64 * (size_t)L + nb * nb + 64) * sizeof(float);
+  // + the Gram partials of the split reduction (small batches: at most KSPLIT_BLOCKS workgroups x 64 x 64 floats)
+  return (nb * nb * 64 * (size_t)L + nb * nb + 64 + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 : 0)) * sizeof(float);
 }
 
 }  // extern "C" (ws_bytes)
@@ -979,6 +1007,12 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   float* wsf = static_cast<float*>(ws);
   a.P = wsf;
   a.tile_loss = wsf + (size_t)nslots * a.nrows_pad * L;
+  a.ksplit = 1;
+  a.kmode = 0;
+  {
+    const size_t nb = (size_t)(B + 63) / 64;
+    a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + (nb * nb * 64 * (size_t)L + nb * nb + 64) : nullptr;
+  }
   FinArgs& f = pl.f;
   f.P = a.P;
   f.tile_loss = a.tile_loss;
@@ -1016,6 +1050,24 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     if (a.symm && a.nbc >= 16 && xcd_order) {   // XCD-aware tile order (xcd_tile): 8 x the largest share, the surplus blocks leave at once
       b.xcd_nbg = (a.nbc + 3) / 4;
       grid = 8 * b.xcd_nbg * (b.xcd_nbg + 1);
+    }
+    // few tiles, many chunks (a small batch of very long rows, e.g. the pair-distance vectors of the ADC model): the tiles
+    // alone would occupy a handful of CUs -- split each tile's reduction over workgroups (first launch), add the partials
+    // up and run the epilogue (second launch)
+    const int ksplit = (b.kpart && b.xcd_nbg == 0 && nch >= 16) ? std::min(std::min(32, nch / 4), KSPLIT_BLOCKS / std::max(pl.ntiles, 1)) : 1;
+    if (ksplit > 1) {
+      b.ksplit = ksplit;
+      for (int mode = 1; mode <= 2; ++mode) {
+        b.kmode = mode;
+        const dim3 gk(mode == 1 ? pl.ntiles * ksplit : pl.ntiles);
+        if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), gk, dim3(NT), 0, st, b);
+        else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), gk, dim3(NT), 0, st, b);
+        else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), gk, dim3(NT), 0, st, b);
+        else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), gk, dim3(NT), 0, st, b);
+        const int rck = emx::check_launch("sk_tile_f16_kernel (split reduction)");
+        if (rck) return rck;
+      }
+      return EMX_OK;
     }
     if (a.L == 2 && pl.fast && nch == 4) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 4>), dim3(grid), dim3(NT), 0, st, b);
     else if (a.L == 2 && pl.fast && nch == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 2>), dim3(grid), dim3(NT), 0, st, b);
