@@ -18,6 +18,7 @@ struct CostArgs {
   float* loss;
   int ldy, ldt, off_sin, off_cos, periodic_output;
   int n, row_begin, row_end, variant, wrap, prescale;
+  int wide;   // stand-alone kernel: one workgroup per row (long rows) instead of one wave
   float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
 };
 

@@ -110,9 +110,12 @@ __global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
   __shared__ float red[8];
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6;
-  const int nwaves = (gridDim.x * NT) >> 6;
+  // long rows (a.wide): a row per workgroup, the columns over all its threads -- a wave per row walks 45 dependent
+  // iterations over a 2850-column row while most of the chip idles behind a 256-row batch
+  const int lane = a.wide ? threadIdx.x : threadIdx.x & 63;
+  const int kstep = a.wide ? NT : 64;
+  const int wave = a.wide ? blockIdx.x : (blockIdx.x * NT + threadIdx.x) >> 6;
+  const int nwaves = a.wide ? gridDim.x : (gridDim.x * NT) >> 6;
   float lsum = 0.f;
   for (int b = a.row_begin + wave; b < a.row_end; b += nwaves) {
     const float* yrow = a.y + (long)b * a.ldy;
@@ -137,7 +140,7 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
         cost_store(a, drow, addrow, k, gn * delta * inv * dd, s, c);
       }
     } else {
-      for (int k = lane; k < a.n; k += 64) {
+      for (int k = lane; k < a.n; k += kstep) {
         float s, c, delta, dd;
         cost_elem(a, yrow, trow, k, s, c, delta, dd);
         float g;
@@ -463,7 +466,8 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   a.row_begin = row_begin;
   a.row_end = row_end;
   a.prescale = loss ? 0 : 1;
-  const int grid = grid_for(row_end - row_begin, 4);
+  a.wide = (n >= 1024 && variant != EMX_MEAN_NORM) ? 1 : 0;
+  const int grid = a.wide ? std::min(row_end - row_begin, EMX_REDUCE_WS) : grid_for(row_end - row_begin, 4);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
   int rc = emx::check_launch("periodic_cost_kernel");
