@@ -637,9 +637,10 @@ __global__ __launch_bounds__(NT) void pdist_fwd_kernel(const float* __restrict__
   for (long p = P + threadIdx.x; p < ldo; p += NT) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
 }
 
-// one thread per selected atom gathers its C-1 pair terms (deterministic, no atomics)
+// one thread per selected atom gathers its C-1 pair terms (deterministic, no atomics); the frame's gradient row is staged in
+// LDS first when it fits (stage_g) -- read in place, every thread walks C - 1 dependent scattered global loads
 __global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
-                                                       int step, int C, int ldo, float* __restrict__ dxyz, int accumulate) {
+                                                       int step, int C, int ldo, float* __restrict__ dxyz, int accumulate, int stage_g) {
   extern __shared__ float sx[];
   const int b = blockIdx.x;
   const float* X = xyz + (long)b * A * 3;
@@ -647,8 +648,14 @@ __global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__
     int c = e / 3, k = e - 3 * c;
     sx[e] = X[3 * (start + step * c) + k];
   }
-  __syncthreads();
   const float* g = dout + (long)b * ldo;
+  if (stage_g) {
+    float* sg = sx + 3 * C;
+    const int P = C * (C - 1) / 2;
+    for (int e = threadIdx.x; e < P; e += NT) sg[e] = g[e];
+    g = sg;
+  }
+  __syncthreads();
   float* D = dxyz + (long)b * A * 3;
   if (!accumulate) {
     // atoms that are not selected receive zero
@@ -1051,9 +1058,12 @@ int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int st
   EMX_REQUIRE(xyz && dout && dxyz && B > 0 && A > 0 && C >= 2 && step >= 1 && start >= 0, "emx_pdist_flat_bwd: bad arguments");
   EMX_REQUIRE(start + (long)step * (C - 1) < A, "emx_pdist_flat_bwd: atom selection outside the frame");
   EMX_REQUIRE(ldo >= (long)C * (C - 1) / 2, "emx_pdist_flat_bwd: gradient row stride too small");
-  const size_t lds = (size_t)3 * C * sizeof(float);
+  size_t lds = (size_t)3 * C * sizeof(float);
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_bwd: %d atoms do not fit the LDS frame buffer", C);
-  hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate);
+  const size_t with_g = lds + (size_t)C * (C - 1) / 2 * sizeof(float);
+  const int stage_g = with_g <= 64 * 1024;
+  if (stage_g) lds = with_g;
+  hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate, stage_g);
   return emx::check_launch("pdist_bwd_kernel");
 }
 
