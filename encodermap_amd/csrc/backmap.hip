@@ -343,6 +343,16 @@ __global__ __launch_bounds__(NT) void d2c_bwd_kernel(const float* __restrict__ d
 // The thread-per-frame kernels above (global loads and library sincosf inside the serial loop, 256 threads on the
 // whole chip) took 97 us forward and 667 us backward at B = 256, A = 228; they remain for frames that do not fit LDS.
 // ---------------------------------------------------------------------------------------------------------
+#ifdef EMX_D2C_TIMING   // per-phase timeline of workgroup 0 (tools/abl_d2c.py)
+__device__ long long emx_dbg_d2c[64];
+#define DSTAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) emx_dbg_d2c[(BWD ? 32 : 0) + 8 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
+#else
+#define DSTAMP(k)
+#endif
+template <int V>
+struct RingIdx {
+  static constexpr int value = V;
+};
 constexpr int FR_NT_FWD = 128, FR_NT_BWD = 256;   // backward: waves 2, 3 run the adjoint recurrence of the two parts
 
 __device__ __forceinline__ void lds_put9(float* d, const M3& m) {
@@ -399,11 +409,13 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   const int n = g.natoms(dir), nd = max(n - 3, 0);
   const int nd0 = max(g.natoms(0) - 3, 0);
   float* Sd = S + (long)(dir ? nd0 : 0) * SW;
+  DSTAMP(0);
   for (int e = tid; e < 3 * A; e += FR_NT) {
     Pf[e] = P[e];
     if (BWD) Gf[e] = dout[(long)b * A * 3 + e];
   }
   __syncthreads();
+  DSTAMP(1);
   // ---- phase A
   for (int i = slane; i < nd; i += LSTEP) {
     const V3 p1 = ld3(Pf + 3 * g.atom(dir, i + 1)), p2 = ld3(Pf + 3 * g.atom(dir, i + 2));
@@ -416,6 +428,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
     st3(Sd + (long)i * SW + 9, p2 - mul(Q, p2));
   }
   __syncthreads();
+  DSTAMP(2);
   // ---- phase B: the serial part, out of LDS.  The state of a recurrence is a 3 x 4 matrix, [R | t] or [Rb | tb]; lane
   //      4 r + c of the wave's first three quads holds element (r, c), and a step is  state <- state x (4 x 4 step matrix):
   //      four FMAs per lane whose left factors are the row's elements, broadcast inside the quad (DPP quad_perm), and whose
@@ -437,19 +450,23 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
       const int o0 = mat ? qc : 9, o1 = mat ? 3 + qc : 10, o2 = mat ? 6 + qc : 11;
       const float b3 = mat ? 0.f : 1.f;
       float val = (mat && qc == (lane >> 2)) ? 1.f : 0.f;
-      float Bn[4] = {0.f, 0.f, 0.f, b3};
+      // right factors two steps ahead, in a ring of three register sets addressed at compile time (a rotation by register
+      // moves would wait for the load it has just issued): the LDS latency of a step's column stays off the serial path
+      float Bf[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
       if (nd > 0) {
-        Bn[0] = Sd[o0];
-        Bn[1] = Sd[o1];
-        Bn[2] = Sd[o2];
+        const float* qa = Sd;
+        const float* qb = Sd + (long)min(1, nd - 1) * SW;
+        Bf[0][0] = qa[o0]; Bf[0][1] = qa[o1]; Bf[0][2] = qa[o2];
+        Bf[1][0] = qb[o0]; Bf[1][1] = qb[o1]; Bf[1][2] = qb[o2];
       }
-      for (int k = 0; k < nd; ++k) {
-        float* q = Sd + (long)k * SW;
-        const float Bv[4] = {Bn[0], Bn[1], Bn[2], b3};
-        const float* qn = Sd + (long)min(k + 1, nd - 1) * SW;
-        Bn[0] = qn[o0];
-        Bn[1] = qn[o1];
-        Bn[2] = qn[o2];
+      auto fstep = [&](auto RC, const int k) {
+        constexpr int r = decltype(RC)::value, rn = (r + 2) % 3;
+        float* q = Sd + k * SW;
+        const float* qn = Sd + min(k + 2, nd - 1) * SW;
+        Bf[rn][0] = qn[o0];
+        Bf[rn][1] = qn[o1];
+        Bf[rn][2] = qn[o2];
+        const float Bv[4] = {Bf[r][0], Bf[r][1], Bf[r][2], b3};
         val = step_product(val, Bv);
         if (keep) {
           if (BWD) {
@@ -458,6 +475,11 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
             q[mat ? 3 * qr + qc : 9 + qr] = val;
           }
         }
+      };
+      for (int k = 0; k < nd; k += 3) {
+        fstep(RingIdx<0>{}, k);
+        if (k + 1 < nd) fstep(RingIdx<1>{}, k + 1);
+        if (k + 2 < nd) fstep(RingIdx<2>{}, k + 2);
       }
     } else if (BWD) {
       // descending:  [Rb | tb] += g (x) [p | 1]  (kept for phase C), then  [Rb | tb] <- [Rb | tb] [[Q^T, 0], [c^T, 1]]
@@ -473,20 +495,30 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
         Bv[2] = mat ? q[o2] : 0.f;
         Bv[3] = mat ? q[o3] : 1.f;
       };
-      float Bn[4] = {0.f, 0.f, 0.f, 0.f}, gn = 0.f, pn = 0.f;
-      if (nd > 0) fetch(nd - 1, Bn, gn, pn);
-      for (int j = nd - 1; j >= 0; --j) {
-        float* q = Sd + (long)j * SW;
-        const float Bv[4] = {Bn[0], Bn[1], Bn[2], Bn[3]};
-        const float gr = gn, pp = pn;
-        fetch(max(j - 1, 0), Bn, gn, pn);
-        val = fmaf(gr, pp, val);
+      // (two steps ahead in a ring of three register sets, as above)
+      float Bq[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f};
+      if (nd > 0) {
+        fetch(nd - 1, Bq[0], gq[0], pq[0]);
+        fetch(max(nd - 2, 0), Bq[1], gq[1], pq[1]);
+      }
+      auto bstep = [&](auto RC, const int j) {
+        constexpr int r = decltype(RC)::value, rn = (r + 2) % 3;
+        float* q = Sd + j * SW;
+        fetch(max(j - 2, 0), Bq[rn], gq[rn], pq[rn]);
+        val = fmaf(gq[r], pq[r], val);
         if (keep) q[mat ? 24 + 3 * qr + qc : 21 + qr] = val;
-        val = step_product(val, Bv);
+        val = step_product(val, Bq[r]);
+      };
+      for (int j = nd - 1; j >= 0; j -= 3) {
+        bstep(RingIdx<0>{}, j);
+        if (j - 1 >= 0) bstep(RingIdx<1>{}, j - 1);
+        if (j - 2 >= 0) bstep(RingIdx<2>{}, j - 2);
       }
     }
   }
+  DSTAMP(3);
   __syncthreads();
+  DSTAMP(4);
   // ---- phase C
   if (!BWD) {
     float* O = out + (long)b * A * 3;
@@ -536,6 +568,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
     st3(q + 3, ob);
     st3(q + 6, V3{-wb.x, -wb.y, -wb.z});
   }
+  DSTAMP(5);
   __syncthreads();
   // ---- phase D: every atom collects what it receives: pass-through (atoms s-1 .. s+1), then right part, then left part
   float* DP = dplane + (long)b * A * 3;
@@ -557,6 +590,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
     }
     st3(DP + 3 * a, acc);
   }
+  DSTAMP(6);
 }
 
 // K6, one wave per frame: the angle recurrence is one subtraction per step (serial, LDS), sin/cos and the partial sums of
@@ -1074,6 +1108,10 @@ int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, 
                      dihedrals);
   return emx::check_launch("featurize_kernel");
 }
+
+#ifdef EMX_D2C_TIMING
+extern "C" int emx_debug_read_d2c(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_d2c), sizeof(emx_dbg_d2c)); }
+#endif
 
 int emx_allatom_mask_words(int A) { return A > 0 ? ((A + 2047) / 2048) * 64 : 0; }
 
