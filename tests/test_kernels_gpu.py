@@ -468,6 +468,7 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     (300, 7, 3, (2.0, 3, 6, 1, 2, 6), 0, 300), (130, 4, 4, (1.5, 12, 6, 1, 2, 6), 0, 130), (1030, 16, 2, (8.0, 12, 6, 1, 2, 6), 515, 1030),
     (4096, 128, 2, (16.0, 12, 6, 1, 2, 6), 0, 4096),
     # few tiles, many features: the reduction of a tile is split over workgroups (ADC: pair-distance vectors as points)
+    (1100, 40, 2, (10.0, 12, 6, 1, 2, 6), 0, 1100),      # 18 tile columns: ragged last group of the XCD-aware tile order
     (256, 2850, 2, (80.0, 10, 5, 1, 2, 5), 0, 256), (200, 1000, 3, (45.0, 12, 6, 1, 2, 6), 0, 200), (320, 700, 2, (40.0, 12, 6, 1, 2, 6), 160, 320)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct
