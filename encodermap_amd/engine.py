@@ -214,6 +214,7 @@ class SequentialEngine:
     _cost_in_forward = True                                          # auto cost inside the forward launch (False: layers too wide)
     _graph_steps = max(1, int(os.environ.get("EMX_GRAPH_STEPS", "8")))   # steps per replay of the multi-step graph (1: single-step graph only)
     _graph_multi = None
+    _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (opt-in)
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -414,7 +415,32 @@ class SequentialEngine:
         gc.collect()
         gc.disable()
         try:
-            if self.dp.active:
+            captured = False
+            if self.dp.active and self._dp_graph_allreduce:
+                # opt-in (EMX_DP_GRAPH_ALLREDUCE=1): the RCCL all-reduce captured inside the step's graph, so that the step
+                # is one graph again and replays eight at a time.  Measured with a one-rank RCCL group: 113 -> 94 us per
+                # step (tools/bench_dp_structure.py).  Not the default: it could not be run with more than one GPU here.
+                # (thread-local capture mode: the process group's watchdog thread must not invalidate the capture)
+                try:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                        self._step_body()
+                    gm = None
+                    if self._graph_steps > 1:
+                        restore()
+                        gm = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gm, pool=g.pool(), capture_error_mode="thread_local"):
+                            for _ in range(self._graph_steps):
+                                self._step_body()
+                    self._graph, self._graph_multi, captured = (g,), gm, True
+                except Exception as exc:   # fall back to the two-graph form
+                    print(f"encodermap_amd: capturing the all-reduce failed ({type(exc).__name__}: {exc}); using the eager all-reduce")
+                    self._dp_graph_allreduce = False
+                    torch.cuda.synchronize()
+                    restore()
+            if captured:
+                pass
+            elif self.dp.active:
                 g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g1):
                     self._step_pre()

@@ -77,3 +77,48 @@ def test_two_ranks_on_one_gpu(mode, tmp_path):
         np.testing.assert_allclose(r0["loss"], e._engine.losses(), rtol=2e-5)
         diff = np.abs(r0["w"] - e._engine.w.cpu().numpy())
         assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3
+
+
+def _one_rank_rccl_worker(rank, port, out_dir):
+    """The data-parallel path over RCCL itself, with the one rank a single GPU allows: two hipGraphs around the eager
+    all-reduce, and (EMX_DP_GRAPH_ALLREDUCE=1) the all-reduce captured inside the step's graph."""
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    import encodermap_amd as em
+    from encodermap_amd.engine import DataParallel, SequentialEngine
+
+    class OneRank(DataParallel):
+        @property
+        def active(self):
+            return True
+
+    data = _data()
+    out = {}
+    for name, captured in (("eager", False), ("captured", True)):
+        SequentialEngine._dp_graph_allreduce = captured
+        p = em.Parameters(n_steps=20, batch_size=256, seed=11)
+        e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=OneRank(0, 1, "replica"))
+        e._engine.run_steps(20)
+        out[name] = e._engine.losses()
+        out[name + "_w"] = e._engine.w.cpu().numpy()
+    p = em.Parameters(n_steps=20, batch_size=256, seed=11)
+    e = em.EncoderMap(p, data, model=_weights(p), read_only=True)
+    e._engine.run_steps(20)
+    out["single"] = e._engine.losses()
+    np.savez(os.path.join(out_dir, "one_rank.npz"), **out)
+    dist.destroy_process_group()
+
+
+def test_one_rank_over_rccl(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "one_rank.npz")
+    assert np.isfinite(r["eager"]).all() and len(r["eager"]) == 20
+    np.testing.assert_array_equal(r["eager"], r["captured"])          # same kernels, same order: bitwise the same run
+    np.testing.assert_array_equal(r["eager_w"], r["captured_w"])
+    np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-5)    # one rank averages with itself: the single-process run
