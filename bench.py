@@ -126,6 +126,29 @@ def kernel_roofline(eng, launches):
                     "VALU-issue bound (epilogue ~40 instructions per pair)"}
 
 
+def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
+    """N > 1: one child process per rank checks, BEFORE this process touches the GPU, whether an RCCL all-reduce captured in
+    a hipGraph works with this many ranks on this machine (encodermap_amd/_probe_graph_allreduce.py).  Passed on every
+    rank: the data-parallel step runs as one graph, eight steps per replay; failed, or hung until the
+    timeout (the child is killed, its queues go with it): the all-reduce stays eager between two graphs."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["EMX_PROBE_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 173)
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    try:
+        proc = subprocess.Popen([sys.executable, "-m", "encodermap_amd._probe_graph_allreduce"], cwd=ROOT, env=env,
+                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except Exception:
+        return False
+    try:
+        return proc.wait(timeout=timeout_s) == 0
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        proc.wait()
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -144,6 +167,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     device = f"cuda:{local_rank}"
+    graph_allreduce = world > 1 and probe_graph_allreduce(world) if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None else \
+        os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1"
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
@@ -152,7 +177,14 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import encodermap_amd as em
-    from encodermap_amd.engine import DataParallel
+    from encodermap_amd.engine import DataParallel, SequentialEngine
+
+    if world > 1:
+        # every rank must take the same path: the captured all-reduce only if the probe passed on ALL ranks
+        flag = torch.tensor([1.0 if graph_allreduce else 0.0], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        graph_allreduce = bool(float(flag) == 1.0)
+        SequentialEngine._dp_graph_allreduce = graph_allreduce
 
     p = em.Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
     dp = DataParallel(rank, world, args.dp_mode) if world > 1 else None
@@ -189,6 +221,7 @@ def main():
             "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, batch 4096 per GPU, "
                                    "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
                        "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
+                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between two graphs") if world > 1 else None,
                        "hip_graph": True},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }

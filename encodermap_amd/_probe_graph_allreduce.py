@@ -1,0 +1,72 @@
+"""Probe: does an RCCL all-reduce captured inside a hipGraph work on THIS machine with THIS many ranks?
+
+Run as a child process by ``bench.py`` (one child per rank, before the parent touches the GPU; RANK / WORLD_SIZE /
+LOCAL_RANK / MASTER_ADDR come from the launcher, the children meet on their own port).  Exit code 0: a graph holding
+[scale, all_reduce(AVG), add] was captured and replayed 200 times with the right result on every rank.  Anything else --
+an exception, a wrong number, or a hang that the parent ends with its timeout -- means: keep the all-reduce eager
+(engine default).  A hang costs only this child: its queues die with it.
+"""
+import os
+import sys
+
+
+def main() -> int:
+    import torch
+    import torch.distributed as dist
+
+    rank, world, local = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ["MASTER_PORT"] = os.environ["EMX_PROBE_PORT"]
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    n = 66700 + 8                                   # the flat [gradient | loss terms] buffer of the benchmark model
+    x = torch.full((n,), float(rank + 1), device="cuda")
+    for _ in range(3):                              # communicator set-up and warm-up outside any capture
+        dist.all_reduce(x, op=dist.ReduceOp.AVG)
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(8):                      # eight "steps" per graph, as the engine replays them
+                x.mul_(2.0)
+                dist.all_reduce(x, op=dist.ReduceOp.AVG)
+                x.add_(1.0)
+    torch.cuda.current_stream().wait_stream(s)
+    x.fill_(float(rank + 1))
+    torch.cuda.synchronize()
+    for _ in range(25):
+        g.replay()
+    torch.cuda.synchronize()
+    # (x has overflowed to inf by now -- v <- 2 v + 1, 200 times: that graph only has to replay without hanging.)  The
+    # number that is checked comes from a bounded recurrence:  y <- mean_ranks(y) / 2 + (rank + 1)
+    y = torch.full((n,), float(rank + 1), device="cuda")
+    gy = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(gy, capture_error_mode="thread_local"):
+            dist.all_reduce(y, op=dist.ReduceOp.AVG)
+            y.mul_(0.5).add_(float(rank + 1))
+    torch.cuda.current_stream().wait_stream(s)
+    y.fill_(float(rank + 1))
+    torch.cuda.synchronize()
+    ref = [float(r + 1) for r in range(world)]
+    for _ in range(200):
+        gy.replay()
+        m = sum(ref) / world
+        ref = [0.5 * m + (r + 1) for r in range(world)]
+    torch.cuda.synchronize()
+    ok = abs(float(y[0]) - ref[rank]) < 1e-3 * max(1.0, abs(ref[rank])) and bool((y == y[0]).all())
+    flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    torch.cuda.synchronize()
+    dist.destroy_process_group()
+    return 0 if float(flag) == 1.0 else 3
+
+
+if __name__ == "__main__":
+    try:
+        code = main()
+    except Exception as exc:   # noqa: BLE001
+        sys.stderr.write(f"probe failed: {type(exc).__name__}: {exc}\n")
+        code = 2
+    sys.exit(code)
