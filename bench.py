@@ -133,7 +133,9 @@ def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
     timeout (the child is killed, its queues go with it): the all-reduce stays eager between two graphs."""
     import subprocess
 
-    env = dict(os.environ)
+    # the children rendezvous among themselves: nothing of the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE makes
+    # rank 0 a CLIENT of the launcher's store, which does not listen on the probe's port)
+    env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["EMX_PROBE_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 173)
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     try:
@@ -156,6 +158,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-mode", default="replica", choices=["replica", "rowblock"])
+    ap.add_argument("--one-rank-dp", action="store_true",
+                    help="N = 1 only: run the DATA-PARALLEL code path (probe, RCCL group, all-reduce) with its one rank -- a self-test, "
+                         "not a benchmark configuration")
     args = ap.parse_args()
 
     import torch
@@ -167,19 +172,27 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     device = f"cuda:{local_rank}"
-    graph_allreduce = world > 1 and probe_graph_allreduce(world) if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None else \
+    multi = world > 1 or (args.one_rank_dp and world == 1)
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]   # (RCCL's version banner goes to stdout, which is reserved for the JSON line)
+    if multi:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        os.environ.setdefault("LOCAL_RANK", "0")
+    graph_allreduce = multi and probe_graph_allreduce(world) if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None else \
         os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1"
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if multi:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
 
     import encodermap_amd as em
     from encodermap_amd.engine import DataParallel, SequentialEngine
 
-    if world > 1:
+    if multi:
         # every rank must take the same path: the captured all-reduce only if the probe passed on ALL ranks
         flag = torch.tensor([1.0 if graph_allreduce else 0.0], device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -188,13 +201,18 @@ def main():
 
     p = em.Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
     dp = DataParallel(rank, world, args.dp_mode) if world > 1 else None
+    if multi and world == 1:
+        class _OneRank(DataParallel):      # the data-parallel path with the one rank a single GPU allows
+            active = True
+
+        dp = _OneRank(0, 1, args.dp_mode)
     data = make_blobs(device, N_ROWS, D, seed=1)
     e = em.EncoderMap(p, __import__("numpy").zeros((B, D), "float32"), read_only=True, device=device, dp=dp)
     eng = e._engine
     eng.set_data(data)                      # 512 MB, resident in HBM before the timed region
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -204,7 +222,7 @@ def main():
     eng.run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -221,15 +239,24 @@ def main():
             "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, batch 4096 per GPU, "
                                    "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
                        "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
-                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between two graphs") if world > 1 else None,
+                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between two graphs") if multi else None,
                        "hip_graph": True},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }
         out["roofline"] = kernel_roofline(eng, max(args.steps, 50))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
+        # RCCL writes its version banner to the C-level stdout, which is flushed at exit -- behind this line unless it is
+        # flushed first; the JSON line must be the last thing on stdout
+        try:
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
