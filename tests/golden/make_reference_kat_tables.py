@@ -7,6 +7,8 @@ Sources (relative to AG-Peter/encodermap @ 2025-05-23):
   * tests/test_dihedral_to_cartesian.py:104-148  33x3 helix table (dihedrals [phi,psi,0]x10, straight chain of 33)
   * tests/test_dihedral_to_cartesian.py:186-197  7x3 straight_tetrahedral_chain(bond_lengths=[1,2,3,1,2,3])
   * tests/data/known_angles_{dists,angles,dihedrals}.npy + known_angles.pdb coordinates (6 frames x 4 atoms)
+  * tests/test_angles.py:72-103  the 28 backbone angles (rad) of tests/data/Ala10_helix.pdb, with the N/CA/C coordinates
+    of that file (30 atoms) as the input
 The tables are parsed out of the test file with a regex over numeric literals; no reference code is executed
 or copied.
 """
@@ -51,6 +53,14 @@ def main():
     out["known_angles_xyz_angstrom"] = frames
     for k in ("dists", "angles", "dihedrals"):
         out[f"known_angles_{k}"] = np.load(os.path.join(REF, f"tests/data/known_angles_{k}.npy")).tolist()
+    # Ala10 helix: backbone N, CA, C coordinates in residue order + the literal angle table of tests/test_angles.py
+    bb = [[float(l[30:38]), float(l[38:46]), float(l[46:54])] for l in open(os.path.join(REF, "tests/data/Ala10_helix.pdb"))
+          if l.startswith("ATOM") and l[12:16].strip() in ("N", "CA", "C")]
+    src_a = open(os.path.join(REF, "tests/test_angles.py")).read()
+    ala = numbers_between(src_a, "moldata.angles,", "def test_chain_in_plane")
+    assert len(bb) == 30 and len(ala) == 28, (len(bb), len(ala))
+    out["ala10_backbone_xyz_angstrom"] = bb
+    out["ala10_backbone_angles_rad"] = ala
     with open(os.path.join(HERE, "reference_kat_tables.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("helix", helix.shape, "chain", chain.shape, "frames", np.array(frames).shape)

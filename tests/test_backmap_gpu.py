@@ -181,6 +181,9 @@ def test_backbone_featurisation(L):
     np.testing.assert_allclose(f["central_distances"], np.array(T["known_angles_dists"]), atol=2e-4)
     np.testing.assert_allclose(np.rad2deg(f["central_angles"]), np.array(T["known_angles_angles"]), atol=1e-2)
     np.testing.assert_allclose(np.abs(np.rad2deg(f["central_dihedrals"])), np.abs(np.array(T["known_angles_dihedrals"])), atol=1e-2)
+    # the 28 backbone angles of Ala10_helix.pdb (reference tests/test_angles.py:72-103)
+    ala = em.featurize_backbone(np.array(T["ala10_backbone_xyz_angstrom"], np.float32)[None] / 10.0)
+    np.testing.assert_allclose(ala["central_angles"][0], np.array(T["ala10_backbone_angles_rad"]), atol=2e-5)
     # round trip: features of a back-mapped chain are the inputs of the back-mapping
     rng = np.random.default_rng(2)
     B, A = 40, 60

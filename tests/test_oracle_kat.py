@@ -244,6 +244,16 @@ def test_known_angles_fixture():  # tests/data/known_angles.pdb + known_angles_*
     np.testing.assert_allclose(np.abs(dih), np.abs(np.array(T["known_angles_dihedrals"])), atol=1e-2)
 
 
+def test_ala10_backbone_angle_table():  # tests/test_angles.py:72-103 (MolData.angles of tests/data/Ala10_helix.pdb)
+    T = _tables()
+    xyz = t64(np.array(T["ala10_backbone_xyz_angstrom"])[None] / 10.0)
+    v1 = xyz[:, :-2] - xyz[:, 1:-1]
+    v2 = xyz[:, 2:] - xyz[:, 1:-1]
+    ang = torch.acos((v1 * v2).sum(-1) / torch.linalg.norm(v1, dim=-1) / torch.linalg.norm(v2, dim=-1))
+    # the reference's own assertion is np.allclose with its defaults (rtol 1e-5, atol 1e-8); measured here: 2.4e-7 rad
+    np.testing.assert_allclose(ang.numpy()[0], np.array(T["ala10_backbone_angles_rad"]), rtol=1e-5, atol=1e-8)
+
+
 # ---- the two oracle statements agree (values and gradients) ----------------------------------
 @pytest.mark.parametrize("periodicity", [float("inf"), 2 * PI])
 @pytest.mark.parametrize("sig", [DEFAULT_SIG, (16.0, 12, 6, 1, 2, 6), (0.2, 3, 6, 1, 2, 6)])
