@@ -51,6 +51,7 @@ SIGNATURES = {
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
     "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "emx_l2_partials": (_i, [_p, _p, _l, _p, _p]),
+    "emx_adam_step_history": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
     "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
@@ -358,6 +359,19 @@ def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, w
     _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
                                 float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), md, mp,
                                 nb, int(bool(bookkeeping_done)), _stream()), "emx_adam_step")
+
+
+def adam_step_history(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, terms, n_terms, history, term_history, hstep,
+                      plan=None, next_batch=None):
+    """The optimizer launch of a data-parallel step: Adam on the all-reduced gradient (bookkeeping already done in front of
+    the collective) + the history row of the all-reduced cost terms (emx_adam_step_history)."""
+    md, mp = _mirror_args(plan)
+    nb = C.byref(next_batch) if next_batch is not None else None
+    cap = history.numel() if history is not None else (term_history.shape[0] if term_history is not None else 0)
+    _check(load().emx_adam_step_history(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1),
+                                        float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(ws), md, mp,
+                                        nb, _ptr(terms), int(n_terms), _ptr(history), _ptr(term_history), cap, _ptr(hstep), _stream()),
+           "emx_adam_step_history")
 
 
 def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None, next_batch=None,

@@ -212,6 +212,15 @@ struct AdamArgs {
   MirrorArgs mir;
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
   GatherArgs next;
+
+  // optional (emx_adam_step_history): the LAST workgroup of the launch writes the history row of the step whose counters are
+  // already advanced -- history[*hstep - 1] = sum(terms), term_history row -- from terms that were final when the launch began
+  const float* row_terms;
+  int row_n;
+  float* history;
+  float* term_history;
+  long capacity;
+  const int64_t* hstep;
 };
 
 __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, float l2c, const AdamArgs& a, float alpha,
@@ -280,10 +289,25 @@ __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
 __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   __shared__ float red[NT / 64];
   const int nt = blockDim.x;
+  if (a.hstep && blockIdx.x == gridDim.x - 1) {
+    if (threadIdx.x == 0) {
+      const long hs = *a.hstep - 1;
+      float tl[64];
+      for (int i = 0; i < a.row_n; ++i) tl[i] = a.row_terms[i];
+      float tot = 0.f;
+      for (int i = 0; i < a.row_n; ++i) tot += tl[i];
+      if (hs >= 0 && hs < a.capacity) {
+        if (a.history) a.history[hs] = tot;
+        if (a.term_history)
+          for (int i = 0; i < a.row_n; ++i) a.term_history[hs * a.row_n + i] = tl[i];
+      }
+    }
+    return;
+  }
   if ((int)blockIdx.x >= a.adam_blocks) {
     // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
     // beside it, on other CUs, instead of in a launch of their own at the head of the next step
-    const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks;
+    const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks - (a.hstep ? 1 : 0);
     gather_rows_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     return;
   }
@@ -555,6 +579,29 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
     rc = emx::check_launch("final_sum_kernel");
   }
   return rc;
+}
+
+int emx_adam_step_history(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float clip, const int64_t* step, float* ws, const emx_mlp_desc* mirror_desc, float* mirror,
+                          const emx_next_batch* next, const float* terms, int n_terms, float* history, float* term_history,
+                          int64_t capacity, const int64_t* hstep, emx_stream_t stream) {
+  int rcn = check_next(next, "emx_adam_step_history");
+  if (rcn) return rcn;
+  EMX_REQUIRE(w && g && m && v && step && ws && terms && hstep, "emx_adam_step_history: null pointer argument");
+  EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step_history: mirror without a valid descriptor");
+  EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && capacity >= 0, "emx_adam_step_history: bad sizes");
+  AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
+  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  a.late = 1;
+  a.next.batch_step = 0;
+  a.row_terms = terms;
+  a.row_n = n_terms;
+  a.history = history;
+  a.term_history = term_history;
+  a.capacity = (long)capacity;
+  a.hstep = hstep;
+  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next) + 1), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("adam_kernel");
 }
 
 int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_t partial_stride, float* m, float* v, const float* l2coef,

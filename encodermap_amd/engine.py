@@ -330,18 +330,30 @@ class SequentialEngine:
         emx_l2_partials at the start), and the optimizer runs last with ``bookkeeping_done``."""
         return not self.dp.active and self._fold_finish
 
+    def _dp_late_bookkeeping(self) -> bool:
+        """Data parallel: the rank's cost sums, the regulariser cost and the counters ride along with the weight-gradient
+        launch in front of the all-reduce (the terms travel in it); the optimizer launch behind it runs with the bookkeeping
+        done and writes the history row of the reduced terms itself (emx_adam_step_history) -- no launch for the epilogue."""
+        return self.dp.active and self._fold_finish
+
+    def _reg_job(self):
+        # the regulariser cost is the same on every rank: under the SUM all-reduce of the row-block mode each rank adds 1/G of it
+        scale = 1.0 / self.dp.world_size if (self.dp.active and self.dp.mode == "rowblock" and self._dp_late_bookkeeping()) else 1.0
+        return (self.red_ws2, _lib.EMX_REDUCE_WS, scale, None, self._reg_slot, False)
+
     def _wgrad(self) -> None:
         """Weight gradients.  Single GPU: the slice partials stay in the workspace and the Adam kernel adds them up
         itself; data parallel: reduced into the flat gradient buffer for the all-reduce."""
         n = len(self.layout.layers)
         fin = None
         if self._late_bookkeeping():
-            jobs = self._jobs_pre() + [(self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)]
+            jobs = self._jobs_pre() + [self._reg_job()]
             fin = _lib.make_finish_desc(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
-        elif self.dp.active and self._fold_finish and self._jobs_pre():
+        elif self._dp_late_bookkeeping():
             # the rank's shares of the cost terms, summed by the extra workgroup: they travel in the same all-reduce as the
-            # gradients (no history row, no counters here: those follow the optimizer)
-            fin = _lib.make_finish_desc(self._jobs_pre(), self.terms, N_TERMS)
+            # gradients; the counters advance here too, the history row follows the all-reduce (inside the optimizer launch)
+            fin = _lib.make_finish_desc(self._jobs_pre() + [self._reg_job()], self.terms, N_TERMS, None, None, self.hstep, self.cursor,
+                                        self.step)
         _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws, finish=fin)
         if fin is None and self.dp.active and self._jobs_pre():
             _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
@@ -350,7 +362,7 @@ class SequentialEngine:
         """clip + L2 + Adam (+ operand store, + the next batch), and -- unless it rode along with the weight gradients --
         ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost, history and counters."""
         p = self.p
-        reg_job = (self.red_ws2, _lib.EMX_REDUCE_WS, 1.0, None, self._reg_slot, False)
+        reg_job = self._reg_job()
         nxt = None
         if self._prefetch:
             nxt = _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
@@ -359,6 +371,11 @@ class SequentialEngine:
             _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
                                   p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt,
                                   bookkeeping_done=True)
+            return
+        if self._dp_late_bookkeeping():
+            _lib.adam_step_history(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step,
+                                   self.red_ws2, self.terms, N_TERMS, self.history, self.term_history, self.hstep, plan=self.plan,
+                                   next_batch=nxt)
             return
         if self.dp.active:
             _lib.adam_step(self.w, self.g, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, None, self.red_ws2,
@@ -373,7 +390,7 @@ class SequentialEngine:
     def _sync_derived_state(self) -> None:
         """After the weights were written by anything but the optimizer: operand store and regulariser shares."""
         self.plan.refresh_mirror()
-        if self._late_bookkeeping():
+        if self._late_bookkeeping() or self._dp_late_bookkeeping():
             _lib.l2_partials(self.w, self.l2coef, self.red_ws2)
 
     def _step_body(self) -> None:

@@ -227,6 +227,18 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
  * for the weights a run starts from. */
 int emx_l2_partials(const float* w, const float* l2coef, int64_t n, float* ws /* EMX_REDUCE_WS floats */, emx_stream_t stream);
 
+/* The optimizer launch of a DATA-PARALLEL step: emx_adam_step with bookkeeping_done = 1 on the
+ * all-reduced gradient g, plus one extra workgroup that writes the step's history row from the all-reduced cost terms:
+ *   history[*hstep - 1] = sum(terms[0 .. n_terms)),  term_history[(*hstep - 1) * n_terms + i] = terms[i]
+ * (*hstep was advanced by the emx_finish_desc that rode along with emx_mlp_wgrad, in front of the all-reduce, together with
+ * *step and *cursor; the row needs the REDUCED terms, so it is written here, behind it -- the Keras History entry of
+ * models.py:3399-3401).  No launch of its own for the scalar epilogue: a rank's step is five launches + one slice reduction
+ * + the collective.  history / term_history may be NULL. */
+int emx_adam_step_history(float* w, const float* g, float* m, float* v, const float* l2coef, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float clip, const int64_t* step, float* ws, const emx_mlp_desc* mirror_desc, float* mirror,
+                          const emx_next_batch* next, const float* terms, int n_terms, float* history, float* term_history,
+                          int64_t capacity, const int64_t* hstep, emx_stream_t stream);
+
 /* emx_adam_step + emx_step_tick behind one entry point, optionally consuming the weight-gradient slice partials of emx_mlp_wgrad_partials directly
  * (gradient = fixed-order sum over n_slices slices of g_partials[s * partial_stride + i]) so that no separate
  * reduction pass is needed on a single GPU.  terms[reg_slot] receives the regulariser cost; then
