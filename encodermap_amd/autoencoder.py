@@ -319,6 +319,9 @@ class Autoencoder:
     def encode(self, data: Optional[np.ndarray] = None) -> np.ndarray:
         """Projects ``data`` (default: the train data) to the latent space (autoencoder.py:1110-1152)."""
         if data is None:
+            eng = getattr(self, "_engine", None)
+            if eng is not None and eng.data is not None and tuple(eng.data.shape) == tuple(np.shape(self.train_data)):
+                return eng.encode_resident()      # the training set already lives in HBM: only the latent rows come back
             data = self.train_data
         if isinstance(data, (list, tuple)):
             raise Exception("a sequence of arrays is only valid for AngleDihedralCartesianEncoderMap")

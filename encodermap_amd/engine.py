@@ -585,6 +585,23 @@ class SequentialEngine:
         return out
 
     @torch.no_grad()
+    def encode_resident(self, chunk: int = 262144) -> np.ndarray:
+        """``encode`` of the training set from its HBM-resident copy (``set_data``): no host-to-device transfer, only the
+        [N, L] result crosses PCIe.  Same kernels, same chunking, hence the same numbers as ``encode(train_data)``."""
+        if self.data is None:
+            raise _lib.EmxError("encode_resident: no resident training set (set_data)")
+        lay, N = self.layout, self.data.shape[0]
+        out = torch.empty(N, self.L, dtype=torch.float32, device=self.device)
+        for s in range(0, N, chunk):
+            xc = self.data[s: s + chunk]
+            if self.periodic:
+                xin = torch.empty(xc.shape[0], self.net_dim, dtype=torch.float32, device=self.device)
+                _lib.periodic_in(xc, self.periodicity, xin)
+                xc = xin
+            out[s: s + chunk] = self._infer(xc, 0, lay.n_enc)
+        return out.cpu().numpy()
+
+    @torch.no_grad()
     def decode_raw(self, z: np.ndarray, chunk: int = 262144) -> np.ndarray:
         """Output of the last Dense layer (before the atan2 of periodic models)."""
         lay = self.layout

@@ -206,6 +206,10 @@ def test_facade_defaults_and_errors(em, tmp_path):
     e = em.EncoderMap(read_only=True)
     assert e.train_data.shape == (16000, 4) and e.p.periodicity == INF and e.p.using_hypercube
     assert e.encode().shape == (16000, 2)
+    # encode() of the train data runs on its HBM-resident copy: the same numbers as the explicit array, bit for bit
+    assert np.array_equal(e.encode(), e.encode(e.train_data))
+    ep = em.EncoderMap(em.Parameters(), np.random.default_rng(5).uniform(-PI, PI, (700, 6)).astype(np.float32), read_only=True)
+    assert np.array_equal(ep.encode(), ep.encode(ep.train_data))
     acts = [l.activation for l in e.model.layers]
     assert acts == ["tanh", "tanh", None, "tanh", "tanh", None]   # tests/test_autoencoder.py:1613-1646
     with pytest.raises(Exception, match="periodicity"):
