@@ -20,6 +20,7 @@ Step:
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional, Sequence
 
 import numpy as np
@@ -38,6 +39,7 @@ def _round4(n: int) -> int:
 
 class ADCEngine(SequentialEngine):
     _prefetch = False   # the feature block is assembled inside the step (gather + featurisation)
+    _fused_head = os.environ.get("EMX_ADC_HEAD", "1") != "0"   # gathers + sin/cos + soft start in one launch (A/B switch)
 
     TERM_NAMES = ADC_TERM_NAMES
     _reg_slot = T_REG
@@ -211,9 +213,17 @@ class ADCEngine(SequentialEngine):
         p, B, per = self.p, self.B, self.periodicity
         lay, n = self.layout, len(self.layout.layers)
         t = self.terms
-        _lib.gather_rows(self.data, self.idx_block, INF, self.feat, None, cursor=self.cursor, B=B)
-        _lib.gather_rows(self.data_cart, self.idx_block, INF, self.cart.view(B, -1), None, cursor=self.cursor, B=B)
-        self._encoder_input(self.feat, self.xin)
+        a, b = p.cartesian_cost_scale_soft_start if p.cartesian_cost_scale_soft_start is not None else (None, None)
+        c = p.cartesian_cost_scale
+        soft = (-1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b, 0.0 if c is None else float(c))
+        if self._fused_head:
+            # batch rows, encoder input and the soft-start scale of this step in one launch
+            _lib.adc_batch_head(self.data, self.data_cart, self.idx_block, self.cursor, B, self.feat, self.cart.view(B, -1), self.parts, per,
+                                self.xin, self.step, *soft, self.cart_scale)
+        else:
+            _lib.gather_rows(self.data, self.idx_block, INF, self.feat, None, cursor=self.cursor, B=B)
+            _lib.gather_rows(self.data_cart, self.idx_block, INF, self.cart.view(B, -1), None, cursor=self.cursor, B=B)
+            self._encoder_input(self.feat, self.xin)
         _lib.mlp_forward(self.plan, 0, n, self.xin, 0, B)
         Y, Z = self.h[-1], self.h[lay.n_enc - 1]
         self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
@@ -222,10 +232,8 @@ class ADCEngine(SequentialEngine):
         _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
 
         # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
-        a, b = p.cartesian_cost_scale_soft_start if p.cartesian_cost_scale_soft_start is not None else (None, None)
-        c = p.cartesian_cost_scale
-        _lib.soft_start_scale(self.step, -1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b,
-                              0.0 if c is None else float(c), self.cart_scale)
+        if not self._fused_head:
+            _lib.soft_start_scale(self.step, *soft, self.cart_scale)
         _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
                                    1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
                                    coef_scale=self.cart_scale)

@@ -844,6 +844,58 @@ __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, flo
   *out = sc;
 }
 
+// The head of an ADC step in one launch: the batch's feature rows and Cartesian rows by index, the sin/cos encoder input of
+// the angular blocks, and the soft-start scale of this step (a wave per row; thread 0 of the launch does the scalar).
+struct AdcHeadArgs {
+  const float* feat_data;
+  const float* cart_data;
+  const int64_t* idx;
+  const int64_t* cursor;
+  float* feat;
+  float* cart;
+  float* xin;
+  int B, F, C3, ld_xin, n_parts;
+  int off[4], n[4], col[4];
+  float ang_scale;
+  const int64_t* step;
+  float soft_a, soft_b, scale_c;
+  float* cart_scale;
+};
+
+__global__ __launch_bounds__(NT) void adc_head_kernel(const AdcHeadArgs a) {
+  if (a.cart_scale && blockIdx.x == 0 && threadIdx.x == 0) {
+    float sc = a.scale_c;
+    if (a.soft_a >= 0.f) {
+      const float t = (float)*a.step;
+      if (t < a.soft_a) sc = 0.f;
+      else if (t <= a.soft_b) sc = a.scale_c / (a.soft_b - a.soft_a) * (t - a.soft_a);
+    }
+    *a.cart_scale = sc;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6, nwaves = (gridDim.x * NT) >> 6;
+  const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
+  for (int b = wave; b < a.B; b += nwaves) {
+    const long row = idx[b];
+    const float* __restrict__ fs = a.feat_data + row * a.F;
+    const float* __restrict__ cs = a.cart_data + row * a.C3;
+    float* fd = a.feat + (long)b * a.F;
+    float* cd = a.cart + (long)b * a.C3;
+    for (int k = lane; k < a.F; k += 64) fd[k] = fs[k];
+    for (int k = lane; k < a.C3; k += 64) cd[k] = cs[k];
+    for (int p = 0; p < a.n_parts; ++p) {
+      float* xo = a.xin + (long)b * a.ld_xin + a.col[p];
+      const int n = a.n[p];
+      for (int k = lane; k < n; k += 64) {
+        float sn, cn;
+        emx::sincos_bounded(fs[a.off[p] + k] * a.ang_scale, &sn, &cn);
+        xo[k] = sn;
+        xo[n + k] = cn;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1133,6 +1185,46 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
   EMX_REQUIRE(soft_a < 0.f || soft_b > soft_a, "emx_soft_start_scale: soft start needs b > a");
   hipLaunchKernelGGL(soft_start_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step, soft_a, soft_b, scale_c, out);
   return emx::check_launch("soft_start_kernel");
+}
+
+int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
+                       int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
+                       float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
+                       float* cart_scale, emx_stream_t stream) {
+  EMX_REQUIRE(feat_data && cart_data && idx && feat && cart && xin, "emx_adc_batch_head: null pointer argument");
+  EMX_REQUIRE(N > 0 && F > 0 && C3 > 0 && B > 0 && n_parts >= 1 && n_parts <= 4 && part_off && part_n && part_col, "emx_adc_batch_head: bad shape");
+  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "emx_adc_batch_head: the angular blocks need a finite periodicity");
+  EMX_REQUIRE(!cart_scale || (step && (soft_a < 0.f || soft_b > soft_a)), "emx_adc_batch_head: soft start needs the step counter and b > a");
+  AdcHeadArgs a{};
+  for (int p = 0; p < n_parts; ++p) {
+    EMX_REQUIRE(part_off[p] >= 0 && part_n[p] > 0 && part_off[p] + part_n[p] <= F && part_col[p] >= 0 && part_col[p] + 2 * part_n[p] <= ld_xin,
+                "emx_adc_batch_head: block %d outside the feature row or the encoder input", p);
+    a.off[p] = part_off[p];
+    a.n[p] = part_n[p];
+    a.col[p] = part_col[p];
+  }
+  a.feat_data = feat_data;
+  a.cart_data = cart_data;
+  a.idx = idx;
+  a.cursor = cursor;
+  a.feat = feat;
+  a.cart = cart;
+  a.xin = xin;
+  a.B = B;
+  a.F = F;
+  a.C3 = C3;
+  a.ld_xin = ld_xin;
+  a.n_parts = n_parts;
+  const float two_pi = 6.283185307179586f;
+  a.ang_scale = periodicity == two_pi ? 1.f : two_pi / periodicity;
+  a.step = step;
+  a.soft_a = soft_a;
+  a.soft_b = soft_b;
+  a.scale_c = scale_c;
+  a.cart_scale = cart_scale;
+  const int grid = std::min((B + 3) / 4, 1024);
+  hipLaunchKernelGGL(adc_head_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("adc_head_kernel");
 }
 
 int emx_clash_count(const float* xyz, int B, int A, float clash_distance, int64_t* counts, emx_stream_t stream) {

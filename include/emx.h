@@ -433,6 +433,19 @@ int emx_allatom_backmap(const float* xyz0, int64_t frame_stride, int64_t n_frame
  * *out = 0 (t < a), c (t - a)/(b - a) (a <= t <= b), c (t > b); a < 0 -> constant c.   t = *step */
 int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float scale_c, float* out, emx_stream_t stream);
 
+/* The head of an ADC training step in ONE launch (gen_functional_model's inputs, models.py:385-1060; tf.data batching,
+ * autoencoder.py:1613-1644; IncreaseCartesianCost, callbacks.py:584-606): rows idx[*cursor * B + b] (cursor NULL: idx[b]) of
+ *   feat_data [N, F] -> feat [B, F]   (angles | dihedrals | side dihedrals | distances)      emx_gather_rows
+ *   cart_data [N, C3] -> cart [B, C3] (flattened Cartesians)                                  emx_gather_rows
+ *   for each of the n_parts <= 4 angular blocks (part_off, part_n) of the feature row: sin / cos into
+ *   xin[b, part_col .. part_col + 2 part_n)                                                    emx_periodic_in
+ *   *cart_scale = soft-start scale of step *step (cart_scale NULL: skipped)                   emx_soft_start_scale
+ * -- the same numbers as those four entry points, one launch instead of four. */
+int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
+                       int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
+                       float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
+                       float* cart_scale, emx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -247,3 +247,37 @@ def test_clash_count_and_kabsch_rmsd(B, A):
         iu = np.triu_indices(A, k=1)
         near = (np.abs(d[:, iu[0], iu[1]] - thr) < 1e-5 * max(thr, 1.0)).sum(axis=1)
         assert np.all(np.abs(counts.cpu().numpy() - want) <= near)
+
+
+@pytest.mark.parametrize("periodicity,soft", [(2 * PI, (6.0, 12.0, 1.0)), (360.0, (-1.0, -1.0, 2.5))])
+def test_adc_batch_head_equals_its_four_parts(L, periodicity, soft):
+    """emx_adc_batch_head == emx_gather_rows x 2 + emx_periodic_in per block + emx_soft_start_scale, bit for bit, at a cursor
+    position inside the index block, with a ragged number of rows per workgroup."""
+    rng = np.random.default_rng(17)
+    N, B, A, S = 500, 37, 21, 5
+    n_ang, n_dih, n_len = A - 2, A - 3, A - 1
+    F = n_ang + n_dih + S + n_len
+    feat_data = dev(rng.uniform(-periodicity / 2, periodicity / 2, (N, F)))
+    cart_data = dev(rng.normal(0, 1, (N, 3 * A)))
+    idx = torch.from_numpy(rng.integers(0, N, 4 * B)).cuda()
+    cursor = torch.tensor([2], dtype=torch.int64, device="cuda")
+    step = torch.tensor([9], dtype=torch.int64, device="cuda")
+    parts = [(0, n_ang, 0), (n_ang, n_dih, 2 * n_ang), (n_ang + n_dih, S, 2 * (n_ang + n_dih))]
+    W = 2 * (n_ang + n_dih + S)
+    feat, cart, xin = (torch.full((B, k), float("nan"), device="cuda") for k in (F, 3 * A, W))
+    sc = torch.zeros(1, device="cuda")
+    L.adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, periodicity, xin, step, *soft, sc)
+    feat2, cart2, xin2 = (torch.full((B, k), float("nan"), device="cuda") for k in (F, 3 * A, W))
+    sc2 = torch.zeros(1, device="cuda")
+    L.gather_rows(feat_data, idx, float("inf"), feat2, None, cursor=cursor, B=B)
+    L.gather_rows(cart_data, idx, float("inf"), cart2, None, cursor=cursor, B=B)
+    for off, n, col in parts:
+        L.periodic_in(feat2[:, off: off + n], periodicity, xin2[:, col: col + 2 * n])
+    L.soft_start_scale(step, *soft, sc2)
+    torch.cuda.synchronize()
+    rows = idx[2 * B: 3 * B]
+    assert torch.equal(feat, feat_data[rows]) and torch.equal(cart, cart_data[rows])
+    assert torch.equal(feat, feat2) and torch.equal(cart, cart2) and torch.equal(xin, xin2) and torch.equal(sc, sc2)
+    assert float(sc) == pytest.approx(0.5 if soft[0] >= 0 else 2.5)
+    with pytest.raises(L.EmxError, match="outside the feature row"):
+        L.adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, [(F - 2, 5, 0)], periodicity, xin, step, *soft, sc)
