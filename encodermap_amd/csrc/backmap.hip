@@ -845,7 +845,7 @@ __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, flo
 }
 
 // The head of an ADC step in one launch: the batch's feature rows and Cartesian rows by index, the sin/cos encoder input of
-// the angular blocks, and the soft-start scale of this step (a wave per row; thread 0 of the launch does the scalar).
+// the angular blocks, and the soft-start scale of this step (a workgroup per row; thread 0 of the launch does the scalar).
 struct AdcHeadArgs {
   const float* feat_data;
   const float* cart_data;
@@ -872,21 +872,22 @@ __global__ __launch_bounds__(NT) void adc_head_kernel(const AdcHeadArgs a) {
     }
     *a.cart_scale = sc;
   }
-  const int lane = threadIdx.x & 63;
-  const int wave = (blockIdx.x * NT + threadIdx.x) >> 6, nwaves = (gridDim.x * NT) >> 6;
+  // a workgroup per row: a few hundred columns per row and only a few hundred rows per batch -- a wave per row walks ~35
+  // dependent iterations behind its three hops (cursor, index, row) while most of the chip idles
+  const int lane = threadIdx.x;
   const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
-  for (int b = wave; b < a.B; b += nwaves) {
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
     const long row = idx[b];
     const float* __restrict__ fs = a.feat_data + row * a.F;
     const float* __restrict__ cs = a.cart_data + row * a.C3;
     float* fd = a.feat + (long)b * a.F;
     float* cd = a.cart + (long)b * a.C3;
-    for (int k = lane; k < a.F; k += 64) fd[k] = fs[k];
-    for (int k = lane; k < a.C3; k += 64) cd[k] = cs[k];
+    for (int k = lane; k < a.F; k += NT) fd[k] = fs[k];
+    for (int k = lane; k < a.C3; k += NT) cd[k] = cs[k];
     for (int p = 0; p < a.n_parts; ++p) {
       float* xo = a.xin + (long)b * a.ld_xin + a.col[p];
       const int n = a.n[p];
-      for (int k = lane; k < n; k += 64) {
+      for (int k = lane; k < n; k += NT) {
         float sn, cn;
         emx::sincos_bounded(fs[a.off[p] + k] * a.ang_scale, &sn, &cn);
         xo[k] = sn;
@@ -1222,7 +1223,7 @@ int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N
   a.soft_b = soft_b;
   a.scale_c = scale_c;
   a.cart_scale = cart_scale;
-  const int grid = std::min((B + 3) / 4, 1024);
+  const int grid = std::min(B, 2048);
   hipLaunchKernelGGL(adc_head_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adc_head_kernel");
 }
