@@ -97,23 +97,31 @@ __device__ __forceinline__ M3 rodrigues(V3 u, float c, float s) {
 // ---------------------------------------------------------------------------------------------------------
 // K8: column mean.  block = 64 columns x 4 row phases; out[k] = mean_b x[b, k]
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void colmean_kernel(const float* __restrict__ x, int B, int n, int ldx, float* __restrict__ out) {
-  __shared__ float part[4][64];
+constexpr int CM_PH = 16;   // row phases per workgroup: 64 columns x 16 phases = 1024 threads (a few hundred rows, a few hundred
+                            // columns: four phases left 64 dependent-ish rows per thread on four workgroups)
+__global__ __launch_bounds__(64 * CM_PH) void colmean_kernel(const float* __restrict__ x, int B, int n, int ldx, float* __restrict__ out) {
+  __shared__ float part[CM_PH][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (c < n) {
     int b = ph;
-    for (; b + 12 < B; b += 16) {   // 4 independent loads in flight per thread
+    for (; b + 3 * CM_PH < B; b += 4 * CM_PH) {   // 4 independent loads in flight per thread
       s0 += x[(long)b * ldx + c];
-      s1 += x[(long)(b + 4) * ldx + c];
-      s2 += x[(long)(b + 8) * ldx + c];
-      s3 += x[(long)(b + 12) * ldx + c];
+      s1 += x[(long)(b + CM_PH) * ldx + c];
+      s2 += x[(long)(b + 2 * CM_PH) * ldx + c];
+      s3 += x[(long)(b + 3 * CM_PH) * ldx + c];
     }
-    for (; b < B; b += 4) s0 += x[(long)b * ldx + c];
+    for (; b < B; b += CM_PH) s0 += x[(long)b * ldx + c];
   }
   part[ph][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
-  if (ph == 0 && c < n) out[c] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x])) / (float)B;
+  if (ph == 0 && c < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < CM_PH; q += 4)
+      t += (part[q][threadIdx.x] + part[q + 1][threadIdx.x]) + (part[q + 2][threadIdx.x] + part[q + 3][threadIdx.x]);
+    out[c] = t / (float)B;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1076,7 +1084,7 @@ extern "C" {
 
 int emx_colmean(const float* x, int B, int n, int ldx, float* out, emx_stream_t stream) {
   EMX_REQUIRE(x && out && B > 0 && n > 0 && ldx >= n, "emx_colmean: bad arguments");
-  hipLaunchKernelGGL(colmean_kernel, dim3((n + 63) / 64), dim3(NT), 0, (hipStream_t)stream, x, B, n, ldx, out);
+  hipLaunchKernelGGL(colmean_kernel, dim3((n + 63) / 64), dim3(64 * CM_PH), 0, (hipStream_t)stream, x, B, n, ldx, out);
   return emx::check_launch("colmean_kernel");
 }
 
