@@ -659,34 +659,38 @@ __device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
   j = (int)(p - ((long)ii * C - (long)ii * (ii + 1) / 2)) + ii + 1;
 }
 
-__global__ __launch_bounds__(NT) void pdist_fwd_kernel(const float* __restrict__ xyz, int A, int start, int step, int C, long P, int ldo,
+constexpr int PD_NT = 1024;   // threads per frame: a 256-frame batch is 256 workgroups, one per CU -- each should bring all its waves
+__global__ __launch_bounds__(PD_NT) void pdist_fwd_kernel(const float* __restrict__ xyz, int A, int start, int step, int C, long P, int ldo,
                                                        float* __restrict__ out) {
   extern __shared__ float sx[];   // [C][3]
   const int b = blockIdx.x;
   const float* X = xyz + (long)b * A * 3;
-  for (int e = threadIdx.x; e < 3 * C; e += NT) {
+  for (int e = threadIdx.x; e < 3 * C; e += PD_NT) {
     int c = e / 3, k = e - 3 * c;
     sx[e] = X[3 * (start + step * c) + k];
   }
   __syncthreads();
   float* o = out + (long)b * ldo;
-  for (long p = threadIdx.x; p < P; p += NT) {
+  for (long p = threadIdx.x; p < P; p += PD_NT) {
     int i, j;
     pair_decode(p, C, i, j);
     const float dx = sx[3 * i] - sx[3 * j], dy = sx[3 * i + 1] - sx[3 * j + 1], dz = sx[3 * i + 2] - sx[3 * j + 2];
     o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
   }
-  for (long p = P + threadIdx.x; p < ldo; p += NT) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
+  for (long p = P + threadIdx.x; p < ldo; p += PD_NT) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
 }
 
-// one thread per selected atom gathers its C-1 pair terms (deterministic, no atomics); the frame's gradient row is staged in
-// LDS first when it fits (stage_g) -- read in place, every thread walks C - 1 dependent scattered global loads
-__global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
-                                                       int step, int C, int ldo, float* __restrict__ dxyz, int accumulate, int stage_g) {
+// T threads per selected atom (T a power of two <= 8, consecutive lanes) gather its C-1 pair terms, j = q, q + T, ..., and add
+// their shares in a fixed tree (deterministic, no atomics); the frame's gradient row is staged in LDS first when it fits
+// (stage_g) -- read in place, every thread walks its dependent scattered global loads.  (One thread per atom left 76 of 256
+// threads with 75 serial terms each at the ADC shape.)
+__global__ __launch_bounds__(PD_NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
+                                                          int step, int C, int ldo, float* __restrict__ dxyz, int accumulate, int stage_g,
+                                                          int T) {
   extern __shared__ float sx[];
   const int b = blockIdx.x;
   const float* X = xyz + (long)b * A * 3;
-  for (int e = threadIdx.x; e < 3 * C; e += NT) {
+  for (int e = threadIdx.x; e < 3 * C; e += PD_NT) {
     int c = e / 3, k = e - 3 * c;
     sx[e] = X[3 * (start + step * c) + k];
   }
@@ -694,25 +698,29 @@ __global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__
   if (stage_g) {
     float* sg = sx + 3 * C;
     const int P = C * (C - 1) / 2;
-    for (int e = threadIdx.x; e < P; e += NT) sg[e] = g[e];
+    for (int e = threadIdx.x; e < P; e += PD_NT) sg[e] = g[e];
     g = sg;
   }
   __syncthreads();
   float* D = dxyz + (long)b * A * 3;
   if (!accumulate) {
     // atoms that are not selected receive zero
-    for (int e = threadIdx.x; e < 3 * A; e += NT) {
+    for (int e = threadIdx.x; e < 3 * A; e += PD_NT) {
       int a = e / 3;
       bool sel = a >= start && (a - start) % step == 0 && (a - start) / step < C;
       if (!sel) D[e] = 0.f;
     }
   }
-  for (int i = threadIdx.x; i < C; i += NT) {
-    const float xi = sx[3 * i], yi = sx[3 * i + 1], zi = sx[3 * i + 2];
+  const int q = threadIdx.x & (T - 1), per_pass = PD_NT / T;
+  for (int i0 = 0; i0 < C; i0 += per_pass) {          // uniform trip count: every lane takes part in the shuffles
+    const int i = i0 + threadIdx.x / T;
+    const bool ok = i < C;
+    const int ic = ok ? i : C - 1;
+    const float xi = sx[3 * ic], yi = sx[3 * ic + 1], zi = sx[3 * ic + 2];
     float gx = 0.f, gy = 0.f, gz = 0.f;
-    for (int j = 0; j < C; ++j) {
-      if (j == i) continue;
-      const int lo = min(i, j), hi = max(i, j);
+    for (int j = q; j < C; j += T) {
+      if (j == ic) continue;
+      const int lo = min(ic, j), hi = max(ic, j);
       const long p = (long)lo * C - (long)lo * (lo + 1) / 2 + (hi - lo - 1);
       const float dx = xi - sx[3 * j], dy = yi - sx[3 * j + 1], dz = zi - sx[3 * j + 2];
       const float d2 = dx * dx + dy * dy + dz * dz;
@@ -721,11 +729,18 @@ __global__ __launch_bounds__(NT) void pdist_bwd_kernel(const float* __restrict__
       gy = fmaf(w, dy, gy);
       gz = fmaf(w, dz, gz);
     }
-    float* q = D + 3 * (start + step * i);
-    if (accumulate) {
-      q[0] += gx; q[1] += gy; q[2] += gz;
-    } else {
-      q[0] = gx; q[1] = gy; q[2] = gz;
+    for (int o = 1; o < T; o <<= 1) {
+      gx += __shfl_xor(gx, o, 64);
+      gy += __shfl_xor(gy, o, 64);
+      gz += __shfl_xor(gz, o, 64);
+    }
+    if (ok && q == 0) {
+      float* qd = D + 3 * (start + step * i);
+      if (accumulate) {
+        qd[0] += gx; qd[1] += gy; qd[2] += gz;
+      } else {
+        qd[0] = gx; qd[1] = gy; qd[2] = gz;
+      }
     }
   }
 }
@@ -1144,7 +1159,7 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
   EMX_REQUIRE(ldo >= P, "emx_pdist_flat_fwd: output row stride %d < %ld pairs", ldo, P);
   const size_t lds = (size_t)3 * C * sizeof(float);
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_fwd: %d atoms do not fit the LDS frame buffer", C);
-  hipLaunchKernelGGL(pdist_fwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, A, start, step, C, P, ldo, out);
+  hipLaunchKernelGGL(pdist_fwd_kernel, dim3(B), dim3(PD_NT), lds, (hipStream_t)stream, xyz, A, start, step, C, P, ldo, out);
   return emx::check_launch("pdist_fwd_kernel");
 }
 
@@ -1158,7 +1173,10 @@ int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int st
   const size_t with_g = lds + (size_t)C * (C - 1) / 2 * sizeof(float);
   const int stage_g = with_g <= 64 * 1024;
   if (stage_g) lds = with_g;
-  hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate, stage_g);
+  int T = 8;
+  while (T > 1 && (long)C * T > PD_NT) T >>= 1;
+  hipLaunchKernelGGL(pdist_bwd_kernel, dim3(B), dim3(PD_NT), lds, (hipStream_t)stream, xyz, dout, A, start, step, C, ldo, dxyz, accumulate, stage_g,
+                     T);
   return emx::check_launch("pdist_bwd_kernel");
 }
 

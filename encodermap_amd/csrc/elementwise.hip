@@ -490,7 +490,9 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   a.row_begin = row_begin;
   a.row_end = row_end;
   a.prescale = loss ? 0 : 1;
-  a.wide = (n >= 1024 && variant != EMX_MEAN_NORM) ? 1 : 0;
+  // one workgroup per row: long rows, or a few hundred rows of a few hundred columns (a wave per row leaves most CUs idle
+  // behind a 256-row batch, with an atan2 per element)
+  a.wide = ((n >= 1024 || (n >= 128 && row_end - row_begin <= EMX_REDUCE_WS)) && variant != EMX_MEAN_NORM) ? 1 : 0;
   const int grid = a.wide ? std::min(row_end - row_begin, EMX_REDUCE_WS) : grid_for(row_end - row_begin, 4);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
