@@ -48,6 +48,7 @@ SIGNATURES = {
     "emx_periodic_out": (_i, [_p, _i, _i, _i, _i, _i, _f, _p, _i, _p]),
     "emx_periodic_cost_fwd_bwd": (_i, [_p, _i, _i, _i, _i, _p, _i, _i, _i, _f, _i, _f, _p, _p, _i, _i, _p, _p, _p, _p]),
     "emx_center_cost_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _p]),
+    "emx_periodic_cost_batch": (_i, [_p, _i, _i, _i, _i, _p]),
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
     "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "emx_l2_partials": (_i, [_p, _p, _l, _p, _p]),
@@ -84,6 +85,7 @@ SIGNATURES = {
 
 EMX_MAX_LAYERS = 8
 EMX_MAX_SUM_JOBS = 8
+EMX_MAX_COST_JOBS = 4
 
 
 class LatentGrad(C.Structure):
@@ -335,6 +337,30 @@ def periodic_cost_fwd_bwd(y, off_sin, off_cos, periodic_output, target, n, perio
         _ptr(y), y.stride(0), off_sin, off_cos, int(bool(periodic_output)), _ptr(target), target.stride(0), B, n,
         float(periodicity), VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef), _ptr(coef_scale),
         _ptr(dpred_add), int(row_begin), int(row_end), _ptr(loss), _ptr(dY), _ptr(ws), _stream()), "emx_periodic_cost_fwd_bwd")
+
+
+class CostJob(C.Structure):
+    """Mirror of ``emx_cost_job`` (include/emx.h)."""
+
+    _fields_ = [("y", _p), ("ldy", _i), ("off_sin", _i), ("off_cos", _i), ("periodic_output", _i), ("target", _p), ("ldt", _i), ("n", _i),
+                ("periodicity", _f), ("variant", _i), ("coef", _f), ("coef_scale", _p), ("dpred_add", _p), ("dY", _p), ("ws", _p)]
+
+
+def periodic_cost_batch(jobs, B, row_begin, row_end):
+    """Several row-mean costs in one launch.  jobs: dicts with the keyword names of ``periodic_cost_fwd_bwd`` (y, off_sin, off_cos,
+    periodic_output, target, n, periodicity, variant, coef, dY, ws, coef_scale, dpred_add); partials go to each job's ws."""
+    arr = (CostJob * len(jobs))()
+    for a, j in zip(arr, jobs):
+        y, dY, add = j["y"], j.get("dY"), j.get("dpred_add")
+        assert dY is None or dY.stride(0) == y.stride(0)
+        assert add is None or (add.is_contiguous() and add.shape[1] == j["n"])
+        v = j["variant"]
+        a.y, a.ldy, a.off_sin, a.off_cos, a.periodic_output = _ptr(y), y.stride(0), int(j["off_sin"]), int(j["off_cos"]), int(bool(j["periodic_output"]))
+        a.target, a.ldt, a.n = _ptr(j["target"]), j["target"].stride(0), int(j["n"])
+        a.periodicity, a.variant, a.coef = float(j["periodicity"]), VARIANTS[v] if isinstance(v, str) else int(v), float(j["coef"])
+        a.coef_scale, a.dpred_add, a.dY, a.ws = _ptr(j.get("coef_scale")), _ptr(add), _ptr(dY), _ptr(j["ws"])
+    _check(load().emx_periodic_cost_batch(C.cast(arr, C.c_void_p), len(jobs), int(B), int(row_begin), int(row_end), _stream()),
+           "emx_periodic_cost_batch")
 
 
 def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):

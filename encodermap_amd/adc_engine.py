@@ -40,6 +40,7 @@ def _round4(n: int) -> int:
 class ADCEngine(SequentialEngine):
     _prefetch = False   # the feature block is assembled inside the step (gather + featurisation)
     _fused_head = os.environ.get("EMX_ADC_HEAD", "1") != "0"   # gathers + sin/cos + soft start in one launch (A/B switch)
+    _batched_costs = os.environ.get("EMX_ADC_COST_BATCH", "1") != "0"   # the angle-like costs in one launch (A/B switch)
 
     TERM_NAMES = ADC_TERM_NAMES
     _reg_slot = T_REG
@@ -106,9 +107,12 @@ class ADCEngine(SequentialEngine):
         self.dY = z(B, self.net_dim)
         self.dZ, self.dZ2 = z(B, self.L), z(B, self.L)
         self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
-        self.ang_pred = z(B, self.n_ang) if self.use_ang else z(1, self.n_ang)
+        # batch means of the whole feature block in ONE launch: the mean bond lengths (BackMapLayer, layers.py:971) and -- without
+        # backbone angles in the model -- the mean angles (MeanAngles, layers.py:1153-1161) are views into it
+        self.feat_mean = z(self.F)
+        self.ang_pred = z(B, self.n_ang) if self.use_ang else self.feat_mean[self.off_ang: self.off_ang + self.n_ang].view(1, self.n_ang)
         self.dih_pred = z(B, self.n_dih)
-        self.mean_len = z(self.n_len)
+        self.mean_len = self.feat_mean[self.off_len: self.off_len + self.n_len]
         self.plane, self.xyz = z(B, self.A, 3), z(B, self.A, 3)
         self.dxyz, self.dplane = z(B, self.A, 3), z(B, self.A, 3)
         self.inp_pair, self.out_pair, self.dpair = z(B, self.ldp), z(B, self.ldp), z(B, self.ldp)
@@ -162,9 +166,12 @@ class ADCEngine(SequentialEngine):
                 _lib.periodic_out(Y, n, col, col + n, self.periodicity, ang_pred)
             elif off == self.off_dih:
                 _lib.periodic_out(Y, n, col, col + n, self.periodicity, dih_pred)
-        if not self.use_ang:
-            _lib.colmean(feat[:, self.off_ang: self.off_ang + self.n_ang], ang_pred.view(-1))
-        _lib.colmean(feat[:, self.off_len: self.off_len + self.n_len], mean_len)
+        if feat is self.feat and mean_len.data_ptr() == self.mean_len.data_ptr():
+            _lib.colmean(feat, self.feat_mean)
+        else:
+            if not self.use_ang:
+                _lib.colmean(feat[:, self.off_ang: self.off_ang + self.n_ang], ang_pred.view(-1))
+            _lib.colmean(feat[:, self.off_len: self.off_len + self.n_len], mean_len)
         _lib.chain_in_plane_fwd(mean_len, _Bcast(ang_pred) if not self.use_ang else ang_pred, plane)
         _lib.dihedrals_to_cartesian_fwd(dih_pred, math.pi, plane, xyz)
 
@@ -242,7 +249,9 @@ class ADCEngine(SequentialEngine):
         if self.use_ang:
             _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
 
-        # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward)
+        # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward): one
+        # launch for all of them (emx_periodic_cost_batch)
+        jobs = []
         for off, nn, col in self.parts:
             tgt = self.feat[:, off: off + nn]
             if off == self.off_dih:
@@ -252,13 +261,20 @@ class ADCEngine(SequentialEngine):
             else:
                 sc, var, ref, slot, extra = p.side_dihedral_cost_scale, p.side_dihedral_cost_variant, p.side_dihedral_cost_reference, T_SIDE, None
             coef = 0.0 if sc is None else float(sc) / float(ref)
-            _lib.periodic_cost_fwd_bwd(Y, col, col + nn, True, tgt, nn, per, var, coef, 0, B, None, self.dY, self.cost_ws_rows[self._row_of[slot]],
-                                       dpred_add=extra)
+            jobs.append(dict(y=Y, off_sin=col, off_cos=col + nn, periodic_output=True, target=tgt, n=nn, periodicity=per, variant=var, coef=coef,
+                             dY=self.dY, ws=self.cost_ws_rows[self._row_of[slot]], dpred_add=extra))
         if not self.use_ang:   # mean angles carry no gradient, the cost is still reported (models.py:2383)
             sc = p.angle_cost_scale
-            _lib.periodic_cost_fwd_bwd(_Bcast(self.ang_pred), 0, 0, False, self.feat[:, self.off_ang: self.off_ang + self.n_ang], self.n_ang,
-                                       per, p.angle_cost_variant, 0.0 if sc is None else float(sc) / float(p.angle_cost_reference), 0, B,
-                                       None, None, self.cost_ws_rows[self._row_of[T_ANG]], B=B)
+            jobs.append(dict(y=_Bcast(self.ang_pred), off_sin=0, off_cos=0, periodic_output=False,
+                             target=self.feat[:, self.off_ang: self.off_ang + self.n_ang], n=self.n_ang, periodicity=per,
+                             variant=p.angle_cost_variant, coef=0.0 if sc is None else float(sc) / float(p.angle_cost_reference), dY=None,
+                             ws=self.cost_ws_rows[self._row_of[T_ANG]]))
+        if self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS:
+            _lib.periodic_cost_batch(jobs, B, 0, B)
+        else:
+            for j in jobs:
+                _lib.periodic_cost_fwd_bwd(j["y"], j["off_sin"], j["off_cos"], j["periodic_output"], j["target"], j["n"], j["periodicity"],
+                                           j["variant"], j["coef"], 0, B, None, j["dY"], j["ws"], B=B, dpred_add=j.get("dpred_add"))
 
         # latent costs: cartesian distance cost (Euclidean, high-d = input pair distances) with the center cost fused,
         # and the periodic distance cost on the angular inputs when it is switched on

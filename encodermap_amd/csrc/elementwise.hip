@@ -108,14 +108,14 @@ __global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restric
 // K5: row-mean cost on periodic differences, fused with PeriodicOutput (atan2) forward + backward.
 // one wave per row (two passes over the row for mean_norm); per-block partial -> ws, final sum below.
 // ---------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
-  __shared__ float red[8];
+// (bid of nblk: this workgroup among those that work on the cost `a` -- the whole grid, or one job's share of a batched launch)
+__device__ __forceinline__ void periodic_cost_body(const CostArgs& a, const int bid, const int nblk, float (&red)[8]) {
   // long rows (a.wide): a row per workgroup, the columns over all its threads -- a wave per row walks 45 dependent
   // iterations over a 2850-column row while most of the chip idles behind a 256-row batch
   const int lane = a.wide ? threadIdx.x : threadIdx.x & 63;
   const int kstep = a.wide ? NT : 64;
-  const int wave = a.wide ? blockIdx.x : (blockIdx.x * NT + threadIdx.x) >> 6;
-  const int nwaves = a.wide ? gridDim.x : (gridDim.x * NT) >> 6;
+  const int wave = a.wide ? bid : (bid * NT + threadIdx.x) >> 6;
+  const int nwaves = a.wide ? nblk : (nblk * NT) >> 6;
   float lsum = 0.f;
   for (int b = a.row_begin + wave; b < a.row_end; b += nwaves) {
     const float* yrow = a.y + (long)b * a.ldy;
@@ -156,9 +156,27 @@ __global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
     }
   }
   float t = block_sum<NT>(lsum, red);
-  if (threadIdx.x == 0) a.ws[blockIdx.x] = a.prescale ? t * a.gnorm * (a.coef_scale ? *a.coef_scale : 1.f) : t;
-  if (a.prescale && blockIdx.x == 0)   // unused scratch entries read as zero by the summing job
-    for (int i = gridDim.x + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
+  if (threadIdx.x == 0) a.ws[bid] = a.prescale ? t * a.gnorm * (a.coef_scale ? *a.coef_scale : 1.f) : t;
+  if (a.prescale && bid == 0)   // unused scratch entries read as zero by the summing job
+    for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += NT) a.ws[i] = 0.f;
+}
+
+__global__ __launch_bounds__(NT) void periodic_cost_kernel(const CostArgs a) {
+  __shared__ float red[8];
+  periodic_cost_body(a, blockIdx.x, gridDim.x, red);
+}
+
+// several row-mean costs of one step in one launch (emx_periodic_cost_batch): job j owns the workgroups [first[j], first[j + 1])
+struct CostBatch {
+  CostArgs job[EMX_MAX_COST_JOBS];
+  int first[EMX_MAX_COST_JOBS + 1];
+  int n_jobs;
+};
+__global__ __launch_bounds__(NT) void periodic_cost_batch_kernel(const CostBatch b) {
+  __shared__ float red[8];
+  int j = 0;
+  while (j + 1 < b.n_jobs && (int)blockIdx.x >= b.first[j + 1]) ++j;
+  periodic_cost_body(b.job[j], blockIdx.x - b.first[j], b.first[j + 1] - b.first[j], red);
 }
 
 // *out = scale * sum_{i<n} ws[i], fixed order
@@ -465,20 +483,20 @@ int emx_periodic_out(const float* y, int B, int n, int ldy, int off_sin, int off
   return emx::check_launch("periodic_out_kernel");
 }
 
-int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output, const float* target, int ldt,
-                              int B, int n, float periodicity, int variant, float coef, const float* coef_scale,
-                              const float* dpred_add, int row_begin, int row_end, float* loss, float* dY, float* ws,
-                              emx_stream_t stream) {
-  EMX_REQUIRE(y && target && ws, "emx_periodic_cost_fwd_bwd: null pointer argument");
-  EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "emx_periodic_cost_fwd_bwd: bad shape");
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "emx_periodic_cost_fwd_bwd: bad row block");
-  EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "emx_periodic_cost_fwd_bwd: cost variant %d not available", variant);
+namespace {
+// validated description of one row-mean cost; *grid = its workgroups
+int fill_cost_job(CostArgs& a, int* grid, const float* y, int ldy, int off_sin, int off_cos, int periodic_output, const float* target, int ldt,
+                  int B, int n, float periodicity, int variant, float coef, const float* coef_scale, const float* dpred_add, int row_begin,
+                  int row_end, float* loss, float* dY, float* ws, const char* who) {
+  EMX_REQUIRE(y && target && ws, "%s: null pointer argument", who);
+  EMX_REQUIRE(B > 0 && n > 0 && ldt >= n, "%s: bad shape", who);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "%s: bad row block", who);
+  EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "%s: cost variant %d not available", who, variant);
   // ldy == 0 broadcasts one prediction row to every batch row (forward only: the batch-mean angles of MeanAngles)
-  EMX_REQUIRE(ldy > 0 || !dY, "emx_periodic_cost_fwd_bwd: a broadcast prediction (ldy == 0) cannot receive a gradient");
+  EMX_REQUIRE(ldy > 0 || !dY, "%s: a broadcast prediction (ldy == 0) cannot receive a gradient", who);
   EMX_REQUIRE(off_sin >= 0 && (ldy == 0 || off_sin + n <= ldy) && (!periodic_output || (off_cos >= 0 && (ldy == 0 || off_cos + n <= ldy))),
-              "emx_periodic_cost_fwd_bwd: column window outside the row");
-  EMX_REQUIRE(!periodic_output || std::isfinite(periodicity), "emx_periodic_cost_fwd_bwd: periodic output needs a finite periodicity");
-  CostArgs a;
+              "%s: column window outside the row", who);
+  EMX_REQUIRE(!periodic_output || std::isfinite(periodicity), "%s: periodic output needs a finite periodicity", who);
   a.y = y;
   a.target = target;
   a.dpred_add = dpred_add;
@@ -493,13 +511,44 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
   // one workgroup per row: long rows, or a few hundred rows of a few hundred columns (a wave per row leaves most CUs idle
   // behind a 256-row batch, with an atan2 per element)
   a.wide = ((n >= 1024 || (n >= 128 && row_end - row_begin <= EMX_REDUCE_WS)) && variant != EMX_MEAN_NORM) ? 1 : 0;
-  const int grid = a.wide ? std::min(row_end - row_begin, EMX_REDUCE_WS) : grid_for(row_end - row_begin, 4);
+  *grid = a.wide ? std::min(row_end - row_begin, EMX_REDUCE_WS) : grid_for(row_end - row_begin, 4);
+  return EMX_OK;
+}
+}  // namespace
+
+int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos, int periodic_output, const float* target, int ldt,
+                              int B, int n, float periodicity, int variant, float coef, const float* coef_scale,
+                              const float* dpred_add, int row_begin, int row_end, float* loss, float* dY, float* ws,
+                              emx_stream_t stream) {
+  CostArgs a;
+  int grid = 0;
+  int rc = fill_cost_job(a, &grid, y, ldy, off_sin, off_cos, periodic_output, target, ldt, B, n, periodicity, variant, coef, coef_scale, dpred_add,
+                         row_begin, row_end, loss, dY, ws, "emx_periodic_cost_fwd_bwd");
+  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(periodic_cost_kernel, dim3(grid), dim3(NT), 0, st, a);
-  int rc = emx::check_launch("periodic_cost_kernel");
+  rc = emx::check_launch("periodic_cost_kernel");
   if (rc || !loss) return rc;
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, a.gnorm, coef_scale, loss);
   return emx::check_launch("final_sum_kernel");
+}
+
+int emx_periodic_cost_batch(const emx_cost_job* jobs, int n_jobs, int B, int row_begin, int row_end, emx_stream_t stream) {
+  EMX_REQUIRE(jobs && n_jobs >= 1 && n_jobs <= EMX_MAX_COST_JOBS, "emx_periodic_cost_batch: 1 .. %d jobs", EMX_MAX_COST_JOBS);
+  CostBatch b{};
+  b.n_jobs = n_jobs;
+  b.first[0] = 0;
+  for (int j = 0; j < n_jobs; ++j) {
+    const emx_cost_job& q = jobs[j];
+    int grid = 0;
+    int rc = fill_cost_job(b.job[j], &grid, q.y, q.ldy, q.off_sin, q.off_cos, q.periodic_output, q.target, q.ldt, B, q.n, q.periodicity, q.variant,
+                           q.coef, q.coef_scale, q.dpred_add, row_begin, row_end, nullptr, q.dY, q.ws, "emx_periodic_cost_batch");
+    if (rc) return rc;
+    for (int i = 0; i < j; ++i) EMX_REQUIRE(jobs[i].ws != q.ws, "emx_periodic_cost_batch: jobs %d and %d share their scratch", i, j);
+    b.first[j + 1] = b.first[j] + grid;
+  }
+  hipLaunchKernelGGL(periodic_cost_batch_kernel, dim3(b.first[n_jobs]), dim3(NT), 0, (hipStream_t)stream, b);
+  return emx::check_launch("periodic_cost_batch_kernel");
 }
 
 int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_begin, int row_end, float* loss, float* dZ,

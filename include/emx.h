@@ -161,6 +161,26 @@ int emx_periodic_cost_fwd_bwd(const float* y, int ldy, int off_sin, int off_cos,
                               int row_begin, int row_end, float* loss, float* dY,
                               float* ws /* >= EMX_REDUCE_WS floats */, emx_stream_t stream);
 
+/* Several row-mean costs of one step in ONE launch (the ADC model evaluates a dihedral, an angle and a side-dihedral cost on
+ * column windows of the same output rows, models.py:2260-2521): each job is the argument list of
+ * emx_periodic_cost_fwd_bwd with loss == NULL -- its ws[0 .. EMX_REDUCE_WS) receives the per-workgroup partials -- over the
+ * common rows [row_begin, row_end) of a batch of B.  The same numbers as n_jobs separate calls.  Jobs must not share ws. */
+typedef struct {
+  const float* y;
+  int ldy, off_sin, off_cos, periodic_output;
+  const float* target;
+  int ldt, n;
+  float periodicity;
+  int variant;
+  float coef;
+  const float* coef_scale; /* may be NULL */
+  const float* dpred_add;  /* may be NULL */
+  float* dY;               /* may be NULL */
+  float* ws;
+} emx_cost_job;
+#define EMX_MAX_COST_JOBS 4
+int emx_periodic_cost_batch(const emx_cost_job* jobs, int n_jobs, int B, int row_begin, int row_end, emx_stream_t stream);
+
 /* center cost alone: mean(z^2)*scale over the global batch (loss_functions.py:422-449); dZ written or accumulated */
 int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_begin, int row_end,
                             float* loss, float* dZ, int accumulate, emx_stream_t stream);

@@ -493,3 +493,57 @@ def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     g = dZ.cpu().numpy().astype(np.float64)[rb:re]
     assert float(dist) == pytest.approx(loss_o, rel=1e-5, abs=1e-9)
     np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
+
+
+def test_periodic_cost_batch_equals_separate_calls(L):
+    """emx_periodic_cost_batch == one emx_periodic_cost_fwd_bwd per job (partials, gradients: bit for bit), jobs of different
+    widths, variants and modes (atan2 output with a joined gradient, broadcast prediction without a gradient, long rows)."""
+    rng = np.random.default_rng(23)
+    B, W = 200, 2 * (150 + 40)
+    Y = dev(rng.normal(0, 1, (B, W)))
+    t1, t2 = dev(rng.uniform(-PI, PI, (B, 150))), dev(rng.uniform(-PI, PI, (B, 40)))
+    add = dev(rng.normal(0, 1e-3, (B, 150)))
+    mean = dev(rng.uniform(-PI, PI, (1, 60)))
+    t3 = dev(rng.uniform(-PI, PI, (B, 60)))
+    yl, tl = dev(rng.normal(0, 1, (B, 1500))), dev(rng.normal(0, 1, (B, 1500)))
+
+    class Row0:   # a single row presented with row stride 0 (as the engine's _Bcast does)
+        def __init__(self, t):
+            self.t, self.is_cuda, self.shape = t, True, (1, t.shape[-1])
+
+        def stride(self, i):
+            return 0 if i == 0 else 1
+
+        def data_ptr(self):
+            return self.t.data_ptr()
+
+        def is_contiguous(self):
+            return True
+
+    def jobs(dY, dYl, ws):
+        return [dict(y=Y, off_sin=0, off_cos=150, periodic_output=True, target=t1, n=150, periodicity=2 * PI, variant="mean_abs", coef=0.7,
+                     dY=dY, ws=ws[0], dpred_add=add),
+                dict(y=Y, off_sin=300, off_cos=340, periodic_output=True, target=t2, n=40, periodicity=2 * PI, variant="mean_square", coef=1.3,
+                     dY=dY, ws=ws[1]),
+                dict(y=Row0(mean), off_sin=0, off_cos=0, periodic_output=False, target=t3, n=60, periodicity=2 * PI, variant="mean_abs",
+                     coef=0.5, dY=None, ws=ws[2]),
+                dict(y=yl, off_sin=0, off_cos=0, periodic_output=False, target=tl, n=1500, periodicity=INF, variant="mean_abs", coef=2.0,
+                     dY=dYl, ws=ws[3])]
+
+    def fresh():
+        return (torch.full((B, W), float("nan"), device="cuda"), torch.full((B, 1500), float("nan"), device="cuda"),
+                torch.full((4, L.EMX_REDUCE_WS), float("nan"), device="cuda"))
+
+    dYa, dYla, wsa = fresh()
+    L.periodic_cost_batch(jobs(dYa, dYla, wsa), B, 0, B)
+    dYb, dYlb, wsb = fresh()
+    for j in jobs(dYb, dYlb, wsb):
+        L.periodic_cost_fwd_bwd(j["y"], j["off_sin"], j["off_cos"], j["periodic_output"], j["target"], j["n"], j["periodicity"], j["variant"],
+                                j["coef"], 0, B, None, j["dY"], j["ws"], B=B, dpred_add=j.get("dpred_add"))
+    torch.cuda.synchronize()
+    assert torch.equal(wsa, wsb) and not torch.isnan(wsa).any()
+    assert torch.equal(dYa, dYb) and torch.equal(dYla, dYlb) and not torch.isnan(dYa).any()
+    with pytest.raises(L.EmxError, match="share their scratch"):
+        js = jobs(dYa, dYla, wsa)
+        js[1]["ws"] = js[0]["ws"]
+        L.periodic_cost_batch(js, B, 0, B)
