@@ -18,7 +18,7 @@ struct CostArgs {
   float* loss;
   int ldy, ldt, off_sin, off_cos, periodic_output;
   int n, row_begin, row_end, variant, wrap, prescale;
-  int wide;   // stand-alone kernel: one workgroup per row (long rows) instead of one wave
+  int wide;   // stand-alone kernel: S >= 1 workgroups per row (long rows, or few rows) instead of one wave per row (0)
   float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
 };
 

@@ -112,10 +112,11 @@ __global__ __launch_bounds__(NT) void periodic_out_kernel(const float* __restric
 __device__ __forceinline__ void periodic_cost_body(const CostArgs& a, const int bid, const int nblk, float (&red)[8]) {
   // long rows (a.wide): a row per workgroup, the columns over all its threads -- a wave per row walks 45 dependent
   // iterations over a 2850-column row while most of the chip idles behind a 256-row batch
-  const int lane = a.wide ? threadIdx.x : threadIdx.x & 63;
-  const int kstep = a.wide ? NT : 64;
-  const int wave = a.wide ? bid : (bid * NT + threadIdx.x) >> 6;
-  const int nwaves = a.wide ? nblk : (nblk * NT) >> 6;
+  // (a.wide = S workgroups per row: workgroup bid takes the columns (bid % S) NT + threadIdx.x, + S NT, ... of row bid / S)
+  const int lane = a.wide ? (bid % a.wide) * NT + threadIdx.x : threadIdx.x & 63;
+  const int kstep = a.wide ? a.wide * NT : 64;
+  const int wave = a.wide ? bid / a.wide : (bid * NT + threadIdx.x) >> 6;
+  const int nwaves = a.wide ? nblk / a.wide : (nblk * NT) >> 6;
   float lsum = 0.f;
   for (int b = a.row_begin + wave; b < a.row_end; b += nwaves) {
     const float* yrow = a.y + (long)b * a.ldy;
@@ -511,7 +512,15 @@ int fill_cost_job(CostArgs& a, int* grid, const float* y, int ldy, int off_sin, 
   // one workgroup per row: long rows, or a few hundred rows of a few hundred columns (a wave per row leaves most CUs idle
   // behind a 256-row batch, with an atan2 per element)
   a.wide = ((n >= 1024 || (n >= 128 && row_end - row_begin <= EMX_REDUCE_WS)) && variant != EMX_MEAN_NORM) ? 1 : 0;
-  *grid = a.wide ? std::min(row_end - row_begin, EMX_REDUCE_WS) : grid_for(row_end - row_begin, 4);
+  if (a.wide) {
+    // a few hundred long rows: several workgroups per row, as long as every row keeps its own workgroups
+    const int rows = row_end - row_begin;
+    const int S = std::max(1, std::min(EMX_REDUCE_WS / rows, (n + 2 * NT - 1) / (2 * NT)));
+    a.wide = rows <= EMX_REDUCE_WS ? S : 1;
+    *grid = std::min(rows, EMX_REDUCE_WS) * a.wide;
+  } else {
+    *grid = grid_for(row_end - row_begin, 4);
+  }
   return EMX_OK;
 }
 }  // namespace
