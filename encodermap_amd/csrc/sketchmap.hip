@@ -1112,13 +1112,14 @@ __global__ __launch_bounds__(NT) void sk_split_kernel(const float* __restrict__ 
 
 // long rows (thousands of features): one workgroup per row instead of one wave -- the two passes over a row are a chain of
 // dependent round trips per lane, and a small batch of long rows leaves most of the chip idle with one wave per row
-__global__ __launch_bounds__(NT) void sk_split_wide_kernel(const float* __restrict__ X, int D, int ldx, const SplitRows s) {
-  __shared__ float red_n[NT / 64], red_m[NT / 64];
+constexpr int SPW_NT = 1024;   // (a 256-row batch is 256 workgroups: each brings a full CU's worth of waves)
+__global__ __launch_bounds__(SPW_NT) void sk_split_wide_kernel(const float* __restrict__ X, int D, int ldx, const SplitRows s) {
+  __shared__ float red_n[SPW_NT / 64], red_m[SPW_NT / 64];
   const long b = blockIdx.x;
   const int tid = threadIdx.x;
   const float* __restrict__ src = X + b * ldx;
   float nrm = 0.f, mx = 0.f;
-  for (int k = tid; k < D; k += NT) {
+  for (int k = tid; k < D; k += SPW_NT) {
     const float v = src[k] - X[k];
     nrm = fmaf(v, v, nrm);
     mx = fmaxf(mx, fabsf(v));
@@ -1131,13 +1132,18 @@ __global__ __launch_bounds__(NT) void sk_split_wide_kernel(const float* __restri
     red_m[tid >> 6] = mx;
   }
   __syncthreads();
-  nrm = (red_n[0] + red_n[1]) + (red_n[2] + red_n[3]);
-  mx = fmaxf(fmaxf(red_m[0], red_m[1]), fmaxf(red_m[2], red_m[3]));
+  nrm = 0.f;
+  mx = 0.f;
+#pragma unroll
+  for (int w = 0; w < SPW_NT / 64; w += 4) {   // fixed order
+    nrm += (red_n[w] + red_n[w + 1]) + (red_n[w + 2] + red_n[w + 3]);
+    mx = fmaxf(mx, fmaxf(fmaxf(red_m[w], red_m[w + 1]), fmaxf(red_m[w + 2], red_m[w + 3])));
+  }
   // (same scale rule as emx::split_row)
   int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;
   E = mx > 0.f ? min(max(E, -100), 100) : 14;
   const float sc = __uint_as_float((uint32_t)(127 + 14 - E) << 23), rs = __uint_as_float((uint32_t)(127 - 14 + E) << 23);
-  for (int k = tid; k < s.ld; k += NT) {
+  for (int k = tid; k < s.ld; k += SPW_NT) {
     const float v = k < D ? (src[k] - X[k]) * sc : 0.f;
     const _Float16 h = (_Float16)v;
     const _Float16 l = (_Float16)(v - (float)h);
@@ -1160,7 +1166,7 @@ int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, e
   EMX_REQUIRE((reinterpret_cast<uintptr_t>(split_ws) & 15) == 0, "emx_sketchmap_split: workspace must be 16-byte aligned");
   const SplitRows sp = split_view(split_ws, B, D);
   if (D >= 1024 && B <= 8192) {
-    hipLaunchKernelGGL(sk_split_wide_kernel, dim3((unsigned)B), dim3(NT), 0, (hipStream_t)stream, X, D, ldx, sp);
+    hipLaunchKernelGGL(sk_split_wide_kernel, dim3((unsigned)B), dim3(SPW_NT), 0, (hipStream_t)stream, X, D, ldx, sp);
     return emx::check_launch("sk_split_wide_kernel");
   }
   hipLaunchKernelGGL(sk_split_kernel, dim3((unsigned)std::min((B + 3) / 4, 4096)), dim3(NT), 0, (hipStream_t)stream, X, B, D, ldx, sp);
