@@ -611,13 +611,23 @@ __global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict
   float* o = xyz + (long)b * A * 3;
   for (int i = lane; i < A - 2; i += 64) sm[i + 1] = PI_F - th[i];
   __syncthreads();
-  if (lane == 0) {
-    float phi = 0.f;
-    sm[0] = 0.f;
-    for (int i = 1; i < A - 1; ++i) {
-      phi = sm[i] - phi;
-      sm[i] = phi;
+  // phi_i = c_i - phi_{i-1}, phi_0 = 0  <=>  (-1)^i phi_i = sum_{k = 1..i} (-1)^k c_k: a prefix sum across the lanes, 64 steps
+  // at a time with a carry, instead of A - 2 dependent LDS round trips on one lane
+  {
+    float carry = 0.f;
+    for (int i0 = 1; i0 < A - 1; i0 += 64) {
+      const int i = i0 + lane;
+      float v = i < A - 1 ? ((i & 1) ? -sm[i] : sm[i]) : 0.f;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const float u = __shfl_up(v, off, 64);
+        if (lane >= off) v += u;
+      }
+      const float t = carry + v;
+      if (i < A - 1) sm[i] = (i & 1) ? -t : t;
+      carry += __shfl(v, 63, 64);
     }
+    if (lane == 0) sm[0] = 0.f;
   }
   __syncthreads();
   if (lane == 0) st3(o, V3{0.f, 0.f, 0.f});
