@@ -1054,7 +1054,8 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     // few tiles, many chunks (a small batch of very long rows, e.g. the pair-distance vectors of the ADC model): the tiles
     // alone would occupy a handful of CUs -- split each tile's reduction over workgroups (first launch), add the partials
     // up and run the epilogue (second launch)
-    const int ksplit = (b.kpart && b.xcd_nbg == 0 && nch >= 16) ? std::min(std::min(32, nch / 4), KSPLIT_BLOCKS / std::max(pl.ntiles, 1)) : 1;
+    static const int ksplit_cap = getenv("EMX_SK_KSPLIT") ? std::max(1, atoi(getenv("EMX_SK_KSPLIT"))) : 16;   // (measured at the ADC shape: 32 -> 180.8, 16 -> 178.3, 8 -> 179.8 us per step)
+    const int ksplit = (b.kpart && b.xcd_nbg == 0 && nch >= 16) ? std::min(std::min(ksplit_cap, nch / 4), KSPLIT_BLOCKS / std::max(pl.ntiles, 1)) : 1;
     if (ksplit > 1) {
       b.ksplit = ksplit;
       for (int mode = 1; mode <= 2; ++mode) {
