@@ -40,7 +40,7 @@ SIGNATURES = {
     "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p, _p]),
     "emx_sketchmap_split_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_split": (_i, [_p, _i, _i, _i, _p, _p]),
-    "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_sketchmap_describe": (_i, [_i, _i, _i, _p, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _sz, _p]),
     "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
     "emx_gather_rows": (_i, [_p, _l, _i, _p, _p, _i, _f, _p, _p, _p, _p]),
@@ -296,9 +296,10 @@ def sketchmap_split(X, split_ws):
     _check(load().emx_sketchmap_split(_ptr(X), B, D, X.stride(0), _ptr(split_ws), _stream()), "emx_sketchmap_split")
 
 
-def sketchmap_finish(B, D, Z, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws):
+def sketchmap_finish(B, D, Z, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws, periodicity=float("inf")):
+    """``periodicity``: the value given to ``sketchmap_tiles`` (it selects the tile size, hence the workspace layout)."""
     sig_arr = (_f * 6)(*[float(s) for s in sig])
-    _check(load().emx_sketchmap_finish(B, D, _ptr(Z), Z.shape[1], sig_arr, float(scale),
+    _check(load().emx_sketchmap_finish(B, D, _ptr(Z), Z.shape[1], float(periodicity), sig_arr, float(scale),
                                        float(center_scale if center_loss is not None else 0.0), int(row_begin), int(row_end),
                                        _ptr(dist_loss), _ptr(center_loss), _ptr(dZ), _ptr(ws), ws.numel() * ws.element_size(),
                                        _stream()), "emx_sketchmap_finish")

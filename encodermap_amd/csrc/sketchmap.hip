@@ -910,11 +910,25 @@ void dispatch2(const SkArgs& a, int ntiles, bool periodic, bool fast, hipStream_
   }
 }
 
-int pick_tile(int B, int nrows, bool gram) {
-  // 64x64 everywhere.  The MFMA (Gram) tiles exist in that size only, and the VALU kernel's 128x128 instantiation (half the
-  // LDS traffic per pair-element) needs 256 VGPRs + 12 AGPRs: one wave per SIMD, where the VALU issues 0.15 instructions
-  // per clock instead of 0.35 at four waves -- measured at B = 8192, D = 512 periodic: 2.19 ms against 1.40 ms.
-  (void)B;
+constexpr int SMALL_TILE_MAX_B = 512;   // batches up to this size run the VALU tiles at 32 x 32
+
+// floats of the per-tile partial sums + tile costs at the front of the workspace (the larger of the 64- and 32-tile layouts)
+size_t ws_front_floats(int B, int L) {
+  const size_t nb = (size_t)(B + 63) / 64;
+  const size_t f64 = nb * nb * 64 * (size_t)L + nb * nb + 64;
+  if (B > SMALL_TILE_MAX_B) return f64;
+  const size_t n32 = (size_t)(B + 31) / 32;
+  return std::max(f64, n32 * n32 * 32 * (size_t)L + n32 * n32 + 64);
+}
+
+int pick_tile(int B, int nrows, bool gram, bool periodic) {
+  if (periodic && B <= SMALL_TILE_MAX_B) return 32;   // (a function of B and the periodicity only: every entry point that plans
+                                                      //  the workspace layout knows both)
+  // 64x64 for every large batch.  The MFMA (Gram) tiles exist in that size only, and the VALU kernel's 128x128 instantiation
+  // (half the LDS traffic per pair-element) needs 256 VGPRs + 12 AGPRs: one wave per SIMD, where the VALU issues 0.15
+  // instructions per clock instead of 0.35 at four waves -- measured at B = 8192, D = 512 periodic: 2.19 ms against 1.40 ms.
+  // Small batches on the VALU tiles (periodic data): 32x32, because a 256-row batch is ten 64-tiles on ten CUs -- 36 tiles
+  // of a quarter of the pairs each finish sooner (the default EncoderMap parameters are such a batch).
   (void)nrows;
   (void)gram;
   return 64;
@@ -945,7 +959,7 @@ size_t emx_sketchmap_ws_bytes(int B, int L) {
   if (B <= 0 || L <= 0) return 0;
   size_t nb = (size_t)(B + 63) / 64;
   // + the Gram partials of the split reduction (small batches: at most KSPLIT_BLOCKS workgroups x 64 x 64 floats)
-  return (nb * nb * 64 * (size_t)L + nb * nb + 64 + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 : 0)) * sizeof(float);
+  return (ws_front_floats(B, L) + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 : 0)) * sizeof(float);
 }
 
 }  // extern "C" (ws_bytes)
@@ -980,7 +994,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   }
   const bool vec4ok = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const bool split_ok = split_ws != nullptr && pl.gram && !pl.periodic;
-  const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok);
+  const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok, pl.periodic);
   pl.T = T;
   pl.fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
   SkArgs& a = pl.a;
@@ -1011,7 +1025,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.kmode = 0;
   {
     const size_t nb = (size_t)(B + 63) / 64;
-    a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + (nb * nb * 64 * (size_t)L + nb * nb + 64) : nullptr;
+    a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + ws_front_floats(B, L) : nullptr;
   }
   FinArgs& f = pl.f;
   f.P = a.P;
@@ -1089,7 +1103,10 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     }
     return emx::check_launch("sk_tile_mfma_kernel");
   }
-  if (pl.T != 64) {
+  if (pl.T == 32) {
+    if (a.L == 2) dispatch2<32, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    else dispatch2<32, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
+  } else if (pl.T != 64) {
     return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_tiles: no %d x %d tile kernel", pl.T, pl.T);
   } else {
     if (a.L == 2) dispatch2<64, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
@@ -1198,12 +1215,12 @@ int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, i
   return launch_tiles_plan(pl, (hipStream_t)stream);
 }
 
-int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6], float scale, float center_scale,
+int emx_sketchmap_finish(int B, int D, const float* Z, int L, float periodicity, const float sig[6], float scale, float center_scale,
                          int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ, void* ws,
                          size_t ws_bytes, emx_stream_t stream) {
   EMX_REQUIRE(dist_loss && dZ, "emx_sketchmap_finish: null pointer argument");
   SkPlan pl;
-  int rc = make_plan(Z /* X unused by the finish pass */, B, D, D, Z, L, INFINITY, sig, scale, center_scale, row_begin, row_end,
+  int rc = make_plan(Z /* X unused by the finish pass */, B, D, D, Z, L, periodicity, sig, scale, center_scale, row_begin, row_end,
                      dist_loss, center_loss, dZ, ws, ws_bytes, pl, "emx_sketchmap_finish");
   if (rc) return rc;
   return launch_finish_plan(pl, (hipStream_t)stream);

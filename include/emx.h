@@ -86,7 +86,8 @@ int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, i
  * emx_sketchmap_split makes them from a dense [B, D] block.  split_ws: emx_sketchmap_split_bytes(B, D) bytes, 16-byte aligned. */
 size_t emx_sketchmap_split_bytes(int B, int D);
 int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, emx_stream_t stream);
-int emx_sketchmap_finish(int B, int D, const float* Z, int L, const float sig[6], float scale, float center_scale,
+int emx_sketchmap_finish(int B, int D, const float* Z, int L, float periodicity /* as given to emx_sketchmap_tiles: it selects the
+                         tile size, hence the layout of ws */, const float sig[6], float scale, float center_scale,
                          int row_begin, int row_end, float* dist_loss, float* center_loss, float* dZ,
                          void* ws, size_t ws_bytes, emx_stream_t stream);
 

@@ -547,3 +547,22 @@ def test_periodic_cost_batch_equals_separate_calls(L):
         js = jobs(dYa, dYla, wsa)
         js[1]["ws"] = js[0]["ws"]
         L.periodic_cost_batch(js, B, 0, B)
+
+
+@pytest.mark.parametrize("B,periodicity", [(200, 2 * PI), (513, 2 * PI), (200, INF)])
+def test_sketchmap_tiles_then_finish_equals_the_single_call(L, B, periodicity):
+    """emx_sketchmap_tiles + emx_sketchmap_finish (given the same periodicity: it selects the tile size -- 32 x 32 for periodic
+    batches of up to 512 rows -- and with it the workspace layout) == emx_sketchmap_fwd_bwd, bit for bit."""
+    rng = np.random.default_rng(B)
+    x, z = make_xz(rng, B, 12, 2, periodicity, 1.0)
+    sig = DEFAULT_SIG if periodicity != INF else (3.0, 12, 6, 1, 2, 6)
+    loss, cen, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
+    X, Z = dev(x), dev(z)
+    ws = torch.empty(L.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
+    dist, c2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    dZ = torch.full((B, 2), float("nan"), device="cuda")
+    L.sketchmap_tiles(X, Z, periodicity, sig, 0, B, ws, None)
+    L.sketchmap_finish(B, 12, Z, sig, 500.0, 1e-4, 0, B, dist, c2, dZ, ws, periodicity=periodicity)
+    torch.cuda.synchronize()
+    assert float(dist) == loss and float(c2) == cen
+    assert np.array_equal(dZ.cpu().numpy().astype(np.float64), g)
