@@ -996,6 +996,10 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
 static int wgrad_slice_rows(int n_rows) {
   int r = EMX_WGRAD_SLICE_ROWS;
   while ((long)r * EMX_WGRAD_MAX_SLICES < n_rows) r *= 2;
+  // small batches: shorter slices, so that a few hundred rows still spread over eight slices' worth of workgroups (the
+  // reduction over a slice's rows is a serial chain of 4-row steps per workgroup)
+  static const int min_rows = getenv("EMX_WGRAD_MIN_SLICE") ? std::max(4, atoi(getenv("EMX_WGRAD_MIN_SLICE"))) : 32;
+  while (r > min_rows && n_rows < 8 * r) r /= 2;
   return r;
 }
 
