@@ -196,7 +196,9 @@ def test_gather_and_periodic_transforms(L, periodicity):
 
 @pytest.mark.parametrize("variant", ["mean_abs", "mean_square", "mean_norm"])
 @pytest.mark.parametrize("periodicity,periodic_output", [(2 * PI, True), (360.0, True), (INF, False), (2 * PI, False)])
-@pytest.mark.parametrize("B,n", [(203, 45), (131, 1500)])     # 1500 columns: one workgroup per row instead of one wave
+# 45 columns: a wave per row; 1500 columns of 131 rows: three workgroups per row; 200 columns of 300 rows: a workgroup per row;
+# 1100 columns of 1500 rows: a workgroup per row, more rows than workgroups
+@pytest.mark.parametrize("B,n", [(203, 45), (131, 1500), (300, 200), (1500, 1100)])
 def test_periodic_cost(L, variant, periodicity, periodic_output, B, n):
     rng = np.random.default_rng(8)
     lim = PI if periodicity == INF else periodicity / 2
