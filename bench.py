@@ -171,7 +171,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
-    device = f"cuda:{local_rank}"
+    # self-test hooks (not benchmark configurations): EMX_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and EMX_BENCH_BACKEND=gloo
+    # replaces RCCL, so that the N > 1 plumbing of this script can be run with two ranks on a one-GPU box
+    one_device = os.environ.get("EMX_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("EMX_BENCH_BACKEND", "nccl")
+    device = "cuda:0" if one_device else f"cuda:{local_rank}"
     multi = world > 1 or (args.one_rank_dp and world == 1)
     if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
         del os.environ["NCCL_DEBUG"]   # (RCCL's version banner goes to stdout, which is reserved for the JSON line)
@@ -181,20 +185,27 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("LOCAL_RANK", "0")
-    graph_allreduce = multi and probe_graph_allreduce(world) if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None else \
-        os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1"
+    if backend != "nccl":
+        graph_allreduce = False             # only an RCCL all-reduce can be captured
+    elif os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None:
+        graph_allreduce = multi and probe_graph_allreduce(world)
+    else:
+        graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1"
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
     if multi:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import encodermap_amd as em
     from encodermap_amd.engine import DataParallel, SequentialEngine
 
     if multi:
         # every rank must take the same path: the captured all-reduce only if the probe passed on ALL ranks
-        flag = torch.tensor([1.0 if graph_allreduce else 0.0], device=device)
+        flag = torch.tensor([1.0 if graph_allreduce else 0.0], device=device if backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         graph_allreduce = bool(float(flag) == 1.0)
         SequentialEngine._dp_graph_allreduce = graph_allreduce
@@ -223,7 +234,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if multi:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     losses = eng.losses()
@@ -240,6 +251,7 @@ def main():
                                    "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
                        "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
                        "allreduce": ("captured in the step graph" if graph_allreduce else "eager between two graphs") if multi else None,
+                       **({"self_test": f"backend {backend}, one device: {one_device}"} if (one_device or backend != "nccl") else {}),
                        "hip_graph": True},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }

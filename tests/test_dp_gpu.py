@@ -122,3 +122,24 @@ def test_one_rank_over_rccl(tmp_path):
     np.testing.assert_array_equal(r["eager"], r["captured"])          # same kernels, same order: bitwise the same run
     np.testing.assert_array_equal(r["eager_w"], r["captured_w"])
     np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-5)    # one rank averages with itself: the single-process run
+
+
+def test_bench_script_with_two_ranks(tmp_path):
+    """bench.py's N > 1 plumbing (rank environment, DataParallel replica mode, barrier, MAX over ranks of the timed region,
+    one JSON line from rank 0) under torch.distributed.run with two ranks -- on this one GPU through its self-test hooks
+    (EMX_BENCH_ONE_DEVICE, EMX_BENCH_BACKEND=gloo; the RCCL path itself needs two GPUs)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMX_BENCH_ONE_DEVICE="1", EMX_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 2 * 4096 and line["config"]["parallelism"] == "dp2-replica"
+    assert line["value"] == pytest.approx(2 * 4096 * line["steps_per_sec"], rel=1e-6)
+    assert all(np.isfinite(v) for v in line["loss_first_last"]) and "cpu_baseline" not in line
