@@ -14,20 +14,12 @@ h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
 dl = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
 plan = _lib.MlpPlan(lay, params, h, dl)
 x = torch.randn(B, D, device="cuda")
-fused = len(sys.argv) > 2 and sys.argv[2] == "fused"
 fusedbwd = len(sys.argv) > 2 and sys.argv[2] == "fusedbwd"
 if fusedbwd:
     xb = x; dlat = torch.zeros(B, 2, device="cuda"); cws = torch.zeros(_lib.mlp_row_blocks(B), device="cuda")
     cost = _lib.make_auto_cost(xb, D, 0, D, False, float("inf"), "mean_square", 1.0, B, dl[-1], cws)
     for _ in range(20): _lib.mlp_forward_backward(plan, 0, n, x, 0, B, cost, lay.n_enc, dbelow=dlat)
     n = n + 3   # units: 6 forward + 3 backward
-elif fused:
-    N = 1000000
-    data = torch.randn(N, D, device="cuda"); idx = torch.randint(0, N, (4 * B,), device="cuda"); cursor = torch.tensor([1], device="cuda")
-    xb = torch.zeros(B, D, device="cuda"); dY = torch.zeros(B, D, device="cuda"); cws = torch.zeros(_lib.mlp_row_blocks(B), device="cuda")
-    feed = _lib.make_feed(data, idx, cursor, B, float("inf"), xb, None)
-    cost = _lib.make_auto_cost(xb, D, 0, D, False, float("inf"), "mean_square", 1.0, B, dY, cws)
-    for _ in range(20): _lib.mlp_forward(plan, 0, n, None, 0, B, feed=feed, cost=cost)
 else:
     for _ in range(20): _lib.mlp_forward(plan, 0, n, x, 0, B)
 torch.cuda.synchronize()
