@@ -6,7 +6,8 @@ from encodermap_amd import _lib
 _lib.LIB_PATH = os.path.abspath(sys.argv[1])
 from encodermap_amd.layout import build_layout, init_parameters
 lib = _lib.load()
-B, D = 4096, 128
+B = int(sys.argv[3]) if len(sys.argv) > 3 else 4096   # rows
+D = int(sys.argv[4]) if len(sys.argv) > 4 else 128    # width of the network's input (2 x features for periodic data)
 lay = build_layout([128, 128, 2], ["", "tanh", "tanh", ""], D)
 n = len(lay.layers)
 params = torch.from_numpy(init_parameters(lay, 0)).cuda()
@@ -26,7 +27,7 @@ torch.cuda.synchronize()
 buf = np.zeros(8192, dtype=np.int64)
 lib.emx_debug_read.argtypes = [ctypes.c_void_p]
 assert lib.emx_debug_read(buf.ctypes.data) == 0
-for blk in (0, 1):
+for blk in ((0, 1) if B >= 16 * 101 else (0,)):   # (the kernel records workgroups 0 and 100)
     clk = buf[blk * 2048: blk * 2048 + 512].reshape(8, 64); wall = clk * 0
     nslot = 3 + 5 * n
     for w in (0, 3, 7):
