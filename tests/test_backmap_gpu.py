@@ -42,7 +42,7 @@ def make_chain(rng, B, A):
 
 def test_colmean(L):
     rng = np.random.default_rng(0)
-    for B, n in [(256, 227), (1000, 3), (7, 130)]:
+    for B, n in [(256, 227), (1000, 3), (7, 130), (16, 64), (17, 65), (1, 5), (300, 680)]:
         x = rng.normal(1, 2, (B, n)).astype(np.float32)
         out = torch.empty(n, device="cuda")
         L.colmean(dev(x), out)
@@ -104,10 +104,12 @@ def test_backmapping_helix_table(L):
     np.testing.assert_allclose(D.pdist_flat(out.cpu().numpy().astype(np.float64))[0], D.pdist_flat(tab[None])[0], atol=2e-4)
 
 
-@pytest.mark.parametrize("A,start,step,C", [(228, 1, 3, 76), (24, 0, 1, 24), (30, 2, 4, 7), (10, 0, 1, 2)])
-def test_pdist_flat(L, A, start, step, C):
+# the backward pass spreads an atom's terms over 8 / 4 / 2 / 1 lanes (C <= 128 / 256 / 512 / more) and stages the gradient row
+# in LDS when it fits (C <= ~180); 1100 atoms: more atoms than threads
+@pytest.mark.parametrize("A,start,step,C,B", [(228, 1, 3, 76, 37), (24, 0, 1, 24, 37), (30, 2, 4, 7, 37), (10, 0, 1, 2, 37), (150, 0, 1, 150, 9),
+                                             (200, 0, 1, 200, 5), (457, 0, 1, 457, 3), (1100, 0, 1, 1100, 2)])
+def test_pdist_flat(L, A, start, step, C, B):
     rng = np.random.default_rng(C)
-    B = 37
     xyz = rng.normal(0, 3, (B, A, 3)).astype(np.float32)
     xyz[:, start + step] = xyz[:, start]           # coincident atoms: exact 0 and zero gradient (distances.py:247-253)
     P = C * (C - 1) // 2
