@@ -233,8 +233,10 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
 
-  int ti, tj;
-  if (a.symm) {
+  int ti, tj, tslot = blockIdx.x;
+  if (a.xcd_nbg > 0) {   // XCD-aware order (xcd_tile): every XCD's L2 sees half of the row panels instead of all of them
+    if (!xcd_tile(blockIdx.x, a.xcd_nbg, a.nbc, ti, tj, tslot)) return;
+  } else if (a.symm) {
     tri_decode(blockIdx.x, a.nbc, ti, tj);
   } else {
     ti = blockIdx.x / a.nbc;
@@ -358,7 +360,7 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   // tile loss: deterministic block reduction (own small LDS area behind the partials)
   float* red = smem + SMEM - 8;
   float tl = block_sum<NT>(lsum, red);  // contains __syncthreads -> partials visible
-  if (tid == 0) a.tile_loss[blockIdx.x] = offdiag ? 2.f * tl : tl;
+  if (tid == 0) a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
 
   // fold the 16 partials per (row, l) in fixed order and publish to this tile's private slot
   for (int e = tid; e < TM * LMAX; e += NT) {
@@ -1109,8 +1111,15 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   } else if (pl.T != 64) {
     return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_tiles: no %d x %d tile kernel", pl.T, pl.T);
   } else {
-    if (a.L == 2) dispatch2<64, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
-    else dispatch2<64, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    SkArgs b = a;
+    int grid = pl.ntiles;
+    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    if (a.symm && a.nbc >= 16 && xcd_order) {   // as for the f16 tiles: 8 x the largest share, surplus blocks leave at once
+      b.xcd_nbg = (a.nbc + 3) / 4;
+      grid = 8 * b.xcd_nbg * (b.xcd_nbg + 1);
+    }
+    if (a.L == 2) dispatch2<64, 2>(b, grid, pl.periodic, pl.fast, st);
+    else dispatch2<64, 0>(b, grid, pl.periodic, pl.fast, st);
   }
   return emx::check_launch("sk_tile_kernel");
 }
