@@ -20,8 +20,19 @@ MEAN_ABS, MEAN_SQUARE, MEAN_NORM = 0, 1, 2
 VARIANTS = {"mean_abs": MEAN_ABS, "mean_square": MEAN_SQUARE, "mean_norm": MEAN_NORM}
 
 
+EMX_EUNSUPPORTED = -2   # include/emx.h: the launch plan does not fit (LDS images, unit count, latent width): try another plan
+
+
 class EmxError(RuntimeError):
-    pass
+    """A rejected libemx call; ``code`` is the entry point's return value (0 for errors raised by the binding itself)."""
+
+    def __init__(self, msg, code: int = 0):
+        super().__init__(msg)
+        self.code = int(code)
+
+    @property
+    def unsupported(self) -> bool:
+        return self.code == EMX_EUNSUPPORTED
 
 
 _f = C.c_float
@@ -231,7 +242,7 @@ def load() -> C.CDLL:
 
 def _check(rc: int, what: str) -> None:
     if rc != 0:
-        raise EmxError(f"{what} failed ({rc}): {load().emx_last_error().decode()}")
+        raise EmxError(f"{what} failed ({rc}): {load().emx_last_error().decode()}", rc)
 
 
 def require_gpu() -> None:

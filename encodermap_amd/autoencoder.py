@@ -157,6 +157,7 @@ class Autoencoder:
         eng = getattr(self, "_engine", None)
         if eng is not None and self.train_data.shape[1] == eng.D:
             eng.set_data(self.train_data)
+            self._data_missing = False   # a model reloaded without data (from_checkpoint) can train from here on
 
     def _get_model(self) -> ModelView:
         from .engine import SequentialEngine

@@ -78,7 +78,8 @@ def resolve(checkpoint_path) -> Path:
 
 
 def reconcile_step(ckpt: Path, p, use_previous_model: bool):
-    """The intermediate-step rule of the reference (saving_loading_models.py:542-559, 597-614)."""
+    """The intermediate-step rule of the reference: the ADC (``cartesian``) branch resumes at ``step + 1``
+    (saving_loading_models.py:542-559), the plain Autoencoder / EncoderMap branch at ``step`` (597-616)."""
     step = step_of(ckpt)
     if step is None or step == p.current_training_step:
         return p
@@ -96,7 +97,8 @@ def reconcile_step(ckpt: Path, p, use_previous_model: bool):
         s = step_of(f)
         if s is not None and s > step:
             shutil.copyfile(f, f.parent / (f.name[: -len(SUFFIX)] + f"_backup_from_{step}_{_now()}" + SUFFIX))
-    p.current_training_step = step + 1
-    p.n_steps = step + 1
+    resume = step + 1 if hasattr(p, "cartesian_cost_scale") else step
+    p.current_training_step = resume
+    p.n_steps = resume
     p.save()
     return p

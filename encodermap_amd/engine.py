@@ -244,7 +244,9 @@ class SequentialEngine:
                     _lib.mlp_forward_backward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost, lay.n_enc,
                                               dbelow=self.dlat)
                 return True
-            except _lib.EmxError:
+            except _lib.EmxError as exc:
+                if not exc.unsupported:        # only "this plan does not fit" switches the plan; every other error is a bug
+                    raise
                 self._fuse_decoder = False     # e.g. layers too wide for one LDS image per layer: two launches from now on
                 return self._forward()
         if self._cost_in_forward or cost is None:
@@ -255,8 +257,8 @@ class SequentialEngine:
                     _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
                     _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost=cost)
                 return False
-            except _lib.EmxError:
-                if cost is None:
+            except _lib.EmxError as exc:
+                if cost is None or not exc.unsupported:
                     raise
                 self._cost_in_forward = False   # output rows too wide to keep their targets in LDS next to the images
         # widest nets: plain forward launch, the auto cost as its own kernel (its workgroup shares land in cost_ws as well)
@@ -481,6 +483,13 @@ class SequentialEngine:
         finally:
             if gc_was_on:
                 gc.enable()
+        # first replays are slower than later ones (the graph's kernels and nodes are uploaded on first use): pay that here,
+        # not inside the first timed multi-step replay of a short warm-up
+        restore()
+        for g in (self._graph_multi, *((self._graph if len(self._graph) == 1 else ()))):
+            if g is not None:
+                g.replay()
+        torch.cuda.synchronize()
         restore()
 
     def _replay(self) -> None:
@@ -503,6 +512,14 @@ class SequentialEngine:
         block = index_block if index_block is not None else self.draw_index_block(n_steps)
         if block.numel() != n_steps * self.B:
             raise ValueError(f"index block has {block.numel()} entries, expected {n_steps} x {self.B}")
+        if index_block is not None:
+            # the gather kernels dereference data + idx * D unchecked: validate a caller's block once, outside the graph
+            wrong_dev = block.device.type != self.device.type or (self.device.index is not None and block.device.index != self.device.index)
+            if block.dtype != torch.int64 or wrong_dev:
+                raise ValueError(f"index block must be an int64 tensor on {self.device}, got {block.dtype} on {block.device}")
+            lo, hi = (int(v) for v in torch.aminmax(block))
+            if lo < 0 or hi >= self.data.shape[0]:
+                raise ValueError(f"index block holds rows in [{lo}, {hi}], the data set has {self.data.shape[0]} rows")
         cap = self._block_capacity()
         if self.idx_block is None or self.idx_block.numel() < cap * self.B:
             self.idx_block = torch.zeros(cap * self.B, dtype=torch.int64, device=self.device)

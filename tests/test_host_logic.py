@@ -165,7 +165,11 @@ def test_checkpoint_roundtrip_and_rules(tmp_path):
     with pytest.raises(Exception, match="intermediate"):
         ckpt.reconcile_step(tmp_path / "saved_model_10.emx.npz", p, False)
     p2 = ckpt.reconcile_step(tmp_path / "saved_model_10.emx.npz", p, True)
-    assert p2.current_training_step == 11 and p2.n_steps == 11
+    assert p2.current_training_step == 10 and p2.n_steps == 10      # non-ADC branch: no +1 (saving_loading_models.py:614-615)
+    pa = em.ADCParameters(main_path=str(tmp_path), current_training_step=20, n_steps=20)
+    pa.save()
+    pa2 = ckpt.reconcile_step(tmp_path / "saved_model_10.emx.npz", pa, True)
+    assert pa2.current_training_step == 11 and pa2.n_steps == 11    # ADC branch: step + 1 (saving_loading_models.py:557-558)
     assert list(tmp_path.glob("parameters_at_20_*")) and list(tmp_path.glob("saved_model_20_backup_from_10_*"))
     stamped = ckpt.checkpoint_name(tmp_path, None)
     assert re.fullmatch(r"saved_model_\d{4}-\d\d-\d\dT.*\.emx\.npz", stamped.name)

@@ -194,11 +194,16 @@ def test_facade_train_checkpoint_resume(em, tmp_path):
     with pytest.raises(Exception, match="intermediate"):
         em.EncoderMap.from_checkpoint(tmp_path / "saved_model_10.emx.npz", train_data=data)
     e3 = em.EncoderMap.from_checkpoint(tmp_path / "saved_model_10.emx.npz", train_data=data, use_previous_model=True)
-    assert e3.p.current_training_step == 11 and e3.p.n_steps == 11
-    # reload without data: train() reports missing data instead of training on the placeholder
+    # plain Autoencoder / EncoderMap branch: resumes AT the checkpoint's step (saving_loading_models.py:614-615; +1 only for ADC)
+    assert e3.p.current_training_step == 10 and e3.p.n_steps == 10 and e3._engine.current_step() == 10
+    # reload without data: train() reports missing data instead of training on the placeholder ...
     e4 = em.EncoderMap.from_checkpoint(tmp_path)
     e4.p.n_steps += 5
     assert e4.train() is None
+    # ... and trains once set_train_data() has provided it (the flow the message recommends)
+    e4.set_train_data(data)
+    h4 = e4.train()
+    assert h4 is not None and len(h4.history["loss"]) == 5 and all(np.isfinite(h4.history["loss"]))
 
 
 def test_facade_defaults_and_errors(em, tmp_path):
