@@ -82,16 +82,17 @@ SIGNATURES = {
     "emx_allatom_backmap": (_i, [_p, _l, _l, _i, _p, _p, _i, _p, _l, _p, _p]),
     "emx_mlp_mirror_floats": (_sz, [_p]),
     "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
-    "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p]),
+    "emx_mlp_aop_bytes": (_sz, [_p, _i]),
+    "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     "emx_mlp_row_blocks": (_i, [_i]),
-    "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p]),
+    "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "emx_clash_count": (_i, [_p, _i, _i, _f, _p, _p]),
     "emx_kabsch_rmsd": (_i, [_p, _p, _i, _i, C.POINTER(_f), _i, _p, _p]),
     "emx_metric_tick": (_i, [_p, _p, _i, _p, _p, _l, _p, _p]),
-    "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p]),
-    "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p]),
+    "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p]),
+    "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
-    "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _p, _p, _sz, _p, _p]),
+    "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
 }
 
 EMX_MAX_LAYERS = 8
@@ -183,9 +184,13 @@ class MlpDesc(C.Structure):
 
 
 class MlpPlan:
-    """Descriptor + pointer tables for one network (built once per engine)."""
+    """Descriptor + pointer tables for one network (built once per engine).
 
-    def __init__(self, layout, params, h, delta, mirror=None):
+    ``mirror``: the weight operand store (include/emx.h, emx_mlp_mirror), shared between plans over the same weights.
+    ``train_rows``: > 0 allocates the weight-gradient operand store for batches of that many rows (emx_mlp_aop_bytes);
+    forward / backward launches then leave their fragments there and ``mlp_wgrad`` consumes them.  0: inference only."""
+
+    def __init__(self, layout, params, h, delta, mirror=None, train_rows: int = 0):
         n = len(layout.layers)
         if n > EMX_MAX_LAYERS:
             raise EmxError(f"{n} dense layers not supported by the fused MLP kernels (max {EMX_MAX_LAYERS})")
@@ -204,17 +209,26 @@ class MlpPlan:
         PtrArr = _p * EMX_MAX_LAYERS
         self.h = PtrArr(*[(t.data_ptr() if t is not None else None) for t in h] + [None] * (EMX_MAX_LAYERS - n))
         self.delta = PtrArr(*[(t.data_ptr() if t is not None else None) for t in delta] + [None] * (EMX_MAX_LAYERS - n))
-        # W^T copy read by the forward kernel (include/emx.h, emx_mlp_mirror); shared between plans over the same weights
         if mirror is None:
-            import torch
             mirror = torch.zeros(load().emx_mlp_mirror_floats(C.byref(d)), dtype=torch.float32, device=params.device)
             self.mirror = mirror
             self.refresh_mirror()
         self.mirror = mirror
+        self.aop_rows = int(train_rows)
+        self.aop = None
+        if self.aop_rows > 0:
+            self.aop = torch.zeros(load().emx_mlp_aop_bytes(C.byref(d), self.aop_rows), dtype=torch.uint8, device=params.device)
 
     def refresh_mirror(self):
-        """Rebuild the mirror after `params` was written by anything other than emx_adam_step*."""
+        """Rebuild the operand store after `params` was written by anything other than emx_adam_step*."""
         _check(load().emx_mlp_mirror(C.byref(self.desc), _ptr(self.params), _ptr(self.mirror), _stream()), "emx_mlp_mirror")
+
+    def aop_args(self, train: bool):
+        """(aop pointer, aop_rows) for a launch; (NULL, 0) for inference launches or plans without a store."""
+        if not train or self.aop is None:
+            return None, 0
+        return self.aop.data_ptr(), self.aop_rows
+
 
 _lib = None
 
@@ -443,17 +457,22 @@ def step_tick(terms, n_terms, history, term_history, step, cursor=None, counter2
                                 _stream()), "emx_step_tick")
 
 
-def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" = None):
-    """Layers [l0, l1) on rows [row_begin, row_end); ``cost`` evaluates the auto cost on the last layer's rows in the same launch."""
+def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" = None, train: bool = True):
+    """Layers [l0, l1) on rows [row_begin, row_end); ``cost`` evaluates the auto cost on the last layer's rows in the same launch.
+    ``train``: leave the weight-gradient fragments in the plan's store (if it has one; the row range must then start at a
+    multiple of 16)."""
+    ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_forward_cost(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
-                                       int(row_end), plan.h, C.byref(cost) if cost is not None else None, _stream()), "emx_mlp_forward")
+                                       int(row_end), plan.h, C.byref(cost) if cost is not None else None, ap, ar, _stream()),
+           "emx_mlp_forward")
 
 
-def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None):
+def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None, train: bool = True):
     """Forward [l0, l1), auto cost, backward-data through [bwd_begin, l1) in one launch (delta[l1 - 1] = d cost / d output)."""
+    ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_forward_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
                                            int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, _ptr(dbelow),
-                                           _stream()), "emx_mlp_forward_backward")
+                                           ap, ar, _stream()), "emx_mlp_forward_backward")
 
 
 def clash_count(xyz, clash_distance, counts):
@@ -481,10 +500,11 @@ def mlp_row_blocks(n_rows):
     return int(load().emx_mlp_row_blocks(int(n_rows)))
 
 
-def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None):
+def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None, train: bool = True):
+    ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
                                    int(layer_add), C.byref(latent) if latent is not None else None, _ptr(dbelow), int(row_begin),
-                                   int(row_end), plan.h, plan.delta, _stream()), "emx_mlp_backward")
+                                   int(row_end), plan.h, plan.delta, ap, ar, _stream()), "emx_mlp_backward")
 
 
 def sketchmap_describe(X, Z, periodicity, sig, scale, center_scale, row_begin, row_end, ws) -> SketchmapPartials:
@@ -509,11 +529,14 @@ def mlp_wgrad_ws_floats(n_params, n_rows):
     return int(load().emx_mlp_wgrad_ws_floats(int(n_params), int(n_rows)))
 
 
-def mlp_wgrad(plan: MlpPlan, l0, l1, xin, row_begin, row_end, grad, ws, finish: "FinishDesc" = None):
-    """grad=None leaves the per-slice partials in ws (consumed by adam_step_slices); ``finish``: the step's scalar epilogue
-    rides along as one extra workgroup."""
-    _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, _ptr(xin), xin.stride(0),
-                                int(row_begin), int(row_end), plan.h, plan.delta, _ptr(grad), _ptr(ws), ws.numel(),
+def mlp_wgrad(plan: MlpPlan, l0, l1, row_begin, row_end, grad, ws, finish: "FinishDesc" = None):
+    """Weight gradients of layers [l0, l1) over rows [row_begin, row_end) from the fragments the forward and backward launches
+    left in the plan's store.  grad=None leaves the per-slice partials in ws (consumed by adam_step_slices); ``finish``: the
+    step's scalar epilogue rides along as one extra workgroup."""
+    if plan.aop is None:
+        raise EmxError("mlp_wgrad: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
+    _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, plan.aop.data_ptr(), plan.aop_rows,
+                                int(row_begin), int(row_end), _ptr(grad), _ptr(ws), ws.numel(),
                                 C.byref(finish) if finish is not None else None, _stream()), "emx_mlp_wgrad")
 
 

@@ -127,7 +127,7 @@ class ADCEngine(SequentialEngine):
         self._row_of = {T_CART: 0, T_DIH: 1, T_ANG: 2, T_SIDE: 3}
         self._cost_rows = [(0, T_CART), (1, T_DIH), (2, T_ANG)] + ([(3, T_SIDE)] if self.S else [])
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
-        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
+        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
 
     # -- data ------------------------------------------------------------------------------------------
     def set_data(self, angles, dihedrals, cartesians, distances, side_dihedrals=None) -> None:

@@ -3,7 +3,7 @@
 // where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
 #include "emx_common.h"
 #include "cost.h"
-#include "mirror.h"
+#include "wop.h"
 #include "split.h"
 
 namespace {
@@ -227,8 +227,10 @@ struct AdamArgs {
   int late;             // the step's bookkeeping already ran (emx_finish_desc of emx_mlp_wgrad): t = *step, the regulariser shares are
                         // those of the NEW weights (the next step's cost), the next batch is the one under *cursor
 
-  float* mirror;        // optional: operand store of the dense layers, rewritten with the new weights (mirror.h)
-  MirrorArgs mir;
+  char* mirror;         // optional: weight operand store of the dense layers, rewritten with the new weights (wop.h)
+  WopArgs mir;
+  int bias_item_begin[EMX_MAX_LAYERS + 1];   // with a store: work items behind the 32 x 32 kernel blocks, 64 bias elements each
+  long b_off[EMX_MAX_LAYERS];
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
   GatherArgs next;
 
@@ -302,6 +304,19 @@ __device__ __forceinline__ float4 grad4(const AdamArgs& a, long i4) {
                      (p0.w + p1.w) + (p2.w + p3.w));
 }
 
+// one element, with grad4's association (slice s goes to partial s % 4): the same bits whichever path updates an element
+__device__ __forceinline__ float grad1(const AdamArgs& a, long i) {
+  if (!a.gpart) return a.g[i];
+  float p[4] = {0.f, 0.f, 0.f, 0.f};
+  int s = 0;
+  for (; s + 4 <= a.n_slices; s += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) p[u] += a.gpart[(long)(s + u) * a.gstride + i];
+  }
+  for (; s < a.n_slices; ++s) p[0] += a.gpart[(long)s * a.gstride + i];
+  return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 // Launched with one wave per workgroup: the update of ~1e5 parameters reads 36 streams (32 gradient slices, w, m, v,
 // l2coef), ~150 KB per 1024 parameters, and a CU takes 64 B/clk -- on 65 CUs (256-thread workgroups) the loads alone were
 // 2300+ cycles of L1 fill per CU; one wave per workgroup spreads them over every CU.
@@ -340,46 +355,116 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     return a.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.log2_b1));
   };
   float reg = 0.f;
-  const long n4 = a.n >> 2;
   const bool vec = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.m) |
                      reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef) | reinterpret_cast<uintptr_t>(a.gpart) |
                      (uintptr_t)(a.gstride * 4)) & 15) == 0;
-  long start = 0;
-  if (vec) {
-    for (long i = (long)blockIdx.x * nt + threadIdx.x; i < n4; i += (long)nblk * nt) {
-      float4 w = reinterpret_cast<float4*>(a.w)[i];
-      float4 m = reinterpret_cast<float4*>(a.m)[i];
-      float4 v = reinterpret_cast<float4*>(a.v)[i];
-      float4 l = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 g = grad4(a, i);
-      const float alpha = alpha_of(step_now);
-      FSTAMP(17);
-      adam_one(w.x, g.x, m.x, v.x, l.x, a, alpha, reg);
-      adam_one(w.y, g.y, m.y, v.y, l.y, a, alpha, reg);
-      adam_one(w.z, g.z, m.z, v.z, l.z, a, alpha, reg);
-      adam_one(w.w, g.w, m.w, v.w, l.w, a, alpha, reg);
-      reinterpret_cast<float4*>(a.w)[i] = w;
-      reinterpret_cast<float4*>(a.m)[i] = m;
-      reinterpret_cast<float4*>(a.v)[i] = v;
-      FSTAMP(18);
-      if (a.mirror) mirror_scatter4(a.mir, a.mirror, 4 * i, w.x, w.y, w.z, w.w);
+  if (a.mirror) {
+    // With a weight operand store the kernels are walked by 32 x 32 block, one wave each: the block's new weights, their
+    // scale (the block's largest |w|) and its f16 pair fragments for both directions leave in the same pass (wop.h).
+    // Lane (kr = lane >> 3, c4 = lane & 7) owns W[32 kb + kr + 8 j][32 nb + 4 c4 + i].  Biases follow as items of 64.
+    __shared__ __align__(16) _Float16 img[2048];
+    const int lane = threadIdx.x & 63;
+    const int n_blocks = a.mir.item_begin[a.mir.n_layers], n_items = a.bias_item_begin[a.mir.n_layers];
+    for (int item = blockIdx.x; item < n_items; item += nblk) {
+      if (item < n_blocks) {
+        int l, kb, nb;
+        wop_item(a.mir, item, l, kb, nb);
+        const int K = a.mir.K[l], N = a.mir.N[l];
+        const long woff = a.mir.w_off[l];
+        const int kr = lane >> 3, c4 = lane & 7;
+        const bool lvec = vec && (N & 3) == 0 && (woff & 3) == 0;
+        float wv[16];
+        float4 w4[4], m4[4], v4[4], l4[4], g4[4];
+        bool full[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 32 * kb + kr + 8 * j, c = 32 * nb + 4 * c4;
+          full[j] = lvec && k < K && c + 3 < N;
+          if (full[j]) {
+            const long i4 = (woff + (long)k * N + c) >> 2;
+            w4[j] = reinterpret_cast<float4*>(a.w)[i4];
+            m4[j] = reinterpret_cast<float4*>(a.m)[i4];
+            v4[j] = reinterpret_cast<float4*>(a.v)[i4];
+            l4[j] = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            g4[j] = grad4(a, i4);
+          }
+        }
+        const float alpha = alpha_of(step_now);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int k = 32 * kb + kr + 8 * j, c = 32 * nb + 4 * c4;
+          if (full[j]) {
+            adam_one(w4[j].x, g4[j].x, m4[j].x, v4[j].x, l4[j].x, a, alpha, reg);
+            adam_one(w4[j].y, g4[j].y, m4[j].y, v4[j].y, l4[j].y, a, alpha, reg);
+            adam_one(w4[j].z, g4[j].z, m4[j].z, v4[j].z, l4[j].z, a, alpha, reg);
+            adam_one(w4[j].w, g4[j].w, m4[j].w, v4[j].w, l4[j].w, a, alpha, reg);
+            const long i4 = (woff + (long)k * N + c) >> 2;
+            reinterpret_cast<float4*>(a.w)[i4] = w4[j];
+            reinterpret_cast<float4*>(a.m)[i4] = m4[j];
+            reinterpret_cast<float4*>(a.v)[i4] = v4[j];
+            wv[4 * j] = w4[j].x, wv[4 * j + 1] = w4[j].y, wv[4 * j + 2] = w4[j].z, wv[4 * j + 3] = w4[j].w;
+          } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              float wn = 0.f;
+              if (k < K && c + i < N) {
+                const long e = woff + (long)k * N + c + i;
+                float mm = a.m[e], vv = a.v[e];
+                wn = a.w[e];
+                adam_one(wn, grad1(a, e), mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha, reg);
+                a.w[e] = wn;
+                a.m[e] = mm;
+                a.v[e] = vv;
+              }
+              wv[4 * j + i] = wn;
+            }
+          }
+        }
+        wop_write_block(a.mir, a.mirror, l, kb, nb, wv, lane, img);
+      } else {
+        int l = 0;
+        while (l + 1 < a.mir.n_layers && item >= a.bias_item_begin[l + 1]) ++l;
+        const int j = (item - a.bias_item_begin[l]) * 64 + lane;
+        if (j < a.mir.N[l]) {
+          const long e = a.b_off[l] + j;
+          float wn = a.w[e], mm = a.m[e], vv = a.v[e];
+          adam_one(wn, grad1(a, e), mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha_of(step_now), reg);
+          a.w[e] = wn;
+          a.m[e] = mm;
+          a.v[e] = vv;
+        }
+      }
     }
-    start = n4 << 2;
-  }
-  for (long i = start + (long)blockIdx.x * nt + threadIdx.x; i < a.n; i += (long)nblk * nt) {
-    float w = a.w[i], m = a.m[i], v = a.v[i];
-    float g;
-    if (a.gpart) {
-      g = 0.f;
-      for (int s = 0; s < a.n_slices; ++s) g += a.gpart[(long)s * a.gstride + i];
-    } else {
-      g = a.g[i];
+  } else {
+    const long n4 = a.n >> 2;
+    long start = 0;
+    if (vec) {
+      for (long i = (long)blockIdx.x * nt + threadIdx.x; i < n4; i += (long)nblk * nt) {
+        float4 w = reinterpret_cast<float4*>(a.w)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        float4 l = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = grad4(a, i);
+        const float alpha = alpha_of(step_now);
+        FSTAMP(17);
+        adam_one(w.x, g.x, m.x, v.x, l.x, a, alpha, reg);
+        adam_one(w.y, g.y, m.y, v.y, l.y, a, alpha, reg);
+        adam_one(w.z, g.z, m.z, v.z, l.z, a, alpha, reg);
+        adam_one(w.w, g.w, m.w, v.w, l.w, a, alpha, reg);
+        reinterpret_cast<float4*>(a.w)[i] = w;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+        FSTAMP(18);
+      }
+      start = n4 << 2;
     }
-    adam_one(w, g, m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha_of(step_now), reg);
-    a.w[i] = w;
-    a.m[i] = m;
-    a.v[i] = v;
-    if (a.mirror) mirror_scatter(a.mir, a.mirror, i, w);
+    for (long i = start + (long)blockIdx.x * nt + threadIdx.x; i < a.n; i += (long)nblk * nt) {
+      float w = a.w[i], m = a.m[i], v = a.v[i];
+      adam_one(w, grad1(a, i), m, v, a.l2coef ? a.l2coef[i] : 0.f, a, alpha_of(step_now), reg);
+      a.w[i] = w;
+      a.m[i] = m;
+      a.v[i] = v;
+    }
   }
   FSTAMP(19);
   reg = wave_sum(reg);
@@ -582,6 +667,13 @@ int check_next(const emx_next_batch* next, const char* who) {
   return EMX_OK;
 }
 
+// workgroups (one wave each) of the optimizer part of the launch: float4 lanes over the flat buffer, or -- with a weight
+// operand store -- one per 32 x 32 kernel block and per 64 bias elements
+inline int adam_grid(const AdamArgs& a, int64_t n) {
+  if (a.mirror) return std::min(a.bias_item_begin[a.mir.n_layers], EMX_REDUCE_WS);
+  return grid_for((n + 3) / 4, 64);
+}
+
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
                    int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
                    const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next = nullptr) {
@@ -592,8 +684,18 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
                         periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin, SplitRows{}};
     if (next->split_ws) a.next.split = split_view(next->split_ws, next->B, next->D);
   }
-  a.mirror = (mirror_desc && mirror) ? mirror : nullptr;
-  if (a.mirror) fill_mirror_args(mirror_desc, a.mir);
+  a.mirror = (mirror_desc && mirror) ? reinterpret_cast<char*>(mirror) : nullptr;
+  if (a.mirror) {
+    fill_wop_args(mirror_desc, a.mir);
+    int items = a.mir.item_begin[mirror_desc->n_layers];
+    for (int l = 0; l <= mirror_desc->n_layers; ++l) {
+      a.bias_item_begin[l] = items;
+      if (l < mirror_desc->n_layers) {
+        a.b_off[l] = mirror_desc->b_off[l];
+        items += (mirror_desc->width[l + 1] + 63) / 64;
+      }
+    }
+  }
   a.w = w;
   a.g = g;
   a.gpart = gpart;
@@ -626,7 +728,7 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0, "emx_adam_step: empty parameter buffer");
   AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
-  const int grid = grid_for((n + 3) / 4, ADAM_NT);
+  const int grid = adam_grid(a, n);
   a.adam_blocks = grid;
   a.late = bookkeeping_done ? 1 : 0;
   if (a.late) a.next.batch_step = 0;
@@ -651,7 +753,7 @@ int emx_adam_step_history(float* w, const float* g, float* m, float* v, const fl
   EMX_REQUIRE(!mirror || (mirror_desc && mirror_desc->n_layers >= 1 && mirror_desc->n_layers <= EMX_MAX_LAYERS), "emx_adam_step_history: mirror without a valid descriptor");
   EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && capacity >= 0, "emx_adam_step_history: bad sizes");
   AdamArgs a = make_adam(w, g, nullptr, 0, 0, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc, mirror, next);
-  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  a.adam_blocks = adam_grid(a, n);
   a.late = 1;
   a.next.batch_step = 0;
   a.row_terms = terms;
@@ -675,7 +777,7 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
   EMX_REQUIRE(n > 0 && n_slices > 0 && partial_stride >= n, "emx_adam_step_slices: bad slice layout");
   AdamArgs a = make_adam(w, nullptr, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, step, ws, mirror_desc,
                          mirror, next);
-  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  a.adam_blocks = adam_grid(a, n);
   a.late = bookkeeping_done ? 1 : 0;
   if (a.late) a.next.batch_step = 0;
   hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next)), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
@@ -698,7 +800,7 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
   EMX_REQUIRE(!g_partials || (n_slices > 0 && partial_stride >= n), "emx_adam_tick: bad slice layout");
   EMX_REQUIRE(n > 0 && n_terms > 0 && n_terms <= 64 && reg_slot >= 0 && reg_slot < n_terms, "emx_adam_tick: bad sizes");
   AdamArgs a = make_adam(w, g, g_partials, n_slices, partial_stride, m, v, l2coef, n, lr, beta1, beta2, eps, clip, opt_step, ws, mirror_desc, mirror);
-  a.adam_blocks = grid_for((n + 3) / 4, ADAM_NT);
+  a.adam_blocks = adam_grid(a, n);
   // Three plain launches on the stream.  (An in-kernel hand-off -- last workgroup finishes -- was measured slower: its
   // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
   const int grid = a.adam_blocks;

@@ -60,12 +60,15 @@ class DataParallel:
         return self.world_size > 1
 
     def row_block(self, batch_size: int):
-        """Rows of the global batch owned by this rank (balanced contiguous blocks)."""
+        """Rows of the global batch owned by this rank: balanced contiguous runs of whole 16-row blocks (the granule of the
+        dense-layer kernels' weight-gradient fragments, include/emx.h: emx_mlp_aop_bytes); the last rank takes the ragged end."""
         if not self.active or self.mode == "replica":
             return 0, batch_size
-        base, rem = divmod(batch_size, self.world_size)
+        n_blk = (batch_size + 15) // 16
+        base, rem = divmod(n_blk, self.world_size)
         begin = self.rank * base + min(self.rank, rem)
-        return begin, begin + base + (1 if self.rank < rem else 0)
+        end = begin + base + (1 if self.rank < rem else 0)
+        return min(16 * begin, batch_size), min(16 * end, batch_size)
 
     def all_reduce_(self, flat: torch.Tensor) -> None:
         """The single collective of a step: gradients and loss terms in one flat buffer."""
@@ -173,7 +176,7 @@ class SequentialEngine:
         # auto cost per row block (zero: no auto cost); at least EMX_REDUCE_WS long for the stand-alone cost kernel's shares
         self.cost_ws = torch.zeros(max(_lib.mlp_row_blocks(self.re - self.rb), _lib.EMX_REDUCE_WS), dtype=f32, device=dev)
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
-        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta)
+        self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
         self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
 
     # -- data feed -------------------------------------------------------------------------------
@@ -356,7 +359,7 @@ class SequentialEngine:
             # gradients; the counters advance here too, the history row follows the all-reduce (inside the optimizer launch)
             fin = _lib.make_finish_desc(self._jobs_pre() + [self._reg_job()], self.terms, N_TERMS, None, None, self.hstep, self.cursor,
                                         self.step)
-        _lib.mlp_wgrad(self.plan, 0, n, self.xin, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws, finish=fin)
+        _lib.mlp_wgrad(self.plan, 0, n, self.rb, self.re, self.g if self.dp.active else None, self.wg_ws, finish=fin)
         if fin is None and self.dp.active and self._jobs_pre():
             _lib.finish_step(self._jobs_pre(), self.terms, N_TERMS)
 
@@ -585,7 +588,7 @@ class SequentialEngine:
         h = [torch.empty(n, l.n_out, dtype=torch.float32, device=self.device) if l0 <= i < l1 else None
              for i, l in enumerate(lay.layers)]
         plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers), mirror=self.plan.mirror)
-        _lib.mlp_forward(plan, l0, l1, x_dev, 0, n)
+        _lib.mlp_forward(plan, l0, l1, x_dev, 0, n, train=False)
         return h[l1 - 1]
 
     @torch.no_grad()

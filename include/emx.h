@@ -306,28 +306,39 @@ int emx_step_tick(const float* terms, int n_terms, float* history, float* term_h
                   int64_t* counter2 /* may be NULL; ++*counter2: the optimizer's update counter */, emx_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------ *
- * K12  dense encoder/decoder, fused over layers, on the exact-f32 matrix cores
+ * K12  dense encoder/decoder, fused over layers, on the 16-bit matrix cores with float32-accurate operands
  *   replaces: tf.keras.layers.Dense forward (y = act(x W + b), W [in,out])  encodermap/models/models.py:3179-3220
  *             and its autodiff (tape.gradient)                              encodermap/models/models.py:3392-3393
  *   The network is described once by an emx_mlp_desc (host struct): width[0] is the input width, width[l+1]
  *   the outputs of layer l, act[l] 0 = linear / 1 = tanh, w_off/b_off the float offsets of the [in,out] kernel
  *   and the bias inside the flat parameter buffer `params` (encodermap_amd/layout.py).
- *   h[l] / delta[l] (host arrays of device pointers, [B, width[l+1]] contiguous) receive the activations and
- *   d loss / d pre-activation of layer l.  Layer ranges let a data-parallel rank run the encoder on all rows and
- *   the decoder on its own row block.
+ *   h[l] / delta[l] (host arrays of device pointers, [B, width[l+1]] contiguous; an entry may be NULL: not kept) receive
+ *   the activations and d loss / d pre-activation of layer l as float32.  Layer ranges let a data-parallel rank run the
+ *   encoder on all rows and the decoder on its own row block.
+ *   Arithmetic: every float32 operand is carried as a power-of-two-scaled pair of f16 values (22 significant bits;
+ *   csrc/wop.h) and a product runs as three 16-bit matrix instructions with an f32 accumulator -- the accuracy class
+ *   of an f32 fused-multiply-add chain at a fraction of the f32 matrix instruction's cycles.  A row's results do not
+ *   depend on the row range or batch it is computed in.
  * ------------------------------------------------------------------------------------------------ */
 
-/* Operand store ("mirror"): a second flat buffer holding, per layer, the kernel in the order the row-block kernels stream
- * it -- for the forward pass (B[k = in][j = out]) and for the backward-data pass (B[k = out][j = in]) -- as 1-KB blocks
- * [tile of 16 j][step of 16 k][lane = 16 g + m][i < 4] = B[16 q + 4 g + i][16 t + m], zero padded; the [in, out] kernel
- * itself would be read with half-used cache lines in either direction.  emx_mlp_mirror_floats floats; emx_mlp_mirror
- * builds it from `params`, emx_adam_step* keep it current when they are handed the descriptor. */
+/* Weight operand store ("mirror"): a second buffer holding, per layer, the kernel as block-scaled f16 pairs in the order
+ * the row-block kernels stream it -- for the forward pass (B[k = in][col = out]) and for the backward-data pass
+ * (B[k = out][col = in]) -- as 1-KB fragments of v_mfma_f32_16x16x32_f16 plus one scale per 32 x 32 block (layout:
+ * csrc/wop.h).  emx_mlp_mirror_floats floats; emx_mlp_mirror builds it from `params`, emx_adam_step* keep it current when
+ * they are handed the descriptor. */
 size_t emx_mlp_mirror_floats(const emx_mlp_desc* desc);
 int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror, emx_stream_t stream);
 
+/* Weight-gradient operand store ("aop"): what the forward / backward launches leave for emx_mlp_wgrad -- the network
+ * input, every h_l and every delta_l as block-scaled f16 fragments of v_mfma_f32_32x32x16_f16 with the reduction index
+ * on the batch rows (layout: csrc/aop.h).  emx_mlp_aop_bytes(desc, n_rows) bytes for batches of up to n_rows rows; the
+ * same `aop_rows` = n_rows must be passed to every launch that uses the store.  aop == NULL: inference, nothing is
+ * kept.  With a store the row range must start at a multiple of 16. */
+size_t emx_mlp_aop_bytes(const emx_mlp_desc* desc, int n_rows);
+
 /* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
-                    int ld_in, int row_begin, int row_end, float* const* h, emx_stream_t stream);
+                    int ld_in, int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream);
 /* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch
  * latency for a few hundred kilobytes): the cost of emx_periodic_cost_fwd_bwd is evaluated on the rows of layer
  * layer_end-1 while they are still on chip.  dY [*, width[layer_end]] receives d cost / d output; ws[g],
@@ -348,35 +359,37 @@ typedef struct {
 } emx_auto_cost;
 int emx_mlp_row_blocks(int n_rows);
 int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
-                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, emx_stream_t stream);
+                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, void* aop, int aop_rows,
+                         emx_stream_t stream);
 /* Forward pass, auto cost and the backward-data pass through the upper layers [bwd_begin, layer_end) in ONE launch: the
- * row block never leaves the CU between them (its activations stay in LDS images, one per layer), which saves the second
- * launch's start-up (the weights' first-touch latency, ~4 us) and the HBM round trip of d cost / d output.
- *   h[l] (all forward layers) and delta[l] (bwd_begin <= l < layer_end) are still written for the weight gradients;
+ * row block never leaves the CU between them (its activations stay in LDS), which saves the second launch's start-up
+ * (the weights' first-touch latency, ~4 us) and the HBM round trip of d cost / d output.
+ *   h[l] (all forward layers) and delta[l] (bwd_begin <= l < layer_end) are written as for the separate calls;
  *   delta[layer_end - 1] = d cost / d output (the top layer must be linear); dbelow (may be NULL) receives dh below
  *   layer bwd_begin -- exactly what emx_mlp_forward_cost followed by emx_mlp_backward(bwd_begin, layer_end, dtop = dY,
- *   dbelow) produce.  EMX_EUNSUPPORTED when the layers' LDS images do not fit (then use the two calls). */
+ *   dbelow) produce.  EMX_EUNSUPPORTED when the row block's LDS images do not fit (then use the two calls). */
 int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                              int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
-                             float* const* delta, float* dbelow, emx_stream_t stream);
+                             float* const* delta, float* dbelow, void* aop, int aop_rows, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and
  *   the encoder can be back-propagated by separate launches (the decoder's overlaps the all-pairs kernel). */
 int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
                      int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent /* may be NULL; joins at layer_add */,
-                     float* dbelow, int row_begin, int row_end, float* const* h, float* const* delta, emx_stream_t stream);
+                     float* dbelow, int row_begin, int row_end, float* const* h, float* const* delta, void* aop, int aop_rows,
+                     emx_stream_t stream);
 /* grad[w_off[l]..] = X_l^T delta[l], grad[b_off[l]..] = column sums of delta[l] over rows [row_begin,row_end), for
- * layers [layer_begin, layer_end); X_l = xin for l == layer_begin, h[l-1] otherwise.  Two launches: per-slice partials
- * (EMX_WGRAD_SLICE_ROWS rows each, more for batches beyond EMX_WGRAD_SLICE_ROWS * EMX_WGRAD_MAX_SLICES rows) into ws, then a
- * fixed-order sum.  ws: emx_mlp_wgrad_ws_floats(n_params, n_rows)
- * floats, ZERO-INITIALISED ONCE by the caller (alignment padding between tensors is never written). */
+ * layers [layer_begin, layer_end), from the fragments the forward and backward launches left in `aop` for these rows
+ * (X_0 = the network input, X_l = h[l-1]).  Two launches: per-slice partials (EMX_WGRAD_SLICE_ROWS rows each, more for
+ * batches beyond EMX_WGRAD_SLICE_ROWS * EMX_WGRAD_MAX_SLICES rows) into ws, then a fixed-order sum.
+ * ws: emx_mlp_wgrad_ws_floats(n_params, n_rows) floats, ZERO-INITIALISED ONCE by the caller (alignment padding between
+ * tensors is never written). */
 size_t emx_mlp_wgrad_ws_floats(int64_t n_params, int n_rows);
-int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const float* xin,
-                  int ld_xin, int row_begin, int row_end, float* const* h, float* const* delta, float* grad /* NULL: leave
-                  the slice partials in ws for emx_adam_step_slices */, float* ws, size_t ws_floats,
-                  const emx_finish_desc* finish /* may be NULL: emx_finish_step with these arguments, run by one extra
-                  workgroup of this launch */, emx_stream_t stream);
+int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int layer_begin, int layer_end, const void* aop, int aop_rows,
+                  int row_begin, int row_end, float* grad /* NULL: leave the slice partials in ws for emx_adam_step_slices */,
+                  float* ws, size_t ws_floats, const emx_finish_desc* finish /* may be NULL: emx_finish_step with these
+                  arguments, run by one extra workgroup of this launch */, emx_stream_t stream);
 /* number of row slices emx_mlp_wgrad leaves in ws for n_rows rows (slice s starts at ws + s * n_params) */
 int emx_mlp_wgrad_slices(int n_rows);
 

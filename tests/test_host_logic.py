@@ -205,7 +205,8 @@ def test_row_block_partition():
         assert blocks[0][0] == 0 and blocks[-1][1] == B
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
         sizes = [e - b for b, e in blocks]
-        assert max(sizes) - min(sizes) <= 1
+        assert max(sizes) - min(sizes) <= 16                      # balanced to one 16-row block ...
+        assert all(b % 16 == 0 or b == B for b, _ in blocks)      # ... the granule of the weight-gradient fragments (emx_mlp_aop_bytes)
     assert DataParallel(2, 8, "replica").row_block(4096) == (0, 4096)
     assert DataParallel().row_block(256) == (0, 256) and not DataParallel().active
     assert DataParallel(0, 2, "rowblock").batch_seed(5) == DataParallel(1, 2, "rowblock").batch_seed(5)

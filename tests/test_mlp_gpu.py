@@ -1,5 +1,6 @@
-"""Fused dense-layer kernels (emx_mlp_forward / backward / wgrad, exact-f32 MFMA) against a float64 torch reference
-of the same layers (Keras Dense semantics, encodermap/models/models.py:3179-3220).  Needs an MI355X.
+"""Fused dense-layer kernels (emx_mlp_forward / backward / wgrad: float32 operands as scaled f16 pairs on the 16-bit
+matrix cores) against a float64 torch reference of the same layers (Keras Dense semantics,
+encodermap/models/models.py:3179-3220).  Needs an MI355X.
 Tolerances: activations 2e-6 * (1 + |x|), gradients 2e-5 relative to the largest entry."""
 import numpy as np
 import pytest
@@ -72,7 +73,7 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
     params = torch.from_numpy(flat).to(dev)
     h = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
     delta = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
-    plan = L.MlpPlan(lay, params, h, delta)
+    plan = L.MlpPlan(lay, params, h, delta, train_rows=B)
     X = torch.from_numpy(x).to(dev)
     L.mlp_forward(plan, 0, n, X, 0, B)
     torch.cuda.synchronize()
@@ -105,7 +106,7 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
         assert torch.equal(delta2[i], delta[i]), f"split backward differs at layer {i}"
     g = torch.full((lay.n_params,), float("nan"), device=dev)
     ws = torch.zeros(L.mlp_wgrad_ws_floats(lay.n_params, B), device=dev)
-    L.mlp_wgrad(plan, 0, n, X, 0, B, g, ws)
+    L.mlp_wgrad(plan, 0, n, 0, B, g, ws)
     torch.cuda.synchronize()
     gh = g.cpu().numpy()
     for i, l in enumerate(lay.layers):
@@ -126,7 +127,7 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
     assert np.all(gh[pad] == 0)
     # deterministic
     g2 = torch.empty_like(g)
-    L.mlp_wgrad(plan, 0, n, X, 0, B, g2, ws)
+    L.mlp_wgrad(plan, 0, n, 0, B, g2, ws)
     torch.cuda.synchronize()
     assert torch.equal(g[lo:hi], g2[lo:hi])
     # the step's scalar epilogue riding along as one extra workgroup: same gradients, same sums and bookkeeping as the
@@ -140,7 +141,7 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
         cnt = [torch.tensor([1], dtype=torch.int64, device=dev) for _ in range(3)]
         g3 = torch.empty_like(g)
         fin = L.make_finish_desc(jobs, terms, 4, hist, thist, *cnt)
-        L.mlp_wgrad(plan, 0, n, X, 0, B, g3, ws, finish=fin if fold else None)
+        L.mlp_wgrad(plan, 0, n, 0, B, g3, ws, finish=fin if fold else None)
         if not fold:
             L.finish_step(jobs, terms, 4, hist, thist, *cnt)
         torch.cuda.synchronize()
@@ -158,12 +159,16 @@ def test_mlp_rejects_bad_arguments(L):
     lay = build_layout([8, 2], ["", "tanh", ""], 6)
     params = torch.from_numpy(init_parameters(lay, 0)).cuda()
     h = [torch.zeros(4, l.n_out, device="cuda") for l in lay.layers]
-    plan = L.MlpPlan(lay, params, h, h)
+    plan = L.MlpPlan(lay, params, h, h, train_rows=4)
     x = torch.zeros(4, 6, device="cuda")
     with pytest.raises(L.EmxError, match="layer range"):
         L.mlp_forward(plan, 2, 1, x, 0, 4)
     with pytest.raises(L.EmxError, match="workspace"):
-        L.mlp_wgrad(plan, 0, 4, x, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))
+        L.mlp_wgrad(plan, 0, 4, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))
+    with pytest.raises(L.EmxError, match="multiple of 16"):     # the weight-gradient fragments are kept per 16-row block
+        L.mlp_forward(plan, 0, 4, x, 1, 4)
+    with pytest.raises(L.EmxError, match="operand store"):
+        L.mlp_wgrad(L.MlpPlan(lay, params, h, h), 0, 4, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))
 
 
 @pytest.mark.gpu
@@ -326,3 +331,53 @@ def test_forward_backward_in_one_launch_equals_two(L, periodicity, variant, D, B
     for l in range(lay.n_enc, n):
         np.testing.assert_allclose(d2[l].cpu().numpy(), d1[l].cpu().numpy(), rtol=1e-6, atol=1e-12)
     np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net_dim,n_neurons,B", [(40, [48, 3], 50), (130, [70, 33, 2], 37), (300, [160, 2], 16)])
+def test_integer_data_is_exact(L, net_dim, n_neurons, B):
+    """Lane maps of the matrix instructions, the transposed LDS images, the operand stores and the k order inside a K-step,
+    checked with exact data (cdna_hip_programming.md section 3: 'check the map with exact integer data'): small integers
+    are their own f16 hi planes, every product and sum below 2^24 is exact in float32, so a linear network must
+    reproduce the integer matrix products bit for bit -- forward, backward and the weight gradients."""
+    from encodermap_amd.layout import build_layout, pack_weights
+
+    rng = np.random.default_rng(B)
+    afs = [""] * (len(n_neurons) + 1)
+    lay = build_layout(n_neurons, afs, net_dim)
+    n = len(lay.layers)
+    arrays = []
+    for l in lay.layers:
+        arrays += [rng.integers(-1, 2, (l.n_in, l.n_out)).astype(np.float32), rng.integers(-3, 4, l.n_out).astype(np.float32)]
+    x = rng.integers(-4, 5, (B, net_dim)).astype(np.float32)
+    dtop = rng.integers(-1, 2, (B, net_dim)).astype(np.float32)
+    hs, cur = [], x.astype(np.int64)
+    for i in range(n):
+        cur = cur @ arrays[2 * i].astype(np.int64) + arrays[2 * i + 1].astype(np.int64)
+        hs.append(cur)
+    assert max(np.abs(h).max() for h in hs) < 2 ** 22      # 22 bits: exactly a scaled f16 pair
+    deltas, d = [None] * n, dtop.astype(np.int64)
+    for i in reversed(range(n)):
+        deltas[i] = d
+        d = d @ arrays[2 * i].astype(np.int64).T
+    assert max(np.abs(d).max() for d in deltas) < 2 ** 22
+    params = torch.from_numpy(pack_weights(lay, arrays)).cuda()
+    h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+    dl = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
+    plan = L.MlpPlan(lay, params, h, dl, train_rows=B)
+    L.mlp_forward(plan, 0, n, torch.from_numpy(x).cuda(), 0, B)
+    L.mlp_backward(plan, 0, n, torch.from_numpy(dtop).cuda(), None, 0, 0, B)
+    g = torch.zeros(lay.n_params, device="cuda")
+    ws = torch.zeros(L.mlp_wgrad_ws_floats(lay.n_params, B), device="cuda")
+    L.mlp_wgrad(plan, 0, n, 0, B, g, ws)
+    torch.cuda.synchronize()
+    for i in range(n):
+        assert np.array_equal(h[i].cpu().numpy().astype(np.int64), hs[i]), f"activation {i}"
+        assert np.array_equal(dl[i].cpu().numpy().astype(np.int64), deltas[i]), f"delta {i}"
+    gh = g.cpu().numpy().astype(np.int64)
+    for i, l in enumerate(lay.layers):
+        xin = x.astype(np.int64) if i == 0 else hs[i - 1]
+        dW = xin.T @ deltas[i]
+        assert np.abs(dW).max() < 2 ** 24
+        assert np.array_equal(gh[l.w_off: l.w_off + l.n_in * l.n_out].reshape(l.n_in, l.n_out), dW), f"dW {i}"
+        assert np.array_equal(gh[l.b_off: l.b_off + l.n_out], deltas[i].sum(0)), f"db {i}"

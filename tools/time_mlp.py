@@ -12,7 +12,9 @@ n = len(lay.layers)
 params = torch.from_numpy(init_parameters(lay, 0)).cuda()
 h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
 dl = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
-plan = _lib.MlpPlan(lay, params, h, dl)
+plan = _lib.MlpPlan(lay, params, h, dl, train_rows=B)
+cost_ws = torch.zeros(_lib.mlp_row_blocks(B), device="cuda")
+dlat = torch.zeros(B, 2, device="cuda")
 x = torch.randn(B, D, device="cuda"); dY = torch.randn(B, D, device="cuda"); dZ = torch.randn(B, 2, device="cuda")
 g = torch.zeros(lay.n_params, device="cuda"); ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), device="cuda")
 def timeit(fn, reps=50):
@@ -25,13 +27,13 @@ def timeit(fn, reps=50):
 print("B", B, "D", D)
 print("forward  us", timeit(lambda: _lib.mlp_forward(plan, 0, n, x, 0, B)))
 print("backward us", timeit(lambda: _lib.mlp_backward(plan, 0, n, dY, dZ, lay.n_enc - 1, 0, B)))
-print("wgrad    us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, x, 0, B, g, ws)))
+print("wgrad    us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, 0, B, g, ws)))
+cost = _lib.make_auto_cost(x, D, 0, D, False, float("inf"), "mean_abs", 1.0, B, dl[-1], cost_ws)
+print("forward + cost + decoder backward us", timeit(lambda: _lib.mlp_forward_backward(plan, 0, n, x, 0, B, cost, lay.n_enc, dbelow=dlat)))
+print("encoder backward us", timeit(lambda: _lib.mlp_backward(plan, 0, lay.n_enc, dlat, dZ, lay.n_enc - 1, 0, B)))
+print("forward (inference, no fragments) us", timeit(lambda: _lib.mlp_forward(plan, 0, n, x, 0, B, train=False)))
 for l in range(n):
     src = x if l == 0 else h[l - 1]
-    print(f"forward layer {l} ({lay.layers[l].n_in}->{lay.layers[l].n_out}) us", timeit(lambda: _lib.mlp_forward(plan, l, l + 1, src, 0, B)))
-for l in range(1, n):
-    print(f"backward layers [{l},{l+1}) us", timeit(lambda: _lib.mlp_backward(plan, l, l + 1, h[l], None, 0, 0, B)))
-    print(f"backward layers [{l-1},{l+1}) us", timeit(lambda: _lib.mlp_backward(plan, l - 1, l + 1, h[l], None, 0, 0, B)))
+    print(f"forward layer {l} ({lay.layers[l].n_in}->{lay.layers[l].n_out}) us", timeit(lambda: _lib.mlp_forward(plan, l, l + 1, src, 0, B, train=False)))
 for l in range(n):
-    src = x if l == 0 else h[l - 1]
-    print(f"wgrad layer {l} us", timeit(lambda: _lib.mlp_wgrad(plan, l, l + 1, src, 0, B, g, ws)))
+    print(f"wgrad layer {l} us", timeit(lambda: _lib.mlp_wgrad(plan, l, l + 1, 0, B, g, ws)))
