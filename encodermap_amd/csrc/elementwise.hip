@@ -251,7 +251,7 @@ __device__ __forceinline__ void adam_one(float& w, float g, float& m, float& v, 
   if (a.clip > 0.f) g = fminf(fmaxf(g, -a.clip), a.clip);
   m = fmaf(g - m, 1.f - a.b1, m);
   v = fmaf(fmaf(g, g, -v), 1.f - a.b2, v);
-  w = w - alpha * m / (sqrtf(v) + a.eps);
+  w = fmaf(-alpha, m / (sqrtf(v) + a.eps), w);   // (explicit: the flat and the block-wise path of adam_kernel must round alike)
   if (a.late) reg = fmaf(0.5f * l2c * w, w, reg);
 }
 
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     // Lane (kr = lane >> 3, c4 = lane & 7) owns W[32 kb + kr + 8 j][32 nb + 4 c4 + i].  Biases follow as items of 64.
     __shared__ __align__(16) _Float16 img[2048];
     const int lane = threadIdx.x & 63;
+    const long tcur = step_now + (a.late ? 0 : 1);   // index of this update
     const int n_blocks = a.mir.item_begin[a.mir.n_layers], n_items = a.bias_item_begin[a.mir.n_layers];
     for (int item = blockIdx.x; item < n_items; item += nblk) {
       if (item < n_blocks) {
@@ -373,6 +374,9 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
         const long woff = a.mir.w_off[l];
         const int kr = lane >> 3, c4 = lane & 7;
         const bool lvec = vec && (N & 3) == 0 && (woff & 3) == 0;
+        // the layer's scale: from the largest |w| the PREVIOUS update recorded (wop.h)
+        WopHeader* hdr = wop_header(a.mirror, l);
+        const unsigned long long prev = hdr->slot[(tcur + 1) & 1];
         float wv[16];
         float4 w4[4], m4[4], v4[4], l4[4], g4[4];
         bool full[4];
@@ -420,7 +424,13 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
             }
           }
         }
-        wop_write_block(a.mir, a.mirror, l, kb, nb, wv, lane, img);
+        float ws_, wrs_;
+        pow2_scale_bits<WOP_TOP>((unsigned)prev, ws_, wrs_);
+        const unsigned bmax = wop_write_block(a.mir, a.mirror, l, kb, nb, wv, ws_, lane, img);
+        if (lane == 0) {
+          atomicMax(&hdr->slot[tcur & 1], ((unsigned long long)tcur << 32) | bmax);
+          hdr->rs = wrs_;
+        }
       } else {
         int l = 0;
         while (l + 1 < a.mir.n_layers && item >= a.bias_item_begin[l + 1]) ++l;

@@ -12,16 +12,23 @@
 //                     partials are summed in a fixed order by the optimizer (or mlp_wgrad_reduce_kernel): deterministic.
 //
 // Arithmetic.  The f32 matrix instruction of gfx950 runs at the vector rate (1/16 of the 16-bit matrix rate,
-// MI355X_MICROARCH.md), and round 1 measured these kernels at 0.2 of even that roof.  Every float32 operand is therefore
-// carried as a SCALED f16 PAIR (wop.h): x = (h + l) / s with s a power of two, h = f16(s x), l = f16(s x - h), 22
-// significant bits, and a product runs as the three instructions hh + hl + lh of v_mfma_f32_16x16x32_f16 (row-block
-// kernels) / v_mfma_f32_32x32x16_f16 (weight gradients) with exact partial products in the f32 accumulator.  Scales:
-//   weights      one per 32 x 32 block of W (wop.h), kept current by the optimizer;
-//   activations  one per (row, 32 columns) in the LDS images -- a K-step of the matrix instruction covers exactly 32
-//                columns produced by ONE wave, so the scale needs no cross-wave reduction, and every row's numbers are
-//                independent of which rows share its block (row ranges and batch sizes do not change a row's result);
+// MI355X_MICROARCH.md).  Every float32 operand is therefore carried as a SCALED f16 PAIR (wop.h): x = (h + l) / s with s a
+// power of two, h = f16(s x), l = f16(s x - h), 22 significant bits, and a product runs as the three instructions
+// hh + hl + lh of v_mfma_f32_16x16x32_f16 (row-block kernels) / v_mfma_f32_32x32x16_f16 (weight gradients) with exact
+// partial products in the f32 accumulator.  Scales:
+//   weights      one per layer (wop.h), kept current by the optimizer;
+//   activations  tanh outputs lie in [-1, 1]: the FIXED scale 2^14 -- a whole reduction accumulates inside the matrix
+//                instruction and is unscaled once per output element.  Everything else (the network input, linear layers,
+//                gradients): one scale per (row, 32 columns) in the LDS image; a K-step of the matrix instruction covers
+//                exactly those 32 columns, its result is unscaled by one multiply-add per accumulator element.  A row's
+//                numbers do not depend on which rows share its block (row ranges and batch sizes do not change results);
 //   wgrad        one per (16 rows, 32 columns) block (aop.h): the row-scaled pair with its exponents shifted, exact.
-// The unscaling is one fused multiply-add per accumulator element and K-step (acc += d * (1/s_a)(1/s_w)).
+//
+// What bounds the kernels (profiles/r02_*): a wave issues about one instruction of ANY kind per 4-5 cycles, so a
+// workgroup with one wave per SIMD is bound by its instruction count, not by the matrix pipe or the weight stream (the
+// stream alone: 0.55 us per 64-KB unit and CU, tools/ubench_stream.hip).  Hence eight waves per workgroup (two per SIMD,
+// one 16-column tile each) and an instruction-lean hot path: no per-element validity selects (buffer bounds and zero
+// scales do that), no per-K-step unscaling behind tanh layers, addresses hoisted out of the unit loop.
 //
 // Lane maps (cdna_hip_programming.md section 3; checked with integer data by tests/test_mlp_gpu.py):
 //   16x16x32: A[m = lane & 15][k = 8 (lane >> 4) + e], B[k][n = lane & 15], D[row = 4 (lane >> 4) + reg][col = lane & 15];
@@ -39,11 +46,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int NT = 256;            // weight-gradient kernels
-constexpr int NTC = 256;           // row-block chain kernels: 4 waves, one per SIMD, two 16-column MFMA tiles each
+constexpr int NTC = 512;           // row-block chain kernels: 8 waves, two per SIMD, one 16-column MFMA tile each
+constexpr int NWC = NTC / 64;
 constexpr int R = 16;              // batch rows per workgroup
 constexpr int MAXL = EMX_MAX_LAYERS;
 constexpr int MAXG = 2 * MAXL + 1;   // GEMMs per launch
 constexpr int MAXU = 120;            // units (128 output columns x 128 k) per launch
+constexpr float TANH_RS = 1.f / 16384.f;   // reciprocal of the fixed scale of tanh outputs
 
 // tanh(x) = 1 - 2 / (e^{2x} + 1): two transcendental + three plain VALU instructions, absolute error <= ~1.5e-7 over the
 // whole range (v_exp_f32 and v_rcp_f32 are 1-ulp; e = inf gives rcp = 0 -> 1, e = 0 gives -1), which is the float32
@@ -54,15 +63,16 @@ __device__ __forceinline__ float tanh_f32(float x) {
 }
 
 template <int CTRL>
-__device__ __forceinline__ float dpp_f32(float x) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+__device__ __forceinline__ unsigned dpp_u32(unsigned x) {
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, true);
 }
-// maximum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row
-__device__ __forceinline__ float row16_max(float x) {
-  x = fmaxf(x, dpp_f32<0xB1>(x));    // quad_perm [1, 0, 3, 2]
-  x = fmaxf(x, dpp_f32<0x4E>(x));    // quad_perm [2, 3, 0, 1]
-  x = fmaxf(x, dpp_f32<0x124>(x));   // row_ror:4
-  x = fmaxf(x, dpp_f32<0x128>(x));   // row_ror:8
+// maximum over the 16 lanes of a DPP row (lanes 16 g .. 16 g + 15), result in every lane of the row.  On bit patterns of
+// |x| (unsigned order = float order there): v_max_u32 with a DPP operand, one instruction per step.
+__device__ __forceinline__ unsigned row16_max(unsigned x) {
+  x = max(x, dpp_u32<0xB1>(x));    // quad_perm [1, 0, 3, 2]
+  x = max(x, dpp_u32<0x4E>(x));    // quad_perm [2, 3, 0, 1]
+  x = max(x, dpp_u32<0x124>(x));   // row_ror:4
+  x = max(x, dpp_u32<0x128>(x));   // row_ror:8
   return x;
 }
 
@@ -71,49 +81,46 @@ __device__ __forceinline__ float row16_max(float x) {
 //
 // LDS images.  The activations (forward) or pre-activation gradients (backward) of the row block, one image per layer
 // boundary: two f16 planes stored TRANSPOSED, [k = column][16 rows] (32 bytes per column; the lo plane behind the hi plane),
-// and the per-(32-column group, row) reciprocal scales as floats.  A K-step's A fragment is then two ds_read_b64_tr_b16 per
-// plane at  plane + 1024 ks + 8 lane  (+ 512): lane (m, g) receives row m, columns 32 ks + 4 g + q and 32 ks + 16 + 4 g + q --
-// the k order kk(g, e) of wop.h, conflict-free (a 32-lane half reads 256 contiguous bytes); the epilogue's D tile (lane =
-// column, registers = 4 consecutive rows) is one 8-byte LDS write per tile and plane.
+// and -- unless the image holds tanh outputs -- the per-(32-column group, row) reciprocal scales as floats.  A K-step's A
+// fragment is two ds_read_b64_tr_b16 per plane at  plane + 1024 ks + 8 lane  (+ 512): lane (m, g) receives row m, columns
+// 32 ks + 4 g + q and 32 ks + 16 + 4 g + q -- the k order kk(g, e) of wop.h, conflict-free (a 32-lane half reads 256
+// contiguous bytes); the epilogue's D tile (lane = column, registers = 4 consecutive rows) is one 8-byte LDS write per plane.
 //
-// Weight stream.  Every workgroup needs every weight (64 KB per 128 x 128 layer), so the kernel is built around that
-// stream as in round 1: the host flattens the layer range into UNITS (layer, pass of 128 columns, chunk of 128 k; one unit
-// = 24 matrix instructions per wave), everything a unit needs from memory -- 16 operand pieces, the weight scales, the
-// epilogue operands -- travels in one package NB - 1 units ahead in a register ring, results are stored one unit late,
-// and every iteration issues the same vector-memory sequence (no conditional load or exec-masked store), so that every
-// s_waitcnt the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
+// Weight stream.  Every workgroup needs every weight (64 KB per 128 x 128 layer): the host flattens the layer range into
+// UNITS (layer, pass of 128 columns, chunk of 128 k; one unit = 12 matrix instructions per wave), everything a unit needs
+// from memory -- 8 operand pieces, the layer's scale, the epilogue operands -- travels in one package NB - 1 units ahead
+// in a register ring, and every iteration issues the same vector-memory sequence (no conditional load, no exec-masked
+// store: results leave through buffer resources whose bounds check drops what does not exist), so that every s_waitcnt
+// the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
 // ---------------------------------------------------------------------------------------------------------
-enum { U_FIRST = 1, U_LAST = 2, U_LAYER_END = 4 };
 enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4 };
 
-struct GemmRec {          // one layer of the range in one direction
-  int op_kb;              // first 1-KB piece of the operand block inside the weight store
-  int Q, T;               // K-steps (32 k) and column groups (32 columns) of the operand
-  int ws_off, ws_ss, ws_sw;   // weight scales: float index of block (K-step 0, group 0), strides per K-step / column group
-  int n;                  // output columns
+struct GemmRec {          // one layer of the range in one direction: P x C regular units (128 columns x 128 k)
+  int P, C;               // passes of 128 output columns, chunks of 128 reduction indices
+  int n;                  // output columns that exist
   int sflags;             // S_*
+  int aux_rs;             // row stride of aux (0: one broadcast row)
+  float src_rs;           // != 0: the source image holds tanh outputs at this fixed reciprocal scale (no scale table)
+  const float* ws;        // the layer's reciprocal weight scale (its header in the store)
   const float* aux;       // epilogue operand: the bias (forward), rows of h for the activation derivative (backward)
-  int aux_rs;             // its row stride (0: one broadcast row)
-  int src_pl, src_sc;     // LDS byte offsets of the source image: planes, scales
-  int dst_pl, dst_sc;     // destination image (-1: none)
+  int src_pl, src_lo, src_sc;   // LDS byte offsets of the source image: hi plane, distance of the lo plane, scales
+  int dst_pl, dst_lo, dst_sc;   // destination image (dst_pl -1: none)
   int dst_f32, dst_f32_pitch;   // float32 copy of the output rows in LDS, [16][pitch] (-1: none): cost input, tanh' of the fused backward
   int h_f32, h_f32_pitch;       // fused backward units: float32 copy of h for the activation derivative (-1: through aux)
   float* out;             // [*, n] float32 rows in HBM (null: not kept)
   AopTensor aop;          // fragments of the output for the weight gradients (frag null: not kept)
-};
-struct UnitRec {
-  unsigned char gemm, pass, chunk, flags;
 };
 
 enum { CHAIN_FWD = 0, CHAIN_BWD = 1, CHAIN_FUSED = 2 };
 
 struct ChainArgs {
   GemmRec g[MAXG];
-  UnitRec u[MAXU];
-  int nu;
-  const char* wop;        // weight operand store
+  int ng;                 // GEMMs of the launch
+  int ng_fwd;             // fused mode: the first ng_fwd are the forward layers, the cost runs behind them
+  const char* units;      // first unit of the launch in the weight operand store (wop.h: units lie in execution order)
+  const char* units_bwd;  // fused mode: first unit of the backward part
   const float* in;        // forward: input rows; backward: d loss / d h_top
-  int ld_in, in_cols, in_Q;
+  int ld_in, in_cols, in_Q, in_Qp;   // in_Q: column groups of 32 that exist, in_Qp: of the image (padded to whole chunks)
   int in_pl, in_sc;       // image that receives the row block
   AopTensor in_aop;       // its fragments for the weight gradients (forward from layer 0: the network input; backward: delta_top)
   int row0, row_end;
@@ -130,23 +137,18 @@ struct ChainArgs {
   CostArgs cost;
   int y_f32, y_pitch;     // float32 copy of the last forward layer's rows: the cost's input, receives d cost / d output in place
   int tgt_off;            // LDS byte offset of the target rows [16][cost.n]
-  // fused mode: the cost runs behind unit cost_at; d cost / d output is re-staged into the image (top_pl, top_sc), the
-  // source of the first backward unit, and into top_aop
-  int cost_at, top_pl, top_sc, top_Q;
+  // fused mode: d cost / d output is re-staged into the image (top_pl, top_sc), the source of the first backward GEMM, and
+  // into top_aop
+  int top_pl, top_sc, top_Q, top_Qp;
   AopTensor top_aop;
 };
 
-struct PendStore {        // results of a unit's epilogue, stored at the head of the next iteration through buffer
-  float v[8];             // resources whose bounds check drops what does not exist (no exec-masked vector-memory instruction)
-  half4 fr[4];
-  float rs;
-  const float* out_base;
-  int out_bytes, out_n;
-  unsigned out_voff[2];   // per tile: byte offset of (row 4 g, the tile's column), out of bounds when the column does not exist
-  const char* fr_base;
-  int fr_bytes;
-  const float* rs_base;
-};
+#ifdef EMX_CHAIN_TIMING   // in-kernel timeline (tools/abl_timing.py); stamps go to LDS so that they do not touch vmcnt
+__device__ long long emx_dbg[8192];
+#define TSTAMP(slot) do { if (lane == 0 && (slot) < 64) dbg_lds[wave * 64 + (slot)] = clock64(); } while (0)
+#else
+#define TSTAMP(slot)
+#endif
 
 template <int V>
 struct IC_ {
@@ -156,17 +158,25 @@ struct IC_ {
 template <int MODE, int NB>
 __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   constexpr bool BWD = MODE == CHAIN_BWD;
-  constexpr int NE = BWD ? 8 : 2;   // epilogue operands per lane: h of 4 rows x 2 tiles (backward) or the bias of 2 columns
+  constexpr int NE = BWD ? 4 : 1;   // epilogue operands per lane: h of 4 rows (backward) or the bias of its column
   extern __shared__ __align__(16) char lds[];
-  __shared__ float cred[NTC / 64];
+  __shared__ float cred[NWC];
+  __shared__ __align__(16) unsigned mxbuf[NWC][R];   // row maxima of the waves' tiles (dynamic-scale epilogues)
+#ifdef EMX_CHAIN_TIMING
+  __shared__ long long dbg_lds[NTC];
+  int tcount = 0;
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
+  TSTAMP(0);
   const int r0 = a.row0 + blockIdx.x * R;
   const int rb = r0 >> 4;   // row block of the weight-gradient fragments (row0 is a multiple of 16 whenever they are kept)
   const int rows_valid = min(R, a.row_end - r0);
-  const int nu = a.nu;
-  const float* wsf = reinterpret_cast<const float*>(a.wop);
+  // the GEMM table is indexed at run time: read it through the kernel-argument segment itself (scalar loads from constant
+  // memory; indexing the by-value struct makes hipcc copy all of it to scratch in the larger instantiations)
+  typedef const ChainArgs __attribute__((address_space(4))) * KArgs;
+  const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
   float* lat = reinterpret_cast<float*>(lds + a.lat_off);
   float* tgt = reinterpret_cast<float*>(lds + a.tgt_off);
 
@@ -175,7 +185,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     // lanes over the per-tile slots, fixed order)
     const int N = a.join_n;
     if (a.lg.partials != nullptr) {
-      for (int el = wave; el < R * N; el += NTC / 64) {
+      for (int el = wave; el < R * N; el += NWC) {
         const int r = el / N, c = el - r * N;
         const bool rok = r0 + r < a.row_end;
         float v = 0.f;
@@ -203,20 +213,22 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     __syncthreads();
   }
 
-  // ---- staging a row block [16][ncols] of float32 values into an image: wave w takes the column groups w, w + 4, ...;
+  // ---- staging a row block [16][ncols] of float32 values into an image: wave w takes the column groups w, w + 8, ...;
   //      lane (c = lane & 31, hf = lane >> 5) the column 32 group + c, rows 8 hf .. 8 hf + 7 -- its 8 halves are 16
   //      contiguous bytes of the transposed plane AND, with lane as the fragment's lane, the weight-gradient fragment (aop.h).
+  //      Rows beyond the batch and columns beyond the tensor enter as zeros; groups beyond the tensor (the image is padded
+  //      to whole 128-column chunks) are zero-filled.
   const int sc_c = lane & 31, sc_hf = lane >> 5;
-  auto stage_finish = [&](const float (&v)[8], int grp, int Q, int pl, int sc, const AopTensor& ao) {
+  auto stage_finish = [&](const float (&v)[8], int grp, int lo_off, int pl, int sc, const AopTensor& ao, bool keep_frag) __attribute__((always_inline)) {
     // per-row scale over the group's 32 columns (lanes of one half)
     float s[8], rs[8];
-    float bm = 0.f;
+    unsigned bm = 0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      float m = row16_max(fabsf(v[e]));
-      m = fmaxf(m, __shfl_xor(m, 16, 64));
-      pow2_scale(m, s[e], rs[e]);
-      bm = fmaxf(bm, m);
+      unsigned m = row16_max(abs_bits(v[e]));
+      m = max(m, (unsigned)__shfl_xor((int)m, 16, 64));
+      pow2_scale_bits<ACT_TOP>(m, s[e], rs[e]);
+      bm = max(bm, m);
     }
     half8 hi, lo;
 #pragma unroll
@@ -227,17 +239,17 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     }
     const int k = 32 * grp + sc_c;
     *reinterpret_cast<half8*>(lds + pl + k * 32 + sc_hf * 16) = hi;
-    *reinterpret_cast<half8*>(lds + pl + Q * 1024 + k * 32 + sc_hf * 16) = lo;
-    if (sc_c == 0) {
+    *reinterpret_cast<half8*>(lds + pl + lo_off + k * 32 + sc_hf * 16) = lo;
+    {   // (every lane of a half writes the same 32 bytes: no branch)
       float* dst = reinterpret_cast<float*>(lds + sc) + grp * 16 + 8 * sc_hf;
       *reinterpret_cast<f32x4*>(dst) = f32x4{rs[0], rs[1], rs[2], rs[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
     }
-    if (ao.frag != nullptr) {
+    if (keep_frag && ao.frag != nullptr) {
       // block scale (16 rows x 32 columns) for the weight gradients: the row-scaled pair with its exponents shifted
-      bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
+      bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
       float sb, rsb;
-      pow2_scale(bm, sb, rsb);
+      pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
       half8 fh, fl;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -251,124 +263,140 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       if (lane == 0) ao.rscale[(long)rb * ao.CG + grp] = rsb;
     }
   };
-  // the row block from HBM (forward: input rows; backward: delta_top = (dtop [+ join]) * act'(h_top))
+  // the row block from HBM (forward: input rows; backward: delta_top = (dtop [+ join]) * act'(h_top)).  Addresses are
+  // clamped and the values masked by a multiplication: a select on a loaded value makes hipcc emit an exec-masked load
+  // followed by s_waitcnt vmcnt(0) per element, eight dependent round trips at the head of the kernel.
   const int sK = a.in_cols;
-  auto stage_load = [&](int grp, float (&v)[8]) {
+  auto stage_load = [&](int grp, float (&x)[8], float (&hv)[8]) __attribute__((always_inline)) {
+    const int cc = min(32 * grp + sc_c, sK - 1);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const long grow = (long)min(r0 + 8 * sc_hf + e, a.row_end - 1);
+      x[e] = a.in[grow * a.ld_in + cc];
+      if (BWD) hv[e] = a.top_h[grow * sK + cc];
+    }
+  };
+  auto stage_value = [&](int grp, const float (&x)[8], const float (&hv)[8], float (&v)[8]) __attribute__((always_inline)) {
     const int col = 32 * grp + sc_c, cc = min(col, sK - 1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int row = 8 * sc_hf + e;
-      const long grow = (long)min(r0 + row, a.row_end - 1);
-      float x = a.in[grow * a.ld_in + cc];
+      float y = x[e];
       if (BWD) {
-        if (a.top_flags & S_JOIN) x += lat[row * sK + cc];
-        if (a.top_flags & S_ACT) {
-          const float hv = a.top_h[grow * sK + cc];
-          x *= fmaf(-hv, hv, 1.f);
-        }
+        if (a.top_flags & S_JOIN) y += lat[row * sK + cc];
+        if (a.top_flags & S_ACT) y *= fmaf(-hv[e], hv[e], 1.f);
       }
-      v[e] = (col < sK && row < rows_valid) ? x : 0.f;
-    }
-  };
-  auto stage_top_out = [&](int grp, const float (&v)[8]) {
-    if (!BWD || a.top_out == nullptr) return;
-    const int col = 32 * grp + sc_c;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int row = 8 * sc_hf + e;
-      if (col < sK && row < rows_valid) a.top_out[(long)(r0 + row) * sK + col] = v[e];
+      v[e] = y * ((col < sK && row < rows_valid) ? 1.f : 0.f);
+      if (BWD && a.top_out != nullptr && col < sK && row < rows_valid) a.top_out[(long)(r0 + row) * sK + col] = v[e];
     }
   };
 
   // ---- the register ring
-  half8 wp[NB][4][2][2];   // [slot][K-step][tile][plane]
+  half8 wp[NB][4][2];   // [slot][K-step][plane]
   float ep[NB][NE];
   float wsc[NB];
 
-  struct Req {             // what a request burst needs (wave-uniform)
-    const char* pbase;     // first piece of this wave's column group in this chunk
-    int kq;                // K-steps in this chunk, 1..4
-    const float* aux0;     // epilogue operand row base
-    int aux_rs, aux_n, col0;
-    const float* ws;       // weight scale of K-step 0
-    int ws_ss;
+  // per-GEMM state of a unit stream, wave-uniform (scalar registers); the request stream runs NB - 1 units ahead of the
+  // execution stream.  Units are regular (wop.h): the next unit's package is 64 KB behind this one's.
+  struct Stream {
+    int gi, g_end;          // current GEMM, end of the segment
+    int p, c;               // pass, chunk
+    int P, C;
   };
-  auto make_req = [&](int uu) {
-    const UnitRec U = a.u[max(0, min(uu, nu - 1))];
-    const GemmRec& G = a.g[U.gemm];
-    const int Q = G.Q, cg = min(4 * U.pass + wave, G.T - 1), ks0 = 4 * U.chunk;
-    Req q;
-    q.kq = min(4, Q - ks0);
-    q.pbase = a.wop + ((long)G.op_kb + ((long)cg * Q + ks0) * 4) * 1024;
-    q.aux0 = G.aux;
-    q.aux_rs = G.aux_rs;
-    q.aux_n = G.n;
-    q.col0 = 128 * U.pass + 32 * wave;
-    q.ws = wsf + G.ws_off + (long)ks0 * G.ws_ss + (long)cg * G.ws_sw;
-    q.ws_ss = G.ws_ss;
-    return q;
+  auto stream_next = [&](Stream& st) __attribute__((always_inline)) -> bool {   // returns true when the GEMM changed
+    if (++st.c < st.C) return false;
+    st.c = 0;
+    if (++st.p < st.P) return false;
+    st.p = 0;
+    ++st.gi;
+    return true;
   };
-  auto request_head = [&](const Req& q, float (&ee)[NE], float& wq) {
+
+  // request stream
+  Stream rq;
+  const char* rq_ptr;       // this wave's pieces of the unit to request next
+  const float* rq_aux;
+  const float* rq_ws;
+  int rq_aux_rs, rq_n;
+  bool rq_live;
+  auto rq_load_gemm = [&]() __attribute__((always_inline)) {
+    const auto& G = ka->g[rq.gi];
+    rq.P = G.P;
+    rq.C = G.C;
+    rq_aux = G.aux;
+    rq_aux_rs = G.aux_rs;
+    rq_n = G.n;
+    rq_ws = G.ws;
+  };
+  auto request = [&](auto RC) __attribute__((always_inline)) {   // the package of the request stream's unit into ring slot r, then advance
+    constexpr int r = decltype(RC)::value;
+    const int ccol = min(128 * rq.p + 16 * wave + n, rq_n - 1);
+    if (BWD) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int ccol = min(q.col0 + 16 * t + n, q.aux_n - 1);
-      if (BWD) {
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) ee[4 * t + reg] = q.aux0[(long)min(r0 + 4 * g + reg, a.row_end - 1) * q.aux_rs + ccol];
-      } else {
-        ee[t] = q.aux0[ccol];
-      }
+      for (int reg = 0; reg < 4; ++reg) ep[r][reg] = rq_aux[(long)min(r0 + 4 * g + reg, a.row_end - 1) * rq_aux_rs + ccol];
+    } else {
+      ep[r][0] = rq_aux[ccol];
     }
-    wq = q.ws[(long)min(lane & 3, q.kq - 1) * q.ws_ss];
+    wsc[r] = *rq_ws;
   };
-  auto request_pieces = [&](const Req& q, int s, half8 (&w)[2][2]) {
-    const char* p = q.pbase + (long)min(s, q.kq - 1) * 4096 + lane * 16;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) w[t][pl] = *reinterpret_cast<const half8*>(p + (t * 2 + pl) * 1024);
+  auto request_pieces = [&](auto RC, int s) __attribute__((always_inline)) {
+    constexpr int r = decltype(RC)::value;
+    const char* p = rq_ptr + s * 2048 + lane * 16;
+    wp[r][s][0] = *reinterpret_cast<const half8*>(p);
+    wp[r][s][1] = *reinterpret_cast<const half8*>(p + 1024);
   };
-
-  PendStore pend;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) pend.v[i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) pend.fr[i] = half4{0, 0, 0, 0};
-  pend.rs = 0.f;
-  pend.out_base = wsf;
-  pend.out_bytes = 0;
-  pend.out_n = 0;
-  pend.out_voff[0] = pend.out_voff[1] = 0x80000000u;
-  pend.fr_base = a.wop;
-  pend.fr_bytes = 0;
-  pend.rs_base = wsf;
-  auto flush_pend = [&]() {
-    __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.out_base), 0, pend.out_bytes, 0x00020000);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int reg = 0; reg < 4; ++reg)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend.v[4 * t + reg]), ro, pend.out_voff[t] + reg * pend.out_n * 4, 0, 0);
-    __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(pend.fr_base), 0, pend.fr_bytes, 0x00020000);
-    const unsigned fvoff = (unsigned)((32 * (g >> 1) + n) * 16 + (g & 1) * 8);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int pl = 0; pl < 2; ++pl) {
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, pend.fr[2 * t + pl]), rf, fvoff + pl * 1024 + t * 256, 0, 0);
-      }
-    __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pend.rs_base), 0, pend.fr_bytes ? 4 : 0, 0x00020000);
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, pend.rs), rr, lane == 0 ? 0u : 0x80000000u, 0, 0);
-    pend.out_bytes = 0;
-    pend.fr_bytes = 0;
+  auto rq_advance = [&]() __attribute__((always_inline)) {
+    if (!rq_live) return;
+    Stream nx = rq;
+    const bool changed = stream_next(nx);
+    if (changed && nx.gi >= nx.g_end) {   // the segment's last unit: keep requesting it (the same instruction sequence; nothing depends on it)
+      rq_live = false;
+      return;
+    }
+    rq = nx;
+    rq_ptr += WOP_UNIT;
+    if (changed) rq_load_gemm();
   };
 
-  // auto cost on the last forward layer's rows (float32 copy in LDS): 16 threads per row; d cost / d output goes to HBM
+  // execution stream: the current GEMM's record in scalar registers
+  Stream ex;
+  struct GX {
+    int n, sflags;
+    float src_rs;
+    int src_pl, src_lo, src_sc, dst_pl, dst_lo, dst_sc, dst_f32, dst_f32_pitch, h_f32, h_f32_pitch;
+    float* out;
+    char* frag;
+    float* rscale;
+    int CG;
+  } X;
+  auto ex_load_gemm = [&]() __attribute__((always_inline)) {
+    const auto& G = ka->g[min(ex.gi, ex.g_end - 1)];
+    ex.P = G.P;
+    ex.C = G.C;
+    X.n = G.n;
+    X.sflags = G.sflags;
+    X.src_rs = G.src_rs;
+    X.src_pl = G.src_pl;
+    X.src_lo = G.src_lo;
+    X.src_sc = G.src_sc;
+    X.dst_pl = G.dst_pl;
+    X.dst_lo = G.dst_lo;
+    X.dst_sc = G.dst_sc;
+    X.dst_f32 = G.dst_f32;
+    X.dst_f32_pitch = G.dst_f32_pitch;
+    X.h_f32 = G.h_f32;
+    X.h_f32_pitch = G.h_f32_pitch;
+    X.out = G.out;
+    X.frag = G.aop.frag;
+    X.rscale = G.aop.rscale;
+    X.CG = G.aop.CG;
+  };
+
+  // auto cost on the last forward layer's rows (float32 copy in LDS): 32 threads per row; d cost / d output goes to HBM
   // and, in place, into the copy
-  auto cost_phase = [&]() {
+  auto cost_phase = [&]() __attribute__((always_inline)) {
     const CostArgs& cst = a.cost;
-    const int row = tid >> 4, l16 = tid & 15;
+    const int row = tid >> 5, l32 = tid & 31;
     const bool rok = row < rows_valid;
     const long grow = (long)min(r0 + row, a.row_end - 1);
     float* yrow = reinterpret_cast<float*>(lds + a.y_f32) + row * a.y_pitch;
@@ -377,17 +405,17 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     float lsum = 0.f;
     if (cst.variant == EMX_MEAN_NORM) {
       float ss = 0.f;
-      for (int k = l16; k < cst.n; k += 16) {
+      for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
         cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
         ss = fmaf(delta, delta, ss);
       }
 #pragma unroll
-      for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's 16 lanes
+      for (int o = 16; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);   // stays inside the row's 32 lanes
       const float nrm = sqrtf(ss);
       const float inv = nrm > 0.f ? 1.f / nrm : 0.f;
-      if (l16 == 0 && rok) lsum = nrm;
-      for (int k = l16; k < cst.n; k += 16) {
+      if (l32 == 0 && rok) lsum = nrm;
+      for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
         cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
         const float gq = rok ? cst.gnorm * delta * inv * dd : 0.f;
@@ -395,7 +423,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
         cost_store(cst, yrow, nullptr, k, gq, sn, cs);
       }
     } else {
-      for (int k = l16; k < cst.n; k += 16) {
+      for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
         cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
         float gq;
@@ -415,244 +443,338 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   };
 
-  f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-  float sv[8];
-  float tv[4] = {0.f, 0.f, 0.f, 0.f};
-  const bool with_cost = !BWD && a.cost.ws != nullptr;
-  Req Lq = make_req(0);
-  UnitRec XU = a.u[0];
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // the tile's accumulator in units of 1 / (weight scale [x source scale])
 
-  // Iteration ui requests the package of unit ui + NB - 1 into ring slot r and executes unit ui from slot r + 1; the first
-  // NB - 1 iterations (ui < 0) only request.
-  auto unit = [&](auto RC, const int ui) {
-    constexpr int r = decltype(RC)::value;
-    constexpr int rx = (r + 1) % NB;
-    const bool run = ui >= 0 && ui < nu;
-    const GemmRec& X = a.g[XU.gemm];
-    const int Q = X.Q;
-    const int ks0 = 4 * XU.chunk;
-    const int kq = run ? min(4, Q - ks0) : 0;
-    const int cgw = 4 * XU.pass + wave;
-    const bool mine = cgw < X.T;
+  // lane-dependent address parts, the same for every unit
+  const int lane8 = lane * 8;
+  const unsigned fvoff = (unsigned)((32 * (g >> 1) + 16 * (wave & 1) + n) * 16 + (g & 1) * 8);   // this lane's 8 bytes inside a fragment
+  const float* const wsf = reinterpret_cast<const float*>(a.units);
 
-    flush_pend();
-    if (ui == -(NB - 1)) {
-      // the row block itself travels ahead of the first package and reaches LDS behind it
-      if (wave < a.in_Q) stage_load(wave, sv);
-      if (with_cost) {
-        const int c = 4 * (tid & 15), row = tid >> 4;
-        const long grow = (long)min(r0 + row, a.row_end - 1);
+  // Executes the execution stream's unit from ring slot rx while the request stream's unit is requested into slot r.  Every
+  // call issues the same vector-memory sequence: NE + 1 epilogue operands, 8 pieces (two per K-step of matrix work), 7
+  // result stores through buffer resources whose bounds check drops what does not exist -- no conditional load, no
+  // exec-masked store, so that every wait the compiler inserts is for the oldest package only.
+  auto exec = [&](auto RC) __attribute__((always_inline)) {
+    constexpr int r = decltype(RC)::value;          // slot being requested into
+    constexpr int rx = (r + 1) % NB;                // slot being executed
+    const bool dyn = X.src_rs == 0.f;
+#ifdef EMX_CHAIN_TIMING
+    const int ui = tcount++;
+#endif
+    TSTAMP(3 + 5 * ui);
+    request(RC);
+
+    if (ex.c == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragments of the chunk's four K-steps up front (one LDS latency per unit)
+    half8 ah[4], al[4];
+    f32x4 rsa[4];
+    {
+      const char* apl = lds + X.src_pl + ex.c * 4096 + lane8;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) tv[i] = a.cost.target[grow * a.cost.ldt + min(c + i, a.cost.n - 1)];
-      }
-    }
-    request_head(Lq, ep[r], wsc[r]);
-
-    if (run && (XU.flags & U_FIRST)) acc[0] = acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const char* apl = lds + X.src_pl + ks0 * 1024 + lane * 8;
-    const float* asc = reinterpret_cast<const float*>(lds + X.src_sc) + ks0 * 16 + 4 * g;
-    const float wq = wsc[rx];
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (mine && s < kq) {
+      for (int s = 0; s < 4; ++s) {
         const half4 h0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + s * 1024));
         const half4 h1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + s * 1024 + 512));
-        const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + Q * 1024 + s * 1024));
-        const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + Q * 1024 + s * 1024 + 512));
-        const f32x4 rsa = *reinterpret_cast<const f32x4*>(asc + s * 16);
-        const half8 ah = {h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-        const half8 al = {l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-        const float rsw = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, wq), s));
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          f32x4 d = {0.f, 0.f, 0.f, 0.f};
-          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wp[rx][s][t][1], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, wp[rx][s][t][0], d, 0, 0, 0);
-          d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, wp[rx][s][t][0], d, 0, 0, 0);
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) acc[t][reg] = fmaf(d[reg], rsa[reg] * rsw, acc[t][reg]);
-        }
+        const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + s * 1024));
+        const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + s * 1024 + 512));
+        ah[s] = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+        al[s] = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       }
-      request_pieces(Lq, s, wp[r][s]);
-      __builtin_amdgcn_sched_barrier(0);
+      if (dyn) {
+        const char* asc = lds + X.src_sc + ex.c * 256 + g * 16;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) rsa[s] = *reinterpret_cast<const f32x4*>(asc + s * 64);
+      }
     }
-    // the next iteration's records: scalar loads issued here land behind the epilogue
-    const Req Ln = make_req(ui + NB);
-    const UnitRec XUn = a.u[max(0, min(ui + 1, nu - 1))];
-    Lq = Ln;
+    if (dyn) {
+      // per-(row, 32 columns) source scales: each K-step's product is unscaled as it is added
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], d, 0, 0, 0);
+        acc = d * rsa[s] + acc;
+        request_pieces(RC, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      // tanh outputs at their fixed scale: the whole reduction accumulates inside the matrix instruction
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], acc, 0, 0, 0);
+        request_pieces(RC, s);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    TSTAMP(4 + 5 * ui);
+    rq_advance();
+    TSTAMP(5 + 5 * ui);
 
-    if (ui == -(NB - 1)) {
-      if (wave < a.in_Q) {
-        stage_top_out(wave, sv);
-        stage_finish(sv, wave, a.in_Q, a.in_pl, a.in_sc, a.in_aop);
-      }
-      for (int grp = wave + 4; grp < a.in_Q; grp += 4) {
-        float v[8];
-        stage_load(grp, v);
-        stage_top_out(grp, v);
-        stage_finish(v, grp, a.in_Q, a.in_pl, a.in_sc, a.in_aop);
-      }
-      if (with_cost) {
-        const int c = 4 * (tid & 15), row = tid >> 4;
-        const long grow = (long)min(r0 + row, a.row_end - 1);
+    // ---- epilogue (last chunk of a pass).  Columns beyond the layer and rows beyond the batch are NOT masked: their
+    //      values are finite (clamped addresses, zero-padded weights), they never reach HBM (buffer bounds), a later layer
+    //      multiplies such columns with zero weights, and such rows enter the weight-gradient fragments with factor 0.
+    const bool last = ex.c == ex.C - 1;
+    const int sflags = X.sflags;
+    const bool ubwd = (sflags & S_BWD) != 0;
+    const bool bounded = !ubwd && (sflags & S_ACT);            // tanh outputs: fixed scale
+    const bool has_img = X.dst_pl >= 0;
+    const int col = 128 * ex.p + 16 * wave + n;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+    float rsb = TANH_RS;
+    if (last) {
+      const float cmul = wsc[rx] * (dyn ? 1.f : X.src_rs);
+      const int colc = min(col, X.n - 1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (c + i < a.cost.n) tgt[row * a.cost.n + c + i] = tv[i];
-        for (int cc = c + 64; cc < a.cost.n; cc += 64)
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (cc + i < a.cost.n) tgt[row * a.cost.n + cc + i] = a.cost.target[grow * a.cost.ldt + cc + i];
-      }
-      __syncthreads();
-    }
-    if (!run) {
-      XU = XUn;
-      return;
-    }
-
-    // ---- epilogue
-    if (XU.flags & U_LAST) {
-      const int sflags = X.sflags;
-      const int cols = X.n - 128 * XU.pass;           // columns of this pass that exist (may exceed 128)
-      const int colw = 32 * wave;                     // this wave's first column inside the pass
-      const bool ubwd = (sflags & S_BWD) != 0;
-      float v[2][4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int cp = colw + 16 * t + n;             // column inside the pass
-        const int col = 128 * XU.pass + cp;
-        const bool cok = mine && cp < cols;
-#pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const int row = 4 * g + reg;
-          float x = acc[t][reg];
-          if (!ubwd) {
-            x += ep[rx][BWD ? 0 : t];
-            if (sflags & S_ACT) x = tanh_f32(x);
-          } else {
-            if (sflags & S_JOIN) x += lat[row * X.n + min(col, X.n - 1)];
-            if (sflags & S_ACT) {
-              float hv;
-              if (MODE == CHAIN_FUSED)
-                hv = reinterpret_cast<const float*>(lds + X.h_f32)[row * X.h_f32_pitch + min(col, X.n - 1)];
-              else
-                hv = ep[rx][BWD ? 4 * t + reg : 0];
-              x *= fmaf(-hv, hv, 1.f);
-            }
-          }
-          v[t][reg] = (cok && row < rows_valid) ? x : 0.f;
-        }
-      }
-      if (mine) {
-        if (X.dst_f32 >= 0) {
-          float* f = reinterpret_cast<float*>(lds + X.dst_f32);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const int col = 128 * XU.pass + colw + 16 * t + n;
-            if (col < X.n) {
-#pragma unroll
-              for (int reg = 0; reg < 4; ++reg) f[(4 * g + reg) * X.dst_f32_pitch + col] = v[t][reg];
-            }
+      for (int reg = 0; reg < 4; ++reg) {
+        float x;
+        if (!ubwd) {
+          x = fmaf(acc[reg], cmul, ep[rx][0]);
+          if (sflags & S_ACT) x = tanh_f32(x);
+        } else {
+          x = acc[reg] * cmul;
+          if (sflags & S_JOIN) x += lat[(4 * g + reg) * X.n + colc];
+          if (sflags & S_ACT) {
+            float hv;
+            if (MODE == CHAIN_FUSED)
+              hv = reinterpret_cast<const float*>(lds + X.h_f32)[(4 * g + reg) * X.h_f32_pitch + colc];
+            else
+              hv = ep[rx][BWD ? reg : 0];
+            x *= fmaf(-hv, hv, 1.f);
           }
         }
-        if (X.dst_pl >= 0) {
-          // per-row scale over the wave's 32 columns, split, transposed image write (lane = column, 4 rows = 8 bytes)
-          float s[4], rs[4];
-          half4 hi[2], lo[2];
-          float bm = 0.f;
+        v[reg] = x;
+      }
+      if (X.dst_f32 >= 0) {   // (the copy's rows are padded to whole passes: every lane has a slot)
+        float* f = reinterpret_cast<float*>(lds + X.dst_f32) + 4 * g * X.dst_f32_pitch + col;
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) f[reg * X.dst_f32_pitch] = v[reg];
+      }
+      if (has_img) {
+        float s[4], rs[4];
+        unsigned bm = 0;
+        if (bounded) {
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) s[reg] = 16384.f, rs[reg] = TANH_RS;
+        } else {
+          // per-row scale over the 32 columns of the tile PAIR (the K-step of the consumer): the two waves of a pair
+          // exchange their tiles' row maxima through LDS (all eight waves are here: the condition is workgroup-uniform)
+          unsigned m[4];
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) m[reg] = row16_max(abs_bits(v[reg]));
+          typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+          *reinterpret_cast<u32x4*>(&mxbuf[wave][4 * g]) = u32x4{m[0], m[1], m[2], m[3]};
+          __syncthreads();
+          const u32x4 pm = *reinterpret_cast<const u32x4*>(&mxbuf[wave ^ 1][4 * g]);
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            const float m = row16_max(fmaxf(fabsf(v[0][reg]), fabsf(v[1][reg])));
-            pow2_scale(m, s[reg], rs[reg]);
-            bm = fmaxf(bm, m);
+            m[reg] = max(m[reg], pm[reg]);
+            pow2_scale_bits<ACT_TOP>(m[reg], s[reg], rs[reg]);
+            bm = max(bm, m[reg]);
           }
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-              const float x = v[t][reg] * s[reg];
-              hi[t][reg] = (_Float16)x;
-              lo[t][reg] = (_Float16)(x - (float)hi[t][reg]);
-            }
-          const int Qd = (X.n + 31) >> 5;
-          char* dp = lds + X.dst_pl + (128 * XU.pass + colw + n) * 32 + 8 * g;
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            *reinterpret_cast<half4*>(dp + t * 512) = hi[t];
-            *reinterpret_cast<half4*>(dp + Qd * 1024 + t * 512) = lo[t];
-          }
-          if (n == 0) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(lds + X.dst_sc) + cgw * 16 + 4 * g) = f32x4{rs[0], rs[1], rs[2], rs[3]};
-          if (X.aop.frag != nullptr) {
-            bm = fmaxf(bm, __shfl_xor(bm, 16, 64));
-            bm = fmaxf(bm, __shfl_xor(bm, 32, 64));
-            float sb, rsb;
-            pow2_scale(bm, sb, rsb);
-            half4 ratio;
-#pragma unroll
-            for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(sb * rs[reg]);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-              pend.fr[2 * t] = hi[t] * ratio;
-              pend.fr[2 * t + 1] = lo[t] * ratio;
-            }
-            pend.rs = rsb;
-            pend.fr_base = X.aop.frag + ((long)rb * X.aop.CG + cgw) * 2048;
-            pend.fr_bytes = 2048;
-            pend.rs_base = X.aop.rscale + (long)rb * X.aop.CG + cgw;
-          }
+          // (both waves of the pair and the 16 lanes of a row group write the same 16 bytes: no branch)
+          *reinterpret_cast<f32x4*>(lds + X.dst_sc + (4 * ex.p + (wave >> 1)) * 64 + g * 16) = f32x4{rs[0], rs[1], rs[2], rs[3]};
         }
-        if (X.out != nullptr) {
 #pragma unroll
-          for (int t = 0; t < 2; ++t)
+        for (int reg = 0; reg < 4; ++reg) {
+          const float x = v[reg] * s[reg];
+          hi[reg] = (_Float16)x;
+          lo[reg] = (_Float16)(x - (float)hi[reg]);
+        }
+        char* dp = lds + X.dst_pl + col * 32 + 8 * g;
+        *reinterpret_cast<half4*>(dp) = hi;
+        *reinterpret_cast<half4*>(dp + X.dst_lo) = lo;
+        if (X.frag != nullptr) {
+          // the weight-gradient fragment: the image's pair under the block's scale (16 rows x 32 columns); rows beyond
+          // the batch get factor 0
+          half4 ratio;
+          if (bounded) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) pend.v[4 * t + reg] = v[t][reg];
-          const int col = 128 * XU.pass + colw + n;
-          pend.out_base = X.out + (long)r0 * X.n;
-          pend.out_n = X.n;
-          pend.out_bytes = max(0, rows_valid) * X.n * 4;
-          // a column beyond n would alias the next row inside the buffer's bounds: such a lane's offset is pushed out of them
+            for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(4 * g + reg < rows_valid ? 1.f : 0.f);
+          } else {
+            bm = max(bm, (unsigned)__shfl_xor((int)bm, 16, 64));
+            bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
+            float sb;
+            pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
 #pragma unroll
-          for (int t = 0; t < 2; ++t) pend.out_voff[t] = col + 16 * t < X.n ? (unsigned)((4 * g * X.n + col + 16 * t) * 4) : 0x80000000u;
+            for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(4 * g + reg < rows_valid ? sb * rs[reg] : 0.f);
+          }
+          hi = hi * ratio;
+          lo = lo * ratio;
         }
       }
     }
-    if (XU.flags & U_LAYER_END) __syncthreads();
-    if (MODE == CHAIN_FUSED && ui == a.cost_at) {
-      // the forward part is complete: cost; d cost / d output -> HBM and, re-staged, the first backward unit's image
-      cost_phase();
-      __syncthreads();
-      const CostArgs& cst = a.cost;
-      const float* yb = reinterpret_cast<const float*>(lds + a.y_f32);
-      const int wout = cst.ldy;
-      for (int grp = wave; grp < a.top_Q; grp += 4) {
-        const int col = 32 * grp + sc_c;
-        const bool covered = (col >= cst.off_sin && col < cst.off_sin + cst.n) ||
-                             (cst.periodic_output && col >= cst.off_cos && col < cst.off_cos + cst.n);
-        float v[8];
+    {
+      // float32 rows: column col of rows 4 g + reg; a column beyond n would alias the next row inside the buffer's
+      // bounds, so such a lane's offset is pushed out of them
+      const bool keep = last && X.out != nullptr;
+      const float* ob = keep ? X.out + (long)r0 * X.n : wsf;
+      __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ob), 0, keep ? max(0, rows_valid) * X.n * 4 : 0, 0x00020000);
+      const unsigned vo = col < X.n ? (unsigned)((4 * g * X.n + col) * 4) : 0x80000000u;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (covered && col < wout) ? yb[(8 * sc_hf + e) * a.y_pitch + col] : 0.f;
-        stage_finish(v, grp, a.top_Q, a.top_pl, a.top_sc, a.top_aop);
-      }
-      __syncthreads();
+      for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[reg]), ro, vo + reg * X.n * 4, 0, 0);
+      // weight-gradient fragment of the tile pair: lane (n, g) of tile t = wave & 1 holds rows 4 g .. 4 g + 3 of column
+      // 16 t + n = fragment lane 32 (g >> 1) + 16 t + n, elements 4 (g & 1) ..; column groups beyond the tensor do not exist
+      const int grp = 4 * ex.p + (wave >> 1);
+      const bool keepf = last && X.frag != nullptr && has_img && grp < X.CG;
+      const char* fb = keepf ? X.frag + ((long)rb * X.CG + grp) * 2048 : a.units;
+      __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fb), 0, keepf ? 2048 : 0, 0x00020000);
+      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rf, fvoff, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rf, fvoff + 1024, 0, 0);
+      const bool keeps = keepf && (wave & 1) == 0;
+      const float* rsp = keeps ? X.rscale + (long)rb * X.CG + grp : wsf;
+      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rsp), 0, keeps ? 4 : 0, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rsb), rr, lane == 0 ? 0u : 0x80000000u, 0, 0);
     }
-    XU = XUn;
+    TSTAMP(6 + 5 * ui);
+    // the layer's rows are complete in the destination image when its last unit is done
+    const bool layer_end = last && ex.p == ex.P - 1;
+    if (layer_end) __syncthreads();
+    TSTAMP(7 + 5 * ui);
+    if (stream_next(ex)) ex_load_gemm();
   };
 
-  for (int ui = -(NB - 1);; ui += NB) {
-    unit(IC_<0>{}, ui);
-    if (ui + 1 >= nu) break;
-    unit(IC_<1>{}, ui + 1);
-    if (ui + 2 >= nu) break;
+  // GEMMs [g0, g1) through the ring, their units starting at `units`: the packages of the first NB - 1 units are requested,
+  // `between` runs while they are in flight (staging the row block; the cost phase of the fused launch), then every
+  // iteration executes one unit and requests the one NB - 1 ahead.
+  auto pipeline = [&](const int g0, const int g1, const char* units, auto between) __attribute__((always_inline)) {
+    rq = Stream{g0, g1, 0, 0, 0, 0};
+    rq_live = true;
+    rq_ptr = units + wave * 8192;
+    rq_load_gemm();
+    request(IC_<0>{});
+#pragma unroll
+    for (int s = 0; s < 4; ++s) request_pieces(IC_<0>{}, s);
+    rq_advance();
     if constexpr (NB >= 3) {
-      unit(IC_<2>{}, ui + 2);
-      if (ui + 3 >= nu) break;
+      request(IC_<1>{});
+#pragma unroll
+      for (int s = 0; s < 4; ++s) request_pieces(IC_<1>{}, s);
+      rq_advance();
     }
+    ex = Stream{g0, g1, 0, 0, 0, 0};
+    ex_load_gemm();
+    between();
+    // iteration k executes the k-th unit from slot k % NB and requests the (k + NB - 1)-th into slot (k + NB - 1) % NB
+    for (;;) {
+      exec(IC_<NB - 1>{});
+      if (ex.gi >= g1) break;
+      exec(IC_<0>{});
+      if (ex.gi >= g1) break;
+      if constexpr (NB >= 3) {
+        exec(IC_<1>{});
+        if (ex.gi >= g1) break;
+      }
+    }
+  };
+
+  const bool with_cost = !BWD && a.cost.ws != nullptr;
+  // the row block travels ahead of the first packages and reaches LDS behind them
+  float sx[8], shv[8], tv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (wave < a.in_Q) stage_load(wave, sx, shv);
+  if (with_cost) {
+    const int c = 4 * (tid & 31), row = tid >> 5;
+    const long grow = (long)min(r0 + row, a.row_end - 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tv[i] = a.cost.target[grow * a.cost.ldt + min(c + i, a.cost.n - 1)];
   }
-  flush_pend();
+  TSTAMP(1);
+  const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  auto stage_rest = [&]() __attribute__((always_inline)) {
+    const int lo_off = a.in_Qp * 1024;
+    if (wave < a.in_Q) {
+      float v[8];
+      stage_value(wave, sx, shv, v);
+      stage_finish(v, wave, lo_off, a.in_pl, a.in_sc, a.in_aop, true);
+    } else if (wave < a.in_Qp) {
+      stage_finish(zero8, wave, lo_off, a.in_pl, a.in_sc, a.in_aop, false);
+    }
+    for (int grp = wave + NWC; grp < a.in_Qp; grp += NWC) {
+      if (grp < a.in_Q) {
+        float x[8], hv[8], v[8];
+        stage_load(grp, x, hv);
+        stage_value(grp, x, hv, v);
+        stage_finish(v, grp, lo_off, a.in_pl, a.in_sc, a.in_aop, true);
+      } else {
+        stage_finish(zero8, grp, lo_off, a.in_pl, a.in_sc, a.in_aop, false);
+      }
+    }
+    if (with_cost) {
+      const int c = 4 * (tid & 31), row = tid >> 5;
+      const long grow = (long)min(r0 + row, a.row_end - 1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (c + i < a.cost.n) tgt[row * a.cost.n + c + i] = tv[i];
+      for (int cc = c + 128; cc < a.cost.n; cc += 128)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (cc + i < a.cost.n) tgt[row * a.cost.n + cc + i] = a.cost.target[grow * a.cost.ldt + cc + i];
+    }
+    __syncthreads();
+    TSTAMP(2);
+  };
+  if (MODE == CHAIN_FUSED) {
+    pipeline(0, a.ng_fwd, a.units, stage_rest);
+    if (a.ng_fwd < a.ng) {
+      // the forward part is complete.  The first backward packages are requested, then -- while they are in flight -- the
+      // cost runs and d cost / d output goes to HBM and, re-staged, into the first backward GEMM's image
+      pipeline(a.ng_fwd, a.ng, a.units_bwd, [&]() __attribute__((always_inline)) {
+        cost_phase();
+        __syncthreads();
+        const CostArgs& cst = a.cost;
+        const float* yb = reinterpret_cast<const float*>(lds + a.y_f32);
+        const int wout = cst.ldy;
+        for (int grp = wave; grp < a.top_Qp; grp += NWC) {
+          const int col = 32 * grp + sc_c;
+          const bool covered = (col >= cst.off_sin && col < cst.off_sin + cst.n) ||
+                               (cst.periodic_output && col >= cst.off_cos && col < cst.off_cos + cst.n);
+          float vv[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) vv[e] = (covered && col < wout) ? yb[(8 * sc_hf + e) * a.y_pitch + min(col, wout - 1)] : 0.f;
+          stage_finish(vv, grp, a.top_Qp * 1024, a.top_pl, a.top_sc, a.top_aop, grp < a.top_Q);
+        }
+        __syncthreads();
+      });
+    } else {
+      cost_phase();
+    }
+  } else {
+    pipeline(0, a.ng, a.units, stage_rest);
+  }
+  TSTAMP(60);
   if (MODE == CHAIN_FWD && with_cost) cost_phase();
+  TSTAMP(61);
+#ifdef EMX_CHAIN_TIMING
+  __syncthreads();
+  if (blockIdx.x == 0 || blockIdx.x == 100) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
+#endif
 }
 
-// the operand store from the flat parameter buffer: one wave per 32 x 32 block (the optimizer keeps it current afterwards)
+// The operand store from the flat parameter buffer (the optimizer keeps it current afterwards).  Two launches: the layers'
+// exact maxima -> headers (scale, both slots seeded, wop.h), then one wave per 32 x 32 block writes the pieces.
+__global__ __launch_bounds__(256) void mlp_mirror_max_kernel(const WopArgs wa, const float* __restrict__ params, char* __restrict__ store) {
+  __shared__ unsigned red[4];
+  const int l = blockIdx.x;
+  const long nW = (long)wa.K[l] * wa.N[l];
+  const float* W = params + wa.w_off[l];
+  unsigned mx = 0;
+  for (long i = threadIdx.x; i < nW; i += 256) mx = max(mx, abs_bits(W[i]));
+  mx = wave_max_u32(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = max(max(red[0], red[1]), max(red[2], red[3]));
+    float s, rs;
+    pow2_scale_bits<WOP_TOP>(mx, s, rs);
+    WopHeader* h = wop_header(store, l);
+    h->rs = rs;
+    h->pad = 0.f;
+    h->slot[0] = h->slot[1] = mx;   // update index 0: any optimizer update supersedes it
+  }
+}
 __global__ __launch_bounds__(64) void mlp_mirror_kernel(const WopArgs wa, const float* __restrict__ params, char* __restrict__ store) {
   __shared__ __align__(16) _Float16 img[2048];
   const int lane = threadIdx.x;
@@ -660,7 +782,9 @@ __global__ __launch_bounds__(64) void mlp_mirror_kernel(const WopArgs wa, const 
   wop_item(wa, blockIdx.x, l, kb, nb);
   float wv[16];
   wop_load_block(wa, params, l, kb, nb, lane, wv);
-  wop_write_block(wa, store, l, kb, nb, wv, lane, img);
+  float s, rs;
+  pow2_scale_bits<WOP_TOP>((unsigned)wop_header(store, l)->slot[0], s, rs);
+  wop_write_block(wa, store, l, kb, nb, wv, s, lane, img);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -840,25 +964,26 @@ int set_lds(const void* fn, size_t bytes, const char* who) {
   return EMX_OK;
 }
 
-// Builds the launch description: LDS allocation (two ping-pong images sized per parity, float32 copies, side buffers), the
-// GEMM records and the flattened unit list.
+// Builds the launch description: LDS allocation (two ping-pong images sized per parity, float32 copies, side buffers) and
+// the GEMM records.  Images are padded to whole 128-column chunks (regular units, wop.h).
 struct ChainBuilder {
   ChainArgs a{};
   WopArgs wa{};
   const emx_mlp_desc* desc;
   const char* who;
+  const char* wop;
   int ng = 0;
   int Qp[2] = {0, 0};
   int extra[2] = {0, 0};   // bytes another tenant of the parity's region needs (a float32 copy that lives there once the image is dead)
   int pl[2] = {0, 0}, sc[2] = {0, 0};
   int lds = 0;
-  ChainBuilder(const emx_mlp_desc* d, const char* w) : desc(d), who(w) {
+  ChainBuilder(const emx_mlp_desc* d, const float* mirror, const char* w) : desc(d), who(w), wop(reinterpret_cast<const char*>(mirror)) {
     fill_wop_args(d, wa);
     a.lat_off = a.tgt_off = 0;
     a.y_f32 = -1;
-    a.cost_at = -1;
   }
-  void need(int parity, int width) { Qp[parity] = std::max(Qp[parity], groups32(width)); }
+  static int padded_groups(int width) { return 4 * groups128(width); }
+  void need(int parity, int width) { Qp[parity] = std::max(Qp[parity], padded_groups(width)); }
   int alloc(int bytes) {
     const int o = lds;
     lds += (bytes + 15) & ~15;
@@ -866,56 +991,42 @@ struct ChainBuilder {
   }
   void layout_images() {
     for (int p = 0; p < 2; ++p) {
-      const int q = std::max(Qp[p], 1);
+      const int q = std::max(Qp[p], 4);
       pl[p] = alloc(std::max(q * (2048 + 64), extra[p]));
       sc[p] = pl[p] + q * 2048;
     }
   }
-  static int f32_pitch(int n) { return ((n + 7) / 8) * 8 + 4; }
-  // one layer in one direction; returns the GEMM's index or a negative error
-  int add_gemm(int l, bool bwd, int src_par, int dst_par, const float* aux, int aux_rs, float* out, int sflags, const AopTensor& aop) {
+  static int f32_pitch(int n) { return 128 * groups128(n) + 4; }   // whole passes (every lane has a slot) + 4
+  const char* fwd_units(int l) const { return wop + wa.units_begin + wa.fwd_unit[l] * WOP_UNIT; }
+  const char* bwd_units(int l) const { return wop + wa.units_begin + wa.bwd_unit[l] * WOP_UNIT; }
+  // one layer in one direction; returns the GEMM's index or a negative error.  src_tanh: the source image holds tanh
+  // outputs (written at the fixed scale by the forward epilogue of the layer below)
+  int add_gemm(int l, bool bwd, int src_par, bool src_tanh, int dst_par, const float* aux, int aux_rs, float* out, int sflags, const AopTensor& aop) {
     if (ng >= MAXG) return emx::fail(EMX_EUNSUPPORTED, "%s: more than %d GEMMs in one launch", who, MAXG);
     const int K = desc->width[l], N = desc->width[l + 1];
     const int kred = bwd ? N : K, nout = bwd ? K : N;
-    const long base = wa.begin[l];
-    const long opb = bwd ? base + wop_operand_bytes(K, N) : base;
-    if ((opb + wop_operand_bytes(K, N)) / 1024 > 0x7fffffffL) return emx::fail(EMX_EUNSUPPORTED, "%s: operand store too large", who);
     GemmRec& G = a.g[ng];
-    G.op_kb = (int)(opb / 1024);
-    G.Q = groups32(kred);
-    G.T = groups32(nout);
-    G.ws_off = (int)((base + 2 * wop_operand_bytes(K, N)) / 4);
-    G.ws_ss = bwd ? 1 : groups32(N);
-    G.ws_sw = bwd ? groups32(N) : 1;
+    G.P = groups128(nout);
+    G.C = groups128(kred);
     G.n = nout;
     G.sflags = sflags | (bwd ? S_BWD : 0);
     G.aux = aux;
     G.aux_rs = aux_rs;
+    G.ws = reinterpret_cast<const float*>(wop + (long)l * sizeof(WopHeader));
     G.src_pl = pl[src_par];
+    G.src_lo = padded_groups(kred) * 1024;
     G.src_sc = sc[src_par];
+    G.src_rs = src_tanh ? TANH_RS : 0.f;
     G.dst_pl = dst_par >= 0 ? pl[dst_par] : -1;
+    G.dst_lo = padded_groups(nout) * 1024;
     G.dst_sc = dst_par >= 0 ? sc[dst_par] : -1;
     G.dst_f32 = G.h_f32 = -1;
     G.dst_f32_pitch = G.h_f32_pitch = 0;
     G.out = out;
     G.aop = aop;
-    // the source image was laid out for its own width: the lo plane sits Q K-steps behind the hi plane
-    if (G.Q > 255 * 4 || G.T > 255 * 4) return emx::fail(EMX_EUNSUPPORTED, "%s: layer too wide", who);
-    const int P = (nout + 127) / 128, C = (kred + 127) / 128;
-    for (int p = 0; p < P; ++p)
-      for (int c = 0; c < C; ++c) {
-        if (a.nu >= MAXU) return emx::fail(EMX_EUNSUPPORTED, "%s: layer range needs more than %d 128x128 units", who, MAXU);
-        a.u[a.nu++] = UnitRec{(unsigned char)ng, (unsigned char)p, (unsigned char)c,
-                              (unsigned char)((c == 0 ? U_FIRST : 0) | (c == C - 1 ? U_LAST : 0) | (c == C - 1 && p == P - 1 ? U_LAYER_END : 0))};
-      }
     return ng++;
   }
 };
-
-// The source image's lo plane offset is Q_image * 1024 where Q_image is the K-step count of the image as laid out for the
-// tensor it holds: ping-pong images are shared between tensors of different widths, so every tensor uses its OWN Q for the
-// plane offset (planes of a narrower tensor simply occupy the head of the allocation); producer and consumer agree because
-// both derive it from the tensor's width.
 
 int fill_cost(ChainArgs& a, const emx_auto_cost* cost, int wout, float* dY, const char* who) {
   EMX_REQUIRE(cost->target && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0, "%s: incomplete cost description", who);
@@ -965,7 +1076,7 @@ size_t emx_mlp_mirror_floats(const emx_mlp_desc* desc) {
   if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL) return 0;
   WopArgs wa;
   fill_wop_args(desc, wa);
-  return (size_t)(wa.begin[desc->n_layers] / 4);
+  return (size_t)(wop_total_bytes(wa) / 4);
 }
 
 int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror, emx_stream_t stream) {
@@ -974,6 +1085,12 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
   EMX_REQUIRE(params && mirror, "emx_mlp_mirror: null pointer argument");
   WopArgs wa;
   fill_wop_args(desc, wa);
+  // the zero padding of the layers (to whole 128 x 128 units) is written here, once; the optimizer rewrites real blocks only
+  if (hipMemsetAsync(mirror, 0, (size_t)wop_total_bytes(wa), (hipStream_t)stream) != hipSuccess) return emx::check_launch("emx_mlp_mirror (memset)");
+  hipLaunchKernelGGL(mlp_mirror_max_kernel, dim3((unsigned)desc->n_layers), dim3(256), 0, (hipStream_t)stream, wa, params,
+                     reinterpret_cast<char*>(mirror));
+  rc = emx::check_launch("mlp_mirror_max_kernel");
+  if (rc) return rc;
   hipLaunchKernelGGL(mlp_mirror_kernel, dim3((unsigned)wa.item_begin[desc->n_layers]), dim3(64), 0, (hipStream_t)stream, wa, params,
                      reinterpret_cast<char*>(mirror));
   return emx::check_launch("mlp_mirror_kernel");
@@ -999,7 +1116,7 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "%s: bad rows / stride", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);
   if (rc) return rc;
-  ChainBuilder b(desc, who);
+  ChainBuilder b(desc, mirror, who);
   AopLayout AL;
   if (aop) aop_layout(desc, aop_rows, AL);
   const int nf = layer_end - layer_begin;
@@ -1008,20 +1125,23 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   // the cost's float32 copy of the output rows lives where the image of parity nf & 1 was: the last layer reads the other
   // parity, and every reader of this one is behind the barrier in front of the last layer
   if (cost) b.extra[nf & 1] = R * ChainBuilder::f32_pitch(wout) * 4;
+  // a range that ends inside the network (a data-parallel rank's encoder pass) still leaves the fragments of its last
+  // layer for the weight gradients of the layer above: they come out of the split, i.e. of a destination image
+  const bool tail_frags = aop && layer_end < desc->n_layers;
+  EMX_REQUIRE(!(tail_frags && cost), "%s: the cost belongs to the network's last layer", who);
+  if (tail_frags) b.need(nf & 1, wout);
   b.layout_images();
   for (int st = 0; st < nf; ++st) {
     const int l = layer_begin + st;
     const bool last = st == nf - 1;
     // the fragments of h_l are the X operand of layer l + 1's weight gradient: not needed for the network's last layer
     const AopTensor ao = (aop && l + 1 < desc->n_layers) ? aop_tensor(aop, AL, 1 + l) : AopTensor{nullptr, nullptr, 0};
-    const int gi = b.add_gemm(l, false, st & 1, last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, ao);
+    const int gi = b.add_gemm(l, false, st & 1, st > 0 && desc->act[l - 1], (!last || tail_frags) ? (st + 1) & 1 : -1, params + desc->b_off[l], 0,
+                              h[l], desc->act[l] ? S_ACT : 0, ao);
     if (gi < 0) return gi;
-    if (last && ao.frag) {   // (a sub-range that ends inside the network: the fragments need the split, i.e. a destination image)
-      b.need((st + 1) & 1, wout);
-      return emx::fail(EMX_EUNSUPPORTED, "%s: a layer range that ends inside the network cannot leave weight-gradient fragments of its last layer", who);
-    }
   }
   ChainArgs& a = b.a;
+  a.ng = a.ng_fwd = b.ng;
   if (cost) {
     rc = fill_cost(a, cost, wout, cost->dY, who);
     if (rc) return rc;
@@ -1031,11 +1151,13 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
     G.dst_f32 = a.y_f32 = b.pl[nf & 1];
     a.tgt_off = b.alloc(R * cost->n * 4);
   }
-  a.wop = reinterpret_cast<const char*>(mirror);
+  a.units = b.fwd_units(layer_begin);
+  a.units_bwd = a.units;
   a.in = in;
   a.ld_in = ld_in;
   a.in_cols = desc->width[layer_begin];
   a.in_Q = groups32(a.in_cols);
+  a.in_Qp = ChainBuilder::padded_groups(a.in_cols);
   a.in_pl = b.pl[0];
   a.in_sc = b.sc[0];
   a.in_aop = (aop && layer_begin == 0) ? aop_tensor(aop, AL, 0) : AopTensor{nullptr, nullptr, 0};
@@ -1061,7 +1183,7 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "%s: layer_add outside the layer range", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);
   if (rc) return rc;
-  ChainBuilder b(desc, who);
+  ChainBuilder b(desc, mirror, who);
   ChainArgs& a = b.a;
   AopLayout AL;
   if (aop) aop_layout(desc, aop_rows, AL);
@@ -1090,41 +1212,37 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
     const int st = top - l;
     const bool last = l == lo;
     int gi;
-    if (l > layer_begin)
-      gi = b.add_gemm(l, true, st & 1, last ? -1 : (st + 1) & 1, desc->act[l - 1] ? h[l - 1] : params, desc->act[l - 1] ? Kin : 0, delta[l - 1],
-                      sflags(l - 1), dop(l - 1));
-    else
-      gi = b.add_gemm(l, true, st & 1, -1, params, 0, dbelow, 0, AopTensor{nullptr, nullptr, 0});
-    if (gi < 0) return gi;
-    // delta_{l-1} is an operand of the next GEMM and / or of the weight gradients: both need the split, i.e. an image
-    GemmRec& G = a.g[gi];
-    if (l > layer_begin && G.dst_pl < 0 && G.aop.frag) {
-      b.a.g[gi].dst_pl = b.pl[(st + 1) & 1];
-      b.a.g[gi].dst_sc = b.sc[(st + 1) & 1];
+    if (l > layer_begin) {
+      // delta_{l-1} is an operand of the next GEMM and / or of the weight gradients: both need the split, i.e. an image
+      const AopTensor ao = dop(l - 1);
+      gi = b.add_gemm(l, true, st & 1, false, (!last || ao.frag) ? (st + 1) & 1 : -1, desc->act[l - 1] ? h[l - 1] : params,
+                      desc->act[l - 1] ? Kin : 0, delta[l - 1], sflags(l - 1), ao);
+    } else {
+      gi = b.add_gemm(l, true, st & 1, false, -1, params, 0, dbelow, 0, AopTensor{nullptr, nullptr, 0});
     }
+    if (gi < 0) return gi;
   }
+  if (b.ng == 0) {
+    // a one-layer range without dbelow: only delta_top is formed (while the row block is staged); the pipeline still wants
+    // one unit: the layer's own, with nothing kept
+    const int gi = b.add_gemm(top, true, 0, false, -1, params, 0, nullptr, 0, AopTensor{nullptr, nullptr, 0});
+    if (gi < 0) return gi;
+    a.g[gi].P = a.g[gi].C = 1;
+  }
+  a.ng = a.ng_fwd = b.ng;
   if (join) a.lat_off = b.alloc(R * a.join_n * 4);
-  a.wop = reinterpret_cast<const char*>(mirror);
+  a.units = b.bwd_units(top);
+  a.units_bwd = a.units;
   a.in = dtop;
   a.ld_in = ld_top;
   a.in_cols = desc->width[layer_end];
   a.in_Q = groups32(a.in_cols);
+  a.in_Qp = ChainBuilder::padded_groups(a.in_cols);
   a.in_pl = b.pl[0];
   a.in_sc = b.sc[0];
   a.in_aop = dop(top);
   a.row0 = row_begin;
   a.row_end = row_end;
-  if (a.nu == 0) {   // a one-layer range without dbelow: only delta_top is formed; the kernel still wants one readable record
-    a.g[0] = GemmRec{};
-    a.g[0].Q = a.g[0].T = 1;
-    a.g[0].n = 1;
-    a.g[0].aux = params;
-    a.g[0].src_pl = b.pl[0];
-    a.g[0].src_sc = b.sc[0];
-    a.g[0].dst_pl = a.g[0].dst_sc = a.g[0].dst_f32 = a.g[0].h_f32 = -1;
-    a.g[0].sflags = S_BWD;
-    a.u[0] = UnitRec{0, 0, 0, 0};
-  }
   return launch_chain<CHAIN_BWD>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (backward)");
 }
 
@@ -1143,7 +1261,7 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
   EMX_REQUIRE(cost->dY == delta[top] || cost->dY == nullptr, "%s: d cost / d output is delta[layer_end - 1]; pass that buffer (or NULL) as cost->dY", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);
   if (rc) return rc;
-  ChainBuilder b(desc, who);
+  ChainBuilder b(desc, mirror, who);
   ChainArgs& a = b.a;
   AopLayout AL;
   if (aop) aop_layout(desc, aop_rows, AL);
@@ -1160,9 +1278,10 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
     const int l = layer_begin + st;
     const bool last = st == nf - 1;
     const AopTensor ao = (aop && l + 1 < n) ? aop_tensor(aop, AL, 1 + l) : AopTensor{nullptr, nullptr, 0};
-    const int gi = b.add_gemm(l, false, st & 1, last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l], desc->act[l] ? S_ACT : 0, ao);
-    if (gi < 0) return gi;
     EMX_REQUIRE(!(last && ao.frag), "%s: the fused launch ends at the network's last layer", who);
+    const int gi = b.add_gemm(l, false, st & 1, st > 0 && desc->act[l - 1], last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l],
+                              desc->act[l] ? S_ACT : 0, ao);
+    if (gi < 0) return gi;
     // float32 copy of h_l in LDS: the cost's input (last layer) or the activation derivative of the backward units
     const bool for_bwd = desc->act[l] && l >= bwd_begin && l < top;
     if (last || for_bwd) {
@@ -1171,7 +1290,7 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
       G.dst_f32 = hcopy[l] = b.alloc(R * G.dst_f32_pitch * 4);
     }
   }
-  a.cost_at = a.nu - 1;
+  a.ng_fwd = b.ng;
   a.y_f32 = hcopy[top];
   a.y_pitch = hpitch[top];
   for (int l = top; l >= lo; --l) {
@@ -1180,28 +1299,32 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
     int gi;
     if (l > bwd_begin) {
       // delta_{l-1} = (delta_l W_l^T) * act'(h_{l-1}); h_{l-1} is still in its float32 LDS copy
-      gi = b.add_gemm(l, true, st & 1, (st + 1) & 1, params, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, dop(l - 1));
+      const AopTensor ao = dop(l - 1);
+      gi = b.add_gemm(l, true, st & 1, false, (!last || ao.frag) ? (st + 1) & 1 : -1, params, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, ao);
       if (gi < 0) return gi;
       a.g[gi].h_f32 = hcopy[l - 1];
       a.g[gi].h_f32_pitch = hpitch[l - 1];
-      if (last && !a.g[gi].aop.frag) a.g[gi].dst_pl = a.g[gi].dst_sc = -1;
     } else {
-      gi = b.add_gemm(l, true, st & 1, -1, params, 0, dbelow, 0, AopTensor{nullptr, nullptr, 0});
+      gi = b.add_gemm(l, true, st & 1, false, -1, params, 0, dbelow, 0, AopTensor{nullptr, nullptr, 0});
       if (gi < 0) return gi;
     }
   }
+  a.ng = b.ng;
   rc = fill_cost(a, cost, wout, delta[top], who);
   if (rc) return rc;
   a.tgt_off = b.alloc(R * cost->n * 4);
   a.top_pl = b.pl[0];
   a.top_sc = b.sc[0];
   a.top_Q = groups32(wout);
+  a.top_Qp = ChainBuilder::padded_groups(wout);
   a.top_aop = dop(top);
-  a.wop = reinterpret_cast<const char*>(mirror);
+  a.units = b.fwd_units(layer_begin);
+  a.units_bwd = b.bwd_units(top);
   a.in = in;
   a.ld_in = ld_in;
   a.in_cols = desc->width[layer_begin];
   a.in_Q = groups32(a.in_cols);
+  a.in_Qp = ChainBuilder::padded_groups(a.in_cols);
   a.in_pl = b.pl[0];
   a.in_sc = b.sc[0];
   a.in_aop = (aop && layer_begin == 0) ? aop_tensor(aop, AL, 0) : AopTensor{nullptr, nullptr, 0};
@@ -1291,3 +1414,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 }
 
 }  // extern "C"
+
+#ifdef EMX_CHAIN_TIMING
+extern "C" int emx_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg), sizeof(emx_dbg)); }
+#endif

@@ -3,21 +3,33 @@
 //
 // A float32 product on gfx950's f32 matrix instruction costs 16x the cycles of a 16-bit one (MI355X_MICROARCH.md), and a
 // float32 value is the sum of two f16 values to 22 significant bits.  The kernel [K = in, N = out] of every layer is
-// therefore kept as BLOCK-SCALED f16 PAIRS: per 32 x 32 block (kb, nb) of W one power-of-two scale s (the block's
-// largest |w| goes to ~2^14, so any magnitude is representable) and two f16 planes
+// therefore kept as a SCALED f16 PAIR: one power-of-two scale s per layer and two f16 planes
 //     h = f16(s w),  l = f16(s w - h)            |s w - h - l| <= max(2^-22 |s w|, 2^-25)
 // and a product x.w runs as the three 16-bit matrix instructions hh + hl + lh (every partial product exact in the f32
-// accumulator; the dropped l.l term is 2^-22 relative), scaled back by 1/s per K-step in the consuming kernel.
+// accumulator; the dropped l.l term is 2^-22 relative), scaled back by 1/s once per output element.
 //
-// Per layer the store holds, in this order (byte offsets from the layer's begin[]):
-//   forward operand   B[k = in][col = out]  : pieces [nb][kb][tile t < 2][plane < 2], 1 KB each
-//   backward operand  B[k = out][col = in]  : pieces [kb][nb][tile t < 2][plane < 2], 1 KB each
-//   1/s               float [kb][nb]
+// The scale.  One scale per LAYER lets a whole reduction accumulate inside the matrix instruction (a scale per K-step
+// costs a multiply-add per accumulator element and K-step, which is what bounded the first version of these kernels).
+// It brings the layer's largest |w| to [2^12, 2^13): three binades of headroom below the f16 maximum, and -- f16 being a
+// floating-point format -- no loss of precision for being 8x smaller than it could be.  The optimizer rewrites the store in
+// the launch that updates the weights, where the new maximum is not known before every workgroup has finished; it
+// therefore uses the maximum RECORDED BY THE PREVIOUS UPDATE (weights move by ~lr per step) and records its own for the
+// next one: slot[t & 1] of the layer's header receives (t << 32 | bits of max|w|) by a 64-bit atomic maximum, so a new
+// step's first record supersedes whatever an older step left, without a reset.  A weight that outgrows the headroom within
+// ONE update becomes an f16 infinity and the losses NaN: loud, not silent.  emx_mlp_mirror (fresh build) uses the exact
+// maximum and seeds both slots.
+//
+// Layout.  Every layer is padded with zeros to multiples of 128 in both dimensions, so that the row-block kernels run
+// REGULAR UNITS -- 128 output columns x 128 reduction indices: 8 tiles of 16 columns (one per wave) x 4 K-steps of 32 x 2
+// planes = 64 pieces of 1 KB -- and the units are stored in the order the kernels execute them, so that a launch walks
+// the store front to back and the address of a unit's package is the previous one + 64 KB:
+//   headers           64 bytes per layer (WopHeader), region padded to 1 KB
+//   forward units     for l = 0 .. n-1: for pass p (128 columns of out): for chunk c (128 k of in): [wave][K-step][plane] x 1 KB
+//   backward units    for l = n-1 .. 0: for pass p (128 columns of in):  for chunk c (128 k of out): likewise
 // A piece is the B fragment of ONE v_mfma_f32_16x16x32_f16: lane (n = lane & 15, g = lane >> 4) holds the 8 halves
-//   B[32 ks + kk(g, e)][32 cg + 16 t + n],  kk(g, e) = 4 g + e (e < 4), 16 + 4 g + (e - 4) (e >= 4)
+//   B[32 ks + kk(g, e)][16 t + n],  kk(g, e) = 4 g + e (e < 4), 16 + 4 g + (e - 4) (e >= 4)
 // (the k order inside a K-step is free as long as both operands agree; this one makes the activations' transposed LDS
 // read conflict-free, mlp.hip) -- 16 bytes per lane, so one global_load_dwordx4 per wave fetches eight whole lines.
-// Zero padded: K and N are rounded up to multiples of 32.
 #pragma once
 #include <cstdint>
 
@@ -29,56 +41,80 @@ typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef __fp16 fp16x4_builtin __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
+constexpr long WOP_UNIT = 65536;   // bytes of one unit's package
+
 struct WopArgs {
   int n_layers;
   int K[EMX_MAX_LAYERS], N[EMX_MAX_LAYERS];
   long w_off[EMX_MAX_LAYERS];          // float offset of the [K, N] kernel inside the flat parameter buffer
-  long begin[EMX_MAX_LAYERS + 1];      // byte offset of the layer's region inside the store
+  long fwd_unit[EMX_MAX_LAYERS + 1];   // index of the layer's first forward unit (units of WOP_UNIT behind units_begin)
+  long bwd_unit[EMX_MAX_LAYERS + 1];   // index of the layer's first backward unit; [n_layers]: total number of units
+  long units_begin;                    // byte offset of unit 0
   int item_begin[EMX_MAX_LAYERS + 1];  // prefix sum of 32 x 32 blocks (work items of the kernels that write the store)
 };
 
+struct WopHeader {                 // 64 bytes per layer at the head of the store
+  float rs;                        // 1/s of the layer's pieces as they stand
+  float pad;
+  unsigned long long slot[2];      // (update index << 32) | bits of the largest |w| that update wrote
+  unsigned long long reserved[5];
+};
+
 __host__ __device__ inline int groups32(int x) { return (x + 31) >> 5; }
-__host__ __device__ inline long wop_operand_bytes(int K, int N) { return 4096L * groups32(K) * groups32(N); }
-__host__ __device__ inline long wop_layer_bytes(int K, int N) {
-  return 2 * wop_operand_bytes(K, N) + (((long)groups32(K) * groups32(N) * 4 + 1023) / 1024) * 1024;   // a multiple of the piece size
-}
-// byte offsets inside a layer's region
-__host__ __device__ inline long wop_fwd_piece(int K, int N, int kb, int nb, int t, int plane) {
-  return ((((long)nb * groups32(K) + kb) * 2 + t) * 2 + plane) * 1024;
-}
-__host__ __device__ inline long wop_bwd_piece(int K, int N, int kb, int nb, int t, int plane) {
-  return wop_operand_bytes(K, N) + ((((long)kb * groups32(N) + nb) * 2 + t) * 2 + plane) * 1024;
-}
-__host__ __device__ inline long wop_scale(int K, int N, int kb, int nb) { return 2 * wop_operand_bytes(K, N) + ((long)kb * groups32(N) + nb) * 4; }
+__host__ __device__ inline int groups128(int x) { return (x + 127) >> 7; }
 
 inline void fill_wop_args(const emx_mlp_desc* desc, WopArgs& wa) {
-  wa.n_layers = desc->n_layers;
-  long o = 0;
+  const int n = desc->n_layers;
+  wa.n_layers = n;
+  wa.units_begin = ((long)n * 64 + 1023) / 1024 * 1024;
+  long u = 0;
   int items = 0;
-  for (int l = 0; l <= desc->n_layers; ++l) {
-    wa.begin[l] = o;
+  for (int l = 0; l < n; ++l) {
+    wa.K[l] = desc->width[l];
+    wa.N[l] = desc->width[l + 1];
+    wa.w_off[l] = desc->w_off[l];
+    wa.fwd_unit[l] = u;
     wa.item_begin[l] = items;
-    if (l < desc->n_layers) {
-      wa.K[l] = desc->width[l];
-      wa.N[l] = desc->width[l + 1];
-      wa.w_off[l] = desc->w_off[l];
-      o += wop_layer_bytes(wa.K[l], wa.N[l]);
-      items += groups32(wa.K[l]) * groups32(wa.N[l]);
-    }
+    u += (long)groups128(wa.K[l]) * groups128(wa.N[l]);
+    items += groups32(wa.K[l]) * groups32(wa.N[l]);
   }
+  wa.fwd_unit[n] = u;
+  wa.item_begin[n] = items;
+  for (int l = n - 1; l >= 0; --l) {
+    wa.bwd_unit[l] = u;
+    u += (long)groups128(wa.K[l]) * groups128(wa.N[l]);
+  }
+  wa.bwd_unit[n] = u;   // total
+}
+inline long wop_total_bytes(const WopArgs& wa) { return wa.units_begin + wa.bwd_unit[wa.n_layers] * WOP_UNIT; }
+
+// byte offset of the piece (plane) of block row kb (32 k of in) / block column nb (32 columns of out), tile t of the pair
+__host__ __device__ inline long wop_fwd_piece(const WopArgs& wa, int l, int kb, int nb, int t, int plane) {
+  const long unit = wa.fwd_unit[l] + (long)(nb >> 2) * groups128(wa.K[l]) + (kb >> 2);
+  return wa.units_begin + unit * WOP_UNIT + (((2 * (nb & 3) + t) * 4 + (kb & 3)) * 2 + plane) * 1024;
+}
+__host__ __device__ inline long wop_bwd_piece(const WopArgs& wa, int l, int kb, int nb, int t, int plane) {
+  const long unit = wa.bwd_unit[l] + (long)(kb >> 2) * groups128(wa.N[l]) + (nb >> 2);
+  return wa.units_begin + unit * WOP_UNIT + (((2 * (kb & 3) + t) * 4 + (nb & 3)) * 2 + plane) * 1024;
 }
 
-// power-of-two scale that brings mx (>= 0) to [2^13, 2^14), and its reciprocal; mx = 0, denormal or huge: exponent clamped
-__device__ __forceinline__ void pow2_scale(float mx, float& s, float& rs) {
-  int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;   // mx = f 2^E, f in [0.5, 1)
-  E = mx > 0.f ? min(max(E, -100), 100) : 14;
-  s = __uint_as_float((uint32_t)(127 + 14 - E) << 23);
-  rs = __uint_as_float((uint32_t)(127 - 14 + E) << 23);
+// Power-of-two scale from the bit pattern of a maximum |x| = f 2^E (f in [0.5, 1)): s = 2^(TOP - E) brings it to
+// [2^(TOP-1), 2^TOP), rs = 1/s.  The exponent field is clamped to E in [-100, 100]; an all-zero group gets the largest
+// scale (0 * s = 0).  Unsigned integer arithmetic only -- maxima of |x| are taken on the bit patterns (unsigned order =
+// float order there), where fmaxf would cost a canonicalising extra instruction per operand.
+template <int TOP>
+__device__ __forceinline__ void pow2_scale_bits(unsigned ab, float& s, float& rs) {
+  const unsigned ef = min(max(ab & 0x7f800000u, 26u << 23), 226u << 23);
+  s = __uint_as_float(((unsigned)(253 + TOP) << 23) - ef);
+  rs = __uint_as_float(ef - ((unsigned)(TOP - 1) << 23));
 }
+__device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+constexpr int WOP_TOP = 13;    // weights: the layer's maximum goes to [2^12, 2^13)
+constexpr int ACT_TOP = 14;    // activations and gradients: a group's maximum goes to [2^13, 2^14)
 
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
   return v;
 }
 
@@ -86,19 +122,16 @@ __device__ __forceinline__ half4 lds_read_tr16(const _Float16* p) {
   return (half4)__builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_builtin*)(p));
 }
 
-// One wave writes the two operand pieces-sets and the scale of block (kb, nb) of layer l from the block's weights:
+// One wave writes the pieces of block (kb, nb) of layer l -- two tiles in each direction -- from the block's weights:
 // lane (kr = lane >> 3, c4 = lane & 7) passes wv[4 j + i] = W[32 kb + kr + 8 j][32 nb + 4 c4 + i] (zero outside the layer).
-// img: 4 KB of LDS private to the wave (two [32 k][32 n] f16 planes); every lane of the wave must call (the transposed
-// LDS read needs EXEC all ones).
-__device__ __forceinline__ void wop_write_block(const WopArgs& wa, char* __restrict__ store, int l, int kb, int nb, const float (&wv)[16],
-                                                int lane, _Float16* img) {
-  const int K = wa.K[l], N = wa.N[l];
-  float mx = 0.f;
+// s: the layer's scale.  img: 4 KB of LDS private to the wave (two [32 k][32 n] f16 planes); every lane of the wave must
+// call (the transposed LDS read needs EXEC all ones).  Returns the largest |w| of the block (bit pattern, wave-uniform).
+__device__ __forceinline__ unsigned wop_write_block(const WopArgs& wa, char* __restrict__ store, int l, int kb, int nb, const float (&wv)[16],
+                                                    float s, int lane, _Float16* img) {
+  unsigned mx = 0;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) mx = fmaxf(mx, fabsf(wv[i]));
-  mx = wave_max(mx);
-  float s, rs;
-  pow2_scale(mx, s, rs);
+  for (int i = 0; i < 16; ++i) mx = max(mx, abs_bits(wv[i]));
+  mx = wave_max_u32(mx);
   const int kr = lane >> 3, c4 = lane & 7;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -114,7 +147,6 @@ __device__ __forceinline__ void wop_write_block(const WopArgs& wa, char* __restr
   }
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (no other wave touches img)
   __builtin_amdgcn_wave_barrier();
-  char* base = store + wa.begin[l];
   const int n = lane & 15, g = lane >> 4;
 #pragma unroll
   for (int plane = 0; plane < 2; ++plane) {
@@ -127,16 +159,16 @@ __device__ __forceinline__ void wop_write_block(const WopArgs& wa, char* __restr
       const half4 f0 = lds_read_tr16(pl + (4 * g + q) * 32 + 16 * t + 4 * p);
       const half4 f1 = lds_read_tr16(pl + (16 + 4 * g + q) * 32 + 16 * t + 4 * p);
       half8 fw = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-      *reinterpret_cast<half8*>(base + wop_fwd_piece(K, N, kb, nb, t, plane) + lane * 16) = fw;
+      *reinterpret_cast<half8*>(store + wop_fwd_piece(wa, l, kb, nb, t, plane) + lane * 16) = fw;
       // backward piece: B[k = out][col = in]: row 16 t + n of the image, columns kk(g, e)
       const half4 b0 = *reinterpret_cast<const half4*>(pl + (16 * t + n) * 32 + 4 * g);
       const half4 b1 = *reinterpret_cast<const half4*>(pl + (16 * t + n) * 32 + 16 + 4 * g);
       half8 bw = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      *reinterpret_cast<half8*>(base + wop_bwd_piece(K, N, kb, nb, t, plane) + lane * 16) = bw;
+      *reinterpret_cast<half8*>(store + wop_bwd_piece(wa, l, kb, nb, t, plane) + lane * 16) = bw;
     }
   }
-  if (lane == 0) *reinterpret_cast<float*>(base + wop_scale(K, N, kb, nb)) = rs;
   __builtin_amdgcn_wave_barrier();   // img may be rewritten by the caller's next block only behind these reads
+  return mx;
 }
 
 // loads the block's weights from the flat parameter buffer in wop_write_block's lane order (zero outside the layer)
@@ -166,5 +198,7 @@ __device__ __forceinline__ void wop_item(const WopArgs& wa, int item, int& l, in
   kb = rel / NB;
   nb = rel - kb * NB;
 }
+
+__device__ __forceinline__ WopHeader* wop_header(char* store, int l) { return reinterpret_cast<WopHeader*>(store) + l; }
 
 }  // namespace emx

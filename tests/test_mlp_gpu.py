@@ -171,18 +171,75 @@ def test_mlp_rejects_bad_arguments(L):
         L.mlp_wgrad(L.MlpPlan(lay, params, h, h), 0, 4, 0, 4, torch.zeros(lay.n_params, device="cuda"), torch.zeros(8, device="cuda"))
 
 
+def decode_operand_store(lay, mirror):
+    """The weight operand store back to float64 kernels, per layer (forward operand, backward operand, both also with
+    their zero padding), following the layout of csrc/wop.h: 64-byte headers (float 1/s per layer; region padded to 1 KB),
+    then 64-KB units in execution order -- forward: layer, pass (128 columns of out), chunk (128 k of in); backward: layers
+    descending, pass over in, chunk over out -- each [wave = tile of 16 columns][K-step of 32][plane] x 1 KB, lane
+    (n = lane & 15, g = lane >> 4) holding B[32 ks + kk(g, e)][16 tile + n], kk(g, e) = 4 g + e (e < 4), 16 + 4 g + e - 4."""
+    raw = mirror.cpu().numpy().view(np.uint8)
+    L_ = len(lay.layers)
+    units_begin = (L_ * 64 + 1023) // 1024 * 1024
+    g128 = lambda x: (x + 127) // 128
+    sizes = [g128(l.n_in) * g128(l.n_out) for l in lay.layers]
+    fwd_unit = np.concatenate([[0], np.cumsum(sizes)])[:-1]
+    bwd_unit = {}
+    u = sum(sizes)
+    for i in reversed(range(L_)):
+        bwd_unit[i] = u
+        u += sizes[i]
+    assert units_begin + u * 65536 == raw.size
+    lane = np.arange(64)
+    n_, g_ = lane & 15, lane >> 4
+    e = np.arange(8)
+    kk = np.where(e < 4, 4 * g_[:, None] + e, 16 + 4 * g_[:, None] + e - 4)          # [lane, e]
+    out = []
+    for i, l in enumerate(lay.layers):
+        K, N = l.n_in, l.n_out
+        rs = float(raw[64 * i: 64 * i + 4].view(np.float32)[0])
+        both = []
+        for base_unit, kred, nout in ((fwd_unit[i], K, N), (bwd_unit[i], N, K)):
+            P, C = g128(nout), g128(kred)
+            full = np.zeros((128 * C, 128 * P))
+            for p in range(P):
+                for c in range(C):
+                    o = units_begin + (base_unit + p * C + c) * 65536
+                    unit = raw[o: o + 65536].view(np.float16).astype(np.float64).reshape(8, 4, 2, 64, 8)   # [wave, ks, plane, lane, e]
+                    val = (unit[:, :, 0] + unit[:, :, 1]) * rs
+                    for w in range(8):
+                        for ks in range(4):
+                            full[128 * c + 32 * ks + kk, (128 * p + 16 * w + n_)[:, None]] = val[w, ks]
+            both.append(full)
+        out.append((both[0][:K, :N], both[1][:N, :K].T, both[0], both[1]))
+    return out
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("net_dim,n_neurons", [(128, [128, 128, 2]), (37, [50, 3]), (300, [136, 20, 2])])
 def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
     """The optimizer rewrites every kernel element at its two places in the operand store of the dense-layer kernels
-    (include/emx.h, emx_mlp_mirror): after an update the store must equal a fresh emx_mlp_mirror of the new weights."""
-    from encodermap_amd.layout import build_layout, init_parameters
+    (include/emx.h, emx_mlp_mirror; layout csrc/wop.h): after an update both operands must decode to the new weights to
+    22 bits (the scaled f16 pair), zero padded -- as a fresh emx_mlp_mirror does.  (The optimizer scales with the maximum
+    recorded by the previous update, a fresh build with the exact one: the two stores may differ by a power of two in
+    scale, not in the numbers they stand for.)"""
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
 
     afs = [""] + ["tanh"] * (len(n_neurons) - 1) + [""]
     lay = build_layout(n_neurons, afs, net_dim)
     params = torch.from_numpy(init_parameters(lay, 3)).cuda()
     bufs = [torch.zeros(4, l.n_out, device="cuda") for l in lay.layers]
     plan = L.MlpPlan(lay, params, bufs, bufs)
+
+    def check(mirror):
+        ws = unpack_weights(lay, params.cpu().numpy())[0::2]
+        for (fw, bw, fw_full, bw_full), W in zip(decode_operand_store(lay, mirror), ws):
+            tol = 2.0 ** -21 * np.abs(W).max()
+            np.testing.assert_allclose(fw, W, rtol=0, atol=tol)
+            np.testing.assert_allclose(bw, W, rtol=0, atol=tol)
+            K, N = W.shape
+            assert not fw_full[K:].any() and not fw_full[:, N:].any() and not bw_full[N:].any() and not bw_full[:, K:].any()
+
+    check(plan.mirror)
     g = torch.randn_like(params)
     m, v = torch.zeros_like(params), torch.zeros_like(params)
     step = torch.zeros(1, dtype=torch.int64, device="cuda")
@@ -190,14 +247,25 @@ def test_adam_keeps_operand_store_current(L, net_dim, n_neurons):
     before = plan.mirror.clone()
     for _ in range(2):
         L.adam_step(params, g, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, plan=plan)
-    fresh = L.MlpPlan(lay, params, bufs, bufs)
+        step += 1
     assert not torch.equal(before, plan.mirror)
-    assert torch.equal(fresh.mirror, plan.mirror)
+    check(plan.mirror)
+    check(L.MlpPlan(lay, params, bufs, bufs).mirror)
     # slice-partial form
     parts = torch.randn(3, params.numel(), device="cuda")
     L.adam_step_slices(params, parts, 3, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, ws, plan=plan)
-    fresh = L.MlpPlan(lay, params, bufs, bufs)
-    assert torch.equal(fresh.mirror, plan.mirror)
+    check(plan.mirror)
+    # the update itself is the one of the flat path, bit for bit (on the parameters: the flat path also walks the alignment
+    # padding between tensors, whose gradient is zero in real use)
+    real = torch.zeros(params.numel(), dtype=torch.bool)
+    for l in lay.layers:
+        real[l.w_off: l.w_off + l.n_in * l.n_out] = True
+        real[l.b_off: l.b_off + l.n_out] = True
+    real = real.cuda()
+    p2, m2, v2 = params.clone(), m.clone(), v.clone()
+    L.adam_step(params, g, m, v, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, plan=plan)
+    L.adam_step(p2, g, m2, v2, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws)
+    assert torch.equal(params[real], p2[real]) and torch.equal(m[real], m2[real]) and torch.equal(v[real], v2[real])
 
 
 @pytest.mark.gpu
