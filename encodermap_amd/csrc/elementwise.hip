@@ -359,77 +359,68 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
                      reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef) | reinterpret_cast<uintptr_t>(a.gpart) |
                      (uintptr_t)(a.gstride * 4)) & 15) == 0;
   if (a.mirror) {
-    // With a weight operand store the kernels are walked by 32 x 32 block, one wave each: the block's new weights, their
-    // scale (the block's largest |w|) and its f16 pair fragments for both directions leave in the same pass (wop.h).
-    // Lane (kr = lane >> 3, c4 = lane & 7) owns W[32 kb + kr + 8 j][32 nb + 4 c4 + i].  Biases follow as items of 64.
-    __shared__ __align__(16) _Float16 img[2048];
+    // With a weight operand store the kernels are walked by SLAB (8 rows x 32 columns, one wave each, one float4 per lane
+    // and tensor as in the flat pass): the slab's new weights and its part of the f16 pair fragments for both directions
+    // leave in the same pass (wop.h).  Lane (kr = lane >> 3, c4 = lane & 7) owns W[8 k8 + kr][32 nb + 4 c4 + i].  Biases
+    // follow as items of 64.
+    __shared__ __align__(16) _Float16 img[512];
     const int lane = threadIdx.x & 63;
     const long tcur = step_now + (a.late ? 0 : 1);   // index of this update
     const int n_blocks = a.mir.item_begin[a.mir.n_layers], n_items = a.bias_item_begin[a.mir.n_layers];
     for (int item = blockIdx.x; item < n_items; item += nblk) {
       if (item < n_blocks) {
-        int l, kb, nb;
-        wop_item(a.mir, item, l, kb, nb);
+        int l, k8, nb;
+        wop_item(a.mir, item, l, k8, nb);
         const int K = a.mir.K[l], N = a.mir.N[l];
         const long woff = a.mir.w_off[l];
         const int kr = lane >> 3, c4 = lane & 7;
-        const bool lvec = vec && (N & 3) == 0 && (woff & 3) == 0;
+        const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
         // the layer's scale: from the largest |w| the PREVIOUS update recorded (wop.h)
         WopHeader* hdr = wop_header(a.mirror, l);
         const unsigned long long prev = hdr->slot[(tcur + 1) & 1];
-        float wv[16];
-        float4 w4[4], m4[4], v4[4], l4[4], g4[4];
-        bool full[4];
+        const unsigned long long mine_so_far = hdr->slot[tcur & 1];
+        float wv[4];
+        if (vec && (N & 3) == 0 && (woff & 3) == 0 && k < K && c + 3 < N) {
+          const long i4 = (woff + (long)k * N + c) >> 2;
+          float4 w4 = reinterpret_cast<float4*>(a.w)[i4];
+          float4 m4 = reinterpret_cast<float4*>(a.m)[i4];
+          float4 v4 = reinterpret_cast<float4*>(a.v)[i4];
+          const float4 l4 = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float4 g4 = grad4(a, i4);
+          const float alpha = alpha_of(step_now);
+          adam_one(w4.x, g4.x, m4.x, v4.x, l4.x, a, alpha, reg);
+          adam_one(w4.y, g4.y, m4.y, v4.y, l4.y, a, alpha, reg);
+          adam_one(w4.z, g4.z, m4.z, v4.z, l4.z, a, alpha, reg);
+          adam_one(w4.w, g4.w, m4.w, v4.w, l4.w, a, alpha, reg);
+          reinterpret_cast<float4*>(a.w)[i4] = w4;
+          reinterpret_cast<float4*>(a.m)[i4] = m4;
+          reinterpret_cast<float4*>(a.v)[i4] = v4;
+          wv[0] = w4.x, wv[1] = w4.y, wv[2] = w4.z, wv[3] = w4.w;
+        } else {
+          const float alpha = alpha_of(step_now);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = 32 * kb + kr + 8 * j, c = 32 * nb + 4 * c4;
-          full[j] = lvec && k < K && c + 3 < N;
-          if (full[j]) {
-            const long i4 = (woff + (long)k * N + c) >> 2;
-            w4[j] = reinterpret_cast<float4*>(a.w)[i4];
-            m4[j] = reinterpret_cast<float4*>(a.m)[i4];
-            v4[j] = reinterpret_cast<float4*>(a.v)[i4];
-            l4[j] = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            g4[j] = grad4(a, i4);
-          }
-        }
-        const float alpha = alpha_of(step_now);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int k = 32 * kb + kr + 8 * j, c = 32 * nb + 4 * c4;
-          if (full[j]) {
-            adam_one(w4[j].x, g4[j].x, m4[j].x, v4[j].x, l4[j].x, a, alpha, reg);
-            adam_one(w4[j].y, g4[j].y, m4[j].y, v4[j].y, l4[j].y, a, alpha, reg);
-            adam_one(w4[j].z, g4[j].z, m4[j].z, v4[j].z, l4[j].z, a, alpha, reg);
-            adam_one(w4[j].w, g4[j].w, m4[j].w, v4[j].w, l4[j].w, a, alpha, reg);
-            const long i4 = (woff + (long)k * N + c) >> 2;
-            reinterpret_cast<float4*>(a.w)[i4] = w4[j];
-            reinterpret_cast<float4*>(a.m)[i4] = m4[j];
-            reinterpret_cast<float4*>(a.v)[i4] = v4[j];
-            wv[4 * j] = w4[j].x, wv[4 * j + 1] = w4[j].y, wv[4 * j + 2] = w4[j].z, wv[4 * j + 3] = w4[j].w;
-          } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              float wn = 0.f;
-              if (k < K && c + i < N) {
-                const long e = woff + (long)k * N + c + i;
-                float mm = a.m[e], vv = a.v[e];
-                wn = a.w[e];
-                adam_one(wn, grad1(a, e), mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha, reg);
-                a.w[e] = wn;
-                a.m[e] = mm;
-                a.v[e] = vv;
-              }
-              wv[4 * j + i] = wn;
+          for (int i = 0; i < 4; ++i) {
+            float wn = 0.f;
+            if (k < K && c + i < N) {
+              const long e = woff + (long)k * N + c + i;
+              float mm = a.m[e], vv = a.v[e];
+              wn = a.w[e];
+              adam_one(wn, grad1(a, e), mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha, reg);
+              a.w[e] = wn;
+              a.m[e] = mm;
+              a.v[e] = vv;
             }
+            wv[i] = wn;
           }
         }
         float ws_, wrs_;
         pow2_scale_bits<WOP_TOP>((unsigned)prev, ws_, wrs_);
-        const unsigned bmax = wop_write_block(a.mir, a.mirror, l, kb, nb, wv, ws_, lane, img);
+        const unsigned bmax = wop_write_slab(a.mir, a.mirror, l, k8, nb, wv, ws_, lane, img);
         if (lane == 0) {
-          atomicMax(&hdr->slot[tcur & 1], ((unsigned long long)tcur << 32) | bmax);
-          hdr->rs = wrs_;
+          // record this update's maximum for the next one; most slabs find a larger record of this update already there
+          const unsigned long long rec = ((unsigned long long)tcur << 32) | bmax;
+          if (rec > mine_so_far) atomicMax(&hdr->slot[tcur & 1], rec);
+          if (k8 == 0 && nb == 0) hdr->rs = wrs_;
         }
       } else {
         int l = 0;

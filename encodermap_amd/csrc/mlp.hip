@@ -354,7 +354,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       return;
     }
     rq = nx;
+#ifndef EMX_EXP_NOSTREAM   // (experiment: every unit re-reads the first package -- times the kernel without its weight stream)
     rq_ptr += WOP_UNIT;
+#endif
     if (changed) rq_load_gemm();
   };
 
@@ -369,28 +371,29 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     float* rscale;
     int CG;
   } X;
-  auto ex_load_gemm = [&]() __attribute__((always_inline)) {
-    const auto& G = ka->g[min(ex.gi, ex.g_end - 1)];
-    ex.P = G.P;
-    ex.C = G.C;
-    X.n = G.n;
-    X.sflags = G.sflags;
-    X.src_rs = G.src_rs;
-    X.src_pl = G.src_pl;
-    X.src_lo = G.src_lo;
-    X.src_sc = G.src_sc;
-    X.dst_pl = G.dst_pl;
-    X.dst_lo = G.dst_lo;
-    X.dst_sc = G.dst_sc;
-    X.dst_f32 = G.dst_f32;
-    X.dst_f32_pitch = G.dst_f32_pitch;
-    X.h_f32 = G.h_f32;
-    X.h_f32_pitch = G.h_f32_pitch;
-    X.out = G.out;
-    X.frag = G.aop.frag;
-    X.rscale = G.aop.rscale;
-    X.CG = G.aop.CG;
+  auto load_gx = [&](int gi, int g_end, GX& x, int& P, int& C) __attribute__((always_inline)) {
+    const auto& G = ka->g[min(gi, g_end - 1)];
+    P = G.P;
+    C = G.C;
+    x.n = G.n;
+    x.sflags = G.sflags;
+    x.src_rs = G.src_rs;
+    x.src_pl = G.src_pl;
+    x.src_lo = G.src_lo;
+    x.src_sc = G.src_sc;
+    x.dst_pl = G.dst_pl;
+    x.dst_lo = G.dst_lo;
+    x.dst_sc = G.dst_sc;
+    x.dst_f32 = G.dst_f32;
+    x.dst_f32_pitch = G.dst_f32_pitch;
+    x.h_f32 = G.h_f32;
+    x.h_f32_pitch = G.h_f32_pitch;
+    x.out = G.out;
+    x.frag = G.aop.frag;
+    x.rscale = G.aop.rscale;
+    x.CG = G.aop.CG;
   };
+  auto ex_load_gemm = [&]() __attribute__((always_inline)) { load_gx(ex.gi, ex.g_end, X, ex.P, ex.C); };
 
   // auto cost on the last forward layer's rows (float32 copy in LDS): 32 threads per row; d cost / d output goes to HBM
   // and, in place, into the copy
@@ -463,6 +466,12 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
 #endif
     TSTAMP(3 + 5 * ui);
     request(RC);
+    // the next unit of the execution stream; when it belongs to another GEMM its record is fetched now (scalar loads from
+    // the kernel arguments), a whole unit ahead of its first use
+    Stream exn = ex;
+    const bool ex_changed = stream_next(exn);
+    GX Xn = X;
+    if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
 
     if (ex.c == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
     // A fragments of the chunk's four K-steps up front (one LDS latency per unit)
@@ -634,7 +643,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     const bool layer_end = last && ex.p == ex.P - 1;
     if (layer_end) __syncthreads();
     TSTAMP(7 + 5 * ui);
-    if (stream_next(ex)) ex_load_gemm();
+    ex = exn;
+    X = Xn;
   };
 
   // GEMMs [g0, g1) through the ring, their units starting at `units`: the packages of the first NB - 1 units are requested,
@@ -718,12 +728,16 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   };
   if (MODE == CHAIN_FUSED) {
     pipeline(0, a.ng_fwd, a.units, stage_rest);
+    TSTAMP(49);
     if (a.ng_fwd < a.ng) {
       // the forward part is complete.  The first backward packages are requested, then -- while they are in flight -- the
       // cost runs and d cost / d output goes to HBM and, re-staged, into the first backward GEMM's image
       pipeline(a.ng_fwd, a.ng, a.units_bwd, [&]() __attribute__((always_inline)) {
+        TSTAMP(50);
         cost_phase();
+        TSTAMP(51);
         __syncthreads();
+        TSTAMP(52);
         const CostArgs& cst = a.cost;
         const float* yb = reinterpret_cast<const float*>(lds + a.y_f32);
         const int wout = cst.ldy;
@@ -736,7 +750,9 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
           for (int e = 0; e < 8; ++e) vv[e] = (covered && col < wout) ? yb[(8 * sc_hf + e) * a.y_pitch + min(col, wout - 1)] : 0.f;
           stage_finish(vv, grp, a.top_Qp * 1024, a.top_pl, a.top_sc, a.top_aop, grp < a.top_Q);
         }
+        TSTAMP(53);
         __syncthreads();
+        TSTAMP(54);
       });
     } else {
       cost_phase();
@@ -776,15 +792,19 @@ __global__ __launch_bounds__(256) void mlp_mirror_max_kernel(const WopArgs wa, c
   }
 }
 __global__ __launch_bounds__(64) void mlp_mirror_kernel(const WopArgs wa, const float* __restrict__ params, char* __restrict__ store) {
-  __shared__ __align__(16) _Float16 img[2048];
+  __shared__ __align__(16) _Float16 img[512];
   const int lane = threadIdx.x;
-  int l, kb, nb;
-  wop_item(wa, blockIdx.x, l, kb, nb);
-  float wv[16];
-  wop_load_block(wa, params, l, kb, nb, lane, wv);
+  int l, k8, nb;
+  wop_item(wa, blockIdx.x, l, k8, nb);
+  const int K = wa.K[l], N = wa.N[l];
+  const int k = 8 * k8 + (lane >> 3), c = 32 * nb + 4 * (lane & 7);
+  const float* W = params + wa.w_off[l];
+  float wv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wv[i] = (k < K && c + i < N) ? W[(long)k * N + c + i] : 0.f;
   float s, rs;
   pow2_scale_bits<WOP_TOP>((unsigned)wop_header(store, l)->slot[0], s, rs);
-  wop_write_block(wa, store, l, kb, nb, wv, s, lane, img);
+  wop_write_slab(wa, store, l, k8, nb, wv, s, lane, img);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1054,7 +1074,7 @@ int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStr
   const int grid = (row_end - row_begin + R - 1) / R;
   // more than one row block per CU: the two-deep ring (<= 256 registers, two workgroups per CU); else the three-deep one
   static const int force_nb = getenv("EMX_CHAIN_NB") ? atoi(getenv("EMX_CHAIN_NB")) : 0;
-  const bool deep = force_nb ? force_nb >= 3 : grid <= 256;
+  const bool deep = force_nb >= 3;   // (measured at C2: the deeper ring buys nothing -- the kernels are bound by instruction issue -- and costs registers)
   int rc;
   if (deep) {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 3>), lds, b.who);

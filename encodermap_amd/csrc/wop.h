@@ -50,7 +50,7 @@ struct WopArgs {
   long fwd_unit[EMX_MAX_LAYERS + 1];   // index of the layer's first forward unit (units of WOP_UNIT behind units_begin)
   long bwd_unit[EMX_MAX_LAYERS + 1];   // index of the layer's first backward unit; [n_layers]: total number of units
   long units_begin;                    // byte offset of unit 0
-  int item_begin[EMX_MAX_LAYERS + 1];  // prefix sum of 32 x 32 blocks (work items of the kernels that write the store)
+  int item_begin[EMX_MAX_LAYERS + 1];  // prefix sum of 8 x 32 slabs (work items of the kernels that write the store)
 };
 
 struct WopHeader {                 // 64 bytes per layer at the head of the store
@@ -76,7 +76,7 @@ inline void fill_wop_args(const emx_mlp_desc* desc, WopArgs& wa) {
     wa.fwd_unit[l] = u;
     wa.item_begin[l] = items;
     u += (long)groups128(wa.K[l]) * groups128(wa.N[l]);
-    items += groups32(wa.K[l]) * groups32(wa.N[l]);
+    items += ((wa.K[l] + 7) >> 3) * groups32(wa.N[l]);
   }
   wa.fwd_unit[n] = u;
   wa.item_begin[n] = items;
@@ -122,81 +122,63 @@ __device__ __forceinline__ half4 lds_read_tr16(const _Float16* p) {
   return (half4)__builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4_builtin*)(p));
 }
 
-// One wave writes the pieces of block (kb, nb) of layer l -- two tiles in each direction -- from the block's weights:
-// lane (kr = lane >> 3, c4 = lane & 7) passes wv[4 j + i] = W[32 kb + kr + 8 j][32 nb + 4 c4 + i] (zero outside the layer).
-// s: the layer's scale.  img: 4 KB of LDS private to the wave (two [32 k][32 n] f16 planes); every lane of the wave must
-// call (the transposed LDS read needs EXEC all ones).  Returns the largest |w| of the block (bit pattern, wave-uniform).
-__device__ __forceinline__ unsigned wop_write_block(const WopArgs& wa, char* __restrict__ store, int l, int kb, int nb, const float (&wv)[16],
-                                                    float s, int lane, _Float16* img) {
-  unsigned mx = 0;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) mx = max(mx, abs_bits(wv[i]));
+// One wave writes its part of the pieces of layer l from a SLAB of 8 x 32 weights -- rows k = 8 k8 .. 8 k8 + 7 of the
+// kernel, columns 32 nb .. 32 nb + 31: lane (kr = lane >> 3, c4 = lane & 7) passes w[i] = W[8 k8 + kr][32 nb + 4 c4 + i]
+// (zero outside the layer).  s: the layer's scale.  A slab is a quarter of the 32 x 32 block behind two forward and two
+// backward pieces per plane: every lane ends up with 8 of the 16 bytes of one fragment lane, in each direction, and the
+// stores of the four slabs of a block complete each other's cache lines (one float4 per lane and tensor, as in the flat
+// optimizer pass: the optimizer is a latency-bound stream, a whole block per wave made its critical path four times longer).
+// img: 1 KB of LDS private to the wave (two [8 k][32 n] f16 planes); every lane must call (transposed LDS read: EXEC all
+// ones).  Returns the largest |w| of the slab (bit pattern, wave-uniform).
+__device__ __forceinline__ unsigned wop_write_slab(const WopArgs& wa, char* __restrict__ store, int l, int k8, int nb, const float (&w)[4], float s,
+                                                   int lane, _Float16* img) {
+  unsigned mx = max(max(abs_bits(w[0]), abs_bits(w[1])), max(abs_bits(w[2]), abs_bits(w[3])));
   mx = wave_max_u32(mx);
   const int kr = lane >> 3, c4 = lane & 7;
+  half4 h, lo;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    half4 h, lo;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float t = wv[4 * j + i] * s;   // exact
-      h[i] = (_Float16)t;
-      lo[i] = (_Float16)(t - (float)h[i]);
-    }
-    *reinterpret_cast<half4*>(img + (kr + 8 * j) * 32 + 4 * c4) = h;
-    *reinterpret_cast<half4*>(img + 1024 + (kr + 8 * j) * 32 + 4 * c4) = lo;
+  for (int i = 0; i < 4; ++i) {
+    const float t = w[i] * s;   // exact
+    h[i] = (_Float16)t;
+    lo[i] = (_Float16)(t - (float)h[i]);
   }
+  *reinterpret_cast<half4*>(img + kr * 32 + 4 * c4) = h;
+  *reinterpret_cast<half4*>(img + 256 + kr * 32 + 4 * c4) = lo;
   __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed (no other wave touches img)
   __builtin_amdgcn_wave_barrier();
-  const int n = lane & 15, g = lane >> 4;
+  const int kb = k8 >> 2, j = k8 & 3;   // the slab is rows 8 j .. 8 j + 7 of block row kb
 #pragma unroll
   for (int plane = 0; plane < 2; ++plane) {
-    const _Float16* pl = img + 1024 * plane;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      // forward piece: B[k = in][col = out]: transposed reads of the [k][n] image -- lane 4 q + p of a 16-lane group addresses
-      // row k0 + q, columns 16 t + 4 p ..; lane i of the group receives column 16 t + i of the four rows
-      const int q = (lane & 15) >> 2, p = lane & 3;
-      const half4 f0 = lds_read_tr16(pl + (4 * g + q) * 32 + 16 * t + 4 * p);
-      const half4 f1 = lds_read_tr16(pl + (16 + 4 * g + q) * 32 + 16 * t + 4 * p);
-      half8 fw = {f0[0], f0[1], f0[2], f0[3], f1[0], f1[1], f1[2], f1[3]};
-      *reinterpret_cast<half8*>(store + wop_fwd_piece(wa, l, kb, nb, t, plane) + lane * 16) = fw;
-      // backward piece: B[k = out][col = in]: row 16 t + n of the image, columns kk(g, e)
-      const half4 b0 = *reinterpret_cast<const half4*>(pl + (16 * t + n) * 32 + 4 * g);
-      const half4 b1 = *reinterpret_cast<const half4*>(pl + (16 * t + n) * 32 + 16 + 4 * g);
-      half8 bw = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-      *reinterpret_cast<half8*>(store + wop_bwd_piece(wa, l, kb, nb, t, plane) + lane * 16) = bw;
+    const _Float16* pl = img + 256 * plane;
+    {
+      // forward pieces B[k = in][col = out]: one transposed read serves both tiles -- the 16-lane group G = lane >> 4 takes
+      // the 4 x 16 block (k block G & 1, tile G >> 1); lane 4 q + p of the group addresses row 4 (G & 1) + q, columns
+      // 16 (G >> 1) + 4 p ..; lane i receives column 16 t + i of the four rows = 4 consecutive k of one fragment lane
+      const int G = lane >> 4, q = (lane & 15) >> 2, p = lane & 3, i = lane & 15;
+      const half4 f = lds_read_tr16(pl + (4 * (G & 1) + q) * 32 + 16 * (G >> 1) + 4 * p);
+      const int r = 8 * j + 4 * (G & 1);             // first of the four k (0 .. 31) inside the K-step
+      const int fg = (r & 15) >> 2, second = r >> 4;  // fragment lane group, element half (kk(g, e) of the piece)
+      *reinterpret_cast<half4*>(store + wop_fwd_piece(wa, l, kb, nb, G >> 1, plane) + (16 * fg + i) * 16 + 8 * second) = f;
+    }
+    {
+      // backward pieces B[k = out][col = in]: row kr of the slab is in-feature 8 j + kr of block row kb: tile t = j >> 1,
+      // fragment column n = 8 (j & 1) + kr; lane (kr, g, half) takes out = 4 g + e / 16 + 4 g + e from the slab's row
+      const int g = (lane >> 1) & 3, second = lane & 1;
+      const half4 b = *reinterpret_cast<const half4*>(pl + kr * 32 + 16 * second + 4 * g);
+      *reinterpret_cast<half4*>(store + wop_bwd_piece(wa, l, kb, nb, j >> 1, plane) + (16 * g + 8 * (j & 1) + kr) * 16 + 8 * second) = b;
     }
   }
-  __builtin_amdgcn_wave_barrier();   // img may be rewritten by the caller's next block only behind these reads
+  __builtin_amdgcn_wave_barrier();   // img may be rewritten by the caller's next slab only behind these reads
   return mx;
 }
 
-// loads the block's weights from the flat parameter buffer in wop_write_block's lane order (zero outside the layer)
-__device__ __forceinline__ void wop_load_block(const WopArgs& wa, const float* __restrict__ params, int l, int kb, int nb, int lane,
-                                               float (&wv)[16]) {
-  const int K = wa.K[l], N = wa.N[l];
-  const int kr = lane >> 3, c4 = lane & 7;
-  const float* W = params + wa.w_off[l];
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = 32 * kb + kr + 8 * j, c = 32 * nb + 4 * c4;
-    if ((N & 3) == 0 && (wa.w_off[l] & 3) == 0 && k < K && c + 3 < N) {
-      const float4 v = *reinterpret_cast<const float4*>(W + (long)k * N + c);
-      wv[4 * j] = v.x, wv[4 * j + 1] = v.y, wv[4 * j + 2] = v.z, wv[4 * j + 3] = v.w;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) wv[4 * j + i] = (k < K && c + i < N) ? W[(long)k * N + c + i] : 0.f;
-    }
-  }
-}
-
-// work item -> (layer, kb, nb)
-__device__ __forceinline__ void wop_item(const WopArgs& wa, int item, int& l, int& kb, int& nb) {
+// work item -> (layer, k8, nb): slabs of 8 rows x 32 columns
+__device__ __forceinline__ void wop_item(const WopArgs& wa, int item, int& l, int& k8, int& nb) {
   l = 0;
   while (l + 1 < wa.n_layers && item >= wa.item_begin[l + 1]) ++l;
   const int rel = item - wa.item_begin[l], NB = groups32(wa.N[l]);
-  kb = rel / NB;
-  nb = rel - kb * NB;
+  k8 = rel / NB;
+  nb = rel - k8 * NB;
 }
 
 __device__ __forceinline__ WopHeader* wop_header(char* store, int l) { return reinterpret_cast<WopHeader*>(store) + l; }

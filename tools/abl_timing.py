@@ -33,6 +33,8 @@ for blk in ((0, 1) if B >= 16 * 101 else (0,)):   # (the kernel records workgrou
     for w in (0, 7):
         c = clk[w] - clk[w, 0]
         print(f"block {blk*100} wave {w}:  stage loads issued {c[1]}  staged + barrier {c[2]}  loop end {c[60]}  end {c[61]}")
+        if mode == "fused":
+            print(f"   fused: forward units done {c[49]}  packages requested, cost starts {c[50]}  cost done {c[51]}  barrier {c[52]}  re-staged {c[53]}  barrier {c[54]}")
         for l in range(n):
             s3, s4, s5, s6, s7 = (c[3 + 5 * l + i] for i in range(5))
             prev = c[2] if l == 0 else c[7 + 5 * (l - 1)]
