@@ -46,6 +46,8 @@ constexpr int KC = 32;       // feature chunk staged per iteration
 constexpr int LS = KC + 4;   // padded LDS row stride (floats)
 
 struct SigDev {
+  float k6;         // fast high-d form (a = 12, b = 6): inv_sig2 * c^(1/6), so that c v^6 = (k6 d^2)^6
+  float c_inv;      // fast low-d form (a = 2): c / sig^2
   float inv_sig2;   // 1/sig^2
   float c;          // 2^(a/b) - 1
   float half_a;     // a/2
@@ -88,10 +90,12 @@ __device__ __forceinline__ float powi(float v) {
 // complement of the sketch-map sigmoid, E(v) = (1 + c v^(a/2))^(-b/a), v = (d/sig)^2   (distances.py:86)
 template <bool FAST>
 __device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
-  if constexpr (FAST) {  // a = 12, b = 6; an overflowing v^6 gives q = inf, rsq = 0: the correct limit, no clamp needed
-    const float v = d2 * s.inv_sig2;
-    float q = fmaf(s.c, powi<6>(v), 1.f);
-    return __builtin_amdgcn_rsqf(q);
+  if constexpr (FAST) {  // a = 12, b = 6: E = (1 + w^6)^(-1/2), w = d^2 c^(1/6) / sig^2 -- four instructions in front of the rsq; an
+                         // overflowing w^6 gives q = inf, rsq = 0: the correct limit; a d^2 that rounding made slightly negative
+                         // enters through an even power, so the caller needs no clamp at 0
+    const float w = d2 * s.k6;
+    const float w3 = w * w * w;
+    return __builtin_amdgcn_rsqf(fmaf(w3, w3, 1.f));
   } else {
     float v = fminf(d2 * s.inv_sig2, s.vmax);
     float t = __builtin_amdgcn_exp2f(s.half_a * __builtin_amdgcn_logf(v));
@@ -104,8 +108,7 @@ __device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
 template <bool FAST>
 __device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, float& G) {
   if constexpr (FAST) {  // a = 2, b = 6
-    const float v = d2 * s.inv_sig2;
-    float q = fmaf(s.c, v, 1.f);
+    float q = fmaf(s.c_inv, d2, 1.f);
     float r = __builtin_amdgcn_rcpf(q);
     E = r * r * r;
     G = E * r;
@@ -769,7 +772,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       dl2 = fmaf(dz[l], dz[l], dl2);
     }
     const float2 nri = nr_b[ro];
-    float d2 = fmaxf(fmaf(acc[r] * nri.y, cj, nri.x + nj), 0.f);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
+    float d2 = fmaf(acc[r] * nri.y, cj, nri.x + nj);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
+    if (!FASTSIG) d2 = fmaxf(d2, 0.f);                 // (the fast form takes an even power of d^2: no clamp at 0 needed)
     if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
     const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
     float El, G;
@@ -888,6 +892,8 @@ SigDev make_sig(float sig, float aa, float bb) {
   SigDev s;
   s.inv_sig2 = 1.f / (sig * sig);
   s.c = (float)(std::pow(2.0, (double)aa / bb) - 1.0);
+  s.k6 = (float)(std::pow(std::pow(2.0, (double)aa / bb) - 1.0, 1.0 / 6.0) / ((double)sig * sig));
+  s.c_inv = (float)((std::pow(2.0, (double)aa / bb) - 1.0) / ((double)sig * sig));
   s.half_a = 0.5f * aa;
   s.nba = -bb / aa;
   s.half_am2 = 0.5f * (aa - 2.f);

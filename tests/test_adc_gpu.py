@@ -176,3 +176,33 @@ def test_adc_tracked_metrics(em, tmp_path):
     h = em.AngleDihedralCartesianEncoderMap(data, p2, read_only=True).train()
     assert len(h.history["ADCClashMetric"]) == 5 and len(h.history["ADCRMSDMetric"]) == 5
     assert np.isfinite(h.history["ADCRMSDMetric"]).all() and min(h.history["ADCRMSDMetric"]) > 0
+
+
+def test_adc_free_running_drift_envelope(em):
+    """The 228-atom chain (BASELINE.json configs[2]'s shape) free-running, with the float32 drift of the reference formulation
+    itself as the yardstick (tests/test_training_gpu.py::test_long_horizon_drift_envelope): the oracle loop in float64 and
+    in float32 on identical weights and batches; at every step, for the total loss and every term,
+        |engine - f64| <= K |oracle_f32 - f64| + 2e-4 |f64|,   K = 4
+    (test_adc_loss_trajectory checks the same steps one by one with teacher forcing)."""
+    from tests.test_training_gpu import drift_ratio
+
+    name, kw, n_res, n_side, B = CASES[3]
+    rng = np.random.default_rng(n_res)
+    data = R.synthetic_backbone(rng, 700, n_res, n_side)
+    n_steps = 10
+    p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
+    A = 3 * n_res
+    net_dim = 2 * (A - 3)
+    w0 = weights_for(em, p, net_dim)
+    idx = rng.integers(0, 700, (n_steps, B))
+    e = em.AngleDihedralCartesianEncoderMap(data, p, model=[w.copy() for w in w0], read_only=True)
+    e._engine.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    got, got_terms = e._engine.losses(), e._engine.loss_terms()
+    runs = {dt: R.adc_train_steps(R.ADCOracle(A, n_side, p.to_dict(), w0, dtype=dt), data, idx) for dt in (torch.float64, torch.float32)}
+    (f64, t64), (f32, t32) = runs[torch.float64], runs[torch.float32]
+    ratios = {"loss": drift_ratio(got, f64, f32, rel=2e-4)}
+    for k in t64[0]:
+        ratios[k] = drift_ratio(got_terms[k], [t[k] for t in t64], [t[k] for t in t32], rel=2e-4)
+    print("adc drift ratios", {k: round(v, 2) for k, v in ratios.items()},
+          "final rel. deviation engine %.2e oracle-f32 %.2e" % (abs(got[-1] - f64[-1]) / abs(f64[-1]), abs(f32[-1] - f64[-1]) / abs(f64[-1])))
+    assert max(ratios.values()) <= 4.0, ratios

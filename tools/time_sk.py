@@ -3,6 +3,7 @@ import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from encodermap_amd import _lib
+if os.environ.get("EMX_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["EMX_LIB"])
 _lib.load()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 128
