@@ -67,6 +67,7 @@ SIGNATURES = {
     "emx_adam_step_history": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
+    "emx_permute": (_i, [_p, _l, C.c_uint64, C.c_uint64, _p]),
     "emx_finish_step": (_i, [_p, _i, _p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_step_tick": (_i, [_p, _i, _p, _p, _l, _p, _p, _p, _p]),
     "emx_colmean": (_i, [_p, _i, _i, _i, _p, _p]),
@@ -333,6 +334,12 @@ def sketchmap_finish(B, D, Z, sig, scale, center_scale, row_begin, row_end, dist
 def pairwise_dist(X, periodicity, out):
     B, D = X.shape
     _check(load().emx_pairwise_dist(_ptr(_f32c(X, "X")), B, D, X.stride(0), float(periodicity), _ptr(out), _stream()), "emx_pairwise_dist")
+
+
+def permute(out, seed: int, epoch: int):
+    """out (int64 device tensor of n elements) <- a pseudo-random permutation of 0 .. n-1 chosen by (seed, epoch)."""
+    assert out.dtype == torch.int64 and out.is_contiguous()
+    _check(load().emx_permute(_ptr(out), out.numel(), int(seed) & (2 ** 64 - 1), int(epoch) & (2 ** 64 - 1), _stream()), "emx_permute")
 
 
 def gather_rows(data, idx, periodicity, xb, xin, cursor=None, B=None, split_ws=None):

@@ -300,7 +300,8 @@ class ADCEngine(SequentialEngine):
 
     # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
     @torch.no_grad()
-    def reference_costs(self, n_batches: int, mean_ang: np.ndarray, mean_dih: np.ndarray, mean_len: np.ndarray) -> dict:
+    def reference_costs(self, n_batches: int, mean_ang: np.ndarray, mean_dih: np.ndarray, mean_len: np.ndarray,
+                        index_block: Optional[torch.Tensor] = None) -> dict:
         """Costs of the trivial model that always answers with the data-set means, per batch: dihedral cost, angle cost
         and cartesian cost (pair distances of the mean structure vs the batch), all mean_abs with scale 1 / reference 1
         and periodicity 2 pi as a fresh ``ADCParameters()`` defines them."""
@@ -313,7 +314,9 @@ class ADCEngine(SequentialEngine):
         _lib.chain_in_plane_fwd(m_len, m_ang, plane)
         _lib.dihedrals_to_cartesian_fwd(m_dih, math.pi, plane, xyz)
         _lib.pdist_flat_fwd(xyz, self.pw_start, self.pw_step, self.C, pd_mean)
-        block = self.draw_index_block(n_batches)
+        block = index_block if index_block is not None else self.draw_index_block(n_batches)   # (index_block: injected batches, [n_batches * B])
+        if block.numel() != n_batches * B:
+            raise ValueError(f"index block has {block.numel()} entries, expected {n_batches} x {B}")
         out = torch.zeros(n_batches, 3, dtype=torch.float32, device=dev)
         two_pi = 2 * math.pi
         for i in range(n_batches):

@@ -36,6 +36,38 @@ __device__ long long emx_dbg_fin[64];
 #include "finish.h"   // (after FSTAMP)
 namespace {
 
+// K13: the shuffle of the data feed as a keyed bijection (include/emx.h, emx_permute; host twin: layout.feistel_permutation)
+struct PermArgs {
+  int64_t* out;
+  long n;
+  int abits, bbits;        // bits of the left / right half-word
+  unsigned key[6];
+};
+__host__ __device__ inline unsigned mix32(unsigned h) {   // murmur3 finaliser
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+__global__ __launch_bounds__(NT) void permute_kernel(const PermArgs a) {
+  const long i = (long)blockIdx.x * NT + threadIdx.x;
+  if (i >= a.n) return;
+  const unsigned long long amask = (1ull << a.abits) - 1, bmask = (1ull << a.bbits) - 1;
+  unsigned long long x = (unsigned long long)i;
+  do {   // cycle walking: the network permutes [0, 2^(abits + bbits)), which is < 2 n values
+    unsigned long long l = x >> a.bbits, r = x & bmask;   // l: abits wide, r: bbits wide
+#pragma unroll
+    for (int k = 0; k < 6; k += 2) {
+      l = (l ^ mix32((unsigned)r ^ a.key[k])) & amask;
+      r = (r ^ mix32((unsigned)l ^ a.key[k + 1])) & bmask;
+    }
+    x = (l << a.bbits) | r;
+  } while (x >= (unsigned long long)a.n);
+  a.out[i] = (int64_t)x;
+}
+
 struct GatherArgs {
   const float* data;
   int D;
@@ -538,6 +570,24 @@ extern "C" {
 int emx_version(void) { return EMX_VERSION; }
 const char* emx_last_error(void) { return g_err; }
 const char* emx_target_arch(void) { return "gfx950"; }
+
+int emx_permute(int64_t* out, int64_t n, uint64_t seed, uint64_t epoch, emx_stream_t stream) {
+  EMX_REQUIRE(out && n > 0, "emx_permute: bad arguments");
+  EMX_REQUIRE(n <= (1ll << 62), "emx_permute: n too large");
+  PermArgs a{};
+  a.out = out;
+  a.n = (long)n;
+  int bits = 2;
+  while ((1ull << bits) < (unsigned long long)n) ++bits;
+  a.abits = bits / 2;
+  a.bbits = bits - a.abits;
+  EMX_REQUIRE(a.bbits <= 32, "emx_permute: n too large");
+  for (int k = 0; k < 6; ++k)
+    a.key[k] = mix32((unsigned)(seed & 0xffffffffu) ^ mix32((unsigned)(seed >> 32) + 0x9e3779b9u * (unsigned)(k + 1)) ^
+                     mix32((unsigned)(epoch & 0xffffffffu) + 0x7f4a7c15u * (unsigned)(k + 1)) ^ mix32((unsigned)(epoch >> 32) ^ 0x165667b1u));
+  hipLaunchKernelGGL(permute_kernel, dim3((unsigned)((n + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("permute_kernel");
+}
 
 int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B, float periodicity,
                     float* xb, float* xin, void* split_ws, emx_stream_t stream) {

@@ -232,7 +232,7 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   float* Xi_s = smem;
   float* Xj_s = smem + TM * LS;
 
-  const int L = LT ? LT : a.L;
+  const int L = LT == 2 ? 2 : a.L;   // LT: 2 = exactly two latent columns (compile time); 0 / 8 = up to 4 / 8 columns at run time, zero padded
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
 
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
   float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
   float* red = cpart + T * LMAX * 2;
 
-  const int L = LT ? LT : a.L;
+  const int L = LT == 2 ? 2 : a.L;   // LT: 2 = exactly two latent columns (compile time); 0 / 8 = up to 4 / 8 columns at run time, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
@@ -630,7 +630,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
   float* red = cpart + T * LMAX * 2;
 
-  const int L = LT ? LT : a.L;
+  const int L = LT == 2 ? 2 : a.L;   // LT: 2 = exactly two latent columns (compile time); 0 / 8 = up to 4 / 8 columns at run time, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
@@ -924,12 +924,14 @@ constexpr int SMALL_TILE_MAX_B = 512;   // batches up to this size run the VALU 
 size_t ws_front_floats(int B, int L) {
   const size_t nb = (size_t)(B + 63) / 64;
   const size_t f64 = nb * nb * 64 * (size_t)L + nb * nb + 64;
-  if (B > SMALL_TILE_MAX_B) return f64;
+  if (B > SMALL_TILE_MAX_B && L <= 4) return f64;   // (latent widths 5..8 may run the 32 x 32 tiles at any batch size: pick_tile)
   const size_t n32 = (size_t)(B + 31) / 32;
   return std::max(f64, n32 * n32 * 32 * (size_t)L + n32 * n32 + 64);
 }
 
-int pick_tile(int B, int nrows, bool gram, bool periodic) {
+int pick_tile(int B, int nrows, bool gram, bool periodic, int L) {
+  if (L > 4) return 32;   // latent widths 5..8 run the 32 x 32 VALU tiles (their partial-sum area fits the static LDS limit at that size
+                          // only); like the rule below a function of what every entry point that plans the workspace layout knows
   if (periodic && B <= SMALL_TILE_MAX_B) return 32;   // (a function of B and the periodicity only: every entry point that plans
                                                       //  the workspace layout knows both)
   // 64x64 for every large batch.  The MFMA (Gram) tiles exist in that size only, and the VALU kernel's 128x128 instantiation
@@ -986,7 +988,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
               float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who, void* split_ws = nullptr) {
   EMX_REQUIRE(X && Z && ws && sig, "%s: null pointer argument", who);
   EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "%s: bad shape B=%d D=%d ldx=%d", who, B, D, ldx);
-  if (L < 1 || L > 4) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..4)", who, L);
+  if (L < 1 || L > 8) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..8)", who, L);
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "%s: bad row block [%d,%d) of %d", who, row_begin,
               row_end, B);
   EMX_REQUIRE(periodicity > 0.f, "%s: periodicity must be > 0 (INFINITY for none)", who);
@@ -1002,7 +1004,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   }
   const bool vec4ok = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const bool split_ok = split_ws != nullptr && pl.gram && !pl.periodic;
-  const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok, pl.periodic);
+  const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok, pl.periodic, L);
   pl.T = T;
   pl.fast = sig[1] == 12.f && sig[2] == 6.f && sig[4] == 2.f && sig[5] == 6.f;
   SkArgs& a = pl.a;
@@ -1101,7 +1103,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), dim3(grid), dim3(NT), 0, st, b);
     return emx::check_launch("sk_tile_f16_kernel");
   }
-  if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram) {
+  if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram && a.L <= 4) {
     if (a.L == 2) {
       if (pl.fast) hipLaunchKernelGGL((sk_tile_mfma_kernel<2, true>), dim3(pl.ntiles), dim3(NT), 0, st, a);
       else hipLaunchKernelGGL((sk_tile_mfma_kernel<2, false>), dim3(pl.ntiles), dim3(NT), 0, st, a);
@@ -1113,6 +1115,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   }
   if (pl.T == 32) {
     if (a.L == 2) dispatch2<32, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    else if (a.L > 4) dispatch2<32, 8>(a, pl.ntiles, pl.periodic, pl.fast, st);
     else dispatch2<32, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
   } else if (pl.T != 64) {
     return emx::fail(EMX_EUNSUPPORTED, "emx_sketchmap_tiles: no %d x %d tile kernel", pl.T, pl.T);

@@ -191,24 +191,25 @@ class SequentialEngine:
 
     def _init_batch_stream(self) -> None:
         seed = self.dp.batch_seed(self.p.seed)
-        self._gen = torch.Generator(device=self.device)
         if seed is None:
-            self._gen.seed()
-        else:
-            self._gen.manual_seed(int(seed))
+            seed = int(np.random.SeedSequence().entropy & (2 ** 63 - 1))
+        self._shuffle_seed, self._shuffle_epoch = int(seed), 0
         self._left = torch.empty(0, dtype=torch.int64, device=self.device)
 
     def draw_index_block(self, n_batches: int) -> torch.Tensor:
-        """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes."""
+        """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes.  Every pass is one
+        emx_permute (a keyed bijection evaluated per element: no sort, no host work); torch only owns the buffers."""
         need = n_batches * self.B
-        parts, have = [self._left], self._left.numel()
         N = self.data.shape[0]
-        while have < need:
-            parts.append(torch.randperm(N, generator=self._gen, device=self.device))
-            have += N
-        allidx = torch.cat(parts)
-        self._left = allidx[need:].clone()
-        return allidx[:need].contiguous()
+        have = self._left.numel()
+        n_perm = max(0, -(-(need - have) // N))
+        buf = torch.empty(have + n_perm * N, dtype=torch.int64, device=self.device)
+        buf[:have].copy_(self._left)
+        for k in range(n_perm):
+            _lib.permute(buf[have + k * N: have + (k + 1) * N], self._shuffle_seed, self._shuffle_epoch)
+            self._shuffle_epoch += 1
+        self._left = buf[need:].clone()
+        return buf[:need]
 
     # -- forward / backward ------------------------------------------------------------------------
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)

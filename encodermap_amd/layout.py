@@ -142,15 +142,57 @@ def weights_from_initializer_dict(layout: NetLayout, d: dict) -> np.ndarray:
     return pack_weights(layout, arrays)
 
 
+def _mix32(h):
+    """murmur3 finaliser on uint32 arrays (the round function of feistel_permutation)."""
+    h = np.asarray(h, np.uint32).copy()
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h *= np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def feistel_permutation(n: int, seed: int, epoch: int) -> np.ndarray:
+    """Host statement of ``emx_permute`` (include/emx.h), bit for bit: a pseudo-random permutation of 0 .. n-1 chosen by
+    (seed, epoch) -- a 6-round Feistel network on the ceil(log2 n) bits of the index, cycle-walked until the value falls
+    below n."""
+    n = int(n)
+    seed, epoch = int(seed) & (2 ** 64 - 1), int(epoch) & (2 ** 64 - 1)
+    bits = 2
+    while (1 << bits) < n:
+        bits += 1
+    abits = bits // 2
+    bbits = bits - abits
+    amask, bmask = np.uint64((1 << abits) - 1), np.uint64((1 << bbits) - 1)
+    with np.errstate(over="ignore"):
+        u32 = lambda v: np.uint32(v & 0xFFFFFFFF)
+        keys = [_mix32(u32(seed) ^ _mix32(u32((seed >> 32) + 0x9E3779B9 * (k + 1))) ^ _mix32(u32((epoch & 0xFFFFFFFF) + 0x7F4A7C15 * (k + 1))) ^
+                       _mix32(u32((epoch >> 32) ^ 0x165667B1))) for k in range(6)]
+        x = np.arange(n, dtype=np.uint64)
+        todo = np.ones(n, bool)
+        while todo.any():
+            v = x[todo]
+            l, r = v >> np.uint64(bbits), v & bmask
+            for k in range(0, 6, 2):
+                l = (l ^ _mix32((r & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ keys[k]).astype(np.uint64)) & amask
+                r = (r ^ _mix32((l & np.uint64(0xFFFFFFFF)).astype(np.uint32) ^ keys[k + 1]).astype(np.uint64)) & bmask
+            v = (l << np.uint64(bbits)) | r
+            x[todo] = v
+            todo[todo] = v >= np.uint64(n)
+    return x.astype(np.int64)
+
+
 class BatchIndexStream:
     """Row indices for ``Dataset.shuffle(N, reshuffle_each_iteration=True).repeat().batch(B)``
-    (encodermap/autoencoder/autoencoder.py:845-856): a fresh uniform permutation per pass, batches always
-    full and allowed to straddle passes.  Host-side statement used for planning/tests; the engine draws the
-    same stream on the device with ``torch.randperm``."""
+    (encodermap/autoencoder/autoencoder.py:845-856): a fresh permutation per pass, batches always full and allowed to
+    straddle passes.  Host-side statement of the stream the engine draws on the device (``emx_permute`` with the same seed,
+    one epoch per pass): the two are identical index for index."""
 
     def __init__(self, n_rows: int, batch_size: int, seed: Optional[int] = None):
         self.n, self.b = int(n_rows), int(batch_size)
-        self.rng = np.random.default_rng(seed)
+        self.seed = int(np.random.SeedSequence().entropy & (2 ** 63 - 1)) if seed is None else int(seed)
+        self.epoch = 0
         self._left = np.empty(0, np.int64)
 
     def next_block(self, n_batches: int) -> np.ndarray:
@@ -158,7 +200,8 @@ class BatchIndexStream:
         parts = [self._left]
         have = self._left.size
         while have < need:
-            p = self.rng.permutation(self.n).astype(np.int64)
+            p = feistel_permutation(self.n, self.seed, self.epoch)
+            self.epoch += 1
             parts.append(p)
             have += p.size
         allidx = np.concatenate(parts)

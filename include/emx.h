@@ -128,6 +128,14 @@ int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, 
  *   work (emx_step_tick advances it); xb [B, D] gathered rows (may be NULL);
  *   xin [B, 2D] = [sin(x*2pi/p) | cos(x*2pi/p)] (may be NULL; periodicity ignored then).
  * ------------------------------------------------------------------------------------------------ */
+/* The shuffle of the data feed: out[i] = pi(i), i < n, a pseudo-random permutation of 0 .. n-1 chosen by (seed, epoch) --
+ * one pass of Dataset.shuffle(N, reshuffle_each_iteration=True) (autoencoder.py:845-856; the reference's own order comes
+ * from TensorFlow's generator and is not reproducible elsewhere).  pi is a keyed bijection, evaluated independently per
+ * element: a 6-round Feistel network on the ceil(log2 n) bits of the index (round function: the 32-bit murmur3 finaliser
+ * of the half-word xor a round key), cycle-walked until the value falls below n -- no sort, no atomics, no global
+ * synchronisation, and bit-identical to its host statement encodermap_amd.layout.feistel_permutation. */
+int emx_permute(int64_t* out, int64_t n, uint64_t seed, uint64_t epoch, emx_stream_t stream);
+
 int emx_gather_rows(const float* data, int64_t N, int D, const int64_t* idx, const int64_t* cursor, int B,
                     float periodicity, float* xb, float* xin, void* split_ws /* may be NULL: emx_sketchmap_split of the gathered rows */,
                     emx_stream_t stream);

@@ -514,6 +514,34 @@ def adc_train_steps(model: ADCOracle, data: dict, batch_indices, start_step: int
     return losses, terms_all
 
 
+def train_for_references(data: dict, batch_indices, pwd_start=None, pwd_stop=None, pwd_step=None, dtype=torch.float64) -> dict:
+    """AngleDihedralCartesianEncoderMap.train_for_references (autoencoder/autoencoder.py:1816-1937): the costs of the trivial
+    model that answers every batch with the data-set means, per batch, with the cost closures of a FRESH ADCParameters
+    (scales 1, references 1, mean_abs, periodicity 2 pi; :1822-1826):
+      dihedral / angle cost   the batch against the column means of the whole data set, repeated to batch size (:1849-1861),
+      cartesian cost          pair distances of the mean structure -- chain_in_plane(mean bond lengths, mean angles) turned by
+                              the mean dihedrals + pi (:1863-1877), sliced by cartesian_pwd_{start,stop,step} -- against the
+                              pair distances of the batch's Cartesians (:1912-1921), plain differences.
+    ``batch_indices``: the rows of each batch (the reference iterates its shuffled tf.data set).  Returns the per-batch
+    lists; their means are the new ``*_cost_reference`` (:1927-1934)."""
+    t = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in data.items()}
+    mean_dih = t["central_dihedrals"].mean(0, keepdim=True)
+    mean_ang = t["central_angles"].mean(0, keepdim=True)
+    mean_len = t["central_distances"].mean(0, keepdim=True)
+    chain = chain_in_plane(mean_len, mean_ang)
+    gen = dihedrals_to_cartesian(mean_dih + PI, chain)
+    pd_mean = pairwise_dist(gen[:, pwd_start:pwd_stop:pwd_step], flat=True)
+    out = {"dihedral_cost": [], "angle_cost": [], "cartesian_cost": []}
+    for idx in batch_indices:
+        ii = torch.as_tensor(np.asarray(idx), dtype=torch.long)
+        B = len(ii)
+        out["dihedral_cost"].append(float(angle_like_cost(t["central_dihedrals"][ii], mean_dih.expand(B, -1), 2 * PI, "mean_abs", 1.0, 1.0)))
+        out["angle_cost"].append(float(angle_like_cost(t["central_angles"][ii], mean_ang.expand(B, -1), 2 * PI, "mean_abs", 1.0, 1.0)))
+        pd = pairwise_dist(t["central_cartesians"][ii][:, pwd_start:pwd_stop:pwd_step], flat=True)
+        out["cartesian_cost"].append(float(cartesian_cost(pd_mean.expand(B, -1), pd, "mean_abs", 1.0, 1.0)))
+    return out
+
+
 def synthetic_backbone(rng: np.random.Generator, n_frames: int, n_residues: int, n_side: int = 0) -> dict:
     """Synthetic protein-like backbone: dihedrals around two basins, angles N(2.0, 0.05),
     bond lengths N(1.4, 0.02) (arbitrary length unit); central_cartesians are built with THIS file's

@@ -114,12 +114,23 @@ def test_adc_facade_train_and_references(em, tmp_path):
         CVs = data
 
     e = em.AngleDihedralCartesianEncoderMap(Ensemble(), p)
+    # train_for_references (autoencoder.py:1816-1937) with injected batches against its oracle restatement: every batch's
+    # three costs, and the references they average to
+    nb = 1200 // 128
+    idx = rng.integers(0, 1200, (nb, 128))
+    got_refs = e._engine.reference_costs(nb, data["central_angles"].mean(0), data["central_dihedrals"].mean(0), data["central_distances"].mean(0),
+                                         index_block=torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    want_refs = R.train_for_references(data, idx, p.cartesian_pwd_start, p.cartesian_pwd_stop, p.cartesian_pwd_step)
+    for k in ("dihedral_cost", "angle_cost", "cartesian_cost"):
+        np.testing.assert_allclose(got_refs[k], want_refs[k], rtol=1e-4, err_msg=k)
     hist = e.train()         # runs train_for_references first (all references were 1)
     assert p.dihedral_cost_reference != 1 and p.angle_cost_reference != 1 and p.cartesian_cost_reference != 1
-    # references = mean cost of predicting the data-set means (autoencoder.py:1816-1937), checked against numpy
-    md = data["central_dihedrals"].astype(np.float64).mean(0)
-    d = np.abs(data["central_dihedrals"] - md)
-    assert p.dihedral_cost_reference == pytest.approx(np.minimum(d, 2 * PI - d).mean(), rel=0.05)
+    # the references the facade stored: means over its own (shuffled) batches = the data-set-wide cost of the mean model, up to
+    # the sampling noise of nb batches of 128 frames
+    full = R.train_for_references(data, [np.arange(1200)], p.cartesian_pwd_start, p.cartesian_pwd_stop, p.cartesian_pwd_step)
+    assert p.dihedral_cost_reference == pytest.approx(full["dihedral_cost"][0], rel=0.03)
+    assert p.angle_cost_reference == pytest.approx(full["angle_cost"][0], rel=0.03)
+    assert p.cartesian_cost_reference == pytest.approx(full["cartesian_cost"][0], rel=0.03)
     assert len(hist.history["loss"]) == 40 and np.isfinite(hist.history["loss"]).all()
     assert hist.history["cartesian_cost"][5] == 0.0 and hist.history["cartesian_cost"][30] > 0      # soft start (10, 20)
     assert hist.history["loss"][-1] < hist.history["loss"][0]

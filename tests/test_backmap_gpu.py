@@ -182,7 +182,9 @@ def test_backbone_featurisation(L):
     f = em.featurize_backbone(xyz)
     np.testing.assert_allclose(f["central_distances"], np.array(T["known_angles_dists"]), atol=2e-4)
     np.testing.assert_allclose(np.rad2deg(f["central_angles"]), np.array(T["known_angles_angles"]), atol=1e-2)
-    np.testing.assert_allclose(np.abs(np.rad2deg(f["central_dihedrals"])), np.abs(np.array(T["known_angles_dihedrals"])), atol=1e-2)
+    # SIGNED dihedrals, compared modulo 360 degrees (the fixture's sign convention is pinned, not only the magnitudes)
+    dd = np.rad2deg(f["central_dihedrals"]) - np.array(T["known_angles_dihedrals"])
+    assert np.abs((dd + 180.0) % 360.0 - 180.0).max() < 1e-2
     # the 28 backbone angles of Ala10_helix.pdb (reference tests/test_angles.py:72-103)
     ala = em.featurize_backbone(np.array(T["ala10_backbone_xyz_angstrom"], np.float32)[None] / 10.0)
     np.testing.assert_allclose(ala["central_angles"][0], np.array(T["ala10_backbone_angles_rad"]), atol=2e-5)

@@ -65,6 +65,11 @@ SK_CASES = [
     (200, 12, 1, 360.0, (90.0, 10, 5, 1.5, 4, 2)),  # general path, L=1, period 360
     (130, 4, 4, INF, (1.5, 12, 6, 1, 2, 6)),      # L=4 runtime-L instantiation
     (500, 20, 2, INF, (3.0, 2, 2, 1, 1.5, 3)),    # a_l < 2: singular S'/d needs the d==0 mask
+    # latent widths 5 .. 8 (the reference stacks any n_neurons, models.py:3133-3160): the eight-column instantiations of the
+    # 32 x 32 VALU tiles (with split rows too: see test_sketchmap_on_split_rows)
+    (300, 16, 5, INF, (4.0, 12, 6, 1, 2, 6)),
+    (700, 33, 8, 2 * PI, DEFAULT_SIG),
+    (260, 10, 7, INF, (2.0, 3, 6, 1, 2, 6)),
 ]
 
 
@@ -117,11 +122,11 @@ def test_sketchmap_deterministic_and_rejects(L):
     a = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
     b = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
     assert a[0] == b[0] and np.array_equal(a[2], b[2])           # bitwise reproducible
-    X, Z = dev(x), dev(np.zeros((777, 5), np.float32))
+    X, Z = dev(x), dev(np.zeros((777, 9), np.float32))
     ws = torch.empty(1 << 20, device="cuda")
-    with pytest.raises(L.EmxError, match="latent dimension"):
+    with pytest.raises(L.EmxError, match="latent dimension"):       # 1 .. 8 latent columns
         L.sketchmap_fwd_bwd(X, Z, INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
-                            torch.zeros(777, 5, device="cuda"), ws)
+                            torch.zeros(777, 9, device="cuda"), ws)
     with pytest.raises(L.EmxError, match="workspace"):
         L.sketchmap_fwd_bwd(X, dev(z), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
                             torch.zeros(777, 2, device="cuda"), torch.empty(16, device="cuda"))
@@ -471,7 +476,8 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     (4096, 128, 2, (16.0, 12, 6, 1, 2, 6), 0, 4096),
     # few tiles, many features: the reduction of a tile is split over workgroups (ADC: pair-distance vectors as points)
     (1100, 40, 2, (10.0, 12, 6, 1, 2, 6), 0, 1100),      # 18 tile columns: ragged last group of the XCD-aware tile order
-    (256, 2850, 2, (80.0, 10, 5, 1, 2, 5), 0, 256), (200, 1000, 3, (45.0, 12, 6, 1, 2, 6), 0, 200), (320, 700, 2, (40.0, 12, 6, 1, 2, 6), 160, 320)])
+    (256, 2850, 2, (80.0, 10, 5, 1, 2, 5), 0, 256), (200, 1000, 3, (45.0, 12, 6, 1, 2, 6), 0, 200), (320, 700, 2, (40.0, 12, 6, 1, 2, 6), 160, 320),
+    (600, 64, 6, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 8, (5.0, 3, 6, 1, 2, 6), 100, 300)])      # latent widths 5 .. 8
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct
     formulas -- same tolerances as the float32 path -- on data far from the origin, where the row-0 shift and the
@@ -568,3 +574,27 @@ def test_sketchmap_tiles_then_finish_equals_the_single_call(L, B, periodicity):
     torch.cuda.synchronize()
     assert float(dist) == loss and float(c2) == cen
     assert np.array_equal(dZ.cpu().numpy().astype(np.float64), g)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 256, 1000, 100003, 1000000])
+def test_permute_equals_its_host_statement(L, n):
+    """emx_permute: the device shuffle is bit-identical to layout.feistel_permutation (integer work: exact), for several
+    seeds and epochs, and the engine's index stream equals layout.BatchIndexStream batch for batch."""
+    from encodermap_amd.layout import feistel_permutation
+
+    for seed, epoch in ((0, 0), (5, 3), (2 ** 40 + 17, 2 ** 33 + 1)):
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        L.permute(out, seed, epoch)
+        assert np.array_equal(out.cpu().numpy(), feistel_permutation(n, seed, epoch)), (n, seed, epoch)
+
+
+def test_engine_index_stream_equals_host_stream(L):
+    import encodermap_amd as em
+    from encodermap_amd.layout import BatchIndexStream
+
+    data = np.random.default_rng(0).uniform(-3, 3, (1000, 4)).astype(np.float32)
+    e = em.EncoderMap(em.Parameters(batch_size=96, seed=9), data, read_only=True)
+    host = BatchIndexStream(1000, 96, seed=e._engine._shuffle_seed)   # (DataParallel.batch_seed derives the stream's seed from p.seed)
+    for nb in (3, 11, 1, 25):          # 40 batches x 96 rows: almost four passes, blocks straddle them
+        got = e._engine.draw_index_block(nb).cpu().numpy().reshape(nb, 96)
+        assert np.array_equal(got, host.next_block(nb))

@@ -61,6 +61,9 @@ CASES = [
     # float64 oracle's [B, B, D] temporaries can hold
     ("c4_shape_wide_periodic", dict(batch_size=192, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6)),
      lambda r: r.uniform(-np.pi, np.pi, (1500, 512)).astype(np.float32)),
+    # a five-dimensional latent space (the reference stacks any n_neurons, models.py:3133-3160)
+    ("latent_5d", dict(periodicity=INF, n_neurons=[64, 32, 5], batch_size=300, dist_sig_parameters=(6.0, 12, 6, 1, 2, 6)),
+     lambda r: (r.normal(0, 3, (6, 24))[r.integers(0, 6, 3000)] + r.normal(0, 1, (3000, 24))).astype(np.float32)),
     # C5's shape (configs[4]): 256 Euclidean features
     ("c5_shape_euclid_256", dict(periodicity=INF, batch_size=384, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)),
      lambda r: (r.normal(0, 4, (16, 256))[r.integers(0, 16, 4000)] + r.normal(0, 1, (4000, 256))).astype(np.float32)),
