@@ -96,7 +96,7 @@ SIGNATURES = {
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
 }
 
-EMX_MAX_LAYERS = 8
+EMX_MAX_LAYERS = 12
 EMX_MAX_SUM_JOBS = 8
 EMX_MAX_COST_JOBS = 4
 

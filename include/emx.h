@@ -196,7 +196,7 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 
 /* description of the dense network (see K12 below); declared here because the optimizer keeps the operand store of the
  * dense-layer kernels current */
-#define EMX_MAX_LAYERS 8
+#define EMX_MAX_LAYERS 12   /* Dense layers of one network: n_neurons of up to six entries (encoder + mirrored decoder) */
 #define EMX_WGRAD_SLICE_ROWS 128   /* rows per weight-gradient slice; doubled until ... */
 #define EMX_WGRAD_MAX_SLICES 32    /* ... at most this many slices remain (emx_mlp_wgrad_slices) */
 typedef struct {

@@ -50,6 +50,8 @@ CASES = [
     (33, [50, 17, 4], ["", "tanh", "tanh", "tanh"], 77),
     (6, [8, 2], ["", "tanh", ""], 5),
     (40, [32, 2], ["", "tanh", ""], 9000),     # more than 32 x 128 rows: the weight-gradient slices grow to 512 rows, ragged end
+    (24, [40, 32, 24, 16, 3], ["", "tanh", "tanh", "tanh", "tanh", ""], 100),   # ten Dense layers (EMX_MAX_LAYERS = 12)
+    (260, [300, 130, 2], ["", "tanh", "tanh", ""], 50),   # layers of several 128-column passes and 128-k chunks
 ]
 
 
