@@ -51,6 +51,8 @@ SIGNATURES = {
     "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p, _p]),
     "emx_sketchmap_split_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_split": (_i, [_p, _i, _i, _i, _p, _p]),
+    "emx_sketchmap_tiles_dealt": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _p, _sz, _p, _i, _i, _p]),
+    "emx_sketchmap_reduce_dealt": (_i, [_i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_sketchmap_describe": (_i, [_i, _i, _i, _p, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _sz, _p]),
     "emx_pairwise_dist": (_i, [_p, _i, _i, _i, _f, _p, _p]),
@@ -310,6 +312,23 @@ def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws, split_ws=Non
     _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, int(row_begin),
                                       int(row_end), _ptr(ws), ws.numel() * ws.element_size(), _ptr(split_ws), _stream()),
            "emx_sketchmap_tiles")
+
+
+def sketchmap_tiles_dealt(X, Z, periodicity, sig, ws, split_ws, rank, world):
+    """The symmetric tile pass over the whole batch, this rank's share of the upper-triangle tiles (tile t -> rank t % world)."""
+    B, D = X.shape
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    _check(load().emx_sketchmap_tiles_dealt(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, _ptr(ws),
+                                            ws.numel() * ws.element_size(), _ptr(split_ws), int(rank), int(world), _stream()),
+           "emx_sketchmap_tiles_dealt")
+
+
+def sketchmap_reduce_dealt(B, D, Z, periodicity, sig, scale, center_scale, own_begin, own_end, rank, world, dZ, ws):
+    """d cost / d z of ALL rows from this rank's tiles (+ the center gradient on its own rows): summed over ranks, the full gradient."""
+    sig_arr = (_f * 6)(*[float(s) for s in sig])
+    _check(load().emx_sketchmap_reduce_dealt(int(B), int(D), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, float(scale), float(center_scale),
+                                             int(own_begin), int(own_end), int(rank), int(world), _ptr(dZ), _ptr(ws),
+                                             ws.numel() * ws.element_size(), _stream()), "emx_sketchmap_reduce_dealt")
 
 
 def sketchmap_split_bytes(B, D):

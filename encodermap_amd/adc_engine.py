@@ -216,6 +216,15 @@ class ADCEngine(SequentialEngine):
             out["ADCRMSDMetric"] = self.rmsd_hist[:k].cpu().numpy()
         return out
 
+    def _dealt(self) -> bool:
+        return False            # (the ADC step runs single-process or as replicas: one collective per step)
+
+    def _step_pre_a(self) -> None:
+        self._step_pre()
+
+    def _step_pre_b(self) -> None:
+        pass
+
     def _step_pre(self) -> None:
         p, B, per = self.p, self.B, self.periodicity
         lay, n = self.layout, len(self.layout.layers)

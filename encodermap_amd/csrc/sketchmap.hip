@@ -77,7 +77,15 @@ struct SkArgs {
   // epilogue.  kmode 0: one workgroup per tile does both.
   int ksplit, kmode;
   float* kpart;      // [tiles][ksplit][4 waves][16][64]
+  // data parallel: the upper-triangle tiles are DEALT to the ranks -- tile t (row-major triangle index)
+  // belongs to rank t % deal_world; a workgroup of another rank's tile leaves at once (its cost slot zeroed).  0 / 1: off.
+  int deal_rank, deal_world;
 };
+__device__ __forceinline__ bool dealt_away(const SkArgs& a, int tslot) {
+  if (a.deal_world <= 1 || tslot % a.deal_world == a.deal_rank) return false;
+  if (threadIdx.x == 0) a.tile_loss[tslot] = 0.f;
+  return true;
+}
 
 template <int N>
 __device__ __forceinline__ float powi(float v) {
@@ -245,6 +253,7 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
     ti = blockIdx.x / a.nbc;
     tj = blockIdx.x - ti * a.nbc;
   }
+  if (dealt_away(a, tslot)) return;
   const int i0 = a.row0 + ti * TM;
   const int j0 = tj * TN;
   const bool offdiag = a.symm && (ti != tj);
@@ -445,6 +454,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
     ti = blockIdx.x / a.nbc;
     tj = blockIdx.x - ti * a.nbc;
   }
+  if (dealt_away(a, blockIdx.x)) return;
   const int i0 = a.row0 + ti * T;
   const int j0 = tj * T;
   const bool offdiag = a.symm && (ti != tj);
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     ti = tile_id / a.nbc;
     tj = tile_id - ti * a.nbc;
   }
+  if (dealt_away(a, tslot)) return;
   const int i0 = a.row0 + ti * T;
   const int j0 = tj * T;
   const bool offdiag = a.symm && (ti != tj);
@@ -888,6 +899,32 @@ __global__ __launch_bounds__(NT) void sk_finish_kernel(const FinArgs a) {
   a.dZ[gidx] = g;
 }
 
+// Data parallel with dealt tiles: d cost / d z of ALL rows from the tiles THIS rank computed -- for row block ib the slot s
+// holds the partial of tile (min(ib, s), max(ib, s)), owned iff its triangle index % world == rank -- plus the center
+// cost's gradient on the rank's own rows.  The sum over ranks (one all-reduce of B x L floats) is the full gradient.
+struct DealtArgs {
+  const float* P;
+  const float* Z;
+  float* dZ;
+  int B, L, nbc, nrows_pad, tile, rank, world, own_begin, own_end;
+  float gscale, cgrad;
+};
+__global__ __launch_bounds__(NT) void sk_reduce_dealt_kernel(const DealtArgs a) {
+  const int e = blockIdx.x * NT + threadIdx.x;
+  if (e >= a.B * a.L) return;
+  const int row = e / a.L, ib = row / a.tile;
+  const long stride = (long)a.nrows_pad * a.L;
+  float part[4] = {0.f, 0.f, 0.f, 0.f};   // fixed association -> deterministic
+  for (int s = 0; s < a.nbc; ++s) {
+    const int ti = min(ib, s), tj = max(ib, s);
+    const int t = ti * a.nbc - ti * (ti - 1) / 2 + (tj - ti);
+    if (t % a.world == a.rank) part[s & 3] += a.P[(long)s * stride + e];
+  }
+  float g = a.gscale * ((part[0] + part[1]) + (part[2] + part[3]));
+  if (row >= a.own_begin && row < a.own_end) g = fmaf(a.cgrad, a.Z[e], g);
+  a.dZ[e] = g;
+}
+
 SigDev make_sig(float sig, float aa, float bb) {
   SigDev s;
   s.inv_sig2 = 1.f / (sig * sig);
@@ -1033,6 +1070,8 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.tile_loss = wsf + (size_t)nslots * a.nrows_pad * L;
   a.ksplit = 1;
   a.kmode = 0;
+  a.deal_rank = 0;
+  a.deal_world = 1;
   {
     const size_t nb = (size_t)(B + 63) / 64;
     a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + ws_front_floats(B, L) : nullptr;
@@ -1242,6 +1281,34 @@ int emx_sketchmap_finish(int B, int D, const float* Z, int L, float periodicity,
                      dist_loss, center_loss, dZ, ws, ws_bytes, pl, "emx_sketchmap_finish");
   if (rc) return rc;
   return launch_finish_plan(pl, (hipStream_t)stream);
+}
+
+/* Data parallel, symmetric: the all-pairs pass over the WHOLE batch with its upper-triangle tiles dealt
+ * to the ranks -- every rank computes 1 / world of the pair work (the rectangle rows x [0, B) of a row-block rank is twice
+ * that) and keeps row AND column partials of its tiles. */
+int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6], void* ws,
+                              size_t ws_bytes, void* split_ws, int rank, int world, emx_stream_t stream) {
+  EMX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "emx_sketchmap_tiles_dealt: bad rank %d of %d", rank, world);
+  SkPlan pl;
+  int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl,
+                     "emx_sketchmap_tiles_dealt", split_ws);
+  if (rc) return rc;
+  pl.a.deal_rank = rank;
+  pl.a.deal_world = world;
+  return launch_tiles_plan(pl, (hipStream_t)stream);
+}
+
+int emx_sketchmap_reduce_dealt(int B, int D, const float* Z, int L, float periodicity, const float sig[6], float scale, float center_scale,
+                               int own_begin, int own_end, int rank, int world, float* dZ, void* ws, size_t ws_bytes, emx_stream_t stream) {
+  EMX_REQUIRE(dZ && world >= 1 && rank >= 0 && rank < world, "emx_sketchmap_reduce_dealt: bad arguments");
+  EMX_REQUIRE(0 <= own_begin && own_begin <= own_end && own_end <= B, "emx_sketchmap_reduce_dealt: bad own rows");
+  SkPlan pl;
+  int rc = make_plan(Z, B, D, D, Z, L, periodicity, sig, scale, center_scale, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl,
+                     "emx_sketchmap_reduce_dealt");
+  if (rc) return rc;
+  DealtArgs a{pl.f.P, Z, dZ, B, L, pl.a.nbc, pl.f.nrows_pad, pl.T, rank, world, own_begin, own_end, pl.f.gscale, pl.f.cgrad};
+  hipLaunchKernelGGL(sk_reduce_dealt_kernel, dim3((unsigned)((B * L + NT - 1) / NT)), dim3(NT), 0, (hipStream_t)stream, a);
+  return emx::check_launch("sk_reduce_dealt_kernel");
 }
 
 int emx_sketchmap_describe(int B, int D, int ldx, const float* X, const float* Z, int L, float periodicity, const float sig[6],

@@ -44,8 +44,11 @@ INF = float("inf")
 class DataParallel:
     """Partition of one step over ranks.  ``mode``:
 
-    ``"rowblock"``  every rank sees the same global batch of ``batch_size`` rows, owns a contiguous row block
-                    and all-reduces (SUM) the flat gradient: bit-for-bit the single-process objective.
+    ``"rowblock"``  every rank sees the same global batch of ``batch_size`` rows and owns a contiguous row block of it for
+                    the dense layers; the all-pairs cost runs symmetrically over the whole batch with its upper-triangle
+                    tiles DEALT to the ranks (1 / G of the pair work each).  Two small SUM all-reduces per step -- the
+                    [B, L] latent gradient in front of the encoder's backward pass, the flat [gradient | cost terms]
+                    buffer in front of the optimizer: the single-process objective exactly.
     ``"replica"``   every rank draws its own mini-batch of ``batch_size`` rows and gradients are averaged:
                     classic data parallelism (weak scaling), the objective is the mean of the per-rank costs.
     """
@@ -70,12 +73,30 @@ class DataParallel:
         end = begin + base + (1 if self.rank < rem else 0)
         return min(16 * begin, batch_size), min(16 * end, batch_size)
 
-    def all_reduce_(self, flat: torch.Tensor) -> None:
-        """The single collective of a step: gradients and loss terms in one flat buffer."""
+    def dealt_tiles(self, batch_size: int, tile: int):
+        """Tiles (ti, tj), ti <= tj, of the symmetric all-pairs pass over the whole batch that this rank computes in the
+        row-block mode: the upper triangle of the tile grid in row-major order, dealt round-robin (tile t to rank
+        t % world_size -- the rule of emx_sketchmap_tiles_dealt, include/emx.h).  A diagonal tile is half the work of an
+        off-diagonal one; with hundreds of tiles per rank the deal is balanced to within one tile."""
+        nb = (batch_size + tile - 1) // tile
+        out, t = [], 0
+        for ti in range(nb):
+            for tj in range(ti, nb):
+                if not self.active or self.mode == "replica" or t % self.world_size == self.rank:
+                    out.append((ti, tj))
+                t += 1
+        return out
+
+    def all_reduce_(self, flat: torch.Tensor, op: Optional[str] = None) -> None:
+        """A collective of a step: gradients and loss terms in one flat buffer (replica: averaged; row blocks: summed), or --
+        ``op="sum"`` -- the row-block ranks' contributions to the latent gradient."""
         if not self.active:
             return
         import torch.distributed as dist
 
+        if op == "sum":
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            return
         if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective
         else:
@@ -278,22 +299,41 @@ class SequentialEngine:
     def _use_sketchmap(self) -> bool:
         return self.with_distance and self.p.distance_cost_scale is not None
 
+    def _dealt(self) -> bool:
+        """data parallel over row blocks with the all-pairs tiles dealt to the ranks (DataParallel mode "rowblock")"""
+        return self.dp.active and self.dp.mode == "rowblock" and self._use_sketchmap()
+
     def _latent_costs(self) -> None:
         """all-pairs tile pass of the sketch-map cost (its O(B) reduction is folded into the encoder's backward kernel and
-        the scalar epilogue), or the center cost alone"""
+        the scalar epilogue), or the center cost alone.  Row-block data parallelism: this rank's share of the symmetric
+        pass over the whole batch, reduced to its contribution to d cost / d z of ALL rows (summed by _mid_collective)."""
         p = self.p
         Z = self.h[self.layout.n_enc - 1]
-        if self._use_sketchmap():
+        if self._dealt():
+            cs = p.center_cost_scale
+            _lib.sketchmap_tiles_dealt(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.sk_ws, self.split_ws, self.dp.rank,
+                                       self.dp.world_size)
+            _lib.sketchmap_reduce_dealt(self.B, self.D, Z, self.periodicity, p.dist_sig_parameters, float(p.distance_cost_scale),
+                                        float(cs) if cs is not None else 0.0, self.rb, self.re, self.dp.rank, self.dp.world_size, self.dZ,
+                                        self.sk_ws)
+        elif self._use_sketchmap():
             _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws, self.split_ws)
         else:
             cs = p.center_cost_scale
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, self.rb, self.re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)
 
+    def _mid_collective(self) -> None:
+        """Row-block data parallelism: the ranks' contributions to the latent gradient are summed before the encoder's
+        backward pass (B x L floats: latency-bound)."""
+        if self._dealt():
+            self.dp.all_reduce_(self.dZ, op="sum")
+
     def _describe_sketchmap(self):
         p = self.p
         cs = p.center_cost_scale
+        rb, re = (0, self.B) if self._dealt() else (self.rb, self.re)   # (dealt tiles: the symmetric layout of the whole batch)
         return _lib.sketchmap_describe(self.xb, self.h[self.layout.n_enc - 1], self.periodicity, p.dist_sig_parameters,
-                                       float(p.distance_cost_scale), float(cs) if cs is not None else 0.0, self.rb, self.re, self.sk_ws)
+                                       float(p.distance_cost_scale), float(cs) if cs is not None else 0.0, rb, re, self.sk_ws)
 
     def _jobs_pre(self) -> list:
         """scalar sums that must be final before a data-parallel all-reduce: (src, n, scale, dev_scale, slot, square)"""
@@ -306,9 +346,14 @@ class SequentialEngine:
         return jobs
 
     def _step_pre(self) -> None:
-        """Everything up to the gradients.  After the forward pass there are two independent branches -- the all-pairs
-        kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at the latent layer; they
-        run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
+        """Everything up to the gradients, single process or replica ranks (no collective inside)."""
+        self._step_pre_a()
+        self._step_pre_b()
+
+    def _step_pre_a(self) -> None:
+        """Forward pass, auto cost, decoder backward, all-pairs tiles.  After the forward pass there are two independent
+        branches -- the all-pairs kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at
+        the latent layer; they run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
         lay, n = self.layout, len(self.layout.layers)
         decoder_done = self._forward()
         if decoder_done:
@@ -324,7 +369,13 @@ class SequentialEngine:
         else:
             _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
             self._latent_costs()
-        if self._use_sketchmap():
+
+    def _step_pre_b(self) -> None:
+        """Encoder backward (the latent gradient joins here) and the weight gradients."""
+        lay = self.layout
+        if self._dealt():
+            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        elif self._use_sketchmap():
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
         else:
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
@@ -400,9 +451,18 @@ class SequentialEngine:
             _lib.l2_partials(self.w, self.l2coef, self.red_ws2)
 
     def _step_body(self) -> None:
-        self._step_pre()
+        self._step_pre_a()
+        self._mid_collective()
+        self._step_pre_b()
         self.dp.all_reduce_(self.g_ext)
         self._step_post()
+
+    def _dp_segments(self):
+        """The data-parallel step as (launches, collective behind them) pairs: each launch sequence becomes a hipGraph, the
+        collectives run eagerly between them."""
+        if self._dealt():
+            return [(self._step_pre_a, self._mid_collective), (self._step_pre_b, lambda: self.dp.all_reduce_(self.g_ext)), (self._step_post, None)]
+        return [(self._step_pre, lambda: self.dp.all_reduce_(self.g_ext)), (self._step_post, None)]
 
     # -- driver --------------------------------------------------------------------------------------
     def _state_tensors(self):
@@ -464,12 +524,14 @@ class SequentialEngine:
             if captured:
                 pass
             elif self.dp.active:
-                g1, g2 = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g1):
-                    self._step_pre()
-                with torch.cuda.graph(g2, pool=g1.pool()):
-                    self._step_post()
-                self._graph = (g1, g2)
+                graphs, pool = [], None
+                for launches, _ in self._dp_segments():
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, pool=pool):
+                        launches()
+                    pool = pool or g.pool()
+                    graphs.append(g)
+                self._graph = tuple(graphs)
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -500,9 +562,10 @@ class SequentialEngine:
         if len(self._graph) == 1:
             self._graph[0].replay()
         else:
-            self._graph[0].replay()
-            self.dp.all_reduce_(self.g_ext)
-            self._graph[1].replay()
+            for g, (_, collective) in zip(self._graph, self._dp_segments()):
+                g.replay()
+                if collective is not None:
+                    collective()
 
     def run_steps(self, n_steps: int, index_block: Optional[torch.Tensor] = None) -> None:
         """Enqueue ``n_steps`` training steps (asynchronous).  ``index_block`` ([n_steps*B] int64, device) injects

@@ -115,6 +115,18 @@ int emx_sketchmap_describe(int B, int D, int ldx, const float* X, const float* Z
                            float scale, float center_scale, int row_begin, int row_end, void* ws, size_t ws_bytes,
                            emx_sketchmap_partials* out);
 
+/* Data parallel with the objective of the single process (loss_functions.py:351-367 needs ALL B^2 pairs of
+ * the global batch): the symmetric tile pass over the whole batch with its upper-triangle tiles DEALT to the ranks -- tile t
+ * (row-major triangle index) belongs to rank t % world, so every rank does 1 / world of the pair work and keeps row and column
+ * partials of its tiles; cost slots of other ranks' tiles are zeroed (sum(tile_loss) is the rank's share of the cost).
+ * emx_sketchmap_reduce_dealt then forms, for ALL rows, d cost / d z from this rank's tiles (+ the center cost's gradient on
+ * rows [own_begin, own_end)): the SUM over ranks -- one all-reduce of B x L floats -- is the gradient emx_sketchmap_finish
+ * would give.  Same workspace as emx_sketchmap_tiles(row_begin = 0, row_end = B). */
+int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6], void* ws,
+                              size_t ws_bytes, void* split_ws /* may be NULL */, int rank, int world, emx_stream_t stream);
+int emx_sketchmap_reduce_dealt(int B, int D, const float* Z, int L, float periodicity, const float sig[6], float scale, float center_scale,
+                               int own_begin, int own_end, int rank, int world, float* dZ, void* ws, size_t ws_bytes, emx_stream_t stream);
+
 /* materialising variants, for parity tests of a2/a3 only (out is [B,B]) */
 int emx_pairwise_dist(const float* X, int B, int D, int ldx, float periodicity, float* out, emx_stream_t stream);
 

@@ -80,6 +80,34 @@ def sketchmap_fwd_bwd(x, z, periodicity, sig, scale=1.0, row_begin=0, row_end=No
     return loss, dZ
 
 
+def sketchmap_tiles_fwd_bwd(x, z, periodicity, sig, scale, tiles, tile):
+    """The same cost over a SET OF TILES of the symmetric pair matrix (symmetric row-block
+    partition): ``tiles`` holds (ti, tj) with ti <= tj, rows [ti*tile, (ti+1)*tile) x columns [tj*tile, (tj+1)*tile).
+
+    An off-diagonal tile stands for its mirror image too: its pairs count twice in the cost and contribute to the latent
+    gradient of the rows on BOTH sides.  Returns (loss share, dZ[B,L] share); summed over a partition of the upper
+    triangle they are the full-batch cost and gradient of sketchmap_fwd_bwd."""
+    x = np.asarray(x, np.float64)
+    z = np.asarray(z, np.float64)
+    B = x.shape[0]
+    dh = pairwise_dist_direct(x) if periodicity == float("inf") else pairwise_dist_periodic_direct(x, periodicity)
+    dl = pairwise_dist_direct(z)
+    diff = sigmoid(dh, *sig[:3]) - sigmoid(dl, *sig[3:])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        w = np.where(dl > 0, -2.0 * scale * diff * sigmoid_prime(dl, *sig[3:]) / (B * B) / dl, 0.0)
+    loss, dZ = 0.0, np.zeros_like(z)
+    for ti, tj in tiles:
+        I = slice(ti * tile, min((ti + 1) * tile, B))
+        J = slice(tj * tile, min((tj + 1) * tile, B))
+        mult = 1.0 if ti == tj else 2.0
+        loss += mult * scale * np.sum(diff[I, J] ** 2) / (B * B)
+        wt = w[I, J]
+        dZ[I] += 2.0 * (wt.sum(1)[:, None] * z[I] - wt @ z[J])
+        if ti != tj:
+            dZ[J] += 2.0 * (wt.sum(0)[:, None] * z[J] - wt.T @ z[I])
+    return loss, dZ
+
+
 def pdist_flat(xyz):
     """pairwise_dist(flat=True) (encodermap/misc/distances.py:235-253): strict upper triangle, row-major."""
     xyz = np.asarray(xyz, np.float64)

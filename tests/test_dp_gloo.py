@@ -1,9 +1,10 @@
-"""Data-parallel host logic on CPU with the gloo backend, world_size 2.
+"""Data-parallel host logic on CPU with the gloo backend, world_size 2 and 3.
 
 The HIP kernels cannot run here, so the per-rank compute is played by the float64 oracle; what is under test is the
-product's partition + collective plumbing (``encodermap_amd.engine.DataParallel``): row blocks, the single
-all-reduce of the flat [gradient | loss terms] buffer, SUM for the exact row-block objective and the mean for
-independent replica batches.  The row-block scheme must reproduce the single-process gradient and loss exactly."""
+product's partition + collective plumbing (``encodermap_amd.engine.DataParallel``): runs of 16-row blocks for the dense
+layers, the tiles of the symmetric all-pairs pass dealt round-robin, the SUM all-reduce of the [B, L] latent-gradient
+shares, the all-reduce of the flat [gradient | loss terms] buffer (SUM for the exact row-block objective, the mean for
+independent replica batches).  The row-block scheme must reproduce the single-process gradient and loss exactly."""
 import os
 import socket
 
@@ -27,41 +28,47 @@ def _free_port():
     return port
 
 
+BATCH = 72     # five 16-row blocks, the last one ragged: 3 + 2 blocks at two ranks, 2 + 2 + 1 (8 rows) at three
+TILE = 16      # 5 x 5 tile grid, 15 tiles in the upper triangle: 8 + 7 at two ranks, 5 each at three
+
+
 def _setup():
     from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
     from encodermap_amd.parameters import Parameters
 
     rng = np.random.default_rng(0)
-    p = Parameters(batch_size=48, n_neurons=[16, 2], activation_functions=["", "tanh", ""])
-    x = rng.uniform(-PI, PI, (48, 5)).astype(np.float32)
+    p = Parameters(batch_size=BATCH, n_neurons=[16, 2], activation_functions=["", "tanh", ""])
+    x = rng.uniform(-PI, PI, (BATCH, 5)).astype(np.float32)
     lay = build_layout(p.n_neurons, p.activation_functions, 10)
     w0 = unpack_weights(lay, init_parameters(lay, 1))
     return p, x, w0
 
 
-def _rank_flat(rank, world, mode, p, x, w0):
-    """[grad | auto, center, distance] as rank `rank` computes it, following the engine's scheme: encoder on all rows,
-    d(distance+center)/dz for own rows from the row-block kernel (oracle: direct_ops), decoder/backward on own rows."""
+def _rank_flat(rank, world, mode, p, x, w0, reduce_latent=True):
+    """[grad | auto, center, distance] as rank `rank` computes it, following the engine's scheme (engine.py:
+    _step_pre_a, _mid_collective, _step_pre_b): encoder on all rows; this rank's dealt tiles of the symmetric all-pairs
+    pass (oracle: direct_ops) give its share of d distance / dz of EVERY row, summed over the ranks by the first
+    collective; decoder, auto cost, center cost and the backward pass on its own rows."""
     from encodermap_amd.engine import DataParallel
 
     dp = DataParallel(rank, world, mode)
     B = x.shape[0]
-    if mode == "replica":                       # own mini-batch: rows differ per rank
-        xr = np.roll(x, 7 * rank, axis=0).copy()
-        rb, re = dp.row_block(B)
-    else:
-        xr = x
-        rb, re = dp.row_block(B)
+    xr = np.roll(x, 7 * rank, axis=0).copy() if mode == "replica" else x     # replica: own mini-batch per rank
+    rb, re = dp.row_block(B)
     model = R.SequentialOracle(5, p.n_neurons, p.activation_functions, p.periodicity, w0)
     X = torch.tensor(xr, dtype=torch.float64)
     z = model.encoder(X)
     y = model.decoder(z[rb:re])
     auto = torch.sum(torch.abs(R.periodic_distance(X[rb:re], y, p.periodicity))) / (B * 5) * p.auto_cost_scale
-    loss_d, dZ = D.sketchmap_fwd_bwd(xr, z.detach().numpy(), p.periodicity, p.dist_sig_parameters, p.distance_cost_scale, rb, re)
+    loss_d, dZ = D.sketchmap_tiles_fwd_bwd(xr, z.detach().numpy(), p.periodicity, p.dist_sig_parameters, p.distance_cost_scale,
+                                           dp.dealt_tiles(B, TILE), TILE)
+    dZ = torch.tensor(dZ)
+    if reduce_latent and mode == "rowblock":     # (replica ranks hold whole batches of their own: no exchange here)
+        dp.all_reduce_(dZ, op="sum")
     center = torch.sum(z[rb:re] ** 2) / (B * 2) * p.center_cost_scale
-    surrogate = auto + center + torch.sum(torch.tensor(dZ[rb:re]) * z[rb:re])
+    surrogate = auto + center + torch.sum(dZ[rb:re] * z[rb:re])
     grads = torch.autograd.grad(surrogate, model.params)
-    flat = torch.cat([g.reshape(-1) for g in grads] + [torch.tensor([float(auto), float(center), loss_d])])
+    flat = torch.cat([g.reshape(-1) for g in grads] + [torch.tensor([float(auto.detach()), float(center.detach()), loss_d])])
     return dp, flat.detach()
 
 
@@ -76,12 +83,32 @@ def _worker(rank, world, port, mode, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["rowblock", "replica"])
-def test_two_ranks(mode, tmp_path):
-    world = 2
+def test_dealt_tiles_partition_the_upper_triangle():
+    from encodermap_amd.engine import DataParallel
+
+    for B, tile, world in ((72, 16, 2), (72, 16, 3), (4096, 64, 8), (300, 32, 3)):
+        nb = -(-B // tile)
+        deals = [DataParallel(r, world, "rowblock").dealt_tiles(B, tile) for r in range(world)]
+        flat = sorted(t for d in deals for t in d)
+        assert flat == [(i, j) for i in range(nb) for j in range(i, nb)]          # every tile exactly once
+        assert max(map(len, deals)) - min(map(len, deals)) <= 1
+    assert DataParallel(0, 1, "rowblock").dealt_tiles(72, 16) == [(i, j) for i in range(5) for j in range(i, 5)]
+    # the oracle's tile form over the whole triangle is the row form over the whole batch
+    p, x, w0 = _setup()
+    z = np.random.default_rng(1).normal(size=(BATCH, 2))
+    full = D.sketchmap_fwd_bwd(x, z, p.periodicity, p.dist_sig_parameters, p.distance_cost_scale)
+    tiled = D.sketchmap_tiles_fwd_bwd(x, z, p.periodicity, p.dist_sig_parameters, p.distance_cost_scale,
+                                      DataParallel(0, 1, "rowblock").dealt_tiles(BATCH, TILE), TILE)
+    np.testing.assert_allclose(tiled[0], full[0], rtol=1e-12)
+    np.testing.assert_allclose(tiled[1], full[1], rtol=1e-10, atol=1e-14)
+
+
+@pytest.mark.parametrize("mode,world", [("rowblock", 2), ("rowblock", 3), ("replica", 2)])
+def test_ranks(mode, world, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
     got = [np.load(tmp_path / f"{mode}_{r}.npy") for r in range(world)]
-    np.testing.assert_array_equal(got[0], got[1])                 # every rank holds the same reduced buffer
+    for g in got[1:]:
+        np.testing.assert_array_equal(got[0], g)                  # every rank holds the same reduced buffer
     p, x, w0 = _setup()
     if mode == "rowblock":
         # single-process reference: full-batch loss and gradient (minus the regulariser, which is added after the reduce)
@@ -95,6 +122,6 @@ def test_two_ranks(mode, tmp_path):
         # replica mode: mean of the per-rank buffers
         from encodermap_amd.engine import DataParallel
 
-        parts = [_rank_flat(r, world, mode, p, x, w0)[1].numpy() for r in range(world)]
-        assert DataParallel(0, world, mode).row_block(48) == (0, 48)
+        parts = [_rank_flat(r, world, mode, p, x, w0, reduce_latent=False)[1].numpy() for r in range(world)]
+        assert DataParallel(0, world, mode).row_block(BATCH) == (0, BATCH)
         np.testing.assert_allclose(got[0], (parts[0] + parts[1]) / 2, rtol=1e-12)

@@ -576,6 +576,57 @@ def test_sketchmap_tiles_then_finish_equals_the_single_call(L, B, periodicity):
     assert np.array_equal(dZ.cpu().numpy().astype(np.float64), g)
 
 
+@pytest.mark.parametrize("B,Dd,Ld,periodicity,tile,split", [
+    (300, 12, 2, 2 * PI, 32, False),      # VALU tiles at 32 x 32 (periodic, small batch), ragged edge
+    (1000, 24, 2, 2 * PI, 64, False),     # VALU tiles at 64 x 64
+    (1000, 24, 2, INF, 64, True),         # f16 matrix-core tiles on split rows
+    (1000, 24, 2, INF, 64, False),        # Euclidean VALU tiles
+    (400, 10, 6, INF, 32, False),         # wide latent
+])
+@pytest.mark.parametrize("world", [2, 3])
+def test_sketchmap_dealt_tiles_sum_to_the_full_pass(L, B, Dd, Ld, periodicity, tile, split, world):
+    """Row-block data parallelism (SURVEY.md section 8e): the upper-triangle tiles of the symmetric pass are dealt round-robin;
+    each rank's emx_sketchmap_tiles_dealt + emx_sketchmap_reduce_dealt is its share of the cost and of d cost / d z of ALL
+    rows (center gradient on its own rows) -- the oracle's share for the same tiles, and summed over ranks the single call."""
+    from encodermap_amd.engine import DataParallel
+
+    rng = np.random.default_rng(B + world)
+    x, z = make_xz(rng, B, Dd, Ld, periodicity, 1.0)
+    sig = DEFAULT_SIG if periodicity != INF else (2.0 * math.sqrt(Dd), 12, 6, 1, 2, 6)
+    loss_full, cen_full, g_full = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
+    X, Z = dev(x), dev(z)
+    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    split_ws = None
+    if split:
+        split_ws = torch.empty(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
+        L.sketchmap_split(X, split_ws)
+    loss_sum, g_sum = 0.0, np.zeros((B, Ld))
+    for rank in range(world):
+        dp = DataParallel(rank, world, "rowblock")
+        rb, re = dp.row_block(B)
+        ws.fill_(float("nan"))
+        dZ = torch.full((B, Ld), float("nan"), device="cuda")
+        L.sketchmap_tiles_dealt(X, Z, periodicity, sig, ws, split_ws, rank, world)
+        L.sketchmap_reduce_dealt(B, Dd, Z, periodicity, sig, 500.0, 1e-4, rb, re, rank, world, dZ, ws)
+        sk = L.sketchmap_describe(X, Z, periodicity, sig, 500.0, 1e-4, 0, B, ws)
+        torch.cuda.synchronize()
+        off = (sk.tile_loss - ws.data_ptr()) // 4
+        tl = ws[off:off + sk.n_tiles].cpu().numpy().astype(np.float64)
+        mine = dp.dealt_tiles(B, tile)
+        assert sk.n_tiles == (-(-B // tile)) * (-(-B // tile) + 1) // 2
+        assert np.count_nonzero(tl) == len(mine)                   # the other ranks' tiles: cost slots zeroed, not computed
+        lo_o, g_o = D.sketchmap_tiles_fwd_bwd(x, z, periodicity, sig, 500.0, mine, tile)
+        g_o[rb:re] += 2e-4 * z[rb:re].astype(np.float64) / z.size
+        loss = tl.sum() * sk.loss_scale
+        g = dZ.cpu().numpy().astype(np.float64)
+        assert loss == pytest.approx(lo_o, rel=2e-5 if not split else 1e-4)
+        np.testing.assert_allclose(g, g_o, rtol=0, atol=(2e-5 if not split else 2e-4) * np.abs(g_full).max())
+        loss_sum += loss
+        g_sum += g
+    assert loss_sum == pytest.approx(loss_full, rel=2e-6 if not split else 1e-4)
+    np.testing.assert_allclose(g_sum, g_full, rtol=0, atol=(1e-5 if not split else 2e-4) * np.abs(g_full).max())
+
+
 @pytest.mark.parametrize("n", [1, 2, 7, 256, 1000, 100003, 1000000])
 def test_permute_equals_its_host_statement(L, n):
     """emx_permute: the device shuffle is bit-identical to layout.feistel_permutation (integer work: exact), for several
