@@ -10,19 +10,25 @@ distance + auto + center + L2 cost, backward, clip + Adam) on synthetic Gaussian
 before the timed region starts.  One JSON line is printed by rank 0:
 
   value        whole-job samples/s = N_gpus * 4096 * K / (max over ranks of the time for K steps)
-  roofline     the dominant kernel (sk_tile_f16_kernel, the O(B^2 D) all-pairs pass): algorithmic FLOPs per launch
-               (2 per pair-element for the Gram tiles) / its average duration, measured here with HIP events
-               around K back-to-back launches on live data, against the 157.3 TFLOP/s fp32 matrix peak -- the precision the
-               path delivers (the Gram products run as three f16 matrix instructions per float32 product on split rows,
-               csrc/split.h; priced against the f16 peak the executed 6 W FLOPs would be a few per cent: the kernel is bound
-               by the VALU work of its sigmoid epilogue).  ``traffic`` = HBM bytes per launch from the rocprofv3 PMC
-               passes kept under profiles/.
+  roofline     the kernel that takes the largest share of the STEP (today the fused dense-layer launch: forward, auto cost,
+               decoder backward), ``roofline_all_pairs`` the O(B^2 D) all-pairs kernel.  Both are timed here with HIP events
+               around back-to-back launches on the live batch.  Every float32 product of these kernels runs as THREE f16
+               matrix instructions on operands split into two 16-bit planes, so ``achieved`` counts the executed FLOPs
+               (3 x the algorithmic 2 per multiply-add) and ``peak`` is the dense f16 matrix peak; ``fractions`` gives the
+               three ways to price the same launch: fp32_equivalent (algorithmic FLOPs against the 157.3 TFLOP/s fp32 matrix
+               peak -- the precision delivered), executed_f16 (= ``frac``) and valu_issue (VALU instructions per launch, from the
+               PMC passes under profiles/, per SIMD and clock -- what actually bounds both kernels).
+               ``traffic`` = HBM bytes per launch from the PMC passes under profiles/ (``traffic_source`` names the file).
   cpu_baseline the reference-formulation CPU path (oracle/reference_ops.py in float32: Gram-matrix distances with
                B x B temporaries, autograd, per-element clipped Adam) timed on this host for a few steps of the same
                workload.  N=1 only.  kind "port": TensorFlow itself cannot be installed here.
 
 N > 1: weak scaling -- every rank trains on its own mini-batch of 4096 rows (global batch 4096*N) and the flat
-gradient buffer is averaged by one RCCL all-reduce per step (engine.DataParallel mode "replica").
+gradient buffer is averaged by one RCCL all-reduce per step (engine.DataParallel mode "replica": the objective is the
+mean of N independent 4096-row sketch-map costs, what N reference processes with averaged gradients would minimise).
+``--dp-mode rowblock`` is the other objective: ONE sketch-map cost over ONE global batch (``--global-batch``, default
+4096: strong scaling of the single-GPU objective; ``--global-batch 0`` = 4096 * N), dense layers on runs of row blocks,
+the symmetric all-pairs tiles dealt to the ranks, two all-reduces per step (latent gradient shares, [gradient | terms]).
 """
 from __future__ import annotations
 
@@ -39,6 +45,10 @@ if ROOT not in sys.path:
 B, D, N_ROWS = 4096, 128, 1_000_000
 SIG = (16.0, 12, 6, 1, 2, 6)
 FP32_PEAK = 157.3e12   # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md chip table)
+F16_PEAK = 2.5e15      # dense f16 / bf16 matrix peak (same table; the headline figure with 2:1 sparsity is not used)
+SIMDS, CLOCK = 1024, 2.4e9
+DTYPE = "f32 (split-f16 x3 mfma)"
+COUNTERS = os.path.join("profiles", "r02_step_counters.json")
 
 
 def make_blobs(device, n_rows, d, seed):
@@ -90,40 +100,77 @@ def cpu_baseline(n_steps=12):
                       f"{dt / n_steps * 1e3:.0f} ms/step with {best} of {cores} host threads, the fastest of a one-step probe)"}
 
 
-def kernel_roofline(eng, launches):
-    """Average duration of the tile kernel alone on the engine's live batch (HIP events on the launch stream)."""
+def _time_launches(fn, launches):
+    """average duration of ``fn`` (asynchronous launches on torch's current stream) over back-to-back calls, seconds"""
     import torch
 
-    from encodermap_amd import _lib
-
-    Z = eng.h[eng.layout.n_enc - 1]
     for _ in range(5):
-        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws, eng.split_ws)
+        fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
     for _ in range(launches):
-        _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, B, eng.sk_ws, eng.split_ws)
+        fn()
     e1.record()
     torch.cuda.synchronize()
-    t = e0.elapsed_time(e1) * 1e-3 / launches
-    W = D * B * (B - 1) / 2           # pair-elements per launch (i<->j symmetry exploited)
-    flops = 2.0 * W                   # Gram form on the f32 matrix cores: one multiply-add per pair-element (SURVEY.md
-                                      # section 8d: "the Gram form would be 2 W"; the direct-difference form counts 3 W)
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.isfile(tf):
-        try:
-            traffic = json.load(open(tf)).get("sk_tile_kernel_hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-    return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": FP32_PEAK / 1e12, "unit": "TFLOP/s",
-            "frac": flops / t / FP32_PEAK, "traffic": traffic, "kernel": "sk_tile_f16_kernel", "kernel_us": t * 1e6,
-            "algorithmic_bytes": 4 * B * (D + 2 * 2 + 2) + 4,
-            "note": "Gram tiles as 3 v_mfma_f32_32x32x16_f16 per float32 product on rows split into two f16 planes (float32-accurate), "
-                    "VALU sigmoid epilogue; 2 FLOP per pair-element over the upper triangle, priced against the fp32 matrix peak (the "
-                    "delivered precision); algorithmic HBM bytes per launch are ~2 MB so the HBM roof does not bind; the kernel is "
-                    "VALU-issue bound (epilogue ~40 instructions per pair)"}
+    return e0.elapsed_time(e1) * 1e-3 / launches
+
+
+def _counters(kernel_key):
+    """static per-launch counters of the step's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh)"""
+    try:
+        for name, c in json.load(open(os.path.join(ROOT, COUNTERS)))["kernels"].items():
+            if kernel_key in name:
+                return c
+    except Exception:
+        pass
+    return {}
+
+
+def _record(kernel, kernel_key, t, mults, note, algorithmic_bytes):
+    """One roofline object: ``mults`` multiply-adds of float32 precision per launch, each executed as three f16 matrix
+    instructions' worth of FLOPs."""
+    c = _counters(kernel_key)
+    executed = 6.0 * mults
+    valu = c.get("SQ_INSTS_VALU")
+    out = {"bound": "mfma", "achieved": executed / t / 1e12, "peak": F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": executed / t / F16_PEAK,
+           "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": f"{COUNTERS} (static: PMC passes over this workload)" if c else None,
+           "kernel": kernel, "kernel_us": t * 1e6, "algorithmic_bytes": algorithmic_bytes,
+           "fractions": {"fp32_equivalent": 2.0 * mults / t / FP32_PEAK, "executed_f16": executed / t / F16_PEAK,
+                         "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None},
+           "fp32_equiv_tflops": 2.0 * mults / t / 1e12,
+           "limiter": "instruction issue: neither the matrix pipes nor HBM are near their roofs; valu_issue is VALU wave-instructions "
+                      "per SIMD and clock (measured ceiling 0.32-0.37 with >= 4 waves per SIMD, profiles/r01_valu_issue_rates.txt)",
+           "note": note}
+    return out
+
+
+def kernel_rooflines(eng, launches):
+    """(dominant kernel of the step, all-pairs kernel), each timed alone on the engine's live batch."""
+    from encodermap_amd import _lib
+
+    lay = eng.layout
+    n = len(lay.layers)
+    Z = eng.h[lay.n_enc - 1]
+    Bt = eng.B
+    t_sk = _time_launches(lambda: _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, Bt, eng.sk_ws, eng.split_ws), launches)
+    W = D * Bt * (Bt - 1) / 2          # pair-elements per launch (i<->j symmetry exploited): one multiply-add each in the Gram form
+    sk = _record("sk_tile_f16_kernel", "sk_tile_f16", t_sk, W,
+                 "Gram tiles on rows split into two f16 planes, VALU sigmoid epilogue (~40 instructions per pair); 2 FLOP per "
+                 "pair-element over the upper triangle (SURVEY.md section 8d)", 4 * Bt * (D + 2 * 2 + 2) + 4)
+    recs = [sk]
+    if (eng.rb, eng.re) == (0, Bt) and eng._forward():      # one fused launch (single process / replica ranks)
+        t_ch = _time_launches(eng._forward, launches)
+        dims = [(l.n_in, l.n_out) for l in lay.layers]
+        mults = Bt * (sum(k * m for k, m in dims) + sum(k * m for k, m in dims[lay.n_enc:]))   # forward + the decoder's dX products
+        n_par = sum(k * m + m for k, m in dims)
+        recs.append(_record("chain_kernel<FUSED>", "chain_kernel<FUSED>", t_ch, mults,
+                            "forward of all layers, auto cost and the decoder's backward pass in one launch per 16-row block; weights "
+                            "from the pre-split operand store, activations split in the epilogue; algorithmic bytes: the batch in, "
+                            "activations + deltas out as f16 fragments for the weight-gradient kernel, one pass over the weights",
+                            4 * Bt * D + 4 * Bt * sum(m for _, m in dims) * 2 + 4 * n_par))
+    recs.sort(key=lambda r: -r["kernel_us"])
+    return recs[0], sk
 
 
 def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
@@ -158,6 +205,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dp-mode", default="replica", choices=["replica", "rowblock"])
+    ap.add_argument("--global-batch", type=int, default=B,
+                    help="--dp-mode rowblock: rows of the ONE global batch all ranks share (0: 4096 per rank)")
     ap.add_argument("--one-rank-dp", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL code path (probe, RCCL group, all-reduce) with its one rank -- a self-test, "
                          "not a benchmark configuration")
@@ -185,12 +234,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("LOCAL_RANK", "0")
-    if backend != "nccl":
-        graph_allreduce = False             # only an RCCL all-reduce can be captured
-    elif os.environ.get("EMX_DP_GRAPH_ALLREDUCE") is None:
-        graph_allreduce = multi and probe_graph_allreduce(world)
-    else:
-        graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1"
+    # The all-reduces run EAGERLY between the step's graphs unless EMX_DP_GRAPH_ALLREDUCE=1 asks for the captured form (one graph
+    # per step, eight steps per replay): that form has only ever run with a one-rank RCCL group, so it is opt-in until a run
+    # on two or more GPUs has validated it; asked for, it is still taken only if the child-process probe passes on every rank.
+    probe = None
+    graph_allreduce = False
+    if multi and backend == "nccl" and os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1":
+        probe = probe_graph_allreduce(world)
+        graph_allreduce = probe
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
@@ -210,7 +261,9 @@ def main():
         graph_allreduce = bool(float(flag) == 1.0)
         SequentialEngine._dp_graph_allreduce = graph_allreduce
 
-    p = em.Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
+    rowblock = args.dp_mode == "rowblock" and world > 1
+    batch = (args.global_batch or B * world) if rowblock else B     # rows per engine step: the rank's own batch, or the shared one
+    p = em.Parameters(periodicity=float("inf"), batch_size=batch, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
     dp = DataParallel(rank, world, args.dp_mode) if world > 1 else None
     if multi and world == 1:
         class _OneRank(DataParallel):      # the data-parallel path with the one rank a single GPU allows
@@ -218,7 +271,7 @@ def main():
 
         dp = _OneRank(0, 1, args.dp_mode)
     data = make_blobs(device, N_ROWS, D, seed=1)
-    e = em.EncoderMap(p, __import__("numpy").zeros((B, D), "float32"), read_only=True, device=device, dp=dp)
+    e = em.EncoderMap(p, __import__("numpy").zeros((batch, D), "float32"), read_only=True, device=device, dp=dp)
     eng = e._engine
     eng.set_data(data)                      # 512 MB, resident in HBM before the timed region
 
@@ -241,21 +294,39 @@ def main():
     assert all(l == l and abs(l) != float("inf") for l in losses), "non-finite loss in the benchmark run"
 
     if rank == 0:
-        global_batch = B * world if args.dp_mode == "replica" else B
+        global_batch = batch if rowblock else B * world
+        if rowblock:
+            objective = (f"one sketch-map cost over one global batch of {batch} rows (the single-process objective at that batch size); "
+                         f"dense layers on {world} runs of 16-row blocks, the upper-triangle tiles of the all-pairs pass dealt round-robin")
+            scaling = "strong" if batch == B else "weak"
+        else:
+            objective = (f"mean of {world} independent sketch-map costs over {B} rows each (gradients averaged)" if world > 1
+                         else f"one sketch-map cost over one batch of {B} rows")
+            scaling = "weak"
+        rccl = None
+        if multi and backend == "nccl":
+            try:
+                rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                rccl = None
         out = {
             "metric": "train_samples_per_sec", "value": global_batch * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "steps_per_sec": args.steps / dt, "higher_is_better": True,
-            "scaling": "weak" if args.dp_mode == "replica" else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, batch 4096 per GPU, "
-                                   "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
+            "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
+            "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, "
+                                   + (f"one batch of {batch} rows over all GPUs, " if rowblock else "batch 4096 per GPU, ")
+                                   + "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
                        "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
-                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between two graphs") if multi else None,
+                       "objective": objective,
+                       "ranks_seen": dist.get_world_size() if multi else 1, "backend": backend if multi else None, "rccl_version": rccl,
+                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None,
+                       "graph_allreduce_probe": probe,
                        **({"self_test": f"backend {backend}, one device: {one_device}"} if (one_device or backend != "nccl") else {}),
                        "hip_graph": True},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }
-        out["roofline"] = kernel_roofline(eng, max(args.steps, 50))
+        out["roofline"], out["roofline_all_pairs"] = kernel_rooflines(eng, max(args.steps, 50))
         if world == 1 and not multi and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         # RCCL writes its version banner to the C-level stdout, which is flushed at exit -- behind this line unless it is

@@ -142,10 +142,12 @@ def test_one_rank_over_rccl(tmp_path):
     np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-4)
 
 
-def test_bench_script_with_two_ranks(tmp_path):
-    """bench.py's N > 1 plumbing (rank environment, DataParallel replica mode, barrier, MAX over ranks of the timed region,
-    one JSON line from rank 0) under torch.distributed.run with two ranks -- on this one GPU through its self-test hooks
-    (EMX_BENCH_ONE_DEVICE, EMX_BENCH_BACKEND=gloo; the RCCL path itself needs two GPUs)."""
+@pytest.mark.parametrize("mode,extra,batch,scaling", [("replica", [], 2 * 4096, "weak"), ("rowblock", [], 4096, "strong"),
+                                                       ("rowblock", ["--global-batch", "0"], 2 * 4096, "weak")])
+def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
+    """bench.py's N > 1 plumbing (rank environment, DataParallel modes, barrier, MAX over ranks of the timed region, one JSON
+    line from rank 0 that names its objective and the ranks it saw) under torch.distributed.run with two ranks -- on this one
+    GPU through its self-test hooks (EMX_BENCH_ONE_DEVICE, EMX_BENCH_BACKEND=gloo; the RCCL path itself needs two GPUs)."""
     import json
     import subprocess
     import sys
@@ -153,11 +155,15 @@ def test_bench_script_with_two_ranks(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, EMX_BENCH_ONE_DEVICE="1", EMX_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8"]
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8",
+           "--dp-mode", mode] + extra
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == "weak"
-    assert line["config"]["global_batch"] == 2 * 4096 and line["config"]["parallelism"] == "dp2-replica"
-    assert line["value"] == pytest.approx(2 * 4096 * line["steps_per_sec"], rel=1e-6)
+    assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == scaling
+    cfg = line["config"]
+    assert cfg["global_batch"] == batch and cfg["parallelism"] == f"dp2-{mode}" and cfg["ranks_seen"] == 2
+    assert cfg["allreduce"] == "eager between the step's graphs" and str(batch if mode == "rowblock" else 4096) in cfg["objective"]
+    assert line["value"] == pytest.approx(batch * line["steps_per_sec"], rel=1e-6)
+    assert line["dtype"].startswith("f32") and line["roofline_all_pairs"]["kernel"] == "sk_tile_f16_kernel"
     assert all(np.isfinite(v) for v in line["loss_first_last"]) and "cpu_baseline" not in line
