@@ -47,11 +47,11 @@ SIGNATURES = {
     "emx_last_error": (C.c_char_p, []),
     "emx_target_arch": (C.c_char_p, []),
     "emx_sketchmap_ws_bytes": (_sz, [_i, _i]),
-    "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
-    "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _i, _i, _p, _sz, _p, _p]),
+    "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
+    "emx_sketchmap_tiles": (_i, [_p, _i, _i, _i, _p, _i, _f, _f, C.POINTER(_f), _i, _i, _p, _sz, _p, _p]),
     "emx_sketchmap_split_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_split": (_i, [_p, _i, _i, _i, _p, _p]),
-    "emx_sketchmap_tiles_dealt": (_i, [_p, _i, _i, _i, _p, _i, _f, C.POINTER(_f), _p, _sz, _p, _i, _i, _p]),
+    "emx_sketchmap_tiles_dealt": (_i, [_p, _i, _i, _i, _p, _i, _f, _f, C.POINTER(_f), _p, _sz, _p, _i, _i, _p]),
     "emx_sketchmap_reduce_dealt": (_i, [_i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _i, _i, _p, _p, _sz, _p]),
     "emx_sketchmap_finish": (_i, [_i, _i, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),
     "emx_sketchmap_describe": (_i, [_i, _i, _i, _p, _p, _i, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _sz, _p]),
@@ -291,7 +291,9 @@ def sketchmap_ws_bytes(B: int, L: int) -> int:
     return int(load().emx_sketchmap_ws_bytes(B, L))
 
 
-def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws):
+def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ, ws, data_span=None):
+    """``data_span``: max - min over the data the rows come from, if known (periodic data spanning less than 1.5 periods run
+    the fixed-point tiles; None: the general float form)."""
     lib = load()
     _f32c(Z, "Z"), _f32c(dZ, "dZ")
     assert X.dtype == torch.float32 and X.stride(1) == 1
@@ -299,26 +301,26 @@ def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, ro
     L = Z.shape[1]
     sig_arr = (_f * 6)(*[float(s) for s in sig])
     rc = lib.emx_sketchmap_fwd_bwd(
-        _ptr(X), B, D, X.stride(0), _ptr(Z), L, float(periodicity), sig_arr, float(scale),
+        _ptr(X), B, D, X.stride(0), _ptr(Z), L, float(periodicity), float(data_span or 0.0), sig_arr, float(scale),
         float(center_scale if center_loss is not None else 0.0), int(row_begin), int(row_end),
         _ptr(dist_loss), _ptr(center_loss), _ptr(dZ), _ptr(ws), ws.numel() * ws.element_size(), _stream())
     _check(rc, "emx_sketchmap_fwd_bwd")
 
 
-def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws, split_ws=None):
+def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws, split_ws=None, data_span=None):
     """``split_ws`` (from sketchmap_split / gather_rows / the optimizer's next-batch gather): Gram products on the bf16 cores."""
     B, D = X.shape
     sig_arr = (_f * 6)(*[float(s) for s in sig])
-    _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, int(row_begin),
+    _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), float(data_span or 0.0), sig_arr, int(row_begin),
                                       int(row_end), _ptr(ws), ws.numel() * ws.element_size(), _ptr(split_ws), _stream()),
            "emx_sketchmap_tiles")
 
 
-def sketchmap_tiles_dealt(X, Z, periodicity, sig, ws, split_ws, rank, world):
+def sketchmap_tiles_dealt(X, Z, periodicity, sig, ws, split_ws, rank, world, data_span=None):
     """The symmetric tile pass over the whole batch, this rank's share of the upper-triangle tiles (tile t -> rank t % world)."""
     B, D = X.shape
     sig_arr = (_f * 6)(*[float(s) for s in sig])
-    _check(load().emx_sketchmap_tiles_dealt(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), sig_arr, _ptr(ws),
+    _check(load().emx_sketchmap_tiles_dealt(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), float(data_span or 0.0), sig_arr, _ptr(ws),
                                             ws.numel() * ws.element_size(), _ptr(split_ws), int(rank), int(world), _stream()),
            "emx_sketchmap_tiles_dealt")
 

@@ -302,7 +302,8 @@ class ADCEngine(SequentialEngine):
             lo = self.off_ang if self.use_ang else self.off_dih
             hi = self.off_side + self.S if self.use_ang else self.off_dih + self.n_dih
             _lib.sketchmap_fwd_bwd(self.feat[:, lo:hi], Z, per, p.dist_sig_parameters, float(p.distance_cost_scale), 0.0, 0, B,
-                                   t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws)
+                                   t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws,
+                                   data_span=2.0 * np.pi)   # angles in [0, pi], torsions in (-pi, pi], both made on the device
             self.dZ.add_(self.dZ2)
         _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
         self._wgrad()

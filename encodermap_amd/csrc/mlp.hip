@@ -811,46 +811,86 @@ __global__ __launch_bounds__(64) void mlp_mirror_kernel(const WopArgs wa, const 
 // weight gradients: partial[slice][l] = X_l^T delta_l over the slice's rows, from the fragments the row-block kernels left
 // (aop.h).  grid = (128 x 128 output blocks of all layers) x slices; a wave owns a 64 x 64 quadrant = 2 x 2 tiles of
 // v_mfma_f32_32x32x16_f16 whose reduction index runs over the 16 rows of ONE row block, so both operands of an instruction
-// carry one scale each and the tile is unscaled by a wave-uniform factor when it is added to the accumulator.  Operands go
-// straight from HBM/L2 to the matrix instruction: one 16-byte load per lane and fragment, no LDS, no barrier.
-// db comes from the same fragments through a ones operand (two instructions per column group, row 0 of the result).
+// carry one power-of-two scale each; the row blocks of a slice are brought to the slice's common scales (below) and accumulate
+// in the matrix unit.  Operands go straight from HBM/L2 to the matrix instruction: one 16-byte load per lane and fragment,
+// no LDS, no barrier.
+// db comes from the same (down-shifted) fragments on the VALU: v_dot2_f32_f16 with ones over the lane's eight rows.
 // ---------------------------------------------------------------------------------------------------------
-struct WgradDev {
-  int l0, l1;
-  int K[MAXL], N[MAXL];
-  long w_off[MAXL], b_off[MAXL];
-  AopTensor X[MAXL], D[MAXL];
-  int tile_begin[MAXL + 1];  // prefix sum of 128x128 output blocks per layer (relative to l0)
-  float* partial;            // [n_slices][n_params]
-  long n_params;
+struct WgLayer {               // everything a workgroup needs to know about its layer: ONE 64-byte scalar load
+  const char* xfrag;
+  const float* xrs;
+  const char* dfrag;
+  const float* drs;
+  long w_off, b_off;
+  int K, N, CGx, CGd;
+};
+static_assert(sizeof(WgLayer) == 64, "WgLayer is read with one s_load_dwordx16");
+struct WgHead {                // the first 128 bytes of the arguments: one s_load_dwordx16 x 2, every workgroup's first trip
+  int tile_begin[MAXL + 1];    // prefix sum of 128x128 output blocks per layer (entry i: layer l0 + i); unused entries INT_MAX
+  int nl;                      // number of layers in this launch
   int rb0, rb_end, rbs_per_slice;
-  int has_fin;               // the last blockIdx.x column is not a dW block: its y = 0 workgroup runs the step's scalar epilogue
+  int has_fin;                 // the last blockIdx.x column is not a dW block: its y = 0 workgroup runs the step's scalar epilogue
+  float* partial;              // [n_slices][n_params]
+  long n_params;
+  int pad[10];
+};
+static_assert(sizeof(WgHead) == 128 && MAXL == 12, "WgHead is read with two s_load_dwordx16");
+struct WgradDev {
+  WgHead h;
+  WgLayer lay[MAXL];           // entry i: layer l0 + i
   FinishArgs fin;
 };
+typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+
+#ifdef EMX_CHAIN_TIMING   // timeline of workgroups (0, 0), (0, last slice) and the scalar epilogue: tools/abl_wgrad.py
+#define WSTAMP(k) do { if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1) && (blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) \
+    emx_dbg[4096 + ((blockIdx.x ? 2 : 0) + (blockIdx.y ? 1 : 0)) * 16 + (k)] = wall_clock64(); } while (0)
+#else
+#define WSTAMP(k)
+#endif
 
 __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
+  WSTAMP(0);
   __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
   __shared__ float fin_tl[64];
-  if (a.has_fin && blockIdx.x == gridDim.x - 1) {
+  // Every trip to the kernel arguments costs about as much as one to HBM, and a dependent chain of them is what a short kernel
+  // is made of (the first version made eight before its first fragment load, and one more inside each guarded store).  Two
+  // trips here: the head (both halves requested together, read through the argument segment so that they stay two wide
+  // loads), then the layer's 64-byte record.
+  typedef const u32x16 __attribute__((address_space(4))) * KVec;
+  const KVec kv = (KVec)__builtin_amdgcn_kernarg_segment_ptr();
+  const u32x16 h0 = kv[0], h1 = kv[1];
+  WgHead hd;
+  __builtin_memcpy(&hd, &h0, 64);
+  __builtin_memcpy(reinterpret_cast<char*>(&hd) + 64, &h1, 64);
+  if (hd.has_fin && blockIdx.x == gridDim.x - 1) {
     // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs are complete
     // before this launch starts, and a launch of its own costs ~6.5 us of the step.
     if (blockIdx.y == 0) finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);
+    WSTAMP(5);
     return;
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int l = a.l0;
-  while (l + 1 < a.l1 && (int)blockIdx.x >= a.tile_begin[l + 1 - a.l0]) ++l;
-  const int tb = blockIdx.x - a.tile_begin[l - a.l0];
-  const int Kin = a.K[l], N = a.N[l];
+  int li = 0, tbase = 0;
+#pragma unroll
+  for (int i = 1; i < MAXL; ++i)
+    if ((int)blockIdx.x >= hd.tile_begin[i]) {
+      li = i;
+      tbase = hd.tile_begin[i];
+    }
+  const int tb = blockIdx.x - tbase;
+  const u32x16 lrec = kv[2 + li];
+  WgLayer L;
+  __builtin_memcpy(&L, &lrec, 64);
+  const int Kin = L.K, N = L.N;
   const int nbn = (N + 127) >> 7;
   const int bi = tb / nbn, bj = tb - bi * nbn;
   const int ig0 = 4 * bi + 2 * (wave >> 1), jg0 = 4 * bj + 2 * (wave & 1);   // first column groups of the wave's quadrant
-  const AopTensor X = a.X[l], D = a.D[l];
-  const int CGx = X.CG, CGd = D.CG;
-  const int rbs = a.rb0 + blockIdx.y * a.rbs_per_slice;
-  const int rbe = min(rbs + a.rbs_per_slice, a.rb_end);
-  float* __restrict__ out = a.partial + (long)blockIdx.y * a.n_params;
+  const int CGx = L.CGx, CGd = L.CGd;
+  const int rbs = hd.rb0 + blockIdx.y * hd.rbs_per_slice;
+  const int rbe = min(rbs + hd.rbs_per_slice, hd.rb_end);
+  float* __restrict__ out = hd.partial + (long)blockIdx.y * hd.n_params;
   const bool iact[2] = {ig0 < CGx, ig0 + 1 < CGx}, jact[2] = {jg0 < CGd, jg0 + 1 < CGd};
   const bool do_bias = bi == 0 && (wave >> 1) == 0;
 
@@ -862,92 +902,142 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[u][v][i] = 0.f;
   float bacc[2] = {0.f, 0.f};
-  half8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (_Float16)1.f;
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  const half2v one2 = {(_Float16)1.f, (_Float16)1.f};
 
   if (iact[0] && jact[0]) {
     struct Frags {
       half8 x[2][2], d[2][2];   // [group][plane]
       float sx[2], sd[2];
     };
-    auto load = [&](int rbk, Frags& f) {
-      const int rbc = min(rbk, a.rb_end - 1);
+    auto load = [&](int rbc, Frags& f) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int ig = min(ig0 + u, CGx - 1), jg = min(jg0 + u, CGd - 1);
-        const char* px = X.frag + ((long)rbc * CGx + ig) * 2048 + lane * 16;
-        const char* pd = D.frag + ((long)rbc * CGd + jg) * 2048 + lane * 16;
+        const char* px = L.xfrag + ((long)rbc * CGx + ig) * 2048 + lane * 16;
+        const char* pd = L.dfrag + ((long)rbc * CGd + jg) * 2048 + lane * 16;
         f.x[u][0] = *reinterpret_cast<const half8*>(px);
         f.x[u][1] = *reinterpret_cast<const half8*>(px + 1024);
         f.d[u][0] = *reinterpret_cast<const half8*>(pd);
         f.d[u][1] = *reinterpret_cast<const half8*>(pd + 1024);
-        f.sx[u] = X.rscale[(long)rbc * CGx + ig];
-        f.sd[u] = D.rscale[(long)rbc * CGd + jg];
+        f.sx[u] = L.xrs[(long)rbc * CGx + ig];
+        f.sd[u] = L.drs[(long)rbc * CGd + jg];
       }
     };
-    auto mma = [&](const Frags& f) {
+    // A group of GB row blocks (a 128-row slice is one group).  All fragments of the group are requested before the first
+    // matrix instruction: the slice pays ONE trip to HBM/L2 instead of one per row block (a workgroup is alone on its CU,
+    // one wave per SIMD: the 8 x 36 registers are there).  The blocks' power-of-two scales differ, so each fragment is
+    // shifted DOWN to the group's common scale first (v_pk_mul_f16 by 2^-d: exact while the low plane stays above 2^-24,
+    // i.e. for blocks within 2^10 of the group's largest; beyond that their last bits fall 2^-37 below that largest) --
+    // then the products of all row blocks accumulate inside the matrix unit, four independent accumulators in turn (a
+    // dependent v_mfma_f32_32x32x16_f16 waits 16 passes for its predecessor: back to back on one accumulator the matrix unit
+    // idles half of the time, which is what the per-row-block zero / multiply / scaled add of the first version did).
+    constexpr int GB = 8;
+    auto ratio = [&](float sblk, float sgrp) __attribute__((always_inline)) {   // sblk / sgrp, both powers of two, sblk <= sgrp
+      const int d = min((int)(__float_as_uint(sgrp) >> 23) - (int)(__float_as_uint(sblk) >> 23), 30);
+      return (_Float16)__uint_as_float((unsigned)(127 - d) << 23);
+    };
+    for (int g = rbs; g < rbe; g += GB) {
+      Frags f[GB];
+#pragma unroll
+      for (int q = 0; q < GB; ++q)
+        if (g + q < rbe) load(g + q, f[q]);
+      WSTAMP(1);
+      float Rx[2] = {0.f, 0.f}, Rd[2] = {0.f, 0.f};
+#pragma unroll
+      for (int q = 0; q < GB; ++q)
+        if (g + q < rbe) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            Rx[u] = fmaxf(Rx[u], f[q].sx[u]);
+            Rd[u] = fmaxf(Rd[u], f[q].sd[u]);
+          }
+        }
+      f32x16 ga[2][2];
+      float gb[2] = {0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ga[0][0][i] = ga[0][1][i] = ga[1][0][i] = ga[1][1][i] = 0.f;
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        if (g + q < rbe) {
+          Frags& fq = f[q];
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const _Float16 rx = ratio(fq.sx[u], Rx[u]), rd = ratio(fq.sd[u], Rd[u]);
+            if (rx != (_Float16)1.f) {   // (wave-uniform)
+              fq.x[u][0] *= rx;
+              fq.x[u][1] *= rx;
+            }
+            if (rd != (_Float16)1.f) {
+              fq.d[u][0] *= rd;
+              fq.d[u][1] *= rd;
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {   // small products first: (h, l), (l, h), (h, h)
+            const int px = c == 1 ? 1 : 0, pd = c == 0 ? 1 : 0;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+              for (int v = 0; v < 2; ++v)
+                if (iact[u] && jact[v]) ga[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq.x[u][px], fq.d[v][pd], ga[u][v], 0, 0, 0);
+          }
+          if (do_bias) {   // db: the lane's eight rows of its column, both planes (v_dot2_f32_f16 with ones: exact products, f32 sums)
+#pragma unroll
+            for (int v = 0; v < 2; ++v)
+#pragma unroll
+              for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                  half2v pr = {fq.d[v][pl][e], fq.d[v][pl][e + 1]};
+                  gb[v] = __builtin_amdgcn_fdot2(pr, one2, gb[v], false);
+                }
+          }
+        }
+      }
+      WSTAMP(2);
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int v = 0; v < 2; ++v) {
+          const float sc = Rx[u] * Rd[v];
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[u][v][i] = fmaf(ga[u][v][i], sc, acc[u][v][i]);
+        }
+#pragma unroll
+      for (int v = 0; v < 2; ++v) bacc[v] = fmaf(gb[v], Rd[v], bacc[v]);
+    }
+    WSTAMP(3);
+    // store: tile (u, v), D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31] -- buffer stores: a lane outside
+    // the layer's [K, N] gets an offset beyond the buffer and the hardware drops it (no exec masks, no branches)
+    {
+      float* wbase = out + L.w_off;
+      __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(wbase, 0, Kin * N * 4, 0x00020000);
 #pragma unroll
       for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
           if (iact[u] && jact[v]) {
-            f32x16 d;
+            const int jj = 32 * (jg0 + v) + (lane & 31);
+            const int i0 = 32 * (ig0 + u) + 4 * (lane >> 5);
+            const unsigned vo = jj < N ? (unsigned)((i0 * N + jj) * 4) : 0x80000000u;   // (rows beyond K fall off the end of the buffer)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = 0.f;
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.x[u][0], f.d[v][1], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.x[u][1], f.d[v][0], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(f.x[u][0], f.d[v][0], d, 0, 0, 0);
-            const float sc = f.sx[u] * f.sd[v];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[u][v][i] = fmaf(d[i], sc, acc[u][v][i]);
+            for (int reg = 0; reg < 16; ++reg)
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][v][reg]), rw, vo + ((reg & 3) + 8 * (reg >> 2)) * N * 4, 0, 0);
           }
         }
       if (do_bias) {
+        __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(out + L.b_off, 0, N * 4, 0x00020000);
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-          if (jact[v]) {
-            f32x16 d;
-#pragma unroll
-            for (int i = 0; i < 16; ++i) d[i] = 0.f;
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, f.d[v][1], d, 0, 0, 0);
-            d = __builtin_amdgcn_mfma_f32_32x32x16_f16(ones, f.d[v][0], d, 0, 0, 0);
-            bacc[v] = fmaf(d[0], f.sd[v], bacc[v]);
-          }
+          const float bsum = bacc[v] + __shfl_xor(bacc[v], 32, 64);   // rows 0..7 and 8..15 of the row blocks
+          const int jj = 32 * (jg0 + v) + lane;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rb, (lane < 32 && jact[v]) ? (unsigned)(jj * 4) : 0x80000000u, 0, 0);
         }
-      }
-    };
-    // two fragment sets: set A is loop-carried and reloaded right behind the instructions that consumed it
-    Frags fa, fb;
-    load(rbs, fa);
-    for (int rbk = rbs; rbk < rbe; rbk += 2) {
-      load(rbk + 1, fb);
-      mma(fa);
-      load(rbk + 2, fa);
-      if (rbk + 1 < rbe) mma(fb);
-    }
-    // store: tile (u, v), D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        if (iact[u] && jact[v]) {
-          const int jj = 32 * (jg0 + v) + (lane & 31);
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int ii = 32 * (ig0 + u) + (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5);
-            if (ii < Kin && jj < N) out[a.w_off[l] + (long)ii * N + jj] = acc[u][v][reg];
-          }
-        }
-      }
-    if (do_bias && lane < 32) {
-#pragma unroll
-      for (int v = 0; v < 2; ++v) {
-        const int jj = 32 * (jg0 + v) + lane;
-        if (jact[v] && jj < N) out[a.b_off[l] + jj] = bacc[v];
       }
     }
   }
+  WSTAMP(4);
 }
 
 // g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
@@ -1377,12 +1467,12 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
                   int row_begin, int row_end, float* grad, float* ws, size_t ws_floats, const emx_finish_desc* finish, emx_stream_t stream) {
   const char* who = "emx_mlp_wgrad";
   WgradDev a{};
-  a.has_fin = 0;
+  a.h.has_fin = 0;
   if (finish) {
     int rcf = fill_finish_args(a.fin, finish->jobs, finish->n_jobs, finish->terms, finish->n_terms, finish->history, finish->term_history,
                                finish->capacity, finish->hstep, finish->cursor, finish->counter2, "emx_mlp_wgrad (finish)");
     if (rcf) return rcf;
-    a.has_fin = 1;
+    a.h.has_fin = 1;
   }
   int rc = check_desc(desc, who);
   if (rc) return rc;
@@ -1397,34 +1487,31 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   AopLayout AL;
   aop_layout(desc, aop_rows, AL);
   const int n = desc->n_layers;
-  a.l0 = layer_begin;
-  a.l1 = layer_end;
+  a.h.nl = layer_end - layer_begin;
+  for (int i = 0; i <= MAXL; ++i) a.h.tile_begin[i] = INT_MAX;
   int tiles = 0;
   long lo = -1, hi = 0;
   for (int l = layer_begin; l < layer_end; ++l) {
-    a.K[l] = desc->width[l];
-    a.N[l] = desc->width[l + 1];
-    a.w_off[l] = desc->w_off[l];
-    a.b_off[l] = desc->b_off[l];
-    a.X[l] = aop_tensor(const_cast<void*>(aop), AL, l);          // id 0: the network input, id l = 1 + (l - 1): h_{l-1}
-    a.D[l] = aop_tensor(const_cast<void*>(aop), AL, 1 + n + l);
-    a.tile_begin[l - layer_begin] = tiles;
+    WgLayer& L = a.lay[l - layer_begin];
+    const AopTensor X = aop_tensor(const_cast<void*>(aop), AL, l);          // id 0: the network input, id l = 1 + (l - 1): h_{l-1}
+    const AopTensor Dl = aop_tensor(const_cast<void*>(aop), AL, 1 + n + l);
+    L = WgLayer{X.frag, X.rscale, Dl.frag, Dl.rscale, (long)desc->w_off[l], (long)desc->b_off[l], desc->width[l], desc->width[l + 1], X.CG, Dl.CG};
+    a.h.tile_begin[l - layer_begin] = tiles;
     tiles += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
     const long wl = desc->w_off[l], wh = desc->b_off[l] + desc->width[l + 1];
     lo = (lo < 0) ? wl : std::min(lo, wl);
     hi = std::max(hi, wh);
   }
-  a.tile_begin[layer_end - layer_begin] = tiles;
-  a.partial = ws;
-  a.n_params = n_params;
+  a.h.partial = ws;
+  a.h.n_params = n_params;
   const int rps = wgrad_slice_rows(nrows);
-  a.rb0 = row_begin / 16;
-  a.rb_end = (row_end + 15) / 16;
-  a.rbs_per_slice = rps / 16;
+  a.h.rb0 = row_begin / 16;
+  a.h.rb_end = (row_end + 15) / 16;
+  a.h.rbs_per_slice = rps / 16;
   const int slices = emx_mlp_wgrad_slices(nrows);
   hipStream_t st = (hipStream_t)stream;
   static_assert(FIN_NT == NT, "the scalar epilogue shares the weight-gradient kernel's workgroup size");
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.has_fin, slices), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.h.has_fin, slices), dim3(NT), 0, st, a);
   rc = emx::check_launch("mlp_wgrad_kernel");
   if (rc) return rc;
   if (!grad) return EMX_OK;   // the caller sums the slices itself (emx_adam_step_slices)

@@ -69,6 +69,8 @@ struct SkArgs {
   int symm;
   int vec4;
   float period;
+  float rp_hi, rp_lo, phase_unit2;   // fixed-point periodic tiles: 1 / period in two floats, (period / 2^32)^2
+  int phase_ok;                      // the data span less than 1.5 periods: the fixed-point tiles may run
   SigDev sh, sl;
   SplitRows split;   // optional bf16 planes + norms of the rows (split.h): selects the bf16 Gram kernel
   int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
@@ -143,9 +145,22 @@ __device__ __forceinline__ float minus_abs(float h, float x) {   // h - |x|
   return r;
 }
 
-template <bool PERIODIC>
+// PMODE of the VALU tiles: 0 Euclidean, 1 periodic (float form, any data), 2 periodic on fixed-point phases (data that span
+// less than 1.5 periods, phase_u32 below)
+template <int PMODE>
 __device__ __forceinline__ float acc4(const float4& a, const float4& b, float acc, float period) {
-  if constexpr (PERIODIC) {
+  if constexpr (PMODE == 2) {
+    // the staged values are phases: x / period as a 32-bit fraction of a turn.  The 32-bit difference wraps by itself and,
+    // read as a signed integer, IS the wrapped difference in [-1/2, 1/2) turns: sub, convert, fma -- three instructions
+    // per pair-element instead of four (the sum is scaled by (period / 2^32)^2 once per pair, in front of the epilogue)
+    const uint4 ua = *reinterpret_cast<const uint4*>(&a), ub = *reinterpret_cast<const uint4*>(&b);
+    const float d0 = (float)(int)(ua.x - ub.x), d1 = (float)(int)(ua.y - ub.y), d2 = (float)(int)(ua.z - ub.z),
+                d3 = (float)(int)(ua.w - ub.w);
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  } else if constexpr (PMODE == 1) {
     // min(|d|, p - |d|) = p/2 - | |d| - p/2 |: three subtractions, two of them with a |.| source modifier, instead of two
     // and a v_min_f32, which issues at half the rate of v_sub_f32 on gfx950 (profiles/r01_valu_issue_rates.txt).  Written
     // as instructions: left to itself the compiler pairs the subtractions into v_pk_add_f32, which has no source
@@ -168,6 +183,20 @@ __device__ __forceinline__ float acc4(const float4& a, const float4& b, float ac
     acc = fmaf(d3, d3, acc);
   }
   return acc;
+}
+
+// x / period as a 32-bit fraction of a turn (wrapping), to 2^-32 of a period: t = x * (1 / period) in two floats, its distance
+// from the nearest integer is exact in float32, the rounding error of the product and the low part of 1 / period are added
+// as a second integer.  (Exactly half a turn saturates to 2^31 - 1: one unit.)
+__device__ __forceinline__ unsigned phase_u32(float x, float rp_hi, float rp_lo) {
+  const float t = x * rp_hi;
+  const float fh = t - rintf(t);
+  const float fl = fmaf(x, rp_lo, fmaf(x, rp_hi, -t));
+  return (unsigned)((int)(fh * 4294967296.f) + (int)rintf(fl * 4294967296.f));
+}
+__device__ __forceinline__ float4 phase4(const float4& v, float rp_hi, float rp_lo) {
+  uint4 u = make_uint4(phase_u32(v.x, rp_hi, rp_lo), phase_u32(v.y, rp_hi, rp_lo), phase_u32(v.z, rp_hi, rp_lo), phase_u32(v.w, rp_hi, rp_lo));
+  return *reinterpret_cast<float4*>(&u);
 }
 
 __device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long row, int ldx, int k, int D, bool rowvalid,
@@ -229,7 +258,7 @@ __device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int
   return true;
 }
 
-template <int TM, int TN, int LT, bool PERIODIC, bool FASTSIG>
+template <int TM, int TN, int LT, int PMODE, bool FASTSIG>
 __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   constexpr int RM = TM / 16, RN = TN / 16;
   constexpr int LMAX = LT ? LT : 4;
@@ -285,9 +314,11 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   for (int k0 = 0; k0 < a.D; k0 += KC) {
     __syncthreads();
 #pragma unroll
-    for (int q = 0; q < QI; ++q) *reinterpret_cast<float4*>(&Xi_s[(rb + 32 * q) * LS + 4 * kq]) = pi[q];
+    for (int q = 0; q < QI; ++q)
+      *reinterpret_cast<float4*>(&Xi_s[(rb + 32 * q) * LS + 4 * kq]) = PMODE == 2 ? phase4(pi[q], a.rp_hi, a.rp_lo) : pi[q];
 #pragma unroll
-    for (int q = 0; q < QJ; ++q) *reinterpret_cast<float4*>(&Xj_s[(rb + 32 * q) * LS + 4 * kq]) = pj[q];
+    for (int q = 0; q < QJ; ++q)
+      *reinterpret_cast<float4*>(&Xj_s[(rb + 32 * q) * LS + 4 * kq]) = PMODE == 2 ? phase4(pj[q], a.rp_hi, a.rp_lo) : pj[q];
     __syncthreads();
     if (k0 + KC < a.D) gload(k0 + KC);
 #pragma unroll 2
@@ -299,11 +330,17 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
       for (int c = 0; c < RN; ++c) {
         const float4 bv = *reinterpret_cast<const float4*>(&Xj_s[(tx + 16 * c) * LS + kk]);
 #pragma unroll
-        for (int r = 0; r < RM; ++r) acc[r][c] = acc4<PERIODIC>(av[r], bv, acc[r][c], a.period);
+        for (int r = 0; r < RM; ++r) acc[r][c] = acc4<PMODE>(av[r], bv, acc[r][c], a.period);
       }
     }
   }
   __syncthreads();  // staging LDS is reused for the partial sums below
+  if constexpr (PMODE == 2) {
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) acc[r][c] *= a.phase_unit2;
+  }
 
   // ---- epilogue -----------------------------------------------------------------------------
   float zi[RM][LMAX], zj[RN][LMAX], wr[RM], wc[RN];
@@ -939,19 +976,22 @@ SigDev make_sig(float sig, float aa, float bb) {
   return s;
 }
 
-template <int T, int LT, bool PERIODIC, bool FAST>
+template <int T, int LT, int PMODE, bool FAST>
 void launch_tiles(const SkArgs& a, int ntiles, hipStream_t st) {
-  hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PERIODIC, FAST>), dim3(ntiles), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PMODE, FAST>), dim3(ntiles), dim3(NT), 0, st, a);
 }
 
 template <int T, int LT>
 void dispatch2(const SkArgs& a, int ntiles, bool periodic, bool fast, hipStream_t st) {
-  if (periodic) {
-    if (fast) launch_tiles<T, LT, true, true>(a, ntiles, st);
-    else launch_tiles<T, LT, true, false>(a, ntiles, st);
+  if (periodic && a.phase_ok) {
+    if (fast) launch_tiles<T, LT, 2, true>(a, ntiles, st);
+    else launch_tiles<T, LT, 2, false>(a, ntiles, st);
+  } else if (periodic) {
+    if (fast) launch_tiles<T, LT, 1, true>(a, ntiles, st);
+    else launch_tiles<T, LT, 1, false>(a, ntiles, st);
   } else {
-    if (fast) launch_tiles<T, LT, false, true>(a, ntiles, st);
-    else launch_tiles<T, LT, false, false>(a, ntiles, st);
+    if (fast) launch_tiles<T, LT, 0, true>(a, ntiles, st);
+    else launch_tiles<T, LT, 0, false>(a, ntiles, st);
   }
 }
 
@@ -1022,7 +1062,7 @@ struct SkPlan {
 
 int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6],
               float scale, float center_scale, int row_begin, int row_end, float* dist_loss, float* center_loss,
-              float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who, void* split_ws = nullptr) {
+              float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who, void* split_ws = nullptr, float data_span = 0.f) {
   EMX_REQUIRE(X && Z && ws && sig, "%s: null pointer argument", who);
   EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "%s: bad shape B=%d D=%d ldx=%d", who, B, D, ldx);
   if (L < 1 || L > 8) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..8)", who, L);
@@ -1061,6 +1101,18 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.split = split_ok ? split_view(split_ws, B, D) : SplitRows{};
   a.vec4 = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   a.period = periodicity;
+  // Periodic data that span less than 1.5 periods (angles in [-pi, pi) or [0, 360): every set the reference is used on): all
+  // |x_i - x_j| < 1.5 p, where the reference's min(|d|, p - |d|) squared IS the squared wrapped difference, which the
+  // fixed-point tiles compute.  A wider or unknown span (data_span <= 0) keeps the float form, which follows the reference's
+  // formula for any |d|.  EMX_SK_PHASE=0 forces the float form.
+  static const bool phase_allowed = !(getenv("EMX_SK_PHASE") && atoi(getenv("EMX_SK_PHASE")) == 0);
+  a.phase_ok = (pl.periodic && phase_allowed && data_span > 0.f && data_span < 1.5f * periodicity) ? 1 : 0;
+  {
+    const double rp = pl.periodic ? 1.0 / (double)periodicity : 0.0;
+    a.rp_hi = (float)rp;
+    a.rp_lo = (float)(rp - (double)a.rp_hi);
+    a.phase_unit2 = pl.periodic ? (float)(((double)periodicity / 4294967296.0) * ((double)periodicity / 4294967296.0)) : 0.f;
+  }
   a.sh = make_sig(sig[0], sig[1], sig[2]);
   a.sl = make_sig(sig[3], sig[4], sig[5]);
   pl.ntiles = symm ? a.nbc * (a.nbc + 1) / 2 : a.nbr * a.nbc;
@@ -1248,26 +1300,26 @@ int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, e
   return emx::check_launch("sk_split_kernel");
 }
 
-int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
                           const float sig[6], float scale, float center_scale, int row_begin, int row_end,
                           float* dist_loss, float* center_loss, float* dZ, void* ws, size_t ws_bytes,
                           emx_stream_t stream) {
   EMX_REQUIRE(dist_loss && dZ, "emx_sketchmap_fwd_bwd: null pointer argument");
   SkPlan pl;
   int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, scale, center_scale, row_begin, row_end, dist_loss, center_loss, dZ,
-                     ws, ws_bytes, pl, "emx_sketchmap_fwd_bwd");
+                     ws, ws_bytes, pl, "emx_sketchmap_fwd_bwd", nullptr, data_span);
   if (rc) return rc;
   rc = launch_tiles_plan(pl, (hipStream_t)stream);
   if (rc) return rc;
   return launch_finish_plan(pl, (hipStream_t)stream);
 }
 
-int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
                         const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes, void* split_ws,
                         emx_stream_t stream) {
   SkPlan pl;
   int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, row_begin, row_end, nullptr, nullptr, nullptr, ws, ws_bytes,
-                     pl, "emx_sketchmap_tiles", split_ws);
+                     pl, "emx_sketchmap_tiles", split_ws, data_span);
   if (rc) return rc;
   return launch_tiles_plan(pl, (hipStream_t)stream);
 }
@@ -1286,12 +1338,12 @@ int emx_sketchmap_finish(int B, int D, const float* Z, int L, float periodicity,
 /* Data parallel, symmetric: the all-pairs pass over the WHOLE batch with its upper-triangle tiles dealt
  * to the ranks -- every rank computes 1 / world of the pair work (the rectangle rows x [0, B) of a row-block rank is twice
  * that) and keeps row AND column partials of its tiles. */
-int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6], void* ws,
-                              size_t ws_bytes, void* split_ws, int rank, int world, emx_stream_t stream) {
+int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
+                              const float sig[6], void* ws, size_t ws_bytes, void* split_ws, int rank, int world, emx_stream_t stream) {
   EMX_REQUIRE(world >= 1 && rank >= 0 && rank < world, "emx_sketchmap_tiles_dealt: bad rank %d of %d", rank, world);
   SkPlan pl;
   int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl,
-                     "emx_sketchmap_tiles_dealt", split_ws);
+                     "emx_sketchmap_tiles_dealt", split_ws, data_span);
   if (rc) return rc;
   pl.a.deal_rank = rank;
   pl.a.deal_world = world;

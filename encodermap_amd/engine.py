@@ -208,6 +208,15 @@ class SequentialEngine:
         self.data = data.to(self.device, dtype=torch.float32).contiguous()
         if self.data.shape[1] != self.D:
             raise Exception(f"train data has {self.data.shape[1]} features, the model expects {self.D}")
+        # periodic data: the span of the set, once (one device reduction) -- sets that span less than 1.5 periods run the
+        # all-pairs tiles on fixed-point phases (include/emx.h: data_span of emx_sketchmap_tiles)
+        span = None
+        if self.periodic and self.data.numel():
+            lo, hi = (float(v) for v in torch.aminmax(self.data))
+            span = hi - lo if np.isfinite(hi - lo) else None
+        if span != getattr(self, "_data_span", None):
+            self._graph = None            # the captured step may hold the other tile kernel
+        self._data_span = span
         self._init_batch_stream()
 
     def _init_batch_stream(self) -> None:
@@ -239,6 +248,7 @@ class SequentialEngine:
     _cost_in_forward = True                                          # auto cost inside the forward launch (False: layers too wide)
     _graph_steps = max(1, int(os.environ.get("EMX_GRAPH_STEPS", "8")))   # steps per replay of the multi-step graph (1: single-step graph only)
     _graph_multi = None
+    _data_span = None   # periodic data: max - min over the training set (set_data)
     _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (opt-in)
 
     def _gather_current(self) -> None:
@@ -312,12 +322,13 @@ class SequentialEngine:
         if self._dealt():
             cs = p.center_cost_scale
             _lib.sketchmap_tiles_dealt(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.sk_ws, self.split_ws, self.dp.rank,
-                                       self.dp.world_size)
+                                       self.dp.world_size, data_span=self._data_span)
             _lib.sketchmap_reduce_dealt(self.B, self.D, Z, self.periodicity, p.dist_sig_parameters, float(p.distance_cost_scale),
                                         float(cs) if cs is not None else 0.0, self.rb, self.re, self.dp.rank, self.dp.world_size, self.dZ,
                                         self.sk_ws)
         elif self._use_sketchmap():
-            _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws, self.split_ws)
+            _lib.sketchmap_tiles(self.xb, Z, self.periodicity, p.dist_sig_parameters, self.rb, self.re, self.sk_ws, self.split_ws,
+                                 data_span=self._data_span)
         else:
             cs = p.center_cost_scale
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, self.rb, self.re, self.terms[T_CENTER:T_CENTER + 1], self.dZ, False)

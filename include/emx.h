@@ -67,7 +67,7 @@ const char* emx_target_arch(void);
  * ------------------------------------------------------------------------------------------------ */
 size_t emx_sketchmap_ws_bytes(int B, int L);
 int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L,
-                          float periodicity, const float sig[6], float scale,
+                          float periodicity, float data_span, const float sig[6], float scale,
                           float center_scale, int row_begin, int row_end,
                           float* dist_loss, float* center_loss, float* dZ,
                           void* ws, size_t ws_bytes, emx_stream_t stream);
@@ -75,7 +75,7 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
 /* The two launches of emx_sketchmap_fwd_bwd as separate entry points (per-kernel timing in bench.py, and for
  * callers that want other work between the O(B^2 D) tile pass and the O(B) reduction).  Same arguments; the
  * tile pass leaves per-tile partial sums in `ws`, the finish pass reduces them (scale, center cost, dZ). */
-int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity,
+int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
                         const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes,
                         void* split_ws /* may be NULL; Euclidean distances only */, emx_stream_t stream);
 /* Split rows for emx_sketchmap_tiles: x - x_0 (row 0 of the batch) as three bf16 planes whose sum is the float32 value
@@ -122,8 +122,9 @@ int emx_sketchmap_describe(int B, int D, int ldx, const float* X, const float* Z
  * emx_sketchmap_reduce_dealt then forms, for ALL rows, d cost / d z from this rank's tiles (+ the center cost's gradient on
  * rows [own_begin, own_end)): the SUM over ranks -- one all-reduce of B x L floats -- is the gradient emx_sketchmap_finish
  * would give.  Same workspace as emx_sketchmap_tiles(row_begin = 0, row_end = B). */
-int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, const float sig[6], void* ws,
-                              size_t ws_bytes, void* split_ws /* may be NULL */, int rank, int world, emx_stream_t stream);
+int emx_sketchmap_tiles_dealt(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
+                              const float sig[6], void* ws, size_t ws_bytes, void* split_ws /* may be NULL */, int rank, int world,
+                              emx_stream_t stream);
 int emx_sketchmap_reduce_dealt(int B, int D, const float* Z, int L, float periodicity, const float sig[6], float scale, float center_scale,
                                int own_begin, int own_end, int rank, int world, float* dZ, void* ws, size_t ws_bytes, emx_stream_t stream);
 
@@ -209,8 +210,12 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 /* description of the dense network (see K12 below); declared here because the optimizer keeps the operand store of the
  * dense-layer kernels current */
 #define EMX_MAX_LAYERS 12   /* Dense layers of one network: n_neurons of up to six entries (encoder + mirrored decoder) */
+#ifndef EMX_WGRAD_SLICE_ROWS
 #define EMX_WGRAD_SLICE_ROWS 128   /* rows per weight-gradient slice; doubled until ... */
+#endif
+#ifndef EMX_WGRAD_MAX_SLICES
 #define EMX_WGRAD_MAX_SLICES 32    /* ... at most this many slices remain (emx_mlp_wgrad_slices) */
+#endif
 typedef struct {
   int n_layers;
   int width[EMX_MAX_LAYERS + 1];

@@ -39,14 +39,14 @@ def make_xz(rng, B, Dd, Ld, periodicity, spread=1.0):
     return x.astype(np.float32), z.astype(np.float32)
 
 
-def run_sketchmap(L, x, z, periodicity, sig, scale, center_scale, rb, re):
+def run_sketchmap(L, x, z, periodicity, sig, scale, center_scale, rb, re, data_span=None):
     B, Ld = z.shape
     X, Z = dev(x), dev(z)
     ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
     dist = torch.zeros(1, device="cuda")
     cen = torch.zeros(1, device="cuda") if center_scale is not None else None
     dZ = torch.full((B, Ld), float("nan"), device="cuda")
-    L.sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, rb, re, dist, cen, dZ, ws)
+    L.sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, rb, re, dist, cen, dZ, ws, data_span=data_span)
     torch.cuda.synchronize()
     return float(dist), (float(cen) if cen is not None else None), dZ.cpu().numpy().astype(np.float64)
 
@@ -88,6 +88,63 @@ def test_sketchmap_full_batch(L, B, Dd, Ld, periodicity, sig):
     assert loss == pytest.approx(loss_o, rel=1e-5, abs=1e-9)
     assert cen == pytest.approx(cen_o, rel=1e-5)
     np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
+
+
+@pytest.mark.parametrize("B,Dd,Ld,periodicity,sig,shift", [
+    (64, 10, 2, 2 * PI, DEFAULT_SIG, 0.0),                      # 32 x 32 tiles
+    (300, 12, 2, 2 * PI, DEFAULT_SIG, PI),                      # angles in [0, 2 pi)
+    (1024, 128, 2, 2 * PI, (8.0, 12, 6, 1, 2, 6), 0.0),         # 64 x 64 tiles
+    (700, 33, 8, 360.0, (150.0, 12, 6, 1, 2, 6), 180.0),        # degrees in [0, 360), wide latent, D not a multiple of 4
+    (200, 12, 1, 360.0, (90.0, 10, 5, 1.5, 4, 2), 0.0),         # general sigmoid exponents
+    (600, 7, 3, 2 * PI, DEFAULT_SIG, 0.25 * PI),                # span 1.25 periods: data in [-pi + pi/4, pi + pi/2)
+])
+def test_sketchmap_periodic_fixed_point_tiles(L, B, Dd, Ld, periodicity, sig, shift):
+    """Periodic data whose span is known to be below 1.5 periods (``data_span``) run the tile pass on 32-bit phases (wrapping
+    integer differences); without it the float form of the reference's min(|d|, p - |d|).  Both are the float64 oracle to the
+    kernel's tolerance, and they are not the same launch (the results differ in the last bits)."""
+    rng = np.random.default_rng(B + Dd)
+    x, z = make_xz(rng, B, Dd, Ld, periodicity, 1.0)
+    x = x + np.float32(shift)
+    if shift == 0.25 * PI:
+        x[::2] += np.float32(0.25 * PI)
+    x[0, 0], x[1, 0] = x.min(), x.min() + np.float32(periodicity / 2)        # a pair exactly half a period apart
+    x[2] = x[3]
+    span = float(x.max() - x.min())
+    assert span < 1.5 * periodicity
+    loss_o, g_o = D.sketchmap_fwd_bwd(x, z, periodicity, sig, scale=500.0)
+    res = {}
+    for name, ds in (("float", None), ("phase", span)):
+        loss, _, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, None, 0, B, data_span=ds)
+        assert loss == pytest.approx(loss_o, rel=1e-5, abs=1e-9), name
+        np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12, err_msg=name)
+        res[name] = (loss, g)
+    assert res["float"][0] != res["phase"][0] or not np.array_equal(res["float"][1], res["phase"][1])
+    # row blocks (the asymmetric rectangle path) on phases
+    rb, re = B // 3, B - 5
+    lo_o, gb_o = D.sketchmap_fwd_bwd(x, z, periodicity, sig, 500.0, rb, re)
+    lo, _, gb = run_sketchmap(L, x, z, periodicity, sig, 500.0, None, rb, re, data_span=span)
+    assert lo == pytest.approx(lo_o, rel=1e-5)
+    np.testing.assert_allclose(gb[rb:re], gb_o[rb:re], rtol=0, atol=2e-5 * np.abs(gb_o).max())
+
+
+def test_sketchmap_wide_span_keeps_the_reference_formula(L):
+    """Data that span more than 1.5 periods: the reference's min(|d|, p - |d|) goes NEGATIVE beyond one period and is squared
+    -- not the wrapped distance.  The float tiles follow it for any span; a span of 1.5 periods or more (or none given) selects
+    them.  The phase tiles would compute the wrapped distance: forced on this data (by understating the span) they must
+    disagree with the reference formula -- the gate is what keeps parity."""
+    rng = np.random.default_rng(9)
+    B, Dd, p = 300, 6, 2 * PI
+    x = rng.uniform(-1.6 * p, 1.6 * p, (B, Dd)).astype(np.float32)
+    z = rng.normal(0, 1, (B, 2)).astype(np.float32)
+    span = float(x.max() - x.min())
+    assert span > 1.5 * p
+    loss_o, g_o = D.sketchmap_fwd_bwd(x, z, p, DEFAULT_SIG, scale=500.0)
+    for ds in (None, span, 1.5 * p):
+        loss, _, g = run_sketchmap(L, x, z, p, DEFAULT_SIG, 500.0, None, 0, B, data_span=ds)
+        assert loss == pytest.approx(loss_o, rel=1e-5)
+        np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max())
+    loss_w, _, _ = run_sketchmap(L, x, z, p, DEFAULT_SIG, 500.0, None, 0, B, data_span=1.0)
+    assert abs(loss_w - loss_o) > 1e-3 * abs(loss_o)
 
 
 @pytest.mark.parametrize("B,Dd,periodicity,blocks", [

@@ -27,7 +27,8 @@ def timeit(fn, reps=50):
 print("B", B, "D", D)
 print("forward  us", timeit(lambda: _lib.mlp_forward(plan, 0, n, x, 0, B)))
 print("backward us", timeit(lambda: _lib.mlp_backward(plan, 0, n, dY, dZ, lay.n_enc - 1, 0, B)))
-print("wgrad    us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, 0, B, g, ws)))
+print("wgrad (+ reduce) us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, 0, B, g, ws)))
+print("wgrad (slices only) us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, 0, B, None, ws)))
 cost = _lib.make_auto_cost(x, D, 0, D, False, float("inf"), "mean_abs", 1.0, B, dl[-1], cost_ws)
 print("forward + cost + decoder backward us", timeit(lambda: _lib.mlp_forward_backward(plan, 0, n, x, 0, B, cost, lay.n_enc, dbelow=dlat)))
 print("encoder backward us", timeit(lambda: _lib.mlp_backward(plan, 0, lay.n_enc, dlat, dZ, lay.n_enc - 1, 0, B)))
@@ -36,4 +37,6 @@ for l in range(n):
     src = x if l == 0 else h[l - 1]
     print(f"forward layer {l} ({lay.layers[l].n_in}->{lay.layers[l].n_out}) us", timeit(lambda: _lib.mlp_forward(plan, l, l + 1, src, 0, B, train=False)))
 for l in range(n):
-    print(f"wgrad layer {l} us", timeit(lambda: _lib.mlp_wgrad(plan, l, l + 1, 0, B, g, ws)))
+    print(f"wgrad layer {l} (slices only) us", timeit(lambda: _lib.mlp_wgrad(plan, l, l + 1, 0, B, None, ws)))
+for rows in (128, 512, 1024, 2048):
+    print(f"wgrad rows [0, {rows}) (slices only) us", timeit(lambda: _lib.mlp_wgrad(plan, 0, n, 0, rows, None, ws)))
