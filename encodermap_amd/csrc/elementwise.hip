@@ -30,9 +30,13 @@ namespace {
 #ifdef EMX_CHAIN_TIMING   // in-kernel timelines of the two scalar-ish kernels of a step (tools/abl_finish.py)
 __device__ long long emx_dbg_fin[64];
 #define FSTAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0) emx_dbg_fin[k] = clock64(); } while (0)
+#define ASTAMP(k, blk) do { if (threadIdx.x == 0 && (int)blockIdx.x == (blk)) emx_dbg_fin[k] = wall_clock64(); } while (0)
 #endif
 
 }  // namespace
+#ifndef ASTAMP
+#define ASTAMP(k, blk)
+#endif
 #include "finish.h"   // (after FSTAMP)
 namespace {
 
@@ -103,6 +107,85 @@ __device__ __forceinline__ void gather_rows_body(const GatherArgs& g, int wave, 
         sincos_bounded(v * g.ang_scale, &s, &c);
         g.xin[(long)b * 2 * D + k] = s;
         g.xin[(long)b * 2 * D + D + k] = c;
+      }
+    }
+  }
+}
+
+// The same for the optimizer launch, where the gather is on the critical path of a short kernel: TWO rows per wave, one per
+// half-wave, 16 bytes per lane (a 128-column row is ONE load per lane, and the wave's dependent trips to memory -- cursor, row
+// indices, rows -- serve two rows).  Half as many waves as rows: with one wave per row the launch was more waves than the
+// chip holds at once, and the last rows started when the first were done.  Needs D % 4 == 0 and 16-byte aligned rows.
+__device__ __forceinline__ void gather_rows2_body(const GatherArgs& g, int wave, int nwaves, int lane) {
+  const int64_t* __restrict__ idx = g.idx;
+  if (g.cursor) {
+    const long batch = *g.cursor + g.batch_step;
+    if (g.n_batches > 0 && batch >= g.n_batches) return;
+    idx += batch * (long)g.B;
+  }
+  const int D = g.D, half = lane >> 5, l32 = lane & 31;
+  const bool split = g.split.planes != nullptr;
+  for (int b0 = 2 * wave; b0 < g.B; b0 += 2 * nwaves) {
+    const int b = b0 + half;
+    const bool live = b < g.B;
+    const long irow = idx[min(b, g.B - 1)], iref = idx[0];
+    const float4* __restrict__ src = reinterpret_cast<const float4*>(g.data + irow * (long)D);
+    const float4* __restrict__ ref = reinterpret_cast<const float4*>(g.data + iref * (long)D);
+    const int D4 = D >> 2;
+    float sc = 1.f;
+    if (split) {
+      float nrm = 0.f, mx = 0.f;
+#pragma unroll 2
+      for (int k4 = l32; k4 < D4; k4 += 32) {
+        const float4 x = src[k4], r = ref[k4];
+        const float v0 = x.x - r.x, v1 = x.y - r.y, v2 = x.z - r.z, v3 = x.w - r.w;
+        nrm = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, nrm))));
+        mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
+      }
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) {   // (within the half-wave)
+        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+        nrm += __shfl_xor(nrm, o, 64);
+      }
+      int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;   // as split_row
+      E = mx > 0.f ? min(max(E, -100), 100) : 14;
+      sc = __uint_as_float((uint32_t)(127 + 14 - E) << 23);
+      if (l32 == 0 && live) {
+        g.split.norms[b] = nrm;
+        g.split.rscale[b] = __uint_as_float((uint32_t)(127 - 14 + E) << 23);
+      }
+    }
+    const int k4end = split ? max(g.split.ld >> 2, D4) : D4;
+    for (int k4 = l32; k4 < k4end; k4 += 32) {
+      if (!live) continue;
+      const bool in = k4 < D4;
+      const float4 x = in ? src[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = 4 * k4;
+      if (split && k < g.split.ld) {
+        const float4 r = in ? ref[k4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float v[4] = {(x.x - r.x) * sc, (x.y - r.y) * sc, (x.z - r.z) * sc, (x.w - r.w) * sc};   // exact scaling
+        uint16_t hb[4], lb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const _Float16 h = (_Float16)v[i];
+          hb[i] = f16_bits(h);
+          lb[i] = f16_bits((_Float16)(v[i] - (float)h));
+        }
+        uint16_t* o = g.split.planes + split_index(g.split, b, k);   // (k % 4 == 0: the four halves are adjacent, 8-byte aligned)
+        *reinterpret_cast<uint2*>(o) = make_uint2(hb[0] | ((unsigned)hb[1] << 16), hb[2] | ((unsigned)hb[3] << 16));
+        *reinterpret_cast<uint2*>(o + g.split.plane_stride) = make_uint2(lb[0] | ((unsigned)lb[1] << 16), lb[2] | ((unsigned)lb[3] << 16));
+      }
+      if (in) {
+        if (g.xb) reinterpret_cast<float4*>(g.xb + (long)b * D)[k4] = x;
+        if (g.xin) {
+          float4 sn, cs;
+          sincos_bounded(x.x * g.ang_scale, &sn.x, &cs.x);
+          sincos_bounded(x.y * g.ang_scale, &sn.y, &cs.y);
+          sincos_bounded(x.z * g.ang_scale, &sn.z, &cs.z);
+          sincos_bounded(x.w * g.ang_scale, &sn.w, &cs.w);
+          reinterpret_cast<float4*>(g.xin + (long)b * 2 * D)[k4] = sn;
+          reinterpret_cast<float4*>(g.xin + (long)b * 2 * D + D)[k4] = cs;
+        }
       }
     }
   }
@@ -263,7 +346,16 @@ struct AdamArgs {
   WopArgs mir;
   int bias_item_begin[EMX_MAX_LAYERS + 1];   // with a store: work items behind the 32 x 32 kernel blocks, 64 bias elements each
   long b_off[EMX_MAX_LAYERS];
+  struct Layer {        // what a slab or bias item needs of its layer: one 64-byte scalar load, indexed by the layer found from
+    int K, N;           // the two tables above with static indices (a chain of dependent trips to the kernel arguments is
+    int item_begin;     // what made this kernel long: it has ~250 instructions of work per wave)
+    int bias_item_begin;
+    long w_off, b_off, fwd_unit, bwd_unit;
+    long pad[2];
+  } lay[EMX_MAX_LAYERS];
+  int n_items;          // with a store: slab + bias items
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
+  int next_vec4;        // the rows, xb and xin allow 16-byte lanes: two rows per wave (gather_rows2_body)
   GatherArgs next;
 
   // optional (emx_adam_step_history): the LAST workgroup of the launch writes the history row of the step whose counters are
@@ -355,6 +447,9 @@ __device__ __forceinline__ float grad1(const AdamArgs& a, long i) {
 __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   __shared__ float red[NT / 64];
   const int nt = blockDim.x;
+  ASTAMP(32, 0);
+  ASTAMP(40, a.adam_blocks);
+  ASTAMP(42, (int)gridDim.x - 2);
   if (a.hstep && blockIdx.x == gridDim.x - 1) {
     if (threadIdx.x == 0) {
       const long hs = *a.hstep - 1;
@@ -374,7 +469,10 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
     // beside it, on other CUs, instead of in a launch of their own at the head of the next step
     const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks - (a.hstep ? 1 : 0);
-    gather_rows_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
+    if (a.next_vec4) gather_rows2_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
+    else gather_rows_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
+    ASTAMP(41, a.adam_blocks);
+    ASTAMP(43, (int)gridDim.x - 2);
     return;
   }
   const int nblk = a.adam_blocks;
@@ -398,19 +496,39 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     __shared__ __align__(16) _Float16 img[512];
     const int lane = threadIdx.x & 63;
     const long tcur = step_now + (a.late ? 0 : 1);   // index of this update
-    const int n_blocks = a.mir.item_begin[a.mir.n_layers], n_items = a.bias_item_begin[a.mir.n_layers];
+    typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
+    typedef const u32x16 __attribute__((address_space(4))) * KVec;
+    typedef const char __attribute__((address_space(4))) * KBytes;
+    const KBytes kbase = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(AdamArgs, lay);
+    static_assert(sizeof(AdamArgs::Layer) == 64, "one s_load_dwordx16 per layer record");
+    auto layer_record = [&](int l) __attribute__((always_inline)) {
+      const u32x16 v = *(KVec)(kbase + 64 * l);
+      AdamArgs::Layer L;
+      __builtin_memcpy(&L, &v, 64);
+      return L;
+    };
+    const int n_layers = a.mir.n_layers, n_blocks = a.mir.item_begin[n_layers], n_items = a.n_items;
     for (int item = blockIdx.x; item < n_items; item += nblk) {
       if (item < n_blocks) {
-        int l, k8, nb;
-        wop_item(a.mir, item, l, k8, nb);
-        const int K = a.mir.K[l], N = a.mir.N[l];
-        const long woff = a.mir.w_off[l];
+        int l = 0;
+#pragma unroll
+        for (int i = 1; i < EMX_MAX_LAYERS; ++i) l += (item >= a.mir.item_begin[i]) ? 1 : 0;   // (entries beyond the net: INT_MAX)
+        const AdamArgs::Layer L = layer_record(l);
+        const int K = L.K, N = L.N;
+        const long woff = L.w_off;
+        const int rel = item - L.item_begin, NB = groups32(N);
+        const int k8 = rel / NB, nb = rel - k8 * NB;
         const int kr = lane >> 3, c4 = lane & 7;
         const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
-        // the layer's scale: from the largest |w| the PREVIOUS update recorded (wop.h)
+        // the layer's scale: from the largest |w| the PREVIOUS update recorded (wop.h); both slots are requested with the
+        // operands (which one is the previous update's depends on the step counter, itself still on its way)
         WopHeader* hdr = wop_header(a.mirror, l);
-        const unsigned long long prev = hdr->slot[(tcur + 1) & 1];
-        const unsigned long long mine_so_far = hdr->slot[tcur & 1];
+        if (K > 0) ASTAMP(38, 0);
+        const unsigned long long slot0 = hdr->slot[0], slot1 = hdr->slot[1];
+        WopArgs wl;          // the layer as layer 0 of a one-layer view: static indices, registers
+        wl.n_layers = 1;
+        wl.K[0] = K, wl.N[0] = N, wl.w_off[0] = woff, wl.fwd_unit[0] = L.fwd_unit, wl.bwd_unit[0] = L.bwd_unit;
+        wl.units_begin = a.mir.units_begin;
         float wv[4];
         if (vec && (N & 3) == 0 && (woff & 3) == 0 && k < K && c + 3 < N) {
           const long i4 = (woff + (long)k * N + c) >> 2;
@@ -420,6 +538,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
           const float4 l4 = a.l2coef ? reinterpret_cast<const float4*>(a.l2coef)[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
           const float4 g4 = grad4(a, i4);
           const float alpha = alpha_of(step_now);
+          ASTAMP(33, 0);
           adam_one(w4.x, g4.x, m4.x, v4.x, l4.x, a, alpha, reg);
           adam_one(w4.y, g4.y, m4.y, v4.y, l4.y, a, alpha, reg);
           adam_one(w4.z, g4.z, m4.z, v4.z, l4.z, a, alpha, reg);
@@ -445,9 +564,12 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
             wv[i] = wn;
           }
         }
+        const unsigned long long prev = (tcur & 1) ? slot0 : slot1, mine_so_far = (tcur & 1) ? slot1 : slot0;
         float ws_, wrs_;
         pow2_scale_bits<WOP_TOP>((unsigned)prev, ws_, wrs_);
-        const unsigned bmax = wop_write_slab(a.mir, a.mirror, l, k8, nb, wv, ws_, lane, img);
+        ASTAMP(34, 0);
+        const unsigned bmax = wop_write_slab(wl, a.mirror, 0, k8, nb, wv, ws_, lane, img);
+        ASTAMP(35, 0);
         if (lane == 0) {
           // record this update's maximum for the next one; most slabs find a larger record of this update already there
           const unsigned long long rec = ((unsigned long long)tcur << 32) | bmax;
@@ -456,10 +578,13 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
         }
       } else {
         int l = 0;
-        while (l + 1 < a.mir.n_layers && item >= a.bias_item_begin[l + 1]) ++l;
-        const int j = (item - a.bias_item_begin[l]) * 64 + lane;
-        if (j < a.mir.N[l]) {
-          const long e = a.b_off[l] + j;
+#pragma unroll
+        for (int i = 1; i < EMX_MAX_LAYERS; ++i) l += (item >= a.bias_item_begin[i]) ? 1 : 0;
+        l = min(l, n_layers - 1);
+        const AdamArgs::Layer L = layer_record(l);
+        const int j = (item - L.bias_item_begin) * 64 + lane;
+        if (j < L.N) {
+          const long e = L.b_off + j;
           float wn = a.w[e], mm = a.m[e], vv = a.v[e];
           adam_one(wn, grad1(a, e), mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha_of(step_now), reg);
           a.w[e] = wn;
@@ -500,6 +625,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     }
   }
   FSTAMP(19);
+  ASTAMP(36, 0);
   reg = wave_sum(reg);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = reg;
   __syncthreads();
@@ -509,6 +635,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     a.ws[blockIdx.x] = tsum;
   }
   FSTAMP(20);
+  ASTAMP(37, 0);
   if (blockIdx.x == 0)
     for (int i = nblk + threadIdx.x; i < EMX_REDUCE_WS; i += nt) a.ws[i] = 0.f;
 }
@@ -708,7 +835,14 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 
 namespace {
 constexpr int ADAM_NT = 64;   // one wave per workgroup (see adam_kernel)
-inline int gather_blocks(const emx_next_batch* next) { return next ? (int)std::min<long>(next->B, 8192) : 0; }   // one row per wave
+inline bool gather_vec4(const emx_next_batch* next) {
+  return next && next->D % 4 == 0 && ((reinterpret_cast<uintptr_t>(next->data) | reinterpret_cast<uintptr_t>(next->xb) |
+                                       reinterpret_cast<uintptr_t>(next->xin)) & 15) == 0;
+}
+inline int gather_blocks(const emx_next_batch* next) {   // two rows per wave, or one
+  if (!next) return 0;
+  return (int)std::min<long>(gather_vec4(next) ? (next->B + 1) / 2 : next->B, 8192);
+}
 
 int check_next(const emx_next_batch* next, const char* who) {
   if (!next) return EMX_OK;
@@ -734,18 +868,23 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
     a.next = GatherArgs{next->data, next->D, next->idx, next->cursor, next->B, 1, next->n_batches,
                         periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin, SplitRows{}};
     if (next->split_ws) a.next.split = split_view(next->split_ws, next->B, next->D);
+    a.next_vec4 = gather_vec4(next) ? 1 : 0;
   }
   a.mirror = (mirror_desc && mirror) ? reinterpret_cast<char*>(mirror) : nullptr;
   if (a.mirror) {
     fill_wop_args(mirror_desc, a.mir);
     int items = a.mir.item_begin[mirror_desc->n_layers];
-    for (int l = 0; l <= mirror_desc->n_layers; ++l) {
+    for (int l = 0; l <= EMX_MAX_LAYERS; ++l) {
       a.bias_item_begin[l] = items;
       if (l < mirror_desc->n_layers) {
         a.b_off[l] = mirror_desc->b_off[l];
+        a.lay[l] = AdamArgs::Layer{a.mir.K[l], a.mir.N[l], a.mir.item_begin[l], items, a.mir.w_off[l], (long)mirror_desc->b_off[l],
+                                   a.mir.fwd_unit[l], a.mir.bwd_unit[l], {0, 0}};
         items += (mirror_desc->width[l + 1] + 63) / 64;
       }
     }
+    a.n_items = items;
+    for (int l = mirror_desc->n_layers + 1; l <= EMX_MAX_LAYERS; ++l) a.mir.item_begin[l] = INT_MAX;
   }
   a.w = w;
   a.g = g;

@@ -908,20 +908,25 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
   if (iact[0] && jact[0]) {
     struct Frags {
       half8 x[2][2], d[2][2];   // [group][plane]
-      float sx[2], sd[2];
     };
+    // Fragment loads: buffer loads with the lane's 16 bytes as the vector offset and the fragment's position as the SCALAR
+    // offset (one s_add per load instead of a 64-bit multiply-add per lane: at one wave per SIMD every instruction of the
+    // wave costs ~7 clocks of the slice's time).  The blocks' scales come with ONE vector load per tensor for the whole group
+    // (lane 2 q + u: row block q, column group u), read back with v_readlane into scalar registers.
+    const int igc[2] = {min(ig0, CGx - 1), min(ig0 + 1, CGx - 1)}, jgc[2] = {min(jg0, CGd - 1), min(jg0 + 1, CGd - 1)};
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(L.xfrag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(L.dfrag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rXs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.xrs), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.drs), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
     auto load = [&](int rbc, Frags& f) __attribute__((always_inline)) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
-        const int ig = min(ig0 + u, CGx - 1), jg = min(jg0 + u, CGd - 1);
-        const char* px = L.xfrag + ((long)rbc * CGx + ig) * 2048 + lane * 16;
-        const char* pd = L.dfrag + ((long)rbc * CGd + jg) * 2048 + lane * 16;
-        f.x[u][0] = *reinterpret_cast<const half8*>(px);
-        f.x[u][1] = *reinterpret_cast<const half8*>(px + 1024);
-        f.d[u][0] = *reinterpret_cast<const half8*>(pd);
-        f.d[u][1] = *reinterpret_cast<const half8*>(pd + 1024);
-        f.sx[u] = L.xrs[(long)rbc * CGx + ig];
-        f.sd[u] = L.drs[(long)rbc * CGd + jg];
+        const int ox = (rbc * CGx + igc[u]) * 2048, od = (rbc * CGd + jgc[u]) * 2048;
+        f.x[u][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ox, 0));
+        f.x[u][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rX, lane16, ox + 1024, 0));
+        f.d[u][0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rD, lane16, od, 0));
+        f.d[u][1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rD, lane16, od + 1024, 0));
       }
     };
     // A group of GB row blocks (a 128-row slice is one group).  All fragments of the group are requested before the first
@@ -933,26 +938,34 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
     // dependent v_mfma_f32_32x32x16_f16 waits 16 passes for its predecessor: back to back on one accumulator the matrix unit
     // idles half of the time, which is what the per-row-block zero / multiply / scaled add of the first version did).
     constexpr int GB = 8;
-    auto ratio = [&](float sblk, float sgrp) __attribute__((always_inline)) {   // sblk / sgrp, both powers of two, sblk <= sgrp
-      const int d = min((int)(__float_as_uint(sgrp) >> 23) - (int)(__float_as_uint(sblk) >> 23), 30);
+    auto ratio = [&](unsigned sblk, unsigned sgrp) __attribute__((always_inline)) {   // sblk / sgrp: bit patterns of powers of two, sblk <= sgrp
+      const int d = min((int)(sgrp >> 23) - (int)(sblk >> 23), 30);
       return (_Float16)__uint_as_float((unsigned)(127 - d) << 23);
     };
     for (int g = rbs; g < rbe; g += GB) {
       Frags f[GB];
+      // (bit patterns: the scales are positive, unsigned order = float order)
+      const int sq = min(g + ((lane >> 1) & (GB - 1)), rbe - 1), su = lane & 1;
+      // (buffer loads: a pointer out of the copied record is a generic one, and a flat load makes every later wait a full one)
+      const unsigned vsx = __builtin_amdgcn_raw_buffer_load_b32(rXs, (sq * CGx + (su ? igc[1] : igc[0])) * 4, 0, 0);
+      const unsigned vsd = __builtin_amdgcn_raw_buffer_load_b32(rDs, (sq * CGd + (su ? jgc[1] : jgc[0])) * 4, 0, 0);
+      // (the memory counter of a wave counts to 63: the scales and seven row blocks are requested here, the eighth behind
+      //  the first one's products, so that every wait names the loads it needs and the products start with the first arrival;
+      //  row blocks beyond the slice repeat its last one -- straight-line requests, their products are skipped)
 #pragma unroll
-      for (int q = 0; q < GB; ++q)
-        if (g + q < rbe) load(g + q, f[q]);
+      for (int q = 0; q < GB - 1; ++q) load(min(g + q, rbe - 1), f[q]);
       WSTAMP(1);
-      float Rx[2] = {0.f, 0.f}, Rd[2] = {0.f, 0.f};
+      unsigned sx[GB][2], sd[GB][2], Rxb[2] = {0u, 0u}, Rdb[2] = {0u, 0u};
 #pragma unroll
       for (int q = 0; q < GB; ++q)
-        if (g + q < rbe) {
 #pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            Rx[u] = fmaxf(Rx[u], f[q].sx[u]);
-            Rd[u] = fmaxf(Rd[u], f[q].sd[u]);
-          }
+        for (int u = 0; u < 2; ++u) {   // (row blocks beyond the slice repeat its last one: the maxima are the slice's)
+          sx[q][u] = (unsigned)__builtin_amdgcn_readlane((int)vsx, 2 * q + u);
+          sd[q][u] = (unsigned)__builtin_amdgcn_readlane((int)vsd, 2 * q + u);
+          Rxb[u] = max(Rxb[u], sx[q][u]);
+          Rdb[u] = max(Rdb[u], sd[q][u]);
         }
+      const float Rx[2] = {__uint_as_float(Rxb[0]), __uint_as_float(Rxb[1])}, Rd[2] = {__uint_as_float(Rdb[0]), __uint_as_float(Rdb[1])};
       f32x16 ga[2][2];
       float gb[2] = {0.f, 0.f};
 #pragma unroll
@@ -963,7 +976,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
           Frags& fq = f[q];
 #pragma unroll
           for (int u = 0; u < 2; ++u) {
-            const _Float16 rx = ratio(fq.sx[u], Rx[u]), rd = ratio(fq.sd[u], Rd[u]);
+            const _Float16 rx = ratio(sx[q][u], Rxb[u]), rd = ratio(sd[q][u], Rdb[u]);
             if (rx != (_Float16)1.f) {   // (wave-uniform)
               fq.x[u][0] *= rx;
               fq.x[u][1] *= rx;
@@ -994,6 +1007,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
                 }
           }
         }
+        if (q == 0) load(min(g + GB - 1, rbe - 1), f[GB - 1]);
       }
       WSTAMP(2);
 #pragma unroll
