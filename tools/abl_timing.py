@@ -22,6 +22,11 @@ if mode == "fused":
     cost = _lib.make_auto_cost(x, D, 0, D, False, float("inf"), "mean_square", 1.0, B, dl[-1], cws)
     for _ in range(20): _lib.mlp_forward_backward(plan, 0, n, x, 0, B, cost, lay.n_enc, dbelow=dlat)
     n = n + 3   # units: 6 forward + 3 backward
+elif mode == "bwd":     # the encoder's backward launch of the step (latent gradient joined in)
+    dlat = torch.randn(B, 2, device="cuda"); dZ = torch.randn(B, 2, device="cuda")
+    _lib.mlp_forward(plan, 0, n, x, 0, B)
+    for _ in range(20): _lib.mlp_backward(plan, 0, lay.n_enc, dlat, dZ, lay.n_enc - 1, 0, B)
+    n = lay.n_enc
 else:
     for _ in range(20): _lib.mlp_forward(plan, 0, n, x, 0, B)
 torch.cuda.synchronize()

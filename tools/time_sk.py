@@ -23,6 +23,9 @@ if per == float("inf") and os.environ.get("EMX_TIME_SK_F32", "0") != "1":   # th
     split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")
     _lib.sketchmap_split(X, split)
 reps = 30
+span = float(os.environ["EMX_TIME_SK_SPAN"]) if os.environ.get("EMX_TIME_SK_SPAN") else None   # data_span: selects the periodic tile form
+_tiles = _lib.sketchmap_tiles
+_lib.sketchmap_tiles = lambda *a: _tiles(*a, data_span=span)
 for _ in range(3): _lib.sketchmap_tiles(X, Z, per, sig, 0, B, ws, split)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()

@@ -9,10 +9,12 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 
-enum { FMA, PKFMA, SUB, SUBABS, MINF, PKADD, PKMUL, EXP, LOG, RSQ, RCP, SQRT, CVTI, SUBU, RNDNE, MIX_EUC, MIX_EUC_PK, MIX_PER, MIX_INT, NOPS };
+enum { FMA, PKFMA, SUB, SUBABS, MINF, PKADD, PKMUL, EXP, LOG, RSQ, RCP, SQRT, CVTI, SUBU, RNDNE, MIX_EUC, MIX_EUC_PK, MIX_PER, MIX_INT, SUBCLAMP, MIX_FLOAT3, MIX_RELU, MIX_RELU_PK, MIX_FLOAT3_PK, NOPS };
 const char* NAMES[] = {"v_fma_f32", "v_pk_fma_f32", "v_sub_f32", "v_sub_f32 |abs|(vop3)", "v_min_f32", "v_pk_add_f32", "v_pk_mul_f32",
   "v_exp_f32", "v_log_f32", "v_rsq_f32", "v_rcp_f32", "v_sqrt_f32", "v_cvt_f32_i32", "v_sub_u32", "v_rndne_f32",
-  "mix: sub+fma", "mix: pk_add+pk_fma", "mix: sub,sub|abs|,min,fma", "mix: sub_u32,cvt,fma"};
+  "mix: sub+fma", "mix: pk_add+pk_fma", "mix: sub,sub|abs|,min,fma", "mix: sub_u32,cvt,fma",
+  "v_sub_f32 |abs| clamp (vop3)", "mix: sub,sub|abs|,sub|abs|,fma", "mix: sub,sub|abs|clamp,add", "mix: 2x(sub,sub|abs|clamp),pk_add",
+  "mix: 2x(sub,sub|abs|,sub|abs|),pk_fma"};
 // elements per "instruction group" for reporting
 template <int OP>
 __global__ __launch_bounds__(256) void bench(float* out, int iters, float x, float y) {
@@ -96,6 +98,33 @@ __global__ __launch_bounds__(256) void bench(float* out, int iters, float x, flo
 #define X(n) asm volatile("v_sub_f32 %1, %3, %4\n v_sub_f32 %2, %5, |%1|\n v_min_f32 %1, |%1|, %2\n v_fma_f32 %0, %1, %1, %0" : "+v"(a##n), "=&v"(t), "=&v"(u) : "v"(x), "v"(y), "v"(6.2831853f));
       X(0) X(1) X(2) X(3)
 #undef X
+    } else if constexpr (OP == SUBCLAMP) {
+#define X(n) asm volatile("v_sub_f32_e64 %0, |%0|, 0.5 clamp" : "+v"(a##n));
+      REP8(X) REP8(X)
+#undef X
+    } else if constexpr (OP == MIX_FLOAT3) {  // the float form of the periodic tiles: 4 elements, 16 instr
+      float t, u;
+#define X(n) asm volatile("v_sub_f32 %1, %3, %4\n v_sub_f32_e64 %2, |%1|, %5\n v_sub_f32_e64 %1, %5, |%2|\n v_fma_f32 %0, %1, %1, %0" : "+v"(a##n), "=&v"(t), "=&v"(u) : "v"(x), "v"(y), "v"(3.14159265f));
+      X(0) X(1) X(2) X(3)
+#undef X
+    } else if constexpr (OP == MIX_RELU) {  // Gram + correction form: 5.33 elements, 16 instr
+      float t, u;
+#define X(n) asm volatile("v_sub_f32 %1, %3, %4\n v_sub_f32_e64 %2, |%1|, 0.5 clamp\n v_add_f32 %0, %0, %2" : "+v"(a##n), "=&v"(t), "=&v"(u) : "v"(x), "v"(y));
+      X(0) X(1) X(2) X(3) X(4)
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(t) : "v"(x), "v"(y));
+#undef X
+    } else if constexpr (OP == MIX_RELU_PK) {  // as the compiler writes it: 2 elements = sub, sub, clamp, clamp, pk_add: 15 instr + 1
+      f2 t; float u, w;
+#define X(n) asm volatile("v_sub_f32 %2, %4, %5\n v_sub_f32 %3, %5, %4\n v_sub_f32_e64 %2, |%2|, 0.5 clamp\n v_sub_f32_e64 %3, |%3|, 0.5 clamp\n v_pk_add_f32 %0, %0, %1" : "+v"(p##n), "=&v"(t), "=&v"(u), "=&v"(w) : "v"(x), "v"(y));
+      X(0) X(1) X(2)
+      asm volatile("v_sub_f32 %0, %1, %2" : "=v"(u) : "v"(x), "v"(y));
+#undef X
+    } else if constexpr (OP == MIX_FLOAT3_PK) {  // float form as compiled: 2 elements = 2 sub, 4 sub|abs|, pk_fma: 14 instr + 2
+      f2 t; float u, w;
+#define X(n) asm volatile("v_sub_f32 %2, %4, %5\n v_sub_f32 %3, %5, %4\n v_sub_f32_e64 %2, |%2|, %6\n v_sub_f32_e64 %3, |%3|, %6\n v_sub_f32_e64 %2, %6, |%2|\n v_sub_f32_e64 %3, %6, |%3|\n v_pk_fma_f32 %0, %1, %1, %0" : "+v"(p##n), "=&v"(t), "=&v"(u), "=&v"(w) : "v"(x), "v"(y), "v"(3.14159265f));
+      X(0) X(1)
+      asm volatile("v_sub_f32 %0, %1, %2\n v_sub_f32 %0, %2, %1" : "=v"(u) : "v"(x), "v"(y));
+#undef X
     } else if constexpr (OP == MIX_INT) {  // ~5.33 elements: 16 instr (3 per element)
       float t; int u;
 #define X(n) asm volatile("v_sub_u32 %2, %3, %4\n v_cvt_f32_i32 %1, %2\n v_fma_f32 %0, %1, %1, %0" : "+v"(a##n), "=&v"(t), "=&v"(u) : "v"(i##n), "v"(i0));
@@ -147,5 +176,6 @@ int main() {
   report<FMA>(out); report<PKFMA>(out); report<SUB>(out); report<SUBABS>(out); report<MINF>(out); report<PKADD>(out); report<PKMUL>(out);
   report<EXP>(out); report<LOG>(out); report<RSQ>(out); report<RCP>(out); report<SQRT>(out); report<CVTI>(out); report<SUBU>(out); report<RNDNE>(out);
   report<MIX_EUC>(out); report<MIX_EUC_PK>(out); report<MIX_PER>(out); report<MIX_INT>(out);
+  report<SUBCLAMP>(out); report<MIX_FLOAT3>(out); report<MIX_RELU>(out); report<MIX_RELU_PK>(out); report<MIX_FLOAT3_PK>(out);
   return 0;
 }
