@@ -351,8 +351,16 @@ struct AdamArgs {
     int item_begin;     // what made this kernel long: it has ~250 instructions of work per wave)
     int bias_item_begin;
     long w_off, b_off, fwd_unit, bwd_unit;
-    long pad[2];
+    int layer, slab_begin, slab_end, kind;   // planes: the layer's index, the plane's range of slabs, 0 slabs / 1 bias items
   } lay[EMX_MAX_LAYERS];
+  // With a store the optimizer workgroups form PLANES of 64: workgroup b belongs to plane b >> 6, and the plane's record (a
+  // copy of its layer's, plus the plane's range of the layer's slabs) sits at an address that depends on the workgroup index
+  // alone -- it arrives with the first trip to the kernel arguments, where a table lookup made it a second, dependent one.
+  // Layers are given planes in proportion to their slabs; the last plane holds the bias items.
+  static constexpr int PLANES = 16;
+  static_assert(64 * PLANES <= EMX_REDUCE_WS && PLANES > EMX_MAX_LAYERS, "one regulariser partial per optimizer workgroup; a plane per layer + the bias plane");
+  Layer plane[PLANES];
+  int n_planes;
   int n_items;          // with a store: slab + bias items
   int adam_blocks;      // workgroups beyond these gather the next batch (next.data != null)
   int next_vec4;        // the rows, xb and xin allow 16-byte lanes: two rows per wave (gather_rows2_body)
@@ -499,24 +507,25 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef const u32x16 __attribute__((address_space(4))) * KVec;
     typedef const char __attribute__((address_space(4))) * KBytes;
-    const KBytes kbase = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(AdamArgs, lay);
-    static_assert(sizeof(AdamArgs::Layer) == 64, "one s_load_dwordx16 per layer record");
-    auto layer_record = [&](int l) __attribute__((always_inline)) {
-      const u32x16 v = *(KVec)(kbase + 64 * l);
+    const KBytes kbase = (KBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(sizeof(AdamArgs::Layer) == 64, "one s_load_dwordx16 per record");
+    auto record = [&](size_t off, int i) __attribute__((always_inline)) {
+      const u32x16 v = *(KVec)(kbase + off + 64 * i);
       AdamArgs::Layer L;
       __builtin_memcpy(&L, &v, 64);
       return L;
     };
-    const int n_layers = a.mir.n_layers, n_blocks = a.mir.item_begin[n_layers], n_items = a.n_items;
-    for (int item = blockIdx.x; item < n_items; item += nblk) {
-      if (item < n_blocks) {
-        int l = 0;
-#pragma unroll
-        for (int i = 1; i < EMX_MAX_LAYERS; ++i) l += (item >= a.mir.item_begin[i]) ? 1 : 0;   // (entries beyond the net: INT_MAX)
-        const AdamArgs::Layer L = layer_record(l);
+    const int n_layers = a.mir.n_layers;
+    const int x64 = blockIdx.x & 63;
+    const AdamArgs::Layer PL = record(offsetof(AdamArgs, plane), min((int)(blockIdx.x >> 6), AdamArgs::PLANES - 1));
+    const int n_bias_items = a.n_items - a.mir.item_begin[n_layers];
+    for (int it = (PL.kind ? 0 : PL.slab_begin) + x64; it < (PL.kind ? n_bias_items : PL.slab_end); it += 64) {
+      if (!PL.kind) {
+        const AdamArgs::Layer& L = PL;
+        const int l = L.layer;
         const int K = L.K, N = L.N;
         const long woff = L.w_off;
-        const int rel = item - L.item_begin, NB = groups32(N);
+        const int rel = it, NB = groups32(N);
         const int k8 = rel / NB, nb = rel - k8 * NB;
         const int kr = lane >> 3, c4 = lane & 7;
         const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
@@ -577,11 +586,12 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
           if (k8 == 0 && nb == 0) hdr->rs = wrs_;
         }
       } else {
+        const int item = a.mir.item_begin[n_layers] + it;
         int l = 0;
 #pragma unroll
         for (int i = 1; i < EMX_MAX_LAYERS; ++i) l += (item >= a.bias_item_begin[i]) ? 1 : 0;
         l = min(l, n_layers - 1);
-        const AdamArgs::Layer L = layer_record(l);
+        const AdamArgs::Layer L = record(offsetof(AdamArgs, lay), l);
         const int j = (item - L.bias_item_begin) * 64 + lane;
         if (j < L.N) {
           const long e = L.b_off + j;
@@ -855,7 +865,7 @@ int check_next(const emx_next_batch* next, const char* who) {
 // workgroups (one wave each) of the optimizer part of the launch: float4 lanes over the flat buffer, or -- with a weight
 // operand store -- one per 32 x 32 kernel block and per 64 bias elements
 inline int adam_grid(const AdamArgs& a, int64_t n) {
-  if (a.mirror) return std::min(a.bias_item_begin[a.mir.n_layers], EMX_REDUCE_WS);
+  if (a.mirror) return 64 * a.n_planes;   // (<= EMX_REDUCE_WS: 16 planes of 64)
   return grid_for((n + 3) / 4, 64);
 }
 
@@ -879,12 +889,39 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
       if (l < mirror_desc->n_layers) {
         a.b_off[l] = mirror_desc->b_off[l];
         a.lay[l] = AdamArgs::Layer{a.mir.K[l], a.mir.N[l], a.mir.item_begin[l], items, a.mir.w_off[l], (long)mirror_desc->b_off[l],
-                                   a.mir.fwd_unit[l], a.mir.bwd_unit[l], {0, 0}};
+                                   a.mir.fwd_unit[l], a.mir.bwd_unit[l], l, 0, 0, 0};
         items += (mirror_desc->width[l + 1] + 63) / 64;
       }
     }
     a.n_items = items;
     for (int l = mirror_desc->n_layers + 1; l <= EMX_MAX_LAYERS; ++l) a.mir.item_begin[l] = INT_MAX;
+    {
+      // planes: one per layer first, the rest of the PLANES - 1 slab planes to the layers with the most slabs per plane
+      const int nl = mirror_desc->n_layers;
+      int cnt[EMX_MAX_LAYERS], slabs[EMX_MAX_LAYERS];
+      for (int l = 0; l < nl; ++l) cnt[l] = 1, slabs[l] = a.mir.item_begin[l + 1] == INT_MAX ? 0 : 0;
+      for (int l = 0; l < nl; ++l) slabs[l] = ((a.mir.K[l] + 7) >> 3) * groups32(a.mir.N[l]);
+      for (int extra = AdamArgs::PLANES - 1 - nl; extra > 0; --extra) {
+        int best = -1;
+        for (int l = 0; l < nl; ++l)
+          if (slabs[l] > 64 * cnt[l] && (best < 0 || (long)slabs[l] * cnt[best] > (long)slabs[best] * cnt[l])) best = l;
+        if (best < 0) break;
+        ++cnt[best];
+      }
+      int np = 0;
+      for (int l = 0; l < nl; ++l)
+        for (int c = 0; c < cnt[l]; ++c) {
+          AdamArgs::Layer& P = a.plane[np++];
+          P = a.lay[l];
+          P.slab_begin = (int)((long)slabs[l] * c / cnt[l]);
+          P.slab_end = (int)((long)slabs[l] * (c + 1) / cnt[l]);
+          P.kind = 0;
+        }
+      AdamArgs::Layer& Pb = a.plane[np++];
+      Pb = a.lay[0];
+      Pb.kind = 1;
+      a.n_planes = np;
+    }
   }
   a.w = w;
   a.g = g;

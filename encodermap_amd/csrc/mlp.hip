@@ -185,23 +185,29 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     // lanes over the per-tile slots, fixed order)
     const int N = a.join_n;
     if (a.lg.partials != nullptr) {
-      for (int el = wave; el < R * N; el += NWC) {
-        const int r = el / N, c = el - r * N;
-        const bool rok = r0 + r < a.row_end;
-        float v = 0.f;
-        if (rok) {
-          const float* __restrict__ P = a.lg.partials + (long)(r0 + r - a.lg.row_base) * N + c;
-          for (int sidx = lane; sidx < a.lg.n_slots; sidx += 64) v += P[(long)sidx * a.lg.slot_stride];
-        }
-        v = wave_sum(v);
-        if (lane == 0) {
-          float t = 0.f;
+      // (four elements per wave and pass, every load of the pass requested before the first sum: the partials were written
+      //  by the all-pairs kernel on other XCDs a moment ago, a dependent trip per element was four trips)
+      for (int el0 = wave; el0 < R * N; el0 += 4 * NWC) {
+        float v[4], zz[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int el = el0 + u * NWC;
+          const int r = el / N, c = el - r * N;
+          const bool rok = el < R * N && r0 + r < a.row_end;
+          v[u] = 0.f, zz[u] = 0.f, dd[u] = 0.f;
           if (rok) {
+            const float* __restrict__ P = a.lg.partials + (long)(r0 + r - a.lg.row_base) * N + c;
+            for (int sidx = lane; sidx < a.lg.n_slots; sidx += 64) v[u] += P[(long)sidx * a.lg.slot_stride];
             const long gi = (long)(r0 + r) * N + c;
-            t = fmaf(a.lg.center_grad, a.lg.Z[gi], a.lg.gscale * v);
-            if (a.dadd != nullptr) t += a.dadd[gi];
+            zz[u] = a.lg.Z[gi];
+            if (a.dadd != nullptr) dd[u] = a.dadd[gi];
           }
-          lat[el] = t;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int el = el0 + u * NWC;
+          const float sum = wave_sum(v[u]);
+          if (lane == 0 && el < R * N) lat[el] = fmaf(a.lg.center_grad, zz[u], a.lg.gscale * sum) + dd[u];
         }
       }
     } else {
