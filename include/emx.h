@@ -56,8 +56,12 @@ const char* emx_target_arch(void);
  *             sigmoid_loss_func        encodermap/loss_functions/loss_functions.py:351-367
  *             distance_loss_func       encodermap/loss_functions/loss_functions.py:266-296 (the x scale)
  *             center_loss_func         encodermap/loss_functions/loss_functions.py:422-449 (optional fused term)
- *   X [B, D] (row stride ldx floats) high-d rows (data, no gradient); Z [B, L] latent, L in 1..4.
+ *   X [B, D] (row stride ldx floats) high-d rows (data, no gradient); Z [B, L] latent, L in 1..8.
  *   periodicity: INFINITY -> Euclidean, else the period of X.
+ *   data_span: for periodic X, max - min over the data the rows are drawn from if the caller knows it, else 0.  Below 1.5
+ *   periods every |x_i - x_j| < 1.5 p, where the reference's min(|d|, p - |d|)^2 is the squared wrapped difference, and the
+ *   tile pass runs on wrapping 32-bit phases; 0 (unknown), NaN or a wider span keep the float form, which follows the
+ *   reference's formula for any |d| (its values go negative beyond one period and are squared).  Ignored for Euclidean X.
  *   sig = (sig_h, a_h, b_h, sig_l, a_l, b_l).
  *   *dist_loss   = scale / B^2 * sum_{i in rows} sum_{j<B} (S_h(dh_ij) - S_l(dl_ij))^2
  *   *center_loss = center_scale / (B*L) * sum_{i in rows} sum_l z_il^2      (skipped if center_loss == NULL)
