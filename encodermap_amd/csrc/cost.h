@@ -39,11 +39,15 @@ inline void fill_cost_scalars(CostArgs& a, int B, int n, int ldy, int ldt, int o
   a.gnorm = (float)(coef / denom);
 }
 
-// prediction (pred_s, pred_c: the sin / cos columns when the output is periodic), |difference| (wrapped) and its sign
+// prediction (pred_s, pred_c: the sin / cos columns when the output is periodic), |difference| (wrapped) and its sign.
+// PO: 1 / 0 = the output is / is not periodic at compile time (left to a run-time test the compiler if-converts the branch:
+// atan2f and its ~60 instructions run for every element of a non-periodic output too), -1 = run-time test.
+template <int PO = -1>
 __device__ __forceinline__ void cost_elem(const CostArgs& a, const float* yrow, const float* trow, int k, float& pred_s,
                                           float& pred_c, float& delta, float& ddelta) {
+#pragma clang fp contract(off)   // the stand-alone kernel and the cost phase of the chain kernel must round alike, whatever surrounds the call
   float pred;
-  if (a.periodic_output) {
+  if (PO == 1 || (PO < 0 && a.periodic_output)) {
     pred_s = yrow[a.off_sin + k];
     pred_c = yrow[a.off_cos + k];
     pred = atan2f(pred_s, pred_c) * a.out_scale;
@@ -69,10 +73,12 @@ __device__ __forceinline__ void cost_elem(const CostArgs& a, const float* yrow, 
   }
 }
 
+template <int PO = -1>
 __device__ __forceinline__ void cost_store(const CostArgs& a, float* drow, const float* addrow, int k, float g, float s, float c) {
+#pragma clang fp contract(off)
   if (!drow) return;
   if (addrow) g += addrow[k];
-  if (a.periodic_output) {
+  if (PO == 1 || (PO < 0 && a.periodic_output)) {
     float inv = a.out_scale / (s * s + c * c);
     drow[a.off_sin + k] = g * c * inv;
     drow[a.off_cos + k] = -g * s * inv;

@@ -403,7 +403,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
 
   // auto cost on the last forward layer's rows (float32 copy in LDS): 32 threads per row; d cost / d output goes to HBM
   // and, in place, into the copy
-  auto cost_phase = [&]() __attribute__((always_inline)) {
+  auto cost_body = [&](auto PO_) __attribute__((always_inline)) {
+    constexpr int PO = decltype(PO_)::value;   // periodic output or not: a wave-uniform branch around the whole body (cost.h)
     const CostArgs& cst = a.cost;
     const int row = tid >> 5, l32 = tid & 31;
     const bool rok = row < rows_valid;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       float ss = 0.f;
       for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        cost_elem<PO>(cst, yrow, trow, k, sn, cs, delta, dd);
         ss = fmaf(delta, delta, ss);
       }
 #pragma unroll
@@ -426,15 +427,15 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
       if (l32 == 0 && rok) lsum = nrm;
       for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        cost_elem<PO>(cst, yrow, trow, k, sn, cs, delta, dd);
         const float gq = rok ? cst.gnorm * delta * inv * dd : 0.f;
-        cost_store(cst, drow, nullptr, k, gq, sn, cs);
-        cost_store(cst, yrow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, drow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, yrow, nullptr, k, gq, sn, cs);
       }
     } else {
       for (int k = l32; k < cst.n; k += 32) {
         float sn, cs, delta, dd;
-        cost_elem(cst, yrow, trow, k, sn, cs, delta, dd);
+        cost_elem<PO>(cst, yrow, trow, k, sn, cs, delta, dd);
         float gq;
         if (cst.variant == EMX_MEAN_ABS) {
           if (rok) lsum += fabsf(delta);
@@ -444,12 +445,16 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
           gq = 2.f * delta * dd;
         }
         gq = rok ? cst.gnorm * gq : 0.f;
-        cost_store(cst, drow, nullptr, k, gq, sn, cs);
-        cost_store(cst, yrow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, drow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, yrow, nullptr, k, gq, sn, cs);
       }
     }
     const float tsum = block_sum<NTC>(lsum, cred);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
+  };
+  auto cost_phase = [&]() __attribute__((always_inline)) {
+    if (a.cost.periodic_output) cost_body(IC_<1>{});
+    else cost_body(IC_<0>{});
   };
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // the tile's accumulator in units of 1 / (weight scale [x source scale])
