@@ -308,7 +308,7 @@ def sketchmap_fwd_bwd(X, Z, periodicity, sig, scale, center_scale, row_begin, ro
 
 
 def sketchmap_tiles(X, Z, periodicity, sig, row_begin, row_end, ws, split_ws=None, data_span=None):
-    """``split_ws`` (from sketchmap_split / gather_rows / the optimizer's next-batch gather): Gram products on the bf16 cores."""
+    """``split_ws`` (from sketchmap_split / gather_rows / the optimizer's next-batch gather): Gram products on the f16 matrix cores."""
     B, D = X.shape
     sig_arr = (_f * 6)(*[float(s) for s in sig])
     _check(load().emx_sketchmap_tiles(_ptr(X), B, D, X.stride(0), _ptr(Z), Z.shape[1], float(periodicity), float(data_span or 0.0), sig_arr, int(row_begin),

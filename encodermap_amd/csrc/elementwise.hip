@@ -83,7 +83,7 @@ struct GatherArgs {
   float ang_scale;
   float* xb;
   float* xin;
-  SplitRows split;    // optional (planes != null): bf16 planes + norms of (row - row 0 of the batch) for the all-pairs kernel
+  SplitRows split;    // optional (planes != null): f16 planes + norms of (row - row 0 of the batch) for the all-pairs kernel
 };
 
 // rows b = wave, wave + nwaves, ... of the batch

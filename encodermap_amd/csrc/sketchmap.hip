@@ -72,7 +72,7 @@ struct SkArgs {
   float rp_hi, rp_lo, phase_unit2;   // fixed-point periodic tiles: 1 / period in two floats, (period / 2^32)^2
   int phase_ok;                      // the data span less than 1.5 periods: the fixed-point tiles may run
   SigDev sh, sl;
-  SplitRows split;   // optional bf16 planes + norms of the rows (split.h): selects the bf16 Gram kernel
+  SplitRows split;   // optional f16 planes + norms of the rows (split.h): selects the f16 Gram kernel
   int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
   // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of a first launch
   // (kmode 1: Gram partial of its chunks -> kpart), a second launch (kmode 2) adds them up in a fixed order and runs the

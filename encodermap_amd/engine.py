@@ -5,14 +5,19 @@ and replayed.
 
 What a step does (reference call stack: SURVEY.md section 3.2):
 
-  gather rows (+ sin/cos)            emx_gather_rows           autoencoder.py:845-856, models.py:3347-3351
-  encoder / decoder Dense layers     emx_mlp_forward           models.py:3179-3220 (exact-f32 MFMA, fused over layers)
-  sketch-map distance + center cost  emx_sketchmap_fwd_bwd     loss_functions.py:266-296,351-367,422-449
-  auto cost (+ atan2 output)         emx_periodic_cost_fwd_bwd loss_functions.py:586-626, models.py:3353-3359
-  backward through the Dense layers  emx_mlp_backward / _wgrad (tape.gradient, models.py:3392-3393)
-  [data parallel: one all-reduce of the flat gradient + loss-term buffer]
-  L2 + clip + Adam, regulariser cost emx_adam_step             autoencoder.py:741-743, loss_functions.py:488-506
-  history / counters on the device   emx_step_tick             models.py:3399-3401
+  shuffle, gather rows (+ sin/cos)   emx_permute, emx_next_batch autoencoder.py:845-856, models.py:3347-3351
+  Dense layers forward + auto cost   emx_mlp_forward_backward  models.py:3179-3220, loss_functions.py:586-626,
+   + decoder backward                 (one launch)              models.py:3353-3359, 3392-3393
+  sketch-map distance + center cost  emx_sketchmap_tiles       loss_functions.py:266-296,351-367,422-449
+  encoder backward (+ latent join)   emx_mlp_backward          (tape.gradient, models.py:3392-3393)
+  weight gradients, scalar epilogue  emx_mlp_wgrad (+ finish)  models.py:3392-3401 (history / counters on the device)
+  [data parallel: replica ranks -- one all-reduce of the flat gradient + loss-term buffer; row-block ranks -- the
+   symmetric all-pairs tiles dealt round-robin, an all-reduce of the latent-gradient shares in front of the encoder
+   backward, then the same all-reduce: DESIGN.md section 6]
+  L2 + clip + Adam, regulariser cost emx_adam_step_slices      autoencoder.py:741-743, loss_functions.py:488-506
+   + operand-store update + next batch
+(every float32 product of the dense layers and of the Euclidean all-pairs pass runs as three f16 matrix instructions on
+operands split into two 16-bit planes: DESIGN.md sections 3 and 4)
 
 The reference evaluates the forward pass once per loss term (4x) plus twice more for the latent
 (SURVEY.md section 3.2); the forward is deterministic, so a single pass gives identical numbers.
@@ -190,7 +195,7 @@ class SequentialEngine:
         self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
-        # bf16 planes + norms of the batch rows for the all-pairs kernel (Euclidean data only), made beside the gather
+        # f16 planes + norms of the batch rows for the all-pairs kernel (Euclidean data only), made beside the gather
         self.split_ws = None
         if self._prefetch and not self.periodic and self.with_distance and self.p.distance_cost_scale is not None:
             self.split_ws = torch.zeros(_lib.sketchmap_split_bytes(B, self.D), dtype=torch.uint8, device=dev)

@@ -82,11 +82,11 @@ int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z,
 int emx_sketchmap_tiles(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span,
                         const float sig[6], int row_begin, int row_end, void* ws, size_t ws_bytes,
                         void* split_ws /* may be NULL; Euclidean distances only */, emx_stream_t stream);
-/* Split rows for emx_sketchmap_tiles: x - x_0 (row 0 of the batch) as three bf16 planes whose sum is the float32 value
- * exactly, plus the squared row norms.  With them the tile pass forms its Gram products on the bf16 matrix cores (six
- * v_mfma_f32_32x32x16_bf16 per 16 features, every partial product exact in the f32 accumulator: the accuracy class of the
- * f32 instruction at 0.37x its cycles, and -- unlike the f32 matrix instruction -- without holding the VALU that the
- * sigmoid epilogues of the other waves need).  emx_gather_rows and emx_next_batch produce them beside the gather;
+/* Split rows for emx_sketchmap_tiles: x - x_0 (row 0 of the batch) as two f16 planes with a power-of-two scale per row
+ * (h = f16(s x), l = f16(s x - h): 22 bits), plus the squared row norms and 1/s.  With them the tile pass forms its Gram
+ * products on the f16 matrix cores (three v_mfma_f32_32x32x16_f16 per 16 features -- h.l, l.h, h.h, every partial product
+ * exact in the f32 accumulator: the accuracy class of the f32 matrix instruction at a fifth of its cycles, and -- unlike
+ * that instruction -- without holding the VALU that the sigmoid epilogues of the other waves need).  emx_gather_rows and emx_next_batch produce them beside the gather;
  * emx_sketchmap_split makes them from a dense [B, D] block.  split_ws: emx_sketchmap_split_bytes(B, D) bytes, 16-byte aligned. */
 size_t emx_sketchmap_split_bytes(int B, int D);
 int emx_sketchmap_split(const float* X, int B, int D, int ldx, void* split_ws, emx_stream_t stream);
