@@ -94,7 +94,7 @@ def test_ranks_on_one_gpu(mode, world, euclid, tmp_path):
         assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3
 
 
-def _one_rank_rccl_worker(rank, port, out_dir):
+def _one_rank_rccl_worker(rank, port, out_dir, mode="replica"):
     """The data-parallel path over RCCL itself, with the one rank a single GPU allows: two hipGraphs around the eager
     all-reduce, and (EMX_DP_GRAPH_ALLREDUCE=1) the all-reduce captured inside the step's graph."""
     import torch.distributed as dist
@@ -116,9 +116,10 @@ def _one_rank_rccl_worker(rank, port, out_dir):
     for name, captured in (("eager", False), ("captured", True)):
         SequentialEngine._dp_graph_allreduce = captured
         p = em.Parameters(n_steps=20, batch_size=256, seed=11)
-        e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=OneRank(0, 1, "replica"))
+        e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=OneRank(0, 1, mode))
         e._engine.run_steps(20)
         out[name] = e._engine.losses()
+        out[name + "_graphs"] = np.array(len(e._engine._graph))
         out[name + "_w"] = e._engine.w.cpu().numpy()
     p = em.Parameters(n_steps=20, batch_size=256, seed=11)
     e = em.EncoderMap(p, data, model=_weights(p), read_only=True)
@@ -128,18 +129,25 @@ def _one_rank_rccl_worker(rank, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_one_rank_over_rccl(tmp_path):
+@pytest.mark.parametrize("mode", ["replica", "rowblock"])
+def test_one_rank_over_rccl(mode, tmp_path):
+    """replica: one all-reduce per step; rowblock: the dealt all-pairs tiles (all of them: one rank), the latent-gradient
+    all-reduce in front of the encoder backward and the [gradient | terms] all-reduce -- eagerly between three graphs, or both
+    captured inside the step's graph."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), str(tmp_path), mode), nprocs=1, join=True)
     r = np.load(tmp_path / "one_rank.npz")
     assert np.isfinite(r["eager"]).all() and len(r["eager"]) == 20
+    assert int(r["eager_graphs"]) == (3 if mode == "rowblock" else 2) and int(r["captured_graphs"]) == 1
     np.testing.assert_array_equal(r["eager"], r["captured"])          # same kernels, same order: bitwise the same run
     np.testing.assert_array_equal(r["eager_w"], r["captured_w"])
     # one rank averages with itself: the single-process run up to the summation order of the gradient partials (the
     # data-parallel step reduces them in its own kernel), whose last-bit differences the trajectory amplifies
-    np.testing.assert_allclose(r["eager"][:3], r["single"][:3], rtol=1e-6)
-    np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-3)
+    if mode == "replica":   # (row-block ranks share one shuffle stream of their own: equality with the single-process run is
+        #                      checked with injected batches in test_ranks_on_one_gpu)
+        np.testing.assert_allclose(r["eager"][:3], r["single"][:3], rtol=1e-6)
+        np.testing.assert_allclose(r["eager"], r["single"], rtol=1e-3)
 
 
 @pytest.mark.parametrize("mode,extra,batch,scaling", [("replica", [], 2 * 4096, "weak"), ("rowblock", [], 4096, "strong"),
