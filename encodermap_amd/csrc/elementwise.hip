@@ -452,13 +452,20 @@ __device__ __forceinline__ float grad1(const AdamArgs& a, long i) {
 // Launched with one wave per workgroup: the update of ~1e5 parameters reads 36 streams (32 gradient slices, w, m, v,
 // l2coef), ~150 KB per 1024 parameters, and a CU takes 64 B/clk -- on 65 CUs (256-thread workgroups) the loads alone were
 // 2300+ cycles of L1 fill per CU; one wave per workgroup spreads them over every CU.
-__global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
+// The leading scalars (56 bytes, the struct follows) are preloaded into scalar registers at wave launch
+// (-amdgpu-kernarg-preload-count): a workgroup knows its role, and the pointers of its first loads -- the step counter, the
+// batch cursor -- without a trip to the argument segment; the plane's record (its address depends on the workgroup index
+// alone) is the only trip in front of an optimizer wave's operand loads, where the role fields used to be a first one.
+__global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_hist, int p_next_vec4, int p_batch_step, const int64_t* p_step,
+                                                  const char* p_mirror, const int64_t* p_cursor, const int64_t* p_idx, int p_B, int p_n_batches,
+                                                  const AdamArgs a) {
+  constexpr int EXPLICIT_BYTES = 56;
   __shared__ float red[NT / 64];
   const int nt = blockDim.x;
   ASTAMP(32, 0);
-  ASTAMP(40, a.adam_blocks);
+  ASTAMP(40, p_adam_blocks);
   ASTAMP(42, (int)gridDim.x - 2);
-  if (a.hstep && blockIdx.x == gridDim.x - 1) {
+  if (p_has_hist && blockIdx.x == gridDim.x - 1) {
     if (threadIdx.x == 0) {
       const long hs = *a.hstep - 1;
       float tl[64];
@@ -473,19 +480,25 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     }
     return;
   }
-  if ((int)blockIdx.x >= a.adam_blocks) {
+  if ((int)blockIdx.x >= p_adam_blocks) {
     // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
     // beside it, on other CUs, instead of in a launch of their own at the head of the next step
-    const int gb = blockIdx.x - a.adam_blocks, ngb = gridDim.x - a.adam_blocks - (a.hstep ? 1 : 0);
-    if (a.next_vec4) gather_rows2_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
-    else gather_rows_body(a.next, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
-    ASTAMP(41, a.adam_blocks);
+    const int gb = blockIdx.x - p_adam_blocks, ngb = gridDim.x - p_adam_blocks - (p_has_hist ? 1 : 0);
+    GatherArgs gl = a.next;   // (cursor, index block and batch shape from the preloaded scalars: the cursor load goes out at once)
+    gl.cursor = p_cursor;
+    gl.idx = p_idx;
+    gl.B = p_B;
+    gl.batch_step = p_batch_step;
+    gl.n_batches = p_n_batches;
+    if (p_next_vec4) gather_rows2_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
+    else gather_rows_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
+    ASTAMP(41, p_adam_blocks);
     ASTAMP(43, (int)gridDim.x - 2);
     return;
   }
-  const int nblk = a.adam_blocks;
+  const int nblk = p_adam_blocks;
   FSTAMP(16);
-  const long step_now = *a.step;   // requested first, consumed behind the parameter loads (one round trip, not two)
+  const long step_now = *p_step;   // requested first, consumed behind the parameter loads (one round trip, not two)
   // alpha = lr * sqrt(1 - b2^t) / (1 - b1^t)   (Keras 2.13-2.15 Adam.update_step); b^t = 2^(t log2 b) on the hardware
   // exp2 (the library powf is several hundred instructions in front of the first load of a latency-bound kernel)
   auto alpha_of = [&](long st) {
@@ -496,7 +509,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
   const bool vec = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.g) | reinterpret_cast<uintptr_t>(a.m) |
                      reinterpret_cast<uintptr_t>(a.v) | reinterpret_cast<uintptr_t>(a.l2coef) | reinterpret_cast<uintptr_t>(a.gpart) |
                      (uintptr_t)(a.gstride * 4)) & 15) == 0;
-  if (a.mirror) {
+  if (p_mirror != nullptr) {
     // With a weight operand store the kernels are walked by SLAB (8 rows x 32 columns, one wave each, one float4 per lane
     // and tensor as in the flat pass): the slab's new weights and its part of the f16 pair fragments for both directions
     // leave in the same pass (wop.h).  Lane (kr = lane >> 3, c4 = lane & 7) owns W[8 k8 + kr][32 nb + 4 c4 + i].  Biases
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
     typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
     typedef const u32x16 __attribute__((address_space(4))) * KVec;
     typedef const char __attribute__((address_space(4))) * KBytes;
-    const KBytes kbase = (KBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    const KBytes kbase = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + EXPLICIT_BYTES;
     static_assert(sizeof(AdamArgs::Layer) == 64, "one s_load_dwordx16 per record");
     auto record = [&](size_t off, int i) __attribute__((always_inline)) {
       const u32x16 v = *(KVec)(kbase + off + 64 * i);
@@ -531,7 +544,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
         const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
         // the layer's scale: from the largest |w| the PREVIOUS update recorded (wop.h); both slots are requested with the
         // operands (which one is the previous update's depends on the step counter, itself still on its way)
-        WopHeader* hdr = wop_header(a.mirror, l);
+        WopHeader* hdr = wop_header(const_cast<char*>(p_mirror), l);
         if (K > 0) ASTAMP(38, 0);
         const unsigned long long slot0 = hdr->slot[0], slot1 = hdr->slot[1];
         WopArgs wl;          // the layer as layer 0 of a one-layer view: static indices, registers
@@ -577,7 +590,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(const AdamArgs a) {
         float ws_, wrs_;
         pow2_scale_bits<WOP_TOP>((unsigned)prev, ws_, wrs_);
         ASTAMP(34, 0);
-        const unsigned bmax = wop_write_slab(wl, a.mirror, 0, k8, nb, wv, ws_, lane, img);
+        const unsigned bmax = wop_write_slab(wl, const_cast<char*>(p_mirror), 0, k8, nb, wv, ws_, lane, img);
         ASTAMP(35, 0);
         if (lane == 0) {
           // record this update's maximum for the next one; most slabs find a larger record of this update already there
@@ -869,6 +882,11 @@ inline int adam_grid(const AdamArgs& a, int64_t n) {
   return grid_for((n + 3) / 4, 64);
 }
 
+#define ADAM_LAUNCH(grid_, st_, a_)                                                                                                       \
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_), dim3(ADAM_NT), 0, st_, (a_).adam_blocks, (a_).hstep != nullptr ? 1 : 0, (a_).next_vec4,          \
+                     (a_).next.batch_step, (a_).step, (const char*)(a_).mirror, (a_).next.cursor, (a_).next.idx, (a_).next.B, (a_).next.n_batches, \
+                     a_)
+
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
                    int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
                    const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next = nullptr) {
@@ -960,7 +978,7 @@ int emx_adam_step(float* w, const float* g, float* m, float* v, const float* l2c
   a.late = bookkeeping_done ? 1 : 0;
   if (a.late) a.next.batch_step = 0;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid + gather_blocks(next)), dim3(ADAM_NT), 0, st, a);
+  ADAM_LAUNCH(grid + gather_blocks(next), st, a);
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   if (reg_loss) {
@@ -989,7 +1007,7 @@ int emx_adam_step_history(float* w, const float* g, float* m, float* v, const fl
   a.term_history = term_history;
   a.capacity = (long)capacity;
   a.hstep = hstep;
-  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next) + 1), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
+  ADAM_LAUNCH(a.adam_blocks + gather_blocks(next) + 1, (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
 }
 
@@ -1007,7 +1025,7 @@ int emx_adam_step_slices(float* w, const float* g_partials, int n_slices, int64_
   a.adam_blocks = adam_grid(a, n);
   a.late = bookkeeping_done ? 1 : 0;
   if (a.late) a.next.batch_step = 0;
-  hipLaunchKernelGGL(adam_kernel, dim3(a.adam_blocks + gather_blocks(next)), dim3(ADAM_NT), 0, (hipStream_t)stream, a);
+  ADAM_LAUNCH(a.adam_blocks + gather_blocks(next), (hipStream_t)stream, a);
   return emx::check_launch("adam_kernel");
 }
 
@@ -1032,7 +1050,7 @@ int emx_adam_tick(float* w, const float* g, const float* g_partials, int n_slice
   // agent-scope release has to write back the megabytes of L2 lines the weight-gradient kernel has just dirtied.)
   const int grid = a.adam_blocks;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(adam_kernel, dim3(grid), dim3(ADAM_NT), 0, st, a);
+  ADAM_LAUNCH(grid, st, a);
   int rc = emx::check_launch("adam_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(NT), 0, st, ws, grid, 1.f, (const float*)nullptr, terms + reg_slot);

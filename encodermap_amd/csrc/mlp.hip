@@ -155,8 +155,13 @@ struct IC_ {
   static constexpr int value = V;
 };
 
+// (the leading scalars duplicate what the first loads of a workgroup need -- the row block's source, the auto cost's targets:
+//  preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count), those loads go out with the first
+//  instructions instead of behind a trip to the argument segment; 56 bytes, the struct follows at offset 56)
 template <int MODE, int NB>
-__global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
+__global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
+                                                    int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
+                                                    const ChainArgs a) {
   constexpr bool BWD = MODE == CHAIN_BWD;
   constexpr int NE = BWD ? 4 : 1;   // epilogue operands per lane: h of 4 rows (backward) or the bias of its column
   extern __shared__ __align__(16) char lds[];
@@ -170,13 +175,14 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n = lane & 15, g = lane >> 4;
   TSTAMP(0);
-  const int r0 = a.row0 + blockIdx.x * R;
+  const int r0 = p_row0 + blockIdx.x * R;
   const int rb = r0 >> 4;   // row block of the weight-gradient fragments (row0 is a multiple of 16 whenever they are kept)
-  const int rows_valid = min(R, a.row_end - r0);
+  const int rows_valid = min(R, p_row_end - r0);
   // the GEMM table is indexed at run time: read it through the kernel-argument segment itself (scalar loads from constant
   // memory; indexing the by-value struct makes hipcc copy all of it to scratch in the larger instantiations)
   typedef const ChainArgs __attribute__((address_space(4))) * KArgs;
-  const KArgs ka = (KArgs)__builtin_amdgcn_kernarg_segment_ptr();
+  static_assert(sizeof(ChainArgs) % 8 == 0, "ChainArgs follows 56 bytes of scalars");
+  const KArgs ka = (KArgs)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + 56);
   float* lat = reinterpret_cast<float*>(lds + a.lat_off);
   float* tgt = reinterpret_cast<float*>(lds + a.tgt_off);
 
@@ -272,14 +278,14 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
   // the row block from HBM (forward: input rows; backward: delta_top = (dtop [+ join]) * act'(h_top)).  Addresses are
   // clamped and the values masked by a multiplication: a select on a loaded value makes hipcc emit an exec-masked load
   // followed by s_waitcnt vmcnt(0) per element, eight dependent round trips at the head of the kernel.
-  const int sK = a.in_cols;
+  const int sK = p_in_cols;
   auto stage_load = [&](int grp, float (&x)[8], float (&hv)[8]) __attribute__((always_inline)) {
     const int cc = min(32 * grp + sc_c, sK - 1);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const long grow = (long)min(r0 + 8 * sc_hf + e, a.row_end - 1);
-      x[e] = a.in[grow * a.ld_in + cc];
-      if (BWD) hv[e] = a.top_h[grow * sK + cc];
+      const long grow = (long)min(r0 + 8 * sc_hf + e, p_row_end - 1);
+      x[e] = p_in[grow * p_ld_in + cc];
+      if (BWD) hv[e] = p_top_h[grow * sK + cc];
     }
   };
   auto stage_value = [&](int grp, const float (&x)[8], const float (&hv)[8], float (&v)[8]) __attribute__((always_inline)) {
@@ -692,15 +698,15 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const ChainArgs a) {
     }
   };
 
-  const bool with_cost = !BWD && a.cost.ws != nullptr;
+  const bool with_cost = !BWD && p_with_cost != 0;
   // the row block travels ahead of the first packages and reaches LDS behind them
   float sx[8], shv[8], tv[4] = {0.f, 0.f, 0.f, 0.f};
-  if (wave < a.in_Q) stage_load(wave, sx, shv);
+  if (wave < p_in_Q) stage_load(wave, sx, shv);
   if (with_cost) {
     const int c = 4 * (tid & 31), row = tid >> 5;
-    const long grow = (long)min(r0 + row, a.row_end - 1);
+    const long grow = (long)min(r0 + row, p_row_end - 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) tv[i] = a.cost.target[grow * a.cost.ldt + min(c + i, a.cost.n - 1)];
+    for (int i = 0; i < 4; ++i) tv[i] = p_target[grow * p_ldt + min(c + i, p_cost_n - 1)];
   }
   TSTAMP(1);
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -860,20 +866,24 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 #define WSTAMP(k)
 #endif
 
-__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
+// The first 16 dwords of the arguments are explicit scalars: with -mllvm -amdgpu-kernarg-preload-count=16 the command processor
+// hands them over in scalar registers at wave launch (gfx940+), so the layer's record -- and behind it the fragments -- can be
+// requested with the first instructions instead of after a trip for the head (tile table packed as 13 x 16 bits).
+__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
+                                                       unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int has_fin, int pad_, float* partial,
+                                                       long n_params, const WgradDev a) {   // (14 dwords are preloaded: up to `partial`)
   WSTAMP(0);
   __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
   __shared__ float fin_tl[64];
-  // Every trip to the kernel arguments costs about as much as one to HBM, and a dependent chain of them is what a short kernel
-  // is made of (the first version made eight before its first fragment load, and one more inside each guarded store).  Two
-  // trips here: the head (both halves requested together, read through the argument segment so that they stay two wide
-  // loads), then the layer's 64-byte record.
   typedef const u32x16 __attribute__((address_space(4))) * KVec;
-  const KVec kv = (KVec)__builtin_amdgcn_kernarg_segment_ptr();
-  const u32x16 h0 = kv[0], h1 = kv[1];
-  WgHead hd;
-  __builtin_memcpy(&hd, &h0, 64);
-  __builtin_memcpy(reinterpret_cast<char*>(&hd) + 64, &h1, 64);
+  typedef const char __attribute__((address_space(4))) * KBytes;
+  const KVec kv = (KVec)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64 + offsetof(WgradDev, lay));   // (64: the explicit scalars)
+  struct {
+    int rb0, rb_end, rbs_per_slice, has_fin;
+    float* partial;
+    long n_params;
+  } hd{rb0, rb_end, rbs_per_slice, has_fin, partial, n_params};
+  (void)pad_;   // (the explicit scalars are 64 bytes: 7 + 4 + 1 dwords, a pointer, a long -- the record array's offset above)
   if (hd.has_fin && blockIdx.x == gridDim.x - 1) {
     // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs are complete
     // before this launch starts, and a launch of its own costs ~6.5 us of the step.
@@ -883,18 +893,22 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(const WgradDev a) {
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
   int li = 0, tbase = 0;
 #pragma unroll
-  for (int i = 1; i < MAXL; ++i)
-    if ((int)blockIdx.x >= hd.tile_begin[i]) {
+  for (int i = 1; i < MAXL; ++i) {
+    const int t = (int)((tbw[i >> 1] >> (16 * (i & 1))) & 0xffffu);   // (unused entries: 0xffff)
+    if ((int)blockIdx.x >= t) {
       li = i;
-      tbase = hd.tile_begin[i];
+      tbase = t;
     }
+  }
   const int tb = blockIdx.x - tbase;
-  const u32x16 lrec = kv[2 + li];
+  const u32x16 lrec = kv[li];
   WgLayer L;
   __builtin_memcpy(&L, &lrec, 64);
   const int Kin = L.K, N = L.N;
+  if (Kin > 0) WSTAMP(6);   // (the layer record is in registers)
   const int nbn = (N + 127) >> 7;
   const int bi = tb / nbn, bj = tb - bi * nbn;
   const int ig0 = 4 * bi + 2 * (wave >> 1), jg0 = 4 * bj + 2 * (wave & 1);   // first column groups of the wave's quadrant
@@ -1194,11 +1208,13 @@ int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStr
   if (deep) {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 3>), lds, b.who);
     if (rc) return rc;
-    hipLaunchKernelGGL((chain_kernel<MODE, 3>), dim3(grid), dim3(NTC), lds, st, b.a);
+    hipLaunchKernelGGL((chain_kernel<MODE, 3>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
+                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
   } else {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 2>), lds, b.who);
     if (rc) return rc;
-    hipLaunchKernelGGL((chain_kernel<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a);
+    hipLaunchKernelGGL((chain_kernel<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
+                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
   }
   return emx::check_launch(what);
 }
@@ -1536,7 +1552,14 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   const int slices = emx_mlp_wgrad_slices(nrows);
   hipStream_t st = (hipStream_t)stream;
   static_assert(FIN_NT == NT, "the scalar epilogue shares the weight-gradient kernel's workgroup size");
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.h.has_fin, slices), dim3(NT), 0, st, a);
+  unsigned tbw[7];
+  for (int i = 0; i < 7; ++i) {
+    auto t16 = [&](int k) { return (unsigned)std::min(a.h.tile_begin[std::min(k, MAXL)], 0xffff) & 0xffffu; };
+    tbw[i] = t16(2 * i) | (t16(2 * i + 1) << 16);
+  }
+  EMX_REQUIRE(tiles < 0xffff, "%s: %d output blocks", who, tiles);
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.h.has_fin, slices), dim3(NT), 0, st, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4], tbw[5], tbw[6],
+                     a.h.rb0, a.h.rb_end, a.h.rbs_per_slice, a.h.has_fin, 0, a.h.partial, a.h.n_params, a);
   rc = emx::check_launch("mlp_wgrad_kernel");
   if (rc) return rc;
   if (!grad) return EMX_OK;   // the caller sums the slices itself (emx_adam_step_slices)

@@ -661,7 +661,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint
 // the prefetched pieces are loop-carried registers, the compiler loads into temporaries and copies them into place at the
 // loop's end, and that copy waits for the data one instruction after it was requested.
 template <int LT, bool FASTSIG, int NCH>
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void sk_tile_f16_kernel(const SkArgs a) {
+// (leading scalars: what the tile decode and the first operand loads need, preloaded into scalar registers at wave launch --
+//  -amdgpu-kernarg-preload-count; 56 bytes, the struct follows)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void sk_tile_f16_kernel(
+    const uint16_t* p_planes, long p_plane_stride, int p_xcd_nbg, int p_nbc, int p_symm, int p_deal_world, int p_deal_rank, int p_row0, int p_B,
+    int p_split_B, int p_split_ld, int p_kmode_ksplit, const SkArgs a) {
   // (the compiler sizes its register budget for the occupancy a 64-KB LDS would allow; gfx950 has 160 KB, so the target
   //  is stated: 8 tiles resident per CU: <= 64 VGPRs, <= 20 KB LDS)
   constexpr int T = 64;
@@ -682,21 +686,25 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
 
-  const int kmode = NCH == 0 ? a.kmode : 0;
-  const int tile_id = kmode == 1 ? (int)blockIdx.x / a.ksplit : (int)blockIdx.x;
+  const int kmode = NCH == 0 ? (p_kmode_ksplit >> 16) : 0;
+  const int ksplit_ = p_kmode_ksplit & 0xffff;
+  const int tile_id = kmode == 1 ? (int)blockIdx.x / ksplit_ : (int)blockIdx.x;
   int ti, tj, tslot = tile_id;
-  if (a.xcd_nbg > 0) {
-    if (!xcd_tile(blockIdx.x, a.xcd_nbg, a.nbc, ti, tj, tslot)) return;
-  } else if (a.symm) {
-    tri_decode(tile_id, a.nbc, ti, tj);
+  if (p_xcd_nbg > 0) {
+    if (!xcd_tile(blockIdx.x, p_xcd_nbg, p_nbc, ti, tj, tslot)) return;
+  } else if (p_symm) {
+    tri_decode(tile_id, p_nbc, ti, tj);
   } else {
-    ti = tile_id / a.nbc;
-    tj = tile_id - ti * a.nbc;
+    ti = tile_id / p_nbc;
+    tj = tile_id - ti * p_nbc;
   }
-  if (dealt_away(a, tslot)) return;
-  const int i0 = a.row0 + ti * T;
+  if (p_deal_world > 1 && tslot % p_deal_world != p_deal_rank) {   // (dealt_away with the preloaded copies)
+    if (threadIdx.x == 0) a.tile_loss[tslot] = 0.f;
+    return;
+  }
+  const int i0 = p_row0 + ti * T;
   const int j0 = tj * T;
-  const bool offdiag = a.symm && (ti != tj);
+  const bool offdiag = p_symm && (ti != tj);
 
   KSTAMP(0);
   f32x16 acc;
@@ -713,14 +721,18 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   // ---- K loop: 32 reduction indices per chunk; the four operand planes of the tile's 64 + 64 rows are staged as 16-byte
   //      pieces (8 f16) -- one contiguous 4-KB block per side and plane in the chunk-major planes -- through an LDS image
   //      that is XOR-swizzled so that the ds_read_b128 of 16 consecutive rows covers all 64 banks; 2 x 3 MFMAs per chunk
-  const SplitRows sp = a.split;
+  SplitRows sp = a.split;      // (norms, 1 / scale: used behind the first loads)
+  sp.planes = const_cast<uint16_t*>(p_planes);
+  sp.plane_stride = p_plane_stride;
+  sp.B = p_split_B;
+  sp.ld = p_split_ld;
   const uint16_t* gp[4];
   int lo[4];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int e = tid + NT * u;                       // piece: side (i / j), plane, row, quarter q
     const int side = e >> 9, plane = (e >> 8) & 1, row = (e & 255) >> 2, q = e & 3;
-    const int grow = min((side ? j0 : i0) + row, a.B - 1);
+    const int grow = min((side ? j0 : i0) + row, p_B - 1);
     gp[u] = sp.planes + plane * sp.plane_stride + (long)grow * SPLIT_KC + 8 * q;
     lo[u] = ((side * 2 + plane) * 64 + row) * 4 + (q ^ ((row >> 2) & 3));
   }
@@ -976,6 +988,11 @@ SigDev make_sig(float sig, float aa, float bb) {
   return s;
 }
 
+#define SK_F16_LAUNCH(kern, grid_, args_)                                                                                              \
+  hipLaunchKernelGGL(kern, grid_, dim3(NT), 0, st, (const uint16_t*)(args_).split.planes, (long)(args_).split.plane_stride, (args_).xcd_nbg,  \
+                     (args_).nbc, (args_).symm, (args_).deal_world, (args_).deal_rank, (args_).row0, (args_).B, (args_).split.B,              \
+                     (args_).split.ld, ((args_).kmode << 16) | ((args_).ksplit & 0xffff), args_)
+
 template <int T, int LT, int PMODE, bool FAST>
 void launch_tiles(const SkArgs& a, int ntiles, hipStream_t st) {
   hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PMODE, FAST>), dim3(ntiles), dim3(NT), 0, st, a);
@@ -1176,22 +1193,22 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       for (int mode = 1; mode <= 2; ++mode) {
         b.kmode = mode;
         const dim3 gk(mode == 1 ? pl.ntiles * ksplit : pl.ntiles);
-        if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), gk, dim3(NT), 0, st, b);
-        else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), gk, dim3(NT), 0, st, b);
-        else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), gk, dim3(NT), 0, st, b);
-        else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), gk, dim3(NT), 0, st, b);
+        if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), gk, b);
+        else if (a.L == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, false, 0>), gk, b);
+        else if (pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<0, true, 0>), gk, b);
+        else SK_F16_LAUNCH((sk_tile_f16_kernel<0, false, 0>), gk, b);
         const int rck = emx::check_launch("sk_tile_f16_kernel (split reduction)");
         if (rck) return rck;
       }
       return EMX_OK;
     }
-    if (a.L == 2 && pl.fast && nch == 4) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 4>), dim3(grid), dim3(NT), 0, st, b);
-    else if (a.L == 2 && pl.fast && nch == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 2>), dim3(grid), dim3(NT), 0, st, b);
-    else if (a.L == 2 && pl.fast && nch == 1) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 1>), dim3(grid), dim3(NT), 0, st, b);
-    else if (a.L == 2 && pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<2, true, 0>), dim3(grid), dim3(NT), 0, st, b);
-    else if (a.L == 2) hipLaunchKernelGGL((sk_tile_f16_kernel<2, false, 0>), dim3(grid), dim3(NT), 0, st, b);
-    else if (pl.fast) hipLaunchKernelGGL((sk_tile_f16_kernel<0, true, 0>), dim3(grid), dim3(NT), 0, st, b);
-    else hipLaunchKernelGGL((sk_tile_f16_kernel<0, false, 0>), dim3(grid), dim3(NT), 0, st, b);
+    if (a.L == 2 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 4>), dim3(grid), b);
+    else if (a.L == 2 && pl.fast && nch == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 2>), dim3(grid), b);
+    else if (a.L == 2 && pl.fast && nch == 1) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 1>), dim3(grid), b);
+    else if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), dim3(grid), b);
+    else if (a.L == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, false, 0>), dim3(grid), b);
+    else if (pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<0, true, 0>), dim3(grid), b);
+    else SK_F16_LAUNCH((sk_tile_f16_kernel<0, false, 0>), dim3(grid), b);
     return emx::check_launch("sk_tile_f16_kernel");
   }
   if (!pl.periodic && a.vec4 && pl.T == 64 && pl.gram && a.L <= 4) {

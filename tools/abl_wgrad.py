@@ -21,4 +21,5 @@ t = buf[4096:4096 + 64].reshape(4, 16)
 t0 = min(int(r[0]) for r in t if r[0])
 for name, r in zip(("block 0 slice 0", "block 0 last slice", "epilogue wg", "(last column, last slice)"), t):
     print(name, "entry %.2f us; since entry: loads issued %.2f  products done %.2f  folded %.2f  stores issued %.2f  | epilogue done %.2f" % (
-        (r[0] - t0) / 100.0, *[((r[k] - r[0]) / 100.0 if r[k] else float("nan")) for k in (1, 2, 3, 4, 5)]))
+        (r[0] - t0) / 100.0, *[((r[k] - r[0]) / 100.0 if r[k] else float("nan")) for k in (1, 2, 3, 4, 5)]),
+        "| layer record in registers %.2f" % ((r[6] - r[0]) / 100.0 if r[6] else float("nan")))
