@@ -258,8 +258,10 @@ __device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int
   return true;
 }
 
+// (leading scalars: tile decode and the first row loads, preloaded into scalar registers at wave launch; 56 bytes, the struct follows)
 template <int TM, int TN, int LT, int PMODE, bool FASTSIG>
-__global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
+__global__ __launch_bounds__(NT) void sk_tile_kernel(const float* p_X, int p_ldx, int p_D, int p_B, int p_row0, int p_row_end, int p_nbc, int p_symm,
+                                                     int p_xcd_nbg, int p_vec4, int p_deal_world, int p_deal_rank, int p_pad, const SkArgs a) {
   constexpr int RM = TM / 16, RN = TN / 16;
   constexpr int LMAX = LT ? LT : 4;
   constexpr int STAGE = (TM + TN) * LS;
@@ -273,19 +275,23 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   const int tid = threadIdx.x;
   const int tx = tid & 15, ty = tid >> 4;
 
+  (void)p_pad;
   int ti, tj, tslot = blockIdx.x;
-  if (a.xcd_nbg > 0) {   // XCD-aware order (xcd_tile): every XCD's L2 sees half of the row panels instead of all of them
-    if (!xcd_tile(blockIdx.x, a.xcd_nbg, a.nbc, ti, tj, tslot)) return;
-  } else if (a.symm) {
-    tri_decode(blockIdx.x, a.nbc, ti, tj);
+  if (p_xcd_nbg > 0) {   // XCD-aware order (xcd_tile): every XCD's L2 sees half of the row panels instead of all of them
+    if (!xcd_tile(blockIdx.x, p_xcd_nbg, p_nbc, ti, tj, tslot)) return;
+  } else if (p_symm) {
+    tri_decode(blockIdx.x, p_nbc, ti, tj);
   } else {
-    ti = blockIdx.x / a.nbc;
-    tj = blockIdx.x - ti * a.nbc;
+    ti = blockIdx.x / p_nbc;
+    tj = blockIdx.x - ti * p_nbc;
   }
-  if (dealt_away(a, tslot)) return;
-  const int i0 = a.row0 + ti * TM;
+  if (p_deal_world > 1 && tslot % p_deal_world != p_deal_rank) {   // (dealt_away with the preloaded copies)
+    if (threadIdx.x == 0) a.tile_loss[tslot] = 0.f;
+    return;
+  }
+  const int i0 = p_row0 + ti * TM;
   const int j0 = tj * TN;
-  const bool offdiag = a.symm && (ti != tj);
+  const bool offdiag = p_symm && (ti != tj);
 
   float acc[RM][RN];
 #pragma unroll
@@ -297,21 +303,21 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
   const int kq = tid & 7, rb = tid >> 3;
   constexpr int QI = TM / 32, QJ = TN / 32;
   float4 pi[QI], pj[QJ];
-  const bool vec4 = a.vec4 != 0;
+  const bool vec4 = p_vec4 != 0;
   auto gload = [&](int k0) {
 #pragma unroll
     for (int q = 0; q < QI; ++q) {
       int row = i0 + rb + 32 * q;
-      pi[q] = load_row4(a.X, row, a.ldx, k0 + 4 * kq, a.D, row < a.row_end, vec4);
+      pi[q] = load_row4(p_X, row, p_ldx, k0 + 4 * kq, p_D, row < p_row_end, vec4);
     }
 #pragma unroll
     for (int q = 0; q < QJ; ++q) {
       int row = j0 + rb + 32 * q;
-      pj[q] = load_row4(a.X, row, a.ldx, k0 + 4 * kq, a.D, row < a.B, vec4);
+      pj[q] = load_row4(p_X, row, p_ldx, k0 + 4 * kq, p_D, row < p_B, vec4);
     }
   };
   gload(0);
-  for (int k0 = 0; k0 < a.D; k0 += KC) {
+  for (int k0 = 0; k0 < p_D; k0 += KC) {
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < QI; ++q)
@@ -320,7 +326,7 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const SkArgs a) {
     for (int q = 0; q < QJ; ++q)
       *reinterpret_cast<float4*>(&Xj_s[(rb + 32 * q) * LS + 4 * kq]) = PMODE == 2 ? phase4(pj[q], a.rp_hi, a.rp_lo) : pj[q];
     __syncthreads();
-    if (k0 + KC < a.D) gload(k0 + KC);
+    if (k0 + KC < p_D) gload(k0 + KC);
 #pragma unroll 2
     for (int kk = 0; kk < KC; kk += 4) {
       float4 av[RM];
@@ -995,7 +1001,8 @@ SigDev make_sig(float sig, float aa, float bb) {
 
 template <int T, int LT, int PMODE, bool FAST>
 void launch_tiles(const SkArgs& a, int ntiles, hipStream_t st) {
-  hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PMODE, FAST>), dim3(ntiles), dim3(NT), 0, st, a);
+  hipLaunchKernelGGL((sk_tile_kernel<T, T, LT, PMODE, FAST>), dim3(ntiles), dim3(NT), 0, st, a.X, a.ldx, a.D, a.B, a.row0, a.row_end, a.nbc, a.symm,
+                     a.xcd_nbg, a.vec4, a.deal_world, a.deal_rank, 0, a);
 }
 
 template <int T, int LT>
