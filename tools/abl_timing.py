@@ -1,5 +1,5 @@
 """Reads the in-kernel timestamps of an EMX_CHAIN_TIMING build of the row-block chain kernel (kernel experiments).
-   hipcc ... -DEMX_CHAIN_TIMING -o build_ab/libemx_timing.so ; python tools/abl_timing.py build_ab/libemx_timing.so [fused|fwd] [B] [D]"""
+   hipcc (the build line of __graft_entry__.build, with -mllvm -amdgpu-kernarg-preload-count=16) -DEMX_CHAIN_TIMING -o build_ab/libemx_timing.so ; python tools/abl_timing.py build_ab/libemx_timing.so [fused|fwd] [B] [D]"""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
