@@ -318,11 +318,13 @@ def test_forward_with_cost_equals_separate_kernels(L, periodicity, variant, D, B
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("periodicity,D", [(float("inf"), 128), (2 * np.pi, 10), (360.0, 33)])
-def test_adam_gathers_the_next_batch(L, periodicity, D):
-    """emx_adam_step(next) leaves the rows of batch cursor + 1 in xb / xin exactly as emx_gather_rows would, skips the gather
-    beyond the last batch of the index block, and still performs the same update."""
-    B, N, nb = 96, 500, 3
+@pytest.mark.parametrize("periodicity,D,B", [(float("inf"), 128, 96), (2 * np.pi, 10, 96), (360.0, 33, 96),
+                                             # rows whose width is a multiple of 4: two rows per wave on 16-byte lanes (odd B: a half-empty wave)
+                                             (float("inf"), 36, 97), (2 * np.pi, 12, 97), (360.0, 200, 33), (float("inf"), 300, 5)])
+def test_adam_gathers_the_next_batch(L, periodicity, D, B):
+    """emx_adam_step(next) leaves the rows of batch cursor + 1 in xb / xin (and their split planes) exactly as emx_gather_rows
+    would, skips the gather beyond the last batch of the index block, and still performs the same update."""
+    N, nb = 500, 3
     periodic = np.isfinite(periodicity)
     g = torch.Generator().manual_seed(1)
     data = ((torch.rand(N, D, generator=g) - 0.5) * (periodicity if periodic else 4.0)).cuda()
@@ -336,7 +338,8 @@ def test_adam_gathers_the_next_batch(L, periodicity, D):
         cursor = torch.tensor([cur], dtype=torch.int64, device="cuda")
         xb = torch.full((B, D), -7.0, device="cuda")
         xin = torch.full((B, 2 * D), -7.0, device="cuda") if periodic else None
-        nxt = L.make_next_batch(data, idx, cursor, B, periodicity, xb, xin)
+        split = None if periodic else torch.full((L.sketchmap_split_bytes(B, D),), 0x5A, dtype=torch.uint8, device="cuda")
+        nxt = L.make_next_batch(data, idx, cursor, B, periodicity, xb, xin, split)
         w1, m1, v1 = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
         w2, m2, v2 = w.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
         L.adam_step(w1, grad, m1, v1, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, next_batch=nxt)
@@ -350,6 +353,16 @@ def test_adam_gathers_the_next_batch(L, periodicity, D):
             assert torch.equal(xb, data[idx[(cur + 1) * B:(cur + 2) * B]])
             if periodic:
                 assert torch.equal(xin, xin_ref)
+            else:   # the split rows of the all-pairs kernel: planes bit for bit, norms to the order of their sums
+                split_ref = torch.full_like(split, 0x5A)
+                L.gather_rows(data, idx, periodicity, torch.zeros(B, D, device="cuda"), None, cursor=torch.tensor([cur + 1], device="cuda"), B=B,
+                              split_ws=split_ref)
+                torch.cuda.synchronize()
+                n_plane = 2 * 2 * B * ((D + 31) // 32 * 32)
+                assert torch.equal(split[:n_plane], split_ref[:n_plane])
+                tail = split[n_plane:].view(torch.float32).cpu().numpy(), split_ref[n_plane:].view(torch.float32).cpu().numpy()
+                np.testing.assert_allclose(tail[0][:B], tail[1][:B], rtol=2e-6)        # squared norms
+                np.testing.assert_array_equal(tail[0][B:2 * B], tail[1][B:2 * B])      # 1 / scale
         else:
             assert float(xb.max()) == -7.0   # nothing gathered behind the last batch
 
