@@ -457,15 +457,15 @@ __device__ __forceinline__ float grad1(const AdamArgs& a, long i) {
 // batch cursor -- without a trip to the argument segment; the plane's record (its address depends on the workgroup index
 // alone) is the only trip in front of an optimizer wave's operand loads, where the role fields used to be a first one.
 __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_hist, int p_next_vec4, int p_batch_step, const int64_t* p_step,
-                                                  const char* p_mirror, const int64_t* p_cursor, const int64_t* p_idx, int p_B, int p_n_batches,
-                                                  const AdamArgs a) {
+                                                  const char* p_mirror, const int64_t* p_cursor, const int64_t* p_idx, int p_B, int p_grid,
+                                                  const AdamArgs a) {   // (p_grid = gridDim.x: the hidden argument would be a trip of its own)
   constexpr int EXPLICIT_BYTES = 56;
   __shared__ float red[NT / 64];
-  const int nt = blockDim.x;
+  constexpr int nt = 64;   // = ADAM_NT, the launch's workgroup size (blockDim.x is a hidden argument: a trip)
   ASTAMP(32, 0);
   ASTAMP(40, p_adam_blocks);
-  ASTAMP(42, (int)gridDim.x - 2);
-  if (p_has_hist && blockIdx.x == gridDim.x - 1) {
+  ASTAMP(42, p_grid - 2);
+  if (p_has_hist && (int)blockIdx.x == p_grid - 1) {
     if (threadIdx.x == 0) {
       const long hs = *a.hstep - 1;
       float tl[64];
@@ -483,17 +483,16 @@ __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_h
   if ((int)blockIdx.x >= p_adam_blocks) {
     // the optimizer is a short, latency-bound stream over ~1e5 parameters; the rows of the NEXT batch are gathered
     // beside it, on other CUs, instead of in a launch of their own at the head of the next step
-    const int gb = blockIdx.x - p_adam_blocks, ngb = gridDim.x - p_adam_blocks - (p_has_hist ? 1 : 0);
+    const int gb = blockIdx.x - p_adam_blocks, ngb = p_grid - p_adam_blocks - (p_has_hist ? 1 : 0);
     GatherArgs gl = a.next;   // (cursor, index block and batch shape from the preloaded scalars: the cursor load goes out at once)
     gl.cursor = p_cursor;
     gl.idx = p_idx;
     gl.B = p_B;
     gl.batch_step = p_batch_step;
-    gl.n_batches = p_n_batches;
     if (p_next_vec4) gather_rows2_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     else gather_rows_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     ASTAMP(41, p_adam_blocks);
-    ASTAMP(43, (int)gridDim.x - 2);
+    ASTAMP(43, p_grid - 2);
     return;
   }
   const int nblk = p_adam_blocks;
@@ -857,7 +856,7 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 }
 
 namespace {
-constexpr int ADAM_NT = 64;   // one wave per workgroup (see adam_kernel)
+constexpr int ADAM_NT = 64;   // one wave per workgroup (see adam_kernel, which has the number built in)
 inline bool gather_vec4(const emx_next_batch* next) {
   return next && next->D % 4 == 0 && ((reinterpret_cast<uintptr_t>(next->data) | reinterpret_cast<uintptr_t>(next->xb) |
                                        reinterpret_cast<uintptr_t>(next->xin)) & 15) == 0;
@@ -884,7 +883,7 @@ inline int adam_grid(const AdamArgs& a, int64_t n) {
 
 #define ADAM_LAUNCH(grid_, st_, a_)                                                                                                       \
   hipLaunchKernelGGL(adam_kernel, dim3(grid_), dim3(ADAM_NT), 0, st_, (a_).adam_blocks, (a_).hstep != nullptr ? 1 : 0, (a_).next_vec4,          \
-                     (a_).next.batch_step, (a_).step, (const char*)(a_).mirror, (a_).next.cursor, (a_).next.idx, (a_).next.B, (a_).next.n_batches, \
+                     (a_).next.batch_step, (a_).step, (const char*)(a_).mirror, (a_).next.cursor, (a_).next.idx, (a_).next.B, (int)(grid_),          \
                      a_)
 
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,

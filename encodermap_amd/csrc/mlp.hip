@@ -870,7 +870,7 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 // hands them over in scalar registers at wave launch (gfx940+), so the layer's record -- and behind it the fragments -- can be
 // requested with the first instructions instead of after a trip for the head (tile table packed as 13 x 16 bits).
 __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
-                                                       unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int has_fin, int pad_, float* partial,
+                                                       unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int has_fin, int grid_x, float* partial,
                                                        long n_params, const WgradDev a) {   // (14 dwords are preloaded: up to `partial`)
   WSTAMP(0);
   __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
@@ -883,8 +883,9 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
     float* partial;
     long n_params;
   } hd{rb0, rb_end, rbs_per_slice, has_fin, partial, n_params};
-  (void)pad_;   // (the explicit scalars are 64 bytes: 7 + 4 + 1 dwords, a pointer, a long -- the record array's offset above)
-  if (hd.has_fin && blockIdx.x == gridDim.x - 1) {
+  // (the explicit scalars are 64 bytes: 7 + 4 + 1 dwords, a pointer, a long -- the record array's offset above; grid_x = gridDim.x,
+  //  which as a hidden argument would be a trip of its own)
+  if (hd.has_fin && (int)blockIdx.x == grid_x - 1) {
     // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs are complete
     // before this launch starts, and a launch of its own costs ~6.5 us of the step.
     if (blockIdx.y == 0) finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);
@@ -1559,7 +1560,7 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   }
   EMX_REQUIRE(tiles < 0xffff, "%s: %d output blocks", who, tiles);
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(tiles + a.h.has_fin, slices), dim3(NT), 0, st, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4], tbw[5], tbw[6],
-                     a.h.rb0, a.h.rb_end, a.h.rbs_per_slice, a.h.has_fin, 0, a.h.partial, a.h.n_params, a);
+                     a.h.rb0, a.h.rb_end, a.h.rbs_per_slice, a.h.has_fin, tiles + a.h.has_fin, a.h.partial, a.h.n_params, a);
   rc = emx::check_launch("mlp_wgrad_kernel");
   if (rc) return rc;
   if (!grad) return EMX_OK;   // the caller sums the slices itself (emx_adam_step_slices)
