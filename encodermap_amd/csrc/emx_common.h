@@ -34,10 +34,21 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
+// Sum over the 64 lanes of a wave, in every lane; all lanes must be active.  The association is the xor butterfly's
+// (1, 2, 4, 8, 16, 32) -- bit for bit what six __shfl_xor steps give -- but none of the steps goes through the LDS crossbar
+// (ds_bpermute_b32: ~100 cycles each, and each waits for the one before): within a row of 16 lanes the partner's value comes
+// by DPP (quad permutations; then mirrors, which exchange the right groups because all lanes of a group already agree), and
+// the four row sums are read into scalar registers.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // lane ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // lane ^ 2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror: quad ^ 1
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror: group of 8 ^ 1
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (r0 + r1) + (r2 + r3);   // (rows ^ 1, then halves ^ 1: every lane of the butterfly ends with this sum, up to commutations)
 }
 
 // Block-wide sum for blocks of NT threads (multiple of 64); result valid in thread 0.

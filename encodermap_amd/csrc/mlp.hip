@@ -186,45 +186,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
   float* lat = reinterpret_cast<float*>(lds + a.lat_off);
   float* tgt = reinterpret_cast<float*>(lds + a.tgt_off);
 
-  if (BWD && a.join_n > 0) {
-    // rows joined into dh of one layer: dadd and / or the latent gradient of the all-pairs cost (one wave per element,
-    // lanes over the per-tile slots, fixed order)
-    const int N = a.join_n;
-    if (a.lg.partials != nullptr) {
-      // (four elements per wave and pass, every load of the pass requested before the first sum: the partials were written
-      //  by the all-pairs kernel on other XCDs a moment ago, a dependent trip per element was four trips)
-      for (int el0 = wave; el0 < R * N; el0 += 4 * NWC) {
-        float v[4], zz[4], dd[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int el = el0 + u * NWC;
-          const int r = el / N, c = el - r * N;
-          const bool rok = el < R * N && r0 + r < a.row_end;
-          v[u] = 0.f, zz[u] = 0.f, dd[u] = 0.f;
-          if (rok) {
-            const float* __restrict__ P = a.lg.partials + (long)(r0 + r - a.lg.row_base) * N + c;
-            for (int sidx = lane; sidx < a.lg.n_slots; sidx += 64) v[u] += P[(long)sidx * a.lg.slot_stride];
-            const long gi = (long)(r0 + r) * N + c;
-            zz[u] = a.lg.Z[gi];
-            if (a.dadd != nullptr) dd[u] = a.dadd[gi];
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int el = el0 + u * NWC;
-          const float sum = wave_sum(v[u]);
-          if (lane == 0 && el < R * N) lat[el] = fmaf(a.lg.center_grad, zz[u], a.lg.gscale * sum) + dd[u];
-        }
-      }
-    } else {
-      for (int el = tid; el < R * N; el += NTC) {
-        const int r = el / N, c = el - r * N;
-        lat[el] = r0 + r < a.row_end ? a.dadd[(long)(r0 + r) * N + c] : 0.f;
-      }
-    }
-    __syncthreads();
-  }
-
+  // (the rows joined into dh of one layer are collected in stage_rest, behind the requests for the row block and for the first
+  //  packages: everything this launch waits for first is then in flight together)
   // ---- staging a row block [16][ncols] of float32 values into an image: wave w takes the column groups w, w + 8, ...;
   //      lane (c = lane & 31, hf = lane >> 5) the column 32 group + c, rows 8 hf .. 8 hf + 7 -- its 8 halves are 16
   //      contiguous bytes of the transposed plane AND, with lane as the fragment's lane, the weight-gradient fragment (aop.h).
@@ -708,9 +671,54 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) tv[i] = p_target[grow * p_ldt + min(c + i, p_cost_n - 1)];
   }
+  auto join_rows = [&]() __attribute__((always_inline)) {
+  if (BWD && a.join_n > 0) {
+    // rows joined into dh of one layer: dadd and / or the latent gradient of the all-pairs cost (one wave per element,
+    // lanes over the per-tile slots, fixed order)
+    const int N = a.join_n;
+    if (a.lg.partials != nullptr) {
+      // (four elements per wave and pass, every load of the pass requested before the first sum: the partials were written
+      //  by the all-pairs kernel on other XCDs a moment ago, a dependent trip per element was four trips)
+      for (int el0 = wave; el0 < R * N; el0 += 4 * NWC) {
+        float v[4], zz[4], dd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int el = el0 + u * NWC;
+          const int r = el / N, c = el - r * N;
+          const bool rok = el < R * N && r0 + r < a.row_end;
+          v[u] = 0.f, zz[u] = 0.f, dd[u] = 0.f;
+          if (rok) {
+            const float* __restrict__ P = a.lg.partials + (long)(r0 + r - a.lg.row_base) * N + c;
+            // (up to 64 slots -- batches of up to 4096 rows -- are ONE load per lane and element, clamped and masked instead of
+            //  looped: behind a loop the compiler waits for each element's load before it requests the next one's)
+            const int s0 = min(lane, a.lg.n_slots - 1);
+            v[u] = P[(long)s0 * a.lg.slot_stride] * (lane < a.lg.n_slots ? 1.f : 0.f);
+            for (int sidx = lane + 64; sidx < a.lg.n_slots; sidx += 64) v[u] += P[(long)sidx * a.lg.slot_stride];
+            const long gi = (long)(r0 + r) * N + c;
+            zz[u] = a.lg.Z[gi];
+            if (a.dadd != nullptr) dd[u] = a.dadd[gi];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int el = el0 + u * NWC;
+          const float sum = wave_sum(v[u]);
+          if (lane == 0 && el < R * N) lat[el] = fmaf(a.lg.center_grad, zz[u], a.lg.gscale * sum) + dd[u];
+        }
+      }
+    } else {
+      for (int el = tid; el < R * N; el += NTC) {
+        const int r = el / N, c = el - r * N;
+        lat[el] = r0 + r < a.row_end ? a.dadd[(long)(r0 + r) * N + c] : 0.f;
+      }
+    }
+    __syncthreads();
+  }
+  };
   TSTAMP(1);
   const float zero8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto stage_rest = [&]() __attribute__((always_inline)) {
+    join_rows();
     const int lo_off = a.in_Qp * 1024;
     if (wave < a.in_Q) {
       float v[8];

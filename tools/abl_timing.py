@@ -22,6 +22,16 @@ if mode == "fused":
     cost = _lib.make_auto_cost(x, D, 0, D, False, float("inf"), "mean_square", 1.0, B, dl[-1], cws)
     for _ in range(20): _lib.mlp_forward_backward(plan, 0, n, x, 0, B, cost, lay.n_enc, dbelow=dlat)
     n = n + 3   # units: 6 forward + 3 backward
+elif mode == "bwd_latent":   # the same with the latent gradient joined from the all-pairs kernel's per-tile partial sums (unchanged between launches)
+    dlat = torch.randn(B, 2, device="cuda")
+    _lib.mlp_forward(plan, 0, n, x, 0, B)
+    Z = h[lay.n_enc - 1]
+    sig = (16.0, 12, 6, 1, 2, 6)
+    ws = torch.empty(_lib.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
+    _lib.sketchmap_tiles(x, Z, float("inf"), sig, 0, B, ws, None)
+    sk = _lib.sketchmap_describe(x, Z, float("inf"), sig, 500.0, 1e-4, 0, B, ws)
+    for _ in range(20): _lib.mlp_backward(plan, 0, lay.n_enc, dlat, None, lay.n_enc - 1, 0, B, latent=sk.grad)
+    n = lay.n_enc
 elif mode == "bwd":     # the encoder's backward launch of the step (latent gradient joined in)
     dlat = torch.randn(B, 2, device="cuda"); dZ = torch.randn(B, 2, device="cuda")
     _lib.mlp_forward(plan, 0, n, x, 0, B)
