@@ -142,10 +142,17 @@ __device__ __forceinline__ void gather_rows2_body(const GatherArgs& g, int wave,
         nrm = fmaf(v0, v0, fmaf(v1, v1, fmaf(v2, v2, fmaf(v3, v3, nrm))));
         mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));
       }
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {   // (within the half-wave)
-        mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        nrm += __shfl_xor(nrm, o, 64);
+      // (within the half-wave: lane ^ 16 by a lane swap, the rest by DPP inside the rows of 16 -- no ds_bpermute)
+      {
+        unsigned ma, mb;
+        lane_xor16_pair(__float_as_uint(mx), ma, mb);
+        mx = fmaxf(__uint_as_float(ma), __uint_as_float(mb));
+        nrm = sum_xor16(nrm);
+#define GR_STEP(ctl_)                                                                                                             \
+  mx = fmaxf(mx, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, mx), ctl_, 0xF, 0xF, true)));  \
+  nrm += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, nrm), ctl_, 0xF, 0xF, true));
+        GR_STEP(0x140) GR_STEP(0x141) GR_STEP(0x4E) GR_STEP(0xB1)   // groups of 8, quads, lane ^ 2, lane ^ 1
+#undef GR_STEP
       }
       int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;   // as split_row
       E = mx > 0.f ? min(max(E, -100), 100) : 14;

@@ -34,6 +34,32 @@ inline int check_launch(const char* what) {
 
 constexpr int WAVE = 64;
 
+// The value of lane ^ 16 / lane ^ 32 beside the lane's own, as the unordered pair (a, b): v_permlane16_swap_b32 /
+// v_permlane32_swap_b32 (gfx950) exchange the odd rows (the upper half) of one register with the even rows (the lower half)
+// of another -- applied to two copies of x, every lane then holds its own value in one and its partner's in the other.  A VALU
+// instruction (no LDS crossbar, no wait) where __shfl_xor is a ds_bpermute_b32; for commutative combinations (sum, max) the
+// order inside the pair does not matter.  All lanes must be active.
+__device__ __forceinline__ void lane_xor16_pair(unsigned x, unsigned& a, unsigned& b) {
+  a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void lane_xor32_pair(unsigned x, unsigned& a, unsigned& b) {
+  a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ unsigned max_xor16(unsigned x) { unsigned a, b; lane_xor16_pair(x, a, b); return a > b ? a : b; }
+__device__ __forceinline__ unsigned max_xor32(unsigned x) { unsigned a, b; lane_xor32_pair(x, a, b); return a > b ? a : b; }
+__device__ __forceinline__ float sum_xor16(float x) {
+  unsigned a, b;
+  lane_xor16_pair(__builtin_bit_cast(unsigned, x), a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float sum_xor32(float x) {
+  unsigned a, b;
+  lane_xor32_pair(__builtin_bit_cast(unsigned, x), a, b);
+  return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+
 // Sum over the 64 lanes of a wave, in every lane; all lanes must be active.  The association is the xor butterfly's
 // (1, 2, 4, 8, 16, 32) -- bit for bit what six __shfl_xor steps give -- but none of the steps goes through the LDS crossbar
 // (ds_bpermute_b32: ~100 cycles each, and each waits for the one before): within a row of 16 lanes the partner's value comes

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       unsigned m = row16_max(abs_bits(v[e]));
-      m = max(m, (unsigned)__shfl_xor((int)m, 16, 64));
+      m = max_xor16(m);
       pow2_scale_bits<ACT_TOP>(m, s[e], rs[e]);
       bm = max(bm, m);
     }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
     }
     if (keep_frag && ao.frag != nullptr) {
       // block scale (16 rows x 32 columns) for the weight gradients: the row-scaled pair with its exponents shifted
-      bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
+      bm = max_xor32(bm);
       float sb, rsb;
       pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
       half8 fh, fl;
@@ -584,7 +584,7 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
             for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(4 * g + reg < rows_valid ? 1.f : 0.f);
           } else {
             bm = max(bm, (unsigned)__shfl_xor((int)bm, 16, 64));
-            bm = max(bm, (unsigned)__shfl_xor((int)bm, 32, 64));
+            bm = max_xor32(bm);
             float sb;
             pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
 #pragma unroll
@@ -1078,7 +1078,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
         __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(out + L.b_off, 0, N * 4, 0x00020000);
 #pragma unroll
         for (int v = 0; v < 2; ++v) {
-          const float bsum = bacc[v] + __shfl_xor(bacc[v], 32, 64);   // rows 0..7 and 8..15 of the row blocks
+          const float bsum = sum_xor32(bacc[v]);   // rows 0..7 and 8..15 of the row blocks
           const int jj = 32 * (jg0 + v) + lane;
           __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rb, (lane < 32 && jact[v]) ? (unsigned)(jj * 4) : 0x80000000u, 0, 0);
         }

@@ -627,7 +627,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
   if (offdiag) {
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-      float s = gj[l] + __shfl_xor(gj[l], 32, 64);   // the two row halves of the quadrant
+      float s = sum_xor32(gj[l]);   // the two row halves of the quadrant
       if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
     }
   }
@@ -869,7 +869,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   if (offdiag) {
 #pragma unroll
     for (int l = 0; l < LMAX; ++l) {
-      float s = gj[l] + __shfl_xor(gj[l], 32, 64);   // the two row halves of the quadrant
+      float s = sum_xor32(gj[l]);   // the two row halves of the quadrant
       if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
     }
   }

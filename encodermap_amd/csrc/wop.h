@@ -112,10 +112,12 @@ __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x
 constexpr int WOP_TOP = 13;    // weights: the layer's maximum goes to [2^12, 2^13)
 constexpr int ACT_TOP = 14;    // activations and gradients: a group's maximum goes to [2^13, 2^14)
 
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-  return v;
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {   // (all lanes active; DPP inside the rows, lane swaps across them: no ds_bpermute)
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true));
+  v = max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true));
+  return max_xor32(max_xor16(v));
 }
 
 __device__ __forceinline__ half4 lds_read_tr16(const _Float16* p) {
