@@ -717,13 +717,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  // latent rows of the tile's i side -> LDS (read back as broadcasts in the epilogue instead of living in registers)
-  for (int e = tid; e < T * LMAX; e += NT) {
-    const int rl = e / LMAX, l = e - rl * LMAX;
-    const int ig = min(i0 + rl, a.B - 1);
-    zi_s[e] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
-  }
-
   // ---- K loop: 32 reduction indices per chunk; the four operand planes of the tile's 64 + 64 rows are staged as 16-byte
   //      pieces (8 f16) -- one contiguous 4-KB block per side and plane in the chunk-major planes -- through an LDS image
   //      that is XOR-swizzled so that the ds_read_b128 of 16 consecutive rows covers all 64 banks; 2 x 3 MFMAs per chunk
@@ -772,6 +765,14 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   }
   if (kmode == 0) SK_GLOAD(0)   // ahead of the small prologue loads
   KSTAMP(1);
+  // latent rows of the tile's i side -> LDS (read back as broadcasts in the epilogue instead of living in registers).  Behind
+  // the first chunk's requests: the latent was written by the launch in front of this one, its first use costs a full trip to
+  // memory, and in front of the requests that trip was what every tile's first chunk waited for.
+  for (int e = tid; e < T * LMAX; e += NT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const int ig = min(i0 + rl, a.B - 1);
+    zi_s[e] = (l < L) ? a.Z[(long)ig * L + l] : 0.f;
+  }
   for (int e = tid; e < 2 * T; e += NT) {             // (norm, 1/scale) of both sides' rows
     const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
     nr_s[e] = make_float2(sp.norms[grow], sp.rscale[grow]);
