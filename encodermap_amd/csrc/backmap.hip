@@ -361,6 +361,10 @@ template <int V>
 struct RingIdx {
   static constexpr int value = V;
 };
+template <int V>
+struct DppC {
+  static constexpr int value = V;
+};
 constexpr int FR_NT_FWD = 128, FR_NT_BWD = 256;   // backward: waves 2, 3 run the adjoint recurrence of the two parts
 
 __device__ __forceinline__ void lds_put9(float* d, const M3& m) {
@@ -393,6 +397,72 @@ __device__ __forceinline__ M3 add(const M3& a, const M3& b) {
   return m;
 }
 
+__device__ __forceinline__ M3 zero3() {
+  M3 m;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) m.m[r][c] = 0.f;
+  return m;
+}
+
+// rigid transform x -> R x + t; compose(P, X) = P o X (X first)
+struct Aff {
+  M3 R;
+  V3 t;
+};
+__device__ __forceinline__ Aff aff_identity() { return Aff{identity(), V3{0.f, 0.f, 0.f}}; }
+__device__ __forceinline__ Aff compose(const Aff& P, const Aff& X) { return Aff{mul(P.R, X.R), mul(P.R, X.t) + P.t}; }
+
+// the value of another lane by DPP (row_shr:n 0x110 + n, row_bcast:15 0x142, row_bcast:31 0x143, wave_shr:1 0x138); lanes
+// without a source lane, and rows outside the row mask, receive `neutral`
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_from(float v, float neutral) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, neutral), __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+template <int CTRL, int ROWS>
+__device__ __forceinline__ Aff aff_from(const Aff& x) {
+  Aff p;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p.R.m[r][c] = dpp_from<CTRL, ROWS>(x.R.m[r][c], r == c ? 1.f : 0.f);
+  p.t = V3{dpp_from<CTRL, ROWS>(x.t.x, 0.f), dpp_from<CTRL, ROWS>(x.t.y, 0.f), dpp_from<CTRL, ROWS>(x.t.z, 0.f)};
+  return p;
+}
+// product of the transforms of all lanes below this one (lane 0: the identity), lower lanes on the left
+__device__ __forceinline__ Aff aff_scan_exclusive(Aff x) {
+  x = compose(aff_from<0x111, 0xF>(x), x);
+  x = compose(aff_from<0x112, 0xF>(x), x);
+  x = compose(aff_from<0x114, 0xF>(x), x);
+  x = compose(aff_from<0x118, 0xF>(x), x);
+  x = compose(aff_from<0x142, 0xA>(x), x);
+  x = compose(aff_from<0x143, 0xC>(x), x);
+  return aff_from<0x138, 0xF>(x);
+}
+// the same scan with additions, over 9 + 3 floats
+__device__ __forceinline__ void sum_scan_exclusive(M3 a, V3 v, M3& ea, V3& ev) {
+  auto round = [&](auto CT, auto RM) __attribute__((always_inline)) {
+    constexpr int C = decltype(CT)::value, RW = decltype(RM)::value;
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.m[r][c] += dpp_from<C, RW>(a.m[r][c], 0.f);
+    v = V3{v.x + dpp_from<C, RW>(v.x, 0.f), v.y + dpp_from<C, RW>(v.y, 0.f), v.z + dpp_from<C, RW>(v.z, 0.f)};
+  };
+  round(DppC<0x111>{}, DppC<0xF>{});
+  round(DppC<0x112>{}, DppC<0xF>{});
+  round(DppC<0x114>{}, DppC<0xF>{});
+  round(DppC<0x118>{}, DppC<0xF>{});
+  round(DppC<0x142>{}, DppC<0xA>{});
+  round(DppC<0x143>{}, DppC<0xC>{});
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) ea.m[r][c] = dpp_from<0x138, 0xF>(a.m[r][c], 0.f);
+  ev = V3{dpp_from<0x138, 0xF>(v.x, 0.f), dpp_from<0x138, 0xF>(v.y, 0.f), dpp_from<0x138, 0xF>(v.z, 0.f)};
+}
+
 // LDS floats of the per-frame kernels: the frame (and its gradient), then 12 (forward) / 36 (backward) per step
 __host__ __device__ inline long d2c_frame_floats(int A, bool bwd) { return (long)(bwd ? 6 : 3) * A + (long)(bwd ? 36 : 12) * (A > 4 ? A - 2 : 2); }
 
@@ -418,8 +488,12 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   const int nd0 = max(g.natoms(0) - 3, 0);
   float* Sd = S + (long)(dir ? nd0 : 0) * SW;
   DSTAMP(0);
+  // (coordinates relative to the middle atom, the one both parts start from: the map commutes with translations, and a
+  //  step's translation part is as large as its axis is far from the origin -- float32 rounding scales with that distance)
+  const V3 ctr = ld3(P + 3 * g.s);
   for (int e = tid; e < 3 * A; e += FR_NT) {
-    Pf[e] = P[e];
+    const int c3 = e % 3;
+    Pf[e] = P[e] - (c3 == 0 ? ctr.x : c3 == 1 ? ctr.y : ctr.z);
     if (BWD) Gf[e] = dout[(long)b * A * 3 + e];
   }
   __syncthreads();
@@ -437,90 +511,84 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   }
   __syncthreads();
   DSTAMP(2);
-  // ---- phase B: the serial part, out of LDS.  The state of a recurrence is a 3 x 4 matrix, [R | t] or [Rb | tb]; lane
-  //      4 r + c of the wave's first three quads holds element (r, c), and a step is  state <- state x (4 x 4 step matrix):
-  //      four FMAs per lane whose left factors are the row's elements, broadcast inside the quad (DPP quad_perm), and whose
-  //      right factors are one column of the step matrix, fetched from LDS one step ahead.  ~50 dependent cycles per step
-  //      instead of the ~40 FMAs of a whole 3 x 3 product issued for one useful lane.
-  {
-    const int qc = lane & 3, qr = min(lane >> 2, 2);
-    const bool keep = lane < 12, mat = qc < 3;
-    auto step_product = [](float val, const float (&Bv)[4]) {
-      const int iv = __builtin_bit_cast(int, val);
-      const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x00, 0xF, 0xF, true));
-      const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0x55, 0xF, 0xF, true));
-      const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0xAA, 0xF, 0xF, true));
-      const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(iv, 0xFF, 0xF, 0xF, true));
-      return fmaf(a3, Bv[3], fmaf(a2, Bv[2], fmaf(a1, Bv[1], a0 * Bv[0])));
-    };
-    if (role == 0) {
-      // ascending:  [R | t] <- [R | t] [[Q, c], [0, 1]]   (R_i = R_{i-1} Q_i,  t_i = R_{i-1} c_i + t_{i-1})
-      const int o0 = mat ? qc : 9, o1 = mat ? 3 + qc : 10, o2 = mat ? 6 + qc : 11;
-      const float b3 = mat ? 0.f : 1.f;
-      float val = (mat && qc == (lane >> 2)) ? 1.f : 0.f;
-      // right factors two steps ahead, in a ring of three register sets addressed at compile time (a rotation by register
-      // moves would wait for the load it has just issued): the LDS latency of a step's column stays off the serial path
-      float Bf[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-      if (nd > 0) {
-        const float* qa = Sd;
-        const float* qb = Sd + (long)min(1, nd - 1) * SW;
-        Bf[0][0] = qa[o0]; Bf[0][1] = qa[o1]; Bf[0][2] = qa[o2];
-        Bf[1][0] = qb[o0]; Bf[1][1] = qb[o1]; Bf[1][2] = qb[o2];
+  // ---- phase B: the recurrences as scans over the lanes.  [R_i | t_i] is the prefix product M_0 ... M_i of the steps' rigid
+  //      transforms M = [[Q, c], [0, 1]], an associative product: lane l folds its run of m = ceil(nd / 64) consecutive steps
+  //      (local prefixes stay in LDS), the lanes' totals go through an inclusive wave scan (row_shr 1, 2, 4, 8, row_bcast 15,
+  //      31: a lane without a partner receives the identity, whose product is exact), and every local prefix is multiplied from
+  //      the left by what precedes its lane.  12 + 2 m products of 3 x 4 transforms per lane instead of nd dependent steps on
+  //      one lane (160 cycles each: 18 000 of the forward kernel's 21 700 cycles at 228 atoms).
+  //      Backward: the adjoint recurrence  V_j = V_{j+1} M_{j+1}^T + g_j (x) [p_j | 1]  unrolls to
+  //      V_j = [ (sum_{k >= j} g_k (x) (out_k - t_j)) R_j | sum_{k >= j} g_k ]  (out_k = R_k p_k + t_k, the step's output atom):
+  //      a plain suffix sum of g (x) [out | 1] over the steps -- the same scan with additions, lanes in descending step order
+  //      -- followed by one change of frame per step.
+  if (role == 0 && nd > 0) {
+    const int m = (nd + 63) >> 6;
+    const int s0 = lane * m;
+    constexpr int RO = BWD ? 12 : 0, TO = BWD ? 33 : 9;   // where a step's [R | t] lives
+    Aff acc = aff_identity();
+    for (int s = 0; s < m; ++s) {
+      const int k = s0 + s;
+      if (k < nd) {
+        float* q = Sd + (long)k * SW;
+        const Aff X{lds_get9(q), ld3(q + 9)};
+        acc = compose(acc, X);
+        lds_put9(q + RO, acc.R);
+        st3(q + TO, acc.t);
       }
-      auto fstep = [&](auto RC, const int k) {
-        constexpr int r = decltype(RC)::value, rn = (r + 2) % 3;
-        float* q = Sd + k * SW;
-        const float* qn = Sd + min(k + 2, nd - 1) * SW;
-        Bf[rn][0] = qn[o0];
-        Bf[rn][1] = qn[o1];
-        Bf[rn][2] = qn[o2];
-        const float Bv[4] = {Bf[r][0], Bf[r][1], Bf[r][2], b3};
-        val = step_product(val, Bv);
-        if (keep) {
-          if (BWD) {
-            if (mat) q[12 + 3 * qr + qc] = val;
-          } else {
-            q[mat ? 3 * qr + qc : 9 + qr] = val;
-          }
+    }
+    const Aff E = aff_scan_exclusive(acc);
+    float* O = BWD ? nullptr : out + (long)b * A * 3;
+    for (int s = 0; s < m; ++s) {
+      const int k = s0 + s;
+      if (k < nd) {
+        float* q = Sd + (long)k * SW;
+        const Aff Lk{lds_get9(q + RO), ld3(q + TO)};
+        const Aff Sk = compose(E, Lk);
+        const int a3 = g.atom(dir, k + 3);
+        const V3 o = mul(Sk.R, ld3(Pf + 3 * a3)) + Sk.t;
+        if (BWD) {
+          lds_put9(q + RO, Sk.R);
+          st3(q + TO, Sk.t);
+          lds_put9(q + 24, outer(ld3(Gf + 3 * a3), o));
+        } else {
+          st3(O + 3 * a3, o + ctr);
         }
-      };
-      for (int k = 0; k < nd; k += 3) {
-        fstep(RingIdx<0>{}, k);
-        if (k + 1 < nd) fstep(RingIdx<1>{}, k + 1);
-        if (k + 2 < nd) fstep(RingIdx<2>{}, k + 2);
       }
-    } else if (BWD) {
-      // descending:  [Rb | tb] += g (x) [p | 1]  (kept for phase C), then  [Rb | tb] <- [Rb | tb] [[Q^T, 0], [c^T, 1]]
-      const int o0 = mat ? 3 * qc : 0, o1 = o0 + 1, o2 = o0 + 2, o3 = mat ? 9 + qc : 0;
-      float val = 0.f;
-      auto fetch = [&](int j, float (&Bv)[4], float& gr, float& pp) {
-        const float* q = Sd + (long)j * SW;
-        const int a3 = g.atom(dir, j + 3);
-        gr = Gf[3 * a3 + qr];
-        pp = mat ? Pf[3 * a3 + qc] : 1.f;
-        Bv[0] = mat ? q[o0] : 0.f;
-        Bv[1] = mat ? q[o1] : 0.f;
-        Bv[2] = mat ? q[o2] : 0.f;
-        Bv[3] = mat ? q[o3] : 1.f;
-      };
-      // (two steps ahead in a ring of three register sets, as above)
-      float Bq[3][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, gq[3] = {0.f, 0.f, 0.f}, pq[3] = {0.f, 0.f, 0.f};
-      if (nd > 0) {
-        fetch(nd - 1, Bq[0], gq[0], pq[0]);
-        fetch(max(nd - 2, 0), Bq[1], gq[1], pq[1]);
+    }
+    if (BWD) {
+      // (the moments were written by the lanes of the ascending order, they are read in the descending one: same wave, LDS
+      //  operations complete in order)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      M3 ym = zero3();
+      V3 yv{0.f, 0.f, 0.f};
+      for (int s = 0; s < m; ++s) {
+        const int e = s0 + s;
+        if (e < nd) {
+          float* q = Sd + (long)(nd - 1 - e) * SW;
+          ym = add(ym, lds_get9(q + 24));
+          yv = yv + ld3(Gf + 3 * g.atom(dir, nd - 1 - e + 3));
+          lds_put9(q + 24, ym);
+          st3(q + 21, yv);
+        }
       }
-      auto bstep = [&](auto RC, const int j) {
-        constexpr int r = decltype(RC)::value, rn = (r + 2) % 3;
-        float* q = Sd + j * SW;
-        fetch(max(j - 2, 0), Bq[rn], gq[rn], pq[rn]);
-        val = fmaf(gq[r], pq[r], val);
-        if (keep) q[mat ? 24 + 3 * qr + qc : 21 + qr] = val;
-        val = step_product(val, Bq[r]);
-      };
-      for (int j = nd - 1; j >= 0; j -= 3) {
-        bstep(RingIdx<0>{}, j);
-        if (j - 1 >= 0) bstep(RingIdx<1>{}, j - 1);
-        if (j - 2 >= 0) bstep(RingIdx<2>{}, j - 2);
+      M3 em;
+      V3 ev;
+      sum_scan_exclusive(ym, yv, em, ev);
+      for (int s = 0; s < m; ++s) {
+        const int e = s0 + s;
+        if (e < nd) {
+          float* q = Sd + (long)(nd - 1 - e) * SW;
+          const M3 Ym = add(em, lds_get9(q + 24));
+          const V3 tb = ev + ld3(q + 21);
+          const V3 tj = ld3(q + TO);
+          M3 C = Ym;
+          C.m[0][0] -= tb.x * tj.x; C.m[0][1] -= tb.x * tj.y; C.m[0][2] -= tb.x * tj.z;
+          C.m[1][0] -= tb.y * tj.x; C.m[1][1] -= tb.y * tj.y; C.m[1][2] -= tb.y * tj.z;
+          C.m[2][0] -= tb.z * tj.x; C.m[2][1] -= tb.z * tj.y; C.m[2][2] -= tb.z * tj.z;
+          lds_put9(q + 24, mul(C, lds_get9(q + RO)));
+          st3(q + 21, tb);
+        }
       }
     }
   }
@@ -530,14 +598,8 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   // ---- phase C
   if (!BWD) {
     float* O = out + (long)b * A * 3;
-    if (dir == 0 && lane < 3 && lane < n) st3(O + 3 * g.atom(0, lane), ld3(Pf + 3 * g.atom(0, lane)));
-    for (int i = lane; i < nd; i += 64) {
-      const float* q = Sd + (long)i * SW;
-      const M3 R = lds_get9(q);
-      const int a3 = g.atom(dir, i + 3);
-      st3(O + 3 * a3, mul(R, ld3(Pf + 3 * a3)) + ld3(q + 9));
-    }
-    return;
+    if (dir == 0 && lane < 3 && lane < n) st3(O + 3 * g.atom(0, lane), ld3(P + 3 * g.atom(0, lane)));
+    return;   // (the steps' atoms were written by phase B)
   }
   for (int i = slane; i < nd; i += LSTEP) {
     float* q = Sd + (long)i * SW;
