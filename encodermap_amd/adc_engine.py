@@ -92,6 +92,7 @@ class ADCEngine(SequentialEngine):
         self.pw_start, self.pw_step, self.C = sel.start, sel.step, len(sel)
         self.P = self.C * (self.C - 1) // 2
         self.ldp = _round4(self.P)
+        self._fuse_frame = os.environ.get("EMX_ADC_FUSE_FRAME", "1") != "0"
         self._init_common(col, p, device, weights, dp, use_graph, history_capacity)
 
     # ------------------------------------------------------------------------------------------
@@ -175,6 +176,25 @@ class ADCEngine(SequentialEngine):
         _lib.chain_in_plane_fwd(mean_len, _Bcast(ang_pred) if not self.use_ang else ang_pred, plane)
         _lib.dihedrals_to_cartesian_fwd(dih_pred, math.pi, plane, xyz)
 
+    def _frame_forward(self, Y: torch.Tensor) -> bool:
+        """PeriodicOutput, BackMapLayer and both pair-distance blocks of the step as one launch (emx_adc_frame_fwd) behind the
+        batch means; False when the frame does not fit the fused pass (or EMX_ADC_FUSE_FRAME=0): the single stages follow."""
+        if not self._fuse_frame:
+            return False
+        cols = {off: (col, col + n) for off, n, col in self.parts}
+        _lib.colmean(self.feat, self.feat_mean)
+        try:
+            _lib.adc_frame_fwd(Y, self.periodicity, cols[self.off_ang] if self.use_ang else None,
+                               None if self.use_ang else self.feat_mean[self.off_ang: self.off_ang + self.n_ang],
+                               self.ang_pred if self.use_ang else None, cols[self.off_dih], self.dih_pred, self.mean_len, math.pi, self.plane,
+                               self.xyz, self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair, self.out_pair)
+        except _lib.EmxError as exc:
+            if not exc.unsupported:
+                raise
+            self._fuse_frame = False
+            return False
+        return True
+
     # -- training metrics (ADCClashMetric / ADCRMSDMetric, callbacks/metrics.py:470-581) ------------------------------
     METRIC_WEIGHTS = (14.0067, 24.305, 24.305)   # metrics.py:63
 
@@ -242,10 +262,11 @@ class ADCEngine(SequentialEngine):
             self._encoder_input(self.feat, self.xin)
         _lib.mlp_forward(self.plan, 0, n, self.xin, 0, B)
         Y, Z = self.h[-1], self.h[lay.n_enc - 1]
-        self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
+        if not self._frame_forward(Y):
+            self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
+            _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
+            _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
         self._metrics()
-        _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
-        _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
 
         # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
         if not self._fused_head:

@@ -24,6 +24,7 @@ namespace {
 using namespace emx;
 constexpr int NT = 256;
 constexpr float PI_F = 3.14159265358979323846f;
+constexpr float TWO_PI_F = 6.283185307179586f;
 
 struct V3 {
   float x, y, z;
@@ -466,20 +467,19 @@ __device__ __forceinline__ void sum_scan_exclusive(M3 a, V3 v, M3& ea, V3& ev) {
 // LDS floats of the per-frame kernels: the frame (and its gradient), then 12 (forward) / 36 (backward) per step
 __host__ __device__ inline long d2c_frame_floats(int A, bool bwd) { return (long)(bwd ? 6 : 3) * A + (long)(bwd ? 36 : 12) * (A > 4 ? A - 2 : 2); }
 
-template <bool BWD>
-__global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(const float* __restrict__ dih, int ldd, float offset, const float* __restrict__ plane,
-                                                          const float* __restrict__ dout, int A, float* __restrict__ out,
-                                                          float* __restrict__ ddih, int ldg, float* __restrict__ dplane) {
-  extern __shared__ float sm[];
-  constexpr int FR_NT = BWD ? FR_NT_BWD : FR_NT_FWD;
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+// (the body of the per-frame kernels, also run by the fused ADC frame pass below: NTB threads of one workgroup, every one of them
+//  calls it; wave w works on part w & 1, waves >= 2 help in the phases that run over the steps.  P, dd, dout may be LDS or HBM.)
+template <bool BWD, int NTB>
+__device__ __forceinline__ void d2c_frame_body(const float* __restrict__ dd, float offset, const float* __restrict__ P, const float* __restrict__ dout_row,
+                                               int A, float* __restrict__ out_row, float* __restrict__ out_lds, float* __restrict__ ddih_row,
+                                               float* __restrict__ dplane_row, float* __restrict__ sm) {
+  constexpr int FR_NT = NTB;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int dir = wave & 1, role = wave >> 1;   // role 1 (backward only): the adjoint recurrence in phase B
-  constexpr int LSTEP = BWD ? 128 : 64;         // lanes that share one part's steps in phases A and C
+  constexpr int LSTEP = NTB / 2;                // lanes that share one part's steps in phases A and C
   const int slane = lane + 64 * role;
   const D2C g{A / 2, A};
-  const float* __restrict__ P = plane + (long)b * A * 3;
-  const float* __restrict__ dd = dih + (long)b * ldd;
   float* Pf = sm;                        // [A][3] planar chain
   float* Gf = sm + 3 * A;                // [A][3] d loss / d out (backward)
   float* S = sm + (BWD ? 6 : 3) * A;     // per step: [Q 9 | c 3] ([R 9 | t 3] after phase B), backward + [R 9 | tb 3] + [Rb 9 | -]
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   for (int e = tid; e < 3 * A; e += FR_NT) {
     const int c3 = e % 3;
     Pf[e] = P[e] - (c3 == 0 ? ctr.x : c3 == 1 ? ctr.y : ctr.z);
-    if (BWD) Gf[e] = dout[(long)b * A * 3 + e];
+    if (BWD) Gf[e] = dout_row[e];
   }
   __syncthreads();
   DSTAMP(1);
@@ -537,7 +537,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
       }
     }
     const Aff E = aff_scan_exclusive(acc);
-    float* O = BWD ? nullptr : out + (long)b * A * 3;
+    float* O = out_row;
     for (int s = 0; s < m; ++s) {
       const int k = s0 + s;
       if (k < nd) {
@@ -552,6 +552,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
           lds_put9(q + 24, outer(ld3(Gf + 3 * a3), o));
         } else {
           st3(O + 3 * a3, o + ctr);
+          if (out_lds) st3(out_lds + 3 * a3, o + ctr);
         }
       }
     }
@@ -597,8 +598,11 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   DSTAMP(4);
   // ---- phase C
   if (!BWD) {
-    float* O = out + (long)b * A * 3;
-    if (dir == 0 && lane < 3 && lane < n) st3(O + 3 * g.atom(0, lane), ld3(P + 3 * g.atom(0, lane)));
+    if (wave == 0 && lane < 3 && lane < n) {
+      const V3 p = ld3(P + 3 * g.atom(0, lane));
+      st3(out_row + 3 * g.atom(0, lane), p);
+      if (out_lds) st3(out_lds + 3 * g.atom(0, lane), p);
+    }
     return;   // (the steps' atoms were written by phase B)
   }
   for (int i = slane; i < nd; i += LSTEP) {
@@ -628,7 +632,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
     const V3 ax{Qb.m[2][1] - Qb.m[1][2], Qb.m[0][2] - Qb.m[2][0], Qb.m[1][0] - Qb.m[0][1]};   // <Qb, [v]x> = v . ax
     const V3 Qu = mul(Qb, u), QTu = mulT(Qb, u);
     const float uQu = dot(u, Qu);
-    ddih[(long)b * ldg + g.dih(dir, i)] = -sn * trQ + cs * dot(u, ax) + sn * uQu;
+    ddih_row[g.dih(dir, i)] = -sn * trQ + cs * dot(u, ax) + sn * uQu;
     const V3 ub = sn * ax + (1.f - cs) * (Qu + QTu);
     const V3 wb = inv * (ub - dot(u, ub) * u);   // u = w / |w|
     ob = ob + wb;
@@ -641,7 +645,7 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   DSTAMP(5);
   __syncthreads();
   // ---- phase D: every atom collects what it receives: pass-through (atoms s-1 .. s+1), then right part, then left part
-  float* DP = dplane + (long)b * A * 3;
+  float* DP = dplane_row;
   const int nd1 = max(g.natoms(1) - 3, 0);
   for (int a = tid; a < A; a += FR_NT) {
     V3 acc{0.f, 0.f, 0.f};
@@ -663,16 +667,28 @@ __global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(
   DSTAMP(6);
 }
 
+template <bool BWD>
+__global__ __launch_bounds__(BWD ? FR_NT_BWD : FR_NT_FWD) void d2c_frame_kernel(const float* __restrict__ dih, int ldd, float offset, const float* __restrict__ plane,
+                                                          const float* __restrict__ dout, int A, float* __restrict__ out,
+                                                          float* __restrict__ ddih, int ldg, float* __restrict__ dplane) {
+  extern __shared__ float sm[];
+  const long b = blockIdx.x;
+  d2c_frame_body<BWD, BWD ? FR_NT_BWD : FR_NT_FWD>(dih + b * ldd, offset, plane + b * A * 3, BWD ? dout + b * A * 3 : nullptr, A,
+                                                    BWD ? nullptr : out + b * A * 3, nullptr, BWD ? ddih + b * ldg : nullptr,
+                                                    BWD ? dplane + b * A * 3 : nullptr, sm);
+}
+
 // K6, one wave per frame: the angle recurrence is one subtraction per step (serial, LDS), sin/cos and the partial sums of
 // the steps run over the lanes (a wave-wide inclusive scan per 64 steps).
-__global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda, int A,
-                                                         float* __restrict__ xyz) {
-  extern __shared__ float sm[];   // [A] phi
-  const int b = blockIdx.x, lane = threadIdx.x;
-  const float* __restrict__ th = ang + (long)b * lda;
-  float* o = xyz + (long)b * A * 3;
+// (the body, run by ONE wave; th: the frame's angles, o: its plane row in HBM, ol: an LDS copy of it or null)
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void chain_frame_body(const float* __restrict__ len, const float* __restrict__ th, int A, float* __restrict__ sm,
+                                                 float* __restrict__ o, float* __restrict__ ol, const int lane) {
   for (int i = lane; i < A - 2; i += 64) sm[i + 1] = PI_F - th[i];
-  __syncthreads();
+  wave_sync();
   // phi_i = c_i - phi_{i-1}, phi_0 = 0  <=>  (-1)^i phi_i = sum_{k = 1..i} (-1)^k c_k: a prefix sum across the lanes, 64 steps
   // at a time with a carry, instead of A - 2 dependent LDS round trips on one lane
   {
@@ -691,8 +707,11 @@ __global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict
     }
     if (lane == 0) sm[0] = 0.f;
   }
-  __syncthreads();
-  if (lane == 0) st3(o, V3{0.f, 0.f, 0.f});
+  wave_sync();
+  if (lane == 0) {
+    st3(o, V3{0.f, 0.f, 0.f});
+    if (ol) st3(ol, V3{0.f, 0.f, 0.f});
+  }
   float cx = 0.f, cy = 0.f;   // carry of the partial sums
   for (int i0 = 0; i0 < A - 1; i0 += 64) {
     const int i = i0 + lane;
@@ -711,10 +730,19 @@ __global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict
         dy += uy;
       }
     }
-    if (i < A - 1) st3(o + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
+    if (i < A - 1) {
+      st3(o + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
+      if (ol) st3(ol + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
+    }
     cx += __shfl(dx, 63, 64);
     cy += __shfl(dy, 63, 64);
   }
+}
+__global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda, int A,
+                                                         float* __restrict__ xyz) {
+  extern __shared__ float sm[];   // [A] phi
+  const int b = blockIdx.x;
+  chain_frame_body(len, ang + (long)b * lda, A, sm, xyz + (long)b * A * 3, nullptr, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -731,6 +759,19 @@ __device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
   j = (int)(p - ((long)ii * C - (long)ii * (ii + 1) / 2)) + ii + 1;
 }
 
+// thread t of nt: the pairs t, t + nt, ... of the atoms s0 + st c held in sx ([*][3])
+__device__ __forceinline__ void pdist_pairs(const float* __restrict__ sx, int s0, int st, int C, long P, int ldo, float* __restrict__ o, int t, int nt) {
+  for (long p = t; p < P; p += nt) {
+    int i, j;
+    pair_decode(p, C, i, j);
+    const float* a = sx + 3 * (s0 + st * i);
+    const float* c = sx + 3 * (s0 + st * j);
+    const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
+    o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
+  }
+  for (long p = P + t; p < ldo; p += nt) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
+}
+
 constexpr int PD_NT = 1024;   // threads per frame: a 256-frame batch is 256 workgroups, one per CU -- each should bring all its waves
 __global__ __launch_bounds__(PD_NT) void pdist_fwd_kernel(const float* __restrict__ xyz, int A, int start, int step, int C, long P, int ldo,
                                                        float* __restrict__ out) {
@@ -742,14 +783,7 @@ __global__ __launch_bounds__(PD_NT) void pdist_fwd_kernel(const float* __restric
     sx[e] = X[3 * (start + step * c) + k];
   }
   __syncthreads();
-  float* o = out + (long)b * ldo;
-  for (long p = threadIdx.x; p < P; p += PD_NT) {
-    int i, j;
-    pair_decode(p, C, i, j);
-    const float dx = sx[3 * i] - sx[3 * j], dy = sx[3 * i + 1] - sx[3 * j + 1], dz = sx[3 * i + 2] - sx[3 * j + 2];
-    o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
-  }
-  for (long p = P + threadIdx.x; p < ldo; p += PD_NT) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
+  pdist_pairs(sx, 0, 1, C, P, ldo, out + (long)b * ldo, threadIdx.x, PD_NT);
 }
 
 // T threads per selected atom (T a power of two <= 8, consecutive lanes) gather its C-1 pair terms, j = q, q + T, ..., and add
@@ -815,6 +849,88 @@ __global__ __launch_bounds__(PD_NT) void pdist_bwd_kernel(const float* __restric
       }
     }
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The forward half of the ADC model's back-mapping as ONE launch, a workgroup per frame (emx_adc_frame_fwd): PeriodicOutput of
+// the angle / dihedral blocks, chain_in_plane, dihedrals_to_cartesian and the pair distances of the back-mapped AND of the input
+// frame -- five launches of 4-6 us each at a 256-frame batch, every one of them a chain of dependent trips to memory for a few
+// kilobytes per frame.  Here the frame stays in LDS between the stages (HBM receives what the backward pass and the costs read
+// later); the input frame's pair distances do not depend on the model and run beside the serial chain construction.
+// The stages are the bodies of the kernels above: same arithmetic, same results.
+// ---------------------------------------------------------------------------------------------------------
+constexpr int AF_NT = 1024;
+struct AdcFrameArgs {
+  const float* Y;          // [B, ldy] decoder output
+  int ldy;
+  float out_scale;         // periodicity / 2 pi
+  int n_ang, ang_sin, ang_cos;   // angle block of Y (ang_sin < 0: the angles are the batch means in mean_ang)
+  const float* mean_ang;
+  float* ang_pred;         // [B, A - 2] (written unless the means are used)
+  int dih_sin, dih_cos;
+  float* dih_pred;         // [B, A - 3]
+  const float* mean_len;   // [A - 1]
+  float offset;
+  int A;
+  float* plane;            // [B, A, 3]
+  float* xyz;              // [B, A, 3]
+  const float* cart;       // [B, A, 3] input frames
+  int start, step, C, ldo;
+  float* inp_pair;         // [B, ldo] (null: not wanted)
+  float* out_pair;         // [B, ldo]
+};
+__host__ __device__ inline long adc_frame_floats(int A, int C) { return (long)A + 2 * (long)A + 6 * (long)A + 3 * (long)C + d2c_frame_floats(A, false); }
+
+__global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs a) {
+  extern __shared__ float sm[];
+  const int A = a.A, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long b = blockIdx.x;
+  float* phi = sm;                 // [A]
+  float* ang_l = phi + A;          // [A] angles of the frame
+  float* dih_l = ang_l + A;        // [A] dihedrals
+  float* Pl = dih_l + A;           // [A][3] plane
+  float* Xl = Pl + 3 * A;          // [A][3] back-mapped frame
+  float* sxc = Xl + 3 * A;         // [C][3] selected atoms of the input frame
+  float* fr = sxc + 3 * a.C;       // the frame kernel's own buffers
+  const float* row = a.Y + b * a.ldy;
+  const long P = (long)a.C * (a.C - 1) / 2;
+  // ---- PeriodicOutput; the input frame's selected atoms
+  for (int k = tid; k < A - 2; k += AF_NT) {
+    float v;
+    if (a.ang_sin >= 0) {
+      v = atan2f(row[a.ang_sin + k], row[a.ang_cos + k]) * a.out_scale;
+      a.ang_pred[b * (A - 2) + k] = v;
+    } else {
+      v = a.mean_ang[k];
+    }
+    ang_l[k] = v;
+  }
+  for (int k = tid; k < A - 3; k += AF_NT) {
+    const float v = atan2f(row[a.dih_sin + k], row[a.dih_cos + k]) * a.out_scale;
+    a.dih_pred[b * (A - 3) + k] = v;
+    dih_l[k] = v;
+  }
+  if (a.inp_pair) {
+    const float* X = a.cart + b * A * 3;
+    for (int e = tid; e < 3 * a.C; e += AF_NT) {
+      const int c = e / 3, k = e - 3 * c;
+      sxc[e] = X[3 * (a.start + a.step * c) + k];
+    }
+  }
+  __syncthreads();
+  // ---- chain_in_plane on wave 0; the other waves: pair distances of the input frame
+  if (wave == 0) {
+    chain_frame_body(a.mean_len, ang_l, A, phi, a.plane + b * A * 3, Pl, lane);
+  } else if (a.inp_pair) {
+    pdist_pairs(sxc, 0, 1, a.C, P, a.ldo, a.inp_pair + b * a.ldo, tid - 64, AF_NT - 64);
+  }
+  __syncthreads();
+  // ---- dihedrals_to_cartesian
+  d2c_frame_body<false, AF_NT>(dih_l, a.offset, Pl, nullptr, A, a.xyz + b * A * 3, Xl, nullptr, nullptr, fr);
+  __syncthreads();
+  // ---- pair distances of the back-mapped frame
+  pdist_pairs(Xl, a.start, a.step, a.C, P, a.ldo, a.out_pair + b * a.ldo, tid, AF_NT);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1233,6 +1349,49 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "emx_pdist_flat_fwd: %d atoms do not fit the LDS frame buffer", C);
   hipLaunchKernelGGL(pdist_fwd_kernel, dim3(B), dim3(PD_NT), lds, (hipStream_t)stream, xyz, A, start, step, C, P, ldo, out);
   return emx::check_launch("pdist_fwd_kernel");
+}
+
+int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
+                      int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane, float* xyz,
+                      const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, emx_stream_t stream) {
+  const char* who = "emx_adc_frame_fwd";
+  EMX_REQUIRE(Y && dih_pred && mean_lengths && plane && xyz && out_pair && B > 0 && A >= 4, "%s: bad arguments (A >= 4)", who);
+  EMX_REQUIRE((ang_sin >= 0 && ang_cos >= 0 && ang_pred) || (ang_sin < 0 && mean_angles), "%s: the angles come from Y (columns + ang_pred) or from mean_angles", who);
+  EMX_REQUIRE(ang_sin < 0 || (ang_sin + A - 2 <= ldy && ang_cos + A - 2 <= ldy), "%s: angle columns outside the row", who);
+  EMX_REQUIRE(dih_sin >= 0 && dih_cos >= 0 && dih_sin + A - 3 <= ldy && dih_cos + A - 3 <= ldy, "%s: dihedral columns outside the row", who);
+  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "%s: needs a finite periodicity", who);
+  EMX_REQUIRE(C >= 2 && step >= 1 && start >= 0 && start + (long)step * (C - 1) < A, "%s: atom selection outside the frame", who);
+  const long P = (long)C * (C - 1) / 2;
+  EMX_REQUIRE(ldo >= P, "%s: output row stride %d < %ld pairs", who, ldo, P);
+  EMX_REQUIRE(!inp_pair || cart, "%s: the input frames are needed for their pair distances", who);
+  const size_t lds = (size_t)adc_frame_floats(A, C) * sizeof(float);
+  if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: a frame of %d atoms does not fit the LDS buffers of the fused pass (use the single stages)", who, A);
+  AdcFrameArgs a;
+  a.Y = Y;
+  a.ldy = ldy;
+  a.out_scale = periodicity == TWO_PI_F ? 1.f : periodicity / TWO_PI_F;
+  a.n_ang = A - 2;
+  a.ang_sin = ang_sin;
+  a.ang_cos = ang_cos;
+  a.mean_ang = mean_angles;
+  a.ang_pred = ang_pred;
+  a.dih_sin = dih_sin;
+  a.dih_cos = dih_cos;
+  a.dih_pred = dih_pred;
+  a.mean_len = mean_lengths;
+  a.offset = dihedral_offset;
+  a.A = A;
+  a.plane = plane;
+  a.xyz = xyz;
+  a.cart = cart;
+  a.start = start;
+  a.step = step;
+  a.C = C;
+  a.ldo = ldo;
+  a.inp_pair = inp_pair;
+  a.out_pair = out_pair;
+  hipLaunchKernelGGL(adc_frame_fwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
+  return emx::check_launch("adc_frame_fwd_kernel");
 }
 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo, float* dxyz, int accumulate,

@@ -454,6 +454,20 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo,
                        float* dxyz, int accumulate, emx_stream_t stream);
 
+/* The forward half of the ADC decoder's tail in ONE launch, a workgroup per frame: PeriodicOutput of the angle and dihedral
+ * blocks of the decoder output Y [B, ldy] (columns ang_sin / ang_cos / dih_sin / dih_cos; models.py:2355-2420,
+ * layers.py:1118-1125), BackMapLayer (chain_in_plane + dihedrals_to_cartesian with `dihedral_offset`, layers.py:957-986) and
+ * PairwiseDistancesLayer (layers.py:1252-1267) of the back-mapped frames -> out_pair, and of the input frames `cart` ->
+ * inp_pair (inp_pair NULL: skipped).  Equal, value for value, to emx_periodic_out x2 + emx_chain_in_plane_fwd +
+ * emx_dihedrals_to_cartesian_fwd + emx_pdist_flat_fwd x2; every intermediate is written as those calls write it
+ * (ang_pred [B, A-2], dih_pred [B, A-3], plane, xyz [B, A, 3], pair blocks [B, ldo]).  ang_sin < 0: the angles are the batch
+ * means `mean_angles` [A-2] (MeanAngles, layers.py:1153-1161; ang_pred is not written).  mean_lengths [A-1].
+ * EMX_EUNSUPPORTED when a frame does not fit the LDS buffers of the fused pass (the single stages remain). */
+int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles,
+                      float* ang_pred, int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths,
+                      float dihedral_offset, int A, float* plane, float* xyz, const float* cart, int start, int step, int C,
+                      float* inp_pair, float* out_pair, int ldo, emx_stream_t stream);
+
 /* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
  *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,
  *                    count_nonzero(pairwise_dist(y_pred, flat=True) < d, axis=1)      encodermap/callbacks/metrics.py:505-522

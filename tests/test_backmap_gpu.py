@@ -285,3 +285,59 @@ def test_adc_batch_head_equals_its_four_parts(L, periodicity, soft):
     assert float(sc) == pytest.approx(0.5 if soft[0] >= 0 else 2.5)
     with pytest.raises(L.EmxError, match="outside the feature row"):
         L.adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, [(F - 2, 5, 0)], periodicity, xin, step, *soft, sc)
+
+
+@pytest.mark.parametrize("B,A,start,step,use_ang", [(256, 228, 1, 3, True), (37, 24, 0, 1, False), (5, 457, 0, 1, True), (9, 4, 0, 1, True),
+                                                     (16, 131, 2, 4, False)])
+def test_adc_frame_forward_equals_its_stages(L, B, A, start, step, use_ang):
+    """emx_adc_frame_fwd (PeriodicOutput + BackMapLayer + both PairwiseDistances blocks in one launch, layers.py:957-986,
+    1118-1125, 1252-1267) against the single launches it replaces: every output, value for value."""
+    rng = np.random.default_rng(A + B)
+    n_ang, n_dih = A - 2, A - 3
+    C = len(range(A)[start::step])
+    P = C * (C - 1) // 2
+    ldo = (P + 3) // 4 * 4
+    ldy = 2 * (n_ang + n_dih) + 3
+    Y = dev(rng.normal(0, 1, (B, ldy)).astype(np.float32))
+    cols_ang, cols_dih = (1, 1 + n_ang), (1 + 2 * n_ang, 1 + 2 * n_ang + n_dih)
+    mean_len = dev(rng.normal(0.14, 0.005, (A - 1,)).astype(np.float32))
+    mean_ang = dev(rng.normal(2.0, 0.05, (n_ang,)).astype(np.float32))
+    cart = dev(rng.normal(0, 1, (B, A, 3)).astype(np.float32))
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")
+    # ---- the stages
+    ang0, dih0, plane0, xyz0, ip0, op0 = nan(B, n_ang), nan(B, n_dih), nan(B, A, 3), nan(B, A, 3), nan(B, ldo), nan(B, ldo)
+    L.periodic_out(Y, n_dih, cols_dih[0], cols_dih[1], 2 * PI, dih0)
+    if use_ang:
+        L.periodic_out(Y, n_ang, cols_ang[0], cols_ang[1], 2 * PI, ang0)
+        L.chain_in_plane_fwd(mean_len, ang0, plane0)
+    else:
+        from encodermap_amd.adc_engine import _Bcast
+        L.chain_in_plane_fwd(mean_len, _Bcast(mean_ang.view(1, -1)), plane0)
+    L.dihedrals_to_cartesian_fwd(dih0, PI, plane0, xyz0)
+    L.pdist_flat_fwd(cart, start, step, C, ip0)
+    L.pdist_flat_fwd(xyz0, start, step, C, op0)
+    # ---- one launch
+    ang1, dih1, plane1, xyz1, ip1, op1 = nan(B, n_ang), nan(B, n_dih), nan(B, A, 3), nan(B, A, 3), nan(B, ldo), nan(B, ldo)
+    L.adc_frame_fwd(Y, 2 * PI, cols_ang if use_ang else None, None if use_ang else mean_ang, ang1 if use_ang else None, cols_dih, dih1, mean_len,
+                    PI, plane1, xyz1, cart, start, step, C, ip1, op1)
+    torch.cuda.synchronize()
+    pairs = [("dihedrals", dih0, dih1), ("plane", plane0, plane1), ("xyz", xyz0, xyz1), ("input pairs", ip0, ip1), ("output pairs", op0, op1)]
+    if use_ang:
+        pairs.append(("angles", ang0, ang1))
+    for name, x0, x1 in pairs:
+        assert torch.isfinite(x1).all(), name
+        assert torch.equal(x0, x1), f"{name}: max difference {float((x0 - x1).abs().max())}"
+    # without the input frames' block
+    op2 = nan(B, ldo)
+    L.adc_frame_fwd(Y, 2 * PI, cols_ang if use_ang else None, None if use_ang else mean_ang, ang1 if use_ang else None, cols_dih, dih1, mean_len,
+                    PI, plane1, xyz1, None, start, step, C, None, op2)
+    assert torch.equal(op0, op2)
+
+
+def test_adc_frame_forward_refuses_frames_beyond_lds(L):
+    B, A = 2, 1100
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    with pytest.raises(L.EmxError) as err:
+        L.adc_frame_fwd(z(B, 4 * A), 2 * PI, (0, A), None, z(B, A - 2), (2 * A, 3 * A), z(B, A - 3), z(A - 1), PI, z(B, A, 3), z(B, A, 3),
+                        z(B, A, 3), 0, 1, A, z(B, A * (A - 1) // 2), z(B, A * (A - 1) // 2))
+    assert err.value.unsupported
