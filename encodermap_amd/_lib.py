@@ -65,7 +65,7 @@ SIGNATURES = {
     "emx_adam_step": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p]),
     "emx_adam_step_slices": (_i, [_p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _i, _p]),
     "emx_l2_partials": (_i, [_p, _p, _l, _p, _p]),
-    "emx_adc_batch_head": (_i, [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _i, _p, _f, _f, _f, _p, _p]),
+    "emx_adc_batch_head": (_i, [_p, _p, _l, _i, _i, _p, _p, _i, _p, _p, _p, _p, _p, _i, _f, _p, _i, _p, _f, _f, _f, _p, _p, _p]),
     "emx_adam_step_history": (_i, [_p, _p, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p, _p, _i, _p, _p, _l, _p, _p]),
     "emx_adam_tick": (_i, [_p, _p, _p, _i, _l, _p, _p, _p, _l, _f, _f, _f, _f, _f, _p, _p, _i, _i, _p, _p, _l, _p, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_slices": (_i, [_i]),
@@ -631,16 +631,18 @@ def soft_start_scale(step, a, b, c, out):
     _check(load().emx_soft_start_scale(_ptr(step), float(a), float(b), float(c), _ptr(out), _stream()), "emx_soft_start_scale")
 
 
-def adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, periodicity, xin, step, soft_a, soft_b, scale_c, cart_scale):
-    """Gather of the feature and Cartesian rows, sin/cos of the angular blocks ``parts`` = [(off, n, col), ...] and the
-    soft-start scale in one launch (emx_adc_batch_head)."""
+def adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, periodicity, xin, step, soft_a, soft_b, scale_c, cart_scale,
+                   feat_mean=None):
+    """Gather of the feature and Cartesian rows, sin/cos of the angular blocks ``parts`` = [(off, n, col), ...], the
+    soft-start scale and (``feat_mean``) the column means of the gathered feature rows in one launch (emx_adc_batch_head)."""
     N, F = feat_data.shape
     C3 = cart_data.shape[1]
     n = len(parts)
     arr = lambda k: (C.c_int * n)(*[int(p[k]) for p in parts])
     _check(load().emx_adc_batch_head(_ptr(feat_data), _ptr(cart_data), N, F, C3, _ptr(idx), _ptr(cursor), int(B), _ptr(feat), _ptr(cart),
                                      arr(0), arr(1), arr(2), n, float(periodicity), _ptr(xin), xin.stride(0), _ptr(step), float(soft_a),
-                                     float(soft_b), float(scale_c), _ptr(cart_scale), _stream()), "emx_adc_batch_head")
+                                     float(soft_b), float(scale_c), _ptr(cart_scale), _ptr(feat_mean) if feat_mean is not None else None,
+                                     _stream()), "emx_adc_batch_head")
 
 
 def allatom_mask_words(A):

@@ -182,7 +182,8 @@ class ADCEngine(SequentialEngine):
         if not self._fuse_frame:
             return False
         cols = {off: (col, col + n) for off, n, col in self.parts}
-        _lib.colmean(self.feat, self.feat_mean)
+        if not self._fused_head:   # (the fused head of the step leaves the batch means as well)
+            _lib.colmean(self.feat, self.feat_mean)
         try:
             _lib.adc_frame_fwd(Y, self.periodicity, cols[self.off_ang] if self.use_ang else None,
                                None if self.use_ang else self.feat_mean[self.off_ang: self.off_ang + self.n_ang],
@@ -253,9 +254,9 @@ class ADCEngine(SequentialEngine):
         c = p.cartesian_cost_scale
         soft = (-1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b, 0.0 if c is None else float(c))
         if self._fused_head:
-            # batch rows, encoder input and the soft-start scale of this step in one launch
+            # batch rows, encoder input, the soft-start scale of this step and the batch means of the feature columns in one launch
             _lib.adc_batch_head(self.data, self.data_cart, self.idx_block, self.cursor, B, self.feat, self.cart.view(B, -1), self.parts, per,
-                                self.xin, self.step, *soft, self.cart_scale)
+                                self.xin, self.step, *soft, self.cart_scale, feat_mean=self.feat_mean if self._fuse_frame else None)
         else:
             _lib.gather_rows(self.data, self.idx_block, INF, self.feat, None, cursor=self.cursor, B=B)
             _lib.gather_rows(self.data_cart, self.idx_block, INF, self.cart.view(B, -1), None, cursor=self.cursor, B=B)

@@ -1071,9 +1071,40 @@ struct AdcHeadArgs {
   const int64_t* step;
   float soft_a, soft_b, scale_c;
   float* cart_scale;
+  float* feat_mean;   // [F] batch means of the feature columns (null: not wanted)
+  int row_blocks;     // workgroups that copy rows; those behind them take NT / CM_PH columns of the means each
 };
 
 __global__ __launch_bounds__(NT) void adc_head_kernel(const AdcHeadArgs a) {
+  if (blockIdx.x >= a.row_blocks) {
+    // emx_colmean of the batch's feature rows, read through the index (the row copies of this launch are not waited for): the
+    // partition of colmean_kernel -- 16 row phases of 4 interleaved sums -- and its order of additions, 16 columns per workgroup
+    __shared__ float part[CM_PH][NT / CM_PH];
+    constexpr int CW = NT / CM_PH;   // columns per workgroup: a thread per (column, phase)
+    const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
+    const int cl = threadIdx.x % CW, ph = threadIdx.x / CW, c = (blockIdx.x - a.row_blocks) * CW + cl;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < a.F) {
+      int b = ph;
+      for (; b + 3 * CM_PH < a.B; b += 4 * CM_PH) {
+        const long r0 = idx[b], r1 = idx[b + CM_PH], r2 = idx[b + 2 * CM_PH], r3 = idx[b + 3 * CM_PH];
+        s0 += a.feat_data[r0 * a.F + c];
+        s1 += a.feat_data[r1 * a.F + c];
+        s2 += a.feat_data[r2 * a.F + c];
+        s3 += a.feat_data[r3 * a.F + c];
+      }
+      for (; b < a.B; b += CM_PH) s0 += a.feat_data[idx[b] * a.F + c];
+    }
+    part[ph][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ph == 0 && c < a.F) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < CM_PH; q += 4) t += (part[q][cl] + part[q + 1][cl]) + (part[q + 2][cl] + part[q + 3][cl]);
+      a.feat_mean[c] = t / (float)a.B;
+    }
+    return;
+  }
   if (a.cart_scale && blockIdx.x == 0 && threadIdx.x == 0) {
     float sc = a.scale_c;
     if (a.soft_a >= 0.f) {
@@ -1087,7 +1118,7 @@ __global__ __launch_bounds__(NT) void adc_head_kernel(const AdcHeadArgs a) {
   // dependent iterations behind its three hops (cursor, index, row) while most of the chip idles
   const int lane = threadIdx.x;
   const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
-  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+  for (int b = blockIdx.x; b < a.B; b += a.row_blocks) {
     const long row = idx[b];
     const float* __restrict__ fs = a.feat_data + row * a.F;
     const float* __restrict__ cs = a.cart_data + row * a.C3;
@@ -1448,7 +1479,7 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
 int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
                        int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
                        float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
-                       float* cart_scale, emx_stream_t stream) {
+                       float* cart_scale, float* feat_mean, emx_stream_t stream) {
   EMX_REQUIRE(feat_data && cart_data && idx && feat && cart && xin, "emx_adc_batch_head: null pointer argument");
   EMX_REQUIRE(N > 0 && F > 0 && C3 > 0 && B > 0 && n_parts >= 1 && n_parts <= 4 && part_off && part_n && part_col, "emx_adc_batch_head: bad shape");
   EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "emx_adc_batch_head: the angular blocks need a finite periodicity");
@@ -1480,7 +1511,9 @@ int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N
   a.soft_b = soft_b;
   a.scale_c = scale_c;
   a.cart_scale = cart_scale;
-  const int grid = std::min(B, 2048);
+  a.feat_mean = feat_mean;
+  a.row_blocks = std::min(B, 2048);
+  const int grid = a.row_blocks + (feat_mean ? (F + NT / CM_PH - 1) / (NT / CM_PH) : 0);
   hipLaunchKernelGGL(adc_head_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adc_head_kernel");
 }

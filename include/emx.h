@@ -517,11 +517,13 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
  *   for each of the n_parts <= 4 angular blocks (part_off, part_n) of the feature row: sin / cos into
  *   xin[b, part_col .. part_col + 2 part_n)                                                    emx_periodic_in
  *   *cart_scale = soft-start scale of step *step (cart_scale NULL: skipped)                   emx_soft_start_scale
- * -- the same numbers as those four entry points, one launch instead of four. */
+ *   feat_mean [F] = column means of the gathered feature rows (NULL: skipped)                  emx_colmean
+ *     (mean bond lengths of BackMapLayer, layers.py:971; MeanAngles, layers.py:1153-1161)
+ * -- the same numbers as those entry points, one launch instead of five. */
 int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
                        int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
                        float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
-                       float* cart_scale, emx_stream_t stream);
+                       float* cart_scale, float* feat_mean, emx_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -255,7 +255,7 @@ def test_clash_count_and_kabsch_rmsd(B, A):
 
 @pytest.mark.parametrize("periodicity,soft", [(2 * PI, (6.0, 12.0, 1.0)), (360.0, (-1.0, -1.0, 2.5))])
 def test_adc_batch_head_equals_its_four_parts(L, periodicity, soft):
-    """emx_adc_batch_head == emx_gather_rows x 2 + emx_periodic_in per block + emx_soft_start_scale, bit for bit, at a cursor
+    """emx_adc_batch_head == emx_gather_rows x 2 + emx_periodic_in per block + emx_soft_start_scale + emx_colmean, bit for bit, at a cursor
     position inside the index block, with a ragged number of rows per workgroup."""
     rng = np.random.default_rng(17)
     N, B, A, S = 500, 37, 21, 5
@@ -270,15 +270,19 @@ def test_adc_batch_head_equals_its_four_parts(L, periodicity, soft):
     W = 2 * (n_ang + n_dih + S)
     feat, cart, xin = (torch.full((B, k), float("nan"), device="cuda") for k in (F, 3 * A, W))
     sc = torch.zeros(1, device="cuda")
-    L.adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, periodicity, xin, step, *soft, sc)
+    mean = torch.full((F,), float("nan"), device="cuda")
+    L.adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, periodicity, xin, step, *soft, sc, feat_mean=mean)
     feat2, cart2, xin2 = (torch.full((B, k), float("nan"), device="cuda") for k in (F, 3 * A, W))
     sc2 = torch.zeros(1, device="cuda")
+    mean2 = torch.full((F,), float("nan"), device="cuda")
     L.gather_rows(feat_data, idx, float("inf"), feat2, None, cursor=cursor, B=B)
     L.gather_rows(cart_data, idx, float("inf"), cart2, None, cursor=cursor, B=B)
     for off, n, col in parts:
         L.periodic_in(feat2[:, off: off + n], periodicity, xin2[:, col: col + 2 * n])
     L.soft_start_scale(step, *soft, sc2)
+    L.colmean(feat2, mean2)
     torch.cuda.synchronize()
+    assert torch.equal(mean, mean2)                                        # (emx_colmean's order of additions)
     rows = idx[2 * B: 3 * B]
     assert torch.equal(feat, feat_data[rows]) and torch.equal(cart, cart_data[rows])
     assert torch.equal(feat, feat2) and torch.equal(cart, cart2) and torch.equal(xin, xin2) and torch.equal(sc, sc2)
