@@ -79,7 +79,7 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
-    "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_allatom_mask_words": (_i, [_i]),
@@ -605,9 +605,10 @@ def pdist_flat_fwd(xyz, start, step, C, out):
 
 
 def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih_pred, mean_lengths, dihedral_offset, plane, xyz, cart,
-                  start, step, C, inp_pair, out_pair):
+                  start, step, C, inp_pair, out_pair, split_ws=None):
     """PeriodicOutput + BackMapLayer + both PairwiseDistances blocks in one launch (emx_adc_frame_fwd).  ``ang_cols`` /
-    ``dih_cols``: (sin column, cos column) in Y; ``ang_cols`` None: the angles are ``mean_angles``."""
+    ``dih_cols``: (sin column, cos column) in Y; ``ang_cols`` None: the angles are ``mean_angles``; ``split_ws``: also
+    emx_sketchmap_split of ``inp_pair``."""
     B, A = xyz.shape[0], xyz.shape[1]
     a_sin, a_cos = ang_cols if ang_cols is not None else (-1, -1)
     if ang_cols is not None:
@@ -617,7 +618,8 @@ def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih
                                     _ptr(mean_angles) if mean_angles is not None else None, _ptr(ang_pred) if ang_cols is not None else None,
                                     int(dih_cols[0]), int(dih_cols[1]), _ptr(dih_pred), _ptr(mean_lengths), float(dihedral_offset), A,
                                     _ptr(plane), _ptr(xyz), _ptr(cart) if cart is not None else None, int(start), int(step), int(C),
-                                    _ptr(inp_pair) if inp_pair is not None else None, _ptr(out_pair), out_pair.stride(0), _stream()),
+                                    _ptr(inp_pair) if inp_pair is not None else None, _ptr(out_pair), out_pair.stride(0),
+                                    _ptr(split_ws) if split_ws is not None else None, _stream()),
            "emx_adc_frame_fwd")
 
 

@@ -188,7 +188,8 @@ class ADCEngine(SequentialEngine):
             _lib.adc_frame_fwd(Y, self.periodicity, cols[self.off_ang] if self.use_ang else None,
                                None if self.use_ang else self.feat_mean[self.off_ang: self.off_ang + self.n_ang],
                                self.ang_pred if self.use_ang else None, cols[self.off_dih], self.dih_pred, self.mean_len, math.pi, self.plane,
-                               self.xyz, self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair, self.out_pair)
+                               self.xyz, self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair, self.out_pair,
+                               split_ws=self.split_pair if self.p.cartesian_distance_cost_scale is not None else None)
         except _lib.EmxError as exc:
             if not exc.unsupported:
                 raise
@@ -314,7 +315,8 @@ class ADCEngine(SequentialEngine):
         if cdc is not None:
             # the high-d "points" are the frames' pair-distance vectors (thousands of features, few rows): Gram products on the
             # f16 matrix cores from the split rows
-            _lib.sketchmap_split(self.inp_pair[:, :self.P], self.split_pair)
+            if not self._fuse_frame:   # (the fused frame pass of this step has left the split rows)
+                _lib.sketchmap_split(self.inp_pair[:, :self.P], self.split_pair)
             _lib.sketchmap_tiles(self.inp_pair[:, :self.P], Z, INF, p.cartesian_dist_sig_parameters, 0, B, self.sk_ws, self.split_pair)
             _lib.sketchmap_finish(B, self.P, Z, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0, 0, B,
                                   t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)

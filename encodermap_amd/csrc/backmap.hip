@@ -18,6 +18,7 @@
 // The backward pass walks the chain in reverse, recovering A_{i-1} = A_i o N_i^{-1} instead of storing it, and
 // accumulates the adjoints of the transform, of the dihedral and of the planar coordinates.
 #include "emx_common.h"
+#include "split.h"
 
 namespace {
 
@@ -878,8 +879,13 @@ struct AdcFrameArgs {
   int start, step, C, ldo;
   float* inp_pair;         // [B, ldo] (null: not wanted)
   float* out_pair;         // [B, ldo]
+  int split_wide;          // the rows' norms in the order of emx_sketchmap_split's long-row kernel (else: of its wave-per-row kernel)
+  emx::SplitRows sp;       // planes null: no split.  Else emx_sketchmap_split of inp_pair: its rows minus row 0 as two f16 planes
 };
-__host__ __device__ inline long adc_frame_floats(int A, int C) { return (long)A + 2 * (long)A + 6 * (long)A + 3 * (long)C + d2c_frame_floats(A, false); }
+__host__ __device__ inline long adc_frame_floats(int A, int C, bool split) {
+  return (long)A + 2 * (long)A + 6 * (long)A + 3 * (long)C + d2c_frame_floats(A, false) +
+         (split ? 3 * (long)C + emx::split_ld((int)((long)C * (C - 1) / 2)) : 0);
+}
 
 __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs a) {
   extern __shared__ float sm[];
@@ -893,6 +899,10 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   float* Xl = Pl + 3 * A;          // [A][3] back-mapped frame
   float* sxc = Xl + 3 * A;         // [C][3] selected atoms of the input frame
   float* fr = sxc + 3 * a.C;       // the frame kernel's own buffers
+  const bool split = a.sp.planes != nullptr;
+  float* sxr = fr + d2c_frame_floats(A, false);   // [C][3] selected atoms of input frame 0, the reference row of the split
+  float* vrow = sxr + 3 * a.C;                    // [P] this frame's input pair distances minus frame 0's
+  __shared__ float red_n[AF_NT / 64], red_m[AF_NT / 64];
   const float* row = a.Y + b * a.ldy;
   const long P = (long)a.C * (a.C - 1) / 2;
   // ---- PeriodicOutput; the input frame's selected atoms
@@ -916,14 +926,32 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
     for (int e = tid; e < 3 * a.C; e += AF_NT) {
       const int c = e / 3, k = e - 3 * c;
       sxc[e] = X[3 * (a.start + a.step * c) + k];
+      if (split) sxr[e] = a.cart[3 * (a.start + a.step * c) + k];
     }
   }
   __syncthreads();
   // ---- chain_in_plane on wave 0; the other waves: pair distances of the input frame
   if (wave == 0) {
     chain_frame_body(a.mean_len, ang_l, A, phi, a.plane + b * A * 3, Pl, lane);
-  } else if (a.inp_pair) {
+  } else if (a.inp_pair && !split) {
     pdist_pairs(sxc, 0, 1, a.C, P, a.ldo, a.inp_pair + b * a.ldo, tid - 64, AF_NT - 64);
+  } else if (a.inp_pair) {
+    // (pdist_pairs, and beside every distance the same pair of frame 0: the split works on the difference)
+    float* o = a.inp_pair + b * a.ldo;
+    for (long p = tid - 64; p < P; p += AF_NT - 64) {
+      int i, j;
+      pair_decode(p, a.C, i, j);
+      const float* u = sxc + 3 * i;
+      const float* w = sxc + 3 * j;
+      const float dx = u[0] - w[0], dy = u[1] - w[1], dz = u[2] - w[2];
+      const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+      const float* ur = sxr + 3 * i;
+      const float* wr = sxr + 3 * j;
+      const float ex = ur[0] - wr[0], ey = ur[1] - wr[1], ez = ur[2] - wr[2];
+      o[p] = d;
+      vrow[p] = d - sqrtf(ex * ex + ey * ey + ez * ez);
+    }
+    for (long p = P + tid - 64; p < a.ldo; p += AF_NT - 64) o[p] = 0.f;
   }
   __syncthreads();
   // ---- dihedrals_to_cartesian
@@ -931,6 +959,53 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   __syncthreads();
   // ---- pair distances of the back-mapped frame
   pdist_pairs(Xl, a.start, a.step, a.C, P, a.ldo, a.out_pair + b * a.ldo, tid, AF_NT);
+  if (!split) return;
+  // ---- sk_split_wide_kernel on the row of differences: its partition of the row over 1024 threads, its order of additions
+  //      (a.split_wide; short rows: the order of emx::split_row, a wave per row)
+  float nrm = 0.f, mx = 0.f;
+  const int kstep = a.split_wide ? AF_NT : 64;
+  if (a.split_wide || wave == 0) {
+    for (int k = a.split_wide ? tid : lane; k < (int)P; k += kstep) {
+      const float v = vrow[k];
+      nrm = fmaf(v, v, nrm);
+      mx = fmaxf(mx, fabsf(v));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    nrm = emx::wave_sum(nrm);
+    if (lane == 0) {
+      red_n[wave] = nrm;
+      red_m[wave] = mx;
+    }
+  }
+  __syncthreads();
+  if (a.split_wide) {
+    nrm = 0.f;
+    mx = 0.f;
+#pragma unroll
+    for (int w = 0; w < AF_NT / 64; w += 4) {   // fixed order
+      nrm += (red_n[w] + red_n[w + 1]) + (red_n[w + 2] + red_n[w + 3]);
+      mx = fmaxf(mx, fmaxf(fmaxf(red_m[w], red_m[w + 1]), fmaxf(red_m[w + 2], red_m[w + 3])));
+    }
+  } else {
+    nrm = red_n[0];
+    mx = red_m[0];
+  }
+  int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;   // (the scale rule of emx::split_row)
+  E = mx > 0.f ? min(max(E, -100), 100) : 14;
+  const float sc = __uint_as_float((uint32_t)(127 + 14 - E) << 23), rs = __uint_as_float((uint32_t)(127 - 14 + E) << 23);
+  for (int k = tid; k < a.sp.ld; k += AF_NT) {
+    const float v = k < (int)P ? vrow[k] * sc : 0.f;
+    const _Float16 h = (_Float16)v;
+    const _Float16 l = (_Float16)(v - (float)h);
+    uint16_t* o = a.sp.planes + emx::split_index(a.sp, b, k);
+    o[0] = emx::f16_bits(h);
+    o[a.sp.plane_stride] = emx::f16_bits(l);
+  }
+  if (tid == 0) {
+    a.sp.norms[b] = nrm;
+    a.sp.rscale[b] = rs;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1384,7 +1459,8 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
 
 int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
                       int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane, float* xyz,
-                      const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, emx_stream_t stream) {
+                      const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, void* split_ws,
+                      emx_stream_t stream) {
   const char* who = "emx_adc_frame_fwd";
   EMX_REQUIRE(Y && dih_pred && mean_lengths && plane && xyz && out_pair && B > 0 && A >= 4, "%s: bad arguments (A >= 4)", who);
   EMX_REQUIRE((ang_sin >= 0 && ang_cos >= 0 && ang_pred) || (ang_sin < 0 && mean_angles), "%s: the angles come from Y (columns + ang_pred) or from mean_angles", who);
@@ -1395,7 +1471,9 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
   const long P = (long)C * (C - 1) / 2;
   EMX_REQUIRE(ldo >= P, "%s: output row stride %d < %ld pairs", who, ldo, P);
   EMX_REQUIRE(!inp_pair || cart, "%s: the input frames are needed for their pair distances", who);
-  const size_t lds = (size_t)adc_frame_floats(A, C) * sizeof(float);
+  EMX_REQUIRE(!split_ws || (inp_pair && (reinterpret_cast<uintptr_t>(split_ws) & 15) == 0 && P < (1L << 30)),
+              "%s: the split needs the input pair block and a 16-byte aligned workspace", who);
+  const size_t lds = (size_t)adc_frame_floats(A, C, split_ws != nullptr) * sizeof(float);
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: a frame of %d atoms does not fit the LDS buffers of the fused pass (use the single stages)", who, A);
   AdcFrameArgs a;
   a.Y = Y;
@@ -1421,6 +1499,8 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
   a.ldo = ldo;
   a.inp_pair = inp_pair;
   a.out_pair = out_pair;
+  a.sp = split_ws ? emx::split_view(split_ws, B, (int)P) : emx::SplitRows{};
+  a.split_wide = P >= 1024 && B <= 8192;   // (the rule of emx_sketchmap_split)
   hipLaunchKernelGGL(adc_frame_fwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
   return emx::check_launch("adc_frame_fwd_kernel");
 }

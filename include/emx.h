@@ -462,11 +462,14 @@ int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int st
  * emx_dihedrals_to_cartesian_fwd + emx_pdist_flat_fwd x2; every intermediate is written as those calls write it
  * (ang_pred [B, A-2], dih_pred [B, A-3], plane, xyz [B, A, 3], pair blocks [B, ldo]).  ang_sin < 0: the angles are the batch
  * means `mean_angles` [A-2] (MeanAngles, layers.py:1153-1161; ang_pred is not written).  mean_lengths [A-1].
+ * split_ws (may be NULL; emx_sketchmap_split_bytes(B, C(C-1)/2) bytes): additionally emx_sketchmap_split of inp_pair, the
+ * operand planes of the all-pairs kernel for the cartesian distance cost (its high-d points are the input frames' pair
+ * distances, models.py:2448-2475), bit for bit.
  * EMX_EUNSUPPORTED when a frame does not fit the LDS buffers of the fused pass (the single stages remain). */
 int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles,
                       float* ang_pred, int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths,
                       float dihedral_offset, int A, float* plane, float* xyz, const float* cart, int start, int step, int C,
-                      float* inp_pair, float* out_pair, int ldo, emx_stream_t stream);
+                      float* inp_pair, float* out_pair, int ldo, void* split_ws, emx_stream_t stream);
 
 /* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
  *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,

@@ -325,6 +325,23 @@ def test_adc_frame_forward_equals_its_stages(L, B, A, start, step, use_ang):
     L.adc_frame_fwd(Y, 2 * PI, cols_ang if use_ang else None, None if use_ang else mean_ang, ang1 if use_ang else None, cols_dih, dih1, mean_len,
                     PI, plane1, xyz1, cart, start, step, C, ip1, op1)
     torch.cuda.synchronize()
+    if A == 457:
+        with pytest.raises(L.EmxError) as err:   # (the row of 104 196 pair distances does not fit beside the frame)
+            L.adc_frame_fwd(Y, 2 * PI, cols_ang, None, ang1, cols_dih, dih1, mean_len, PI, plane1, xyz1, cart, start, step, C, ip1, op1,
+                            split_ws=torch.zeros(L.sketchmap_split_bytes(B, P), dtype=torch.uint8, device="cuda"))
+        assert err.value.unsupported
+    elif P >= 2:
+        # ... and with the split of the input pair rows (the all-pairs kernel's operand planes): emx_sketchmap_split, bit for bit
+        sw0 = torch.zeros(L.sketchmap_split_bytes(B, P), dtype=torch.uint8, device="cuda")
+        sw1 = torch.full_like(sw0, 0x5A)
+        sw0.fill_(0x5A)
+        L.sketchmap_split(ip0[:, :P], sw0)
+        ip3, op3 = nan(B, ldo), nan(B, ldo)
+        L.adc_frame_fwd(Y, 2 * PI, cols_ang if use_ang else None, None if use_ang else mean_ang, ang1 if use_ang else None, cols_dih, dih1,
+                        mean_len, PI, plane1, xyz1, cart, start, step, C, ip3, op3, split_ws=sw1)
+        torch.cuda.synchronize()
+        assert torch.equal(ip0, ip3) and torch.equal(op0, op3)
+        assert torch.equal(sw0, sw1), f"split rows differ in {int((sw0 != sw1).sum())} bytes"
     pairs = [("dihedrals", dih0, dih1), ("plane", plane0, plane1), ("xyz", xyz0, xyz1), ("input pairs", ip0, ip1), ("output pairs", op0, op1)]
     if use_ang:
         pairs.append(("angles", ang0, ang1))
