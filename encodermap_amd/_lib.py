@@ -79,6 +79,7 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
     "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
@@ -621,6 +622,16 @@ def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih
                                     _ptr(inp_pair) if inp_pair is not None else None, _ptr(out_pair), out_pair.stride(0),
                                     _ptr(split_ws) if split_ws is not None else None, _stream()),
            "emx_adc_frame_fwd")
+
+
+def adc_frame_bwd(out_pair, inp_pair, variant, coef, coef_scale, ws, xyz, dihedrals, offset, plane, start, step, C, ddihedrals, dplane):
+    """Cartesian cost + backward of the pair distances + backward of dihedrals_to_cartesian in one launch (emx_adc_frame_bwd)."""
+    B, A = xyz.shape[0], xyz.shape[1]
+    assert out_pair.stride(0) == inp_pair.stride(0) and dihedrals.is_contiguous()
+    _check(load().emx_adc_frame_bwd(_ptr(out_pair), _ptr(inp_pair), out_pair.stride(0), VARIANTS[variant] if isinstance(variant, str) else int(variant),
+                                    float(coef), _ptr(coef_scale) if coef_scale is not None else None, _ptr(ws), _ptr(xyz), _ptr(dihedrals),
+                                    float(offset), _ptr(plane), B, A, int(start), int(step), int(C), _ptr(ddihedrals), ddihedrals.stride(0),
+                                    _ptr(dplane), _stream()), "emx_adc_frame_bwd")
 
 
 def pdist_flat_bwd(xyz, dout, start, step, C, dxyz, accumulate=False):

@@ -93,6 +93,7 @@ class ADCEngine(SequentialEngine):
         self.P = self.C * (self.C - 1) // 2
         self.ldp = _round4(self.P)
         self._fuse_frame = os.environ.get("EMX_ADC_FUSE_FRAME", "1") != "0"
+        self._fuse_frame_bwd = self._fuse_frame
         self._init_common(col, p, device, weights, dp, use_graph, history_capacity)
 
     # ------------------------------------------------------------------------------------------
@@ -197,6 +198,23 @@ class ADCEngine(SequentialEngine):
             return False
         return True
 
+    def _frame_backward(self) -> bool:
+        """Cartesian cost, backward of the pair distances and of dihedrals_to_cartesian as one launch (emx_adc_frame_bwd);
+        False outside the shapes that pass is built for: the single stages follow."""
+        if not self._fuse_frame_bwd:
+            return False
+        p = self.p
+        try:
+            _lib.adc_frame_bwd(self.out_pair, self.inp_pair, p.cartesian_cost_variant, 1.0 / float(p.cartesian_cost_reference), self.cart_scale,
+                               self.cost_ws_rows[0], self.xyz, self.dih_pred, math.pi, self.plane, self.pw_start, self.pw_step, self.C,
+                               self.ddih_cart, self.dplane)
+        except _lib.EmxError as exc:
+            if not exc.unsupported:
+                raise
+            self._fuse_frame_bwd = False
+            return False
+        return True
+
     # -- training metrics (ADCClashMetric / ADCRMSDMetric, callbacks/metrics.py:470-581) ------------------------------
     METRIC_WEIGHTS = (14.0067, 24.305, 24.305)   # metrics.py:63
 
@@ -273,11 +291,12 @@ class ADCEngine(SequentialEngine):
         # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
         if not self._fused_head:
             _lib.soft_start_scale(self.step, *soft, self.cart_scale)
-        _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
-                                   1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
-                                   coef_scale=self.cart_scale)
-        _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
-        _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
+        if not self._frame_backward():
+            _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
+                                       1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
+                                       coef_scale=self.cart_scale)
+            _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
+            _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
         if self.use_ang:
             _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
 

@@ -17,6 +17,7 @@
 // "(x - o) @ R(u, -d)" equals the usual right-handed rotation by +d about u acting on column vectors.
 // The backward pass walks the chain in reverse, recovering A_{i-1} = A_i o N_i^{-1} instead of storing it, and
 // accumulates the adjoints of the transform, of the dihedral and of the planar coordinates.
+#include "cost.h"
 #include "emx_common.h"
 #include "split.h"
 
@@ -791,25 +792,9 @@ __global__ __launch_bounds__(PD_NT) void pdist_fwd_kernel(const float* __restric
 // their shares in a fixed tree (deterministic, no atomics); the frame's gradient row is staged in LDS first when it fits
 // (stage_g) -- read in place, every thread walks its dependent scattered global loads.  (One thread per atom left 76 of 256
 // threads with 75 serial terms each at the ADC shape.)
-__global__ __launch_bounds__(PD_NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
-                                                          int step, int C, int ldo, float* __restrict__ dxyz, int accumulate, int stage_g,
-                                                          int T) {
-  extern __shared__ float sx[];
-  const int b = blockIdx.x;
-  const float* X = xyz + (long)b * A * 3;
-  for (int e = threadIdx.x; e < 3 * C; e += PD_NT) {
-    int c = e / 3, k = e - 3 * c;
-    sx[e] = X[3 * (start + step * c) + k];
-  }
-  const float* g = dout + (long)b * ldo;
-  if (stage_g) {
-    float* sg = sx + 3 * C;
-    const int P = C * (C - 1) / 2;
-    for (int e = threadIdx.x; e < P; e += PD_NT) sg[e] = g[e];
-    g = sg;
-  }
-  __syncthreads();
-  float* D = dxyz + (long)b * A * 3;
+// (the part behind the staging: sx the selected atoms, g the frame's gradient row, D the frame's [A][3] result -- HBM or LDS)
+__device__ __forceinline__ void pdist_bwd_body(const float* __restrict__ sx, const float* __restrict__ g, int A, int start, int step, int C,
+                                               float* __restrict__ D, int accumulate, int T) {
   if (!accumulate) {
     // atoms that are not selected receive zero
     for (int e = threadIdx.x; e < 3 * A; e += PD_NT) {
@@ -850,6 +835,26 @@ __global__ __launch_bounds__(PD_NT) void pdist_bwd_kernel(const float* __restric
       }
     }
   }
+}
+__global__ __launch_bounds__(PD_NT) void pdist_bwd_kernel(const float* __restrict__ xyz, const float* __restrict__ dout, int A, int start,
+                                                          int step, int C, int ldo, float* __restrict__ dxyz, int accumulate, int stage_g,
+                                                          int T) {
+  extern __shared__ float sx[];
+  const int b = blockIdx.x;
+  const float* X = xyz + (long)b * A * 3;
+  for (int e = threadIdx.x; e < 3 * C; e += PD_NT) {
+    int c = e / 3, k = e - 3 * c;
+    sx[e] = X[3 * (start + step * c) + k];
+  }
+  const float* g = dout + (long)b * ldo;
+  if (stage_g) {
+    float* sg = sx + 3 * C;
+    const int P = C * (C - 1) / 2;
+    for (int e = threadIdx.x; e < P; e += PD_NT) sg[e] = g[e];
+    g = sg;
+  }
+  __syncthreads();
+  pdist_bwd_body(sx, g, A, start, step, C, dxyz + (long)b * A * 3, accumulate, T);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1006,6 +1011,86 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
     a.sp.norms[b] = nrm;
     a.sp.rscale[b] = rs;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// ... and the way back (emx_adc_frame_bwd): the cartesian cost on the frame's pair distances (emx_periodic_cost_fwd_bwd on
+// out_pair against inp_pair), the pair distances' backward pass and the backward pass of dihedrals_to_cartesian, a workgroup
+// per frame -- three launches of 6-10 us.  d cost / d pair distances and d cost / d xyz never leave LDS.  The cost's workgroup
+// shares land in ws exactly as the stand-alone launch leaves them (its partition of a row: S = 4 workgroups of 256 threads,
+// here the four quarters of this workgroup), so that the step's scalar epilogue adds up the same numbers in the same order.
+// ---------------------------------------------------------------------------------------------------------
+struct AdcFrameBwdArgs {
+  emx::CostArgs cost;      // y = out_pair, target = inp_pair, n = P; dY unused (the gradient row stays in LDS)
+  const float* xyz;        // [B, A, 3] back-mapped frames
+  const float* dih;        // [B, A - 3]
+  const float* plane;      // [B, A, 3]
+  float offset;
+  int A, start, step, C, T;
+  float* ddih;             // [B, ldg]
+  int ldg;
+  float* dplane;           // [B, A, 3]
+};
+__host__ __device__ inline long adc_frame_bwd_floats(int A, int C) {
+  return 3 * (long)C + (long)C * (C - 1) / 2 + 3 * (long)A + d2c_frame_floats(A, true);
+}
+static_assert(AF_NT == PD_NT, "the pair-distance bodies run on the whole workgroup");
+
+__global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdArgs a) {
+  extern __shared__ float sm[];
+  __shared__ float red[AF_NT / 64];
+  const int A = a.A, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long b = blockIdx.x;
+  const int P = a.C * (a.C - 1) / 2;
+  float* sx = sm;                 // [C][3] selected atoms of the back-mapped frame
+  float* sg = sx + 3 * a.C;       // [P] d cost / d pair distances
+  float* dx = sg + P;             // [A][3] d cost / d xyz
+  float* fr = dx + 3 * A;         // the frame kernel's buffers
+  {
+    const float* X = a.xyz + b * A * 3;
+    for (int e = tid; e < 3 * a.C; e += AF_NT) {
+      const int c = e / 3, k = e - 3 * c;
+      sx[e] = X[3 * (a.start + a.step * c) + k];
+    }
+  }
+  // ---- the cost on row b (periodic_cost_body with four workgroups per row: quarter q of this workgroup is its workgroup 4 b + q)
+  {
+    const emx::CostArgs& c = a.cost;
+    const float* yrow = c.y + b * c.ldy;
+    const float* trow = c.target + b * c.ldt;
+    const float gn = c.coef_scale ? c.gnorm * *c.coef_scale : c.gnorm;
+    float lsum = 0.f;
+    for (int k = tid; k < c.n; k += AF_NT) {
+      float s, cs, delta, dd;
+      emx::cost_elem(c, yrow, trow, k, s, cs, delta, dd);
+      float g;
+      if (c.variant == EMX_MEAN_ABS) {
+        lsum += fabsf(delta);
+        g = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+      } else {
+        lsum = fmaf(delta, delta, lsum);
+        g = 2.f * delta * dd;
+      }
+      emx::cost_store(c, sg, nullptr, k, gn * g, s, cs);
+    }
+    lsum = emx::wave_sum(lsum);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();   // (also: sx and sg are complete)
+    if ((tid & 255) == 0) {
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r += red[wave + i];
+      c.ws[4 * b + (tid >> 8)] = r * c.gnorm * (c.coef_scale ? *c.coef_scale : 1.f);
+    }
+    if (b == 0)   // unused scratch entries read as zero by the summing job
+      for (int i = 4 * (int)gridDim.x + tid; i < EMX_REDUCE_WS; i += AF_NT) c.ws[i] = 0.f;
+  }
+  // ---- pair distances, backward: d cost / d xyz of the frame
+  pdist_bwd_body(sx, sg, A, a.start, a.step, a.C, dx, 0, a.T);
+  __syncthreads();
+  // ---- dihedrals_to_cartesian, backward
+  d2c_frame_body<true, AF_NT>(a.dih + b * (A - 3), a.offset, a.plane + b * A * 3, dx, A, nullptr, nullptr, a.ddih + b * a.ldg, a.dplane + b * A * 3, fr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1503,6 +1588,55 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
   a.split_wide = P >= 1024 && B <= 8192;   // (the rule of emx_sketchmap_split)
   hipLaunchKernelGGL(adc_frame_fwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
   return emx::check_launch("adc_frame_fwd_kernel");
+}
+
+int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale, float* ws,
+                      const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start, int step, int C,
+                      float* ddihedrals, int ldg, float* dplane, emx_stream_t stream) {
+  const char* who = "emx_adc_frame_bwd";
+  EMX_REQUIRE(out_pair && inp_pair && ws && xyz && dihedrals && plane && ddihedrals && dplane && B > 0 && A >= 4 && ldg >= A - 3, "%s: bad arguments (A >= 4)", who);
+  EMX_REQUIRE(C >= 2 && step >= 1 && start >= 0 && start + (long)step * (C - 1) < A, "%s: atom selection outside the frame", who);
+  const long P = (long)C * (C - 1) / 2;
+  EMX_REQUIRE(ldo >= P, "%s: row stride %d < %ld pairs", who, ldo, P);
+  EMX_REQUIRE(variant >= EMX_MEAN_ABS && variant <= EMX_MEAN_NORM, "%s: cost variant %d not available", who, variant);
+  // the stand-alone cost launch puts S = min(EMX_REDUCE_WS / B, ceil(P / 512)) workgroups of 256 threads on a row; the fused pass
+  // is that partition for S = 4 (a few hundred frames with a few thousand pair distances each)
+  const bool four = variant != EMX_MEAN_NORM && B <= EMX_REDUCE_WS / 4 && P > 3 * 512;
+  if (!four)
+    return emx::fail(EMX_EUNSUPPORTED, "%s: B = %d frames x %ld pair distances (variant %d) is outside the fused pass (use the single stages)", who, B, P, variant);
+  const size_t lds = (size_t)adc_frame_bwd_floats(A, C) * sizeof(float);
+  if (lds > 160 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: a frame of %d atoms does not fit the LDS buffers of the fused pass (use the single stages)", who, A);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_frame_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+  AdcFrameBwdArgs a{};
+  a.cost.y = out_pair;
+  a.cost.target = inp_pair;
+  a.cost.dpred_add = nullptr;
+  a.cost.coef_scale = coef_scale;
+  a.cost.dY = nullptr;
+  a.cost.ws = ws;
+  a.cost.loss = nullptr;
+  emx::fill_cost_scalars(a.cost, B, (int)P, ldo, ldo, 0, 0, 0, INFINITY, variant, coef);
+  a.cost.row_begin = 0;
+  a.cost.row_end = B;
+  a.cost.prescale = 1;
+  a.cost.wide = 4;
+  a.xyz = xyz;
+  a.dih = dihedrals;
+  a.plane = plane;
+  a.offset = dihedral_offset;
+  a.A = A;
+  a.start = start;
+  a.step = step;
+  a.C = C;
+  int T = 8;
+  while (T > 1 && (long)C * T > PD_NT) T >>= 1;
+  a.T = T;
+  a.ddih = ddihedrals;
+  a.ldg = ldg;
+  a.dplane = dplane;
+  hipLaunchKernelGGL(adc_frame_bwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
+  return emx::check_launch("adc_frame_bwd_kernel");
 }
 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo, float* dxyz, int accumulate,

@@ -471,6 +471,18 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
                       float dihedral_offset, int A, float* plane, float* xyz, const float* cart, int start, int step, int C,
                       float* inp_pair, float* out_pair, int ldo, void* split_ws, emx_stream_t stream);
 
+/* ... and the way back in ONE launch, a workgroup per frame: the cartesian cost (models.py:2405-2447: the row-mean cost
+ * `variant` with `coef` [x *coef_scale, the soft-start scale] of out_pair against inp_pair, [B, ldo] each with C(C-1)/2 pair
+ * distances per row), the backward pass of PairwiseDistancesLayer and of dihedrals_to_cartesian (tape.gradient,
+ * models.py:3392-3393).  Equal, value for value, to emx_periodic_cost_fwd_bwd (loss NULL: its prescaled workgroup shares in
+ * ws [EMX_REDUCE_WS]) + emx_pdist_flat_bwd + emx_dihedrals_to_cartesian_bwd; d cost / d pair distances and d cost / d xyz
+ * stay on the chip.  Written: ws, ddihedrals [B, A-3] (stride ldg), dplane [B, A, 3].
+ * EMX_EUNSUPPORTED outside the shapes the pass is built for (B <= EMX_REDUCE_WS / 4 frames, more than 1536 pair distances
+ * per frame, not EMX_MEAN_NORM, a frame that fits LDS): the single stages remain. */
+int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale,
+                      float* ws, const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A,
+                      int start, int step, int C, float* ddihedrals, int ldg, float* dplane, emx_stream_t stream);
+
 /* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
  *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,
  *                    count_nonzero(pairwise_dist(y_pred, flat=True) < d, axis=1)      encodermap/callbacks/metrics.py:505-522

@@ -362,3 +362,50 @@ def test_adc_frame_forward_refuses_frames_beyond_lds(L):
         L.adc_frame_fwd(z(B, 4 * A), 2 * PI, (0, A), None, z(B, A - 2), (2 * A, 3 * A), z(B, A - 3), z(A - 1), PI, z(B, A, 3), z(B, A, 3),
                         z(B, A, 3), 0, 1, A, z(B, A * (A - 1) // 2), z(B, A * (A - 1) // 2))
     assert err.value.unsupported
+
+
+@pytest.mark.parametrize("B,A,start,step,variant,soft", [(256, 228, 1, 3, "mean_abs", True), (64, 180, 0, 3, "mean_square", False),
+                                                         (200, 57, 0, 1, "mean_abs", True)])
+def test_adc_frame_backward_equals_its_stages(L, B, A, start, step, variant, soft):
+    """emx_adc_frame_bwd (cartesian cost + backward of PairwiseDistances + backward of dihedrals_to_cartesian in one launch,
+    models.py:2405-2447, 3392-3393) against the three launches it replaces: the cost's workgroup shares and both gradients, value for
+    value."""
+    rng = np.random.default_rng(A * B)
+    C = len(range(A)[start::step])
+    P = C * (C - 1) // 2
+    ldo = (P + 3) // 4 * 4
+    lengths, angles, dih = make_chain(rng, B, A)
+    mean_len = dev(lengths.astype(np.float64).mean(0).astype(np.float32))
+    ANG, DIH = dev(angles), dev(dih)
+    plane, xyz = torch.empty(B, A, 3, device="cuda"), torch.empty(B, A, 3, device="cuda")
+    L.chain_in_plane_fwd(mean_len, ANG, plane)
+    L.dihedrals_to_cartesian_fwd(DIH, PI, plane, xyz)
+    cart = xyz + 0.05 * torch.randn(B, A, 3, device="cuda")
+    inp, out = torch.zeros(B, ldo, device="cuda"), torch.zeros(B, ldo, device="cuda")
+    L.pdist_flat_fwd(cart, start, step, C, inp)
+    L.pdist_flat_fwd(xyz, start, step, C, out)
+    scale = torch.tensor([0.37], device="cuda") if soft else None
+    nan = lambda *s: torch.full(s, float("nan"), device="cuda")
+    ws0, dpair, dxyz, dd0, dp0 = nan(L.EMX_REDUCE_WS), nan(B, ldo), nan(B, A, 3), nan(B, A - 3), nan(B, A, 3)
+    L.periodic_cost_fwd_bwd(out, 0, 0, False, inp, P, float("inf"), variant, 1.0 / 8.0, 0, B, None, dpair, ws0, coef_scale=scale)
+    L.pdist_flat_bwd(xyz, dpair, start, step, C, dxyz, False)
+    L.dihedrals_to_cartesian_bwd(DIH, PI, plane, dxyz, dd0, dp0)
+    ws1, dd1, dp1 = nan(L.EMX_REDUCE_WS), nan(B, A - 3), nan(B, A, 3)
+    L.adc_frame_bwd(out, inp, variant, 1.0 / 8.0, scale, ws1, xyz, DIH, PI, plane, start, step, C, dd1, dp1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(ws1).all() and torch.isfinite(dd1).all() and torch.isfinite(dp1).all()
+    assert float(ws1.sum()) > 0
+    assert torch.equal(ws0, ws1), f"cost shares: max difference {float((ws0 - ws1).abs().max())}"
+    assert torch.equal(dd0, dd1), f"d dihedrals: max difference {float((dd0 - dd1).abs().max())}"
+    assert torch.equal(dp0, dp1), f"d plane: max difference {float((dp0 - dp1).abs().max())}"
+
+
+def test_adc_frame_backward_leaves_other_shapes_to_the_stages(L):
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    B, A = 16, 30          # 435 pair distances per frame: the stand-alone cost launch partitions such rows differently
+    P = A * (A - 1) // 2
+    for variant, b in (("mean_abs", B), ("mean_norm", 16)):
+        with pytest.raises(L.EmxError) as err:
+            L.adc_frame_bwd(z(b, P + 1), z(b, P + 1), variant, 1.0, None, z(L.EMX_REDUCE_WS), z(b, A, 3), z(b, A - 3), PI, z(b, A, 3), 0, 1, A,
+                            z(b, A - 3), z(b, A, 3))
+        assert err.value.unsupported

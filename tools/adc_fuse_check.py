@@ -6,7 +6,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     import encodermap_amd as em
     from encodermap_amd.features import featurize_backbone
     rng = np.random.default_rng(3)
-    N, A = 2000, 3 * 40
+    N, A = 1500, 3 * 76
     st = rng.normal(size=(N, A, 3)); st /= np.linalg.norm(st, axis=2, keepdims=True)
     cv = featurize_backbone(np.cumsum(1.4 * st, axis=1).astype(np.float32))
     p = em.ADCParameters(n_steps=300, batch_size=256, seed=5, cartesian_pwd_start=1, cartesian_pwd_step=3, use_backbone_angles=sys.argv[2] == "1",
