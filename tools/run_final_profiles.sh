@@ -17,6 +17,8 @@ python3 tools/abl_timing.py build_ab/libemx_timing.so fused > $o/chain_timeline.
 python3 tools/abl_timing.py build_ab/libemx_timing.so bwd >> $o/chain_timeline.txt 2>&1
 python3 tools/abl_wgrad.py build_ab/libemx_timing.so > $o/wgrad_adam_timeline.txt 2>&1
 python3 tools/abl_finish.py build_ab/libemx_timing.so >> $o/wgrad_adam_timeline.txt 2>&1
+EMX_LIB_PATH=build_ab/lib_d2ct.so python3 tools/abl_d2c.py > $o/d2c_timeline.txt 2>&1
+python3 tools/adc_fuse_check.py > $o/adc_fuse_check.txt 2>&1
 bash tools/run_pmc_step.sh $tag > $o/step_counters.json 2> $o/step_counters.err
 grep -v amdgpu.ids $o/configs.txt
 cut -c1-220 $o/bench.json
