@@ -433,6 +433,17 @@ __device__ __forceinline__ Aff aff_from(const Aff& x) {
   p.t = V3{dpp_from<CTRL, ROWS>(x.t.x, 0.f), dpp_from<CTRL, ROWS>(x.t.y, 0.f), dpp_from<CTRL, ROWS>(x.t.z, 0.f)};
   return p;
 }
+// inclusive prefix sum over the lanes of a wave
+__device__ __forceinline__ float wave_scan_add(float v) {
+  v += dpp_from<0x111, 0xF>(v, 0.f);
+  v += dpp_from<0x112, 0xF>(v, 0.f);
+  v += dpp_from<0x114, 0xF>(v, 0.f);
+  v += dpp_from<0x118, 0xF>(v, 0.f);
+  v += dpp_from<0x142, 0xA>(v, 0.f);
+  v += dpp_from<0x143, 0xC>(v, 0.f);
+  return v;
+}
+__device__ __forceinline__ float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
 // product of the transforms of all lanes below this one (lane 0: the identity), lower lanes on the left
 __device__ __forceinline__ Aff aff_scan_exclusive(Aff x) {
   x = compose(aff_from<0x111, 0xF>(x), x);
@@ -698,14 +709,10 @@ __device__ __forceinline__ void chain_frame_body(const float* __restrict__ len, 
     for (int i0 = 1; i0 < A - 1; i0 += 64) {
       const int i = i0 + lane;
       float v = i < A - 1 ? ((i & 1) ? -sm[i] : sm[i]) : 0.f;
-#pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const float u = __shfl_up(v, off, 64);
-        if (lane >= off) v += u;
-      }
+      v = wave_scan_add(v);   // (DPP: six dependent shuffles through LDS per scan were most of this kernel)
       const float t = carry + v;
       if (i < A - 1) sm[i] = (i & 1) ? -t : t;
-      carry += __shfl(v, 63, 64);
+      carry += lane63(v);
     }
     if (lane == 0) sm[0] = 0.f;
   }
@@ -724,20 +731,14 @@ __device__ __forceinline__ void chain_frame_body(const float* __restrict__ len, 
       dx = len[i] * cs;
       dy = (i & 1) ? -len[i] * sn : len[i] * sn;
     }
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-      const float ux = __shfl_up(dx, off, 64), uy = __shfl_up(dy, off, 64);
-      if (lane >= off) {
-        dx += ux;
-        dy += uy;
-      }
-    }
+    dx = wave_scan_add(dx);
+    dy = wave_scan_add(dy);
     if (i < A - 1) {
       st3(o + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
       if (ol) st3(ol + 3 * (i + 1), V3{cx + dx, cy + dy, 0.f});
     }
-    cx += __shfl(dx, 63, 64);
-    cy += __shfl(dy, 63, 64);
+    cx += lane63(dx);
+    cy += lane63(dy);
   }
 }
 __global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda, int A,
@@ -745,6 +746,57 @@ __global__ __launch_bounds__(64) void chain_frame_kernel(const float* __restrict
   extern __shared__ float sm[];   // [A] phi
   const int b = blockIdx.x;
   chain_frame_body(len, ang + (long)b * lda, A, sm, xyz + (long)b * A * 3, nullptr, threadIdx.x);
+}
+
+// chain_in_plane backward, ONE wave per frame: phi as in the forward body; GX, GY (suffix sums of the coordinate gradients) and
+// the alternating suffix sum of dL/dphi as wave scans over the steps in descending order, 64 at a time with a carry -- the
+// thread-per-frame kernel above walks A - 2 dependent steps with a library sincosf each on 256 threads of the whole chip.
+//   dL/dphi_j = len_j (-sin phi_j GX_j + (-1)^j cos phi_j GY_j);   (-1)^j acc_j = sum_{k >= j} (-1)^k dL/dphi_k;   dtheta_{j-1} = -acc_j
+__device__ __forceinline__ void chain_bwd_body(const float* __restrict__ len, const float* __restrict__ th, const float* __restrict__ g, int A,
+                                               float* __restrict__ sm, float* __restrict__ d, const int lane) {
+  for (int i = lane; i < A - 2; i += 64) sm[i + 1] = PI_F - th[i];
+  wave_sync();
+  {
+    float carry = 0.f;
+    for (int i0 = 1; i0 < A - 1; i0 += 64) {
+      const int i = i0 + lane;
+      float v = i < A - 1 ? ((i & 1) ? -sm[i] : sm[i]) : 0.f;
+      v = wave_scan_add(v);
+      const float t = carry + v;
+      if (i < A - 1) sm[i] = (i & 1) ? -t : t;
+      carry += lane63(v);
+    }
+    if (lane == 0) sm[0] = 0.f;
+  }
+  wave_sync();
+  const int n = A - 1;
+  float cX = 0.f, cY = 0.f, cS = 0.f;
+  for (int e0 = 0; e0 < n; e0 += 64) {
+    const int e = e0 + lane, j = n - 1 - e;
+    const bool ok = e < n;
+    float gx = ok ? g[3 * (j + 1)] : 0.f, gy = ok ? g[3 * (j + 1) + 1] : 0.f;
+    gx = wave_scan_add(gx);
+    gy = wave_scan_add(gy);
+    float alt = 0.f;
+    if (ok) {
+      float sn, cs;
+      emx::sincos_bounded(sm[j], &sn, &cs);
+      const float sgn = (j & 1) ? -1.f : 1.f;
+      const float dphi = len[j] * (-sn * (cX + gx) + sgn * cs * (cY + gy));
+      alt = sgn * dphi;
+    }
+    const float S = cS + wave_scan_add(alt);
+    if (ok && j >= 1) d[j - 1] = (j & 1) ? S : -S;   // -acc_j, acc_j = (-1)^j S
+    cX += lane63(gx);
+    cY += lane63(gy);
+    cS = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, S), 63));
+  }
+}
+__global__ __launch_bounds__(64) void chain_bwd_frame_kernel(const float* __restrict__ len, const float* __restrict__ ang, int lda,
+                                                             const float* __restrict__ dxyz, int A, float* __restrict__ dang, int ldd) {
+  extern __shared__ float sm[];   // [A] phi
+  const long b = blockIdx.x;
+  chain_bwd_body(len, ang + b * lda, dxyz + b * A * 3, A, sm, dang + b * ldd, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1495,6 +1547,11 @@ int emx_chain_in_plane_fwd(const float* lengths, const float* angles, int lda, i
 int emx_chain_in_plane_bwd(const float* lengths, const float* angles, int lda, const float* dxyz, int B, int A, float* dangles, int ldd,
                            emx_stream_t stream) {
   EMX_REQUIRE(lengths && angles && dxyz && dangles && B > 0 && A >= 3 && (lda >= A - 2 || lda == 0) && ldd >= A - 2, "emx_chain_in_plane_bwd: bad arguments");
+  if ((size_t)A * sizeof(float) <= 48 * 1024) {
+    hipLaunchKernelGGL(chain_bwd_frame_kernel, dim3(B), dim3(64), (size_t)A * sizeof(float), (hipStream_t)stream, lengths, angles, lda, dxyz, A,
+                       dangles, ldd);
+    return emx::check_launch("chain_bwd_frame_kernel");
+  }
   hipLaunchKernelGGL(chain_bwd_kernel, dim3((B + NT - 1) / NT), dim3(NT), 0, (hipStream_t)stream, lengths, angles, lda, dxyz, B, A, dangles,
                      ldd);
   return emx::check_launch("chain_bwd_kernel");
