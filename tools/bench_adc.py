@@ -1,5 +1,5 @@
 """Step time of the ADC model (SURVEY.md section 8d, C3b shape: 76 residues = 228 backbone atoms, B=256, pair distances
-of every third atom, cartesian distance cost) on one GPU.   python tools/bench_adc.py [n_residues] [batch]"""
+of every third atom, cartesian distance cost) on one GPU.   python tools/bench_adc.py [n_residues] [batch] [--angles] [--metrics]"""
 import os
 import sys
 import time
@@ -12,8 +12,9 @@ sys.path.insert(0, ROOT)
 import encodermap_amd as em  # noqa: E402
 from encodermap_amd.features import featurize_backbone  # noqa: E402
 
-n_res = int(sys.argv[1]) if len(sys.argv) > 1 else 76
-B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+n_res = int(pos[0]) if len(pos) > 0 else 76
+B = int(pos[1]) if len(pos) > 1 else 256
 N = 20000
 A = 3 * n_res
 rng = np.random.default_rng(3)
@@ -24,7 +25,7 @@ xyz = np.cumsum(1.4 * step, axis=1).astype(np.float32)
 cv = featurize_backbone(xyz)
 p = em.ADCParameters(n_steps=4000, batch_size=B, cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5),
                      dihedral_cost_reference=1.5, angle_cost_reference=0.3, cartesian_cost_reference=8.0, track_clashes="--metrics" in sys.argv,
-                     track_RMSD="--metrics" in sys.argv)
+                     track_RMSD="--metrics" in sys.argv, use_backbone_angles="--angles" in sys.argv)
 m = em.AngleDihedralCartesianEncoderMap(cv, p, read_only=True)
 eng = m._engine
 eng.run_steps(20)
@@ -34,4 +35,4 @@ t0 = time.perf_counter()
 eng.run_steps(steps)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print(f"ADC {n_res} residues ({A} atoms), B={B}: {dt * 1e6:.1f} us/step, {B / dt:.3e} frames/s, loss {eng.losses()[-1]:.4f}")
+print(f"ADC {n_res} residues ({A} atoms), B={B}{', backbone angles' if '--angles' in sys.argv else ''}: {dt * 1e6:.1f} us/step, {B / dt:.3e} frames/s, loss {eng.losses()[-1]:.4f}")
