@@ -356,9 +356,12 @@ __global__ __launch_bounds__(NT) void d2c_bwd_kernel(const float* __restrict__ d
 // ---------------------------------------------------------------------------------------------------------
 #ifdef EMX_D2C_TIMING   // per-phase timeline of workgroup 0 (tools/abl_d2c.py)
 __device__ long long emx_dbg_d2c[64];
-#define DSTAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) emx_dbg_d2c[(BWD ? 32 : 0) + 8 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
+#define DSTAMP(k) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0 && threadIdx.x < (BWD ? 256 : 128)) emx_dbg_d2c[(BWD ? 32 : 0) + 8 * (threadIdx.x >> 6) + (k)] = clock64(); } while (0)
+__device__ long long emx_dbg_af[32];   // the fused frame passes (tools/abl_d2c.py): wave 0 of workgroup 0, forward 0.., backward 16..
+#define AFSTAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) emx_dbg_af[k] = clock64(); } while (0)
 #else
 #define DSTAMP(k)
+#define AFSTAMP(k)
 #endif
 template <int V>
 struct RingIdx {
@@ -813,11 +816,24 @@ __device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
   j = (int)(p - ((long)ii * C - (long)ii * (ii + 1) / 2)) + ii + 1;
 }
 
+// (32-bit form for frames whose pairs fit an int -- every frame that fits LDS: the 64-bit products and the divisions of the form
+//  above were a third of the pair loop)
+__device__ __forceinline__ void pair_decode_i(int p, int C, int& i, int& j) {
+  const float fc = (float)C - 0.5f;
+  int ii = (int)(fc - sqrtf(fmaxf(fc * fc - 2.f * (float)p, 0.f)));
+  ii = max(0, min(ii, C - 2));
+  while (ii > 0 && ((ii * (2 * C - ii - 1)) >> 1) > p) --ii;            // first pair of row ii: ii C - ii (ii + 1) / 2
+  while ((((ii + 1) * (2 * C - ii - 2)) >> 1) <= p) ++ii;
+  i = ii;
+  j = p - ((ii * (2 * C - ii - 1)) >> 1) + ii + 1;
+}
+
 // thread t of nt: the pairs t, t + nt, ... of the atoms s0 + st c held in sx ([*][3])
 __device__ __forceinline__ void pdist_pairs(const float* __restrict__ sx, int s0, int st, int C, long P, int ldo, float* __restrict__ o, int t, int nt) {
   for (long p = t; p < P; p += nt) {
     int i, j;
-    pair_decode(p, C, i, j);
+    if (P < (1L << 30)) pair_decode_i((int)p, C, i, j);
+    else pair_decode(p, C, i, j);
     const float* a = sx + 3 * (s0 + st * i);
     const float* c = sx + 3 * (s0 + st * j);
     const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
@@ -962,6 +978,7 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   __shared__ float red_n[AF_NT / 64], red_m[AF_NT / 64];
   const float* row = a.Y + b * a.ldy;
   const long P = (long)a.C * (a.C - 1) / 2;
+  AFSTAMP(0);
   // ---- PeriodicOutput; the input frame's selected atoms
   for (int k = tid; k < A - 2; k += AF_NT) {
     float v;
@@ -987,6 +1004,7 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
     }
   }
   __syncthreads();
+  AFSTAMP(1);
   // ---- chain_in_plane on wave 0; the other waves: pair distances of the input frame
   if (wave == 0) {
     chain_frame_body(a.mean_len, ang_l, A, phi, a.plane + b * A * 3, Pl, lane);
@@ -995,9 +1013,9 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   } else if (a.inp_pair) {
     // (pdist_pairs, and beside every distance the same pair of frame 0: the split works on the difference)
     float* o = a.inp_pair + b * a.ldo;
-    for (long p = tid - 64; p < P; p += AF_NT - 64) {
+    for (int p = tid - 64; p < (int)P; p += AF_NT - 64) {
       int i, j;
-      pair_decode(p, a.C, i, j);
+      pair_decode_i(p, a.C, i, j);
       const float* u = sxc + 3 * i;
       const float* w = sxc + 3 * j;
       const float dx = u[0] - w[0], dy = u[1] - w[1], dz = u[2] - w[2];
@@ -1010,12 +1028,16 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
     }
     for (long p = P + tid - 64; p < a.ldo; p += AF_NT - 64) o[p] = 0.f;
   }
+  AFSTAMP(2);
   __syncthreads();
+  AFSTAMP(3);
   // ---- dihedrals_to_cartesian
   d2c_frame_body<false, AF_NT>(dih_l, a.offset, Pl, nullptr, A, a.xyz + b * A * 3, Xl, nullptr, nullptr, fr);
   __syncthreads();
+  AFSTAMP(4);
   // ---- pair distances of the back-mapped frame
   pdist_pairs(Xl, a.start, a.step, a.C, P, a.ldo, a.out_pair + b * a.ldo, tid, AF_NT);
+  AFSTAMP(5);
   if (!split) return;
   // ---- sk_split_wide_kernel on the row of differences: its partition of the row over 1024 threads, its order of additions
   //      (a.split_wide; short rows: the order of emx::split_row, a wave per row)
@@ -1051,18 +1073,19 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   int E = (int)((__float_as_uint(mx) >> 23) & 0xff) - 126;   // (the scale rule of emx::split_row)
   E = mx > 0.f ? min(max(E, -100), 100) : 14;
   const float sc = __uint_as_float((uint32_t)(127 + 14 - E) << 23), rs = __uint_as_float((uint32_t)(127 - 14 + E) << 23);
-  for (int k = tid; k < a.sp.ld; k += AF_NT) {
-    const float v = k < (int)P ? vrow[k] * sc : 0.f;
-    const _Float16 h = (_Float16)v;
-    const _Float16 l = (_Float16)(v - (float)h);
+  for (int k = 2 * tid; k < a.sp.ld; k += 2 * AF_NT) {   // (ld is a multiple of 32: a pair never straddles a chunk)
+    const float v0 = k < (int)P ? vrow[k] * sc : 0.f, v1 = k + 1 < (int)P ? vrow[k + 1] * sc : 0.f;
+    const _Float16 h0 = (_Float16)v0, h1 = (_Float16)v1;
+    const _Float16 l0 = (_Float16)(v0 - (float)h0), l1 = (_Float16)(v1 - (float)h1);
     uint16_t* o = a.sp.planes + emx::split_index(a.sp, b, k);
-    o[0] = emx::f16_bits(h);
-    o[a.sp.plane_stride] = emx::f16_bits(l);
+    *reinterpret_cast<uint32_t*>(o) = (uint32_t)emx::f16_bits(h0) | ((uint32_t)emx::f16_bits(h1) << 16);
+    *reinterpret_cast<uint32_t*>(o + a.sp.plane_stride) = (uint32_t)emx::f16_bits(l0) | ((uint32_t)emx::f16_bits(l1) << 16);
   }
   if (tid == 0) {
     a.sp.norms[b] = nrm;
     a.sp.rscale[b] = rs;
   }
+  AFSTAMP(6);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1099,6 +1122,7 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdA
   float* sg = sx + 3 * a.C;       // [P] d cost / d pair distances
   float* dx = sg + P;             // [A][3] d cost / d xyz
   float* fr = dx + 3 * A;         // the frame kernel's buffers
+  AFSTAMP(16);
   {
     const float* X = a.xyz + b * A * 3;
     for (int e = tid; e < 3 * a.C; e += AF_NT) {
@@ -1138,11 +1162,15 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdA
     if (b == 0)   // unused scratch entries read as zero by the summing job
       for (int i = 4 * (int)gridDim.x + tid; i < EMX_REDUCE_WS; i += AF_NT) c.ws[i] = 0.f;
   }
+  AFSTAMP(17);
   // ---- pair distances, backward: d cost / d xyz of the frame
   pdist_bwd_body(sx, sg, A, a.start, a.step, a.C, dx, 0, a.T);
+  AFSTAMP(18);
   __syncthreads();
+  AFSTAMP(19);
   // ---- dihedrals_to_cartesian, backward
   d2c_frame_body<true, AF_NT>(a.dih + b * (A - 3), a.offset, a.plane + b * A * 3, dx, A, nullptr, nullptr, a.ddih + b * a.ldg, a.dplane + b * A * 3, fr);
+  AFSTAMP(20);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1722,6 +1750,7 @@ int emx_backbone_features(const float* xyz, int64_t N, int A, float* distances, 
 }
 
 #ifdef EMX_D2C_TIMING
+extern "C" int emx_debug_read_af(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_af), sizeof(emx_dbg_af)); }
 extern "C" int emx_debug_read_d2c(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg_d2c), sizeof(emx_dbg_d2c)); }
 #endif
 
