@@ -816,28 +816,55 @@ __device__ __forceinline__ void pair_decode(long p, int C, int& i, int& j) {
   j = (int)(p - ((long)ii * C - (long)ii * (ii + 1) / 2)) + ii + 1;
 }
 
-// (32-bit form for frames whose pairs fit an int -- every frame that fits LDS: the 64-bit products and the divisions of the form
-//  above were a third of the pair loop)
-__device__ __forceinline__ void pair_decode_i(int p, int C, int& i, int& j) {
-  const float fc = (float)C - 0.5f;
-  int ii = (int)(fc - sqrtf(fmaxf(fc * fc - 2.f * (float)p, 0.f)));
-  ii = max(0, min(ii, C - 2));
-  while (ii > 0 && ((ii * (2 * C - ii - 1)) >> 1) > p) --ii;            // first pair of row ii: ii C - ii (ii + 1) / 2
-  while ((((ii + 1) * (2 * C - ii - 2)) >> 1) <= p) ++ii;
-  i = ii;
-  j = p - ((ii * (2 * C - ii - 1)) >> 1) + ii + 1;
+// Pairs without a decode: row i of the strict upper triangle (C - 1 - i pairs) and row C - 2 - i (i + 1 pairs) together are C
+// slots, so slot s of the ceil((C - 1) / 2) x C rectangle is  f = s / C, c = s % C  ->  (i, j) = (f, f + 1 + c) for c < C - 1 - f,
+// else (C - 2 - f, C - 1 - f + c - (C - 1 - f) ...) of the mirrored row; the middle row (C even) has only its first part.  One
+// float multiply and a correction instead of a square root and two divergent search loops per pair.
+__device__ __forceinline__ bool pair_slot(int s, int C, float rC, int& i, int& j) {
+  int f = (int)(((float)s + 0.5f) * rC);
+  int c = s - f * C;
+  if (c < 0) {
+    --f;
+    c += C;
+  } else if (c >= C) {
+    ++f;
+    c -= C;
+  }
+  const int n0 = C - 1 - f;          // pairs of row f
+  if (c < n0) {
+    i = f;
+    j = f + 1 + c;
+    return true;
+  }
+  i = C - 2 - f;
+  j = i + 1 + (c - n0);
+  return i != f;                     // (the middle row is not its own mirror)
 }
+__device__ __forceinline__ int pair_slots(int C) { return ((C - 1 + 1) >> 1) * C; }
+__device__ __forceinline__ int pair_index(int i, int j, int C) { return ((i * (2 * C - i - 1)) >> 1) + (j - i - 1); }
 
-// thread t of nt: the pairs t, t + nt, ... of the atoms s0 + st c held in sx ([*][3])
+// thread t of nt: the pairs of the slots t, t + nt, ... of the atoms s0 + st c held in sx ([*][3])
 __device__ __forceinline__ void pdist_pairs(const float* __restrict__ sx, int s0, int st, int C, long P, int ldo, float* __restrict__ o, int t, int nt) {
-  for (long p = t; p < P; p += nt) {
-    int i, j;
-    if (P < (1L << 30)) pair_decode_i((int)p, C, i, j);
-    else pair_decode(p, C, i, j);
-    const float* a = sx + 3 * (s0 + st * i);
-    const float* c = sx + 3 * (s0 + st * j);
-    const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
-    o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
+  if (P < (1L << 30)) {
+    const float rC = 1.f / (float)C;
+    const int ns = pair_slots(C);
+    for (int s = t; s < ns; s += nt) {
+      int i, j;
+      if (!pair_slot(s, C, rC, i, j)) continue;
+      const float* a = sx + 3 * (s0 + st * i);
+      const float* c = sx + 3 * (s0 + st * j);
+      const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
+      o[pair_index(i, j, C)] = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
+  } else {
+    for (long p = t; p < P; p += nt) {
+      int i, j;
+      pair_decode(p, C, i, j);
+      const float* a = sx + 3 * (s0 + st * i);
+      const float* c = sx + 3 * (s0 + st * j);
+      const float dx = a[0] - c[0], dy = a[1] - c[1], dz = a[2] - c[2];
+      o[p] = sqrtf(dx * dx + dy * dy + dz * dz);
+    }
   }
   for (long p = P + t; p < ldo; p += nt) o[p] = 0.f;   // padding columns (row stride rounded up) stay zero
 }
@@ -1013,9 +1040,12 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs
   } else if (a.inp_pair) {
     // (pdist_pairs, and beside every distance the same pair of frame 0: the split works on the difference)
     float* o = a.inp_pair + b * a.ldo;
-    for (int p = tid - 64; p < (int)P; p += AF_NT - 64) {
+    const float rC = 1.f / (float)a.C;
+    const int ns = pair_slots(a.C);
+    for (int sl = tid - 64; sl < ns; sl += AF_NT - 64) {
       int i, j;
-      pair_decode_i(p, a.C, i, j);
+      if (!pair_slot(sl, a.C, rC, i, j)) continue;
+      const int p = pair_index(i, j, a.C);
       const float* u = sxc + 3 * i;
       const float* w = sxc + 3 * j;
       const float dx = u[0] - w[0], dy = u[1] - w[1], dz = u[2] - w[2];
