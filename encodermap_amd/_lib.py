@@ -79,7 +79,7 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
-    "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
     "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
@@ -405,6 +405,17 @@ class CostJob(C.Structure):
 def periodic_cost_batch(jobs, B, row_begin, row_end):
     """Several row-mean costs in one launch.  jobs: dicts with the keyword names of ``periodic_cost_fwd_bwd`` (y, off_sin, off_cos,
     periodic_output, target, n, periodicity, variant, coef, dY, ws, coef_scale, dpred_add); partials go to each job's ws."""
+    arr = _cost_jobs(jobs)
+    _check(load().emx_periodic_cost_batch(C.cast(arr, C.c_void_p), len(jobs), int(B), int(row_begin), int(row_end), _stream()),
+           "emx_periodic_cost_batch")
+
+
+def _void_p(arr):
+    return C.cast(arr, C.c_void_p)
+
+
+def _cost_jobs(jobs):
+    """the ``emx_cost_job`` array of a list of job dicts (see ``periodic_cost_batch``)"""
     arr = (CostJob * len(jobs))()
     for a, j in zip(arr, jobs):
         y, dY, add = j["y"], j.get("dY"), j.get("dpred_add")
@@ -415,8 +426,7 @@ def periodic_cost_batch(jobs, B, row_begin, row_end):
         a.target, a.ldt, a.n = _ptr(j["target"]), j["target"].stride(0), int(j["n"])
         a.periodicity, a.variant, a.coef = float(j["periodicity"]), VARIANTS[v] if isinstance(v, str) else int(v), float(j["coef"])
         a.coef_scale, a.dpred_add, a.dY, a.ws = _ptr(j.get("coef_scale")), _ptr(add), _ptr(dY), _ptr(j["ws"])
-    _check(load().emx_periodic_cost_batch(C.cast(arr, C.c_void_p), len(jobs), int(B), int(row_begin), int(row_end), _stream()),
-           "emx_periodic_cost_batch")
+    return arr
 
 
 def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):
@@ -624,14 +634,18 @@ def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih
            "emx_adc_frame_fwd")
 
 
-def adc_frame_bwd(out_pair, inp_pair, variant, coef, coef_scale, ws, xyz, dihedrals, offset, plane, start, step, C, ddihedrals, dplane):
-    """Cartesian cost + backward of the pair distances + backward of dihedrals_to_cartesian in one launch (emx_adc_frame_bwd)."""
+def adc_frame_bwd(out_pair, inp_pair, variant, coef, coef_scale, ws, xyz, dihedrals, offset, plane, start, step, C, ddihedrals, dplane,
+                  jobs=None):
+    """Cartesian cost + backward of the pair distances + backward of dihedrals_to_cartesian in one launch (emx_adc_frame_bwd);
+    ``jobs``: the job dicts of ``periodic_cost_batch`` to run behind it in the same launch."""
     B, A = xyz.shape[0], xyz.shape[1]
     assert out_pair.stride(0) == inp_pair.stride(0) and dihedrals.is_contiguous()
+    arr = _cost_jobs(jobs) if jobs else None
     _check(load().emx_adc_frame_bwd(_ptr(out_pair), _ptr(inp_pair), out_pair.stride(0), VARIANTS[variant] if isinstance(variant, str) else int(variant),
                                     float(coef), _ptr(coef_scale) if coef_scale is not None else None, _ptr(ws), _ptr(xyz), _ptr(dihedrals),
                                     float(offset), _ptr(plane), B, A, int(start), int(step), int(C), _ptr(ddihedrals), ddihedrals.stride(0),
-                                    _ptr(dplane), _stream()), "emx_adc_frame_bwd")
+                                    _ptr(dplane), _void_p(arr) if arr is not None else None, len(jobs) if jobs else 0, _stream()),
+           "emx_adc_frame_bwd")
 
 
 def pdist_flat_bwd(xyz, dout, start, step, C, dxyz, accumulate=False):

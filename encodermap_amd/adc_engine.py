@@ -94,6 +94,7 @@ class ADCEngine(SequentialEngine):
         self.ldp = _round4(self.P)
         self._fuse_frame = os.environ.get("EMX_ADC_FUSE_FRAME", "1") != "0"
         self._fuse_frame_bwd = self._fuse_frame
+        self._fuse_cost_jobs = self._fuse_frame
         self._init_common(col, p, device, weights, dp, use_graph, history_capacity)
 
     # ------------------------------------------------------------------------------------------
@@ -198,22 +199,27 @@ class ADCEngine(SequentialEngine):
             return False
         return True
 
-    def _frame_backward(self) -> bool:
-        """Cartesian cost, backward of the pair distances and of dihedrals_to_cartesian as one launch (emx_adc_frame_bwd);
-        False outside the shapes that pass is built for: the single stages follow."""
+    def _frame_backward(self, jobs=None) -> int:
+        """Cartesian cost, backward of the pair distances and of dihedrals_to_cartesian as one launch (emx_adc_frame_bwd), with the
+        angle-like cost ``jobs`` behind it in the same launch when they fit it.  Returns 0 outside the shapes that pass is built
+        for (the single stages follow), 1 when the pass ran, 2 when the jobs ran with it."""
         if not self._fuse_frame_bwd:
-            return False
+            return 0
         p = self.p
-        try:
-            _lib.adc_frame_bwd(self.out_pair, self.inp_pair, p.cartesian_cost_variant, 1.0 / float(p.cartesian_cost_reference), self.cart_scale,
-                               self.cost_ws_rows[0], self.xyz, self.dih_pred, math.pi, self.plane, self.pw_start, self.pw_step, self.C,
-                               self.ddih_cart, self.dplane)
-        except _lib.EmxError as exc:
-            if not exc.unsupported:
-                raise
-            self._fuse_frame_bwd = False
-            return False
-        return True
+        for with_jobs in ((True, False) if (jobs and self._fuse_cost_jobs) else (False,)):
+            try:
+                _lib.adc_frame_bwd(self.out_pair, self.inp_pair, p.cartesian_cost_variant, 1.0 / float(p.cartesian_cost_reference),
+                                   self.cart_scale, self.cost_ws_rows[0], self.xyz, self.dih_pred, math.pi, self.plane, self.pw_start,
+                                   self.pw_step, self.C, self.ddih_cart, self.dplane, jobs=jobs if with_jobs else None)
+                return 2 if with_jobs else 1
+            except _lib.EmxError as exc:
+                if not exc.unsupported:
+                    raise
+                if with_jobs:
+                    self._fuse_cost_jobs = False
+                else:
+                    self._fuse_frame_bwd = False
+        return 0
 
     # -- training metrics (ADCClashMetric / ADCRMSDMetric, callbacks/metrics.py:470-581) ------------------------------
     METRIC_WEIGHTS = (14.0067, 24.305, 24.305)   # metrics.py:63
@@ -291,17 +297,9 @@ class ADCEngine(SequentialEngine):
         # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
         if not self._fused_head:
             _lib.soft_start_scale(self.step, *soft, self.cart_scale)
-        if not self._frame_backward():
-            _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
-                                       1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
-                                       coef_scale=self.cart_scale)
-            _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
-            _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
-        if self.use_ang:
-            _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
-
         # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward): one
-        # launch for all of them (emx_periodic_cost_batch)
+        # launch for all of them (emx_periodic_cost_batch) -- or, without backbone angles in the model, none: they ride along with
+        # the frame backward pass (with them, chain_in_plane's backward lies between that pass and the angle cost)
         jobs = []
         for off, nn, col in self.parts:
             tgt = self.feat[:, off: off + nn]
@@ -320,7 +318,19 @@ class ADCEngine(SequentialEngine):
                              target=self.feat[:, self.off_ang: self.off_ang + self.n_ang], n=self.n_ang, periodicity=per,
                              variant=p.angle_cost_variant, coef=0.0 if sc is None else float(sc) / float(p.angle_cost_reference), dY=None,
                              ws=self.cost_ws_rows[self._row_of[T_ANG]]))
-        if self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS:
+        batchable = self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS
+        done = self._frame_backward(jobs if (batchable and not self.use_ang) else None)
+        if done == 0:
+            _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
+                                       1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
+                                       coef_scale=self.cart_scale)
+            _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
+            _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
+        if self.use_ang:
+            _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
+        if done == 2:
+            pass
+        elif batchable:
             _lib.periodic_cost_batch(jobs, B, 0, B)
         else:
             for j in jobs:

@@ -1135,6 +1135,11 @@ struct AdcFrameBwdArgs {
   float* ddih;             // [B, ldg]
   int ldg;
   float* dplane;           // [B, A, 3]
+  // optional: up to four row-mean costs on row b of other blocks (emx_periodic_cost_batch: the angle-like costs of the decoder output;
+  // one of them adds d cost / d dihedrals of this launch to its gradient), each the stand-alone launch's one-workgroup-per-row
+  // form -- 256 threads, here quarter j of the workgroup
+  emx::CostArgs job[EMX_MAX_COST_JOBS];
+  int n_jobs;
 };
 __host__ __device__ inline long adc_frame_bwd_floats(int A, int C) {
   return 3 * (long)C + (long)C * (C - 1) / 2 + 3 * (long)A + d2c_frame_floats(A, true);
@@ -1201,6 +1206,53 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdA
   // ---- dihedrals_to_cartesian, backward
   d2c_frame_body<true, AF_NT>(a.dih + b * (A - 3), a.offset, a.plane + b * A * 3, dx, A, nullptr, nullptr, a.ddih + b * a.ldg, a.dplane + b * A * 3, fr);
   AFSTAMP(20);
+  if (a.n_jobs == 0) return;
+  // ---- the row-mean costs of the batch launch on row b: periodic_cost_body with one workgroup of 256 threads per row, quarter
+  //      by quarter (d cost / d dihedrals of this row was written above: visible behind the barrier)
+  __syncthreads();
+  const int q = wave >> 2, t256 = tid & 255;
+  float lsum = 0.f;
+  auto run = [&](const emx::CostArgs& c) __attribute__((always_inline)) {
+    const float* yrow = c.y + b * c.ldy;
+    const float* trow = c.target + b * c.ldt;
+    float* drow = c.dY ? c.dY + b * c.ldy : nullptr;
+    const float* addrow = c.dpred_add ? c.dpred_add + b * c.n : nullptr;
+    const float gn = c.coef_scale ? c.gnorm * *c.coef_scale : c.gnorm;
+    for (int k = t256; k < c.n; k += 256) {
+      float sn, cs, delta, dd;
+      emx::cost_elem(c, yrow, trow, k, sn, cs, delta, dd);
+      float g;
+      if (c.variant == EMX_MEAN_ABS) {
+        lsum += fabsf(delta);
+        g = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+      } else {
+        lsum = fmaf(delta, delta, lsum);
+        g = 2.f * delta * dd;
+      }
+      emx::cost_store(c, drow, addrow, k, gn * g, sn, cs);
+    }
+  };
+  if (q == 0) run(a.job[0]);
+  else if (q == 1 && a.n_jobs > 1) run(a.job[1]);
+  else if (q == 2 && a.n_jobs > 2) run(a.job[2]);
+  else if (q == 3 && a.n_jobs > 3) run(a.job[3]);
+  lsum = emx::wave_sum(lsum);
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  auto finish = [&](const emx::CostArgs& c) __attribute__((always_inline)) {
+    if (t256 == 0) {
+      float r = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) r += red[wave + i];
+      c.ws[b] = r * c.gnorm * (c.coef_scale ? *c.coef_scale : 1.f);
+    }
+    if (b == 0)
+      for (int i = (int)gridDim.x + t256; i < EMX_REDUCE_WS; i += 256) c.ws[i] = 0.f;
+  };
+  if (q == 0) finish(a.job[0]);
+  else if (q == 1 && a.n_jobs > 1) finish(a.job[1]);
+  else if (q == 2 && a.n_jobs > 2) finish(a.job[2]);
+  else if (q == 3 && a.n_jobs > 3) finish(a.job[3]);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1707,7 +1759,7 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
 
 int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale, float* ws,
                       const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start, int step, int C,
-                      float* ddihedrals, int ldg, float* dplane, emx_stream_t stream) {
+                      float* ddihedrals, int ldg, float* dplane, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
   const char* who = "emx_adc_frame_bwd";
   EMX_REQUIRE(out_pair && inp_pair && ws && xyz && dihedrals && plane && ddihedrals && dplane && B > 0 && A >= 4 && ldg >= A - 3, "%s: bad arguments (A >= 4)", who);
   EMX_REQUIRE(C >= 2 && step >= 1 && start >= 0 && start + (long)step * (C - 1) < A, "%s: atom selection outside the frame", who);
@@ -1750,6 +1802,35 @@ int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int
   a.ddih = ddihedrals;
   a.ldg = ldg;
   a.dplane = dplane;
+  EMX_REQUIRE(n_jobs >= 0 && n_jobs <= EMX_MAX_COST_JOBS && (n_jobs == 0 || jobs), "%s: 0 .. %d cost jobs", who, EMX_MAX_COST_JOBS);
+  a.n_jobs = n_jobs;
+  for (int j = 0; j < n_jobs; ++j) {
+    const emx_cost_job& q = jobs[j];
+    EMX_REQUIRE(q.y && q.target && q.ws && q.n > 0 && q.ldt >= q.n, "%s: cost job %d: incomplete", who, j);
+    EMX_REQUIRE(q.variant >= EMX_MEAN_ABS && q.variant <= EMX_MEAN_NORM, "%s: cost job %d: variant %d not available", who, j, q.variant);
+    EMX_REQUIRE(q.ldy > 0 || !q.dY, "%s: cost job %d: a broadcast prediction (ldy == 0) cannot receive a gradient", who, j);
+    EMX_REQUIRE(q.off_sin >= 0 && (q.ldy == 0 || q.off_sin + q.n <= q.ldy) &&
+                    (!q.periodic_output || (q.off_cos >= 0 && (q.ldy == 0 || q.off_cos + q.n <= q.ldy) && std::isfinite(q.periodicity))),
+                "%s: cost job %d: column window outside the row", who, j);
+    for (int i = 0; i < j; ++i) EMX_REQUIRE(jobs[i].ws != q.ws, "%s: cost jobs %d and %d share their scratch", who, i, j);
+    EMX_REQUIRE(q.ws != ws, "%s: cost job %d shares its scratch with the cartesian cost", who, j);
+    // the stand-alone batch launch gives such a job one workgroup of 256 threads per row exactly when 128 <= n <= 512 (B <= 256 here)
+    if (q.variant == EMX_MEAN_NORM || q.n < 128 || q.n > 512)
+      return emx::fail(EMX_EUNSUPPORTED, "%s: cost job %d (n = %d, variant %d) is outside the fused pass (use emx_periodic_cost_batch)", who, j, q.n, q.variant);
+    emx::CostArgs& c = a.job[j];
+    c.y = q.y;
+    c.target = q.target;
+    c.dpred_add = q.dpred_add;
+    c.coef_scale = q.coef_scale;
+    c.dY = q.dY;
+    c.ws = q.ws;
+    c.loss = nullptr;
+    emx::fill_cost_scalars(c, B, q.n, q.ldy, q.ldt, q.off_sin, q.off_cos, q.periodic_output, q.periodicity, q.variant, q.coef);
+    c.row_begin = 0;
+    c.row_end = B;
+    c.prescale = 1;
+    c.wide = 1;
+  }
   hipLaunchKernelGGL(adc_frame_bwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
   return emx::check_launch("adc_frame_bwd_kernel");
 }

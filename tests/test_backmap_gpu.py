@@ -398,6 +398,32 @@ def test_adc_frame_backward_equals_its_stages(L, B, A, start, step, variant, sof
     assert torch.equal(ws0, ws1), f"cost shares: max difference {float((ws0 - ws1).abs().max())}"
     assert torch.equal(dd0, dd1), f"d dihedrals: max difference {float((dd0 - dd1).abs().max())}"
     assert torch.equal(dp0, dp1), f"d plane: max difference {float((dp0 - dp1).abs().max())}"
+    # ---- with the angle-like costs of the decoder output behind it in the same launch (emx_periodic_cost_batch's jobs; the dihedral
+    #      cost adds d cost / d dihedrals of the cartesian path to its own gradient)
+    n_dih, n_ang = A - 3, A - 2
+    if 128 <= n_dih <= 512:
+        from encodermap_amd.adc_engine import _Bcast
+        g = torch.Generator().manual_seed(A)
+        Y = torch.randn(B, 2 * n_dih + 3, generator=g).cuda()
+        feat = ((torch.rand(B, n_dih + n_ang, generator=g) - 0.5) * 6.0).cuda()
+        mean_ang = torch.full((1, n_ang), 2.0, device="cuda")
+
+        def jobs(dY, w1, w2, add):
+            return [dict(y=Y, off_sin=1, off_cos=1 + n_dih, periodic_output=True, target=feat[:, :n_dih], n=n_dih, periodicity=2 * PI, variant=variant,
+                         coef=0.7, dY=dY, ws=w1, dpred_add=add),
+                    dict(y=_Bcast(mean_ang), off_sin=0, off_cos=0, periodic_output=False, target=feat[:, n_dih:], n=n_ang, periodicity=2 * PI,
+                         variant="mean_abs", coef=0.3, dY=None, ws=w2)]
+        dY0, wa0, wb0 = nan(B, Y.shape[1]), nan(L.EMX_REDUCE_WS), nan(L.EMX_REDUCE_WS)
+        L.periodic_cost_batch(jobs(dY0, wa0, wb0, dd0), B, 0, B)
+        dY1, wa1, wb1, ws2, dd2, dp2 = nan(B, Y.shape[1]), nan(L.EMX_REDUCE_WS), nan(L.EMX_REDUCE_WS), nan(L.EMX_REDUCE_WS), nan(B, A - 3), nan(B, A, 3)
+        L.adc_frame_bwd(out, inp, variant, 1.0 / 8.0, scale, ws2, xyz, DIH, PI, plane, start, step, C, dd2, dp2, jobs=jobs(dY1, wa1, wb1, dd2))
+        torch.cuda.synchronize()
+        assert torch.equal(ws0, ws2) and torch.equal(dd0, dd2) and torch.equal(dp0, dp2)
+        cols = torch.zeros(Y.shape[1], dtype=torch.bool, device="cuda")
+        cols[1: 1 + 2 * n_dih] = True
+        assert torch.equal(dY0[:, cols], dY1[:, cols]), f"d cost / d output: max difference {float((dY0[:, cols] - dY1[:, cols]).abs().max())}"
+        assert torch.isnan(dY1[:, ~cols]).all()                               # (columns outside the job's windows are not touched)
+        assert torch.equal(wa0, wa1) and torch.equal(wb0, wb1)
 
 
 def test_adc_frame_backward_leaves_other_shapes_to_the_stages(L):
@@ -409,3 +435,13 @@ def test_adc_frame_backward_leaves_other_shapes_to_the_stages(L):
             L.adc_frame_bwd(z(b, P + 1), z(b, P + 1), variant, 1.0, None, z(L.EMX_REDUCE_WS), z(b, A, 3), z(b, A - 3), PI, z(b, A, 3), 0, 1, A,
                             z(b, A - 3), z(b, A, 3))
         assert err.value.unsupported
+    # a cost job of fewer than 128 columns runs a wave per row in the batch launch: not this pass
+    b, A2 = 8, 228
+    C2 = 76
+    P2 = C2 * (C2 - 1) // 2
+    with pytest.raises(L.EmxError) as err:
+        L.adc_frame_bwd(z(b, P2), z(b, P2), "mean_abs", 1.0, None, z(L.EMX_REDUCE_WS), z(b, A2, 3), z(b, A2 - 3), PI, z(b, A2, 3), 1, 3, C2,
+                        z(b, A2 - 3), z(b, A2, 3),
+                        jobs=[dict(y=z(b, 80), off_sin=0, off_cos=40, periodic_output=True, target=z(b, 40), n=40, periodicity=2 * PI,
+                                   variant="mean_abs", coef=1.0, dY=z(b, 80), ws=z(L.EMX_REDUCE_WS))])
+    assert err.value.unsupported
