@@ -79,7 +79,7 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
-    "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _i, _p]),
+    "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
@@ -635,16 +635,19 @@ def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih
 
 
 def adc_frame_bwd(out_pair, inp_pair, variant, coef, coef_scale, ws, xyz, dihedrals, offset, plane, start, step, C, ddihedrals, dplane,
-                  jobs=None):
+                  jobs=None, mean_lengths=None, angles=None, dangles=None):
     """Cartesian cost + backward of the pair distances + backward of dihedrals_to_cartesian in one launch (emx_adc_frame_bwd);
-    ``jobs``: the job dicts of ``periodic_cost_batch`` to run behind it in the same launch."""
+    ``angles`` (+ ``mean_lengths``, ``dangles``): chain_in_plane's backward pass behind it; ``jobs``: the job dicts of
+    ``periodic_cost_batch`` behind that, all in the same launch."""
     B, A = xyz.shape[0], xyz.shape[1]
-    assert out_pair.stride(0) == inp_pair.stride(0) and dihedrals.is_contiguous()
+    assert out_pair.stride(0) == inp_pair.stride(0) and dihedrals.is_contiguous() and (angles is None or angles.is_contiguous())
     arr = _cost_jobs(jobs) if jobs else None
     _check(load().emx_adc_frame_bwd(_ptr(out_pair), _ptr(inp_pair), out_pair.stride(0), VARIANTS[variant] if isinstance(variant, str) else int(variant),
                                     float(coef), _ptr(coef_scale) if coef_scale is not None else None, _ptr(ws), _ptr(xyz), _ptr(dihedrals),
                                     float(offset), _ptr(plane), B, A, int(start), int(step), int(C), _ptr(ddihedrals), ddihedrals.stride(0),
-                                    _ptr(dplane), _void_p(arr) if arr is not None else None, len(jobs) if jobs else 0, _stream()),
+                                    _ptr(dplane), _ptr(mean_lengths) if angles is not None else None, _ptr(angles) if angles is not None else None,
+                                    _ptr(dangles) if angles is not None else None, dangles.stride(0) if angles is not None else 0,
+                                    _void_p(arr) if arr is not None else None, len(jobs) if jobs else 0, _stream()),
            "emx_adc_frame_bwd")
 
 

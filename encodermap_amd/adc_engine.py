@@ -210,7 +210,8 @@ class ADCEngine(SequentialEngine):
             try:
                 _lib.adc_frame_bwd(self.out_pair, self.inp_pair, p.cartesian_cost_variant, 1.0 / float(p.cartesian_cost_reference),
                                    self.cart_scale, self.cost_ws_rows[0], self.xyz, self.dih_pred, math.pi, self.plane, self.pw_start,
-                                   self.pw_step, self.C, self.ddih_cart, self.dplane, jobs=jobs if with_jobs else None)
+                                   self.pw_step, self.C, self.ddih_cart, self.dplane, jobs=jobs if with_jobs else None,
+                                   mean_lengths=self.mean_len, angles=self.ang_pred if self.use_ang else None, dangles=self.dang_cart)
                 return 2 if with_jobs else 1
             except _lib.EmxError as exc:
                 if not exc.unsupported:
@@ -298,8 +299,8 @@ class ADCEngine(SequentialEngine):
         if not self._fused_head:
             _lib.soft_start_scale(self.step, *soft, self.cart_scale)
         # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward): one
-        # launch for all of them (emx_periodic_cost_batch) -- or, without backbone angles in the model, none: they ride along with
-        # the frame backward pass (with them, chain_in_plane's backward lies between that pass and the angle cost)
+        # launch for all of them (emx_periodic_cost_batch) -- or none: they ride along with the frame backward pass, behind
+        # chain_in_plane's backward pass when the model has backbone angles
         jobs = []
         for off, nn, col in self.parts:
             tgt = self.feat[:, off: off + nn]
@@ -319,14 +320,14 @@ class ADCEngine(SequentialEngine):
                              variant=p.angle_cost_variant, coef=0.0 if sc is None else float(sc) / float(p.angle_cost_reference), dY=None,
                              ws=self.cost_ws_rows[self._row_of[T_ANG]]))
         batchable = self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS
-        done = self._frame_backward(jobs if (batchable and not self.use_ang) else None)
+        done = self._frame_backward(jobs if batchable else None)
         if done == 0:
             _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
                                        1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],
                                        coef_scale=self.cart_scale)
             _lib.pdist_flat_bwd(self.xyz, self.dpair, self.pw_start, self.pw_step, self.C, self.dxyz, False)
             _lib.dihedrals_to_cartesian_bwd(self.dih_pred, math.pi, self.plane, self.dxyz, self.ddih_cart, self.dplane)
-        if self.use_ang:
+        if self.use_ang and done == 0:   # (the frame backward pass runs chain_in_plane's backward itself)
             _lib.chain_in_plane_bwd(self.mean_len, self.ang_pred, self.dplane, self.dang_cart)
         if done == 2:
             pass

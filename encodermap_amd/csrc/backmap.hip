@@ -1140,9 +1140,14 @@ struct AdcFrameBwdArgs {
   // form -- 256 threads, here quarter j of the workgroup
   emx::CostArgs job[EMX_MAX_COST_JOBS];
   int n_jobs;
+  // optional (models with backbone angles): chain_in_plane's backward pass on d cost / d plane of this launch, in front of the jobs
+  const float* len;        // [A - 1] mean bond lengths
+  const float* ang;        // [B, A - 2] angles (null: skipped)
+  float* dang;             // [B, ldd]
+  int ldd;
 };
 __host__ __device__ inline long adc_frame_bwd_floats(int A, int C) {
-  return 3 * (long)C + (long)C * (C - 1) / 2 + 3 * (long)A + d2c_frame_floats(A, true);
+  return 3 * (long)C + (long)C * (C - 1) / 2 + 3 * (long)A + d2c_frame_floats(A, true) + A;
 }
 static_assert(AF_NT == PD_NT, "the pair-distance bodies run on the whole workgroup");
 
@@ -1206,6 +1211,11 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdA
   // ---- dihedrals_to_cartesian, backward
   d2c_frame_body<true, AF_NT>(a.dih + b * (A - 3), a.offset, a.plane + b * A * 3, dx, A, nullptr, nullptr, a.ddih + b * a.ldg, a.dplane + b * A * 3, fr);
   AFSTAMP(20);
+  if (a.ang != nullptr) {
+    // ---- chain_in_plane, backward (one wave; d cost / d plane of this row was written above)
+    __syncthreads();
+    if (wave == 0) chain_bwd_body(a.len, a.ang + b * (A - 2), a.dplane + b * A * 3, A, fr + d2c_frame_floats(A, true), a.dang + b * a.ldd, lane);
+  }
   if (a.n_jobs == 0) return;
   // ---- the row-mean costs of the batch launch on row b: periodic_cost_body with one workgroup of 256 threads per row, quarter
   //      by quarter (d cost / d dihedrals of this row was written above: visible behind the barrier)
@@ -1759,8 +1769,10 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
 
 int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale, float* ws,
                       const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start, int step, int C,
-                      float* ddihedrals, int ldg, float* dplane, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
+                      float* ddihedrals, int ldg, float* dplane, const float* mean_lengths, const float* angles, float* dangles, int ldd,
+                      const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
   const char* who = "emx_adc_frame_bwd";
+  EMX_REQUIRE(!angles || (mean_lengths && dangles && ldd >= A - 2), "%s: chain_in_plane's backward pass needs the mean lengths and dangles [B, >= A-2]", who);
   EMX_REQUIRE(out_pair && inp_pair && ws && xyz && dihedrals && plane && ddihedrals && dplane && B > 0 && A >= 4 && ldg >= A - 3, "%s: bad arguments (A >= 4)", who);
   EMX_REQUIRE(C >= 2 && step >= 1 && start >= 0 && start + (long)step * (C - 1) < A, "%s: atom selection outside the frame", who);
   const long P = (long)C * (C - 1) / 2;
@@ -1802,6 +1814,10 @@ int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int
   a.ddih = ddihedrals;
   a.ldg = ldg;
   a.dplane = dplane;
+  a.len = mean_lengths;
+  a.ang = angles;
+  a.dang = dangles;
+  a.ldd = ldd;
   EMX_REQUIRE(n_jobs >= 0 && n_jobs <= EMX_MAX_COST_JOBS && (n_jobs == 0 || jobs), "%s: 0 .. %d cost jobs", who, EMX_MAX_COST_JOBS);
   a.n_jobs = n_jobs;
   for (int j = 0; j < n_jobs; ++j) {

@@ -477,16 +477,18 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
  * models.py:3392-3393).  Equal, value for value, to emx_periodic_cost_fwd_bwd (loss NULL: its prescaled workgroup shares in
  * ws [EMX_REDUCE_WS]) + emx_pdist_flat_bwd + emx_dihedrals_to_cartesian_bwd; d cost / d pair distances and d cost / d xyz
  * stay on the chip.  Written: ws, ddihedrals [B, A-3] (stride ldg), dplane [B, A, 3].
+ * angles [B, A-2] (may be NULL; models with backbone angles): additionally emx_chain_in_plane_bwd(mean_lengths, angles, dplane)
+ * -> dangles [B, A-2] (stride ldd) behind the back-mapping's backward pass, in the same launch.
  * jobs (n_jobs 0 .. EMX_MAX_COST_JOBS, may be NULL): additionally emx_periodic_cost_batch(jobs, n_jobs, B, 0, B) behind it, in
  * the same launch -- the angle-like costs of the decoder output (models.py:2260-2521); a job's dpred_add may be `ddihedrals`
- * (the gradient of the cartesian path joins the dihedral cost's, written by this launch).  Jobs of 128 .. 512 columns, not
+ * or `dangles` (the gradient of the cartesian path joins the cost's, written by this launch).  Jobs of 128 .. 512 columns, not
  * EMX_MEAN_NORM (else EMX_EUNSUPPORTED: call without jobs and emx_periodic_cost_batch).
  * EMX_EUNSUPPORTED outside the shapes the pass is built for (B <= EMX_REDUCE_WS / 4 frames, more than 1536 pair distances
  * per frame, not EMX_MEAN_NORM, a frame that fits LDS): the single stages remain. */
 int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale,
                       float* ws, const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A,
-                      int start, int step, int C, float* ddihedrals, int ldg, float* dplane, const emx_cost_job* jobs, int n_jobs,
-                      emx_stream_t stream);
+                      int start, int step, int C, float* ddihedrals, int ldg, float* dplane, const float* mean_lengths,
+                      const float* angles, float* dangles, int ldd, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream);
 
 /* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
  *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,

@@ -398,6 +398,14 @@ def test_adc_frame_backward_equals_its_stages(L, B, A, start, step, variant, sof
     assert torch.equal(ws0, ws1), f"cost shares: max difference {float((ws0 - ws1).abs().max())}"
     assert torch.equal(dd0, dd1), f"d dihedrals: max difference {float((dd0 - dd1).abs().max())}"
     assert torch.equal(dp0, dp1), f"d plane: max difference {float((dp0 - dp1).abs().max())}"
+    # ---- with chain_in_plane's backward pass behind it (models with backbone angles)
+    da0, da3, dd3, dp3, ws3 = nan(B, A - 2), nan(B, A - 2), nan(B, A - 3), nan(B, A, 3), nan(L.EMX_REDUCE_WS)
+    L.chain_in_plane_bwd(mean_len, ANG, dp0, da0)
+    L.adc_frame_bwd(out, inp, variant, 1.0 / 8.0, scale, ws3, xyz, DIH, PI, plane, start, step, C, dd3, dp3, mean_lengths=mean_len, angles=ANG,
+                    dangles=da3)
+    torch.cuda.synchronize()
+    assert torch.equal(ws0, ws3) and torch.equal(dd0, dd3) and torch.equal(dp0, dp3)
+    assert torch.equal(da0, da3), f"d angles: max difference {float((da0 - da3).abs().max())}"
     # ---- with the angle-like costs of the decoder output behind it in the same launch (emx_periodic_cost_batch's jobs; the dihedral
     #      cost adds d cost / d dihedrals of the cartesian path to its own gradient)
     n_dih, n_ang = A - 3, A - 2
