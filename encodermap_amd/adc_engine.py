@@ -48,7 +48,13 @@ class ADCEngine(SequentialEngine):
     def _jobs_pre(self) -> list:
         """The row-mean costs leave their workgroup shares in ``cost_ws`` (one row per term); the step's scalar epilogue adds
         them up.  The all-pairs costs write their terms themselves."""
-        return [(self.cost_ws_rows[k], _lib.EMX_REDUCE_WS, 1.0, None, slot, False) for k, slot in self._cost_rows]
+        jobs = [(self.cost_ws_rows[k], _lib.EMX_REDUCE_WS, 1.0, None, slot, False) for k, slot in self._cost_rows]
+        sk = self._sk_cart
+        if sk is not None:   # (the cartesian distance cost's tile shares and the center cost: see _step_pre)
+            Z = self.h[self.layout.n_enc - 1]
+            jobs.append((sk.tile_loss, sk.n_tiles, sk.loss_scale, None, T_CDIST, False))
+            jobs.append((Z.data_ptr(), self.B * self.L, sk.center_loss_scale, None, T_CENTER, True))
+        return jobs
 
     def _use_sketchmap(self) -> bool:
         return False   # the ADC step reduces its two all-pairs costs with emx_sketchmap_fwd_bwd
@@ -131,6 +137,17 @@ class ADCEngine(SequentialEngine):
         self._cost_rows = [(0, T_CART), (1, T_DIH), (2, T_ANG)] + ([(3, T_SIDE)] if self.S else [])
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, B), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
+        # The cartesian distance cost's O(B) reduction -- tile partials -> d cost / d z and the cost itself -- rides along with the
+        # dense layers' backward launch (the latent join of emx_mlp_backward) and the step's scalar epilogue, as in the EncoderMap
+        # step, instead of a launch of its own (emx_sketchmap_finish).  Not with the second all-pairs cost switched on: it reuses
+        # the tile workspace.  EMX_ADC_JOIN_LATENT=0: the stand-alone reduction.
+        p = self.p
+        self._sk_cart = None
+        if p.cartesian_distance_cost_scale is not None and p.distance_cost_scale is None and os.environ.get("EMX_ADC_JOIN_LATENT", "1") != "0":
+            cs = p.center_cost_scale
+            self._sk_cart = _lib.sketchmap_describe(self.inp_pair[:, :self.P], self.h[lay.n_enc - 1], INF, p.cartesian_dist_sig_parameters,
+                                                    float(p.cartesian_distance_cost_scale), float(cs) if cs is not None else 0.0, 0, B,
+                                                    self.sk_ws)
 
     # -- data ------------------------------------------------------------------------------------------
     def set_data(self, angles, dihedrals, cartesians, distances, side_dihedrals=None) -> None:
@@ -348,8 +365,9 @@ class ADCEngine(SequentialEngine):
             if not self._fuse_frame:   # (the fused frame pass of this step has left the split rows)
                 _lib.sketchmap_split(self.inp_pair[:, :self.P], self.split_pair)
             _lib.sketchmap_tiles(self.inp_pair[:, :self.P], Z, INF, p.cartesian_dist_sig_parameters, 0, B, self.sk_ws, self.split_pair)
-            _lib.sketchmap_finish(B, self.P, Z, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0, 0, B,
-                                  t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
+            if self._sk_cart is None:
+                _lib.sketchmap_finish(B, self.P, Z, p.cartesian_dist_sig_parameters, float(cdc), float(cs) if cs is not None else 0.0, 0, B,
+                                      t[T_CDIST:T_CDIST + 1], t[T_CENTER:T_CENTER + 1], self.dZ, self.sk_ws)
         else:       # (the slot of a cost that is switched off is never written: it stays at its initial 0)
             _lib.center_cost_fwd_bwd(Z, float(cs) if cs is not None else 0.0, 0, B, t[T_CENTER:T_CENTER + 1], self.dZ, False)
         if p.distance_cost_scale is not None:
@@ -359,7 +377,10 @@ class ADCEngine(SequentialEngine):
                                    t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws,
                                    data_span=2.0 * np.pi)   # angles in [0, pi], torsions in (-pi, pi], both made on the device
             self.dZ.add_(self.dZ2)
-        _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
+        if self._sk_cart is not None:
+            _lib.mlp_backward(self.plan, 0, n, self.dY, None, lay.n_enc - 1, 0, B, latent=self._sk_cart.grad)
+        else:
+            _lib.mlp_backward(self.plan, 0, n, self.dY, self.dZ, lay.n_enc - 1, 0, B)
         self._wgrad()
 
     # -- cost references (train_for_references, autoencoder.py:1816-1937) -----------------------------------------
