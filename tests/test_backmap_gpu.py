@@ -49,7 +49,10 @@ def test_colmean(L):
         np.testing.assert_allclose(out.cpu().numpy(), x.astype(np.float64).mean(0), rtol=2e-6, atol=2e-6)
 
 
-@pytest.mark.parametrize("B,A", [(5, 4), (33, 7), (64, 24), (256, 228), (16, 457), (3, 1100)])   # 1100: beyond the LDS frame kernels
+# (5, 6: the smallest chains; 65, 66, 129, 132, 133: the steps of a part / of the plane chain end exactly at, one before and one
+#  behind a multiple of the 64 lanes the scans run over; 1100: nine steps per lane)
+@pytest.mark.parametrize("B,A", [(5, 4), (6, 5), (7, 6), (33, 7), (64, 24), (9, 65), (9, 66), (8, 129), (9, 132), (7, 133), (256, 228), (16, 457),
+                                 (3, 1100)])
 def test_chain_in_plane_and_backmapping(L, B, A):
     rng = np.random.default_rng(A)
     lengths, angles, dih = make_chain(rng, B, A)
