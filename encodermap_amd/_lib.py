@@ -79,6 +79,8 @@ SIGNATURES = {
     "emx_dihedrals_to_cartesian_bwd": (_i, [_p, _i, _f, _p, _p, _i, _i, _p, _i, _p, _p]),
     "emx_pdist_flat_fwd": (_i, [_p, _i, _i, _i, _i, _i, _p, _i, _p]),
     "emx_pdist_flat_bwd": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p, _i, _p]),
+    "emx_adc_head_bytes": (_sz, []),
+    "emx_adc_head_describe": (_i, [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _i, _p, _f, _f, _f, _p, _p, _i, _p]),
     "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
@@ -115,15 +117,23 @@ class NextBatch(C.Structure):
     """Mirror of ``emx_next_batch``: the rows of batch cursor + 1, gathered beside the optimizer."""
 
     _fields_ = [("data", _p), ("n_rows", _l), ("D", _i), ("idx", _p), ("n_batches", _i), ("cursor", _p), ("B", _i), ("periodicity", _f),
-                ("xb", _p), ("xin", _p), ("split_ws", _p)]
+                ("xb", _p), ("xin", _p), ("split_ws", _p), ("adc_head", _p)]
 
 
 def make_next_batch(data, idx, cursor, B, periodicity, xb, xin, split_ws=None) -> NextBatch:
     N, D = data.shape
     assert idx.dtype == torch.int64 and idx.is_contiguous() and data.is_contiguous() and idx.numel() % B == 0
     nb = NextBatch(_ptr(data), N, D, _ptr(idx), idx.numel() // B, _ptr(cursor), int(B), float(periodicity), _ptr(xb), _ptr(xin),
-                   _ptr(split_ws))
+                   _ptr(split_ws), None)
     nb.keep = (data, idx, cursor, xb, xin, split_ws)
+    return nb
+
+
+def make_next_adc_head(record, idx, cursor, B, mean_columns) -> NextBatch:
+    """The head of the next ADC step beside the optimizer: ``record`` from ``adc_head_describe`` (a uint8 device tensor)."""
+    assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.numel() % B == 0
+    nb = NextBatch(None, 0, int(mean_columns), _ptr(idx), idx.numel() // B, _ptr(cursor), int(B), 0.0, None, None, None, _ptr(record))
+    nb.keep = (record, idx, cursor)
     return nb
 
 
@@ -673,6 +683,24 @@ def adc_batch_head(feat_data, cart_data, idx, cursor, B, feat, cart, parts, peri
                                      arr(0), arr(1), arr(2), n, float(periodicity), _ptr(xin), xin.stride(0), _ptr(step), float(soft_a),
                                      float(soft_b), float(scale_c), _ptr(cart_scale), _ptr(feat_mean) if feat_mean is not None else None,
                                      _stream()), "emx_adc_batch_head")
+
+
+def adc_head_describe(feat_data, cart_data, B, feat, cart, parts, periodicity, xin, step, soft_a, soft_b, scale_c, cart_scale, feat_mean,
+                      n_batches) -> torch.Tensor:
+    """The device record of ``adc_batch_head``'s description (emx_adc_head_describe) for ``make_next_adc_head``."""
+    N, F = feat_data.shape
+    C3 = cart_data.shape[1]
+    n = len(parts)
+    arr = lambda k: (C.c_int * n)(*[int(p[k]) for p in parts])
+    # (no fill kernel: it would run on torch's current stream, possibly BEHIND the blocking copy of emx_adc_head_describe)
+    rec = torch.empty(int(load().emx_adc_head_bytes()), dtype=torch.uint8, device=feat_data.device)
+    torch.cuda.current_stream(feat_data.device).synchronize()
+    _check(load().emx_adc_head_describe(_ptr(feat_data), _ptr(cart_data), N, F, C3, int(B), _ptr(feat), _ptr(cart), arr(0), arr(1), arr(2), n,
+                                        float(periodicity), _ptr(xin), xin.stride(0), _ptr(step), float(soft_a), float(soft_b), float(scale_c),
+                                        _ptr(cart_scale), _ptr(feat_mean) if feat_mean is not None else None, int(n_batches), _ptr(rec)),
+           "emx_adc_head_describe")
+    rec.keep = (feat_data, cart_data, feat, cart, xin, step, cart_scale, feat_mean)
+    return rec
 
 
 def allatom_mask_words(A):

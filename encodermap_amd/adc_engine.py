@@ -38,7 +38,10 @@ def _round4(n: int) -> int:
 
 
 class ADCEngine(SequentialEngine):
-    _prefetch = False   # the feature block is assembled inside the step (gather + featurisation)
+    # The head of step t + 1 (batch rows, encoder input, soft-start scale, batch means) runs on workgroups of the optimizer launch
+    # of step t, as the row gather of the EncoderMap step does (emx_next_batch::adc_head); EMX_ADC_PREFETCH_HEAD=0 or the single
+    # launches of EMX_ADC_HEAD=0: a launch at the head of every step.
+    _prefetch = os.environ.get("EMX_ADC_HEAD", "1") != "0" and os.environ.get("EMX_ADC_PREFETCH_HEAD", "1") != "0"
     _fused_head = os.environ.get("EMX_ADC_HEAD", "1") != "0"   # gathers + sin/cos + soft start in one launch (A/B switch)
     _batched_costs = os.environ.get("EMX_ADC_COST_BATCH", "1") != "0"   # the angle-like costs in one launch (A/B switch)
 
@@ -195,6 +198,28 @@ class ADCEngine(SequentialEngine):
         _lib.chain_in_plane_fwd(mean_len, _Bcast(ang_pred) if not self.use_ang else ang_pred, plane)
         _lib.dihedrals_to_cartesian_fwd(dih_pred, math.pi, plane, xyz)
 
+    def _soft_start(self):
+        p = self.p
+        a, b = p.cartesian_cost_scale_soft_start if p.cartesian_cost_scale_soft_start is not None else (None, None)
+        c = p.cartesian_cost_scale
+        return (-1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b, 0.0 if c is None else float(c))
+
+    def _gather_current(self) -> None:
+        """the head of the step under the cursor as a launch of its own (head of an index block; afterwards the optimizer launch of
+        every step does the head of the next one)"""
+        _lib.adc_batch_head(self.data, self.data_cart, self.idx_block, self.cursor, self.B, self.feat, self.cart.view(self.B, -1), self.parts,
+                            self.periodicity, self.xin, self.step, *self._soft_start(), self.cart_scale,
+                            feat_mean=self.feat_mean if self._fuse_frame else None)
+
+    def _next_batch(self):
+        key = (self.data.data_ptr(), self.data_cart.data_ptr(), self.idx_block.data_ptr(), self.idx_block.numel(), self.feat.data_ptr())
+        if getattr(self, "_head_key", None) != key:
+            self._head_record = _lib.adc_head_describe(self.data, self.data_cart, self.B, self.feat, self.cart.view(self.B, -1), self.parts,
+                                                       self.periodicity, self.xin, self.step, *self._soft_start(), self.cart_scale,
+                                                       self.feat_mean if self._fuse_frame else None, self.idx_block.numel() // self.B)
+            self._head_key = key
+        return _lib.make_next_adc_head(self._head_record, self.idx_block, self.cursor, self.B, self.F if self._fuse_frame else 0)
+
     def _frame_forward(self, Y: torch.Tensor) -> bool:
         """PeriodicOutput, BackMapLayer and both pair-distance blocks of the step as one launch (emx_adc_frame_fwd) behind the
         batch means; False when the frame does not fit the fused pass (or EMX_ADC_FUSE_FRAME=0): the single stages follow."""
@@ -296,7 +321,9 @@ class ADCEngine(SequentialEngine):
         a, b = p.cartesian_cost_scale_soft_start if p.cartesian_cost_scale_soft_start is not None else (None, None)
         c = p.cartesian_cost_scale
         soft = (-1.0 if (a is None or b is None) else a, -1.0 if (a is None or b is None) else b, 0.0 if c is None else float(c))
-        if self._fused_head:
+        if self._prefetch:
+            pass   # (done beside the optimizer of the step in front, or by _gather_current at the head of an index block)
+        elif self._fused_head:
             # batch rows, encoder input, the soft-start scale of this step and the batch means of the feature columns in one launch
             _lib.adc_batch_head(self.data, self.data_cart, self.idx_block, self.cursor, B, self.feat, self.cart.view(B, -1), self.parts, per,
                                 self.xin, self.step, *soft, self.cart_scale, feat_mean=self.feat_mean if self._fuse_frame else None)

@@ -17,6 +17,7 @@
 // "(x - o) @ R(u, -d)" equals the usual right-handed rotation by +d about u acting on column vectors.
 // The backward pass walks the chain in reverse, recovering A_{i-1} = A_i o N_i^{-1} instead of storing it, and
 // accumulates the adjoints of the transform, of the dihedral and of the planar coordinates.
+#include "adc_head.h"
 #include "cost.h"
 #include "emx_common.h"
 #include "split.h"
@@ -1389,86 +1390,17 @@ __global__ void soft_start_kernel(const int64_t* __restrict__ step, float a, flo
 
 // The head of an ADC step in one launch: the batch's feature rows and Cartesian rows by index, the sin/cos encoder input of
 // the angular blocks, and the soft-start scale of this step (a workgroup per row; thread 0 of the launch does the scalar).
-struct AdcHeadArgs {
-  const float* feat_data;
-  const float* cart_data;
-  const int64_t* idx;
-  const int64_t* cursor;
-  float* feat;
-  float* cart;
-  float* xin;
-  int B, F, C3, ld_xin, n_parts;
-  int off[4], n[4], col[4];
-  float ang_scale;
-  const int64_t* step;
-  float soft_a, soft_b, scale_c;
-  float* cart_scale;
-  float* feat_mean;   // [F] batch means of the feature columns (null: not wanted)
-  int row_blocks;     // workgroups that copy rows; those behind them take NT / CM_PH columns of the means each
-};
-
-__global__ __launch_bounds__(NT) void adc_head_kernel(const AdcHeadArgs a) {
+__global__ __launch_bounds__(NT) void adc_head_kernel(const emx::AdcHeadArgs a) {
+  const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
   if (blockIdx.x >= a.row_blocks) {
-    // emx_colmean of the batch's feature rows, read through the index (the row copies of this launch are not waited for): the
-    // partition of colmean_kernel -- 16 row phases of 4 interleaved sums -- and its order of additions, 16 columns per workgroup
-    __shared__ float part[CM_PH][NT / CM_PH];
-    constexpr int CW = NT / CM_PH;   // columns per workgroup: a thread per (column, phase)
-    const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
-    const int cl = threadIdx.x % CW, ph = threadIdx.x / CW, c = (blockIdx.x - a.row_blocks) * CW + cl;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (c < a.F) {
-      int b = ph;
-      for (; b + 3 * CM_PH < a.B; b += 4 * CM_PH) {
-        const long r0 = idx[b], r1 = idx[b + CM_PH], r2 = idx[b + 2 * CM_PH], r3 = idx[b + 3 * CM_PH];
-        s0 += a.feat_data[r0 * a.F + c];
-        s1 += a.feat_data[r1 * a.F + c];
-        s2 += a.feat_data[r2 * a.F + c];
-        s3 += a.feat_data[r3 * a.F + c];
-      }
-      for (; b < a.B; b += CM_PH) s0 += a.feat_data[idx[b] * a.F + c];
-    }
-    part[ph][cl] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (ph == 0 && c < a.F) {
-      float t = 0.f;
-#pragma unroll
-      for (int q = 0; q < CM_PH; q += 4) t += (part[q][cl] + part[q + 1][cl]) + (part[q + 2][cl] + part[q + 3][cl]);
-      a.feat_mean[c] = t / (float)a.B;
-    }
+    // emx_colmean of the batch's feature rows, read through the index (the row copies of this launch are not waited for)
+    __shared__ float part[emx::ADC_CM_PH][NT / emx::ADC_CM_PH];
+    emx::adc_head_means<NT / emx::ADC_CM_PH>(a, idx, (blockIdx.x - a.row_blocks) * (NT / emx::ADC_CM_PH), threadIdx.x, part);
     return;
-  }
-  if (a.cart_scale && blockIdx.x == 0 && threadIdx.x == 0) {
-    float sc = a.scale_c;
-    if (a.soft_a >= 0.f) {
-      const float t = (float)*a.step;
-      if (t < a.soft_a) sc = 0.f;
-      else if (t <= a.soft_b) sc = a.scale_c / (a.soft_b - a.soft_a) * (t - a.soft_a);
-    }
-    *a.cart_scale = sc;
   }
   // a workgroup per row: a few hundred columns per row and only a few hundred rows per batch -- a wave per row walks ~35
   // dependent iterations behind its three hops (cursor, index, row) while most of the chip idles
-  const int lane = threadIdx.x;
-  const int64_t* __restrict__ idx = a.idx + (a.cursor ? *a.cursor * (long)a.B : 0);
-  for (int b = blockIdx.x; b < a.B; b += a.row_blocks) {
-    const long row = idx[b];
-    const float* __restrict__ fs = a.feat_data + row * a.F;
-    const float* __restrict__ cs = a.cart_data + row * a.C3;
-    float* fd = a.feat + (long)b * a.F;
-    float* cd = a.cart + (long)b * a.C3;
-    for (int k = lane; k < a.F; k += NT) fd[k] = fs[k];
-    for (int k = lane; k < a.C3; k += NT) cd[k] = cs[k];
-    for (int p = 0; p < a.n_parts; ++p) {
-      float* xo = a.xin + (long)b * a.ld_xin + a.col[p];
-      const int n = a.n[p];
-      for (int k = lane; k < n; k += NT) {
-        float sn, cn;
-        emx::sincos_bounded(fs[a.off[p] + k] * a.ang_scale, &sn, &cn);
-        xo[k] = sn;
-        xo[n + k] = cn;
-      }
-    }
-  }
+  emx::adc_head_rows(a, idx, blockIdx.x, a.row_blocks, threadIdx.x);
 }
 
 }  // namespace
@@ -1903,18 +1835,18 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
   return emx::check_launch("soft_start_kernel");
 }
 
-int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
-                       int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
-                       float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
-                       float* cart_scale, float* feat_mean, emx_stream_t stream) {
-  EMX_REQUIRE(feat_data && cart_data && idx && feat && cart && xin, "emx_adc_batch_head: null pointer argument");
-  EMX_REQUIRE(N > 0 && F > 0 && C3 > 0 && B > 0 && n_parts >= 1 && n_parts <= 4 && part_off && part_n && part_col, "emx_adc_batch_head: bad shape");
-  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "emx_adc_batch_head: the angular blocks need a finite periodicity");
-  EMX_REQUIRE(!cart_scale || (step && (soft_a < 0.f || soft_b > soft_a)), "emx_adc_batch_head: soft start needs the step counter and b > a");
-  AdcHeadArgs a{};
+namespace {
+int fill_adc_head(emx::AdcHeadArgs& a, const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
+                  int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts, float periodicity, float* xin,
+                  int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c, float* cart_scale, float* feat_mean, const char* who) {
+  EMX_REQUIRE(feat_data && cart_data && feat && cart && xin, "%s: null pointer argument", who);
+  EMX_REQUIRE(N > 0 && F > 0 && C3 > 0 && B > 0 && n_parts >= 1 && n_parts <= 4 && part_off && part_n && part_col, "%s: bad shape", who);
+  EMX_REQUIRE(std::isfinite(periodicity) && periodicity > 0.f, "%s: the angular blocks need a finite periodicity", who);
+  EMX_REQUIRE(!cart_scale || (step && (soft_a < 0.f || soft_b > soft_a)), "%s: soft start needs the step counter and b > a", who);
+  a = emx::AdcHeadArgs{};
   for (int p = 0; p < n_parts; ++p) {
     EMX_REQUIRE(part_off[p] >= 0 && part_n[p] > 0 && part_off[p] + part_n[p] <= F && part_col[p] >= 0 && part_col[p] + 2 * part_n[p] <= ld_xin,
-                "emx_adc_batch_head: block %d outside the feature row or the encoder input", p);
+                "%s: block %d outside the feature row or the encoder input", who, p);
     a.off[p] = part_off[p];
     a.n[p] = part_n[p];
     a.col[p] = part_col[p];
@@ -1940,9 +1872,39 @@ int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N
   a.cart_scale = cart_scale;
   a.feat_mean = feat_mean;
   a.row_blocks = std::min(B, 2048);
+  return EMX_OK;
+}
+}  // namespace
+
+int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
+                       int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
+                       float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
+                       float* cart_scale, float* feat_mean, emx_stream_t stream) {
+  EMX_REQUIRE(idx, "emx_adc_batch_head: null pointer argument");
+  emx::AdcHeadArgs a;
+  int rc = fill_adc_head(a, feat_data, cart_data, N, F, C3, idx, cursor, B, feat, cart, part_off, part_n, part_col, n_parts, periodicity, xin, ld_xin,
+                         step, soft_a, soft_b, scale_c, cart_scale, feat_mean, "emx_adc_batch_head");
+  if (rc) return rc;
   const int grid = a.row_blocks + (feat_mean ? (F + NT / CM_PH - 1) / (NT / CM_PH) : 0);
   hipLaunchKernelGGL(adc_head_kernel, dim3(grid), dim3(NT), 0, (hipStream_t)stream, a);
   return emx::check_launch("adc_head_kernel");
+}
+
+size_t emx_adc_head_bytes(void) { return sizeof(emx::AdcHeadArgs); }
+
+int emx_adc_head_describe(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, int B, float* feat, float* cart,
+                          const int* part_off, const int* part_n, const int* part_col, int n_parts, float periodicity, float* xin, int ld_xin,
+                          const int64_t* step, float soft_a, float soft_b, float scale_c, float* cart_scale, float* feat_mean, int n_batches,
+                          void* record) {
+  EMX_REQUIRE(record && n_batches > 0, "emx_adc_head_describe: null record / no batches");
+  emx::AdcHeadArgs a;
+  int rc = fill_adc_head(a, feat_data, cart_data, N, F, C3, nullptr, nullptr, B, feat, cart, part_off, part_n, part_col, n_parts, periodicity, xin,
+                         ld_xin, step, soft_a, soft_b, scale_c, cart_scale, feat_mean, "emx_adc_head_describe");
+  if (rc) return rc;
+  a.n_batches = n_batches;
+  a.batch_step = 1;
+  if (hipMemcpy(record, &a, sizeof(a), hipMemcpyHostToDevice) != hipSuccess) return emx::fail(EMX_ELAUNCH, "emx_adc_head_describe: cannot write the record");
+  return EMX_OK;
 }
 
 int emx_clash_count(const float* xyz, int B, int A, float clash_distance, int64_t* counts, emx_stream_t stream) {

@@ -5,6 +5,7 @@
 #include "cost.h"
 #include "wop.h"
 #include "split.h"
+#include "adc_head.h"
 
 namespace {
 
@@ -84,6 +85,7 @@ struct GatherArgs {
   float* xb;
   float* xin;
   SplitRows split;    // optional (planes != null): f16 planes + norms of (row - row 0 of the batch) for the all-pairs kernel
+  const emx::AdcHeadArgs* adc_head;   // optional (optimizer launch only): the head of the NEXT ADC step instead of the row gather
 };
 
 // rows b = wave, wave + nwaves, ... of the batch
@@ -496,6 +498,22 @@ __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_h
     gl.idx = p_idx;
     gl.B = p_B;
     gl.batch_step = p_batch_step;
+    if (gl.adc_head != nullptr) {
+      // the head of the next ADC step (emx_adc_batch_head's work, adc_head.h): virtual workgroups of 256 threads for the rows (four
+      // of this launch's one-wave workgroups each), then workgroups of 4 columns x 16 row phases for the batch means
+      const emx::AdcHeadArgs& h = *gl.adc_head;
+      const long batch = *p_cursor + p_batch_step;
+      if (h.n_batches > 0 && batch >= h.n_batches) return;
+      const int64_t* __restrict__ idx = p_idx + batch * (long)p_B;
+      const int row_wgs = 4 * h.row_blocks;
+      if (gb < row_wgs) {
+        emx::adc_head_rows(h, idx, gb >> 2, h.row_blocks, (gb & 3) * 64 + (int)threadIdx.x);
+      } else if (h.feat_mean != nullptr) {
+        __shared__ float part[emx::ADC_CM_PH][4];
+        emx::adc_head_means<4>(h, idx, (gb - row_wgs) * 4, threadIdx.x, part);
+      }
+      return;
+    }
     if (p_next_vec4) gather_rows2_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     else gather_rows_body(gl, (gb * nt + threadIdx.x) >> 6, (ngb * nt) >> 6, threadIdx.x & 63);
     ASTAMP(41, p_adam_blocks);
@@ -870,11 +888,16 @@ inline bool gather_vec4(const emx_next_batch* next) {
 }
 inline int gather_blocks(const emx_next_batch* next) {   // two rows per wave, or one
   if (!next) return 0;
+  if (next->adc_head) return 4 * std::min(next->B, 2048) + (next->D + 3) / 4;   // (D: the feature columns whose means are wanted, 0: none)
   return (int)std::min<long>(gather_vec4(next) ? (next->B + 1) / 2 : next->B, 8192);
 }
 
 int check_next(const emx_next_batch* next, const char* who) {
   if (!next) return EMX_OK;
+  if (next->adc_head) {
+    EMX_REQUIRE(next->idx && next->cursor && next->B > 0 && next->n_batches > 0 && next->D >= 0, "%s: incomplete next-batch description (ADC head)", who);
+    return EMX_OK;
+  }
   EMX_REQUIRE(next->data && next->idx && next->cursor && (next->xb || next->xin), "%s: incomplete next-batch description", who);
   EMX_REQUIRE(next->n_rows > 0 && next->D > 0 && next->B > 0 && next->n_batches > 0, "%s: bad next-batch shape", who);
   EMX_REQUIRE(!next->xin || (std::isfinite(next->periodicity) && next->periodicity > 0.f), "%s: sin/cos rows need a finite periodicity", who);
@@ -897,7 +920,15 @@ AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, i
                    int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
                    const emx_mlp_desc* mirror_desc, float* mirror, const emx_next_batch* next = nullptr) {
   AdamArgs a{};
-  if (next) {
+  if (next && next->adc_head) {
+    a.next = GatherArgs{};
+    a.next.idx = next->idx;
+    a.next.cursor = next->cursor;
+    a.next.B = next->B;
+    a.next.batch_step = 1;
+    a.next.n_batches = next->n_batches;
+    a.next.adc_head = static_cast<const emx::AdcHeadArgs*>(next->adc_head);
+  } else if (next) {
     const bool periodic = next->xin != nullptr;
     a.next = GatherArgs{next->data, next->D, next->idx, next->cursor, next->B, 1, next->n_batches,
                         periodic ? (next->periodicity == TWO_PI ? 1.f : TWO_PI / next->periodicity) : 1.f, next->xb, next->xin, SplitRows{}};

@@ -436,10 +436,7 @@ class SequentialEngine:
         ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost, history and counters."""
         p = self.p
         reg_job = self._reg_job()
-        nxt = None
-        if self._prefetch:
-            nxt = _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
-                                       self.xin if self.periodic else None, self.split_ws)
+        nxt = self._next_batch() if self._prefetch else None
         if self._late_bookkeeping():
             _lib.adam_step_slices(self.w, self.wg_ws, _lib.mlp_wgrad_slices(self.re - self.rb), self.m, self.v, self.l2coef,
                                   p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt,
@@ -459,6 +456,11 @@ class SequentialEngine:
                                   p.learning_rate, 0.9, 0.999, 1e-7, 1.0, self.step, self.red_ws2, plan=self.plan, next_batch=nxt)
             jobs = self._jobs_pre() + [reg_job]
         _lib.finish_step(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+
+    def _next_batch(self):
+        """what the optimizer launch prepares for the next step on workgroups of its own (emx_next_batch): the rows of its batch"""
+        return _lib.make_next_batch(self.data, self.idx_block, self.cursor, self.B, self.periodicity if self.periodic else INF, self.xb,
+                                    self.xin if self.periodic else None, self.split_ws)
 
     def _sync_derived_state(self) -> None:
         """After the weights were written by anything but the optimizer: operand store and regulariser shares."""

@@ -243,6 +243,9 @@ typedef struct {
   float* xb;              /* may be NULL: [B, D] raw rows */
   float* xin;             /* may be NULL: [B, 2 D] = [sin | cos] */
   void* split_ws;         /* may be NULL: emx_sketchmap_split_bytes(B, D) bytes, the split rows of emx_sketchmap_split */
+  const void* adc_head;   /* may be NULL.  Else: the head of the next ADC step instead of the row gather -- the device record written
+                             by emx_adc_head_describe (what emx_adc_batch_head would do for batch *cursor + 1); of the fields above
+                             idx, n_batches, cursor, B are used, D = the feature columns whose batch means are wanted (0: none) */
 } emx_next_batch;
 
 /* ------------------------------------------------------------------------------------------------ *
@@ -542,6 +545,14 @@ int emx_soft_start_scale(const int64_t* step, float soft_a, float soft_b, float 
  *   feat_mean [F] = column means of the gathered feature rows (NULL: skipped)                  emx_colmean
  *     (mean bond lengths of BackMapLayer, layers.py:971; MeanAngles, layers.py:1153-1161)
  * -- the same numbers as those entry points, one launch instead of five. */
+/* emx_adc_batch_head's description as a device record (emx_adc_head_bytes() bytes at `record`, written with a blocking copy) for
+ * emx_next_batch::adc_head: the optimizer launch of step t then does the head of step t + 1 on workgroups of its own (the rows
+ * idx[(*cursor + 1) * B + b], skipped behind the index block), as it does the row gather of the EncoderMap step. */
+size_t emx_adc_head_bytes(void);
+int emx_adc_head_describe(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, int B, float* feat, float* cart,
+                          const int* part_off, const int* part_n, const int* part_col, int n_parts, float periodicity, float* xin,
+                          int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c, float* cart_scale,
+                          float* feat_mean, int n_batches, void* record);
 int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N, int F, int C3, const int64_t* idx, const int64_t* cursor,
                        int B, float* feat, float* cart, const int* part_off, const int* part_n, const int* part_col, int n_parts,
                        float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,

@@ -456,3 +456,48 @@ def test_adc_frame_backward_leaves_other_shapes_to_the_stages(L):
                         jobs=[dict(y=z(b, 80), off_sin=0, off_cos=40, periodic_output=True, target=z(b, 40), n=40, periodicity=2 * PI,
                                    variant="mean_abs", coef=1.0, dY=z(b, 80), ws=z(L.EMX_REDUCE_WS))])
     assert err.value.unsupported
+
+
+@pytest.mark.parametrize("B,with_means", [(37, True), (256, True), (64, False)])
+def test_adc_head_beside_the_optimizer(L, B, with_means):
+    """emx_next_batch::adc_head: the optimizer launch does the head of the NEXT ADC step (emx_adc_batch_head for batch cursor + 1) on
+    workgroups of its own -- rows, encoder input, soft-start scale, batch means: bit for bit; nothing is touched behind the last
+    batch of the index block, and the optimizer's own result does not depend on it."""
+    rng = np.random.default_rng(B)
+    N, A, S = 500, 21, 5
+    n_ang, n_dih, n_len = A - 2, A - 3, A - 1
+    F = n_ang + n_dih + S + n_len
+    feat_data = dev(rng.uniform(-3, 3, (N, F)))
+    cart_data = dev(rng.normal(0, 1, (N, 3 * A)))
+    n_batches = 4
+    idx = torch.from_numpy(rng.integers(0, N, n_batches * B)).cuda()
+    parts = [(0, n_ang, 0), (n_ang, n_dih, 2 * n_ang), (n_ang + n_dih, S, 2 * (n_ang + n_dih))]
+    W = 2 * (n_ang + n_dih + S)
+    soft = (6.0, 12.0, 1.0)
+    n = 3000
+    grad = torch.randn(n, device="cuda")
+    for cur in (1, n_batches - 1):
+        step = torch.tensor([9], dtype=torch.int64, device="cuda")
+        cursor = torch.tensor([cur], dtype=torch.int64, device="cuda")
+        feat, cart, xin = (torch.full((B, k), -7.0, device="cuda") for k in (F, 3 * A, W))
+        sc, mean = torch.full((1,), -7.0, device="cuda"), torch.full((F,), -7.0, device="cuda")
+        rec = L.adc_head_describe(feat_data, cart_data, B, feat, cart, parts, 2 * PI, xin, step, *soft, sc, mean if with_means else None, n_batches)
+        nxt = L.make_next_adc_head(rec, idx, cursor, B, F if with_means else 0)
+        w1, m1, v1 = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        w2, m2, v2 = torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+        ws = torch.zeros(L.EMX_REDUCE_WS, device="cuda")
+        L.adam_step(w1, grad, m1, v1, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws, next_batch=nxt)
+        L.adam_step(w2, grad, m2, v2, None, 1e-2, 0.9, 0.999, 1e-7, 1.0, step, None, ws)
+        torch.cuda.synchronize()
+        assert torch.equal(w1, w2) and torch.equal(m1, m2) and torch.equal(v1, v2)
+        if cur + 1 < n_batches:
+            feat2, cart2, xin2 = (torch.full((B, k), -7.0, device="cuda") for k in (F, 3 * A, W))
+            sc2, mean2 = torch.full((1,), -7.0, device="cuda"), torch.full((F,), -7.0, device="cuda")
+            L.adc_batch_head(feat_data, cart_data, idx, torch.tensor([cur + 1], device="cuda"), B, feat2, cart2, parts, 2 * PI, xin2, step, *soft, sc2,
+                             feat_mean=mean2 if with_means else None)
+            torch.cuda.synchronize()
+            assert torch.equal(feat, feat2) and torch.equal(cart, cart2) and torch.equal(xin, xin2) and torch.equal(sc, sc2)
+            assert torch.equal(mean, mean2)
+            assert torch.equal(feat, feat_data[idx[(cur + 1) * B: (cur + 2) * B]])
+        else:
+            assert float(feat.max()) == -7.0 and float(xin.max()) == -7.0 and float(mean.max()) == -7.0   # nothing behind the last batch

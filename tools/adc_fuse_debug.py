@@ -8,13 +8,14 @@ N, A = 1500, 3 * 76
 st = rng.normal(size=(N, A, 3)); st /= np.linalg.norm(st, axis=2, keepdims=True)
 cv = featurize_backbone(np.cumsum(1.4 * st, axis=1).astype(np.float32))
 def make(fuse):
-    os.environ["EMX_ADC_FUSE_FRAME"] = fuse
     p = em.ADCParameters(n_steps=300, batch_size=256, seed=5, cartesian_pwd_start=1, cartesian_pwd_step=3, use_backbone_angles=True,
                          cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5), cartesian_cost_scale_soft_start=(100, 200))
-    return em.AngleDihedralCartesianEncoderMap(cv, p, read_only=True)._engine
+    eng = em.AngleDihedralCartesianEncoderMap(cv, p, read_only=True)._engine
+    eng._prefetch = fuse == "1"
+    return eng
 e1, e0 = make("1"), make("0")
-names = ["feat", "cart", "feat_mean", "xin", "dih_pred", "ang_pred", "plane", "xyz", "inp_pair", "out_pair", "split_pair", "dpair", "dxyz", "dZ", "dY", "w"]
-for nsteps in (1, 1, 1):
+names = ["dih_pred", "ang_pred", "plane", "xyz", "inp_pair", "out_pair", "split_pair", "dpair", "dxyz", "dZ", "dY", "w"]
+for nsteps in (1, 2, 3):
     e1.run_steps(nsteps); e0.run_steps(nsteps)
     torch.cuda.synchronize()
     bad = [n for n in names if not torch.equal(getattr(e1, n), getattr(e0, n))]
