@@ -465,6 +465,9 @@ __device__ __forceinline__ float grad1(const AdamArgs& a, long i) {
 // (-amdgpu-kernarg-preload-count): a workgroup knows its role, and the pointers of its first loads -- the step counter, the
 // batch cursor -- without a trip to the argument segment; the plane's record (its address depends on the workgroup index
 // alone) is the only trip in front of an optimizer wave's operand loads, where the role fields used to be a first one.
+// (ADCH: the instantiation whose extra workgroups can do the head of the next ADC step, emx_next_batch::adc_head -- kept out of the
+//  other one, which the EncoderMap step waits for: the branch costs that launch 0.3 us even when it is not taken)
+template <bool ADCH>
 __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_hist, int p_next_vec4, int p_batch_step, const int64_t* p_step,
                                                   const char* p_mirror, const int64_t* p_cursor, const int64_t* p_idx, int p_B, int p_grid,
                                                   const AdamArgs a) {   // (p_grid = gridDim.x: the hidden argument would be a trip of its own)
@@ -498,7 +501,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_h
     gl.idx = p_idx;
     gl.B = p_B;
     gl.batch_step = p_batch_step;
-    if (gl.adc_head != nullptr) {
+    if constexpr (ADCH) {
       // the head of the next ADC step (emx_adc_batch_head's work, adc_head.h): virtual workgroups of 256 threads for the rows (four
       // of this launch's one-wave workgroups each), then workgroups of 4 columns x 16 row phases for the batch means
       const emx::AdcHeadArgs& h = *gl.adc_head;
@@ -911,10 +914,15 @@ inline int adam_grid(const AdamArgs& a, int64_t n) {
   return grid_for((n + 3) / 4, 64);
 }
 
-#define ADAM_LAUNCH(grid_, st_, a_)                                                                                                       \
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_), dim3(ADAM_NT), 0, st_, (a_).adam_blocks, (a_).hstep != nullptr ? 1 : 0, (a_).next_vec4,          \
+#define ADAM_LAUNCH_(K, grid_, st_, a_)                                                                                                   \
+  hipLaunchKernelGGL(K, dim3(grid_), dim3(ADAM_NT), 0, st_, (a_).adam_blocks, (a_).hstep != nullptr ? 1 : 0, (a_).next_vec4,                    \
                      (a_).next.batch_step, (a_).step, (const char*)(a_).mirror, (a_).next.cursor, (a_).next.idx, (a_).next.B, (int)(grid_),          \
                      a_)
+#define ADAM_LAUNCH(grid_, st_, a_)                                                                                                       \
+  do {                                                                                                                                    \
+    if ((a_).next.adc_head != nullptr) ADAM_LAUNCH_(adam_kernel<true>, grid_, st_, a_);                                                     \
+    else ADAM_LAUNCH_(adam_kernel<false>, grid_, st_, a_);                                                                                  \
+  } while (0)
 
 AdamArgs make_adam(float* w, const float* g, const float* gpart, int n_slices, int64_t gstride, float* m, float* v, const float* l2coef,
                    int64_t n, float lr, float beta1, float beta2, float eps, float clip, const int64_t* step, float* ws,
