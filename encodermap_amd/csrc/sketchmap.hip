@@ -1211,6 +1211,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       return EMX_OK;
     }
     if (a.L == 2 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 4>), dim3(grid), b);
+    else if (a.L == 2 && pl.fast && nch == 8 && !getenv("EMX_SK_NO_NCH8")) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 8>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 2>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 1) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 1>), dim3(grid), b);
     else if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), dim3(grid), b);
