@@ -175,6 +175,16 @@ class ADCEngine(SequentialEngine):
             raise NotImplementedError("input contains NaNs; the sparse ADC model is not part of the HIP engine")
         self.data = torch.from_numpy(np.ascontiguousarray(feats)).to(self.device)
         self.data_cart = torch.from_numpy(np.ascontiguousarray(cartesians.reshape(N, 3 * A))).to(self.device)
+        # the captured step and the head record hold the old set's pointers and row count: a new set means a new capture
+        self._graph = None
+        self._graph_multi = None
+        self._head_key = None
+        # span of the angular block the periodic distance cost runs on (None: not finite): below 1.5 periods the all-pairs tiles
+        # run on fixed-point phases, beyond that (mixed conventions, unwrapped torsions) the reference's float formula
+        lo = self.off_ang if self.use_ang else self.off_dih
+        hi = self.off_side + self.S if self.use_ang else self.off_dih + self.n_dih
+        vmin, vmax = (float(v) for v in torch.aminmax(self.data[:, lo:hi]))
+        self._data_span = (vmax - vmin) if np.isfinite(vmax - vmin) else None
         self._init_batch_stream()
 
     # -- one step ----------------------------------------------------------------------------------------
@@ -402,7 +412,7 @@ class ADCEngine(SequentialEngine):
             hi = self.off_side + self.S if self.use_ang else self.off_dih + self.n_dih
             _lib.sketchmap_fwd_bwd(self.feat[:, lo:hi], Z, per, p.dist_sig_parameters, float(p.distance_cost_scale), 0.0, 0, B,
                                    t[T_DIST:T_DIST + 1], None, self.dZ2, self.sk_ws,
-                                   data_span=2.0 * np.pi)   # angles in [0, pi], torsions in (-pi, pi], both made on the device
+                                   data_span=self._data_span)   # measured once by set_data (None / wide: the float form)
             self.dZ.add_(self.dZ2)
         if self._sk_cart is not None:
             _lib.mlp_backward(self.plan, 0, n, self.dY, None, lay.n_enc - 1, 0, B, latent=self._sk_cart.grad)

@@ -266,7 +266,7 @@ class Autoencoder:
             need_logs = bool(generic) or any(cb.due_steps(cb.steps_counter, cb.steps_counter + k) for cb in based)
             logs = None
             if need_logs:
-                loss = float(eng.losses()[-1])
+                loss = eng.last_loss()
                 self._assert_finite(loss)
                 logs = {"loss": loss}
             for cb in based:
@@ -279,8 +279,8 @@ class Autoencoder:
             for cb in generic:
                 cb.on_train_batch_end(done - 1, logs)
                 stop = stop or bool(getattr(cb, "stop_training", False))
-        losses = eng.losses()[start_hist:]
-        terms = {k: v[start_hist:] for k, v in eng.loss_terms().items()}
+        losses = eng.losses(start_hist)
+        terms = eng.loss_terms(start_hist)
         for v in losses:
             self._assert_finite(float(v))
         for cb in self.callbacks:

@@ -31,12 +31,15 @@ struct AdcHeadArgs {
   int n_batches;      // ... unless that lies behind the index block (0: no check)
 };
 
-// rows: virtual workgroup vb of nvb (256 threads each), thread t of it
-__device__ __forceinline__ void adc_head_rows(const AdcHeadArgs& a, const int64_t* __restrict__ idx, int vb, int nvb, int t) {
+// rows: virtual workgroup vb of nvb (256 threads each), thread t of it.  step_ahead: how far the step this head belongs to lies
+// in front of the counter -- 0 for the head launch of a step and for a head prefetched behind the step's bookkeeping (the
+// counter has advanced already), 1 when the optimizer launch of step t prepares step t + 1 BEFORE the counter moves
+// (EMX_FOLD_FINISH=0): the soft-start scale is that of the step the batch is for (callbacks.py:584-606).
+__device__ __forceinline__ void adc_head_rows(const AdcHeadArgs& a, const int64_t* __restrict__ idx, int vb, int nvb, int t, int step_ahead = 0) {
   if (a.cart_scale && vb == 0 && t == 0) {
     float sc = a.scale_c;
     if (a.soft_a >= 0.f) {
-      const float s = (float)*a.step;
+      const float s = (float)(*a.step + step_ahead);
       if (s < a.soft_a) sc = 0.f;
       else if (s <= a.soft_b) sc = a.scale_c / (a.soft_b - a.soft_a) * (s - a.soft_a);
     }

@@ -510,7 +510,7 @@ __global__ __launch_bounds__(NT) void adam_kernel(int p_adam_blocks, int p_has_h
       const int64_t* __restrict__ idx = p_idx + batch * (long)p_B;
       const int row_wgs = 4 * h.row_blocks;
       if (gb < row_wgs) {
-        emx::adc_head_rows(h, idx, gb >> 2, h.row_blocks, (gb & 3) * 64 + (int)threadIdx.x);
+        emx::adc_head_rows(h, idx, gb >> 2, h.row_blocks, (gb & 3) * 64 + (int)threadIdx.x, p_batch_step);
       } else if (h.feat_mean != nullptr) {
         __shared__ float part[emx::ADC_CM_PH][4];
         emx::adc_head_means<4>(h, idx, (gb - row_wgs) * 4, threadIdx.x, part);

@@ -73,6 +73,10 @@ class DataParallel:
         if not self.active or self.mode == "replica":
             return 0, batch_size
         n_blk = (batch_size + 15) // 16
+        if n_blk < self.world_size:
+            # (the same error on EVERY rank: a rank with an empty range would fail alone and leave the others in the all-reduce)
+            raise ValueError(f"row-block data parallelism needs at least one 16-row block per rank: batch_size {batch_size} gives "
+                             f"{n_blk} blocks for {self.world_size} ranks (use mode='replica' or fewer ranks)")
         base, rem = divmod(n_blk, self.world_size)
         begin = self.rank * base + min(self.rank, rem)
         end = begin + base + (1 if self.rank < rem else 0)
@@ -219,8 +223,10 @@ class SequentialEngine:
         if self.periodic and self.data.numel():
             lo, hi = (float(v) for v in torch.aminmax(self.data))
             span = hi - lo if np.isfinite(hi - lo) else None
-        if span != getattr(self, "_data_span", None):
-            self._graph = None            # the captured step may hold the other tile kernel
+        # the captured step holds the old set's pointer and row count (emx_next_batch) and, for periodic data, the tile kernel its
+        # span selected: a new training set always means a new capture
+        self._graph = None
+        self._graph_multi = None
         self._data_span = span
         self._init_batch_stream()
 
@@ -229,22 +235,38 @@ class SequentialEngine:
         if seed is None:
             seed = int(np.random.SeedSequence().entropy & (2 ** 63 - 1))
         self._shuffle_seed, self._shuffle_epoch = int(seed), 0
-        self._left = torch.empty(0, dtype=torch.int64, device=self.device)
+        self._perm = torch.empty(0, dtype=torch.int64, device=self.device)   # the pass being consumed ...
+        self._perm_pos = 0                                                   # ... and how much of it is used up
 
     def draw_index_block(self, n_batches: int) -> torch.Tensor:
         """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes.  Every pass is one
         emx_permute (a keyed bijection evaluated per element: no sort, no host work); torch only owns the buffers."""
         need = n_batches * self.B
         N = self.data.shape[0]
-        have = self._left.numel()
-        n_perm = max(0, -(-(need - have) // N))
-        buf = torch.empty(have + n_perm * N, dtype=torch.int64, device=self.device)
-        buf[:have].copy_(self._left)
+        have = self._perm.numel() - self._perm_pos
+        if need <= have:
+            # inside the current pass: a view, nothing is copied (the block is consumed -- copied into the index block -- before
+            # the next draw; a pass is only ever replaced by a NEW tensor, so the view stays valid)
+            out = self._perm[self._perm_pos: self._perm_pos + need]
+            self._perm_pos += need
+            return out
+        # the block straddles passes: the unused tail of the current pass + whole new passes; the last of them stays as the
+        # current pass (one emx_permute of N indices per pass, no copy of the remainder per call)
+        n_perm = -(-(need - have) // N)
+        out = torch.empty(need, dtype=torch.int64, device=self.device)
+        out[:have].copy_(self._perm[self._perm_pos:])
+        pos = have
         for k in range(n_perm):
-            _lib.permute(buf[have + k * N: have + (k + 1) * N], self._shuffle_seed, self._shuffle_epoch)
+            last = k == n_perm - 1
+            perm = torch.empty(N, dtype=torch.int64, device=self.device)
+            _lib.permute(perm, self._shuffle_seed, self._shuffle_epoch)
             self._shuffle_epoch += 1
-        self._left = buf[need:].clone()
-        return buf[:need]
+            take = min(N, need - pos)
+            out[pos: pos + take].copy_(perm[:take])
+            pos += take
+            if last:
+                self._perm, self._perm_pos = perm, take
+        return out
 
     # -- forward / backward ------------------------------------------------------------------------
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
@@ -649,14 +671,20 @@ class SequentialEngine:
         self.history, self.term_history, self.history_capacity = h, th, cap
         self._graph = None   # captured pointers are stale
 
-    def losses(self) -> np.ndarray:
-        """Total loss per executed step (synchronises)."""
+    def losses(self, start: int = 0) -> np.ndarray:
+        """Total loss per executed step from step ``start`` on (synchronises; only that tail crosses PCIe)."""
         torch.cuda.synchronize(self.device)
-        return self.history[: self._hstep_host].cpu().numpy()
+        return self.history[start: self._hstep_host].cpu().numpy()
 
-    def loss_terms(self) -> dict:
+    def last_loss(self) -> float:
+        """Loss of the last executed step: ONE float crosses PCIe (what a summary step needs, autoencoder.train)."""
+        if self._hstep_host <= 0:
+            raise Exception("no step has run yet")
+        return float(self.history[self._hstep_host - 1].item())   # (.item() synchronises with the stream)
+
+    def loss_terms(self, start: int = 0) -> dict:
         torch.cuda.synchronize(self.device)
-        th = self.term_history[: self._hstep_host].cpu().numpy()
+        th = self.term_history[start: self._hstep_host].cpu().numpy()
         return {name: th[:, i] for i, name in enumerate(self.TERM_NAMES)}
 
     def current_step(self) -> int:

@@ -9,10 +9,15 @@ Sources (relative to AG-Peter/encodermap @ 2025-05-23):
   * tests/data/known_angles_{dists,angles,dihedrals}.npy + known_angles.pdb coordinates (6 frames x 4 atoms)
   * tests/test_angles.py:72-103  the 28 backbone angles (rad) of tests/data/Ala10_helix.pdb, with the N/CA/C coordinates
     of that file (30 atoms) as the input
+  * encodermap/parameters/parameters.py:611-639, 794-828  the two ``_defaults`` tables (keys and literal values) of
+    ``Parameters`` and ``ADCParameters``, evaluated from the AST of the assignments (``dict(Parameters._defaults, **dict(...))``
+    is resolved by hand; pi and inf are the only names)
 The tables are parsed out of the test file with a regex over numeric literals; no reference code is executed
 or copied.
 """
+import ast
 import json
+import math
 import os
 import re
 
@@ -26,6 +31,50 @@ def numbers_between(text, start_marker, end_marker):
     i = text.index(start_marker)
     j = text.index(end_marker, i)
     return [float(t) for t in re.findall(r"-?\d+\.\d*(?:e-?\d+)?", text[i:j])]
+
+
+def _literal(node, base=None):
+    """value of a literal expression that may use ``pi`` / ``np.pi`` / ``float("inf")``, arithmetic on them, and
+    ``Parameters._defaults[key]`` (looked up in ``base``)"""
+    if isinstance(node, ast.Subscript) and getattr(node.value, "attr", "") == "_defaults":
+        return base[_literal(node.slice)]
+    if isinstance(node, ast.Constant):
+        return node.value
+    if isinstance(node, (ast.List, ast.Tuple)):
+        vals = [_literal(e) for e in node.elts]
+        return vals if isinstance(node, ast.List) else {"__tuple__": vals}
+    if isinstance(node, ast.UnaryOp) and isinstance(node.op, ast.USub):
+        return -_literal(node.operand)
+    if isinstance(node, ast.BinOp):
+        a, b = _literal(node.left), _literal(node.right)
+        return {ast.Mult: a * b, ast.Div: a / b if b else None, ast.Add: a + b, ast.Sub: a - b}[type(node.op)]
+    if isinstance(node, ast.Name) and node.id == "pi":
+        return math.pi
+    if isinstance(node, ast.Attribute) and node.attr == "pi":
+        return math.pi
+    if isinstance(node, ast.Call) and getattr(node.func, "id", "") == "float":
+        return {"__float__": _literal(node.args[0])}      # float("inf"): kept symbolic (JSON has no inf)
+    raise ValueError(ast.dump(node))
+
+
+def parameter_defaults():
+    """{"Parameters": {...}, "ADCParameters": {...}} -- the latter already merged over the former, as the reference's
+    ``dict(Parameters._defaults, **dict(...))`` does."""
+    tree = ast.parse(open(os.path.join(REF, "encodermap/parameters/parameters.py")).read())
+    found = {}
+    for cls in [n for n in ast.walk(tree) if isinstance(n, ast.ClassDef) and n.name in ("Parameters", "ADCParameters")]:
+        for st in cls.body:
+            if isinstance(st, ast.Assign) and any(getattr(t, "id", "") == "_defaults" for t in st.targets):
+                call = st.value
+                assert isinstance(call, ast.Call) and call.func.id == "dict"
+                kw = call.keywords
+                if call.args:      # dict(Parameters._defaults, **dict(k=v, ...))
+                    inner = [k.value for k in kw if k.arg is None]
+                    assert len(inner) == 1 and inner[0].func.id == "dict"
+                    kw = inner[0].keywords
+                found[cls.name] = {k.arg: _literal(k.value, found.get("Parameters")) for k in kw}
+    found["ADCParameters"] = dict(found["Parameters"], **found["ADCParameters"])
+    return found
 
 
 def main():
@@ -61,6 +110,7 @@ def main():
     assert len(bb) == 30 and len(ala) == 28, (len(bb), len(ala))
     out["ala10_backbone_xyz_angstrom"] = bb
     out["ala10_backbone_angles_rad"] = ala
+    out["parameter_defaults"] = parameter_defaults()
     with open(os.path.join(HERE, "reference_kat_tables.json"), "w") as f:
         json.dump(out, f, indent=1)
     print("helix", helix.shape, "chain", chain.shape, "frames", np.array(frames).shape)

@@ -224,3 +224,33 @@ def test_adc_free_running_drift_envelope(em):
     print("adc drift ratios", {k: round(v, 2) for k, v in ratios.items()},
           "final rel. deviation engine %.2e oracle-f32 %.2e" % (abs(got[-1] - f64[-1]) / abs(f64[-1]), abs(f32[-1] - f64[-1]) / abs(f64[-1])))
     assert ratios["loss"] <= 4.0 and max(ratios.values()) <= 8.0, ratios
+
+
+@pytest.mark.parametrize("fold", [True, False])
+def test_adc_soft_start_with_and_without_folded_bookkeeping(em, fold, monkeypatch):
+    """The head of step t + 1 (batch rows, encoder input, SOFT-START SCALE) is prepared on workgroups of the optimizer launch of
+    step t.  With the step's bookkeeping folded into the weight-gradient launch the counter has advanced by then; without
+    it (EMX_FOLD_FINISH=0) it has not, and the head must take the scale of step t + 1, not t (callbacks.py:584-606).  Both
+    forms against the float64 oracle through a soft start that ramps over the run's steps."""
+    from encodermap_amd.engine import SequentialEngine
+
+    monkeypatch.setattr(SequentialEngine, "_fold_finish", fold)
+    name, kw, n_res, n_side, B = CASES[1]
+    kw = dict(kw, cartesian_cost_scale_soft_start=(1, 6), cartesian_cost_scale=3.0)
+    rng = np.random.default_rng(17)
+    data = R.synthetic_backbone(rng, 700, n_res, n_side)
+    n_steps = 8
+    p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
+    A = 3 * n_res
+    net_dim = 2 * ((A - 2) + (A - 3))
+    w0 = weights_for(em, p, net_dim)
+    e = em.AngleDihedralCartesianEncoderMap(data, p, model=[w.copy() for w in w0], read_only=True)
+    assert e._engine._prefetch and e._engine._late_bookkeeping() == fold
+    idx = rng.integers(0, 700, (n_steps, B))
+    e._engine.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    got, terms = e._engine.losses().astype(np.float64), e._engine.loss_terms()
+    want, want_terms = R.adc_train_steps(R.ADCOracle(A, n_side, p.to_dict(), w0), data, idx)
+    np.testing.assert_allclose(got, want, rtol=2e-4)
+    cart = np.array([t["cartesian"] for t in want_terms])
+    assert cart[0] == 0 and cart[1] == 0 and cart[2] > 0 and cart[3] > cart[2]     # the ramp starts inside the run
+    np.testing.assert_allclose(terms["cartesian"], cart, rtol=5e-4, atol=1e-7)

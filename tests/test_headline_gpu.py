@@ -1,0 +1,218 @@
+"""The BASELINE.json configurations at (or next to) their full sizes, as training STEPS through the engine -- round 3.
+
+* C2 (1e6 x 128 blobs, B = 4096, sig (16, 12, 6, 1, 2, 6)): three training steps against the float64 oracle loop
+  (R.train_steps, the reference formulation with its Gram-matrix temporaries: 134 MB each at this size).
+* C3a (the cube example, encodermap/examples/cube.py:25-38): EncoderMap on random_on_cube_edges(50000, 0.05), B = 256,
+  dist_sig_parameters (0.2, 3, 6, 1, 2, 6) -- the general-exponent sigmoid path -- 12 steps against the oracle.
+* C4 (B = 8192, D = 512 periodic) and C5 (B = 16384, D = 256 Euclidean) full-size steps: size-independent properties --
+  finite, decreasing, bitwise reproducible -- and, at B = 8192 / 16384, row-block data parallelism with two ranks on the
+  one GPU against the single process.
+* a new training set through set_data() after a captured run (the captured step holds the old set's pointer).
+Needs an MI355X.
+"""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import reference_ops as R
+
+pytestmark = pytest.mark.gpu
+INF = float("inf")
+
+
+@pytest.fixture(scope="module")
+def em():
+    import encodermap_amd as em
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    return em
+
+
+def _weights(p, net_dim, seed=3):
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+
+    lay = build_layout(p.n_neurons, p.activation_functions, net_dim)
+    return unpack_weights(lay, init_parameters(lay, seed))
+
+
+def blobs(rng, n, d, centres=16):
+    """blob centres normal(0, 4), points centre[k] + normal(0, 1)"""
+    c = rng.normal(0, 4, (centres, d))
+    return (c[rng.integers(0, centres, n)] + rng.normal(0, 1, (n, d))).astype(np.float32)
+
+
+def test_c2_three_steps_against_the_float64_oracle(em):
+    """BASELINE config 2 at its batch size and width.  Tolerances: total loss 1e-4 relative (the north star's bound), every
+    cost term 2e-4."""
+    rng = np.random.default_rng(1)
+    data = blobs(rng, 20000, 128)
+    p = em.Parameters(periodicity=INF, batch_size=4096, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6), n_steps=3)
+    w0 = _weights(p, 128)
+    idx = rng.integers(0, data.shape[0], (3, 4096))
+    e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True)
+    e._engine.run_steps(3, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    got, terms = e._engine.losses().astype(np.float64), e._engine.loss_terms()
+    model = R.SequentialOracle(128, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    want, want_terms = R.train_steps(model, data, idx, p.to_dict())
+    print("C2 steps: engine", got, "oracle", np.array(want), "rel", np.abs(got - want) / np.abs(want))
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+    assert want_terms[0]["distance"] > 0   # (the sigmoid is not saturated at these parameters)
+
+
+def test_c3a_cube_example(em):
+    """encodermap/examples/cube.py:25-38: points on the edges of a cube, Euclidean, sig_h = (0.2, 3, 6) -- a_h = 3 is NOT the
+    fast (12, 6) family: the exp2/log2 form of the high-d sigmoid runs."""
+    from encodermap_amd.misc import random_on_cube_edges
+
+    data, ids = random_on_cube_edges(50000, sigma=0.05, rng=np.random.default_rng(2))
+    data = np.asarray(data, np.float32)
+    assert data.shape == (50000, 3)
+    rng = np.random.default_rng(2)
+    p = em.Parameters(periodicity=INF, batch_size=256, dist_sig_parameters=(0.2, 3, 6, 1, 2, 6), n_steps=12)
+    w0 = _weights(p, 3)
+    idx = rng.integers(0, data.shape[0], (12, 256))
+    e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True)
+    e._engine.run_steps(12, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    got, terms = e._engine.losses().astype(np.float64), e._engine.loss_terms()
+    model = R.SequentialOracle(3, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    want, want_terms = R.train_steps(model, data, idx, p.to_dict())
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+    e._engine.set_weights([b.detach().numpy() for b in model.params])
+    z = e.encode(data[:500])
+    z_o = model.encoder(torch.tensor(data[:500], dtype=torch.float64)).detach().numpy()
+    np.testing.assert_allclose(z, z_o, atol=1e-4)
+
+
+FULL = {
+    # name: (parameters, data maker) -- BASELINE configs 4 and 5 at their batch size and width (the data sets shortened: the
+    # step does not depend on N)
+    "c4": (dict(batch_size=8192, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6)),
+           lambda r: r.uniform(-np.pi, np.pi, (40000, 512)).astype(np.float32)),
+    "c5": (dict(periodicity=INF, batch_size=16384, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)), lambda r: blobs(r, 60000, 256)),
+}
+
+
+def _full_run(em, name, n_steps, dp=None):
+    kw, maker = FULL[name]
+    data = maker(np.random.default_rng(4))
+    p = em.Parameters(n_steps=n_steps, seed=9, **kw)
+    D = data.shape[1]
+    w0 = _weights(p, 2 * D if p.periodicity < INF else D)
+    idx = np.random.default_rng(6).integers(0, data.shape[0], (n_steps, p.batch_size))
+    kwargs = dict(dp=dp) if dp is not None else {}
+    e = em.EncoderMap(p, data, model=w0, read_only=True, **kwargs)
+    e._engine.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    return e
+
+
+@pytest.mark.parametrize("name", ["c4", "c5"])
+def test_full_size_steps_properties(em, name):
+    """20 full-size steps: finite, the cost goes down, and a second run reproduces the first bit for bit (no atomics in any
+    reduction of the step: fixed-order partial sums everywhere)."""
+    runs = []
+    for _ in range(2):
+        e = _full_run(em, name, 20)
+        runs.append((e._engine.losses(), e._engine.w.cpu().numpy(), {k: v.copy() for k, v in e._engine.loss_terms().items()}))
+        del e
+        torch.cuda.empty_cache()
+    loss, w, terms = runs[0]
+    assert np.isfinite(loss).all() and np.isfinite(w).all()
+    assert loss[-1] < loss[0], loss
+    assert all(np.isfinite(v).all() for v in terms.values()) and terms["distance"][0] > 0
+    np.testing.assert_array_equal(loss, runs[1][0])
+    np.testing.assert_array_equal(w, runs[1][1])
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _rowblock_worker(rank, world, port, name, out_dir):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import encodermap_amd as em
+    from encodermap_amd.engine import DataParallel
+
+    e = _full_run(em, name, 4, dp=DataParallel(rank, world, "rowblock"))
+    np.savez(os.path.join(out_dir, f"{name}_{rank}.npz"), loss=e._engine.losses(), w=e._engine.w.cpu().numpy())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["c4", "c5"])
+def test_full_size_rowblock_two_ranks_equal_single_process(em, name, tmp_path):
+    """The objective-preserving partition at the full batch: two row-block ranks on the one GPU (gloo
+    collectives), dealt all-pairs tiles, against the single process: losses to 2e-5 over four steps."""
+    import torch.multiprocessing as mp
+
+    mp.spawn(_rowblock_worker, args=(2, _free_port(), name, str(tmp_path)), nprocs=2, join=True)
+    runs = [np.load(tmp_path / f"{name}_{r}.npz") for r in range(2)]
+    np.testing.assert_array_equal(runs[0]["w"], runs[1]["w"])
+    np.testing.assert_array_equal(runs[0]["loss"], runs[1]["loss"])
+    e = _full_run(em, name, 4)
+    np.testing.assert_allclose(runs[0]["loss"], e._engine.losses(), rtol=2e-5)
+    diff = np.abs(runs[0]["w"] - e._engine.w.cpu().numpy())
+    assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3, (diff.max(), (diff > 2e-5).mean())
+
+
+@pytest.mark.parametrize("periodic", [True, False])
+def test_new_training_set_after_a_captured_run(em, periodic):
+    """Train, hand the engine ANOTHER training set (set_data / set_train_data), train again: the captured step held the old
+    set's pointer and row count, so the graph must be dropped -- the second leg must equal a fresh engine that starts from
+    the first leg's state on the new set, bit for bit."""
+    rng = np.random.default_rng(8)
+    mk = (lambda n: rng.uniform(-math.pi, math.pi, (n, 10)).astype(np.float32)) if periodic else (lambda n: blobs(rng, n, 32, 6))
+    kw = dict() if periodic else dict(periodicity=INF, dist_sig_parameters=(8.0, 12, 6, 1, 2, 6))
+    a, b = mk(3000), mk(1700)          # (a different row count too)
+    p = em.Parameters(n_steps=20, batch_size=256, **kw)
+    w0 = _weights(p, 20 if periodic else 32)
+    ia = rng.integers(0, 3000, (10, 256))
+    ib = rng.integers(0, 1700, (10, 256))
+    e = em.EncoderMap(p, a, model=[w.copy() for w in w0], read_only=True)
+    e._engine.run_steps(10, torch.from_numpy(ia.reshape(-1)).cuda())
+    state = e._engine.state_dict()
+    del a
+    e._engine.set_data(b)
+    e._engine.run_steps(10, torch.from_numpy(ib.reshape(-1)).cuda())
+    second = e._engine.losses(10)
+    f = em.EncoderMap(p, b, model=[w.copy() for w in w0], read_only=True)
+    f._engine.load_state_dict(state)
+    f._engine.run_steps(10, torch.from_numpy(ib.reshape(-1)).cuda())
+    np.testing.assert_array_equal(second, f._engine.losses())
+    np.testing.assert_array_equal(e._engine.w.cpu().numpy(), f._engine.w.cpu().numpy())
+
+
+def test_shuffle_stream_blocks_do_not_copy_the_pass(em):
+    """draw_index_block: consecutive draws inside one pass are views of ONE permutation (no copy + clone of the remainder
+    per call), a draw that straddles passes continues exactly where the host twin (layout.BatchIndexStream on the same
+    keyed bijection) does."""
+    from encodermap_amd.layout import feistel_permutation
+
+    rng = np.random.default_rng(3)
+    data = rng.uniform(-3, 3, (1000, 4)).astype(np.float32)
+    p = em.Parameters(n_steps=5, batch_size=64, seed=7)
+    e = em.EncoderMap(p, data, read_only=True)
+    eng = e._engine
+    seed = eng._shuffle_seed
+    blocks = [eng.draw_index_block(k).cpu().numpy().copy() for k in (3, 5, 9, 20, 1)]     # 38 batches of 64 = 2432 rows: 3 passes
+    got = np.concatenate(blocks)
+    want = np.concatenate([feistel_permutation(1000, seed, ep) for ep in range(3)])[: got.size]
+    np.testing.assert_array_equal(got, want)
+    base = eng._perm.data_ptr()
+    v = eng.draw_index_block(2)
+    assert v.data_ptr() >= base and v.data_ptr() < base + eng._perm.numel() * 8      # a view into the current pass

@@ -39,6 +39,25 @@ def test_parameter_defaults_match_reference_table():
     assert a.dihedral_cost_scale == 1 and a.angle_cost_scale == 0 and a.side_dihedral_cost_scale == 0.5
     assert a.cartesian_cost_scale_soft_start == (None, None) and a.cartesian_dist_sig_parameters == (4.5, 12, 6, 1, 2, 6)
     assert set(p.defaults) < set(a.defaults)
+    # the WHOLE tables, keys and values, against the fixture AST-extracted from the reference's parameters.py:611-639, 794-828
+    # (tests/golden/make_reference_kat_tables.py: data, no reference code)
+    import json
+
+    tables = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_kat_tables.json")))["parameter_defaults"]
+
+    def plain(v):
+        if isinstance(v, dict) and "__tuple__" in v:
+            return tuple(plain(x) for x in v["__tuple__"])
+        if isinstance(v, dict) and "__float__" in v:
+            return float(v["__float__"])
+        return v
+
+    for obj, name in ((p, "Parameters"), (a, "ADCParameters")):
+        want = {k: plain(v) for k, v in tables[name].items()}
+        assert set(obj.defaults) == set(want), (name, set(obj.defaults) ^ set(want))
+        for k, v in want.items():
+            assert obj.defaults[k] == v and type(obj.defaults[k]) is type(v), (name, k, obj.defaults[k], v)
+            assert getattr(obj, k) == v, (name, k)
 
 
 def test_parameter_behaviour(tmp_path, capsys):
@@ -216,13 +235,18 @@ def test_callback_cadence():
 def test_row_block_partition():
     from encodermap_amd.engine import DataParallel
 
-    for B, G in [(4096, 8), (4096, 3), (10, 4), (7, 7)]:
+    for B, G in [(4096, 8), (4096, 3), (80, 3), (100, 7), (16, 1)]:
         blocks = [DataParallel(r, G, "rowblock").row_block(B) for r in range(G)]
         assert blocks[0][0] == 0 and blocks[-1][1] == B
         assert all(blocks[i][1] == blocks[i + 1][0] for i in range(G - 1))
         sizes = [e - b for b, e in blocks]
         assert max(sizes) - min(sizes) <= 16                      # balanced to one 16-row block ...
         assert all(b % 16 == 0 or b == B for b, _ in blocks)      # ... the granule of the weight-gradient fragments (emx_mlp_aop_bytes)
+    # fewer 16-row blocks than ranks: the SAME clear error on every rank (a lone failing rank would leave the others in the all-reduce)
+    for B, G in [(10, 4), (40, 4), (7, 7)]:
+        for r in range(G):
+            with pytest.raises(ValueError, match="at least one 16-row block per rank"):
+                DataParallel(r, G, "rowblock").row_block(B)
     assert DataParallel(2, 8, "replica").row_block(4096) == (0, 4096)
     assert DataParallel().row_block(256) == (0, 256) and not DataParallel().active
     assert DataParallel(0, 2, "rowblock").batch_seed(5) == DataParallel(1, 2, "rowblock").batch_seed(5)
