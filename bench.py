@@ -1,40 +1,52 @@
 #!/usr/bin/env python3
-"""Headline benchmark: EncoderMap training throughput at B=4096, D=128 (BASELINE.json config C2).
+"""Benchmark of the EncoderMap training step on the configurations of BASELINE.json.
 
-    python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py                                    # the headline: C2, one GPU, 300 steps after 30 warm-up steps
+    python bench.py --config C5 --steps 100 --warmup 10
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W [--config C4]
 
-A "step" is one full training step of ``em.EncoderMap`` (gather a mini-batch, encoder/decoder forward, sketch-map
-distance + auto + center + L2 cost, backward, clip + Adam) on synthetic Gaussian blobs that are resident in HBM
-before the timed region starts.  One JSON line is printed by rank 0:
+``--config`` (default C2, the configuration BASELINE.json's metric is quoted on):
+  C1  em.EncoderMap, default Parameters, random float32 array 10000 x 10 (periodic, B = 256)
+  C2  Gaussian blobs 1e6 x 128, B = 4096, Euclidean sketch-map cost, sig (16, 12, 6, 1, 2, 6)
+  C3  AngleDihedralCartesianEncoderMap (dihedral -> Cartesian back-mapping costs), synthetic backbone of 76 residues
+      (228 atoms), 50 000 frames, B = 256
+  C4  synthetic dihedral trajectory 2e6 x 512 (periodic), B = 8192
+  C5  Gaussian blobs 5e5 x 256, B = 16384, Euclidean
 
-  value        whole-job samples/s = N_gpus * 4096 * K / (max over ranks of the time for K steps)
-  roofline     the kernel that takes the largest share of the STEP (today the fused dense-layer launch: forward, auto cost,
-               decoder backward), ``roofline_all_pairs`` the O(B^2 D) all-pairs kernel.  Both are timed here with HIP events
-               around back-to-back launches on the live batch.  Every float32 product of these kernels runs as THREE f16
-               matrix instructions on operands split into two 16-bit planes, so ``achieved`` counts the executed FLOPs
-               (3 x the algorithmic 2 per multiply-add) and ``peak`` is the dense f16 matrix peak; ``fractions`` gives the
-               three ways to price the same launch: fp32_equivalent (algorithmic FLOPs against the 157.3 TFLOP/s fp32 matrix
-               peak -- the precision delivered), executed_f16 (= ``frac``) and valu_issue (VALU instructions per launch, from the
-               PMC passes under profiles/, per SIMD and clock -- what actually bounds both kernels).
-               ``traffic`` = HBM bytes per launch from the PMC passes under profiles/ (``traffic_source`` names the file).
-  cpu_baseline the reference-formulation CPU path (oracle/reference_ops.py in float32: Gram-matrix distances with
-               B x B temporaries, autograd, per-element clipped Adam) timed on this host for a few steps of the same
-               workload.  N=1 only.  kind "port": TensorFlow itself cannot be installed here.
+A "step" is one full training step (mini-batch gather, forward, all cost terms, backward, clip + Adam) on synthetic data
+that is resident in HBM before the timed region starts.  One JSON line is printed by rank 0:
 
-N > 1: weak scaling -- every rank trains on its own mini-batch of 4096 rows (global batch 4096*N) and the flat
-gradient buffer is averaged by one RCCL all-reduce per step (engine.DataParallel mode "replica": the objective is the
-mean of N independent 4096-row sketch-map costs, what N reference processes with averaged gradients would minimise).
-``--dp-mode rowblock`` is the other objective: ONE sketch-map cost over ONE global batch (``--global-batch``, default
-4096: strong scaling of the single-GPU objective; ``--global-batch 0`` = 4096 * N), dense layers on runs of row blocks,
-the symmetric all-pairs tiles dealt to the ranks, two all-reduces per step (latent gradient shares, [gradient | terms]).
+  value        whole-job samples/s = global batch * K / (max over ranks of the time for K steps)
+  roofline     the kernel that takes the largest share of the STEP, timed here with HIP events around back-to-back launches on
+               the live batch (torch's current stream is the stream the kernels are launched on); ``roofline_all_pairs`` the
+               O(B^2 D) all-pairs kernel when it is not that kernel.  Euclidean configurations: every float32 product runs as
+               THREE f16 matrix instructions on operands split into two 16-bit planes (2^-22 relative operand precision, f32
+               accumulate; profiles/r03_split_accuracy.txt prices the result against a true float32 run), so ``achieved`` counts
+               the EXECUTED FLOPs (6 per multiply-add) against the dense f16 matrix peak -- ``frac`` is on that basis in every
+               line of this round and of round 2.  Periodic configurations: the all-pairs pass runs on the VALU (5 FLOP per
+               pair-element) against the fp32 peak.  ``limiter`` names what the PMC counters say bounds the
+               kernel; ``traffic`` = HBM bytes per launch from the PMC passes under profiles/ (``traffic_source`` names file and
+               commit), null where no pass was taken for the configuration.
+  cpu_baseline the reference formulation (oracle/reference_ops.py in float32: Gram-matrix / [B, B, D] temporaries, autograd,
+               per-element clipped Adam) timed on this host: >= 50 steps after 5 warm-up steps at the fastest thread count of a
+               one-step probe, and a few steps on ONE thread.  N = 1 only.  kind "port": TensorFlow cannot be installed here.
+  facade_ms_per_step   C2, N = 1: the same steps through ``em.EncoderMap.train()`` (the user's entry point, callbacks and History
+               included), with the defaults and with the progress read-out every ``summary_step`` steps.
+
+N > 1: C2 -- weak scaling, every rank trains on its own mini-batch of 4096 rows and the flat gradient buffer is averaged by one
+RCCL all-reduce per step (engine.DataParallel mode "replica"; ``--dp-mode rowblock`` is the objective-preserving partition
+of ONE global batch, ``--global-batch``).  C4 / C5 -- ALWAYS the row-block partition of the configuration's one global
+batch (the single-process objective exactly; strong scaling): dense layers on runs of 16-row blocks,
+the symmetric all-pairs tiles dealt to the ranks, two all-reduces per step.
 """
 from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
+import subprocess
 import sys
 import time
 
@@ -42,64 +54,199 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-B, D, N_ROWS = 4096, 128, 1_000_000
-SIG = (16.0, 12, 6, 1, 2, 6)
+INF = float("inf")
 FP32_PEAK = 157.3e12   # MI355X fp32 vector == fp32 MFMA peak (MI355X_MICROARCH.md chip table)
 F16_PEAK = 2.5e15      # dense f16 / bf16 matrix peak (same table; the headline figure with 2:1 sparsity is not used)
+HBM_PEAK = 8.0e12
 SIMDS, CLOCK = 1024, 2.4e9
-DTYPE = "f32 (split-f16 x3 mfma)"
-COUNTERS = os.path.join("profiles", "r02_step_counters.json")
+
+CONFIGS = {
+    "C1": dict(rows=10_000, D=10, kw=dict(), kind="uniform01", model="encodermap",
+               workload="C1: em.EncoderMap with default Parameters on a random float32 array 10000x10 (periodic 2 pi, batch 256)"),
+    "C2": dict(rows=1_000_000, D=128, kw=dict(periodicity=INF, batch_size=4096, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6)), kind="blobs",
+               model="encodermap", seed=1,
+               workload="C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, batch 4096, sketch-map sigmoid loss (Euclidean), "
+                        "sig=(16,12,6,1,2,6)"),
+    "C3": dict(rows=50_000, D=228, kw=dict(batch_size=256, cartesian_pwd_start=1, cartesian_pwd_step=3,
+                                           cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5), dihedral_cost_reference=1.5,
+                                           angle_cost_reference=0.3, cartesian_cost_reference=8.0),
+               kind="backbone", model="adc", n_res=76,
+               workload="C3: AngleDihedralCartesianEncoderMap (dihedral_to_cartesian back-mapping, cartesian + cartesian-distance costs), "
+                        "synthetic backbone of 76 residues = 228 atoms, 50000 frames, batch 256"),
+    "C4": dict(rows=2_000_000, D=512, kw=dict(batch_size=8192, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6)), kind="dihedrals", model="encodermap", seed=4,
+               workload="C4: EncoderMap training, synthetic dihedral trajectory 2e6x512 (periodic 2 pi) resident in HBM, batch 8192, "
+                        "sig=(30,12,6,1,2,6)"),
+    "C5": dict(rows=500_000, D=256, kw=dict(periodicity=INF, batch_size=16384, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)), kind="blobs",
+               model="encodermap", seed=5,
+               workload="C5: EncoderMap training, 5e5x256 Gaussian blobs resident in HBM, batch 16384, sketch-map sigmoid loss (Euclidean), "
+                        "sig=(22.6,12,6,1,2,6)"),
+}
+DTYPES = {"blobs": "f32 (split-f16 x3 mfma: 2^-22 operand precision, f32 accumulate)",
+          "dihedrals": "f32 (dense layers split-f16 x3 mfma; all-pairs pass on 32-bit fixed-point phases, f32 accumulate)",
+          "uniform01": "f32 (dense layers split-f16 x3 mfma; all-pairs pass on 32-bit fixed-point phases, f32 accumulate)",
+          "backbone": "f32 (dense layers and cartesian-distance Gram tiles split-f16 x3 mfma; back-mapping f32)"}
 
 
-def make_blobs(device, n_rows, d, seed):
-    """C2 data: 16 blob centres N(0,4), points = centre + N(0,1)   (SURVEY.md section 8d)."""
+def git_head():
+    try:
+        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# synthetic data, generated ON the device (nothing crosses PCIe inside or in front of the timed region)
+# ------------------------------------------------------------------------------------------------------------------
+def make_data(cfg, device, n_rows=None):
     import torch
 
+    kind, d = cfg["kind"], cfg["D"]
+    n = int(n_rows or cfg["rows"])
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    centres = torch.randn(16, d, generator=g, device=device) * 4.0
-    k = torch.randint(0, 16, (n_rows,), generator=g, device=device)
-    return centres[k] + torch.randn(n_rows, d, generator=g, device=device)
+    g.manual_seed(cfg.get("seed", 0))
+    if kind == "blobs":
+        # 16 blob centres N(0, 4), points = centre + N(0, 1)   
+        centres = torch.randn(16, d, generator=g, device=device) * 4.0
+        k = torch.randint(0, 16, (n,), generator=g, device=device)
+        return centres[k] + torch.randn(n, d, generator=g, device=device)
+    if kind == "uniform01":
+        return torch.rand(n, d, generator=g, device=device)
+    if kind == "dihedrals":
+        # mixture of basins per dihedral (von-Mises-like: a wrapped normal of width 0.35 around one of three basin centres per
+        # column), wrapped to (-pi, pi]; generated in chunks: 2e6 x 512 floats are 4 GB
+        centres = (torch.rand(3, d, generator=g, device=device) * 2 - 1) * math.pi
+        out = torch.empty(n, d, dtype=torch.float32, device=device)
+        for s in range(0, n, 1 << 18):
+            m = min(1 << 18, n - s)
+            k = torch.randint(0, 3, (m, d), generator=g, device=device)
+            x = torch.gather(centres, 0, k) + 0.35 * torch.randn(m, d, generator=g, device=device)
+            out[s: s + m] = torch.remainder(x + math.pi, 2 * math.pi) - math.pi
+        return out
+    raise ValueError(kind)
 
 
-def cpu_baseline(n_steps=12):
+def make_backbone(cfg, n_frames):
+    """random-walk chain with protein-like bond lengths, featurised by the product's own kernel (emx_backbone_features)"""
+    import numpy as np
+
+    from encodermap_amd.features import featurize_backbone
+
+    A = 3 * cfg["n_res"]
+    rng = np.random.default_rng(3)
+    step = rng.normal(size=(n_frames, A, 3)).astype(np.float32)
+    step /= np.linalg.norm(step, axis=2, keepdims=True)
+    return featurize_backbone(np.cumsum(1.4 * step, axis=1).astype(np.float32))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference formulation in float32 on the host cores
+# ------------------------------------------------------------------------------------------------------------------
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return None
+
+
+def cpu_baseline(name, n_steps=50, n_warm=5, budget_s=45.0):
     import numpy as np
     import torch
 
     from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
-    from encodermap_amd.parameters import Parameters
+    from encodermap_amd.parameters import ADCParameters, Parameters
     from oracle import reference_ops as R
 
+    cfg = CONFIGS[name]
     rng = np.random.default_rng(1)
-    n_rows = 20000   # the sample: rows actually touched by the timed steps are drawn from this subset
-    centres = rng.normal(0, 4, (16, D))
-    data = (centres[rng.integers(0, 16, n_rows)] + rng.normal(0, 1, (n_rows, D))).astype(np.float32)
-    p = Parameters(periodicity=float("inf"), batch_size=B, dist_sig_parameters=SIG)
-    lay = build_layout(p.n_neurons, p.activation_functions, D)
-    w0 = unpack_weights(lay, init_parameters(lay, 0))
-    model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0, dtype=torch.float32)
-    idx = rng.integers(0, n_rows, (n_steps + 2, B))
-    R.train_steps(model, data, idx[:1], p.to_dict())           # warm-up step
-    # torch-CPU over-subscribes badly on many-core hosts (128 threads are ~2.5x slower than 32 here), so the thread count
-    # is chosen by a one-step probe among {all, 64, 32, 16} and the fastest setting is used and reported
+    kw = dict(cfg["kw"])
+    B_full = kw.get("batch_size", 256)
+    D = cfg["D"]
+    note = ""
+    if cfg["model"] == "adc":
+        data = R.synthetic_backbone(rng, 2000, cfg["n_res"])
+        p = ADCParameters(**kw)
+        A = 3 * cfg["n_res"]
+        lay = build_layout(p.n_neurons, p.activation_functions, 2 * (A - 3))
+        w0 = unpack_weights(lay, init_parameters(lay, 0))
+        model = R.ADCOracle(A, 0, p.to_dict(), w0, dtype=torch.float32)
+        B = B_full
+
+        def run(idx):
+            R.adc_train_steps(model, data, idx)
+
+        n_rows = 2000
+    else:
+        # the reference formulation materialises [B, B] (Euclidean) or [B, B, D] (periodic) temporaries: at C4 that is 137 GB, at
+        # C5 ~1 GB per temporary and a dozen of them alive under autograd -- those two run at a reduced batch (stated)
+        B = {"C4": 512, "C5": 8192}.get(name, B_full)
+        if B != B_full:
+            kw["batch_size"] = B
+            note = (f"; batch reduced from {B_full} to {B}: the formulation's {'[B, B, D]' if cfg['kind'] == 'dihedrals' else '[B, B]'} "
+                    f"temporaries do not fit at the full batch -- pair work per sample scales with B, so the full-batch rate is lower still")
+        n_rows = 20000
+        if cfg["kind"] == "blobs":
+            c = rng.normal(0, 4, (16, D))
+            data = (c[rng.integers(0, 16, n_rows)] + rng.normal(0, 1, (n_rows, D))).astype(np.float32)
+        elif cfg["kind"] == "uniform01":
+            data = rng.random((10000, D)).astype(np.float32)
+            n_rows = 10000
+        else:
+            data = rng.uniform(-np.pi, np.pi, (n_rows, D)).astype(np.float32)
+        p = Parameters(**kw)
+        net = 2 * D if p.periodicity < INF else D
+        lay = build_layout(p.n_neurons, p.activation_functions, net)
+        w0 = unpack_weights(lay, init_parameters(lay, 0))
+        model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0, dtype=torch.float32)
+
+        def run(idx):
+            R.train_steps(model, data, idx, p.to_dict())
+
+    draw = lambda k: rng.integers(0, n_rows, (k, B))
+    run(draw(1))                                   # first touch
+    # torch-CPU over-subscribes badly on many-core hosts (all threads can be several times slower than 16-32), so the thread
+    # count is chosen by a one-step probe among {all, 64, 32, 16, 8} and the fastest is used and reported; one thread beside it
     cores = os.cpu_count() or torch.get_num_threads()
     best, best_t = torch.get_num_threads(), float("inf")
-    for nt in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16)}, reverse=True):
+    for nt in sorted({cores, min(cores, 64), min(cores, 32), min(cores, 16), min(cores, 8)}, reverse=True):
         torch.set_num_threads(nt)
         t0 = time.perf_counter()
-        R.train_steps(model, data, idx[1:2], p.to_dict())
+        run(draw(1))
         dt1 = time.perf_counter() - t0
         if dt1 < best_t:
             best, best_t = nt, dt1
     torch.set_num_threads(best)
+    steps = max(3, min(n_steps, int(budget_s / max(best_t, 1e-9))))
+    warm = min(n_warm, max(1, steps // 4))
+    run(draw(warm))
     t0 = time.perf_counter()
-    R.train_steps(model, data, idx[2:], p.to_dict())
+    run(draw(steps))
     dt = time.perf_counter() - t0
-    return {"value": B * n_steps / dt, "unit": "samples/s", "cores": best, "kind": "port",
-            "sample": f"{n_steps} training steps at B={B}, D={D} (float32 torch-CPU restatement of the reference formulation, "
-                      f"{dt / n_steps * 1e3:.0f} ms/step with {best} of {cores} host threads, the fastest of a one-step probe)"}
+    # one thread: a few steps (bounded)
+    torch.set_num_threads(1)
+    t0 = time.perf_counter()
+    run(draw(1))
+    one = time.perf_counter() - t0
+    k1 = max(1, min(5, int(10.0 / max(one, 1e-9))))
+    if k1 > 1:
+        t0 = time.perf_counter()
+        run(draw(k1))
+        one = (time.perf_counter() - t0) / k1
+    torch.set_num_threads(best)
+    short = "" if steps >= n_steps else f" ({steps} steps instead of {n_steps}: bounded to ~{budget_s:.0f} s of CPU work)"
+    return {"value": B * steps / dt, "unit": "samples/s", "cores": best, "kind": "port",
+            "sample": f"{steps} training steps after {warm} warm-up steps at B={B}, D={D} (float32 torch-CPU restatement of the reference "
+                      f"formulation, oracle/reference_ops.py): {dt / steps * 1e3:.0f} ms/step with {best} of {cores} host threads, the fastest "
+                      f"of a one-step probe{short}{note}",
+            "single_thread": {"value": B / one, "unit": "samples/s", "cores": 1, "ms_per_step": one * 1e3},
+            "host_cpu": _cpu_model(), "host_threads": cores}
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# per-kernel rooflines, timed live
+# ------------------------------------------------------------------------------------------------------------------
 def _time_launches(fn, launches):
     """average duration of ``fn`` (asynchronous launches on torch's current stream) over back-to-back calls, seconds"""
     import torch
@@ -116,61 +263,106 @@ def _time_launches(fn, launches):
     return e0.elapsed_time(e1) * 1e-3 / launches
 
 
-def _counters(kernel_key):
-    """static per-launch counters of the step's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh)"""
-    try:
-        for name, c in json.load(open(os.path.join(ROOT, COUNTERS)))["kernels"].items():
-            if kernel_key in name:
-                return c
-    except Exception:
-        pass
-    return {}
+def _counters(name, kernel_key):
+    """static per-launch counters of the configuration's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh);
+    returns (counters, source)"""
+    for rnd in ("r03", "r02"):
+        path = os.path.join("profiles", f"{rnd}_step_counters.json" if name == "C2" else f"{rnd}_{name.lower()}_counters.json")
+        try:
+            blob = json.load(open(os.path.join(ROOT, path)))
+            for kname, c in blob["kernels"].items():
+                if kernel_key in kname:
+                    return c, f"{path} (static: PMC passes over this workload, taken at commit {blob.get('commit', 'of that round')})"
+        except Exception:
+            continue
+    return {}, None
 
 
-def _record(kernel, kernel_key, t, mults, note, algorithmic_bytes):
-    """One roofline object: ``mults`` multiply-adds of float32 precision per launch, each executed as three f16 matrix
-    instructions' worth of FLOPs."""
-    c = _counters(kernel_key)
-    executed = 6.0 * mults
+def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, bound, limiter, note, algorithmic_bytes):
+    c, src = _counters(name, kernel_key)
     valu = c.get("SQ_INSTS_VALU")
-    out = {"bound": "mfma", "achieved": executed / t / 1e12, "peak": F16_PEAK / 1e12, "unit": "TFLOP/s", "frac": executed / t / F16_PEAK,
-           "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": f"{COUNTERS} (static: PMC passes over this workload)" if c else None,
-           "kernel": kernel, "kernel_us": t * 1e6, "algorithmic_bytes": algorithmic_bytes,
-           "fractions": {"fp32_equivalent": 2.0 * mults / t / FP32_PEAK, "executed_f16": executed / t / F16_PEAK,
-                         "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None},
-           "fp32_equiv_tflops": 2.0 * mults / t / 1e12,
-           "limiter": "instruction issue: neither the matrix pipes nor HBM are near their roofs; valu_issue is VALU wave-instructions "
-                      "per SIMD and clock (measured ceiling 0.32-0.37 with >= 4 waves per SIMD, profiles/r01_valu_issue_rates.txt)",
-           "note": note}
-    return out
+    return {"bound": bound, "achieved": flops_exec / t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops_exec / t / peak,
+            "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": src,
+            "kernel": kernel, "kernel_us": t * 1e6, "algorithmic_bytes": algorithmic_bytes,
+            "hbm_frac_algorithmic": algorithmic_bytes / t / HBM_PEAK,
+            "fractions": {"fp32_equivalent": flops_alg / t / FP32_PEAK, "executed": flops_exec / t / peak,
+                          "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None},
+            "fp32_equiv_tflops": flops_alg / t / 1e12, "limiter": limiter, "note": note}
 
 
-def kernel_rooflines(eng, launches):
-    """(dominant kernel of the step, all-pairs kernel), each timed alone on the engine's live batch."""
+ISSUE = ("instruction issue / dependent latency: neither the matrix pipes nor HBM are near their roofs; valu_issue is VALU "
+         "wave-instructions per SIMD and clock (measured ceiling 0.32-0.39 with >= 4 waves per SIMD, profiles/r02_valu_issue_rates.txt)")
+
+
+def kernel_rooflines(name, eng, launches):
+    """(dominant kernel of the step, all-pairs kernel or None), each timed alone on the engine's live batch."""
     from encodermap_amd import _lib
 
+    cfg = CONFIGS[name]
     lay = eng.layout
-    n = len(lay.layers)
-    Z = eng.h[lay.n_enc - 1]
-    Bt = eng.B
-    t_sk = _time_launches(lambda: _lib.sketchmap_tiles(eng.xb, Z, float("inf"), SIG, 0, Bt, eng.sk_ws, eng.split_ws), launches)
-    W = D * Bt * (Bt - 1) / 2          # pair-elements per launch (i<->j symmetry exploited): one multiply-add each in the Gram form
-    sk = _record("sk_tile_f16_kernel", "sk_tile_f16", t_sk, W,
-                 "Gram tiles on rows split into two f16 planes, VALU sigmoid epilogue (~40 instructions per pair); 2 FLOP per "
-                 "pair-element over the upper triangle (SURVEY.md section 8d)", 4 * Bt * (D + 2 * 2 + 2) + 4)
-    recs = [sk]
-    if (eng.rb, eng.re) == (0, Bt) and eng._forward():      # one fused launch (single process / replica ranks)
+    Bt, D = eng.B, cfg["D"]
+    recs, sk = [], None
+    dims = [(l.n_in, l.n_out) for l in lay.layers]
+    n_par = sum(k * m + m for k, m in dims)
+    if cfg["model"] == "encodermap" and eng._use_sketchmap() and not eng.dp.active:
+        Z = eng.h[lay.n_enc - 1]
+        sig = eng.p.dist_sig_parameters
+        t_sk = _time_launches(lambda: _lib.sketchmap_tiles(eng.xb, Z, eng.periodicity, sig, 0, Bt, eng.sk_ws, eng.split_ws, data_span=eng._data_span),
+                              launches)
+        W = D * Bt * (Bt - 1) / 2          # pair-elements per launch (i<->j symmetry exploited)
+        abytes = 4 * Bt * (D + 2 * eng.L + eng.L) + 4
+        if eng.periodic:
+            sk = _record(name, "sk_tile_kernel (VALU, fixed-point phases)", "sk_tile_kernel", t_sk, 5 * W, 5 * W, FP32_PEAK, "mfma",
+                         "VALU issue: the pair loop runs at the measured issue ceiling of the vector unit (profiles/r02_tile_counters.json); "
+                         "the fp32 vector peak equals the fp32 matrix peak on this chip",
+                         "direct wrapped differences on the VALU: sub, convert, fma per pair-element over the upper triangle; 5 FLOP per "
+                         "pair-element by SURVEY.md section 8d's count for the periodic form", abytes)
+        else:
+            sk = _record(name, "sk_tile_f16_kernel", "sk_tile_f16", t_sk, 2 * W, 6 * W, F16_PEAK, "mfma", ISSUE,
+                         "Gram tiles on rows split into two f16 planes, VALU sigmoid epilogue (~40 instructions per pair); 2 FLOP per "
+                         "pair-element over the upper triangle (SURVEY.md section 8d), executed three times", abytes)
+        recs.append(sk)
+    if cfg["model"] == "encodermap" and (eng.rb, eng.re) == (0, Bt):
+        fused = eng._forward()
         t_ch = _time_launches(eng._forward, launches)
-        dims = [(l.n_in, l.n_out) for l in lay.layers]
-        mults = Bt * (sum(k * m for k, m in dims) + sum(k * m for k, m in dims[lay.n_enc:]))   # forward + the decoder's dX products
-        n_par = sum(k * m + m for k, m in dims)
-        recs.append(_record("chain_kernel<FUSED>", "chain_kernel<FUSED>", t_ch, mults,
-                            "forward of all layers, auto cost and the decoder's backward pass in one launch per 16-row block; weights "
-                            "from the pre-split operand store, activations split in the epilogue; algorithmic bytes: the batch in, "
-                            "activations + deltas out as f16 fragments for the weight-gradient kernel, one pass over the weights",
-                            4 * Bt * D + 4 * Bt * sum(m for _, m in dims) * 2 + 4 * n_par))
+        mults = Bt * (sum(k * m for k, m in dims) + (sum(k * m for k, m in dims[lay.n_enc:]) if fused else 0))
+        recs.append(_record(name, "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>", "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>",
+                            t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma", ISSUE,
+                            ("forward of all layers, auto cost and the decoder's backward pass" if fused else "forward of all layers (+ auto cost)")
+                            + " in one launch per 16-row block; weights from the pre-split operand store, activations split in the epilogue; "
+                            "algorithmic bytes: the batch in, activations + deltas out as f16 fragments for the weight-gradient kernel, one "
+                            "pass over the weights", 4 * Bt * dims[0][0] + 4 * Bt * sum(m for _, m in dims) * 2 + 4 * n_par))
+    if cfg["model"] == "adc":
+        n = len(lay.layers)
+        t_ch = _time_launches(lambda: _lib.mlp_forward(eng.plan, 0, n, eng.xin, 0, Bt), launches)
+        mults = Bt * sum(k * m for k, m in dims)
+        recs.append(_record(name, "chain_kernel<FWD>", "chain_kernel<FWD>", t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma",
+                            "launch and dependent-trip latency: 256 rows are 16 row blocks on 16 of 256 CUs; the step is priced by its "
+                            "launch count (launches_per_step) and the per-launch floors, DESIGN.md section 4",
+                            "dense layers forward, the largest single launch of the ADC step", 4 * Bt * dims[0][0] + 4 * n_par))
     recs.sort(key=lambda r: -r["kernel_us"])
-    return recs[0], sk
+    return recs[0], (sk if sk is not None and sk is not recs[0] else None)
+
+
+def launches_per_step(eng):
+    """kernel launches of one step: counted by the library itself across one eager step (state saved and restored)"""
+    import torch
+
+    from encodermap_amd import _lib
+
+    lib = _lib.load()
+    saved = [t.clone() for t in eng._state_tensors()]
+    torch.cuda.synchronize()
+    n0 = lib.emx_launch_count()
+    eng._step_body()
+    n1 = lib.emx_launch_count()
+    torch.cuda.synchronize()
+    for t, sv in zip(eng._state_tensors(), saved):
+        t.copy_(sv)
+    eng._sync_derived_state()
+    if eng._prefetch:
+        eng._gather_current()
+    return int(n1 - n0)
 
 
 def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
@@ -178,8 +370,6 @@ def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
     a hipGraph works with this many ranks on this machine (encodermap_amd/_probe_graph_allreduce.py).  Passed on every
     rank: the data-parallel step runs as one graph, eight steps per replay; failed, or hung until the
     timeout (the child is killed, its queues go with it): the all-reduce stays eager between two graphs."""
-    import subprocess
-
     # the children rendezvous among themselves: nothing of the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE makes
     # rank 0 a CLIENT of the launcher's store, which does not listen on the probe's port)
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
@@ -198,19 +388,55 @@ def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
         return False
 
 
+def facade_timing(em, cfg, data, device, steps):
+    """``em.EncoderMap.train()`` -- the reference's entry point (autoencoder.py:967-1029) -- on the same workload: ms per step with
+    the default callbacks and with the progress read-out (one loss per ``summary_step`` steps fetched from the device)."""
+    import numpy as np
+    import torch
+
+    out = {}
+    B, D = cfg["kw"].get("batch_size", 256), cfg["D"]
+    for label, progress in (("defaults", False), ("progress", True)):
+        warm = 64
+        p = em.Parameters(n_steps=warm, seed=7, **cfg["kw"])
+        stderr = sys.stderr
+        try:
+            sys.stderr = open(os.devnull, "w")      # (the progress read-out writes a line per summary step)
+            e = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=device, progress=progress)
+            e._engine.set_data(data)
+            e.train()                                # captures the step's graphs
+            e.p.n_steps += steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e.train()
+            torch.cuda.synchronize()
+            out[label] = (time.perf_counter() - t0) / steps * 1e3
+        finally:
+            sys.stderr = stderr
+        del e
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--rows", type=int, default=0, help="rows of the resident training set (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dp-mode", default="replica", choices=["replica", "rowblock"])
-    ap.add_argument("--global-batch", type=int, default=B,
-                    help="--dp-mode rowblock: rows of the ONE global batch all ranks share (0: 4096 per rank)")
+    ap.add_argument("--no-facade", action="store_true")
+    ap.add_argument("--dp-mode", default=None, choices=["replica", "rowblock"])
+    ap.add_argument("--global-batch", type=int, default=-1,
+                    help="--dp-mode rowblock: rows of the ONE global batch all ranks share (default: the configuration's batch; 0: that batch per rank)")
     ap.add_argument("--one-rank-dp", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL code path (probe, RCCL group, all-reduce) with its one rank -- a self-test, "
                          "not a benchmark configuration")
     args = ap.parse_args()
+    name = args.config
+    cfg = CONFIGS[name]
+    B = cfg["kw"].get("batch_size", 256)
+    D = cfg["D"]
 
     import torch
 
@@ -220,6 +446,10 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # C4 / C5 are DEFINED on 8 GPUs as ONE global batch: the objective-preserving row-block partition
+    dp_mode = args.dp_mode or ("rowblock" if name in ("C4", "C5") else "replica")
+    if cfg["model"] == "adc":
+        dp_mode = "replica"      # (the ADC step runs as replicas: one collective per step)
     # self-test hooks (not benchmark configurations): EMX_BENCH_ONE_DEVICE=1 puts every rank on cuda:0 and EMX_BENCH_BACKEND=gloo
     # replaces RCCL, so that the N > 1 plumbing of this script can be run with two ranks on a one-GPU box
     one_device = os.environ.get("EMX_BENCH_ONE_DEVICE") == "1"
@@ -251,6 +481,8 @@ def main():
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
+    import numpy as np
+
     import encodermap_amd as em
     from encodermap_amd.engine import DataParallel, SequentialEngine
 
@@ -261,19 +493,28 @@ def main():
         graph_allreduce = bool(float(flag) == 1.0)
         SequentialEngine._dp_graph_allreduce = graph_allreduce
 
-    rowblock = args.dp_mode == "rowblock" and world > 1
-    batch = (args.global_batch or B * world) if rowblock else B     # rows per engine step: the rank's own batch, or the shared one
-    p = em.Parameters(periodicity=float("inf"), batch_size=batch, dist_sig_parameters=SIG, n_steps=args.steps + args.warmup, seed=7)
-    dp = DataParallel(rank, world, args.dp_mode) if world > 1 else None
+    rowblock = dp_mode == "rowblock" and world > 1
+    gb = B if args.global_batch < 0 else args.global_batch
+    batch = (gb or B * world) if rowblock else B     # rows per engine step: the rank's own batch, or the shared one
+    dp = DataParallel(rank, world, dp_mode) if world > 1 else None
     if multi and world == 1:
         class _OneRank(DataParallel):      # the data-parallel path with the one rank a single GPU allows
             active = True
 
-        dp = _OneRank(0, 1, args.dp_mode)
-    data = make_blobs(device, N_ROWS, D, seed=1)
-    e = em.EncoderMap(p, __import__("numpy").zeros((batch, D), "float32"), read_only=True, device=device, dp=dp)
-    eng = e._engine
-    eng.set_data(data)                      # 512 MB, resident in HBM before the timed region
+        dp = _OneRank(0, 1, dp_mode)
+    n_rows = args.rows or cfg["rows"]
+    kw = dict(cfg["kw"], batch_size=batch)
+    if cfg["model"] == "adc":
+        p = em.ADCParameters(n_steps=args.steps + args.warmup, seed=7, **kw)
+        e = em.AngleDihedralCartesianEncoderMap(make_backbone(cfg, n_rows), p, read_only=True, device=device, dp=dp)
+        eng = e._engine
+        data = None
+    else:
+        p = em.Parameters(n_steps=args.steps + args.warmup, seed=7, **kw)
+        data = make_data(cfg, device, n_rows)
+        e = em.EncoderMap(p, np.zeros((batch, D), "float32"), read_only=True, device=device, dp=dp)
+        eng = e._engine
+        eng.set_data(data)                      # resident in HBM before the timed region (C2: 512 MB, C4: 4 GB)
 
     def barrier():
         if multi:
@@ -300,8 +541,8 @@ def main():
                          f"dense layers on {world} runs of 16-row blocks, the upper-triangle tiles of the all-pairs pass dealt round-robin")
             scaling = "strong" if batch == B else "weak"
         else:
-            objective = (f"mean of {world} independent sketch-map costs over {B} rows each (gradients averaged)" if world > 1
-                         else f"one sketch-map cost over one batch of {B} rows")
+            objective = (f"mean of {world} independent costs over {B} rows each (gradients averaged)" if world > 1
+                         else f"one cost over one batch of {B} rows")
             scaling = "weak"
         rccl = None
         if multi and backend == "nccl":
@@ -313,22 +554,29 @@ def main():
             "metric": "train_samples_per_sec", "value": global_batch * args.steps / dt, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "steps_per_sec": args.steps / dt, "higher_is_better": True,
-            "scaling": scaling, "vs_baseline": None, "dtype": DTYPE, "data": "synthetic",
-            "config": {"workload": "C2: EncoderMap training, 1e6x128 Gaussian blobs resident in HBM, "
-                                   + (f"one batch of {batch} rows over all GPUs, " if rowblock else "batch 4096 per GPU, ")
-                                   + "sketch-map sigmoid loss (Euclidean), sig=(16,12,6,1,2,6)",
-                       "global_batch": global_batch, "features": D, "parallelism": f"dp{world}-{args.dp_mode}" if world > 1 else "single",
-                       "objective": objective,
+            "scaling": scaling, "vs_baseline": None, "dtype": DTYPES[cfg["kind"]], "data": "synthetic",
+            "config": {"workload": cfg["workload"] + (f" [one batch of {batch} rows over all GPUs]" if rowblock else
+                                                      (f" [batch {B} per GPU]" if world > 1 else "")),
+                       "name": name, "rows_resident": int(n_rows), "global_batch": global_batch, "features": D,
+                       "parallelism": f"dp{world}-{dp_mode}" if world > 1 else "single", "objective": objective,
                        "ranks_seen": dist.get_world_size() if multi else 1, "backend": backend if multi else None, "rccl_version": rccl,
                        "allreduce": ("captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None,
                        "graph_allreduce_probe": probe,
                        **({"self_test": f"backend {backend}, one device: {one_device}"} if (one_device or backend != "nccl") else {}),
-                       "hip_graph": True},
+                       "hip_graph": True, "commit": git_head()},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }
-        out["roofline"], out["roofline_all_pairs"] = kernel_rooflines(eng, max(args.steps, 50))
+        out["roofline"], ap_rec = kernel_rooflines(name, eng, max(min(args.steps, 200), 50))
+        if ap_rec is not None:
+            out["roofline_all_pairs"] = ap_rec
+        if not multi:
+            out["launches_per_step"] = launches_per_step(eng)
+        if world == 1 and not multi and not args.no_facade and name == "C2":
+            f = facade_timing(em, cfg, data, device, max(args.steps, 2000))
+            out["facade_ms_per_step"] = f["defaults"]
+            out["facade_progress_ms_per_step"] = f["progress"]
         if world == 1 and not multi and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(name)
         # RCCL writes its version banner to the C-level stdout, which is flushed at exit -- behind this line unless it is
         # flushed first; the JSON line must be the last thing on stdout
         try:

@@ -20,6 +20,10 @@ thread_local char g_err[512] = "";
 
 namespace emx {
 char* error_buffer() { return g_err; }
+long long& launch_counter() {
+  static long long n = 0;
+  return n;
+}
 }  // namespace emx
 
 namespace {
@@ -747,6 +751,7 @@ extern "C" {
 int emx_version(void) { return EMX_VERSION; }
 const char* emx_last_error(void) { return g_err; }
 const char* emx_target_arch(void) { return "gfx950"; }
+int64_t emx_launch_count(void) { return (int64_t)emx::launch_counter(); }
 
 int emx_permute(int64_t* out, int64_t n, uint64_t seed, uint64_t epoch, emx_stream_t stream) {
   EMX_REQUIRE(out && n > 0, "emx_permute: bad arguments");

@@ -12,6 +12,8 @@ namespace emx {
 
 // thread-local text of the last rejected call (emx_last_error)
 char* error_buffer();
+// launches issued so far (emx_launch_count)
+long long& launch_counter();
 
 inline int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -22,6 +24,7 @@ inline int fail(int code, const char* fmt, ...) {
 }
 
 inline int check_launch(const char* what) {
+  ++launch_counter();
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return fail(EMX_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
   return EMX_OK;

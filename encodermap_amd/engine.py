@@ -548,14 +548,15 @@ class SequentialEngine:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, capture_error_mode="thread_local"):
                         self._step_body()
-                    gm = None
-                    if self._graph_steps > 1:
+                    gm = {}
+                    for k in self._multi_sizes():
                         restore()
-                        gm = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(gm, pool=g.pool(), capture_error_mode="thread_local"):
-                            for _ in range(self._graph_steps):
+                        gk = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(gk, pool=g.pool(), capture_error_mode="thread_local"):
+                            for _ in range(k):
                                 self._step_body()
-                    self._graph, self._graph_multi, captured = (g,), gm, True
+                        gm[k] = gk
+                    self._graph, self._graph_multi, captured = (g,), (gm or None), True
                 except Exception as exc:   # fall back to the two-graph form
                     print(f"encodermap_amd: capturing the all-reduce failed ({type(exc).__name__}: {exc}); using the eager all-reduce")
                     self._dp_graph_allreduce = False
@@ -579,24 +580,35 @@ class SequentialEngine:
                 self._graph = (g,)
                 # the same step several times over in one graph: every kernel reads the device-side counters, so replaying
                 # it is the same as replaying the single-step graph that often, minus the launch gaps between graphs
-                if self._graph_steps > 1:
+                gm = {}
+                for k in self._multi_sizes():
                     restore()
-                    gm = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(gm, pool=g.pool()):
-                        for _ in range(self._graph_steps):
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk, pool=g.pool()):
+                        for _ in range(k):
                             self._step_body()
-                    self._graph_multi = gm
+                    gm[k] = gk
+                self._graph_multi = gm or None
         finally:
             if gc_was_on:
                 gc.enable()
         # first replays are slower than later ones (the graph's kernels and nodes are uploaded on first use): pay that here,
         # not inside the first timed multi-step replay of a short warm-up
         restore()
-        for g in (self._graph_multi, *((self._graph if len(self._graph) == 1 else ()))):
-            if g is not None:
-                g.replay()
+        for g in (*(self._graph_multi or {}).values(), *((self._graph if len(self._graph) == 1 else ()))):
+            restore()
+            g.replay()
         torch.cuda.synchronize()
         restore()
+
+    def _multi_sizes(self):
+        """steps per replay of the multi-step graphs: the largest (EMX_GRAPH_STEPS, default 8) and its halves down to 2, so that
+        a short run needs no single-step replays (every replay costs a graph-launch gap of ~10 us on the host side)"""
+        out, k = [], self._graph_steps
+        while k > 1:
+            out.append(k)
+            k //= 2
+        return out
 
     def _replay(self) -> None:
         if len(self._graph) == 1:
@@ -642,10 +654,11 @@ class SequentialEngine:
                 if self._graph is None:
                     self._capture()
                 r = k
-                if len(self._graph) == 1 and self._graph_multi is not None:
-                    while r >= self._graph_steps:
-                        self._graph_multi.replay()
-                        r -= self._graph_steps
+                if len(self._graph) == 1 and self._graph_multi:
+                    for size in sorted(self._graph_multi, reverse=True):   # 8, 4, 2: 20 steps are 8 + 8 + 4, three replays
+                        while r >= size:
+                            self._graph_multi[size].replay()
+                            r -= size
                 for _ in range(r):
                     self._replay()
             else:

@@ -47,6 +47,11 @@ int emx_version(void);
 const char* emx_last_error(void);
 /* name of the device the library was built for ("gfx950"); used by the host side to fail loudly */
 const char* emx_target_arch(void);
+/* number of kernel launches this library has issued in the calling process so far (every entry point counts the launches it
+ * makes, captured into a hipGraph or not): the difference across one training step is the step's launch count -- what a
+ * launch-bound configuration is priced by (bench.py: launches_per_step; the reference's train_step, models.py:3367-3401, is
+ * ~10^2 TensorFlow op launches) */
+int64_t emx_launch_count(void);
 
 /* ------------------------------------------------------------------------------------------------ *
  * K1/K2  sketch-map sigmoid pairwise-distance cost, forward + gradient wrt the latent

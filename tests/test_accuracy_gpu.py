@@ -1,0 +1,41 @@
+"""The split-f16 arithmetic of the engine against TRUE float32: per quantity of a training step the engine's error against the
+float64 oracle must not exceed twice the error of a float32 run of the reference formulation (tests/accuracy.py; the table
+itself: tools/split_accuracy.py -> profiles/r03_split_accuracy.txt).  Needs an MI355X."""
+import numpy as np
+import pytest
+
+from tests import accuracy as A
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def em():
+    import encodermap_amd as em
+    from encodermap_amd import _lib
+
+    _lib.require_gpu()
+    return em
+
+
+def _check(table, factor=2.0, floor=2e-7):
+    """engine rms error <= factor x float32-oracle rms error (+ a floor of a few float32 ulps: where the float32 oracle happens
+    to be exact -- a bias gradient that is a plain sum -- the ratio means nothing)"""
+    bad = {k: v for k, v in table.items() if v["engine"][0] > factor * v["oracle_f32"][0] + floor}
+    assert not bad, A.format_table("engine worse than 2 x float32:", bad)
+
+
+@pytest.mark.parametrize("name", list(A.SHAPES))
+def test_dense_layers_are_float32_accurate(em, name):
+    table = A.dense_layer_errors(em, name)
+    print(A.format_table(name, table))
+    _check(table)
+
+
+@pytest.mark.parametrize("B,D", [(4096, 128), (1024, 256)])
+def test_all_pairs_pass_is_float32_accurate_far_from_the_origin(em, B, D):
+    table = A.all_pairs_errors(B, D)
+    print(A.format_table(f"all-pairs pass ({B}, {D}), data 40 sigma off the origin", table))
+    _check(table)
+    # and in absolute terms: the cost to 1e-5, the gradient to 2e-5 of its largest entry (the kernels' own tolerances)
+    assert table["distance cost"]["engine"][0] < 1e-5 and table["dZ (latent gradient)"]["engine"][1] < 2e-5

@@ -493,7 +493,9 @@ def test_adc_head_beside_the_optimizer(L, B, with_means):
         if cur + 1 < n_batches:
             feat2, cart2, xin2 = (torch.full((B, k), -7.0, device="cuda") for k in (F, 3 * A, W))
             sc2, mean2 = torch.full((1,), -7.0, device="cuda"), torch.full((F,), -7.0, device="cuda")
-            L.adc_batch_head(feat_data, cart_data, idx, torch.tensor([cur + 1], device="cuda"), B, feat2, cart2, parts, 2 * PI, xin2, step, *soft, sc2,
+            # (this optimizer call runs BEFORE the step's bookkeeping -- no bookkeeping_done --, so the head it prepares belongs to the
+            #  step behind the counter's: batch cursor + 1 AND the soft-start scale of step + 1)
+            L.adc_batch_head(feat_data, cart_data, idx, torch.tensor([cur + 1], device="cuda"), B, feat2, cart2, parts, 2 * PI, xin2, step + 1, *soft, sc2,
                              feat_mean=mean2 if with_means else None)
             torch.cuda.synchronize()
             assert torch.equal(feat, feat2) and torch.equal(cart, cart2) and torch.equal(xin, xin2) and torch.equal(sc, sc2)

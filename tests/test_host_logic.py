@@ -276,7 +276,7 @@ def test_library_exports_every_declared_symbol():
     from encodermap_amd import _lib
 
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "emx.h")).read(), flags=re.S)
-    declared = set(re.findall(r"^(?:int|size_t|const char\*)\s+(emx_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|size_t|const char\*)\s+(emx_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     if not os.path.isfile(_lib.LIB_PATH):
         pytest.skip("libemx.so not built (run __graft_entry__.build())")
