@@ -37,6 +37,7 @@
 #include "cost.h"
 #include "emx_common.h"
 #include "finish.h"
+#include "sk_tile.h"
 #include "wop.h"
 
 namespace {
@@ -93,7 +94,7 @@ __device__ __forceinline__ unsigned row16_max(unsigned x) {
 // store: results leave through buffer resources whose bounds check drops what does not exist), so that every s_waitcnt
 // the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
 // ---------------------------------------------------------------------------------------------------------
-enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4 };
+enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8 };   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
 
 struct GemmRec {          // one layer of the range in one direction: P x C regular units (128 columns x 128 k)
   int P, C;               // passes of 128 output columns, chunks of 128 reduction indices
@@ -155,13 +156,18 @@ struct IC_ {
   static constexpr int value = V;
 };
 
-// (the leading scalars duplicate what the first loads of a workgroup need -- the row block's source, the auto cost's targets:
-//  preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count), those loads go out with the first
-//  instructions instead of behind a trip to the argument segment; 56 bytes, the struct follows at offset 56)
-template <int MODE, int NB>
-__global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
-                                                    int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
-                                                    const ChainArgs a) {
+// where the chain workgroups of a launch that also runs all-pairs tiles (chain_tiles_kernel) publish the latent rows
+struct PubArgs {
+  float* zpub;        // [B][n] rows of the published layer
+  unsigned* ready;    // counter of workgroups that have published
+};
+
+// The kernel's body as a function, so that chain_kernel and chain_tiles_kernel (below) share it.  PUB: the forward GEMM flagged
+// S_PUB hands its rows to the tile workgroups of the same launch (sk_tile.h).
+template <int MODE, int NB, bool PUB>
+__device__ __forceinline__ void chain_body(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
+                                           int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
+                                           const ChainArgs& a, const PubArgs& pub) {
   constexpr bool BWD = MODE == CHAIN_BWD;
   constexpr int NE = BWD ? 4 : 1;   // epilogue operands per lane: h of 4 rows (backward) or the bias of its column
   extern __shared__ __align__(16) char lds[];
@@ -622,6 +628,22 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
     // the layer's rows are complete in the destination image when its last unit is done
     const bool layer_end = last && ex.p == ex.P - 1;
     if (layer_end) __syncthreads();
+    if constexpr (PUB) {
+      if (layer_end && (sflags & S_PUB)) {
+        // the latent rows for the tile workgroups of this launch (sk_tile.h): from the layer's float32 copy in LDS, by ONE wave, as
+        // write-through stores (16 rows x 2 columns are one 128-byte line); the wave drains them, then its lane 0 reports in
+        if (wave == 0) {
+          const float* zc = reinterpret_cast<const float*>(lds + X.dst_f32);
+          const int nL = X.n;
+          for (int e = lane; e < R * nL; e += 64) {
+            const int row = e / nL, c = e - row * nL;
+            if (row < rows_valid) emx::sk::store_sc1(pub.zpub + (long)(r0 + row) * nL + c, zc[row * X.dst_f32_pitch + c]);
+          }
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (lane == 0) __hip_atomic_fetch_add(pub.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
     TSTAMP(7 + 5 * ui);
     ex = exn;
     X = Xn;
@@ -792,6 +814,33 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
   __syncthreads();
   if (blockIdx.x == 0 || blockIdx.x == 100) emx_dbg[(blockIdx.x ? 2048 : 0) + tid] = dbg_lds[tid];
 #endif
+}
+
+// (the leading scalars duplicate what the first loads of a workgroup need -- the row block's source, the auto cost's targets:
+//  preloaded into scalar registers at wave launch (-amdgpu-kernarg-preload-count), those loads go out with the first
+//  instructions instead of behind a trip to the argument segment; 56 bytes, the struct follows at offset 56)
+template <int MODE, int NB>
+__global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
+                                                    int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
+                                                    const ChainArgs a) {
+  chain_body<MODE, NB, false>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a, PubArgs{nullptr, nullptr});
+}
+
+// The fused launch with the all-pairs tiles aboard (sk_tile.h): workgroups [0, row blocks) are the chain workgroups, the rest run two
+// tiles each.  128 registers per lane: a chain workgroup (two waves per SIMD) and a tile workgroup share a CU.  The role is
+// told from the preloaded scalars alone (the chain workgroups' first loads must not wait for a trip to the arguments).
+template <int NB, bool FASTSIG, int NCH>
+__global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_tiles_kernel(
+    const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols, int p_row0, int p_row_end, int p_ldt, int p_cost_n,
+    int p_in_Q, int p_with_cost, const ChainArgs a, const emx::sk::TileRole tr) {
+  const int n_chain = (p_row_end - p_row0 + R - 1) / R;
+  if ((int)blockIdx.x >= n_chain) {
+    extern __shared__ __align__(16) char lds[];
+    emx::sk::tile_pair_role<FASTSIG, NCH>(lds, tr, (int)blockIdx.x - n_chain);
+    return;
+  }
+  chain_body<CHAIN_FUSED, NB, true>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a,
+                                    PubArgs{const_cast<float*>(tr.zpub), tr.sync});
 }
 
 // The operand store from the flat parameter buffer (the optimizer keeps it current afterwards).  Two launches: the layers'
@@ -1406,10 +1455,34 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   return launch_chain<CHAIN_BWD>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (backward)");
 }
 
-int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
-                             int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
-                             float* const* delta, float* dbelow, void* aop, int aop_rows, emx_stream_t stream) {
-  const char* who = "emx_mlp_forward_backward";
+}  // extern "C"
+
+namespace {
+// what emx_mlp_forward_backward_tiles adds to the fused launch
+struct TilesHost {
+  const float* X;
+  int B, D, ldx;
+  const float* sig;
+  void* sk_ws;
+  size_t sk_ws_bytes;
+  void* split_ws;
+  float* zpub;
+  unsigned* sync;
+};
+
+template <bool FAST, int NCH>
+int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
+  int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH>), lds, b.who);
+  if (rc) return rc;
+  hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
+                     b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a, tr);
+  return emx::check_launch("mlp chain kernel (forward + cost + backward, all-pairs tiles aboard)");
+}
+
+int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                          int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                          float* const* delta, float* dbelow, void* aop, int aop_rows, const TilesHost* tiles, const char* who,
+                          emx_stream_t stream) {
   int rc = check_desc(desc, who);
   if (rc) return rc;
   EMX_REQUIRE(params && mirror && h && in && cost && delta, "%s: null pointer argument", who);
@@ -1442,9 +1515,12 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
     const int gi = b.add_gemm(l, false, st & 1, st > 0 && desc->act[l - 1], last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l],
                               desc->act[l] ? S_ACT : 0, ao);
     if (gi < 0) return gi;
-    // float32 copy of h_l in LDS: the cost's input (last layer) or the activation derivative of the backward units
+    // float32 copy of h_l in LDS: the cost's input (last layer), the activation derivative of the backward units, or the rows
+    // the tile workgroups of the launch are waiting for (the latent layer, bwd_begin - 1)
     const bool for_bwd = desc->act[l] && l >= bwd_begin && l < top;
-    if (last || for_bwd) {
+    const bool for_tiles = tiles != nullptr && l == bwd_begin - 1;
+    if (for_tiles) a.g[gi].sflags |= S_PUB;
+    if (last || for_bwd || for_tiles) {
       GemmRec& G = a.g[gi];
       G.dst_f32_pitch = hpitch[l] = ChainBuilder::f32_pitch(desc->width[l + 1]);
       G.dst_f32 = hcopy[l] = b.alloc(R * G.dst_f32_pitch * 4);
@@ -1490,7 +1566,54 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
   a.in_aop = (aop && layer_begin == 0) ? aop_tensor(aop, AL, 0) : AopTensor{nullptr, nullptr, 0};
   a.row0 = row_begin;
   a.row_end = row_end;
-  return launch_chain<CHAIN_FUSED>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (forward + cost + backward)");
+  if (tiles == nullptr)
+    return launch_chain<CHAIN_FUSED>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (forward + cost + backward)");
+  // ---- the all-pairs tiles as extra workgroups of this launch (sk_tile.h)
+  EMX_REQUIRE(layer_begin == 0 && bwd_begin >= 1 && bwd_begin < layer_end, "%s: the tiles need the encoder's layers in the launch", who);
+  EMX_REQUIRE(row_begin == 0 && row_end == tiles->B, "%s: the tiles run over the whole batch (rows [0, %d))", who, tiles->B);
+  EMX_REQUIRE(tiles->zpub && tiles->sync, "%s: null pointer argument (tile role)", who);
+  emx::sk::TileRole tr{};
+  int vblocks = 0, nch = 0;
+  bool fast = false;
+  rc = emx::sk::make_tile_role(tiles->X, tiles->B, tiles->D, tiles->ldx, h[bwd_begin - 1], desc->width[bwd_begin], tiles->sig, tiles->sk_ws, tiles->sk_ws_bytes,
+                               tiles->split_ws, &tr, &vblocks, &nch, &fast, who);
+  if (rc) return rc;
+  const int n_chain = (row_end - row_begin + R - 1) / R;
+  tr.zpub = tiles->zpub;
+  tr.sync = tiles->sync;
+  tr.n_chain = n_chain;
+  tr.n_tile_wgs = tr.a.xcd_nbg > 0 ? vblocks / 2 : (vblocks + 1) / 2;
+  const size_t lds = std::max((size_t)b.lds, (size_t)emx::sk::TILE_ROLE_LDS_BYTES);
+  const int grid = n_chain + tr.n_tile_wgs;
+  hipStream_t st = (hipStream_t)stream;
+  static_assert(sizeof(ChainArgs) + sizeof(emx::sk::TileRole) + 56 <= 4096, "kernel arguments of chain_tiles_kernel");
+  if (!fast) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role is built for the (12, 6 | 2, 6) sigmoid family", who);
+  switch (nch) {
+    case 1: return launch_chain_tiles<true, 1>(b, tr, grid, lds, st);
+    case 2: return launch_chain_tiles<true, 2>(b, tr, grid, lds, st);
+    case 4: return launch_chain_tiles<true, 4>(b, tr, grid, lds, st);
+    case 8: return launch_chain_tiles<true, 8>(b, tr, grid, lds, st);
+    default: return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role is built for rows of 32, 64, 128 or 256 features (got %d chunks)", who, nch);
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                             int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                             float* const* delta, float* dbelow, void* aop, int aop_rows, emx_stream_t stream) {
+  return forward_backward_impl(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop,
+                               aop_rows, nullptr, "emx_mlp_forward_backward", stream);
+}
+
+int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                                   int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                                   float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, const float sig[6],
+                                   void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub, uint32_t* sync, emx_stream_t stream) {
+  TilesHost t{X, row_end - row_begin, D, ldx, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync};
+  return forward_backward_impl(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop,
+                               aop_rows, &t, "emx_mlp_forward_backward_tiles", stream);
 }
 
 // rows per slice: EMX_WGRAD_SLICE_ROWS, doubled until at most EMX_WGRAD_MAX_SLICES slices remain -- every slice costs a

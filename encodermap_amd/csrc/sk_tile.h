@@ -1,0 +1,406 @@
+// What the all-pairs tile kernels share with the fused dense-layer launch that runs the tiles beside the decoder (mlp.hip,
+// chain_tiles_kernel): the argument record, the two sigmoid forms and the tile orders.  See sketchmap.hip for the algorithm.
+#pragma once
+#include "emx_common.h"
+#include "split.h"
+
+namespace emx {
+namespace sk {
+
+struct SigDev {
+  float k6;         // fast high-d form (a = 12, b = 6): inv_sig2 * c^(1/6), so that c v^6 = (k6 d^2)^6
+  float c_inv;      // fast low-d form (a = 2): c / sig^2
+  float inv_sig2;   // 1/sig^2
+  float c;          // 2^(a/b) - 1
+  float half_a;     // a/2
+  float nba;        // -b/a
+  float half_am2;   // (a-2)/2
+  float vmax;       // clamp on (d/sig)^2 so that v^(a/2) stays finite
+  int a_is_2;
+};
+
+struct SkArgs {
+  const float* X;
+  const float* Z;
+  float* P;          // [nslots][nrows_pad][L]
+  float* tile_loss;  // [ntiles]
+  int B, D, ldx, L;
+  int row0, row_end;  // rows handled: [row0,row_end)
+  int nbr, nbc;       // tile rows / tile columns
+  int nrows_pad;
+  int symm;
+  int vec4;
+  float period;
+  float rp_hi, rp_lo, phase_unit2;   // fixed-point periodic tiles: 1 / period in two floats, (period / 2^32)^2
+  int phase_ok;                      // the data span less than 1.5 periods: the fixed-point tiles may run
+  SigDev sh, sl;
+  SplitRows split;   // optional f16 planes + norms of the rows (split.h): selects the f16 Gram kernel
+  int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
+  // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of a first launch
+  // (kmode 1: Gram partial of its chunks -> kpart), a second launch (kmode 2) adds them up in a fixed order and runs the
+  // epilogue.  kmode 0: one workgroup per tile does both.
+  int ksplit, kmode;
+  float* kpart;      // [tiles][ksplit][4 waves][16][64]
+  // data parallel: the upper-triangle tiles are DEALT to the ranks -- tile t (row-major triangle index)
+  // belongs to rank t % deal_world; a workgroup of another rank's tile leaves at once (its cost slot zeroed).  0 / 1: off.
+  int deal_rank, deal_world;
+};
+__device__ __forceinline__ bool dealt_away(const SkArgs& a, int tslot) {
+  if (a.deal_world <= 1 || tslot % a.deal_world == a.deal_rank) return false;
+  if (threadIdx.x == 0) a.tile_loss[tslot] = 0.f;
+  return true;
+}
+
+template <int N>
+__device__ __forceinline__ float powi(float v) {
+  if constexpr (N == 0) return 1.f;
+  else if constexpr (N == 1) return v;
+  else if constexpr (N % 2 == 0) { float h = powi<N / 2>(v); return h * h; }
+  else return v * powi<N - 1>(v);
+}
+
+// complement of the sketch-map sigmoid, E(v) = (1 + c v^(a/2))^(-b/a), v = (d/sig)^2   (distances.py:86)
+template <bool FAST>
+__device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
+  if constexpr (FAST) {  // a = 12, b = 6: E = (1 + w^6)^(-1/2), w = d^2 c^(1/6) / sig^2 -- four instructions in front of the rsq; an
+                         // overflowing w^6 gives q = inf, rsq = 0: the correct limit; a d^2 that rounding made slightly negative
+                         // enters through an even power, so the caller needs no clamp at 0
+    const float w = d2 * s.k6;
+    const float w3 = w * w * w;
+    return __builtin_amdgcn_rsqf(fmaf(w3, w3, 1.f));
+  } else {
+    float v = fminf(d2 * s.inv_sig2, s.vmax);
+    float t = __builtin_amdgcn_exp2f(s.half_a * __builtin_amdgcn_logf(v));
+    float q = fmaf(s.c, t, 1.f);
+    return __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
+  }
+}
+
+// low-d: E and G = S'(d)/d / (b c / sig^2) = v^((a-2)/2) * q^(-b/a-1)
+template <bool FAST>
+__device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, float& G) {
+  if constexpr (FAST) {  // a = 2, b = 6
+    float q = fmaf(s.c_inv, d2, 1.f);
+    float r = __builtin_amdgcn_rcpf(q);
+    E = r * r * r;
+    G = E * r;
+  } else {
+    float v = fminf(d2 * s.inv_sig2, s.vmax);
+    float lv = __builtin_amdgcn_logf(v);
+    float t = __builtin_amdgcn_exp2f(s.half_a * lv);
+    float q = fmaf(s.c, t, 1.f);
+    E = __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
+    float um = s.a_is_2 ? 1.f : __builtin_amdgcn_exp2f(s.half_am2 * lv);
+    G = um * E * __builtin_amdgcn_rcpf(q);
+    G = (v > 0.f) ? G : 0.f;  // reference mask: coincident latent points carry no gradient
+  }
+}
+
+// upper-triangle linear index -> (ti, tj), ti <= tj < nb, row-major
+__device__ __forceinline__ void tri_decode(int t, int nb, int& ti, int& tj) {
+  float fn = 2.f * nb + 1.f;
+  int i = (int)((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
+  i = max(0, min(i, nb - 1));
+  while (i > 0 && (i * nb - i * (i - 1) / 2) > t) --i;
+  while ((i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
+  ti = i;
+  tj = i + (t - (i * nb - i * (i - 1) / 2));
+}
+
+// XCD-aware order of the upper-triangle tiles.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one,
+// observed, speed only -- nothing below depends on it for correctness), each XCD has its own L2, and a tile needs the
+// planes of its row panel and of its column panel.  In row-major triangle order every XCD ends up pulling ALL panels
+// through the fabric (8 x 2 MB at C2, while all 2048 resident tiles stage at once).  Here the panels form four groups
+// and the triangle ten group pairs: the six off-diagonal pairs (nbg^2 tiles each) go to the blocks with b % 8 = 0..5, the
+// four diagonal ones (nbg (nbg + 1) / 2 tiles each) two by two to b % 8 = 6, 7 -- every XCD touches half of the panels,
+// 256 / 272 tiles at C2.  Blocks beyond an XCD's share (and tiles beyond a ragged last group) leave at once.
+// Returns false for such a block; t = the tile's index in row-major triangle order (its tile_loss slot).
+__device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int& tj, int& t) {
+  const int x = bid & 7, k = bid >> 3;
+  int gi, gj, li, lj;
+  if (x < 6) {
+    gi = x < 3 ? 0 : (x < 5 ? 1 : 2);
+    gj = x < 3 ? x + 1 : (x < 5 ? x - 1 : 3);
+    if (k >= nbg * nbg) return false;
+    li = k / nbg;
+    lj = k - li * nbg;
+  } else {
+    const int T2 = nbg * (nbg + 1) / 2;
+    if (k >= 2 * T2) return false;
+    const int second = k >= T2 ? 1 : 0;
+    gi = gj = 2 * (x - 6) + second;
+    tri_decode(k - second * T2, nbg, li, lj);
+  }
+  ti = gi * nbg + li;
+  tj = gj * nbg + lj;
+  if (ti >= nbc || tj >= nbc) return false;
+  t = ti * nbc - ti * (ti - 1) / 2 + (tj - ti);
+  return true;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The all-pairs tiles as a ROLE inside the fused dense-layer launch (mlp.hip: chain_tiles_kernel).
+//
+// The tile pass needs the batch rows (split planes, left by the optimizer launch of the step in front) and the latent rows --
+// which the first three of the fused launch's fifteen units produce.  As a launch of its own it ran behind the WHOLE fused launch
+// (decoder forward, auto cost, decoder backward: ~15 of its ~24 us at B = 4096) although it depends on none of that.  Here the
+// tiles are extra workgroups of the fused launch: workgroups [0, n_chain) push their 16-row blocks through the layers and PUBLISH
+// their latent rows when the encoder's last layer is done (write-through stores, then one agent-scope add to a counter);
+// workgroups [n_chain, ...) each take TWO tiles (a 512-thread workgroup = two 4-wave halves in lockstep: the barriers are
+// workgroup-wide), run the Gram products -- which need no latent -- at once, wait for the counter, and run the sigmoid epilogue
+// under the decoder half of the chain workgroups.  Per tile the arithmetic, the order of every addition and the slots the
+// partial sums go to are those of sk_tile_f16_kernel<2, FASTSIG, NCH>: the results are bit-identical to the separate launches.
+//
+// Progress: the chain workgroups never wait for anything, and the dispatcher hands out workgroups in index order (per XCD), so
+// every chain workgroup is resident before a tile workgroup of its XCD can occupy a slot; the spin below is nevertheless
+// BOUNDED -- on expiry the workgroup raises sync[2] and carries on (wrong numbers, reported by the host, never a hang).
+// Visibility (MI355X_MICROARCH.md, inter-workgroup visibility): every published byte is stored with sc1 by ONE wave, which
+// drains its stores (s_waitcnt vmcnt(0)) before its lane 0 adds to the counter at agent scope; the consumer polls the counter
+// with sc1 loads from one lane, a workgroup barrier follows, and EVERY load of the published rows is an sc1 load to registers.
+// ---------------------------------------------------------------------------------------------------------------------
+struct TileRole {
+  SkArgs a;             // as for the stand-alone launch: planes, norms, partial-sum slots, sigmoid constants, XCD tile order
+  const float* zpub;    // [B][2] latent rows as published by the chain workgroups of THIS launch
+  unsigned* sync;       // [0] chain workgroups that have published, [1] tile workgroups that are done, [2] spin expired (sticky)
+  int n_chain;          // chain workgroups of the launch
+  int n_tile_wgs;       // tile workgroups of the launch
+};
+constexpr int TILE_ROLE_SMEM_FLOATS = 4096 + 4 * 64 + 64 * 2 + 64 * 2 * 2 + 8;   // one tile (sk_tile_f16_kernel<2, ...>: 18976 bytes)
+constexpr int TILE_ROLE_LDS_BYTES = 2 * TILE_ROLE_SMEM_FLOATS * 4;
+constexpr unsigned TILE_ROLE_SPIN_LIMIT = 1u << 16;                                // x ~0.5 us of sleep: tens of milliseconds
+
+typedef float rf32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float load_sc1(const float* p) {
+  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ void store_sc1(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// w: index of this tile workgroup, 512 threads.  NCH: 32-feature chunks of a row (compile time, as in sk_tile_f16_kernel).
+template <bool FASTSIG, int NCH>
+__device__ __forceinline__ void tile_pair_role(char* lds, const TileRole& tr, const int w) {
+  constexpr int T = 64, LMAX = 2, L = 2, RP = 20, HNT = 256;
+  constexpr int MAIN = 4096;
+  const SkArgs& a = tr.a;
+  const int half = threadIdx.x >> 8;
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  float* smem = reinterpret_cast<float*>(lds) + half * TILE_ROLE_SMEM_FLOATS;
+  float2* nr_s = reinterpret_cast<float2*>(smem + MAIN);   // [2 T] (|x|^2, 1/s): rows of the i side, then of the j side
+  float* zi_s = smem + MAIN + 4 * T;                       // [T][LMAX]
+  float* cpart = zi_s + T * LMAX;                          // [T][LMAX][2]
+  float* red = cpart + T * LMAX * 2;
+  const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
+  const int lr = lane & 31, h = lane >> 5;
+
+  // the two tiles of this workgroup: virtual block ids of the stand-alone launch's XCD-aware order that share this workgroup's
+  // XCD (workgroups are dealt round-robin over the XCDs; the chain workgroups in front are a multiple of 8 for whole 128-row batches)
+  const int vb = (2 * (w >> 3) + half) * 8 + (w & 7);
+  int ti = 0, tj = 0, tslot = 0;
+  bool valid;
+  if (a.xcd_nbg > 0) {
+    valid = xcd_tile(vb, a.xcd_nbg, a.nbc, ti, tj, tslot);
+  } else {
+    const int t = 2 * w + half;
+    valid = t < a.nbc * (a.nbc + 1) / 2;
+    if (valid) tri_decode(t, a.nbc, ti, tj);
+    tslot = t;
+  }
+  {   // a workgroup whose two tiles both lie outside the triangle (surplus blocks of the XCD-aware order) only reports in
+    int oi, oj, os;
+    const int ovb = (2 * (w >> 3) + (1 - half)) * 8 + (w & 7);
+    const bool other = a.xcd_nbg > 0 ? xcd_tile(ovb, a.xcd_nbg, a.nbc, oi, oj, os) : (2 * w + 1 - half) < a.nbc * (a.nbc + 1) / 2;
+    if (!valid && !other) {
+      if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == (unsigned)tr.n_tile_wgs - 1) {   // (cannot be the last one unless every tile workgroup is empty)
+          __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      return;
+    }
+  }
+  if (!valid) ti = tj = tslot = 0;   // (keeps the half in step with the other one's barriers; nothing of it is stored)
+  const int i0 = ti * T, j0 = tj * T;
+  const bool offdiag = ti != tj;
+
+  rf32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  const SplitRows& sp = a.split;
+  const uint16_t* gp[4];
+  int lo[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int e = tid + HNT * u;                       // piece: side (i / j), plane, row, quarter q
+    const int side = e >> 9, plane = (e >> 8) & 1, row = (e & 255) >> 2, q = e & 3;
+    const int grow = min((side ? j0 : i0) + row, a.B - 1);
+    gp[u] = sp.planes + plane * sp.plane_stride + (long)grow * SPLIT_KC + 8 * q;
+    lo[u] = ((side * 2 + plane) * 64 + row) * 4 + (q ^ ((row >> 2) & 3));
+  }
+  ru32x4 pre[4];
+  const long chunk_stride = (long)sp.B * SPLIT_KC;
+  const int ra = wm * 32 + lr, rbj = wn * 32 + lr;
+  ru32x4* buf = reinterpret_cast<ru32x4*>(smem);
+#define SKR_GLOAD(cc)                                                                                      \
+  {                                                                                                        \
+    const long goff = (long)min((cc), NCH - 1) * chunk_stride;                                             \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const ru32x4*>(gp[u] + goff); \
+  }
+#define SKR_CHUNK(cc, more)                                                                                             \
+  {                                                                                                                     \
+    __syncthreads();                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[lo[u]] = pre[u];                                                  \
+    __syncthreads();                                                                                                    \
+    if (more) SKR_GLOAD((cc) + 1)                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+      const int qa = (2 * t + h) ^ ((ra >> 2) & 3), qb = (2 * t + h) ^ ((rbj >> 2) & 3);                                \
+      const rf16x8 ah = __builtin_bit_cast(rf16x8, buf[ra * 4 + qa]), al = __builtin_bit_cast(rf16x8, buf[(64 + ra) * 4 + qa]);          \
+      const rf16x8 bh = __builtin_bit_cast(rf16x8, buf[(128 + rbj) * 4 + qb]), bl = __builtin_bit_cast(rf16x8, buf[(192 + rbj) * 4 + qb]); \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0); /* small products first */                    \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);                                               \
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);                                               \
+    }                                                                                                                   \
+  }
+  SKR_GLOAD(0)
+  for (int e = tid; e < 2 * T; e += HNT) {             // (norm, 1/scale) of both sides' rows
+    const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
+    nr_s[e] = make_float2(sp.norms[grow], sp.rscale[grow]);
+  }
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) SKR_CHUNK(c, c + 1 < NCH)
+#undef SKR_CHUNK
+#undef SKR_GLOAD
+
+  // ---- the latent rows: published by the chain workgroups of this launch
+  if (threadIdx.x == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&tr.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tr.n_chain) {
+      __builtin_amdgcn_s_sleep(20);
+      if (++spins > TILE_ROLE_SPIN_LIMIT) {
+        __hip_atomic_store(&tr.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();   // the counter has been seen; all MFMA operand reads are done: the staging area becomes the row-partial area
+  for (int e = tid; e < T * LMAX; e += HNT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const int ig = min(i0 + rl, a.B - 1);
+    zi_s[e] = load_sc1(tr.zpub + (long)ig * L + l);
+  }
+  // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
+  const int jl = wn * 32 + lr;
+  const int jg = j0 + jl;
+  const bool jok = jg < a.B;
+  float zj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) zj[l] = jok ? load_sc1(tr.zpub + (long)jg * L + l) : 0.f;
+  __syncthreads();   // latent rows of the i side visible
+  const float2 nrj = nr_s[T + jl];
+  const float nj = nrj.x, cj = -2.f * nrj.y;
+
+  float* rpart = smem;   // [T][LMAX][RP]
+  float gj[LMAX];
+#pragma unroll
+  for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+  float lsum = 0.f;
+  const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+  const int ib = wm * 32 + 4 * h;
+  const float2* nr_b = nr_s + ib;
+  const float* zi_b = zi_s + ib * LMAX;
+  float* rp_b = rpart + ib * LMAX * RP + (jl >> 2);
+  auto pair = [&](int r, bool masked) {
+    const int ro = (r & 3) + 8 * (r >> 2);
+    float dz[LMAX];
+    float dl2 = 0.f;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      dz[l] = zi_b[ro * LMAX + l] - zj[l];
+      dl2 = fmaf(dz[l], dz[l], dl2);
+    }
+    const float2 nri = nr_b[ro];
+    float d2 = fmaf(acc[r] * nri.y, cj, nri.x + nj);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
+    if (!FASTSIG) d2 = fmaxf(d2, 0.f);
+    if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
+    const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+    float El, G;
+    sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+    float f = El - Eh;
+    if (masked) f = (i0 + ib + ro < a.row_end && jok) ? f : 0.f;
+    lsum = fmaf(f, f, lsum);
+    const float g = f * G;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      float v = g * dz[l];
+      gj[l] -= v;
+      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+      rp_b[(ro * LMAX + l) * RP] = v;
+    }
+  };
+  if (edge) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, true);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pair(r, false);
+  }
+  if (offdiag) {
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      float s = sum_xor32(gj[l]);   // the two row halves of the quadrant
+      if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
+    }
+  }
+  // tile cost: block_sum<256>'s order (wave sums, then waves 0..3) on this half's four waves
+  {
+    const float v = wave_sum(lsum);
+    if (lane == 0) red[wave] = v;
+  }
+  __syncthreads();   // partials and wave sums visible
+  if (tid == 0 && valid) {
+    float tl = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tl += red[i];
+    a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
+  }
+  if (valid) {
+    for (int e = tid; e < T * LMAX; e += HNT) {
+      const int rl = e / LMAX, l = e - rl * LMAX;
+      const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+      const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+      const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                      (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+      a.P[((long)tj * a.nrows_pad + i0 + rl) * L + l] = s;
+    }
+    if (offdiag) {
+      for (int e = tid; e < T * LMAX; e += HNT) {
+        const int rl = e / LMAX, l = e - rl * LMAX;
+        a.P[((long)ti * a.nrows_pad + j0 + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+      }
+    }
+  }
+  // the last tile workgroup to finish resets the launch's counters (every chain workgroup has published by then: this
+  // workgroup saw the full count)
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)tr.n_tile_wgs - 1) {
+      __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// host side (sketchmap.hip): the tile plan of emx_sketchmap_tiles for the full batch on split rows, as a role description
+int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, const float sig[6], void* ws, size_t ws_bytes, void* split_ws,
+                   TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, const char* who);
+
+}  // namespace sk
+}  // namespace emx

@@ -31,6 +31,7 @@
 // direct differences instead of the Gram identity (no cancellation); the periodic path omits the +1e-12
 // regularisers of distances.py:169-175 (they only keep TF's sqrt gradient finite; X carries no gradient here).
 #include "emx_common.h"
+#include "sk_tile.h"
 #include "split.h"
 
 #include <cstdlib>
@@ -38,6 +39,7 @@
 namespace {
 
 using namespace emx;
+using namespace emx::sk;
 
 constexpr int NT = 256;
 constexpr int KSPLIT_MAX_NB = 10;      // batches of up to 640 rows may split the reduction of a tile over several workgroups
@@ -45,94 +47,7 @@ constexpr int KSPLIT_BLOCKS = 512;     // ... over at most this many in total
 constexpr int KC = 32;       // feature chunk staged per iteration
 constexpr int LS = KC + 4;   // padded LDS row stride (floats)
 
-struct SigDev {
-  float k6;         // fast high-d form (a = 12, b = 6): inv_sig2 * c^(1/6), so that c v^6 = (k6 d^2)^6
-  float c_inv;      // fast low-d form (a = 2): c / sig^2
-  float inv_sig2;   // 1/sig^2
-  float c;          // 2^(a/b) - 1
-  float half_a;     // a/2
-  float nba;        // -b/a
-  float half_am2;   // (a-2)/2
-  float vmax;       // clamp on (d/sig)^2 so that v^(a/2) stays finite
-  int a_is_2;
-};
 
-struct SkArgs {
-  const float* X;
-  const float* Z;
-  float* P;          // [nslots][nrows_pad][L]
-  float* tile_loss;  // [ntiles]
-  int B, D, ldx, L;
-  int row0, row_end;  // rows handled: [row0,row_end)
-  int nbr, nbc;       // tile rows / tile columns
-  int nrows_pad;
-  int symm;
-  int vec4;
-  float period;
-  float rp_hi, rp_lo, phase_unit2;   // fixed-point periodic tiles: 1 / period in two floats, (period / 2^32)^2
-  int phase_ok;                      // the data span less than 1.5 periods: the fixed-point tiles may run
-  SigDev sh, sl;
-  SplitRows split;   // optional f16 planes + norms of the rows (split.h): selects the f16 Gram kernel
-  int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
-  // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of a first launch
-  // (kmode 1: Gram partial of its chunks -> kpart), a second launch (kmode 2) adds them up in a fixed order and runs the
-  // epilogue.  kmode 0: one workgroup per tile does both.
-  int ksplit, kmode;
-  float* kpart;      // [tiles][ksplit][4 waves][16][64]
-  // data parallel: the upper-triangle tiles are DEALT to the ranks -- tile t (row-major triangle index)
-  // belongs to rank t % deal_world; a workgroup of another rank's tile leaves at once (its cost slot zeroed).  0 / 1: off.
-  int deal_rank, deal_world;
-};
-__device__ __forceinline__ bool dealt_away(const SkArgs& a, int tslot) {
-  if (a.deal_world <= 1 || tslot % a.deal_world == a.deal_rank) return false;
-  if (threadIdx.x == 0) a.tile_loss[tslot] = 0.f;
-  return true;
-}
-
-template <int N>
-__device__ __forceinline__ float powi(float v) {
-  if constexpr (N == 0) return 1.f;
-  else if constexpr (N == 1) return v;
-  else if constexpr (N % 2 == 0) { float h = powi<N / 2>(v); return h * h; }
-  else return v * powi<N - 1>(v);
-}
-
-// complement of the sketch-map sigmoid, E(v) = (1 + c v^(a/2))^(-b/a), v = (d/sig)^2   (distances.py:86)
-template <bool FAST>
-__device__ __forceinline__ float sig_E_high(float d2, const SigDev& s) {
-  if constexpr (FAST) {  // a = 12, b = 6: E = (1 + w^6)^(-1/2), w = d^2 c^(1/6) / sig^2 -- four instructions in front of the rsq; an
-                         // overflowing w^6 gives q = inf, rsq = 0: the correct limit; a d^2 that rounding made slightly negative
-                         // enters through an even power, so the caller needs no clamp at 0
-    const float w = d2 * s.k6;
-    const float w3 = w * w * w;
-    return __builtin_amdgcn_rsqf(fmaf(w3, w3, 1.f));
-  } else {
-    float v = fminf(d2 * s.inv_sig2, s.vmax);
-    float t = __builtin_amdgcn_exp2f(s.half_a * __builtin_amdgcn_logf(v));
-    float q = fmaf(s.c, t, 1.f);
-    return __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
-  }
-}
-
-// low-d: E and G = S'(d)/d / (b c / sig^2) = v^((a-2)/2) * q^(-b/a-1)
-template <bool FAST>
-__device__ __forceinline__ void sig_E_low(float d2, const SigDev& s, float& E, float& G) {
-  if constexpr (FAST) {  // a = 2, b = 6
-    float q = fmaf(s.c_inv, d2, 1.f);
-    float r = __builtin_amdgcn_rcpf(q);
-    E = r * r * r;
-    G = E * r;
-  } else {
-    float v = fminf(d2 * s.inv_sig2, s.vmax);
-    float lv = __builtin_amdgcn_logf(v);
-    float t = __builtin_amdgcn_exp2f(s.half_a * lv);
-    float q = fmaf(s.c, t, 1.f);
-    E = __builtin_amdgcn_exp2f(s.nba * __builtin_amdgcn_logf(q));
-    float um = s.a_is_2 ? 1.f : __builtin_amdgcn_exp2f(s.half_am2 * lv);
-    G = um * E * __builtin_amdgcn_rcpf(q);
-    G = (v > 0.f) ? G : 0.f;  // reference mask: coincident latent points carry no gradient
-  }
-}
 
 __device__ __forceinline__ float abs_minus(float x, float h) {   // |x| - h
   float r;
@@ -216,47 +131,6 @@ __device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long ro
   return v;
 }
 
-// upper-triangle linear index -> (ti, tj), ti <= tj < nb, row-major
-__device__ __forceinline__ void tri_decode(int t, int nb, int& ti, int& tj) {
-  float fn = 2.f * nb + 1.f;
-  int i = (int)((fn - sqrtf(fn * fn - 8.f * (float)t)) * 0.5f);
-  i = max(0, min(i, nb - 1));
-  while (i > 0 && (i * nb - i * (i - 1) / 2) > t) --i;
-  while ((i + 1) * nb - (i + 1) * i / 2 <= t) ++i;
-  ti = i;
-  tj = i + (t - (i * nb - i * (i - 1) / 2));
-}
-
-// XCD-aware order of the upper-triangle tiles.  Workgroups are dealt round-robin over the 8 XCDs (b and b + 8 share one,
-// observed, speed only -- nothing below depends on it for correctness), each XCD has its own L2, and a tile needs the
-// planes of its row panel and of its column panel.  In row-major triangle order every XCD ends up pulling ALL panels
-// through the fabric (8 x 2 MB at C2, while all 2048 resident tiles stage at once).  Here the panels form four groups
-// and the triangle ten group pairs: the six off-diagonal pairs (nbg^2 tiles each) go to the blocks with b % 8 = 0..5, the
-// four diagonal ones (nbg (nbg + 1) / 2 tiles each) two by two to b % 8 = 6, 7 -- every XCD touches half of the panels,
-// 256 / 272 tiles at C2.  Blocks beyond an XCD's share (and tiles beyond a ragged last group) leave at once.
-// Returns false for such a block; t = the tile's index in row-major triangle order (its tile_loss slot).
-__device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int& tj, int& t) {
-  const int x = bid & 7, k = bid >> 3;
-  int gi, gj, li, lj;
-  if (x < 6) {
-    gi = x < 3 ? 0 : (x < 5 ? 1 : 2);
-    gj = x < 3 ? x + 1 : (x < 5 ? x - 1 : 3);
-    if (k >= nbg * nbg) return false;
-    li = k / nbg;
-    lj = k - li * nbg;
-  } else {
-    const int T2 = nbg * (nbg + 1) / 2;
-    if (k >= 2 * T2) return false;
-    const int second = k >= T2 ? 1 : 0;
-    gi = gj = 2 * (x - 6) + second;
-    tri_decode(k - second * T2, nbg, li, lj);
-  }
-  ti = gi * nbg + li;
-  tj = gj * nbg + lj;
-  if (ti >= nbc || tj >= nbc) return false;
-  t = ti * nbc - ti * (ti - 1) / 2 + (tj - ti);
-  return true;
-}
 
 // (leading scalars: tile decode and the first row loads, preloaded into scalar registers at wave launch; 56 bytes, the struct follows)
 template <int TM, int TN, int LT, int PMODE, bool FASTSIG>
@@ -1256,6 +1130,33 @@ int launch_finish_plan(const SkPlan& pl, hipStream_t st) {
 }
 
 }  // namespace
+
+// The plan of emx_sketchmap_tiles (full batch, Euclidean, split rows) as the description of the tile ROLE of the fused
+// dense-layer launch (sk_tile.h, mlp.hip: emx_mlp_forward_backward_tiles).  EMX_EUNSUPPORTED outside the shapes that role is
+// built for: the caller keeps the separate launches.
+namespace emx {
+namespace sk {
+int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, const float sig[6], void* ws, size_t ws_bytes, void* split_ws,
+                   TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, const char* who) {
+  EMX_REQUIRE(out && virtual_blocks && n_chunks && fast && split_ws, "%s: null pointer argument (tile role)", who);
+  SkPlan pl;
+  int rc = make_plan(X, B, D, ldx, Z, L, INFINITY, sig, 1.f, 0.f, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl, who, split_ws, 0.f);
+  if (rc) return rc;
+  if (L != 2 || pl.T != 64 || pl.a.split.planes == nullptr) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role runs two-column latents on split rows", who);
+  out->a = pl.a;
+  out->a.xcd_nbg = 0;
+  *virtual_blocks = pl.ntiles;
+  static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+  if (pl.a.nbc >= 16 && xcd_order) {   // (as launch_tiles_plan)
+    out->a.xcd_nbg = (pl.a.nbc + 3) / 4;
+    *virtual_blocks = 8 * out->a.xcd_nbg * (out->a.xcd_nbg + 1);
+  }
+  *n_chunks = pl.a.split.ld / SPLIT_KC;
+  *fast = pl.fast;
+  return EMX_OK;
+}
+}  // namespace sk
+}  // namespace emx
 
 __global__ __launch_bounds__(NT) void sk_split_kernel(const float* __restrict__ X, int B, int D, int ldx, const SplitRows sp) {
   const int lane = threadIdx.x & 63;

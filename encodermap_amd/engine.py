@@ -208,6 +208,11 @@ class SequentialEngine:
         self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
         self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
+        # the all-pairs tiles as workgroups of the fused dense-layer launch (emx_mlp_forward_backward_tiles): the latent rows as the
+        # chain workgroups publish them, and the launch's counters (zeroed once; the launch leaves them at zero)
+        self.zpub = torch.zeros(B, self.L, dtype=f32, device=dev)
+        self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._tiles_ran = False
 
     # -- data feed -------------------------------------------------------------------------------
     def set_data(self, data) -> None:
@@ -277,6 +282,10 @@ class SequentialEngine:
     _graph_multi = None
     _data_span = None   # periodic data: max - min over the training set (set_data)
     _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (opt-in)
+    # the all-pairs tiles ride in the fused dense-layer launch, beside the decoder half of it (single process, Euclidean data on
+    # split rows, two latent columns; anything else keeps the separate tile launch).  EMX_OVERLAP_TILES=0: always separate.
+    _overlap_tiles = os.environ.get("EMX_OVERLAP_TILES", "1") != "0"
+    _tiles_ran = False
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -297,7 +306,18 @@ class SequentialEngine:
         if p.auto_cost_scale is not None:
             cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
                                        float(p.auto_cost_scale), self.B, self.delta[-1] if fuse else self.dY, self.cost_ws)
+        self._tiles_ran = False
         if fuse:
+            if full and self._overlap_tiles and self._tiles_fit():
+                try:
+                    _lib.mlp_forward_backward_tiles(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
+                                                    self.sk_ws, self.split_ws, self.zpub, self.sk_sync)
+                    self._tiles_ran = True
+                    return True
+                except _lib.EmxError as exc:
+                    if not exc.unsupported:
+                        raise
+                    self._overlap_tiles = False    # outside what the tile role is built for: the separate launches from now on
             try:
                 if full:
                     _lib.mlp_forward_backward(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, dbelow=self.dlat)
@@ -335,6 +355,17 @@ class SequentialEngine:
 
     def _use_sketchmap(self) -> bool:
         return self.with_distance and self.p.distance_cost_scale is not None
+
+    def _tiles_fit(self) -> bool:
+        """may the all-pairs tiles ride in the fused dense-layer launch?  (the library has the last word: EMX_EUNSUPPORTED)"""
+        return (self._use_sketchmap() and not self.dp.active and not self.periodic and self.split_ws is not None and self.L == 2
+                and self.layout.n_enc >= 1)
+
+    def check_sync(self) -> None:
+        """raises if a tile workgroup of a fused launch ever gave up waiting for the latent rows (emx.h: sync[2])"""
+        if int(self.sk_sync[2].item()) != 0:
+            raise _lib.EmxError("a tile workgroup of the fused dense-layer launch gave up waiting for the latent rows: the results of "
+                                "this run are invalid (set EMX_OVERLAP_TILES=0 and report)")
 
     def _dealt(self) -> bool:
         """data parallel over row blocks with the all-pairs tiles dealt to the ranks (DataParallel mode "rowblock")"""
@@ -395,7 +426,8 @@ class SequentialEngine:
         lay, n = self.layout, len(self.layout.layers)
         decoder_done = self._forward()
         if decoder_done:
-            self._latent_costs()
+            if not self._tiles_ran:      # (else the tiles were workgroups of the forward launch)
+                self._latent_costs()
         elif self._fork:
             main = torch.cuda.current_stream()
             side = self._side_stream
@@ -687,6 +719,8 @@ class SequentialEngine:
     def losses(self, start: int = 0) -> np.ndarray:
         """Total loss per executed step from step ``start`` on (synchronises; only that tail crosses PCIe)."""
         torch.cuda.synchronize(self.device)
+        if self._tiles_ran:
+            self.check_sync()
         return self.history[start: self._hstep_host].cpu().numpy()
 
     def last_loss(self) -> float:

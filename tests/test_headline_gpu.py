@@ -216,3 +216,30 @@ def test_shuffle_stream_blocks_do_not_copy_the_pass(em):
     base = eng._perm.data_ptr()
     v = eng.draw_index_block(2)
     assert v.data_ptr() >= base and v.data_ptr() < base + eng._perm.numel() * 8      # a view into the current pass
+
+
+@pytest.mark.parametrize("B,D,steps", [(4096, 128, 40), (1000, 128, 24), (640, 32, 24), (2048, 256, 16), (1024, 64, 16)])
+def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, monkeypatch):
+    """emx_mlp_forward_backward_tiles: the all-pairs tiles as workgroups of the fused dense-layer launch (chain workgroups publish
+    the latent rows, tile workgroups wait for them inside the launch) against the separate launches -- the same arithmetic in
+    the same order into the same slots, so whole training runs must agree BIT FOR BIT (a stale or torn latent row anywhere in
+    `steps` steps x B^2 pairs would show); batches that are not whole tiles / whole groups of eight row blocks included."""
+    from encodermap_amd.engine import SequentialEngine
+
+    rng = np.random.default_rng(B + D)
+    data = blobs(rng, 6000, D)
+    idx = rng.integers(0, 6000, (steps, B))
+    out = []
+    for overlap in (True, False):
+        monkeypatch.setattr(SequentialEngine, "_overlap_tiles", overlap)
+        p = em.Parameters(periodicity=INF, batch_size=B, dist_sig_parameters=(math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
+        e = em.EncoderMap(p, data, model=_weights(p, D), read_only=True)
+        e._engine.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
+        loss = e._engine.losses()
+        assert e._engine._tiles_ran == overlap
+        out.append((loss, e._engine.w.cpu().numpy(), e._engine.loss_terms()["distance"], e._engine.sk_sync.cpu().numpy()))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    np.testing.assert_array_equal(out[0][2], out[1][2])
+    assert (out[0][3] == 0).all()            # the launch left its counters at zero, nobody gave up waiting
+    assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
