@@ -295,7 +295,8 @@ ISSUE = ("instruction issue / dependent latency: neither the matrix pipes nor HB
 
 
 def kernel_rooflines(name, eng, launches):
-    """(dominant kernel of the step, all-pairs kernel or None), each timed alone on the engine's live batch."""
+    """(the kernel that takes the largest share of the step, the all-pairs kernel or None -- possibly the same record), each timed
+    alone on the engine's live batch."""
     from encodermap_amd import _lib
 
     cfg = CONFIGS[name]
@@ -304,7 +305,7 @@ def kernel_rooflines(name, eng, launches):
     recs, sk = [], None
     dims = [(l.n_in, l.n_out) for l in lay.layers]
     n_par = sum(k * m + m for k, m in dims)
-    if cfg["model"] == "encodermap" and eng._use_sketchmap() and not eng.dp.active:
+    if cfg["model"] == "encodermap" and eng._use_sketchmap():      # (data parallel: the full symmetric pass on the rank's live batch, timed alone)
         Z = eng.h[lay.n_enc - 1]
         sig = eng.p.dist_sig_parameters
         t_sk = _time_launches(lambda: _lib.sketchmap_tiles(eng.xb, Z, eng.periodicity, sig, 0, Bt, eng.sk_ws, eng.split_ws, data_span=eng._data_span),
@@ -341,7 +342,7 @@ def kernel_rooflines(name, eng, launches):
                             "launch count (launches_per_step) and the per-launch floors, DESIGN.md section 4",
                             "dense layers forward, the largest single launch of the ADC step", 4 * Bt * dims[0][0] + 4 * n_par))
     recs.sort(key=lambda r: -r["kernel_us"])
-    return recs[0], (sk if sk is not None and sk is not recs[0] else None)
+    return recs[0], sk
 
 
 def launches_per_step(eng):
@@ -399,9 +400,11 @@ def facade_timing(em, cfg, data, device, steps):
     for label, progress in (("defaults", False), ("progress", True)):
         warm = 64
         p = em.Parameters(n_steps=warm, seed=7, **cfg["kw"])
-        stderr = sys.stderr
+        stderr, stdout = sys.stderr, sys.stdout
         try:
-            sys.stderr = open(os.devnull, "w")      # (the progress read-out writes a line per summary step)
+            # (the progress read-out writes a line per summary step to stderr, save() its read-only notice to stdout -- which is
+            #  reserved for the JSON line)
+            sys.stderr = sys.stdout = open(os.devnull, "w")
             e = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=device, progress=progress)
             e._engine.set_data(data)
             e.train()                                # captures the step's graphs
@@ -412,7 +415,7 @@ def facade_timing(em, cfg, data, device, steps):
             torch.cuda.synchronize()
             out[label] = (time.perf_counter() - t0) / steps * 1e3
         finally:
-            sys.stderr = stderr
+            sys.stderr, sys.stdout = stderr, stdout
         del e
     return out
 

@@ -244,6 +244,7 @@ class Autoencoder:
         eng = self._engine
         total = int(self.p.n_steps) - int(self.p.current_training_step)
         start_hist = eng.hstep_host()
+        eng.reserve_history(total)
         for cb in self.callbacks:
             if hasattr(cb, "on_train_begin"):
                 cb.on_train_begin()

@@ -35,6 +35,7 @@
 #include "split.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -772,6 +773,225 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   KSTAMP(23);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Large batches (B >= 8192): 128 x 128 MACRO-TILES.  With 64 x 64 tiles the kernel stages 131 KB per tile at D = 256 -- 4.3 GB
+// from the L2s into LDS per launch at B = 16384, 12.9 TB/s, i.e. the rate at which the L2s can fill LDS is what bounds it
+// (48 executed FLOP per staged byte).  A 128 x 128 tile per workgroup, a 64 x 64 quadrant (2 x 2 matrix-instruction tiles, four
+// accumulators) per wave, stages (128 + 128) rows for four times the products: half the bytes per product, half the LDS reads.
+// The OUTPUT keeps the 64-tile layout every consumer plans with (make_plan: slot s of row block ib): a macro-tile (TI, TJ)
+// writes its row sums into slot 2 TJ (rows of TI), its column sums into slot 2 TI (rows of TJ), zeros into the odd slots
+// beside them, and its cost into the slot of 64-tile (2 TI, 2 TJ) (zeros into its other 64-tiles' slots): the sums the
+// consumers form over the slots are those of the 64-tile pass up to the association of the additions.  Two latent columns, not
+// for dealt tiles (the deal is by 64-tile).
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool FASTSIG, int NCH>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void sk_tile_f16_big_kernel(
+    const uint16_t* p_planes, long p_plane_stride, int p_xcd_nbg, int p_nbc2, int p_B, int p_split_B, int p_split_ld, const SkArgs a) {
+  constexpr int T = 128, LMAX = 2, L = 2, RP = 20;
+  constexpr int STAGE = 2048 * 4;                       // 2 sides x 2 planes x 128 rows x 32 k f16, as 16-byte pieces
+  constexpr int SMEM = STAGE + 4 * T + T * LMAX + T * LMAX * 2 + 8;
+  __shared__ __align__(16) float smem[SMEM];
+  float2* nr_s = reinterpret_cast<float2*>(smem + STAGE);   // [2 T] (|x|^2, 1/s): rows of the i side, then of the j side
+  float* zi_s = smem + STAGE + 4 * T;                   // [T][LMAX]
+  float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
+  float* red = cpart + T * LMAX * 2;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;     // 64 x 64 quadrant of this wave
+  const int lr = lane & 31, h = lane >> 5;
+
+  int TI, TJ, tmacro;
+  if (p_xcd_nbg > 0) {
+    if (!xcd_tile(blockIdx.x, p_xcd_nbg, p_nbc2, TI, TJ, tmacro)) return;
+  } else {
+    tri_decode(blockIdx.x, p_nbc2, TI, TJ);
+  }
+  const int i0 = TI * T, j0 = TJ * T;
+  const bool offdiag = TI != TJ;
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u)
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[u][v][r] = 0.f;
+
+  const uint16_t* gp[8];
+  int lo[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int e = tid + NT * u;                        // piece: side (i / j), plane, row, quarter q
+    const int side = e >> 10, plane = (e >> 9) & 1, row = (e & 511) >> 2, q = e & 3;
+    const int grow = min((side ? j0 : i0) + row, p_B - 1);
+    gp[u] = p_planes + plane * p_plane_stride + (long)grow * SPLIT_KC + 8 * q;
+    lo[u] = ((side * 2 + plane) * 128 + row) * 4 + (q ^ ((row >> 2) & 3));
+  }
+  u32x4 pre[8];
+  const long chunk_stride = (long)p_split_B * SPLIT_KC;
+  const int nch = NCH > 0 ? NCH : p_split_ld / SPLIT_KC;
+  u32x4* buf = reinterpret_cast<u32x4*>(smem);
+#define SKB_GLOAD(cc)                                                                                      \
+  {                                                                                                        \
+    const long goff = (long)min((cc), nch - 1) * chunk_stride;                                             \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) pre[u] = *reinterpret_cast<const u32x4*>(gp[u] + goff); \
+  }
+#define SKB_CHUNK(cc, more)                                                                                             \
+  {                                                                                                                     \
+    __syncthreads();                                                                                                    \
+    _Pragma("unroll") for (int u = 0; u < 8; ++u) buf[lo[u]] = pre[u];                                                  \
+    __syncthreads();                                                                                                    \
+    if (more) SKB_GLOAD((cc) + 1)                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
+      f16x8 ah[2], al[2], bh[2], bl[2];                                                                                 \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) {                                                                   \
+        const int ra = wm * 64 + 32 * u + lr, rb = wn * 64 + 32 * u + lr;                                               \
+        const int qa = (2 * t + h) ^ ((ra >> 2) & 3), qb = (2 * t + h) ^ ((rb >> 2) & 3);                               \
+        ah[u] = __builtin_bit_cast(f16x8, buf[ra * 4 + qa]);                                                            \
+        al[u] = __builtin_bit_cast(f16x8, buf[(128 + ra) * 4 + qa]);                                                    \
+        bh[u] = __builtin_bit_cast(f16x8, buf[(256 + rb) * 4 + qb]);                                                    \
+        bl[u] = __builtin_bit_cast(f16x8, buf[(384 + rb) * 4 + qb]);                                                    \
+      }                                                                                                                 \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
+        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bl[v], acc[u][v], 0, 0, 0); /* small products first */ \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
+        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[u], bh[v], acc[u][v], 0, 0, 0);                           \
+      _Pragma("unroll") for (int u = 0; u < 2; ++u) _Pragma("unroll") for (int v = 0; v < 2; ++v)                       \
+        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[u], bh[v], acc[u][v], 0, 0, 0);                           \
+    }                                                                                                                   \
+  }
+  SKB_GLOAD(0)
+  for (int e = tid; e < T * LMAX; e += NT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const int ig = min(i0 + rl, a.B - 1);
+    zi_s[e] = a.Z[(long)ig * L + l];
+  }
+  for (int e = tid; e < 2 * T; e += NT) {             // (norm, 1/scale) of both sides' rows
+    const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
+    nr_s[e] = make_float2(a.split.norms[grow], a.split.rscale[grow]);
+  }
+  if constexpr (NCH > 0) {
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) SKB_CHUNK(c, c + 1 < NCH)
+  } else {
+    for (int c = 0; c < nch; ++c) SKB_CHUNK(c, true)   // (the last request re-reads its own chunk)
+  }
+#undef SKB_CHUNK
+#undef SKB_GLOAD
+  __syncthreads();   // all MFMA operand reads done: the staging area becomes the row-partial area
+
+  // ---- epilogue: this lane owns the columns 64 wn + 32 v + lr and, per (u, v), the 16 rows 64 wm + 32 u + (r & 3) + 8 (r >> 2) + 4 h
+  float zj[2][LMAX], nj[2], cj[2];
+  bool jok[2];
+#pragma unroll
+  for (int v = 0; v < 2; ++v) {
+    const int jl = wn * 64 + 32 * v + lr, jg = j0 + jl;
+    jok[v] = jg < a.B;
+    const float2 nrj = nr_s[T + jl];
+    nj[v] = nrj.x;
+    cj[v] = -2.f * nrj.y;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) zj[v][l] = jok[v] ? a.Z[(long)jg * L + l] : 0.f;
+  }
+  float* rpart = smem;   // [T][LMAX][RP]
+  float gj[2][LMAX];
+#pragma unroll
+  for (int v = 0; v < 2; ++v)
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) gj[v][l] = 0.f;
+  float lsum = 0.f;
+  const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+  auto rows16 = [&](auto U_, bool masked) __attribute__((always_inline)) {
+    constexpr int u = decltype(U_)::value;
+    const int ib = wm * 64 + 32 * u + 4 * h;
+    const float2* nr_b = nr_s + ib;
+    const float* zi_b = zi_s + ib * LMAX;
+    float* rp_b = rpart + ib * LMAX * RP + ((wn * 32 + lr) >> 2);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ro = (r & 3) + 8 * (r >> 2);
+      const float2 nri = nr_b[ro];
+      float rowg[LMAX] = {0.f, 0.f};
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        float dz[LMAX];
+        float dl2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          dz[l] = zi_b[ro * LMAX + l] - zj[v][l];
+          dl2 = fmaf(dz[l], dz[l], dl2);
+        }
+        float d2 = fmaf(acc[u][v][r] * nri.y, cj[v], nri.x + nj[v]);
+        if (!FASTSIG) d2 = fmaxf(d2, 0.f);
+        if (masked) d2 = (i0 + ib + ro == j0 + wn * 64 + 32 * v + lr) ? 0.f : d2;
+        const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+        float El, G;
+        sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+        float f = El - Eh;
+        if (masked) f = (i0 + ib + ro < a.row_end && jok[v]) ? f : 0.f;
+        lsum = fmaf(f, f, lsum);
+        const float g = f * G;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          const float x = g * dz[l];
+          gj[v][l] -= x;
+          rowg[l] += x;
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        float x = rowg[l];
+        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));
+        x += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));
+        rp_b[(ro * LMAX + l) * RP] = x;
+      }
+    }
+  };
+  if (edge) {
+    rows16(std::integral_constant<int, 0>{}, true);
+    rows16(std::integral_constant<int, 1>{}, true);
+  } else {
+    rows16(std::integral_constant<int, 0>{}, false);
+    rows16(std::integral_constant<int, 1>{}, false);
+  }
+  if (offdiag) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) {
+        const float s = sum_xor32(gj[v][l]);   // the two row halves of the sub-tiles
+        if (h == 0) cpart[((wn * 64 + 32 * v + lr) * LMAX + l) * 2 + wm] = s;
+      }
+  }
+  const float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
+  // ---- outputs in the 64-tile layout: nbc = 64-row blocks of the batch; the macro-tile's four (three) 64-tiles
+  const int nbc = a.nbc;
+  if (tid < 4) {
+    const int ti = 2 * TI + (tid >> 1), tj = 2 * TJ + (tid & 1);
+    if (ti <= tj && tj < nbc) a.tile_loss[ti * nbc - ti * (ti - 1) / 2 + (tj - ti)] = tid == 0 ? (offdiag ? 2.f * tl : tl) : 0.f;
+  }
+  for (int e = tid; e < T * LMAX; e += NT) {
+    const int rl = e / LMAX, l = e - rl * LMAX;
+    const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+    const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+    const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                    (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+    if (i0 + rl < a.nrows_pad) {
+      a.P[((long)(2 * TJ) * a.nrows_pad + i0 + rl) * L + l] = s;
+      if (2 * TJ + 1 < nbc) a.P[((long)(2 * TJ + 1) * a.nrows_pad + i0 + rl) * L + l] = 0.f;
+    }
+  }
+  if (offdiag) {
+    for (int e = tid; e < T * LMAX; e += NT) {
+      const int rl = e / LMAX, l = e - rl * LMAX;
+      if (j0 + rl < a.nrows_pad) {
+        a.P[((long)(2 * TI) * a.nrows_pad + j0 + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+        a.P[((long)(2 * TI + 1) * a.nrows_pad + j0 + rl) * L + l] = 0.f;
+      }
+    }
+  }
+}
+
 struct FinArgs {
   const float* P;
   const float* tile_loss;
@@ -1083,6 +1303,24 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
         if (rck) return rck;
       }
       return EMX_OK;
+    }
+    // large batches: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); not for dealt tiles
+    static const int big_min_b = getenv("EMX_SK_BIG_MIN_B") ? atoi(getenv("EMX_SK_BIG_MIN_B")) : 8192;
+    if (a.L == 2 && a.symm && a.deal_world <= 1 && a.B >= big_min_b && a.row0 == 0 && a.row_end == a.B) {
+      const int nbc2 = (a.B + 127) / 128;
+      int nbg2 = 0, grid2 = nbc2 * (nbc2 + 1) / 2;
+      if (nbc2 >= 16 && xcd_order) {
+        nbg2 = (nbc2 + 3) / 4;
+        grid2 = 8 * nbg2 * (nbg2 + 1);
+      }
+#define SK_BIG_LAUNCH(kern) hipLaunchKernelGGL(kern, dim3(grid2), dim3(NT), 0, st, (const uint16_t*)a.split.planes, (long)a.split.plane_stride, nbg2, \
+                                               nbc2, a.B, a.split.B, a.split.ld, a)
+      if (pl.fast && nch == 8) SK_BIG_LAUNCH((sk_tile_f16_big_kernel<true, 8>));
+      else if (pl.fast && nch == 4) SK_BIG_LAUNCH((sk_tile_f16_big_kernel<true, 4>));
+      else if (pl.fast) SK_BIG_LAUNCH((sk_tile_f16_big_kernel<true, 0>));
+      else SK_BIG_LAUNCH((sk_tile_f16_big_kernel<false, 0>));
+#undef SK_BIG_LAUNCH
+      return emx::check_launch("sk_tile_f16_big_kernel");
     }
     if (a.L == 2 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 4>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 8 && !getenv("EMX_SK_NO_NCH8")) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 8>), dim3(grid), b);

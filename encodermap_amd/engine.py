@@ -166,7 +166,9 @@ class SequentialEngine:
 
         self.step = torch.full((1,), int(p.current_training_step), dtype=torch.int64, device=dev)
         self.cursor = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.history_capacity = int(history_capacity or max(int(p.n_steps), 1))
+        # (at least 4096 steps of history: growing it means new buffers, i.e. a new capture of the step's graphs -- a model that is
+        #  trained on in small increments must not pay that every time)
+        self.history_capacity = max(int(history_capacity or max(int(p.n_steps), 1)), 4096)
         self.history = torch.zeros(self.history_capacity, dtype=torch.float32, device=dev)
         self.term_history = torch.zeros(self.history_capacity, N_TERMS, dtype=torch.float32, device=dev)
         self.hstep = torch.zeros(1, dtype=torch.int64, device=dev)  # write position in history
@@ -706,6 +708,13 @@ class SequentialEngine:
 
     def hstep_host(self) -> int:
         return self._hstep_host
+
+    def reserve_history(self, n_steps_ahead: int) -> None:
+        """room for ``n_steps_ahead`` more steps of history, made ONCE (a caller that will enqueue them in small portions --
+        train() with callbacks due every few steps -- would otherwise grow the buffers, and re-capture the step, repeatedly)"""
+        need = int(self.hstep_host()) + int(n_steps_ahead)
+        if need > self.history_capacity:
+            self._grow_history(need)
 
     def _grow_history(self, need: int) -> None:
         cap = max(need, 2 * self.history_capacity)

@@ -34,8 +34,12 @@ SHAPES = {
     # BASELINE.json configs 2, 4, 5: the layer widths are what matters for the dense products; the batch is 1024 rows so that
     # the float64 oracle's [B, B(, D)] temporaries stay small (a row's numbers do not depend on the batch size, csrc/mlp.hip)
     "C2 (D=128 Euclidean)": (dict(periodicity=INF, batch_size=1024, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6)), lambda r: blobs(r, 4000, 128)),
-    "C4 (D=512 periodic, 1024-wide ends)": (dict(batch_size=256, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6)),
-                                            lambda r: r.uniform(-np.pi, np.pi, (2000, 512)).astype(np.float32)),
+    # (C4 with the mean_square auto cost: the default mean_abs cost differentiates to sign(delta), a DISCONTINUOUS gradient -- a
+    #  handful of output elements with delta within rounding of zero flip their sign in any float32 run, which puts 1e-4 of
+    #  relative error into the decoder's deltas of the float32 oracle and of the engine alike (ratios 1.4-1.8 either way, a
+    #  matter of which elements flip) and says nothing about the precision of the products)
+    "C4 (D=512 periodic, 1024-wide ends, mean_square)": (dict(batch_size=256, dist_sig_parameters=(30.0, 12, 6, 1, 2, 6), auto_cost_variant="mean_square"),
+                                                         lambda r: r.uniform(-np.pi, np.pi, (2000, 512)).astype(np.float32)),
     "C5 (D=256 Euclidean)": (dict(periodicity=INF, batch_size=1024, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)), lambda r: blobs(r, 4000, 256)),
 }
 

@@ -534,7 +534,10 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     # few tiles, many features: the reduction of a tile is split over workgroups (ADC: pair-distance vectors as points)
     (1100, 40, 2, (10.0, 12, 6, 1, 2, 6), 0, 1100),      # 18 tile columns: ragged last group of the XCD-aware tile order
     (256, 2850, 2, (80.0, 10, 5, 1, 2, 5), 0, 256), (200, 1000, 3, (45.0, 12, 6, 1, 2, 6), 0, 200), (320, 700, 2, (40.0, 12, 6, 1, 2, 6), 160, 320),
-    (600, 64, 6, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 8, (5.0, 3, 6, 1, 2, 6), 100, 300)])      # latent widths 5 .. 8
+    (600, 64, 6, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 8, (5.0, 3, 6, 1, 2, 6), 100, 300),       # latent widths 5 .. 8
+    # batches of 8192 rows and more: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); ragged last tiles,
+    # an odd number of 64-row blocks, the general sigmoid
+    (8192, 32, 2, (8.0, 12, 6, 1, 2, 6), 0, 8192), (8300, 64, 2, (11.0, 12, 6, 1, 2, 6), 0, 8300), (8256, 40, 2, (9.0, 3, 6, 1, 2, 6), 0, 8256)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct
     formulas -- same tolerances as the float32 path -- on data far from the origin, where the row-0 shift and the
