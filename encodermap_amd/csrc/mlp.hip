@@ -162,12 +162,13 @@ struct PubArgs {
   unsigned* ready;    // counter of workgroups that have published
 };
 
-// The kernel's body as a function, so that chain_kernel and chain_tiles_kernel (below) share it.  PUB: the forward GEMM flagged
-// S_PUB hands its rows to the tile workgroups of the same launch (sk_tile.h).
-template <int MODE, int NB, bool PUB>
+// The kernel's body as a function, so that chain_kernel and chain_tiles_kernel (below) share it.  PUB_OFF > 0: the forward GEMM
+// flagged S_PUB hands its rows (two columns) to the tile workgroups of the same launch (sk_tile.h); the offset is that of a
+// PubArgs record in the kernel's arguments.
+template <int MODE, int NB, int PUB_OFF>
 __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
                                            int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
-                                           const ChainArgs& a, const PubArgs& pub) {
+                                           const ChainArgs& a) {
   constexpr bool BWD = MODE == CHAIN_BWD;
   constexpr int NE = BWD ? 4 : 1;   // epilogue operands per lane: h of 4 rows (backward) or the bias of its column
   extern __shared__ __align__(16) char lds[];
@@ -309,8 +310,9 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     rq_n = G.n;
     rq_ws = G.ws;
   };
-  auto request = [&](auto RC) __attribute__((always_inline)) {   // the package of the request stream's unit into ring slot r, then advance
+  auto request = [&](auto RC, const int ln) __attribute__((always_inline)) {   // the package of the request stream's unit into ring slot r, then advance
     constexpr int r = decltype(RC)::value;
+    const int n = ln & 15, g = ln >> 4;
     const int ccol = min(128 * rq.p + 16 * wave + n, rq_n - 1);
     if (BWD) {
 #pragma unroll
@@ -320,9 +322,9 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     }
     wsc[r] = *rq_ws;
   };
-  auto request_pieces = [&](auto RC, int s) __attribute__((always_inline)) {
+  auto request_pieces = [&](auto RC, int s, const int ln) __attribute__((always_inline)) {
     constexpr int r = decltype(RC)::value;
-    const char* p = rq_ptr + s * 2048 + lane * 16;
+    const char* p = rq_ptr + s * 2048 + ln * 16;
     wp[r][s][0] = *reinterpret_cast<const half8*>(p);
     wp[r][s][1] = *reinterpret_cast<const half8*>(p + 1024);
   };
@@ -434,9 +436,6 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
 
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // the tile's accumulator in units of 1 / (weight scale [x source scale])
 
-  // lane-dependent address parts, the same for every unit
-  const int lane8 = lane * 8;
-  const unsigned fvoff = (unsigned)((32 * (g >> 1) + 16 * (wave & 1) + n) * 16 + (g & 1) * 8);   // this lane's 8 bytes inside a fragment
   const float* const wsf = reinterpret_cast<const float*>(a.units);
 
   // Executes the execution stream's unit from ring slot rx while the request stream's unit is requested into slot r.  Every
@@ -446,12 +445,24 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   auto exec = [&](auto RC) __attribute__((always_inline)) {
     constexpr int r = decltype(RC)::value;          // slot being requested into
     constexpr int rx = (r + 1) % NB;                // slot being executed
+    // The lane-dependent address parts.  Where the kernel must fit 128 registers (PUB_OFF > 0: chain_tiles_kernel shares its CUs
+    // with the tile workgroups) they are re-derived from the work-item id in every unit instead of living in registers across
+    // the unit loop: there the allocator spilled them to scratch, and a scratch reload sits in the same in-order memory counter
+    // as the weight packages -- every unit then waited for its NEXT package.
+    int ln = lane;
+    if constexpr (PUB_OFF > 0) {
+      ln = (int)(threadIdx.x & 63u);
+      asm volatile("" : "+v"(ln));
+    }
+    const int lane = ln, n = ln & 15, g = ln >> 4;
+    const int lane8 = ln * 8;
+    const unsigned fvoff = (unsigned)((32 * (g >> 1) + 16 * (wave & 1) + n) * 16 + (g & 1) * 8);   // this lane's 8 bytes inside a fragment
     const bool dyn = X.src_rs == 0.f;
 #ifdef EMX_CHAIN_TIMING
     const int ui = tcount++;
 #endif
     TSTAMP(3 + 5 * ui);
-    request(RC);
+    request(RC, ln);
     // the next unit of the execution stream; when it belongs to another GEMM its record is fetched now (scalar loads from
     // the kernel arguments), a whole unit ahead of its first use
     Stream exn = ex;
@@ -489,7 +500,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], d, 0, 0, 0);
         acc = d * rsa[s] + acc;
-        request_pieces(RC, s);
+        request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -499,7 +510,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][1], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], acc, 0, 0, 0);
-        request_pieces(RC, s);
+        request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -628,20 +639,21 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     // the layer's rows are complete in the destination image when its last unit is done
     const bool layer_end = last && ex.p == ex.P - 1;
     if (layer_end) __syncthreads();
-    if constexpr (PUB) {
-      if (layer_end && (sflags & S_PUB)) {
-        // the latent rows for the tile workgroups of this launch (sk_tile.h): from the layer's float32 copy in LDS, by ONE wave, as
-        // write-through stores (16 rows x 2 columns are one 128-byte line); the wave drains them, then its lane 0 reports in
-        if (wave == 0) {
-          const float* zc = reinterpret_cast<const float*>(lds + X.dst_f32);
-          const int nL = X.n;
-          for (int e = lane; e < R * nL; e += 64) {
-            const int row = e / nL, c = e - row * nL;
-            if (row < rows_valid) emx::sk::store_sc1(pub.zpub + (long)(r0 + row) * nL + c, zc[row * X.dst_f32_pitch + c]);
-          }
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          if (lane == 0) __hip_atomic_fetch_add(pub.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+    if constexpr (PUB_OFF > 0) {
+      if (layer_end && (sflags & S_PUB) && wave == 0) {
+        // the latent rows (two columns) for the tile workgroups of this launch (sk_tile.h): from the layer's float32 copy in LDS, by
+        // ONE wave, as write-through stores -- 16 rows x 2 columns are one 128-byte line, one store instruction; the wave
+        // drains it, then its lane 0 reports in.  The two pointers are fetched from the kernel arguments HERE (an offset the
+        // optimiser cannot see through): held in registers over the whole unit loop they cost the loop its scalar registers.
+        int off = PUB_OFF;
+        asm volatile("" : "+s"(off));
+        typedef const PubArgs __attribute__((address_space(4))) * KPub;
+        const KPub kp = (KPub)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+        const float* zc = reinterpret_cast<const float*>(lds + X.dst_f32);
+        const int row = lane >> 1, c = lane & 1;
+        if (lane < 2 * R && row < rows_valid) emx::sk::store_sc1(kp->zpub + (long)(r0 + row) * 2 + c, zc[row * X.dst_f32_pitch + c]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) __hip_atomic_fetch_add(kp->ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
     TSTAMP(7 + 5 * ui);
@@ -657,14 +669,14 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     rq_live = true;
     rq_ptr = units + wave * 8192;
     rq_load_gemm();
-    request(IC_<0>{});
+    request(IC_<0>{}, lane);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) request_pieces(IC_<0>{}, s);
+    for (int s = 0; s < 4; ++s) request_pieces(IC_<0>{}, s, lane);
     rq_advance();
     if constexpr (NB >= 3) {
-      request(IC_<1>{});
+      request(IC_<1>{}, lane);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) request_pieces(IC_<1>{}, s);
+      for (int s = 0; s < 4; ++s) request_pieces(IC_<1>{}, s, lane);
       rq_advance();
     }
     ex = Stream{g0, g1, 0, 0, 0, 0};
@@ -823,7 +835,7 @@ template <int MODE, int NB>
 __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
                                                     int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
                                                     const ChainArgs a) {
-  chain_body<MODE, NB, false>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a, PubArgs{nullptr, nullptr});
+  chain_body<MODE, NB, 0>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
 }
 
 // The fused launch with the all-pairs tiles aboard (sk_tile.h): workgroups [0, row blocks) are the chain workgroups, the rest run two
@@ -839,8 +851,9 @@ __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     emx::sk::tile_pair_role<FASTSIG, NCH>(lds, tr, (int)blockIdx.x - n_chain);
     return;
   }
-  chain_body<CHAIN_FUSED, NB, true>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a,
-                                    PubArgs{const_cast<float*>(tr.zpub), tr.sync});
+  static_assert(offsetof(emx::sk::TileRole, sync) == offsetof(emx::sk::TileRole, zpub) + 8 && sizeof(ChainArgs) % 8 == 0, "PubArgs inside TileRole");
+  chain_body<CHAIN_FUSED, NB, 56 + (int)sizeof(ChainArgs) + (int)offsetof(emx::sk::TileRole, zpub)>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0,
+                                                                                                 p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
 }
 
 // The operand store from the flat parameter buffer (the optimizer keeps it current afterwards).  Two launches: the layers'
@@ -1582,9 +1595,23 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   tr.zpub = tiles->zpub;
   tr.sync = tiles->sync;
   tr.n_chain = n_chain;
-  tr.n_tile_wgs = tr.a.xcd_nbg > 0 ? vblocks / 2 : (vblocks + 1) / 2;
+  // persistent tile workgroups: one per CU beside its chain workgroup (more would wait for the chain workgroups to leave), each
+  // walking its share of the tile pairs -- in the XCD-aware order 32 per XCD list (pairs k, k + 32, ... of the list)
+  static const int per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : 32;
+  if (tr.a.xcd_nbg > 0) tr.n_tile_wgs = 8 * std::min(per_xcd, tr.a.xcd_nbg * (tr.a.xcd_nbg + 1) / 2);
+  else tr.n_tile_wgs = std::min(8 * per_xcd, (vblocks + 1) / 2);
   const size_t lds = std::max((size_t)b.lds, (size_t)emx::sk::TILE_ROLE_LDS_BYTES);
-  const int grid = n_chain + tr.n_tile_wgs;
+  int grid = n_chain + tr.n_tile_wgs;
+  // (timing experiments only -- wrong results: EMX_TILES_DEBUG=1 launches the chain workgroups alone, =2 tile workgroups that do not wait)
+  static const int dbg = getenv("EMX_TILES_DEBUG") ? atoi(getenv("EMX_TILES_DEBUG")) : 0;
+  if (dbg == 1) grid = n_chain;
+  if (dbg == 2) tr.n_chain = 0;
+  if (dbg == 3) {   // the tile workgroups alone
+    tr.n_chain = 0;
+    grid = tr.n_tile_wgs;
+    b.a.row_end = b.a.row0;
+  }
+  if (dbg == 4) tr.n_tile_wgs = std::min(tr.n_tile_wgs, 8);   // eight tile workgroups beside the chain workgroups: what do they cost the chain?
   hipStream_t st = (hipStream_t)stream;
   static_assert(sizeof(ChainArgs) + sizeof(emx::sk::TileRole) + 56 <= 4096, "kernel arguments of chain_tiles_kernel");
   if (!fast) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role is built for the (12, 6 | 2, 6) sigmoid family", who);

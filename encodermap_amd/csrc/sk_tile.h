@@ -2,6 +2,8 @@
 // chain_tiles_kernel): the argument record, the two sigmoid forms and the tile orders.  See sketchmap.hip for the algorithm.
 #pragma once
 #include "emx_common.h"
+#include <type_traits>
+
 #include "split.h"
 
 namespace emx {
@@ -170,6 +172,12 @@ constexpr int TILE_ROLE_SMEM_FLOATS = 4096 + 4 * 64 + 64 * 2 + 64 * 2 * 2 + 8;  
 constexpr int TILE_ROLE_LDS_BYTES = 2 * TILE_ROLE_SMEM_FLOATS * 4;
 constexpr unsigned TILE_ROLE_SPIN_LIMIT = 1u << 16;                                // x ~0.5 us of sleep: tens of milliseconds
 
+#ifndef EMX_TILE_EXP
+#define EMX_TILE_EXP 0   // timing experiments only (wrong results): 1 = no pair epilogue, 2 = no Gram products
+#endif
+#ifndef EMX_TILE_PFX
+#define EMX_TILE_PFX 3   // chunks of the next tile in flight under the epilogue of the current one
+#endif
 typedef float rf32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 rf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int ru32x4 __attribute__((ext_vector_type(4)));
@@ -181,14 +189,27 @@ __device__ __forceinline__ void store_sc1(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// w: index of this tile workgroup, 512 threads.  NCH: 32-feature chunks of a row (compile time, as in sk_tile_f16_kernel).
+// w: index of this tile workgroup (512 threads) among the launch's n_tile_wgs.  NCH: 32-feature chunks of a row (compile time, as in
+// sk_tile_f16_kernel).  The workgroup is PERSISTENT: it walks its share of the tile pairs -- pair k of its XCD's list, k = w / 8,
+// w / 8 + n_tile_wgs / 8, ... -- and keeps the next pair's operand planes IN FLIGHT under the current pair's sigmoid epilogue (all
+// chunks of a tile are requested at once, into registers: one trip to the L2s per tile, hidden behind the epilogue in front of it;
+// as a launch of its own the pass hides these trips behind seven other resident tiles, which a CU shared with a chain workgroup
+// does not have room for).
 template <bool FASTSIG, int NCH>
 __device__ __forceinline__ void tile_pair_role(char* lds, const TileRole& tr, const int w) {
   constexpr int T = 64, LMAX = 2, L = 2, RP = 20, HNT = 256;
   constexpr int MAIN = 4096;
+  // The operand pieces of a tile travel through a register ring of RING chunk slots (chunk c in slot c % RING): the first PFX chunks
+  // of the NEXT tile are requested when the current tile's products are done and are in flight under its epilogue (more slots
+  // alive there would not fit the 128 registers next to the epilogue's own); the others are requested at the start of the tile's
+  // products -- one trip, partly behind the first chunks' products -- and, for rows of more than 128 features, slot by slot as
+  // the slots come free.
+  constexpr int RING = NCH < 4 ? NCH : 4;
+  constexpr int PFX = NCH < EMX_TILE_PFX ? NCH : EMX_TILE_PFX;
   const SkArgs& a = tr.a;
-  const int half = threadIdx.x >> 8;
-  const int tid = threadIdx.x & 255, lane = tid & 63, wave = tid >> 6;
+  // (half and wave are uniform over a wave: said so, the tile coordinates and everything derived from them live in scalar registers)
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
   float* smem = reinterpret_cast<float*>(lds) + half * TILE_ROLE_SMEM_FLOATS;
   float2* nr_s = reinterpret_cast<float2*>(smem + MAIN);   // [2 T] (|x|^2, 1/s): rows of the i side, then of the j side
   float* zi_s = smem + MAIN + 4 * T;                       // [T][LMAX]
@@ -196,199 +217,265 @@ __device__ __forceinline__ void tile_pair_role(char* lds, const TileRole& tr, co
   float* red = cpart + T * LMAX * 2;
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
-
-  // the two tiles of this workgroup: virtual block ids of the stand-alone launch's XCD-aware order that share this workgroup's
-  // XCD (workgroups are dealt round-robin over the XCDs; the chain workgroups in front are a multiple of 8 for whole 128-row batches)
-  const int vb = (2 * (w >> 3) + half) * 8 + (w & 7);
-  int ti = 0, tj = 0, tslot = 0;
-  bool valid;
-  if (a.xcd_nbg > 0) {
-    valid = xcd_tile(vb, a.xcd_nbg, a.nbc, ti, tj, tslot);
-  } else {
-    const int t = 2 * w + half;
-    valid = t < a.nbc * (a.nbc + 1) / 2;
-    if (valid) tri_decode(t, a.nbc, ti, tj);
-    tslot = t;
-  }
-  {   // a workgroup whose two tiles both lie outside the triangle (surplus blocks of the XCD-aware order) only reports in
-    int oi, oj, os;
-    const int ovb = (2 * (w >> 3) + (1 - half)) * 8 + (w & 7);
-    const bool other = a.xcd_nbg > 0 ? xcd_tile(ovb, a.xcd_nbg, a.nbc, oi, oj, os) : (2 * w + 1 - half) < a.nbc * (a.nbc + 1) / 2;
-    if (!valid && !other) {
-      if (threadIdx.x == 0) {
-        const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (done == (unsigned)tr.n_tile_wgs - 1) {   // (cannot be the last one unless every tile workgroup is empty)
-          __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-      }
-      return;
-    }
-  }
-  if (!valid) ti = tj = tslot = 0;   // (keeps the half in step with the other one's barriers; nothing of it is stored)
-  const int i0 = ti * T, j0 = tj * T;
-  const bool offdiag = ti != tj;
-
-  rf32x16 acc;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
   const SplitRows& sp = a.split;
-  const uint16_t* gp[4];
-  int lo[4];
-#pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int e = tid + HNT * u;                       // piece: side (i / j), plane, row, quarter q
-    const int side = e >> 9, plane = (e >> 8) & 1, row = (e & 255) >> 2, q = e & 3;
-    const int grow = min((side ? j0 : i0) + row, a.B - 1);
-    gp[u] = sp.planes + plane * sp.plane_stride + (long)grow * SPLIT_KC + 8 * q;
-    lo[u] = ((side * 2 + plane) * 64 + row) * 4 + (q ^ ((row >> 2) & 3));
-  }
-  ru32x4 pre[4];
   const long chunk_stride = (long)sp.B * SPLIT_KC;
-  const int ra = wm * 32 + lr, rbj = wn * 32 + lr;
   ru32x4* buf = reinterpret_cast<ru32x4*>(smem);
-#define SKR_GLOAD(cc)                                                                                      \
-  {                                                                                                        \
-    const long goff = (long)min((cc), NCH - 1) * chunk_stride;                                             \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) pre[u] = *reinterpret_cast<const ru32x4*>(gp[u] + goff); \
-  }
-#define SKR_CHUNK(cc, more)                                                                                             \
-  {                                                                                                                     \
-    __syncthreads();                                                                                                    \
-    _Pragma("unroll") for (int u = 0; u < 4; ++u) buf[lo[u]] = pre[u];                                                  \
-    __syncthreads();                                                                                                    \
-    if (more) SKR_GLOAD((cc) + 1)                                                                                       \
-    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                                     \
-      const int qa = (2 * t + h) ^ ((ra >> 2) & 3), qb = (2 * t + h) ^ ((rbj >> 2) & 3);                                \
-      const rf16x8 ah = __builtin_bit_cast(rf16x8, buf[ra * 4 + qa]), al = __builtin_bit_cast(rf16x8, buf[(64 + ra) * 4 + qa]);          \
-      const rf16x8 bh = __builtin_bit_cast(rf16x8, buf[(128 + rbj) * 4 + qb]), bl = __builtin_bit_cast(rf16x8, buf[(192 + rbj) * 4 + qb]); \
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0); /* small products first */                    \
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);                                               \
-      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);                                               \
-    }                                                                                                                   \
-  }
-  SKR_GLOAD(0)
-  for (int e = tid; e < 2 * T; e += HNT) {             // (norm, 1/scale) of both sides' rows
-    const int grow = min((e < T ? i0 : j0 - T) + e, a.B - 1);
-    nr_s[e] = make_float2(sp.norms[grow], sp.rscale[grow]);
-  }
-#pragma unroll
-  for (int c = 0; c < NCH; ++c) SKR_CHUNK(c, c + 1 < NCH)
-#undef SKR_CHUNK
-#undef SKR_GLOAD
+  const int ra = wm * 32 + lr, rbj = wn * 32 + lr;
 
-  // ---- the latent rows: published by the chain workgroups of this launch
-  if (threadIdx.x == 0) {
-    unsigned spins = 0;
-    while (__hip_atomic_load(&tr.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tr.n_chain) {
-      __builtin_amdgcn_s_sleep(20);
-      if (++spins > TILE_ROLE_SPIN_LIMIT) {
-        __hip_atomic_store(&tr.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-    }
-  }
-  __syncthreads();   // the counter has been seen; all MFMA operand reads are done: the staging area becomes the row-partial area
-  for (int e = tid; e < T * LMAX; e += HNT) {
-    const int rl = e / LMAX, l = e - rl * LMAX;
-    const int ig = min(i0 + rl, a.B - 1);
-    zi_s[e] = load_sc1(tr.zpub + (long)ig * L + l);
-  }
-  // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
-  const int jl = wn * 32 + lr;
-  const int jg = j0 + jl;
-  const bool jok = jg < a.B;
-  float zj[LMAX];
-#pragma unroll
-  for (int l = 0; l < LMAX; ++l) zj[l] = jok ? load_sc1(tr.zpub + (long)jg * L + l) : 0.f;
-  __syncthreads();   // latent rows of the i side visible
-  const float2 nrj = nr_s[T + jl];
-  const float nj = nrj.x, cj = -2.f * nrj.y;
+  // this workgroup's pairs: k = k0, k0 + kstep, ... < n_pairs
+  const bool xcd = a.xcd_nbg > 0;
+  const int xq = w & 7;
+  const int n_tiles = a.nbc * (a.nbc + 1) / 2;
+  const int n_pairs = xcd ? a.xcd_nbg * (a.xcd_nbg + 1) / 2 : (n_tiles + 1) / 2;     // (XCD order: pairs per XCD list)
+  const int k0 = xcd ? (w >> 3) : w, kstep = xcd ? (tr.n_tile_wgs >> 3) : tr.n_tile_wgs;
 
-  float* rpart = smem;   // [T][LMAX][RP]
-  float gj[LMAX];
-#pragma unroll
-  for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
-  float lsum = 0.f;
-  const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
-  const int ib = wm * 32 + 4 * h;
-  const float2* nr_b = nr_s + ib;
-  const float* zi_b = zi_s + ib * LMAX;
-  float* rp_b = rpart + ib * LMAX * RP + (jl >> 2);
-  auto pair = [&](int r, bool masked) {
-    const int ro = (r & 3) + 8 * (r >> 2);
-    float dz[LMAX];
-    float dl2 = 0.f;
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      dz[l] = zi_b[ro * LMAX + l] - zj[l];
-      dl2 = fmaf(dz[l], dz[l], dl2);
+  // tile of pair k for this half: packed as ti | tj << 10 | valid << 20 (scalars; tslot follows from ti, tj)
+  auto tile_of = [&](int k) __attribute__((always_inline)) -> int {
+    int ti = 0, tj = 0, tslot = 0;
+    bool valid;
+    if (xcd) {
+      valid = xcd_tile((2 * k + half) * 8 + xq, a.xcd_nbg, a.nbc, ti, tj, tslot);
+    } else {
+      tslot = 2 * k + half;
+      valid = tslot < n_tiles;
+      if (valid) tri_decode(tslot, a.nbc, ti, tj);
     }
-    const float2 nri = nr_b[ro];
-    float d2 = fmaf(acc[r] * nri.y, cj, nri.x + nj);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
-    if (!FASTSIG) d2 = fmaxf(d2, 0.f);
-    if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
-    const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
-    float El, G;
-    sig_E_low<FASTSIG>(dl2, a.sl, El, G);
-    float f = El - Eh;
-    if (masked) f = (i0 + ib + ro < a.row_end && jok) ? f : 0.f;
-    lsum = fmaf(f, f, lsum);
-    const float g = f * G;
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      float v = g * dz[l];
-      gj[l] -= v;
-      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-      rp_b[(ro * LMAX + l) * RP] = v;
+    if (!valid) ti = tj = 0;   // (keeps the half in step with the other one's barriers; nothing of it is stored)
+    return __builtin_amdgcn_readfirstlane(ti | (tj << 10) | ((valid ? 1 : 0) << 20));
+  };
+
+  // piece e = tid + 256 u of a chunk: side u >> 1 (i / j), plane u & 1, row tid >> 2, quarter tid & 3 -- the same for every tile
+  const int prow = tid >> 2, pq = tid & 3;
+  const int lo0 = prow * 4 + (pq ^ ((prow >> 2) & 3));     // + 256 u: ((side * 2 + plane) * 64 + row) * 4 + (q ^ ((row >> 2) & 3))
+  ru32x4 pre[RING][4];
+  float2 nr_pre = make_float2(0.f, 0.f);
+  auto request = [&](const int t, auto C_) __attribute__((always_inline)) {   // chunk C of tile t into its ring slot
+    constexpr int c = decltype(C_)::value;
+    const long goff = (long)c * chunk_stride;
+    const uint16_t* gi = sp.planes + (long)min((t & 1023) * T + prow, a.B - 1) * SPLIT_KC + 8 * pq + goff;
+    const uint16_t* gj = sp.planes + (long)min(((t >> 10) & 1023) * T + prow, a.B - 1) * SPLIT_KC + 8 * pq + goff;
+    pre[c % RING][0] = *reinterpret_cast<const ru32x4*>(gi);
+    pre[c % RING][1] = *reinterpret_cast<const ru32x4*>(gi + sp.plane_stride);
+    pre[c % RING][2] = *reinterpret_cast<const ru32x4*>(gj);
+    pre[c % RING][3] = *reinterpret_cast<const ru32x4*>(gj + sp.plane_stride);
+  };
+  auto request_head = [&](const int t) __attribute__((always_inline)) {   // the chunks that travel under the epilogue in front
+    static_assert(PFX <= 4, "request_head");
+    request(t, std::integral_constant<int, 0>{});
+    if constexpr (PFX > 1) request(t, std::integral_constant<int, 1>{});
+    if constexpr (PFX > 2) request(t, std::integral_constant<int, (PFX > 2 ? 2 : 0)>{});
+    if constexpr (PFX > 3) request(t, std::integral_constant<int, (PFX > 3 ? 3 : 0)>{});
+  };
+  auto request_norms = [&](const int t) __attribute__((always_inline)) {
+    if (tid < 2 * T) {
+      const int grow = min((tid < T ? (t & 1023) * T : ((t >> 10) & 1023) * T - T) + tid, a.B - 1);
+      nr_pre = make_float2(sp.norms[grow], sp.rscale[grow]);
     }
   };
-  if (edge) {
+  // the latent rows a tile's epilogue needs, per thread: element tid of the i side's [T][2] block (threads 0 .. 127) and the two
+  // columns of this lane's j row -- sc1 loads of what the chain workgroups published
+  auto request_z = [&](const int t, float& zi, float (&zj)[LMAX]) __attribute__((always_inline)) {
+    const int ig = min((t & 1023) * T + (tid >> 1), a.B - 1);
+    zi = tid < T * LMAX ? load_sc1(tr.zpub + (long)ig * L + (tid & 1)) : 0.f;
+    const int jg = ((t >> 10) & 1023) * T + wn * 32 + lr;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pair(r, true);
-  } else {
+    for (int l = 0; l < LMAX; ++l) zj[l] = jg < a.B ? load_sc1(tr.zpub + (long)jg * L + l) : 0.f;
+  };
+  auto mfma_chunk = [&](rf32x16& acc) __attribute__((always_inline)) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pair(r, false);
-  }
-  if (offdiag) {
-#pragma unroll
-    for (int l = 0; l < LMAX; ++l) {
-      float s = sum_xor32(gj[l]);   // the two row halves of the quadrant
-      if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
+    for (int t = 0; t < 2; ++t) {
+      const int qa = (2 * t + h) ^ ((ra >> 2) & 3), qb = (2 * t + h) ^ ((rbj >> 2) & 3);
+      const rf16x8 ah = __builtin_bit_cast(rf16x8, buf[ra * 4 + qa]), al = __builtin_bit_cast(rf16x8, buf[(64 + ra) * 4 + qa]);
+      const rf16x8 bh = __builtin_bit_cast(rf16x8, buf[(128 + rbj) * 4 + qb]), bl = __builtin_bit_cast(rf16x8, buf[(192 + rbj) * 4 + qb]);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);   // small products first
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
     }
-  }
-  // tile cost: block_sum<256>'s order (wave sums, then waves 0..3) on this half's four waves
-  {
-    const float v = wave_sum(lsum);
-    if (lane == 0) red[wave] = v;
-  }
-  __syncthreads();   // partials and wave sums visible
-  if (tid == 0 && valid) {
-    float tl = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) tl += red[i];
-    a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
-  }
-  if (valid) {
-    for (int e = tid; e < T * LMAX; e += HNT) {
-      const int rl = e / LMAX, l = e - rl * LMAX;
-      const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
-      const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
-      const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
-                      (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-      a.P[((long)tj * a.nrows_pad + i0 + rl) * L + l] = s;
-    }
-    if (offdiag) {
-      for (int e = tid; e < T * LMAX; e += HNT) {
-        const int rl = e / LMAX, l = e - rl * LMAX;
-        a.P[((long)ti * a.nrows_pad + j0 + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+  };
+  // chunk C of the tile: (C == 0: the ring's remaining slots are requested first) write, barrier, products, then the slot is
+  // requested again for chunk C + RING
+  auto gram = [&](const int t, rf32x16& acc, auto C_, auto&& self) __attribute__((always_inline)) -> void {
+    constexpr int c = decltype(C_)::value;
+    if constexpr (c < NCH) {
+      if constexpr (c == 0) {
+        if constexpr (PFX < RING) request(t, std::integral_constant<int, (PFX < RING ? PFX : 0)>{});
+        if constexpr (PFX + 1 < RING) request(t, std::integral_constant<int, (PFX + 1 < RING ? PFX + 1 : 0)>{});
       }
+      __syncthreads();   // (c = 0: the epilogue in front has finished with the area)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) buf[lo0 + 256 * u] = pre[c % RING][u];
+      if (c == 0 && tid < 2 * T) nr_s[tid] = nr_pre;
+      __syncthreads();
+      if constexpr (c + RING < NCH) request(t, std::integral_constant<int, (c + RING < NCH ? c + RING : 0)>{});
+      mfma_chunk(acc);
+      self(t, acc, std::integral_constant<int, c + 1>{}, self);
+    }
+  };
+  bool latent_ready = false;
+  if (k0 >= n_pairs) goto report;
+  {
+    int cur = tile_of(k0);
+    request_head(cur);
+    request_norms(cur);
+    float zi_c = 0.f, zj_c[LMAX] = {0.f, 0.f};
+    bool z_c = false;
+    for (int k = k0; k < n_pairs; k += kstep) {
+      const int cti = cur & 1023, ctj = (cur >> 10) & 1023;
+      const bool cvalid = (cur >> 20) != 0;
+      const int i0 = cti * T, j0 = ctj * T;
+      const bool offdiag = cti != ctj;
+      rf32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      // ---- Gram products: the chunks through the LDS image (as sk_tile_f16_kernel: write, barrier, six instructions)
+#if EMX_TILE_EXP != 2
+      gram(cur, acc, std::integral_constant<int, 0>{}, gram);
+#else
+      __syncthreads();
+      if (tid < 2 * T) nr_s[tid] = nr_pre;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = pre[0][r & 3][r >> 2] * 1e-9f;
+      __syncthreads();
+#endif
+      // ---- the next pair's planes go on their way now: they travel under this pair's epilogue
+      const int kn = k + kstep;
+      int nxt = cur;
+      float zi_n = 0.f, zj_n[LMAX] = {0.f, 0.f};
+      bool z_n = false;
+      if (kn < n_pairs) {
+        nxt = tile_of(kn);
+        request_head(nxt);
+        request_norms(nxt);
+        if (latent_ready) {   // (the latent rows are all there: the next tile's go on their way with its planes)
+          request_z(nxt, zi_n, zj_n);
+          z_n = true;
+        }
+      }
+      // ---- the latent rows: published by the chain workgroups of this launch (first pair only: then they are all there)
+      if (!latent_ready) {
+        if (threadIdx.x == 0) {
+          unsigned spins = 0;
+          while (__hip_atomic_load(&tr.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tr.n_chain) {
+            __builtin_amdgcn_s_sleep(20);
+            if (++spins > TILE_ROLE_SPIN_LIMIT) {
+              __hip_atomic_store(&tr.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+          }
+        }
+        latent_ready = true;
+      }
+      __syncthreads();   // the counter has been seen; all MFMA operand reads are done: the staging area becomes the row-partial area
+      // ---- epilogue: this lane owns column j = wn*32 + lr and the 16 rows (reg&3) + 8(reg>>2) + 4h of the quadrant
+      const int jl = wn * 32 + lr;
+      const int jg = j0 + jl;
+      const bool jok = jg < a.B;
+      float zj[LMAX];
+      if (!z_c) request_z(cur, zi_c, zj_c);   // (first pair: the rows could not be asked for before they were published)
+      if (tid < T * LMAX) zi_s[tid] = zi_c;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) zj[l] = zj_c[l];
+      __syncthreads();   // latent rows of the i side visible
+      const float2 nrj = nr_s[T + jl];
+      const float nj = nrj.x, cj = -2.f * nrj.y;
+
+      float* rpart = smem;   // [T][LMAX][RP]
+      float gj[LMAX];
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+      float lsum = 0.f;
+      const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+      const int ib = wm * 32 + 4 * h;
+      const float2* nr_b = nr_s + ib;
+      const float* zi_b = zi_s + ib * LMAX;
+      float* rp_b = rpart + ib * LMAX * RP + (jl >> 2);
+      auto pair = [&](int r, bool masked) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+        float dz[LMAX];
+        float dl2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          dz[l] = zi_b[ro * LMAX + l] - zj[l];
+          dl2 = fmaf(dz[l], dz[l], dl2);
+        }
+        const float2 nri = nr_b[ro];
+        float d2 = fmaf(acc[r] * nri.y, cj, nri.x + nj);   // |xi|^2 + |xj|^2 - 2 (xs_i . xs_j) / (s_i s_j)
+        if (!FASTSIG) d2 = fmaxf(d2, 0.f);
+        if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
+        const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+        float El, G;
+        sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+        float f = El - Eh;
+        if (masked) f = (i0 + ib + ro < a.row_end && jok) ? f : 0.f;
+        lsum = fmaf(f, f, lsum);
+        const float g = f * G;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          float v = g * dz[l];
+          gj[l] -= v;
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+          rp_b[(ro * LMAX + l) * RP] = v;
+        }
+      };
+#if EMX_TILE_EXP != 1
+      if (edge) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pair(r, true);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) pair(r, false);
+      }
+#else
+      lsum = acc[0] + acc[5] + zj[0] + nj + cj + zi_b[0] + nr_b[0].x;
+      (void)pair;
+      (void)rp_b;
+#endif
+      if (offdiag) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          float s = sum_xor32(gj[l]);   // the two row halves of the quadrant
+          if (h == 0) cpart[(jl * LMAX + l) * 2 + wm] = s;
+        }
+      }
+      // tile cost: block_sum<256>'s order (wave sums, then waves 0..3) on this half's four waves
+      {
+        const float v = wave_sum(lsum);
+        if (lane == 0) red[wave] = v;
+      }
+      __syncthreads();   // partials and wave sums visible
+      if (tid == 0 && cvalid) {
+        float tl = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tl += red[i];
+        a.tile_loss[cti * a.nbc - cti * (cti - 1) / 2 + (ctj - cti)] = offdiag ? 2.f * tl : tl;   // (row-major triangle index)
+      }
+      if (cvalid) {
+        for (int e = tid; e < T * LMAX; e += HNT) {
+          const int rl = e / LMAX, l = e - rl * LMAX;
+          const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+          const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+          const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                          (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+          a.P[((long)ctj * a.nrows_pad + i0 + rl) * L + l] = s;
+        }
+        if (offdiag) {
+          for (int e = tid; e < T * LMAX; e += HNT) {
+            const int rl = e / LMAX, l = e - rl * LMAX;
+            a.P[((long)cti * a.nrows_pad + j0 + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+          }
+        }
+      }
+      cur = nxt;
+      zi_c = zi_n;
+      zj_c[0] = zj_n[0];
+      zj_c[1] = zj_n[1];
+      z_c = z_n;
     }
   }
-  // the last tile workgroup to finish resets the launch's counters (every chain workgroup has published by then: this
-  // workgroup saw the full count)
+report:
+  // the last tile workgroup to finish resets the launch's counters (every chain workgroup has published by then: a tile
+  // workgroup with work saw the full count)
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == (unsigned)tr.n_tile_wgs - 1) {

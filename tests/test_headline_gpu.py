@@ -230,6 +230,7 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, monkeypat
     data = blobs(rng, 6000, D)
     idx = rng.integers(0, 6000, (steps, B))
     out = []
+    monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
     for overlap in (True, False):
         monkeypatch.setattr(SequentialEngine, "_overlap_tiles", overlap)
         p = em.Parameters(periodicity=INF, batch_size=B, dist_sig_parameters=(math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def main():
     src = sys.argv[1]
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-amdgpu-kernarg-preload-count=16",
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-mllvm", "-amdgpu-kernarg-preload-count=16",
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "encodermap_amd", "csrc"), *sys.argv[2:], "-c", src, "-o", "/dev/null",
            "-Rpass-analysis=kernel-resource-usage"]
     out = subprocess.run(cmd, capture_output=True, text=True, cwd=ROOT)

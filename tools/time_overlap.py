@@ -17,6 +17,7 @@ from encodermap_amd.engine import SequentialEngine  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 INF = float("inf")
+os.environ.setdefault("EMX_OVERLAP_MAX_B", "1000000")   # (the engine limits the tiles-aboard plan to small batches: lifted for the A/B)
 rng = np.random.default_rng(1)
 cen = rng.normal(0, 4, (16, D))
 data = (cen[rng.integers(0, 16, 200000)] + rng.normal(0, 1, (200000, D))).astype(np.float32)
