@@ -445,12 +445,12 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   auto exec = [&](auto RC) __attribute__((always_inline)) {
     constexpr int r = decltype(RC)::value;          // slot being requested into
     constexpr int rx = (r + 1) % NB;                // slot being executed
-    // The lane-dependent address parts.  Where the kernel must fit 128 registers (PUB_OFF > 0: chain_tiles_kernel shares its CUs
-    // with the tile workgroups) they are re-derived from the work-item id in every unit instead of living in registers across
+    // The lane-dependent address parts.  Where the kernel must fit 128 registers (PUB_OFF != 0: chain_tiles_kernel shares its CUs
+    // with the tile workgroups, chain_kernel_c128 with a second chain workgroup) they are re-derived from the work-item id in every unit instead of living in registers across
     // the unit loop: there the allocator spilled them to scratch, and a scratch reload sits in the same in-order memory counter
     // as the weight packages -- every unit then waited for its NEXT package.
     int ln = lane;
-    if constexpr (PUB_OFF > 0) {
+    if constexpr (PUB_OFF != 0) {
       ln = (int)(threadIdx.x & 63u);
       asm volatile("" : "+v"(ln));
     }
@@ -471,35 +471,39 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
 
     if (ex.c == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // A fragments of the chunk's four K-steps up front (one LDS latency per unit)
-    half8 ah[4], al[4];
-    f32x4 rsa[4];
-    {
-      const char* apl = lds + X.src_pl + ex.c * 4096 + lane8;
+    // A fragments of the chunk's four K-steps up front (one LDS latency per unit) -- or, where the backward kernel is held to 128
+    // registers (chain_kernel_c128: a second workgroup on the CU runs in this one's gaps), two K-steps at a time
+    constexpr int AF = (BWD && PUB_OFF != 0) ? 2 : 4;
+    half8 ah[AF], al[AF];
+    f32x4 rsa[AF];
+    const char* apl = lds + X.src_pl + ex.c * 4096 + lane8;
+    const char* asc = lds + X.src_sc + ex.c * 256 + g * 16;
+    auto fragments = [&](const int s0) __attribute__((always_inline)) {
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const half4 h0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + s * 1024));
-        const half4 h1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + s * 1024 + 512));
-        const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + s * 1024));
-        const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + s * 1024 + 512));
+      for (int s = 0; s < AF; ++s) {
+        const half4 h0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + (s0 + s) * 1024));
+        const half4 h1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + (s0 + s) * 1024 + 512));
+        const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + (s0 + s) * 1024));
+        const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(apl + X.src_lo + (s0 + s) * 1024 + 512));
         ah[s] = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
         al[s] = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
       }
       if (dyn) {
-        const char* asc = lds + X.src_sc + ex.c * 256 + g * 16;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) rsa[s] = *reinterpret_cast<const f32x4*>(asc + s * 64);
+        for (int s = 0; s < AF; ++s) rsa[s] = *reinterpret_cast<const f32x4*>(asc + (s0 + s) * 64);
       }
-    }
+    };
+    fragments(0);
     if (dyn) {
       // per-(row, 32 columns) source scales: each K-step's product is unscaled as it is added
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
+        if (AF < 4 && s == AF) fragments(AF);
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][1], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], d, 0, 0, 0);
-        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], d, 0, 0, 0);
-        acc = d * rsa[s] + acc;
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], d, 0, 0, 0);
+        d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], d, 0, 0, 0);
+        acc = d * rsa[s % AF] + acc;
         request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -507,9 +511,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       // tanh outputs at their fixed scale: the whole reduction accumulates inside the matrix instruction
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s], wp[rx][s][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s], wp[rx][s][0], acc, 0, 0, 0);
+        if (AF < 4 && s == AF) fragments(AF);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], acc, 0, 0, 0);
         request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -836,6 +841,16 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
                                                     int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
                                                     const ChainArgs a) {
   chain_body<MODE, NB, 0>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
+}
+
+// The same kernels held to 128 registers per lane: TWO workgroups per CU (four waves per SIMD) where the plain build has room
+// for one.  For batches of several row blocks per CU (8192 rows and more): a unit of the chain is a serial string of dependent
+// trips -- LDS fragments, matrix instructions, epilogue, barrier -- and a second resident row block runs in its gaps.
+template <int MODE, int NB>
+__global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_kernel_c128(
+    const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols, int p_row0, int p_row_end, int p_ldt, int p_cost_n,
+    int p_in_Q, int p_with_cost, const ChainArgs a) {
+  chain_body<MODE, NB, -1>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
 }
 
 // The fused launch with the all-pairs tiles aboard (sk_tile.h): workgroups [0, row blocks) are the chain workgroups, the rest run two
@@ -1276,6 +1291,15 @@ int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStr
   static const int force_nb = getenv("EMX_CHAIN_NB") ? atoi(getenv("EMX_CHAIN_NB")) : 0;
   const bool deep = force_nb >= 3;   // (measured at C2: the deeper ring buys nothing -- the kernels are bound by instruction issue -- and costs registers)
   int rc;
+  // several row blocks per CU and LDS for two of them: the 128-register build, two workgroups per CU
+  static const int c128_min_blocks = getenv("EMX_CHAIN_C128_MIN_BLOCKS") ? atoi(getenv("EMX_CHAIN_C128_MIN_BLOCKS")) : 512;
+  if (!deep && grid >= c128_min_blocks && 2 * (lds + 1024) <= 160 * 1024) {
+    rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_c128<MODE, 2>), lds, b.who);
+    if (rc) return rc;
+    hipLaunchKernelGGL((chain_kernel_c128<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
+                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
+    return emx::check_launch(what);
+  }
   if (deep) {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 3>), lds, b.who);
     if (rc) return rc;

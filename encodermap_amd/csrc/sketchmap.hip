@@ -783,6 +783,11 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // beside them, and its cost into the slot of 64-tile (2 TI, 2 TJ) (zeros into its other 64-tiles' slots): the sums the
 // consumers form over the slots are those of the 64-tile pass up to the association of the additions.  Two latent columns, not
 // for dealt tiles (the deal is by 64-tile).
+// Measured at B = 16384, D = 256 (profiles/r03_c5_counters.json): 335 -> 257 us; matrix pipe 35 %, VALU 51 % busy, L2 hit rate 90 %
+// -- the two pipes take turns (products, then 64 sigmoid pairs per lane) in every workgroup, and three workgroups per CU do not
+// interleave them enough.  Also built, measured, removed: the XCD's tiles walked in 8 x 8 sub-blocks (16 shared panels instead
+// of a whole row of them; 457.8 against 450.5 us per step: the planes are served by the L2s either way) and the rolled K loop at
+// 128 registers, four workgroups per CU (451.9 against 453.4 us).
 // ---------------------------------------------------------------------------------------------------------------------
 template <bool FASTSIG, int NCH>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(3, 3))) void sk_tile_f16_big_kernel(
