@@ -106,7 +106,7 @@ class DataParallel:
         if op == "sum":
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return
-        if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl":
+        if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl" and os.environ.get("EMX_DP_AVG", "1") != "0":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -553,6 +553,7 @@ class SequentialEngine:
         graph for the whole step.  Data parallel: one graph up to the gradients, the RCCL all-reduce issued eagerly
         on the same stream, one graph for Adam + bookkeeping."""
         self._graph_multi = None
+        self._graph_wrap = None
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         saved = [t.clone() for t in self._state_tensors()]
@@ -606,13 +607,23 @@ class SequentialEngine:
                 pass
             elif self.dp.active:
                 graphs, pool = [], None
-                for launches, _ in self._dp_segments():
+                segs = self._dp_segments()
+                for launches, _ in segs:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g, pool=pool):
                         launches()
                     pool = pool or g.pool()
                     graphs.append(g)
                 self._graph = tuple(graphs)
+                # consecutive steps: the optimizer launch of step t and everything of step t + 1 up to its first collective as ONE
+                # graph -- a step is then (number of collectives) graph launches instead of one more (each costs ~9 us of idle
+                # device between a graph and an eagerly issued collective, profiles/r03_dp_one_rank_timeline.txt)
+                restore()
+                gw = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gw, pool=pool):
+                    segs[-1][0]()
+                    segs[0][0]()
+                self._graph_wrap = gw
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
@@ -650,12 +661,25 @@ class SequentialEngine:
             k //= 2
         return out
 
-    def _replay(self) -> None:
+    _graph_wrap = None   # data parallel: [last segment of step t | first segment of step t + 1] as one graph
+
+    def _replay(self, k: int = 1) -> None:
+        """k consecutive steps from the captured graphs"""
         if len(self._graph) == 1:
-            self._graph[0].replay()
-        else:
-            for g, (_, collective) in zip(self._graph, self._dp_segments()):
-                g.replay()
+            for _ in range(k):
+                self._graph[0].replay()
+            return
+        segs = self._dp_segments()
+        wrap = self._graph_wrap if os.environ.get("EMX_DP_WRAP", "1") != "0" else None
+        for i in range(k):
+            for j, (g, (_, collective)) in enumerate(zip(self._graph, segs)):
+                last = j == len(segs) - 1
+                if j == 0 and i > 0 and wrap is not None:
+                    pass                      # (ran inside the wrap graph behind the previous step's optimizer)
+                elif last and i + 1 < k and wrap is not None:
+                    wrap.replay()             # this step's optimizer launch + the next step up to its first collective
+                else:
+                    g.replay()
                 if collective is not None:
                     collective()
 
@@ -699,8 +723,7 @@ class SequentialEngine:
                         while r >= size:
                             self._graph_multi[size].replay()
                             r -= size
-                for _ in range(r):
-                    self._replay()
+                self._replay(r)
             else:
                 for _ in range(k):
                     self._step_body()
