@@ -785,7 +785,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // for dealt tiles (the deal is by 64-tile).
 // Measured at B = 16384, D = 256 (profiles/r03_c5_counters.json): 335 -> 257 us; matrix pipe 35 %, VALU 51 % busy, L2 hit rate 90 %
 // -- the two pipes take turns (products, then 64 sigmoid pairs per lane) in every workgroup, and three workgroups per CU do not
-// interleave them enough.  Also built, measured, removed: the XCD's tiles walked in 8 x 8 sub-blocks (16 shared panels instead
+// interleave them enough (both busy together in a fifth of the matrix cycles; waves waiting for an instruction's result 45 % of
+// their time: profiles/r03_c5_stalls.json).  Also built, measured, removed: a persistent, software-pipelined form -- one workgroup
+// of eight waves per CU walking its tiles with TWO accumulator sets per wave, the products of tile k + 1 issued between the
+// epilogue rows of tile k (two matrix instructions, then a row of pairs; operand pieces three chunks ahead in a register ring):
+// 612-747 us per step against 452 -- with two waves per SIMD and one pair per lane and row the epilogue is a string of dependent
+// instructions, where this kernel's sixteen unrolled pairs give the scheduler sixteen independent chains; the XCD's tiles walked in 8 x 8 sub-blocks (16 shared panels instead
 // of a whole row of them; 457.8 against 450.5 us per step: the planes are served by the L2s either way) and the rolled K loop at
 // 128 registers, four workgroups per CU (451.9 against 453.4 us).
 // ---------------------------------------------------------------------------------------------------------------------
