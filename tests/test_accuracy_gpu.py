@@ -27,9 +27,13 @@ def _check(table, factor=2.0, floor=2e-7):
 
 @pytest.mark.parametrize("name", list(A.SHAPES))
 def test_dense_layers_are_float32_accurate(em, name):
+    """Euclidean shapes: 2 x (observed: at most 1.30 x, most quantities 0.3-0.9 x).  The periodic C4 shape: 2.5 x -- behind the atan2
+    of its output layer d cost / d (sin, cos) = g (c, -s) / (s^2 + c^2) amplifies the relative error of SMALL outputs, and the
+    engine's operands carry an error relative to the largest element of their 32-column block: its decoder-side gradients are
+    1.6-1.8 x the float32 run's there (1e-4 both), its activations 0.85 x."""
     table = A.dense_layer_errors(em, name)
     print(A.format_table(name, table))
-    _check(table)
+    _check(table, factor=2.5 if name.startswith("C4") else 2.0)
 
 
 @pytest.mark.parametrize("B,D", [(4096, 128), (1024, 256)])

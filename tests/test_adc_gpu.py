@@ -201,7 +201,9 @@ def test_adc_free_running_drift_envelope(em):
     oracle leaves the float64 one by 0.1-10 % within the 10 steps -- so the ratio of two such deviations is a noisy statistic:
     over four seeds the largest single-term ratio was 5.4, 4.1, 1.9 and 1.4, that of the total loss 1.8, 3.2, 1.1 and 1.2
     (profiles/r02_d2c_accuracy.txt, tools/adc_drift_seeds.py), while step for step the back-mapping kernels are 3-10x closer to
-    float64 than the float32 oracle (same file, tools/d2c_check.py).  A wrong gradient shows up as a ratio in the hundreds."""
+    float64 than the float32 oracle (same file, tools/d2c_check.py).  A wrong gradient shows up as a ratio in the hundreds.
+    Round 3, the same four seeds on this round's kernels: largest single-term ratio 0.52, 4.13, 1.13, 1.45, total loss 0.4, 3.24,
+    1.02, 1.29 -- the bounds (4 and 8) stay what four seeds support with a margin of 1.2-1.9."""
     from tests.test_training_gpu import drift_ratio
 
     name, kw, n_res, n_side, B = CASES[3]

@@ -284,8 +284,9 @@ def test_long_horizon_drift_envelope(em, name, kw, maker, n_steps):
     arithmetic causes in the REFERENCE FORMULATION ITSELF as the yardstick: the oracle loop is run in float64 and in float32
     on identical weights and batches, and the engine must stay within
         |engine - f64|_t <= K max_{s<=t} |oracle_f32 - f64|_s + 1e-4 |f64|_t     at every step t, total loss and every cost term,
-    K = 4: the engine's matrix products carry 22-bit operands (two f16 planes, csrc/wop.h) against the 24 bits of a
-    float32 run -- a rounding noise up to four times that of the float32 oracle, which the same (chaotic) dynamics amplify."""
+    K = 2 (round 3; it was 4): per quantity of a step the engine is closer to float64 than the float32 oracle or within 1.3 x of
+    it on these shapes (profiles/r03_split_accuracy.txt, tests/test_accuracy_gpu.py), and the ratios observed here are <= 0.64
+    in all three configurations (most are negative: inside the 1e-4 band without the envelope's help)."""
     rng = np.random.default_rng(21)
     data = maker(rng)
     p = em.Parameters(n_steps=n_steps, **kw)
@@ -302,7 +303,7 @@ def test_long_horizon_drift_envelope(em, name, kw, maker, n_steps):
         runs[dt] = R.train_steps(model, data, idx, p.to_dict())
     f64, t64 = runs[torch.float64]
     f32, t32 = runs[torch.float32]
-    K = 4.0
+    K = 2.0
     ratios = {"loss": drift_ratio(got, f64, f32)}
     for k in ("auto", "reg", "center", "distance"):
         ratios[k] = drift_ratio(got_terms[k], [t[k] for t in t64], [t[k] for t in t32])
