@@ -134,11 +134,12 @@ __device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long ro
 
 
 // (leading scalars: tile decode and the first row loads, preloaded into scalar registers at wave launch; 56 bytes, the struct follows)
+constexpr int SK_LT_ANY = 9;   // LT of sk_tile_kernel: any latent width, walked in chunks of eight columns
 template <int TM, int TN, int LT, int PMODE, bool FASTSIG>
 __global__ __launch_bounds__(NT) void sk_tile_kernel(const float* p_X, int p_ldx, int p_D, int p_B, int p_row0, int p_row_end, int p_nbc, int p_symm,
                                                      int p_xcd_nbg, int p_vec4, int p_deal_world, int p_deal_rank, int p_pad, const SkArgs a) {
   constexpr int RM = TM / 16, RN = TN / 16;
-  constexpr int LMAX = LT ? LT : 4;
+  constexpr int LMAX = LT == SK_LT_ANY ? 8 : (LT ? LT : 4);
   constexpr int STAGE = (TM + TN) * LS;
   constexpr int PART = 16 * (TM + TN) * LMAX;
   constexpr int SMEM = (STAGE > PART ? STAGE : PART) + 8;
@@ -221,6 +222,127 @@ __global__ __launch_bounds__(NT) void sk_tile_kernel(const float* p_X, int p_ldx
     for (int r = 0; r < RM; ++r)
 #pragma unroll
       for (int c = 0; c < RN; ++c) acc[r][c] *= a.phase_unit2;
+  }
+
+  // ---- epilogue, any latent width (LT = SK_LT_ANY; the reference stacks any n_neurons, models.py:3133-3160): the low-d squared
+  //      distances over ALL columns first, eight at a time; then, chunk by chunk, the gradient's partial sums as below
+  if constexpr (LT == SK_LT_ANY) {
+    float wr[RM], wc[RN];
+    long rowi[RM], rowj[RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int row = i0 + ty + 16 * r;
+      wr[r] = row < a.row_end ? 1.f : 0.f;
+      rowi[r] = (long)min(row, a.B - 1) * L;
+    }
+#pragma unroll
+    for (int c = 0; c < RN; ++c) {
+      const int row = j0 + tx + 16 * c;
+      wc[c] = row < a.B ? 1.f : 0.f;
+      rowj[c] = (long)min(row, a.B - 1) * L;
+    }
+    float dl2[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) dl2[r][c] = 0.f;
+    for (int l0 = 0; l0 < L; l0 += 8) {
+      float zi[RM][8], zj[RN][8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r) zi[r][l] = l0 + l < L ? a.Z[rowi[r] + l0 + l] : 0.f;
+#pragma unroll
+        for (int c = 0; c < RN; ++c) zj[c][l] = l0 + l < L ? a.Z[rowj[c] + l0 + l] : 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RN; ++c)
+#pragma unroll
+          for (int l = 0; l < 8; ++l) {
+            const float dz = zi[r][l] - zj[c][l];
+            dl2[r][c] = fmaf(dz, dz, dl2[r][c]);
+          }
+    }
+    float g[RM][RN];
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) {
+        const float Eh = sig_E_high<FASTSIG>(acc[r][c], a.sh);
+        float El, G;
+        sig_E_low<FASTSIG>(dl2[r][c], a.sl, El, G);
+        const float f = (El - Eh) * (wr[r] * wc[c]);
+        lsum = fmaf(f, f, lsum);
+        g[r][c] = f * G;
+      }
+    float* red = smem + SMEM - 8;
+    const float tl = block_sum<NT>(lsum, red);
+    if (tid == 0) a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
+    float* rpart = smem;                       // [TM][8][16]
+    float* cpart = smem + 16 * TM * 8;         // [TN][8][16]
+    for (int l0 = 0; l0 < L; l0 += 8) {
+      float zi[RM][8], zj[RN][8], gi[RM][8];
+#pragma unroll
+      for (int l = 0; l < 8; ++l) {
+#pragma unroll
+        for (int r = 0; r < RM; ++r) {
+          zi[r][l] = l0 + l < L ? a.Z[rowi[r] + l0 + l] : 0.f;
+          gi[r][l] = 0.f;
+        }
+#pragma unroll
+        for (int c = 0; c < RN; ++c) zj[c][l] = l0 + l < L ? a.Z[rowj[c] + l0 + l] : 0.f;
+      }
+      __syncthreads();   // (the chunk in front has been folded)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) {
+        float gj[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) gj[l] = 0.f;
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+          for (int l = 0; l < 8; ++l) {
+            const float dz = zi[r][l] - zj[c][l];
+            gi[r][l] = fmaf(g[r][c], dz, gi[r][l]);
+            gj[l] = fmaf(-g[r][c], dz, gj[l]);
+          }
+        if (offdiag) {
+#pragma unroll
+          for (int l = 0; l < 8; ++l) cpart[((tx + 16 * c) * 8 + l) * 16 + ty] = gj[l];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int l = 0; l < 8; ++l) rpart[((ty + 16 * r) * 8 + l) * 16 + tx] = gi[r][l];
+      __syncthreads();
+      for (int e = tid; e < TM * 8; e += NT) {
+        const int rl = e >> 3, l = l0 + (e & 7);
+        if (l < L) {
+          const float4* p = reinterpret_cast<const float4*>(&rpart[e * 16]);
+          const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+          const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                          (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+          a.P[((long)tj * a.nrows_pad + (i0 - a.row0) + rl) * L + l] = s;
+        }
+      }
+      if (offdiag) {
+        for (int e = tid; e < TN * 8; e += NT) {
+          const int rl = e >> 3, l = l0 + (e & 7);
+          if (l < L) {
+            const float4* p = reinterpret_cast<const float4*>(&cpart[e * 16]);
+            const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+            const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+            a.P[((long)ti * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = s;   // symm => row0 == 0
+          }
+        }
+      }
+    }
+    return;
   }
 
   // ---- epilogue -----------------------------------------------------------------------------
@@ -1136,7 +1258,7 @@ size_t ws_front_floats(int B, int L) {
 }
 
 int pick_tile(int B, int nrows, bool gram, bool periodic, int L) {
-  if (L > 4) return 32;   // latent widths 5..8 run the 32 x 32 VALU tiles (their partial-sum area fits the static LDS limit at that size
+  if (L > 4) return 32;   // latent widths 5 and more run the 32 x 32 VALU tiles (their partial-sum area fits the static LDS limit at that size
                           // only); like the rule below a function of what every entry point that plans the workspace layout knows
   if (periodic && B <= SMALL_TILE_MAX_B) return 32;   // (a function of B and the periodicity only: every entry point that plans
                                                       //  the workspace layout knows both)
@@ -1194,7 +1316,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
               float* dZ, void* ws, size_t ws_bytes, SkPlan& pl, const char* who, void* split_ws = nullptr, float data_span = 0.f) {
   EMX_REQUIRE(X && Z && ws && sig, "%s: null pointer argument", who);
   EMX_REQUIRE(B > 0 && D > 0 && ldx >= D, "%s: bad shape B=%d D=%d ldx=%d", who, B, D, ldx);
-  if (L < 1 || L > 8) return emx::fail(EMX_EUNSUPPORTED, "%s: latent dimension %d not supported (1..8)", who, L);
+  EMX_REQUIRE(L >= 1 && L <= 4096, "%s: latent dimension %d", who, L);
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end && row_end <= B, "%s: bad row block [%d,%d) of %d", who, row_begin,
               row_end, B);
   EMX_REQUIRE(periodicity > 0.f, "%s: periodicity must be > 0 (INFINITY for none)", who);
@@ -1354,6 +1476,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   }
   if (pl.T == 32) {
     if (a.L == 2) dispatch2<32, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
+    else if (a.L > 8) dispatch2<32, SK_LT_ANY>(a, pl.ntiles, pl.periodic, pl.fast, st);   // any width, eight columns at a time
     else if (a.L > 4) dispatch2<32, 8>(a, pl.ntiles, pl.periodic, pl.fast, st);
     else dispatch2<32, 0>(a, pl.ntiles, pl.periodic, pl.fast, st);
   } else if (pl.T != 64) {

@@ -61,7 +61,7 @@ int64_t emx_launch_count(void);
  *             sigmoid_loss_func        encodermap/loss_functions/loss_functions.py:351-367
  *             distance_loss_func       encodermap/loss_functions/loss_functions.py:266-296 (the x scale)
  *             center_loss_func         encodermap/loss_functions/loss_functions.py:422-449 (optional fused term)
- *   X [B, D] (row stride ldx floats) high-d rows (data, no gradient); Z [B, L] latent, L in 1..8.
+ *   X [B, D] (row stride ldx floats) high-d rows (data, no gradient); Z [B, L] latent, any L >= 1 (widths beyond 8 are walked eight columns at a time).
  *   periodicity: INFINITY -> Euclidean, else the period of X.
  *   data_span: for periodic X, max - min over the data the rows are drawn from if the caller knows it, else 0.  Below 1.5
  *   periods every |x_i - x_j| < 1.5 p, where the reference's min(|d|, p - |d|)^2 is the squared wrapped difference, and the

@@ -70,6 +70,11 @@ SK_CASES = [
     (300, 16, 5, INF, (4.0, 12, 6, 1, 2, 6)),
     (700, 33, 8, 2 * PI, DEFAULT_SIG),
     (260, 10, 7, INF, (2.0, 3, 6, 1, 2, 6)),
+    # any latent width (round 3): beyond eight columns the tiles walk the latent eight columns at a time (SK_LT_ANY)
+    (300, 16, 9, INF, (4.0, 12, 6, 1, 2, 6)),
+    (700, 33, 16, 2 * PI, DEFAULT_SIG),
+    (333, 10, 21, INF, (2.0, 3, 6, 1, 2, 6)),
+    (150, 40, 64, 2 * PI, (8.0, 12, 6, 2.5, 2, 6)),
 ]
 
 
@@ -179,11 +184,10 @@ def test_sketchmap_deterministic_and_rejects(L):
     a = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
     b = run_sketchmap(L, x, z, INF, DEFAULT_SIG, 500.0, 1e-4, 0, 777)
     assert a[0] == b[0] and np.array_equal(a[2], b[2])           # bitwise reproducible
-    X, Z = dev(x), dev(np.zeros((777, 9), np.float32))
-    ws = torch.empty(1 << 20, device="cuda")
-    with pytest.raises(L.EmxError, match="latent dimension"):       # 1 .. 8 latent columns
-        L.sketchmap_fwd_bwd(X, Z, INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
-                            torch.zeros(777, 9, device="cuda"), ws)
+    X = dev(x)
+    with pytest.raises(L.EmxError, match="workspace"):              # (nine latent columns are fine since round 3 -- with room for them)
+        L.sketchmap_fwd_bwd(X, dev(np.zeros((777, 9), np.float32)), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
+                            torch.zeros(777, 9, device="cuda"), torch.empty(L.sketchmap_ws_bytes(777, 2) // 4, device="cuda"))
     with pytest.raises(L.EmxError, match="workspace"):
         L.sketchmap_fwd_bwd(X, dev(z), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
                             torch.zeros(777, 2, device="cuda"), torch.empty(16, device="cuda"))
@@ -537,6 +541,7 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     (600, 64, 6, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 8, (5.0, 3, 6, 1, 2, 6), 100, 300),       # latent widths 5 .. 8
     # batches of 8192 rows and more: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); ragged last tiles,
     # an odd number of 64-row blocks, the general sigmoid
+    (600, 64, 12, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 19, (5.0, 3, 6, 1, 2, 6), 100, 300),      # latent widths beyond 8
     (8192, 32, 2, (8.0, 12, 6, 1, 2, 6), 0, 8192), (8300, 64, 2, (11.0, 12, 6, 1, 2, 6), 0, 8300), (8256, 40, 2, (9.0, 3, 6, 1, 2, 6), 0, 8256)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct

@@ -64,6 +64,9 @@ CASES = [
     # a five-dimensional latent space (the reference stacks any n_neurons, models.py:3133-3160)
     ("latent_5d", dict(periodicity=INF, n_neurons=[64, 32, 5], batch_size=300, dist_sig_parameters=(6.0, 12, 6, 1, 2, 6)),
      lambda r: (r.normal(0, 3, (6, 24))[r.integers(0, 6, 3000)] + r.normal(0, 1, (3000, 24))).astype(np.float32)),
+    # a twelve-dimensional latent space: beyond eight columns the all-pairs tiles walk the latent in chunks (round 3)
+    ("latent_12d", dict(periodicity=INF, n_neurons=[64, 32, 12], batch_size=300, dist_sig_parameters=(6.0, 12, 6, 2.0, 2, 6)),
+     lambda r: (r.normal(0, 3, (6, 24))[r.integers(0, 6, 3000)] + r.normal(0, 1, (3000, 24))).astype(np.float32)),
     # C5's shape (configs[4]): 256 Euclidean features
     ("c5_shape_euclid_256", dict(periodicity=INF, batch_size=384, dist_sig_parameters=(22.6, 12, 6, 1, 2, 6)),
      lambda r: (r.normal(0, 4, (16, 256))[r.integers(0, 16, 4000)] + r.normal(0, 1, (4000, 256))).astype(np.float32)),
