@@ -151,7 +151,9 @@ def test_one_rank_over_rccl(mode, tmp_path):
 
 
 @pytest.mark.parametrize("mode,extra,batch,scaling", [("replica", [], 2 * 4096, "weak"), ("rowblock", [], 4096, "strong"),
-                                                       ("rowblock", ["--global-batch", "0"], 2 * 4096, "weak")])
+                                                       ("rowblock", ["--global-batch", "0"], 2 * 4096, "weak"),
+                                                       # BASELINE config 5 (defined on 8 GPUs): ONE global batch of 16384 rows over the ranks
+                                                       ("rowblock", ["--config", "C5", "--rows", "40000"], 16384, "strong")])
 def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
     """bench.py's N > 1 plumbing (rank environment, DataParallel modes, barrier, MAX over ranks of the timed region, one JSON
     line from rank 0 that names its objective and the ranks it saw) under torch.distributed.run with two ranks -- on this one
@@ -172,6 +174,7 @@ def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
     cfg = line["config"]
     assert cfg["global_batch"] == batch and cfg["parallelism"] == f"dp2-{mode}" and cfg["ranks_seen"] == 2
     assert cfg["allreduce"] == "eager between the step's graphs" and str(batch if mode == "rowblock" else 4096) in cfg["objective"]
+    assert cfg["name"] == ("C5" if "C5" in extra else "C2") and cfg["name"] in cfg["workload"]
     assert line["value"] == pytest.approx(batch * line["steps_per_sec"], rel=1e-6)
     assert line["dtype"].startswith("f32") and line["roofline_all_pairs"]["kernel"] == "sk_tile_f16_kernel"
     assert all(np.isfinite(v) for v in line["loss_first_last"]) and "cpu_baseline" not in line
