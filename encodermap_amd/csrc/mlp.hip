@@ -1638,7 +1638,14 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   if (dbg == 4) tr.n_tile_wgs = std::min(tr.n_tile_wgs, 8);   // eight tile workgroups beside the chain workgroups: what do they cost the chain?
   hipStream_t st = (hipStream_t)stream;
   static_assert(sizeof(ChainArgs) + sizeof(emx::sk::TileRole) + 56 <= 4096, "kernel arguments of chain_tiles_kernel");
-  if (!fast) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role is built for the (12, 6 | 2, 6) sigmoid family", who);
+  if (!fast) {   // general sigmoid exponents (e.g. the cube example's (0.2, 3, 6 | 1, 2, 6)): rows of up to 128 features
+    switch (nch) {
+      case 1: return launch_chain_tiles<false, 1>(b, tr, grid, lds, st);
+      case 2: return launch_chain_tiles<false, 2>(b, tr, grid, lds, st);
+      case 4: return launch_chain_tiles<false, 4>(b, tr, grid, lds, st);
+      default: return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role with general sigmoid exponents is built for rows of up to 128 features", who);
+    }
+  }
   switch (nch) {
     case 1: return launch_chain_tiles<true, 1>(b, tr, grid, lds, st);
     case 2: return launch_chain_tiles<true, 2>(b, tr, grid, lds, st);

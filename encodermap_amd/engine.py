@@ -244,10 +244,17 @@ class SequentialEngine:
         self._shuffle_seed, self._shuffle_epoch = int(seed), 0
         self._perm = torch.empty(0, dtype=torch.int64, device=self.device)   # the pass being consumed ...
         self._perm_pos = 0                                                   # ... and how much of it is used up
+        self._pending = None
+        self._ring_pos = self._ring_filled = 0                               # (the index block starts over: run_steps)
 
     def draw_index_block(self, n_batches: int) -> torch.Tensor:
         """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes.  Every pass is one
         emx_permute (a keyed bijection evaluated per element: no sort, no host work); torch only owns the buffers."""
+        if self._pending is not None:
+            first, self._pending = self._pending, None
+            if n_batches == 1:
+                return first
+            return torch.cat([first, self.draw_index_block(n_batches - 1)])
         need = n_batches * self.B
         N = self.data.shape[0]
         have = self._perm.numel() - self._perm_pos
@@ -692,10 +699,14 @@ class SequentialEngine:
             return
         if int(self.hstep_host()) + n_steps > self.history_capacity:
             self._grow_history(int(self.hstep_host()) + n_steps)
-        block = index_block if index_block is not None else self.draw_index_block(n_steps)
-        if block.numel() != n_steps * self.B:
+        if index_block is None and not self._append_blocks:
+            index_block = self.draw_index_block(n_steps)     # (EMX_APPEND_BLOCKS=0: the drawn block takes the caller's path)
+            block, validated = index_block, True
+        else:
+            block, validated = index_block, False
+        if block is not None and block.numel() != n_steps * self.B:
             raise ValueError(f"index block has {block.numel()} entries, expected {n_steps} x {self.B}")
-        if index_block is not None:
+        if index_block is not None and not validated:
             # the gather kernels dereference data + idx * D unchecked: validate a caller's block once, outside the graph
             wrong_dev = block.device.type != self.device.type or (self.device.index is not None and block.device.index != self.device.index)
             if block.dtype != torch.int64 or wrong_dev:
@@ -707,28 +718,72 @@ class SequentialEngine:
         if self.idx_block is None or self.idx_block.numel() < cap * self.B:
             self.idx_block = torch.zeros(cap * self.B, dtype=torch.int64, device=self.device)
             self._graph = None
-        done = 0
-        while done < n_steps:
-            k = min(cap, n_steps - done)
-            self.idx_block[: k * self.B].copy_(block[done * self.B: (done + k) * self.B])
-            self.cursor.zero_()
-            if self._prefetch:
-                self._gather_current()
-            if self.use_graph:
-                if self._graph is None:
-                    self._capture()
-                r = k
-                if len(self._graph) == 1 and self._graph_multi:
-                    for size in sorted(self._graph_multi, reverse=True):   # 8, 4, 2: 20 steps are 8 + 8 + 4, three replays
-                        while r >= size:
-                            self._graph_multi[size].replay()
-                            r -= size
-                self._replay(r)
-            else:
-                for _ in range(k):
-                    self._step_body()
-            done += k
+            self._ring_pos = self._ring_filled = 0
+        B = self.B
+        if index_block is None and self._append_blocks:
+            # Batches of the engine's own shuffle stream are APPENDED to the index block behind the cursor, one batch ahead of what
+            # this call consumes: the optimizer launch of the last step finds the rows of the next call's first batch, so a call
+            # costs one small copy -- no cursor reset, no head gather (three launches and their host time per call: what made a
+            # 20-step run 9 % slower per step than a 300-step run).  The block restarts at its front every ~1000 steps.
+            done = 0
+            while done < n_steps:
+                room = cap - 1 - self._ring_pos
+                if room <= 0:
+                    # restart: the batch under the cursor (drawn, its rows already gathered by the last optimizer launch) moves to the front
+                    self.idx_block[:B].copy_(self.idx_block[self._ring_pos * B: (self._ring_pos + 1) * B].clone())
+                    self.cursor.zero_()
+                    self._ring_pos, self._ring_filled = 0, 1
+                    continue
+                k = min(room, n_steps - done)
+                need = self._ring_pos + k + 1 - self._ring_filled
+                if need > 0:
+                    fresh = self._ring_filled == 0
+                    self.idx_block[self._ring_filled * B: (self._ring_filled + need) * B].copy_(self.draw_index_block(need))
+                    self._ring_filled += need
+                    if fresh:
+                        self.cursor.zero_()
+                        if self._prefetch:
+                            self._gather_current()
+                self._run_k(k)
+                self._ring_pos += k
+                done += k
+        else:
+            # a caller's index block: written at the front of the block, the cursor reset, its first batch gathered.  A batch the
+            # shuffle stream had drawn ahead goes back to the stream.
+            if self._ring_filled > self._ring_pos:
+                self._pending = self.idx_block[self._ring_pos * B: (self._ring_pos + 1) * B].clone()
+            self._ring_pos = self._ring_filled = 0
+            done = 0
+            while done < n_steps:
+                k = min(cap, n_steps - done)
+                self.idx_block[: k * B].copy_(block[done * B: (done + k) * B])
+                self.cursor.zero_()
+                if self._prefetch:
+                    self._gather_current()
+                self._run_k(k)
+                done += k
         self._hstep_host += n_steps
+
+    def _run_k(self, k: int) -> None:
+        """k steps on the batches under the cursor"""
+        if self.use_graph:
+            if self._graph is None:
+                self._capture()
+            r = k
+            if len(self._graph) == 1 and self._graph_multi:
+                for size in sorted(self._graph_multi, reverse=True):   # 8, 4, 2: 20 steps are 8 + 8 + 4, three replays
+                    while r >= size:
+                        self._graph_multi[size].replay()
+                        r -= size
+            self._replay(r)
+        else:
+            for _ in range(k):
+                self._step_body()
+
+    _append_blocks = os.environ.get("EMX_APPEND_BLOCKS", "1") != "0"
+    _ring_pos = 0        # batches of the index block consumed (= the device cursor)
+    _ring_filled = 0     # batches of the index block that hold drawn indices
+    _pending = None      # a batch drawn ahead of its use that went back to the stream
 
     def _block_capacity(self) -> int:
         return 1024

@@ -419,8 +419,8 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
  *   split planes (emx_sketchmap_split / emx_next_batch); zpub: B x 2 floats of scratch for the published latent rows; sync: 4
  *   uint32, ZEROED ONCE by the caller (the launch leaves [0] and [1] at zero; [2] != 0 afterwards: a tile workgroup gave up waiting
  *   for the latent -- the results of that launch are invalid).
- * EMX_EUNSUPPORTED outside what the tile role is built for (latent width 2, the (a, b) = (12, 6 | 2, 6) sigmoid family, rows of 32 /
- * 64 / 128 / 256 features, LDS) -- then use emx_mlp_forward_backward + emx_sketchmap_tiles. */
+ * EMX_EUNSUPPORTED outside what the tile role is built for (latent width 2; rows of 32 / 64 / 128 / 256 features -- up to 128 with
+ * sigmoid exponents outside the (a, b) = (12, 6 | 2, 6) family; LDS) -- then use emx_mlp_forward_backward + emx_sketchmap_tiles. */
 int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                                    int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
                                    float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, const float sig[6],

@@ -218,8 +218,9 @@ def test_shuffle_stream_blocks_do_not_copy_the_pass(em):
     assert v.data_ptr() >= base and v.data_ptr() < base + eng._perm.numel() * 8      # a view into the current pass
 
 
-@pytest.mark.parametrize("B,D,steps", [(4096, 128, 40), (1000, 128, 24), (640, 32, 24), (2048, 256, 16), (1024, 64, 16)])
-def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, monkeypatch):
+@pytest.mark.parametrize("B,D,steps,sig", [(4096, 128, 40, None), (1000, 128, 24, None), (640, 32, 24, None), (2048, 256, 16, None), (1024, 64, 16, None),
+                                            (256, 3, 24, (1.5, 3, 6, 1, 2, 6)), (512, 100, 16, (12.0, 10, 5, 1.5, 4, 2))])      # general sigmoid exponents
+def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, monkeypatch):
     """emx_mlp_forward_backward_tiles: the all-pairs tiles as workgroups of the fused dense-layer launch (chain workgroups publish
     the latent rows, tile workgroups wait for them inside the launch) against the separate launches -- the same arithmetic in
     the same order into the same slots, so whole training runs must agree BIT FOR BIT (a stale or torn latent row anywhere in
@@ -233,7 +234,7 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, monkeypat
     monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
     for overlap in (True, False):
         monkeypatch.setattr(SequentialEngine, "_overlap_tiles", overlap)
-        p = em.Parameters(periodicity=INF, batch_size=B, dist_sig_parameters=(math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
+        p = em.Parameters(periodicity=INF, batch_size=B, dist_sig_parameters=sig or (math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
         e = em.EncoderMap(p, data, model=_weights(p, D), read_only=True)
         e._engine.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
         loss = e._engine.losses()
@@ -244,3 +245,40 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, monkeypat
     np.testing.assert_array_equal(out[0][2], out[1][2])
     assert (out[0][3] == 0).all()            # the launch left its counters at zero, nobody gave up waiting
     assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
+
+
+def test_short_calls_equal_one_long_call(em):
+    """run_steps appends the batches of its own shuffle stream behind the cursor, one batch ahead (no cursor reset, no head gather
+    per call): any split of a run into calls -- single steps included, across the restart of the index block after ~1000 steps,
+    with a caller's index block in between (the batch drawn ahead goes back to the stream) -- trains on the same batches in the
+    same order as one call, bit for bit, and as the host statement of the stream (layout.BatchIndexStream) says."""
+    from encodermap_amd.layout import BatchIndexStream
+
+    rng = np.random.default_rng(12)
+    data = rng.uniform(-math.pi, math.pi, (700, 6)).astype(np.float32)
+    kw = dict(batch_size=64, seed=5)
+
+    def engine(n):
+        p = em.Parameters(n_steps=n, **kw)
+        return em.EncoderMap(p, data, model=_weights(p, 12), read_only=True)._engine
+
+    # (a) one call of 1130 steps (beyond the 1024 batches of the index block) against portions of 1, 7, 100, ... steps
+    a = engine(1130)
+    a.run_steps(1130)
+    b = engine(1130)
+    for k in (1, 7, 100, 1, 1, 400, 500, 20, 99, 1):
+        b.run_steps(k)
+    np.testing.assert_array_equal(a.losses(), b.losses())
+    np.testing.assert_array_equal(a.w.cpu().numpy(), b.w.cpu().numpy())
+    # (b) own stream, a caller's block, own stream again == the same batches injected throughout
+    twin = BatchIndexStream(700, 64, seed=b._shuffle_seed)
+    own = twin.next_block(10)
+    inj = rng.integers(0, 700, (3, 64))
+    c = engine(13)
+    c.run_steps(5)
+    c.run_steps(3, torch.from_numpy(inj.reshape(-1)).cuda())
+    c.run_steps(5)
+    d = engine(13)
+    d.run_steps(13, torch.from_numpy(np.concatenate([own[:5], inj, own[5:]]).reshape(-1)).cuda())
+    np.testing.assert_array_equal(c.losses(), d.losses())
+    np.testing.assert_array_equal(c.w.cpu().numpy(), d.w.cpu().numpy())
