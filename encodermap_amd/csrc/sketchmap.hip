@@ -684,7 +684,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
   float* red = cpart + T * LMAX * 2;
 
-  const int L = LT == 2 ? 2 : a.L;   // LT: 2 = exactly two latent columns (compile time); 0 / 8 = up to 4 / 8 columns at run time, zero padded
+  const int L = (LT >= 2 && LT <= 4) ? LT : a.L;   // LT: 2 / 3 / 4 = exactly that many latent columns (compile time); 0 = up to 4 columns at run time, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;     // quadrant of this wave
   const int lr = lane & 31, h = lane >> 5;
@@ -1455,6 +1455,10 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       return emx::check_launch("sk_tile_f16_big_kernel");
     }
     if (a.L == 2 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 4>), dim3(grid), b);
+    else if (a.L == 3 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<3, true, 4>), dim3(grid), b);   // three latent columns at compile time (the run-time
+    else if (a.L == 3 && pl.fast && nch == 8) SK_F16_LAUNCH((sk_tile_f16_kernel<3, true, 8>), dim3(grid), b);   //  width instantiation below needs 102 registers: four tiles per CU)
+    else if (a.L == 4 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<4, true, 4>), dim3(grid), b);
+    else if (a.L == 4 && pl.fast && nch == 8) SK_F16_LAUNCH((sk_tile_f16_kernel<4, true, 8>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 8 && !getenv("EMX_SK_NO_NCH8")) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 8>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 2>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 1) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 1>), dim3(grid), b);

@@ -542,6 +542,7 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     # batches of 8192 rows and more: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); ragged last tiles,
     # an odd number of 64-row blocks, the general sigmoid
     (600, 64, 12, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 19, (5.0, 3, 6, 1, 2, 6), 100, 300),      # latent widths beyond 8
+    (1100, 128, 3, (16.0, 12, 6, 1, 2, 6), 0, 1100), (700, 256, 4, (22.0, 12, 6, 1, 2, 6), 0, 700), (900, 128, 4, (16.0, 12, 6, 1, 2, 6), 0, 900),   # 3 / 4 columns at compile time
     (8192, 32, 2, (8.0, 12, 6, 1, 2, 6), 0, 8192), (8300, 64, 2, (11.0, 12, 6, 1, 2, 6), 0, 8300), (8256, 40, 2, (9.0, 3, 6, 1, 2, 6), 0, 8256)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     """The all-pairs pass with its Gram products on the 16-bit matrix cores (split rows) against the float64 direct
