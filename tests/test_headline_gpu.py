@@ -270,6 +270,12 @@ def test_short_calls_equal_one_long_call(em):
         b.run_steps(k)
     np.testing.assert_array_equal(a.losses(), b.losses())
     np.testing.assert_array_equal(a.w.cpu().numpy(), b.w.cpu().numpy())
+    # (a') the same stream without graphs (eager launches) and in portions
+    p = em.Parameters(n_steps=60, **kw)
+    g = em.EncoderMap(p, data, model=_weights(p, 12), read_only=True, use_graph=False)._engine
+    for k in (3, 1, 40, 16):
+        g.run_steps(k)
+    np.testing.assert_array_equal(a.losses()[:60], g.losses())
     # (b) own stream, a caller's block, own stream again == the same batches injected throughout
     twin = BatchIndexStream(700, 64, seed=b._shuffle_seed)
     own = twin.next_block(10)
