@@ -98,8 +98,8 @@ SIGNATURES = {
     "emx_kabsch_rmsd": (_i, [_p, _p, _i, _i, C.POINTER(_f), _i, _p, _p]),
     "emx_metric_tick": (_i, [_p, _p, _i, _p, _p, _l, _p, _p]),
     "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p]),
-    "emx_mlp_forward_backward_tiles": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, C.POINTER(_f), _p, _sz, _p, _p,
-                                            _p, _p]),
+    "emx_mlp_forward_backward_tiles": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, C.POINTER(_f), _p, _sz, _p,
+                                            _p, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
@@ -529,16 +529,17 @@ def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "Au
 
 
 def mlp_forward_backward_tiles(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow, X, sig, sk_ws, split_ws, zpub, sync,
-                               train: bool = True):
+                               periodicity=float("inf"), data_span=None, train: bool = True):
     """mlp_forward_backward with the all-pairs tiles of the sketch-map cost as extra workgroups of the same launch (emx.h):
-    ``X`` the batch rows [B, D], ``split_ws`` their split planes, ``sk_ws`` the tile workspace (as sketchmap_tiles), ``zpub`` [B, 2]
+    ``X`` the batch rows [B, D], ``split_ws`` their split planes (None for periodic rows), ``sk_ws`` the tile workspace (as sketchmap_tiles), ``zpub`` [B, 2]
     float32 scratch, ``sync`` 4 x int32 zeroed once."""
     ap, ar = plan.aop_args(train)
     sig_arr = (_f * 6)(*[float(v) for v in sig])
     assert sync.dtype == torch.int32 and sync.numel() >= 4 and zpub.dtype == torch.float32
     _check(load().emx_mlp_forward_backward_tiles(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
                                                  int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, _ptr(dbelow),
-                                                 ap, ar, _ptr(X), X.shape[1], X.stride(0), sig_arr, _ptr(sk_ws), sk_ws.numel() * sk_ws.element_size(),
+                                                 ap, ar, _ptr(X), X.shape[1], X.stride(0), float(periodicity), float(data_span or 0.0), sig_arr, _ptr(sk_ws),
+                                                 sk_ws.numel() * sk_ws.element_size(),
                                                  _ptr(split_ws), _ptr(zpub), _ptr(sync), _stream()), "emx_mlp_forward_backward_tiles")
 
 

@@ -856,14 +856,15 @@ __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // The fused launch with the all-pairs tiles aboard (sk_tile.h): workgroups [0, row blocks) are the chain workgroups, the rest run two
 // tiles each.  128 registers per lane: a chain workgroup (two waves per SIMD) and a tile workgroup share a CU.  The role is
 // told from the preloaded scalars alone (the chain workgroups' first loads must not wait for a trip to the arguments).
-template <int NB, bool FASTSIG, int NCH>
+template <int NB, bool FASTSIG, int NCH, int KIND>   // KIND 0: Gram tiles on split rows (NCH chunks); 1 / 2: periodic 32 x 32 VALU tiles, float / phase form
 __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_tiles_kernel(
     const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols, int p_row0, int p_row_end, int p_ldt, int p_cost_n,
     int p_in_Q, int p_with_cost, const ChainArgs a, const emx::sk::TileRole tr) {
   const int n_chain = (p_row_end - p_row0 + R - 1) / R;
   if ((int)blockIdx.x >= n_chain) {
     extern __shared__ __align__(16) char lds[];
-    emx::sk::tile_pair_role<FASTSIG, NCH>(lds, tr, (int)blockIdx.x - n_chain);
+    if constexpr (KIND == 0) emx::sk::tile_pair_role<FASTSIG, NCH>(lds, tr, (int)blockIdx.x - n_chain);
+    else emx::sk::tile32_pair_role<KIND, FASTSIG>(lds, tr, (int)blockIdx.x - n_chain);
     return;
   }
   static_assert(offsetof(emx::sk::TileRole, sync) == offsetof(emx::sk::TileRole, zpub) + 8 && sizeof(ChainArgs) % 8 == 0, "PubArgs inside TileRole");
@@ -1499,6 +1500,7 @@ namespace {
 struct TilesHost {
   const float* X;
   int B, D, ldx;
+  float periodicity, data_span;
   const float* sig;
   void* sk_ws;
   size_t sk_ws_bytes;
@@ -1507,11 +1509,11 @@ struct TilesHost {
   unsigned* sync;
 };
 
-template <bool FAST, int NCH>
+template <bool FAST, int NCH, int KIND = 0>
 int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
-  int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH>), lds, b.who);
+  int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND>), lds, b.who);
   if (rc) return rc;
-  hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
+  hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH, KIND>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
                      b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a, tr);
   return emx::check_launch("mlp chain kernel (forward + cost + backward, all-pairs tiles aboard)");
 }
@@ -1610,10 +1612,10 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   EMX_REQUIRE(row_begin == 0 && row_end == tiles->B, "%s: the tiles run over the whole batch (rows [0, %d))", who, tiles->B);
   EMX_REQUIRE(tiles->zpub && tiles->sync, "%s: null pointer argument (tile role)", who);
   emx::sk::TileRole tr{};
-  int vblocks = 0, nch = 0;
+  int vblocks = 0, nch = 0, kind = 0;
   bool fast = false;
-  rc = emx::sk::make_tile_role(tiles->X, tiles->B, tiles->D, tiles->ldx, h[bwd_begin - 1], desc->width[bwd_begin], tiles->sig, tiles->sk_ws, tiles->sk_ws_bytes,
-                               tiles->split_ws, &tr, &vblocks, &nch, &fast, who);
+  rc = emx::sk::make_tile_role(tiles->X, tiles->B, tiles->D, tiles->ldx, h[bwd_begin - 1], desc->width[bwd_begin], tiles->periodicity, tiles->data_span,
+                               tiles->sig, tiles->sk_ws, tiles->sk_ws_bytes, tiles->split_ws, &tr, &vblocks, &nch, &fast, &kind, who);
   if (rc) return rc;
   const int n_chain = (row_end - row_begin + R - 1) / R;
   tr.zpub = tiles->zpub;
@@ -1638,6 +1640,10 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   if (dbg == 4) tr.n_tile_wgs = std::min(tr.n_tile_wgs, 8);   // eight tile workgroups beside the chain workgroups: what do they cost the chain?
   hipStream_t st = (hipStream_t)stream;
   static_assert(sizeof(ChainArgs) + sizeof(emx::sk::TileRole) + 56 <= 4096, "kernel arguments of chain_tiles_kernel");
+  if (kind != 0) {   // periodic rows: 32 x 32 VALU tiles (float form / 32-bit phases), any row length
+    if (kind == 2) return fast ? launch_chain_tiles<true, 0, 2>(b, tr, grid, lds, st) : launch_chain_tiles<false, 0, 2>(b, tr, grid, lds, st);
+    return fast ? launch_chain_tiles<true, 0, 1>(b, tr, grid, lds, st) : launch_chain_tiles<false, 0, 1>(b, tr, grid, lds, st);
+  }
   if (!fast) {   // general sigmoid exponents (e.g. the cube example's (0.2, 3, 6 | 1, 2, 6)): rows of up to 128 features
     switch (nch) {
       case 1: return launch_chain_tiles<false, 1>(b, tr, grid, lds, st);
@@ -1667,9 +1673,10 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
 
 int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                                    int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
-                                   float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, const float sig[6],
-                                   void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub, uint32_t* sync, emx_stream_t stream) {
-  TilesHost t{X, row_end - row_begin, D, ldx, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync};
+                                   float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, float periodicity,
+                                   float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub, uint32_t* sync,
+                                   emx_stream_t stream) {
+  TilesHost t{X, row_end - row_begin, D, ldx, periodicity, data_span, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync};
   return forward_backward_impl(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop,
                                aop_rows, &t, "emx_mlp_forward_backward_tiles", stream);
 }

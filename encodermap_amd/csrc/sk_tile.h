@@ -141,6 +141,93 @@ __device__ __forceinline__ bool xcd_tile(int bid, int nbg, int nbc, int& ti, int
 }
 
 
+// ---- the VALU tiles' staging and pair-element arithmetic (sk_tile_kernel in sketchmap.hip, tile32_pair_role below)
+constexpr int KC = 32;       // feature chunk staged per iteration
+constexpr int LS = KC + 4;   // padded LDS row stride (floats)
+
+__device__ __forceinline__ float abs_minus(float x, float h) {   // |x| - h
+  float r;
+  asm("v_sub_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(h));
+  return r;
+}
+__device__ __forceinline__ float minus_abs(float h, float x) {   // h - |x|
+  float r;
+  asm("v_sub_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(h), "v"(x));
+  return r;
+}
+
+// PMODE of the VALU tiles: 0 Euclidean, 1 periodic (float form, any data), 2 periodic on fixed-point phases (data that span
+// less than 1.5 periods, phase_u32 below)
+template <int PMODE>
+__device__ __forceinline__ float acc4(const float4& a, const float4& b, float acc, float period) {
+  if constexpr (PMODE == 2) {
+    // the staged values are phases: x / period as a 32-bit fraction of a turn.  The 32-bit difference wraps by itself and,
+    // read as a signed integer, IS the wrapped difference in [-1/2, 1/2) turns: sub, convert, fma -- three instructions
+    // per pair-element instead of four (the sum is scaled by (period / 2^32)^2 once per pair, in front of the epilogue)
+    const uint4 ua = *reinterpret_cast<const uint4*>(&a), ub = *reinterpret_cast<const uint4*>(&b);
+    const float d0 = (float)(int)(ua.x - ub.x), d1 = (float)(int)(ua.y - ub.y), d2 = (float)(int)(ua.z - ub.z),
+                d3 = (float)(int)(ua.w - ub.w);
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  } else if constexpr (PMODE == 1) {
+    // min(|d|, p - |d|) = p/2 - | |d| - p/2 |: three subtractions, two of them with a |.| source modifier, instead of two
+    // and a v_min_f32, which issues at half the rate of v_sub_f32 on gfx950 (profiles/r01_valu_issue_rates.txt).  Written
+    // as instructions: left to itself the compiler pairs the subtractions into v_pk_add_f32, which has no source
+    // modifiers, and spends a v_and_b32 per |.|.
+    const float h = 0.5f * period;
+    float d0 = abs_minus(a.x - b.x, h), d1 = abs_minus(a.y - b.y, h), d2 = abs_minus(a.z - b.z, h), d3 = abs_minus(a.w - b.w, h);
+    d0 = minus_abs(h, d0);
+    d1 = minus_abs(h, d1);
+    d2 = minus_abs(h, d2);
+    d3 = minus_abs(h, d3);
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  } else {
+    float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
+    acc = fmaf(d0, d0, acc);
+    acc = fmaf(d1, d1, acc);
+    acc = fmaf(d2, d2, acc);
+    acc = fmaf(d3, d3, acc);
+  }
+  return acc;
+}
+
+// x / period as a 32-bit fraction of a turn (wrapping), to 2^-32 of a period: t = x * (1 / period) in two floats, its distance
+// from the nearest integer is exact in float32, the rounding error of the product and the low part of 1 / period are added
+// as a second integer.  (Exactly half a turn saturates to 2^31 - 1: one unit.)
+__device__ __forceinline__ unsigned phase_u32(float x, float rp_hi, float rp_lo) {
+  const float t = x * rp_hi;
+  const float fh = t - rintf(t);
+  const float fl = fmaf(x, rp_lo, fmaf(x, rp_hi, -t));
+  return (unsigned)((int)(fh * 4294967296.f) + (int)rintf(fl * 4294967296.f));
+}
+__device__ __forceinline__ float4 phase4(const float4& v, float rp_hi, float rp_lo) {
+  uint4 u = make_uint4(phase_u32(v.x, rp_hi, rp_lo), phase_u32(v.y, rp_hi, rp_lo), phase_u32(v.z, rp_hi, rp_lo), phase_u32(v.w, rp_hi, rp_lo));
+  return *reinterpret_cast<float4*>(&u);
+}
+
+__device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long row, int ldx, int k, int D, bool rowvalid,
+                                            bool vec4) {
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rowvalid && k < D) {
+    const float* p = X + row * (long)ldx + k;
+    if (vec4) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      v.x = p[0];
+      if (k + 1 < D) v.y = p[1];
+      if (k + 2 < D) v.z = p[2];
+      if (k + 3 < D) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+
 // ---------------------------------------------------------------------------------------------------------------------
 // The all-pairs tiles as a ROLE inside the fused dense-layer launch (mlp.hip: chain_tiles_kernel).
 //
@@ -485,9 +572,193 @@ report:
   }
 }
 
+// The same role for PERIODIC batches of up to 512 rows (the default EncoderMap configuration: B = 256, periodic): the 32 x 32 VALU
+// tiles of sk_tile_kernel<32, 32, 2, PMODE, FASTSIG> -- direct (wrapped) differences staged from the batch rows themselves, PMODE
+// 1 the float form, 2 the 32-bit phases -- two tiles per 512-thread workgroup in lockstep, the pair loop (which needs no latent)
+// at once, the epilogue behind the published latent rows.  Same arithmetic, order and slots as the stand-alone kernel.
+constexpr int TILE32_SMEM_FLOATS = (32 + 32) * LS + 8;   // one tile: staging (2304 floats) >= its partial sums (2048)
+
+template <int PMODE, bool FASTSIG>
+__device__ __forceinline__ void tile32_pair_role(char* lds, const TileRole& tr, const int w) {
+  constexpr int T = 32, RM = 2, RN = 2, LMAX = 2, L = 2, HNT = 256;
+  const SkArgs& a = tr.a;
+  const int half = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+  const int tid = threadIdx.x & 255, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane((int)(tid >> 6));
+  float* smem = reinterpret_cast<float*>(lds) + half * TILE32_SMEM_FLOATS;
+  float* Xi_s = smem;
+  float* Xj_s = smem + T * LS;
+  float* red = smem + TILE32_SMEM_FLOATS - 8;
+  const int tx = tid & 15, ty = tid >> 4;
+  const int kq = tid & 7, rb = tid >> 3;
+  const bool vec4 = a.vec4 != 0;
+  const int n_tiles = a.nbc * (a.nbc + 1) / 2, n_pairs = (n_tiles + 1) / 2;
+  bool latent_ready = false;
+  for (int k = w; k < n_pairs; k += tr.n_tile_wgs) {
+    int ti = 0, tj = 0;
+    const int tslot = 2 * k + half;
+    const bool valid = tslot < n_tiles;
+    if (valid) tri_decode(tslot, a.nbc, ti, tj);   // (an odd tile count: the last pair's second half idles in step, nothing of it is stored)
+    ti = __builtin_amdgcn_readfirstlane(ti);
+    tj = __builtin_amdgcn_readfirstlane(tj);
+    const int i0 = ti * T, j0 = tj * T;
+    const bool offdiag = ti != tj;
+    float acc[RM][RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RN; ++c) acc[r][c] = 0.f;
+    // ---- K loop (as sk_tile_kernel)
+    float4 pi, pj;
+    auto gload = [&](int k0) __attribute__((always_inline)) {
+      pi = load_row4(a.X, i0 + rb, a.ldx, k0 + 4 * kq, a.D, i0 + rb < a.row_end, vec4);
+      pj = load_row4(a.X, j0 + rb, a.ldx, k0 + 4 * kq, a.D, j0 + rb < a.B, vec4);
+    };
+    gload(0);
+    for (int k0 = 0; k0 < a.D; k0 += KC) {
+      __syncthreads();   // (first chunk: the pair in front has folded its partial sums out of the area)
+      *reinterpret_cast<float4*>(&Xi_s[rb * LS + 4 * kq]) = PMODE == 2 ? phase4(pi, a.rp_hi, a.rp_lo) : pi;
+      *reinterpret_cast<float4*>(&Xj_s[rb * LS + 4 * kq]) = PMODE == 2 ? phase4(pj, a.rp_hi, a.rp_lo) : pj;
+      __syncthreads();
+      if (k0 + KC < a.D) gload(k0 + KC);
+#pragma unroll 2
+      for (int kk = 0; kk < KC; kk += 4) {
+        float4 av[RM];
+#pragma unroll
+        for (int r = 0; r < RM; ++r) av[r] = *reinterpret_cast<const float4*>(&Xi_s[(ty + 16 * r) * LS + kk]);
+#pragma unroll
+        for (int c = 0; c < RN; ++c) {
+          const float4 bv = *reinterpret_cast<const float4*>(&Xj_s[(tx + 16 * c) * LS + kk]);
+#pragma unroll
+          for (int r = 0; r < RM; ++r) acc[r][c] = acc4<PMODE>(av[r], bv, acc[r][c], a.period);
+        }
+      }
+    }
+    if constexpr (PMODE == 2) {
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RN; ++c) acc[r][c] *= a.phase_unit2;
+    }
+    // ---- the latent rows: published by the chain workgroups of this launch (first pair only)
+    if (!latent_ready) {
+      if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&tr.sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)tr.n_chain) {
+          __builtin_amdgcn_s_sleep(20);
+          if (++spins > TILE_ROLE_SPIN_LIMIT) {
+            __hip_atomic_store(&tr.sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+        }
+      }
+      latent_ready = true;
+    }
+    __syncthreads();  // the counter has been seen; staging LDS is reused for the partial sums below
+    // ---- epilogue (as sk_tile_kernel, LT = 2)
+    float zi[RM][LMAX], zj[RN][LMAX], wr[RM], wc[RN];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      const int row = i0 + ty + 16 * r;
+      const bool ok = row < a.row_end;
+      wr[r] = ok ? 1.f : 0.f;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) zi[r][l] = ok ? load_sc1(tr.zpub + (long)row * L + l) : 0.f;
+    }
+#pragma unroll
+    for (int c = 0; c < RN; ++c) {
+      const int row = j0 + tx + 16 * c;
+      const bool ok = row < a.B;
+      wc[c] = ok ? 1.f : 0.f;
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) zj[c][l] = ok ? load_sc1(tr.zpub + (long)row * L + l) : 0.f;
+    }
+    float* rpart = smem;                       // [T][LMAX][16]
+    float* cpart = smem + 16 * T * LMAX;       // [T][LMAX][16]
+    float gi[RM][LMAX];
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) gi[r][l] = 0.f;
+    float lsum = 0.f;
+#pragma unroll
+    for (int c = 0; c < RN; ++c) {
+      float gj[LMAX];
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) gj[l] = 0.f;
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        float dz[LMAX];
+        float dl2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          dz[l] = zi[r][l] - zj[c][l];
+          dl2 = fmaf(dz[l], dz[l], dl2);
+        }
+        const float Eh = sig_E_high<FASTSIG>(acc[r][c], a.sh);
+        float El, G;
+        sig_E_low<FASTSIG>(dl2, a.sl, El, G);
+        const float f = (El - Eh) * (wr[r] * wc[c]);
+        lsum = fmaf(f, f, lsum);
+        const float g = f * G;
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) {
+          gi[r][l] = fmaf(g, dz[l], gi[r][l]);
+          gj[l] = fmaf(-g, dz[l], gj[l]);
+        }
+      }
+      if (offdiag) {
+#pragma unroll
+        for (int l = 0; l < LMAX; ++l) cpart[((tx + 16 * c) * LMAX + l) * 16 + ty] = gj[l];
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int l = 0; l < LMAX; ++l) rpart[((ty + 16 * r) * LMAX + l) * 16 + tx] = gi[r][l];
+    // tile cost: block_sum<256>'s order on this half's four waves
+    {
+      const float v = wave_sum(lsum);
+      if (lane == 0) red[wave] = v;
+    }
+    __syncthreads();   // partials and wave sums visible
+    if (tid == 0 && valid) {
+      float tl = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) tl += red[i];
+      a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
+    }
+    if (valid) {
+      if (tid < T * LMAX) {
+        const int rl = tid / LMAX, l = tid - rl * LMAX;
+        const float4* p = reinterpret_cast<const float4*>(&rpart[tid * 16]);
+        const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+        const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                        (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+        a.P[((long)tj * a.nrows_pad + i0 + rl) * L + l] = s;
+      }
+      if (offdiag && tid < T * LMAX) {
+        const int rl = tid / LMAX, l = tid - rl * LMAX;
+        const float4* p = reinterpret_cast<const float4*>(&cpart[tid * 16]);
+        const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+        const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
+                        (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+        a.P[((long)ti * a.nrows_pad + j0 + rl) * L + l] = s;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)tr.n_tile_wgs - 1) {
+      __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
 // host side (sketchmap.hip): the tile plan of emx_sketchmap_tiles for the full batch on split rows, as a role description
-int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, const float sig[6], void* ws, size_t ws_bytes, void* split_ws,
-                   TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, const char* who);
+// kind: 0 = Gram tiles on split rows (Euclidean), 1 / 2 = 32 x 32 VALU tiles of periodic rows, float form / 32-bit phases
+int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span, const float sig[6], void* ws,
+                   size_t ws_bytes, void* split_ws, TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, int* kind, const char* who);
 
 }  // namespace sk
 }  // namespace emx

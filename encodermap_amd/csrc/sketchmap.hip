@@ -45,92 +45,7 @@ using namespace emx::sk;
 constexpr int NT = 256;
 constexpr int KSPLIT_MAX_NB = 10;      // batches of up to 640 rows may split the reduction of a tile over several workgroups
 constexpr int KSPLIT_BLOCKS = 512;     // ... over at most this many in total
-constexpr int KC = 32;       // feature chunk staged per iteration
-constexpr int LS = KC + 4;   // padded LDS row stride (floats)
 
-
-
-__device__ __forceinline__ float abs_minus(float x, float h) {   // |x| - h
-  float r;
-  asm("v_sub_f32_e64 %0, |%1|, %2" : "=v"(r) : "v"(x), "v"(h));
-  return r;
-}
-__device__ __forceinline__ float minus_abs(float h, float x) {   // h - |x|
-  float r;
-  asm("v_sub_f32_e64 %0, %1, |%2|" : "=v"(r) : "v"(h), "v"(x));
-  return r;
-}
-
-// PMODE of the VALU tiles: 0 Euclidean, 1 periodic (float form, any data), 2 periodic on fixed-point phases (data that span
-// less than 1.5 periods, phase_u32 below)
-template <int PMODE>
-__device__ __forceinline__ float acc4(const float4& a, const float4& b, float acc, float period) {
-  if constexpr (PMODE == 2) {
-    // the staged values are phases: x / period as a 32-bit fraction of a turn.  The 32-bit difference wraps by itself and,
-    // read as a signed integer, IS the wrapped difference in [-1/2, 1/2) turns: sub, convert, fma -- three instructions
-    // per pair-element instead of four (the sum is scaled by (period / 2^32)^2 once per pair, in front of the epilogue)
-    const uint4 ua = *reinterpret_cast<const uint4*>(&a), ub = *reinterpret_cast<const uint4*>(&b);
-    const float d0 = (float)(int)(ua.x - ub.x), d1 = (float)(int)(ua.y - ub.y), d2 = (float)(int)(ua.z - ub.z),
-                d3 = (float)(int)(ua.w - ub.w);
-    acc = fmaf(d0, d0, acc);
-    acc = fmaf(d1, d1, acc);
-    acc = fmaf(d2, d2, acc);
-    acc = fmaf(d3, d3, acc);
-  } else if constexpr (PMODE == 1) {
-    // min(|d|, p - |d|) = p/2 - | |d| - p/2 |: three subtractions, two of them with a |.| source modifier, instead of two
-    // and a v_min_f32, which issues at half the rate of v_sub_f32 on gfx950 (profiles/r01_valu_issue_rates.txt).  Written
-    // as instructions: left to itself the compiler pairs the subtractions into v_pk_add_f32, which has no source
-    // modifiers, and spends a v_and_b32 per |.|.
-    const float h = 0.5f * period;
-    float d0 = abs_minus(a.x - b.x, h), d1 = abs_minus(a.y - b.y, h), d2 = abs_minus(a.z - b.z, h), d3 = abs_minus(a.w - b.w, h);
-    d0 = minus_abs(h, d0);
-    d1 = minus_abs(h, d1);
-    d2 = minus_abs(h, d2);
-    d3 = minus_abs(h, d3);
-    acc = fmaf(d0, d0, acc);
-    acc = fmaf(d1, d1, acc);
-    acc = fmaf(d2, d2, acc);
-    acc = fmaf(d3, d3, acc);
-  } else {
-    float d0 = a.x - b.x, d1 = a.y - b.y, d2 = a.z - b.z, d3 = a.w - b.w;
-    acc = fmaf(d0, d0, acc);
-    acc = fmaf(d1, d1, acc);
-    acc = fmaf(d2, d2, acc);
-    acc = fmaf(d3, d3, acc);
-  }
-  return acc;
-}
-
-// x / period as a 32-bit fraction of a turn (wrapping), to 2^-32 of a period: t = x * (1 / period) in two floats, its distance
-// from the nearest integer is exact in float32, the rounding error of the product and the low part of 1 / period are added
-// as a second integer.  (Exactly half a turn saturates to 2^31 - 1: one unit.)
-__device__ __forceinline__ unsigned phase_u32(float x, float rp_hi, float rp_lo) {
-  const float t = x * rp_hi;
-  const float fh = t - rintf(t);
-  const float fl = fmaf(x, rp_lo, fmaf(x, rp_hi, -t));
-  return (unsigned)((int)(fh * 4294967296.f) + (int)rintf(fl * 4294967296.f));
-}
-__device__ __forceinline__ float4 phase4(const float4& v, float rp_hi, float rp_lo) {
-  uint4 u = make_uint4(phase_u32(v.x, rp_hi, rp_lo), phase_u32(v.y, rp_hi, rp_lo), phase_u32(v.z, rp_hi, rp_lo), phase_u32(v.w, rp_hi, rp_lo));
-  return *reinterpret_cast<float4*>(&u);
-}
-
-__device__ __forceinline__ float4 load_row4(const float* __restrict__ X, long row, int ldx, int k, int D, bool rowvalid,
-                                            bool vec4) {
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (rowvalid && k < D) {
-    const float* p = X + row * (long)ldx + k;
-    if (vec4) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      v.x = p[0];
-      if (k + 1 < D) v.y = p[1];
-      if (k + 2 < D) v.z = p[2];
-      if (k + 3 < D) v.w = p[3];
-    }
-  }
-  return v;
-}
 
 
 // (leading scalars: tile decode and the first row loads, preloaded into scalar registers at wave launch; 56 bytes, the struct follows)
@@ -1511,23 +1426,31 @@ int launch_finish_plan(const SkPlan& pl, hipStream_t st) {
 // built for: the caller keeps the separate launches.
 namespace emx {
 namespace sk {
-int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, const float sig[6], void* ws, size_t ws_bytes, void* split_ws,
-                   TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, const char* who) {
-  EMX_REQUIRE(out && virtual_blocks && n_chunks && fast && split_ws, "%s: null pointer argument (tile role)", who);
+int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L, float periodicity, float data_span, const float sig[6], void* ws,
+                   size_t ws_bytes, void* split_ws, TileRole* out, int* virtual_blocks, int* n_chunks, bool* fast, int* kind, const char* who) {
+  EMX_REQUIRE(out && virtual_blocks && n_chunks && fast && kind, "%s: null pointer argument (tile role)", who);
   SkPlan pl;
-  int rc = make_plan(X, B, D, ldx, Z, L, INFINITY, sig, 1.f, 0.f, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl, who, split_ws, 0.f);
+  int rc = make_plan(X, B, D, ldx, Z, L, periodicity, sig, 1.f, 0.f, 0, B, nullptr, nullptr, nullptr, ws, ws_bytes, pl, who, split_ws, data_span);
   if (rc) return rc;
-  if (L != 2 || pl.T != 64 || pl.a.split.planes == nullptr) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role runs two-column latents on split rows", who);
   out->a = pl.a;
   out->a.xcd_nbg = 0;
   *virtual_blocks = pl.ntiles;
+  *fast = pl.fast;
+  if (pl.periodic) {
+    // periodic rows: the 32 x 32 VALU tiles (batches of up to 512 rows, pick_tile)
+    if (L != 2 || pl.T != 32) return emx::fail(EMX_EUNSUPPORTED, "%s: the periodic tile role runs two-column latents on 32 x 32 tiles (batches of up to 512 rows)", who);
+    *kind = pl.a.phase_ok ? 2 : 1;
+    *n_chunks = 0;
+    return EMX_OK;
+  }
+  if (L != 2 || pl.T != 64 || pl.a.split.planes == nullptr) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role runs two-column latents on split rows", who);
+  *kind = 0;
   static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
   if (pl.a.nbc >= 16 && xcd_order) {   // (as launch_tiles_plan)
     out->a.xcd_nbg = (pl.a.nbc + 3) / 4;
     *virtual_blocks = 8 * out->a.xcd_nbg * (out->a.xcd_nbg + 1);
   }
   *n_chunks = pl.a.split.ld / SPLIT_KC;
-  *fast = pl.fast;
   return EMX_OK;
 }
 }  // namespace sk

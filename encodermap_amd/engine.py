@@ -320,7 +320,8 @@ class SequentialEngine:
             if full and self._overlap_tiles and self._tiles_fit():
                 try:
                     _lib.mlp_forward_backward_tiles(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
-                                                    self.sk_ws, self.split_ws, self.zpub, self.sk_sync)
+                                                    self.sk_ws, self.split_ws, self.zpub, self.sk_sync,
+                                                    periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
                     self._tiles_ran = True
                     return True
                 except _lib.EmxError as exc:
@@ -373,8 +374,11 @@ class SequentialEngine:
         # workgroup (two tiles in flight) beside it where the separate launch keeps eight tiles resident per CU; two tile waves
         # per SIMD run a tile pair in ~7 us (Gram phase 2.4, sigmoid epilogue 2.2, barriers / reductions / stores 2.4), and at
         # 4.25 pairs per CU that is longer than the decoder half of the chain workgroups it was meant to hide behind.
-        return (self._use_sketchmap() and not self.dp.active and not self.periodic and self.split_ws is not None and self.L == 2
-                and self.layout.n_enc >= 1 and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1024")))
+        if not (self._use_sketchmap() and not self.dp.active and self.L == 2 and self.layout.n_enc >= 1):
+            return False
+        if self.periodic:      # the 32 x 32 VALU tiles of periodic batches (up to 512 rows: the default configuration's 256)
+            return self.B <= min(512, int(os.environ.get("EMX_OVERLAP_MAX_B", "1024")))
+        return self.split_ws is not None and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1024"))
 
     def check_sync(self) -> None:
         """raises if a tile workgroup of a fused launch ever gave up waiting for the latent rows (emx.h: sync[2])"""

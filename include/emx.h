@@ -415,16 +415,18 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
  * rows of layer bwd_begin - 1 (the encoder's last), i.e. beside the decoder's forward pass, the auto cost and the decoder's backward
  * pass.  Outputs: everything emx_mlp_forward_backward leaves, plus the per-tile partial sums and tile costs in sk_ws exactly as
  * emx_sketchmap_tiles(X, B, D, ldx, h[bwd_begin - 1], 2, INFINITY, ., sig, 0, B, sk_ws, ., split_ws) leaves them (bit for bit).
- *   rows [row_begin, row_end) must be the whole batch [0, B); X / D / ldx describe the batch rows (validation only), split_ws their
- *   split planes (emx_sketchmap_split / emx_next_batch); zpub: B x 2 floats of scratch for the published latent rows; sync: 4
+ *   rows [row_begin, row_end) must be the whole batch [0, B); X / D / ldx describe the batch rows, periodicity / data_span as for
+ *   emx_sketchmap_tiles.  Euclidean X (periodicity INFINITY): split_ws = their split planes (emx_sketchmap_split / emx_next_batch),
+ *   the Gram tiles of the f16 matrix cores.  Periodic X: the 32 x 32 VALU tiles on the rows themselves (batches of up to 512 rows); zpub: B x 2 floats of scratch for the published latent rows; sync: 4
  *   uint32, ZEROED ONCE by the caller (the launch leaves [0] and [1] at zero; [2] != 0 afterwards: a tile workgroup gave up waiting
  *   for the latent -- the results of that launch are invalid).
- * EMX_EUNSUPPORTED outside what the tile role is built for (latent width 2; rows of 32 / 64 / 128 / 256 features -- up to 128 with
- * sigmoid exponents outside the (a, b) = (12, 6 | 2, 6) family; LDS) -- then use emx_mlp_forward_backward + emx_sketchmap_tiles. */
+ * EMX_EUNSUPPORTED outside what the tile role is built for (latent width 2; Euclidean rows of 32 / 64 / 128 / 256 features -- up to 128
+ * with sigmoid exponents outside the (a, b) = (12, 6 | 2, 6) family; periodic batches of up to 512 rows; LDS) -- then use emx_mlp_forward_backward + emx_sketchmap_tiles. */
 int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                                    int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
-                                   float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, const float sig[6],
-                                   void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub, uint32_t* sync, emx_stream_t stream);
+                                   float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, float periodicity,
+                                   float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes, void* split_ws /* NULL for periodic X */,
+                                   float* zpub, uint32_t* sync, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and

@@ -218,9 +218,19 @@ def test_shuffle_stream_blocks_do_not_copy_the_pass(em):
     assert v.data_ptr() >= base and v.data_ptr() < base + eng._perm.numel() * 8      # a view into the current pass
 
 
-@pytest.mark.parametrize("B,D,steps,sig", [(4096, 128, 40, None), (1000, 128, 24, None), (640, 32, 24, None), (2048, 256, 16, None), (1024, 64, 16, None),
-                                            (256, 3, 24, (1.5, 3, 6, 1, 2, 6)), (512, 100, 16, (12.0, 10, 5, 1.5, 4, 2))])      # general sigmoid exponents
-def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, monkeypatch):
+OVERLAP_CASES = [
+    # B, D, steps, sig, periodicity, data span in periods (periodic data only)
+    (4096, 128, 40, None, INF, 0), (1000, 128, 24, None, INF, 0), (640, 32, 24, None, INF, 0), (2048, 256, 16, None, INF, 0), (1024, 64, 16, None, INF, 0),
+    (256, 3, 24, (1.5, 3, 6, 1, 2, 6), INF, 0), (512, 100, 16, (12.0, 10, 5, 1.5, 4, 2), INF, 0),      # general sigmoid exponents
+    # periodic batches (the default configuration: B = 256, period 2 pi): 32 x 32 VALU tiles, phase form and -- data over more than
+    # 1.5 periods -- float form; an odd number of tiles, a ragged last tile, the general sigmoid
+    (256, 10, 24, (4.5, 12, 6, 1, 2, 6), 2 * math.pi, 1.0), (512, 6, 16, (90.0, 10, 5, 1.5, 4, 2), 360.0, 1.0), (100, 33, 16, (6.0, 12, 6, 1, 2, 6), 2 * math.pi, 1.0),
+    (200, 12, 16, (4.5, 12, 6, 1, 2, 6), 2 * math.pi, 2.0),
+]
+
+
+@pytest.mark.parametrize("B,D,steps,sig,periodicity,span", OVERLAP_CASES)
+def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, periodicity, span, monkeypatch):
     """emx_mlp_forward_backward_tiles: the all-pairs tiles as workgroups of the fused dense-layer launch (chain workgroups publish
     the latent rows, tile workgroups wait for them inside the launch) against the separate launches -- the same arithmetic in
     the same order into the same slots, so whole training runs must agree BIT FOR BIT (a stale or torn latent row anywhere in
@@ -228,14 +238,17 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, monk
     from encodermap_amd.engine import SequentialEngine
 
     rng = np.random.default_rng(B + D)
-    data = blobs(rng, 6000, D)
+    if periodicity < INF:
+        data = rng.uniform(-0.5 * span * periodicity, 0.5 * span * periodicity, (6000, D)).astype(np.float32)
+    else:
+        data = blobs(rng, 6000, D)
     idx = rng.integers(0, 6000, (steps, B))
     out = []
     monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
     for overlap in (True, False):
         monkeypatch.setattr(SequentialEngine, "_overlap_tiles", overlap)
-        p = em.Parameters(periodicity=INF, batch_size=B, dist_sig_parameters=sig or (math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
-        e = em.EncoderMap(p, data, model=_weights(p, D), read_only=True)
+        p = em.Parameters(periodicity=periodicity, batch_size=B, dist_sig_parameters=sig or (math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
+        e = em.EncoderMap(p, data, model=_weights(p, 2 * D if periodicity < INF else D), read_only=True)
         e._engine.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
         loss = e._engine.losses()
         assert e._engine._tiles_ran == overlap
