@@ -37,6 +37,7 @@
 #include "cost.h"
 #include "emx_common.h"
 #include "finish.h"
+#include "optimizer.h"
 #include "sk_tile.h"
 #include "wop.h"
 
@@ -952,45 +953,30 @@ typedef unsigned u32x16 __attribute__((ext_vector_type(16)));
 #define WSTAMP(k)
 #endif
 
-// The first 16 dwords of the arguments are explicit scalars: with -mllvm -amdgpu-kernarg-preload-count=16 the command processor
-// hands them over in scalar registers at wave launch (gfx940+), so the layer's record -- and behind it the fragments -- can be
-// requested with the first instructions instead of after a trip for the head (tile table packed as 13 x 16 bits).
-__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
-                                                       unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int has_fin, int grid_x, float* partial,
-                                                       long n_params, const WgradDev a) {   // (14 dwords are preloaded: up to `partial`)
-  WSTAMP(0);
-  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
-  __shared__ float fin_tl[64];
-  typedef const u32x16 __attribute__((address_space(4))) * KVec;
-  typedef const char __attribute__((address_space(4))) * KBytes;
-  const KVec kv = (KVec)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64 + offsetof(WgradDev, lay));   // (64: the explicit scalars)
-  struct {
-    int rb0, rb_end, rbs_per_slice, has_fin;
-    float* partial;
-    long n_params;
-  } hd{rb0, rb_end, rbs_per_slice, has_fin, partial, n_params};
-  // (the explicit scalars are 64 bytes: 7 + 4 + 1 dwords, a pointer, a long -- the record array's offset above; grid_x = gridDim.x,
-  //  which as a hidden argument would be a trip of its own)
-  if (hd.has_fin && (int)blockIdx.x == grid_x - 1) {
-    // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs are complete
-    // before this launch starts, and a launch of its own costs ~6.5 us of the step.
-    if (blockIdx.y == 0) finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);
-    WSTAMP(5);
-    return;
-  }
+struct WgHd {
+  int rb0, rb_end, rbs_per_slice, has_fin;
+  float* partial;
+  long n_params;
+};
+typedef const u32x16 __attribute__((address_space(4))) * WgKVec;
+
+// One weight-gradient workgroup: output block bx (over all layers) of row slice by.  SC1: the partials are stored with sc1 (write
+// through: workgroups of the SAME launch read them, mlp_wgrad_adam_kernel).
+template <bool SC1>
+__device__ __forceinline__ void wgrad_block(const unsigned (&tbw)[7], const int bx, const int by, const WgHd& hd, const WgKVec kv) {
+  constexpr int ST_AUX = SC1 ? 16 : 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
   int li = 0, tbase = 0;
 #pragma unroll
   for (int i = 1; i < MAXL; ++i) {
     const int t = (int)((tbw[i >> 1] >> (16 * (i & 1))) & 0xffffu);   // (unused entries: 0xffff)
-    if ((int)blockIdx.x >= t) {
+    if (bx >= t) {
       li = i;
       tbase = t;
     }
   }
-  const int tb = blockIdx.x - tbase;
+  const int tb = bx - tbase;
   const u32x16 lrec = kv[li];
   WgLayer L;
   __builtin_memcpy(&L, &lrec, 64);
@@ -1000,9 +986,9 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
   const int bi = tb / nbn, bj = tb - bi * nbn;
   const int ig0 = 4 * bi + 2 * (wave >> 1), jg0 = 4 * bj + 2 * (wave & 1);   // first column groups of the wave's quadrant
   const int CGx = L.CGx, CGd = L.CGd;
-  const int rbs = hd.rb0 + blockIdx.y * hd.rbs_per_slice;
+  const int rbs = hd.rb0 + by * hd.rbs_per_slice;
   const int rbe = min(rbs + hd.rbs_per_slice, hd.rb_end);
-  float* __restrict__ out = hd.partial + (long)blockIdx.y * hd.n_params;
+  float* __restrict__ out = hd.partial + (long)by * hd.n_params;
   const bool iact[2] = {ig0 < CGx, ig0 + 1 < CGx}, jact[2] = {jg0 < CGd, jg0 + 1 < CGd};
   const bool do_bias = bi == 0 && (wave >> 1) == 0;
 
@@ -1149,7 +1135,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
             const unsigned vo = jj < N ? (unsigned)((i0 * N + jj) * 4) : 0x80000000u;   // (rows beyond K fall off the end of the buffer)
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg)
-              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][v][reg]), rw, vo + ((reg & 3) + 8 * (reg >> 2)) * N * 4, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[u][v][reg]), rw, vo + ((reg & 3) + 8 * (reg >> 2)) * N * 4, 0, ST_AUX);
           }
         }
       if (do_bias) {
@@ -1158,12 +1144,176 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
         for (int v = 0; v < 2; ++v) {
           const float bsum = sum_xor32(bacc[v]);   // rows 0..7 and 8..15 of the row blocks
           const int jj = 32 * (jg0 + v) + lane;
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rb, (lane < 32 && jact[v]) ? (unsigned)(jj * 4) : 0x80000000u, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, bsum), rb, (lane < 32 && jact[v]) ? (unsigned)(jj * 4) : 0x80000000u, 0, ST_AUX);
         }
       }
     }
   }
   WSTAMP(4);
+}
+
+// The first 16 dwords of the arguments are explicit scalars: with -mllvm -amdgpu-kernarg-preload-count=16 the command processor
+// hands them over in scalar registers at wave launch (gfx940+), so the layer's record -- and behind it the fragments -- can be
+// requested with the first instructions instead of after a trip for the head (tile table packed as 13 x 16 bits).
+__global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
+                                                       unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int has_fin, int grid_x, float* partial,
+                                                       long n_params, const WgradDev a) {   // (14 dwords are preloaded: up to `partial`)
+  WSTAMP(0);
+  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
+  __shared__ float fin_tl[64];
+  typedef WgKVec KVec;
+  typedef const char __attribute__((address_space(4))) * KBytes;
+  const KVec kv = (KVec)((KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64 + offsetof(WgradDev, lay));   // (64: the explicit scalars)
+  const WgHd hd{rb0, rb_end, rbs_per_slice, has_fin, partial, n_params};
+  // (the explicit scalars are 64 bytes: 7 + 4 + 1 dwords, a pointer, a long -- the record array's offset above; grid_x = gridDim.x,
+  //  which as a hidden argument would be a trip of its own)
+  if (hd.has_fin && (int)blockIdx.x == grid_x - 1) {
+    // The step's scalar epilogue (cost sums, history, counters) rides along as one extra workgroup: its inputs are complete
+    // before this launch starts, and a launch of its own costs ~6.5 us of the step.
+    if (blockIdx.y == 0) finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);
+    WSTAMP(5);
+    return;
+  }
+  const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
+  wgrad_block<false>(tbw, (int)blockIdx.x, (int)blockIdx.y, hd, kv);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The optimizer as the TAIL of the weight-gradient launch (emx_mlp_wgrad_adam): a step's last two launches in one.
+//   grid = (output blocks, slices + extra rows).  Rows [0, slices): the weight-gradient workgroups, dispatched first -- ALL of
+//   them are resident (the host checks: at most one per CU, one workgroup of this kernel fills a CU), so they may wait for one
+//   another.  Extra rows: workgroup 0 runs the step's scalar epilogue, the others gather the next batch's rows; neither waits.
+//   A weight-gradient workgroup stores its slice partials with sc1, drains them (s_waitcnt vmcnt(0)), and one lane adds to
+//   sync[0] at agent scope; it then waits (one lane polls, bounded) until every slice of every block is there and the epilogue
+//   has read the regulariser shares of the current weights (sync[3]); then its four waves run virtual optimizer workgroups
+//   (adam_store_block: sc1 loads of the partials, fixed order -- the same bits as emx_adam_step_slices behind emx_mlp_wgrad).
+//   Counters: nobody advances the optimizer step or the batch cursor while anyone may read them -- the LAST workgroup to leave
+//   (sync[1]) does, and resets the sync words for the next launch.  sync[2]: sticky, a wait ran out (never expected; the
+//   caller checks it when it synchronises).
+// ---------------------------------------------------------------------------------------------------------
+#ifdef EMX_CHAIN_TIMING   // timeline of the fused launch (tools/abl_tail.py): rows of 16 stamps at emx_dbg[6144 + 16 * who]
+#define TSTAMP(who, k) do { if (threadIdx.x == 0) emx_dbg[8 * (who) + (k)] = wall_clock64(); } while (0)
+#else
+#define TSTAMP(who, k)
+#endif
+struct WgTail {
+  unsigned* sync;
+  int64_t* cursor;
+  int64_t* opt_step;
+  int n_leavers;       // workgroups that count in sync[1]: weight gradients + epilogue + gather
+  int gather_wgs;
+  unsigned spin_limit;
+  int debug;           // EMX_TAIL_DEBUG (timing experiments only): 1 the gather workgroups do nothing, 2 no optimizer work, 4 no waiting
+};
+struct WgradAdamDev {
+  WgLayer lay[MAXL];   // (the head's fields are explicit scalars: no WgHead here, the arguments are 4 KB at most)
+  FinishArgs fin;
+  WgTail t;
+  AdamArgs ad;
+};
+static_assert(sizeof(WgradAdamDev) + 64 <= 4096, "kernel arguments: 4 KB");
+static_assert(AdamArgs::PLANES == 16, "the tail's wave -> virtual workgroup map");
+constexpr unsigned WG_TAIL_SPIN_LIMIT = 1u << 22;   // x (one sc1 load + s_sleep): seconds -- the waits last microseconds
+
+__global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
+                                                            unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int n_tiles, int n_slices,
+                                                            float* partial, long n_params, const WgradAdamDev a) {
+  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
+  __shared__ float fin_tl[64];
+  __shared__ __align__(16) _Float16 img[NT / 64][512];
+  __shared__ float red_dummy;
+  typedef const char __attribute__((address_space(4))) * KBytes;
+  typedef const void __attribute__((address_space(4))) * KArgs;
+  const KBytes kseg = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64;   // (64: the explicit scalars)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = blockIdx.x, by = blockIdx.y;
+  unsigned* const sync = a.t.sync;
+  (void)red_dummy;
+  if (by >= n_slices) {
+    const int e = (by - n_slices) * n_tiles + bx;   // 0: the scalar epilogue; 1 ..: the next batch's rows
+    if (e == 0) {
+      TSTAMP(1000, 0);
+      finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);   // (its cursor / counter2 are null: advanced below)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its reads of the regulariser shares have returned
+      __syncthreads();
+      if (tid == 0) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      TSTAMP(1000, 1);
+    } else if (e - 1 < a.t.gather_wgs) {
+      if (!(a.t.debug & 1)) {
+      const int gw = 512 + e - 1;
+      if (gw >= 0) TSTAMP(gw, 0);
+      gather_rows2_multi<8>(a.ad.next, (e - 1) * (NT / 64) + wave, a.t.gather_wgs * (NT / 64), lane);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (gw >= 0) TSTAMP(gw, 1);
+      }
+    } else {
+      return;   // (padding of the last grid row)
+    }
+  } else {
+    const WgHd hd{rb0, rb_end, rbs_per_slice, 0, partial, n_params};
+    const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
+    const int ww = by * n_tiles + bx;
+    if (ww >= 0) TSTAMP(ww, 0);
+    wgrad_block<true>(tbw, bx, by, hd, (WgKVec)(kseg + offsetof(WgradAdamDev, lay)));
+    if (ww >= 0) TSTAMP(ww, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (ww >= 0) TSTAMP(ww, 2);
+    __syncthreads();
+    const int n_wg = n_tiles * n_slices;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // one word to poll (the epilogue counts as one more arrival), and politely: sc1 loads and the arrivals' atomics of the
+      // whole launch meet at ONE memory channel -- a workgroup that still misses many arrivals sleeps longer between looks
+      unsigned spins = 0;
+      while (!(a.t.debug & 4)) {
+        const unsigned seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (seen >= (unsigned)n_wg + 1u) break;
+        if (++spins > a.t.spin_limit) {
+          __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          break;
+        }
+        if ((unsigned)n_wg + 1u - seen > 16u) __builtin_amdgcn_s_sleep(32);
+        else __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    __syncthreads();
+    if (ww >= 0) TSTAMP(ww, 3);
+    // the optimizer: virtual workgroups of one wave each, the launch's waves in turn
+    const long step_now = *a.ad.step;
+    const int nblk = a.ad.adam_blocks;
+    // (virtual workgroup vb = 64 plane + x; the planes' work sits at their small x: wave w of the launch takes plane w % 16,
+    //  x = w / 16, so that the slabs spread over as many waves as there are)
+    const int n_waves = n_wg * (NT / 64);
+    for (int w = (by * n_tiles + bx) * (NT / 64) + wave; w < 64 * AdamArgs::PLANES; w += n_waves) {
+      const int vb = ((w & (AdamArgs::PLANES - 1)) << 6) | (w >> 4);
+      if (vb >= nblk || (a.t.debug & 2)) continue;   // (fewer planes than 16)
+      float reg = adam_store_block<true>(a.ad, (KArgs)(kseg + offsetof(WgradAdamDev, ad)), a.ad.mirror, vb, lane, step_now, img[wave]);
+      reg = wave_sum(reg);
+      if (lane == 0) a.ad.ws[vb] = reg;
+      if (vb == 0)
+        for (int i = nblk + lane; i < EMX_REDUCE_WS; i += 64) a.ad.ws[i] = 0.f;
+    }
+  }
+  asm volatile("" ::: "memory");
+#ifdef EMX_CHAIN_TIMING
+  if (by < n_slices) {
+    TSTAMP(by * n_tiles + bx, 4);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    TSTAMP(by * n_tiles + bx, 5);
+  }
+#endif
+  // leave: the last one advances the counters and clears the sync words
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done == (unsigned)a.t.n_leavers - 1u) {
+      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.t.cursor) *a.t.cursor += 1;
+      if (a.t.opt_step) *a.t.opt_step += 1;
+    }
+  }
 }
 
 // g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
@@ -1763,6 +1913,112 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
   const long nn = hi - lo;
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3((unsigned)((nn + NT - 1) / NT)), dim3(NT), 0, st, ws, (long)n_params, slices, lo, hi, grad);
   return emx::check_launch("mlp_wgrad_reduce_kernel");
+}
+
+
+static int device_cus() {
+  static int n = [] {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    return v;
+  }();
+  return n;
+}
+
+// weight-gradient workgroups of the launch, spare workgroups for the gather; 0 if the tail does not fit
+static int wgrad_adam_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* tiles_out, int* slices_out, int* gather_out) {
+  int tiles = 0;
+  for (int l = 0; l < desc->n_layers; ++l) tiles += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
+  const int slices = emx_mlp_wgrad_slices(n_rows);
+  const int cus = device_cus();
+  // every weight-gradient workgroup must be resident while it waits for the others: one workgroup of this kernel fills a CU
+  const int spare = cus - tiles * slices - 1;
+  int gather = 0;
+  if (next) {
+    if (next->adc_head || !gather_vec4(next)) return 0;
+    const int want = (next->B + 2 * 8 * (NT / 64) - 1) / (2 * 8 * (NT / 64));   // eight row pairs per wave and pass
+    static const int cap = getenv("EMX_TAIL_GATHER_WGS") ? atoi(getenv("EMX_TAIL_GATHER_WGS")) : 1 << 20;
+    gather = std::min(std::min(want, spare), cap);
+    // (few spare workgroups for a large batch: the gather would outlast the weight gradients)
+    if (gather < 1 || (long)gather * 16 * (NT / 64) * 2 < next->B) return 0;   // (at most two passes)
+  }
+  if (spare < 0 || cus <= 0) return 0;
+  *tiles_out = tiles;
+  *slices_out = slices;
+  *gather_out = gather;
+  return 1;
+}
+
+int emx_mlp_wgrad_adam_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next) {
+  if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL || n_rows < 1) return 0;
+  int t, sl, g;
+  return wgrad_adam_shape(desc, n_rows, next, &t, &sl, &g);
+}
+
+int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params, const void* aop, int aop_rows, int row_begin, int row_end,
+                       float* ws, size_t ws_floats, const emx_finish_desc* finish, float* m, float* v, const float* l2coef, float lr, float beta1,
+                       float beta2, float eps, float clip, float* reg_ws, float* mirror, const emx_next_batch* next, uint32_t* sync,
+                       emx_stream_t stream) {
+  const char* who = "emx_mlp_wgrad_adam";
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  EMX_REQUIRE(params && aop && ws && m && v && reg_ws && mirror && sync && finish, "%s: null pointer argument", who);
+  EMX_REQUIRE(finish->hstep && finish->cursor && finish->counter2, "%s: the epilogue's counters (history step, batch cursor, optimizer step) are required", who);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "%s: bad rows", who);
+  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
+  if (rc) return rc;
+  rc = check_next(next, who);
+  if (rc) return rc;
+  const int nrows = row_end - row_begin;
+  if (ws_floats < emx_mlp_wgrad_ws_floats(n_params, nrows))
+    return emx::fail(EMX_EWORKSPACE, "%s: workspace %zu < %zu floats", who, ws_floats, emx_mlp_wgrad_ws_floats(n_params, nrows));
+  int tiles = 0, slices = 0, gather = 0;
+  if (!wgrad_adam_shape(desc, nrows, next, &tiles, &slices, &gather))
+    return emx::fail(EMX_EUNSUPPORTED, "%s: the launch does not fit this network / batch on the device (emx_mlp_wgrad_adam_fits): use emx_mlp_wgrad + "
+                     "emx_adam_step_slices", who);
+  EMX_REQUIRE((size_t)slices * (size_t)n_params * 4 < (size_t)1 << 31, "%s: slice partials beyond 2 GB", who);
+  WgradAdamDev a{};
+  // the epilogue: as emx_mlp_wgrad's, but the cursor and the optimizer step are advanced by the launch's last workgroup
+  rc = fill_finish_args(a.fin, finish->jobs, finish->n_jobs, finish->terms, finish->n_terms, finish->history, finish->term_history, finish->capacity,
+                        finish->hstep, nullptr, nullptr, "emx_mlp_wgrad_adam (finish)");
+  if (rc) return rc;
+  AopLayout AL;
+  aop_layout(desc, aop_rows, AL);
+  const int n = desc->n_layers;
+  int tile_begin[MAXL + 1];
+  for (int i = 0; i <= MAXL; ++i) tile_begin[i] = INT_MAX;
+  int tcount = 0;
+  for (int l = 0; l < n; ++l) {
+    const AopTensor X = aop_tensor(const_cast<void*>(aop), AL, l);
+    const AopTensor Dl = aop_tensor(const_cast<void*>(aop), AL, 1 + n + l);
+    a.lay[l] = WgLayer{X.frag, X.rscale, Dl.frag, Dl.rscale, (long)desc->w_off[l], (long)desc->b_off[l], desc->width[l], desc->width[l + 1], X.CG, Dl.CG};
+    tile_begin[l] = tcount;
+    tcount += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
+  }
+  EMX_REQUIRE(tcount == tiles && tiles < 0xffff, "%s: %d output blocks", who, tiles);
+  unsigned tbw[7];
+  for (int i = 0; i < 7; ++i) {
+    auto t16 = [&](int k) { return (unsigned)std::min(tile_begin[std::min(k, MAXL)], 0xffff) & 0xffffu; };
+    tbw[i] = t16(2 * i) | (t16(2 * i + 1) << 16);
+  }
+  a.ad = make_adam(params, nullptr, ws, slices, n_params, m, v, l2coef, n_params, lr, beta1, beta2, eps, clip, finish->counter2, reg_ws, desc, mirror, next);
+  a.ad.adam_blocks = 64 * a.ad.n_planes;
+  a.ad.late = 1;          // the regulariser shares left behind are those of the NEW weights ...
+  a.ad.step_ahead = 1;    // ... while *step still counts the updates before this one
+  a.ad.next.batch_step = 1;
+  a.t.sync = sync;
+  a.t.cursor = finish->cursor;
+  a.t.opt_step = finish->counter2;
+  a.t.gather_wgs = gather;
+  a.t.n_leavers = tiles * slices + 1 + gather;
+  static const unsigned spin = getenv("EMX_TAIL_SPIN_LIMIT") ? (unsigned)atol(getenv("EMX_TAIL_SPIN_LIMIT")) : WG_TAIL_SPIN_LIMIT;
+  a.t.spin_limit = spin;
+  static const int dbg = getenv("EMX_TAIL_DEBUG") ? atoi(getenv("EMX_TAIL_DEBUG")) : 0;
+  a.t.debug = dbg;
+  const int extra_rows = (1 + gather + tiles - 1) / tiles;
+  hipLaunchKernelGGL(mlp_wgrad_adam_kernel, dim3(tiles, slices + extra_rows), dim3(NT), 0, (hipStream_t)stream, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4],
+                     tbw[5], tbw[6], row_begin / 16, (row_end + 15) / 16, wgrad_slice_rows(nrows) / 16, tiles, slices, ws, (long)n_params, a);
+  return emx::check_launch("mlp_wgrad_adam_kernel");
 }
 
 }  // extern "C"

@@ -215,6 +215,10 @@ class SequentialEngine:
         self.zpub = torch.zeros(B, self.L, dtype=f32, device=dev)
         self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
         self._tiles_ran = False
+        # the optimizer as the tail of the weight-gradient launch (emx_mlp_wgrad_adam): its counters, zeroed once
+        self.wg_sync = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._tail_ok = None
+        self._tail_ran = False
 
     # -- data feed -------------------------------------------------------------------------------
     def set_data(self, data) -> None:
@@ -294,6 +298,13 @@ class SequentialEngine:
     # the all-pairs tiles ride in the fused dense-layer launch, beside the decoder half of it (single process, Euclidean data on
     # split rows, two latent columns; anything else keeps the separate tile launch).  EMX_OVERLAP_TILES=0: always separate.
     _overlap_tiles = os.environ.get("EMX_OVERLAP_TILES", "1") != "0"
+    # single process: L2 + clip + Adam, the operand store and the next batch's rows as the tail of the weight-gradient launch
+    # (emx_mlp_wgrad_adam: four launches per step instead of five) where every weight-gradient workgroup is resident at once.
+    # OFF by default: bit-identical, but measured slower than the two launches (C2: the one launch 27-33 us against 9.9 + 9.6 us,
+    # profiles/r03_tail_adam_ab.txt -- the workgroups' wait for one another inside the launch costs more than the launch it saves)
+    _tail_adam = os.environ.get("EMX_TAIL_ADAM", "0") == "1"
+    _tail_ran = False
+    _tail_ok = None
     _tiles_ran = False
 
     def _gather_current(self) -> None:
@@ -382,6 +393,9 @@ class SequentialEngine:
 
     def check_sync(self) -> None:
         """raises if a tile workgroup of a fused launch ever gave up waiting for the latent rows (emx.h: sync[2])"""
+        if int(self.wg_sync[2].item()) != 0:
+            raise _lib.EmxError("a weight-gradient workgroup gave up waiting for the others inside emx_mlp_wgrad_adam: the results of this "
+                                "run are invalid (set EMX_TAIL_ADAM=0 and report)")
         if int(self.sk_sync[2].item()) != 0:
             raise _lib.EmxError("a tile workgroup of the fused dense-layer launch gave up waiting for the latent rows: the results of "
                                 "this run are invalid (set EMX_OVERLAP_TILES=0 and report)")
@@ -470,6 +484,13 @@ class SequentialEngine:
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         self._wgrad()
 
+    def _tail_fits(self) -> bool:
+        """whether the step's last two launches run as one (emx_mlp_wgrad_adam; decided once per batch shape)"""
+        if self._tail_ok is None:
+            self._tail_ok = bool(self._tail_adam and self._prefetch and type(self)._step_post is SequentialEngine._step_post
+                                 and _lib.mlp_wgrad_adam_fits(self.plan, self.re - self.rb, self._next_batch()))
+        return self._tail_ok
+
     def _late_bookkeeping(self) -> bool:
         """Single process: the step's scalar epilogue rides along with the weight-gradient launch (its inputs are complete
         by then: the regulariser shares of the CURRENT weights were left by the previous optimizer launch, or by
@@ -492,9 +513,16 @@ class SequentialEngine:
         itself; data parallel: reduced into the flat gradient buffer for the all-reduce."""
         n = len(self.layout.layers)
         fin = None
+        self._tail_ran = False
         if self._late_bookkeeping():
             jobs = self._jobs_pre() + [self._reg_job()]
             fin = _lib.make_finish_desc(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+            if self._tail_fits():
+                p = self.p
+                _lib.mlp_wgrad_adam(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7,
+                                    1.0, self.red_ws2, self.wg_sync, next_batch=self._next_batch())
+                self._tail_ran = True
+                return
         elif self._dp_late_bookkeeping():
             # the rank's shares of the cost terms, summed by the extra workgroup: they travel in the same all-reduce as the
             # gradients; the counters advance here too, the history row follows the all-reduce (inside the optimizer launch)
@@ -508,6 +536,8 @@ class SequentialEngine:
         """clip + L2 + Adam (+ operand store, + the next batch), and -- unless it rode along with the weight gradients --
         ONE single-workgroup launch for every scalar of the step: cost sums, regulariser cost, history and counters."""
         p = self.p
+        if self._tail_ran:          # (the optimizer ran as the tail of the weight-gradient launch)
+            return
         reg_job = self._reg_job()
         nxt = self._next_batch() if self._prefetch else None
         if self._late_bookkeeping():
@@ -816,7 +846,7 @@ class SequentialEngine:
     def losses(self, start: int = 0) -> np.ndarray:
         """Total loss per executed step from step ``start`` on (synchronises; only that tail crosses PCIe)."""
         torch.cuda.synchronize(self.device)
-        if self._tiles_ran:
+        if self._tiles_ran or self._tail_ran:
             self.check_sync()
         return self.history[start: self._hstep_host].cpu().numpy()
 
