@@ -104,6 +104,9 @@ SIGNATURES = {
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
     "emx_mlp_wgrad_adam_fits": (_i, [_p, _i, _p]),
+    "emx_mlp_wgrad_adam_local_fits": (_i, [_p, _i, _p]),
+    "emx_mlp_wgrad_adam_local_ws_floats": (_sz, [_p, _i]),
+    "emx_mlp_wgrad_adam_local": (_i, [_p, _p, _l, _p, _i, _i, _i, _p, _sz, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
     "emx_mlp_wgrad_adam": (_i, [_p, _p, _l, _p, _i, _i, _i, _p, _sz, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
 }
 
@@ -628,6 +631,31 @@ def mlp_wgrad_adam(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishDesc", 
                                      int(row_end), _ptr(ws), ws.numel(), C.byref(finish), _ptr(m), _ptr(v), _ptr(l2coef), float(lr), float(beta1),
                                      float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(reg_ws), _ptr(plan.mirror), nb,
                                      _ptr(sync), _stream()), "emx_mlp_wgrad_adam")
+
+
+def mlp_wgrad_adam_local_fits(plan: MlpPlan, n_rows, next_batch=None) -> bool:
+    """whether emx_mlp_wgrad_adam_local is made for this network / batch (small batches, small networks)"""
+    nb = C.byref(next_batch) if next_batch is not None else None
+    return bool(load().emx_mlp_wgrad_adam_local_fits(C.byref(plan.desc), int(n_rows), nb))
+
+
+def mlp_wgrad_adam_local_ws_floats(plan: MlpPlan, n_rows) -> int:
+    return int(load().emx_mlp_wgrad_adam_local_ws_floats(C.byref(plan.desc), int(n_rows)))
+
+
+def mlp_wgrad_adam_local(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishDesc", m, v, l2coef, lr, beta1, beta2, eps, clip, reg_ws, sync,
+                         next_batch=None):
+    """Weight gradients of all layers without slice partials (a workgroup per 32 x 32 block of a kernel, over all rows), the step's
+    scalar epilogue, L2 + clip + Adam (+ operand store) and the next batch's rows in ONE launch (emx.h).  ``reg_ws``: 2 x
+    EMX_REDUCE_WS floats (the regulariser shares by the parity of the optimizer step)."""
+    if plan.aop is None:
+        raise EmxError("mlp_wgrad_adam_local: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
+    assert sync.dtype == torch.int32 and sync.numel() >= 4 + 256 and reg_ws.numel() >= 2 * EMX_REDUCE_WS
+    nb = C.byref(next_batch) if next_batch is not None else None
+    _check(load().emx_mlp_wgrad_adam_local(C.byref(plan.desc), _ptr(plan.params), plan.n_params, plan.aop.data_ptr(), plan.aop_rows, int(row_begin),
+                                           int(row_end), _ptr(ws), ws.numel() if ws is not None else 0, C.byref(finish), _ptr(m), _ptr(v), _ptr(l2coef), float(lr), float(beta1), float(beta2),
+                                           float(eps), float(clip if clip is not None else 0.0), _ptr(reg_ws), _ptr(plan.mirror), nb, _ptr(sync),
+                                           _stream()), "emx_mlp_wgrad_adam_local")
 
 
 # ---- ADC path ---------------------------------------------------------------------------------------------------

@@ -37,7 +37,8 @@ constexpr int FQ_EMBEDDED = 2;   // ... when it rides along with the weight grad
 // the body of finish_step_kernel, for one workgroup of FIN_NT threads (also run by one extra workgroup of the
 // weight-gradient kernel, so that a single-GPU step needs no launch of its own for it)
 template <int FQ>
-__device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&red)[EMX_MAX_SUM_JOBS][FIN_NT / 64], float (&tl)[64]) {
+__device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&red)[EMX_MAX_SUM_JOBS][FIN_NT / 64], float (&tl)[64],
+                                                 const int shift_job = -1, const long shift = 0) {   // (job shift_job reads src + shift floats)
   constexpr int NT = FIN_NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   FSTAMP(0);
@@ -66,8 +67,9 @@ __device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&re
     for (int jj = 0; jj < 4; ++jj) {
       const int j = g0 + jj;
       // absent and unaligned jobs re-read the first 16 bytes of `terms` with weight 0: no branch around any load
-      const bool vec = j < a.n_jobs && (reinterpret_cast<uintptr_t>(a.jobs[j].src) & 15) == 0;
-      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(vec ? a.jobs[j].src : a.terms_base);
+      const float* const srcj = a.jobs[j < a.n_jobs ? j : 0].src + (j == shift_job ? shift : 0);
+      const bool vec = j < a.n_jobs && (reinterpret_cast<uintptr_t>(srcj) & 15) == 0;
+      const float4* __restrict__ src4 = reinterpret_cast<const float4*>(vec ? srcj : a.terms_base);
       const long n4 = vec ? a.jobs[j].n >> 2 : 0;
 #pragma unroll
       for (int u = 0; u < FQ; ++u) v[jj][u] = src4[min((long)tid + u * NT, max(n4, 1L) - 1)];
@@ -76,7 +78,8 @@ __device__ __forceinline__ void finish_step_body(const FinishArgs& a, float (&re
     for (int jj = 0; jj < 4; ++jj) {
       const int j = g0 + jj;
       const bool live = j < a.n_jobs;
-      const emx_sum_job job = a.jobs[live ? j : 0];
+      emx_sum_job job = a.jobs[live ? j : 0];
+      if (j == shift_job) job.src += shift;
       const bool vec = live && (reinterpret_cast<uintptr_t>(job.src) & 15) == 0;
       const long n = live ? job.n : 0, n4 = vec ? n >> 2 : 0;
       const bool sq = job.square != 0;

@@ -1316,6 +1316,332 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Small batches: weight gradients WITHOUT slice partials, the optimizer in the same workgroup (emx_mlp_wgrad_adam_local).
+//   One workgroup owns one 32 x 32 block of one kernel (and, for the blocks of the first 32 in-features, 32 biases) over ALL
+//   rows of the batch: its four waves take a quarter of the row blocks each (v_mfma_f32_32x32x16_f16 on the fragments of aop.h,
+//   two accumulators in turn, groups of four row blocks on a common scale as in mlp_wgrad_kernel), add their quarters in LDS in a
+//   fixed order, and each wave then runs L2 + clip + Adam and the operand-store rewrite for one 8 x 32 slab of the block -- whose
+//   parameters and moments it requested at the head of the launch.  No partials leave the CU (emx_mlp_wgrad writes and re-reads
+//   slices x parameters floats: 8.4 MB at B = 4096), no workgroup waits for another, and a step ends with this launch: spare
+//   workgroups run the scalar epilogue and gather the next batch's rows.
+//   Counters: every workgroup reads the optimizer step / the batch cursor and then counts in sync[1]; the epilogue workgroup --
+//   the only one that waits, at its end -- advances them when all have counted, and clears sync[1].  Regulariser shares: the
+//   epilogue reads the half of ws the previous launch wrote (parity of the optimizer step), this launch writes the other.
+//   The matrix work of a wave grows with the batch (4096 rows: 192 instructions, ~5 us): the host takes this path for batches
+//   of up to EMX_WGRAD_LOCAL_MAX_ROWS rows and networks of up to 255 blocks (emx_mlp_wgrad_adam_local_fits).
+// ---------------------------------------------------------------------------------------------------------
+struct WlTail {
+  unsigned* sync;
+  int64_t* cursor;
+  int64_t* opt_step;
+  int n_counted;       // workgroups that count in sync[1]: blocks + gather
+  int gather_wgs;
+  unsigned spin_limit;
+  int reg_job;         // the epilogue's job that sums the regulariser shares (its source moves with the step's parity); -1: none
+  short block_begin[MAXL];   // blocks of the layers before layer l (ws slots are numbered in layer order)
+  int splits;          // workgroups that share the rows of a block (1: none of the hand-off below)
+  float* shares;       // [splits][n_blocks][WL_SHARE]: the workgroups' shares of their blocks, for the last one of a block to add
+};
+struct WgradLocalDev {
+  WgLayer lay[MAXL];
+  FinishArgs fin;
+  WlTail t;
+  AdamArgs ad;
+};
+static_assert(sizeof(WgradLocalDev) + 64 <= 4096, "kernel arguments: 4 KB");
+constexpr int WL_SHARE = 1024 + 32;   // a block's 32 x 32 sums in slab order (wave, lane, 4) and its 32 bias sums
+constexpr int WL_GB = 4;   // row blocks per group (one trip to memory, one common scale)
+constexpr int NTL = 512;   // eight waves: the row blocks of a block in eighths -- what bounds the launch is the bytes a CU has in flight
+static_assert(NTL == 2 * FIN_NT, "the epilogue runs on the first FIN_NT threads");
+
+__global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
+                                                             unsigned tbcd, int rb0, int rb_end, int n_blocks, int per_xcd, int n_slots, const int64_t* p_step,
+                                                             const char* p_mirror, const WgradLocalDev a) {
+  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
+  __shared__ float fin_tl[64];
+  __shared__ __align__(16) _Float16 img[4][512];
+  __shared__ float red[NTL / 64][32][33];
+  __shared__ float bred[NTL / 64][32];
+  __shared__ float rreg[4];
+  __shared__ unsigned ticket;
+  typedef const char __attribute__((address_space(4))) * KBytes;
+  const KBytes kseg = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64;   // (64: the explicit scalars)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int bx = blockIdx.x;
+  unsigned* const sync = a.t.sync;
+  const int splits = a.t.splits;
+  if (bx >= splits * n_slots) {
+    const int e = bx - splits * n_slots;   // 0: the scalar epilogue; 1 ..: the next batch's rows
+    if (e == 0) {
+      if (tid >= FIN_NT) return;   // (the epilogue is written for FIN_NT threads; a wave that has ended takes no part in barriers)
+      TSTAMP(1000, 0);
+      const long st = *p_step;
+      // (its cursor / counter2 are null: advanced below; the regulariser shares: the half of ws the previous launch wrote)
+      finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl, a.t.reg_job, (st & 1) * EMX_REDUCE_WS);
+      TSTAMP(1000, 1);
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.t.n_counted) {
+          if (++spins > a.t.spin_limit) {
+            __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(8);
+        }
+        __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (a.t.cursor) *a.t.cursor += 1;
+        *a.t.opt_step = st + 1;
+      }
+      TSTAMP(1000, 2);
+    } else {
+      TSTAMP(512 + e - 1, 0);
+      if (a.ad.next_vec4) gather_rows2_multi<4>(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);
+      else gather_rows_body(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);   // (rows without 16-byte lanes)
+      TSTAMP(512 + e - 1, 1);
+      __syncthreads();   // (every wave has its cursor: the loads that use it are issued)
+      if (tid == 0) __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
+  // ---- one 32 x 32 block ----
+  TSTAMP(bx, 0);
+  const long step_now = *p_step;
+  const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
+  // Slot -> XCD: workgroups go to the XCDs in turn, so slot s of XCD x is workgroup 8 s + x; the host gives every kernel a run of
+  // virtual indices v = per_xcd x + s inside as few XCDs as it can: the blocks of a kernel read the same fragments, and each
+  // XCD fetches what its workgroups read through its own L2 (with the blocks dealt round-robin every fragment crossed the
+  // fabric four times: 72 MB at B = 4096, which bound the launch).  Indices outside every run: nothing to do.
+  // (with the rows of a block split over `splits` workgroups: part = bx / n_slots of them takes slot bx % n_slots)
+  const int part = bx >= n_slots ? bx / n_slots : 0, bs = bx - part * n_slots;
+  const int v = per_xcd > 0 ? (bs & 7) * per_xcd + (bs >> 3) : bs;
+  int li = 0, tbase = (int)(tbw[0] & 0xffffu);
+#pragma unroll
+  for (int i = 1; i < MAXL; ++i) {
+    const int t = (int)((tbw[i >> 1] >> (16 * (i & 1))) & 0xffffu);   // (unused entries: 0xffff)
+    if (v >= t && t >= tbase) {
+      li = i;
+      tbase = t;
+    }
+  }
+  if (v < tbase) return;
+  typedef const u32x16 __attribute__((address_space(4))) * KVec;
+  const u32x16 lrec = ((KVec)(kseg + offsetof(WgradLocalDev, lay)))[li];
+  WgLayer L;
+  __builtin_memcpy(&L, &lrec, 64);
+  const u32x16 arec = ((KVec)(kseg + offsetof(WgradLocalDev, ad) + offsetof(AdamArgs, lay)))[li];
+  AdamArgs::Layer AL;
+  __builtin_memcpy(&AL, &arec, 64);
+  const int CGx = L.CGx, CGd = L.CGd;
+  const int sb = v - tbase;
+  if (sb >= CGx * CGd) return;
+  const int bi = sb / CGd, bj = sb - bi * CGd;
+  const int blk = __builtin_amdgcn_readfirstlane(a.t.block_begin[li] + sb);   // the block's number in layer order (its slot of ws)
+  const int k8 = 4 * bi + (wave & 3);                 // the slab of the block that one of the first four waves updates
+  const bool slab_live = wave < 4 && 8 * k8 < L.K;
+  AdamSlab slab = adam_slab_prefetch(a.ad, AL, p_mirror, slab_live ? k8 : 0, bj, lane);
+  // the rows: `splits` workgroups share a block, the eight waves of each share its rows
+  const int nrb_all = rb_end - rb0;
+  const int per_wg = (nrb_all + splits - 1) / splits;
+  const int wg0 = rb0 + part * per_wg, wg1 = min(wg0 + per_wg, rb_end);
+  const int per = (max(wg1 - wg0, 0) + NTL / 64 - 1) / (NTL / 64);
+  const int rbs = wg0 + wave * per, rbe = min(rbs + per, wg1);
+  const bool do_bias = bi == 0;
+  // (the 32 biases of the blocks of the first in-features: requested now, like the slabs)
+  const bool bias_lane = do_bias && wave == 0 && lane < 32 && 32 * bj + lane < L.N;
+  const long be = L.b_off + 32 * bj + (lane & 31);
+  float bw = 0.f, bm = 0.f, bv = 0.f, bl2 = 0.f;
+  if (bias_lane) {
+    bw = a.ad.w[be], bm = a.ad.m[be], bv = a.ad.v[be];
+    if (a.ad.l2coef) bl2 = a.ad.l2coef[be];
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float bacc = 0.f;
+  typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+  const half2v one2 = {(_Float16)1.f, (_Float16)1.f};
+  if (rbs < rbe) {
+    struct Frags {
+      half8 x[2], d[2];   // [plane]
+    };
+    const __amdgpu_buffer_rsrc_t rX = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(L.xfrag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rD = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(L.dfrag), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rXs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.xrs), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rDs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(L.drs), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    constexpr int GB = WL_GB;
+    // a group's requests: the scales of its row blocks (lane q: row block g + q) and the four fragments of each
+    auto issue = [&](int g, Frags (&f)[GB], unsigned& vsx, unsigned& vsd) __attribute__((always_inline)) {
+      // (row blocks beyond the wave's range: an offset outside the buffer -- the request comes back at once with zeros and without
+      //  a trip to memory, so nothing is outstanding behind the last products; the requests themselves stay unconditional)
+      const int sq = min(g + (lane & (GB - 1)), rbe - 1);
+      const int so = g < rbe ? 0 : (int)0x80000000;
+      vsx = __builtin_amdgcn_raw_buffer_load_b32(rXs, (sq * CGx + bi) * 4 + so, 0, 0);
+      vsd = __builtin_amdgcn_raw_buffer_load_b32(rDs, (sq * CGd + bj) * 4 + so, 0, 0);
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        const bool in = g + q < rbe;
+        const int rbc = in ? g + q : 0;
+        const int vo = in ? lane16 : (int)0x80000000;
+        const int ox = (rbc * CGx + bi) * 2048, od = (rbc * CGd + bj) * 2048;
+        f[q].x[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, ox, 0));
+        f[q].x[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rX, vo, ox + 1024, 0));
+        f[q].d[0] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rD, vo, od, 0));
+        f[q].d[1] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rD, vo, od + 1024, 0));
+      }
+    };
+    auto ratio = [&](unsigned sblk, unsigned sgrp) __attribute__((always_inline)) {   // as in wgrad_block
+      const int d = min((int)(sgrp >> 23) - (int)(sblk >> 23), 30);
+      return (_Float16)__uint_as_float((unsigned)(127 - d) << 23);
+    };
+    auto products = [&](int g, Frags (&f)[GB], unsigned vsx, unsigned vsd) __attribute__((always_inline)) {
+      unsigned sx[GB], sd[GB], Rxb = 0u, Rdb = 0u;
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        sx[q] = (unsigned)__builtin_amdgcn_readlane((int)vsx, q);
+        sd[q] = (unsigned)__builtin_amdgcn_readlane((int)vsd, q);
+        Rxb = max(Rxb, sx[q]);
+        Rdb = max(Rdb, sd[q]);
+      }
+      f32x16 ga[2];
+      float gb = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) ga[0][i] = ga[1][i] = 0.f;
+#pragma unroll
+      for (int q = 0; q < GB; ++q) {
+        if (g + q < rbe) {
+          Frags& fq = f[q];
+          const _Float16 rx = ratio(sx[q], Rxb), rd = ratio(sd[q], Rdb);
+          if (rx != (_Float16)1.f) {   // (wave-uniform)
+            fq.x[0] *= rx;
+            fq.x[1] *= rx;
+          }
+          if (rd != (_Float16)1.f) {
+            fq.d[0] *= rd;
+            fq.d[1] *= rd;
+          }
+#pragma unroll
+          for (int c = 0; c < 3; ++c) {   // small products first: (h, l), (l, h), (h, h); two accumulators in turn
+            const int px = c == 1 ? 1 : 0, pd = c == 0 ? 1 : 0;
+            ga[q & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fq.x[px], fq.d[pd], ga[q & 1], 0, 0, 0);
+          }
+          if (do_bias) {
+#pragma unroll
+            for (int pl = 1; pl >= 0; --pl)
+#pragma unroll
+              for (int e = 0; e < 8; e += 2) {
+                half2v pr = {fq.d[pl][e], fq.d[pl][e + 1]};
+                gb = __builtin_amdgcn_fdot2(pr, one2, gb, false);
+              }
+          }
+        }
+      }
+      const float sc = __uint_as_float(Rxb) * __uint_as_float(Rdb);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = fmaf(ga[0][i] + ga[1][i], sc, acc[i]);
+      bacc = fmaf(gb, __uint_as_float(Rdb), bacc);
+    };
+    // Two groups in flight, every request unconditional (row blocks beyond the wave's range repeat its last one; their products
+    // are skipped): a request under a branch would make every wait behind it a full one.
+    Frags fa[GB], fb[GB];
+    unsigned vxa, vda, vxb, vdb;
+    issue(rbs, fa, vxa, vda);
+    for (int g = rbs; g < rbe; g += 2 * GB) {
+      issue(g + GB, fb, vxb, vdb);
+      products(g, fa, vxa, vda);
+      issue(g + 2 * GB, fa, vxa, vda);
+      products(g + GB, fb, vxb, vdb);
+    }
+  }
+  TSTAMP(bx, 2);
+  static_assert(NTL / 64 == 8, "the fixed-order sums below are written for eight waves");
+  // the waves' shares: D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]
+#pragma unroll
+  for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][lane & 31] = acc[r];
+  if (do_bias) {
+    const float bsum = sum_xor32(bacc);   // rows 0..7 and 8..15 of the row blocks
+    if (lane < 32) bred[wave][lane] = bsum;
+  }
+  __syncthreads();
+  TSTAMP(bx, 3);
+  // Every wave's step counter -- its first request -- arrived long ago: count the workgroup in (the epilogue workgroup advances
+  // the counters when all have).  By a wave that has nothing else left to do: the others do not wait for the atomic.
+  if (tid == NTL - 64) __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float reg = 0.f;
+  const int kr = lane >> 3, c4 = lane & 7;
+  float g[4] = {0.f, 0.f, 0.f, 0.f}, db = 0.f;
+  if (wave < 4) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * wave + kr, col = 4 * c4 + i;
+      g[i] = ((red[0][row][col] + red[1][row][col]) + (red[2][row][col] + red[3][row][col])) +
+             ((red[4][row][col] + red[5][row][col]) + (red[6][row][col] + red[7][row][col]));
+    }
+    if (do_bias && wave == 0 && lane < 32)
+      db = ((bred[0][lane] + bred[1][lane]) + (bred[2][lane] + bred[3][lane])) + ((bred[4][lane] + bred[5][lane]) + (bred[6][lane] + bred[7][lane]));
+  }
+  if (splits > 1) {
+    // Rows split over workgroups: each leaves its share of the block (sc1 stores, drained) and takes a ticket; the LAST one
+    // adds the shares in the order of the parts -- whoever it is, the same bits -- and updates the parameters.  Nobody waits.
+    float* const mine = a.t.shares + ((long)part * n_blocks + blk) * WL_SHARE;
+    const __amdgpu_buffer_rsrc_t rS = __builtin_amdgcn_make_buffer_rsrc(mine, 0, WL_SHARE * 4, 0x00020000);
+    if (wave < 4) {
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+      const u32x4s q = {__float_as_uint(g[0]), __float_as_uint(g[1]), __float_as_uint(g[2]), __float_as_uint(g[3])};
+      __builtin_amdgcn_raw_buffer_store_b128(q, rS, (wave * 64 + lane) * 16, 0, 16);
+      if (do_bias && wave == 0 && lane < 32) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(db), rS, (1024 + lane) * 4, 0, 16);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) ticket = __hip_atomic_fetch_add(&sync[4 + blk], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)splits - 1u) return;
+    if (tid == 0) __hip_atomic_store(&sync[4 + blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wave < 4) {
+      typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
+#pragma unroll 1
+      for (int q = 0; q < splits; ++q) {
+        const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(a.t.shares + ((long)q * n_blocks + blk) * WL_SHARE, 0, WL_SHARE * 4, 0x00020000);
+        const u32x4s x = __builtin_amdgcn_raw_buffer_load_b128(rQ, (wave * 64 + lane) * 16, 0, 16);
+        const float b = (do_bias && wave == 0 && lane < 32) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rQ, (1024 + lane) * 4, 0, 16)) : 0.f;
+        if (q == 0) {
+          g[0] = __uint_as_float(x.x), g[1] = __uint_as_float(x.y), g[2] = __uint_as_float(x.z), g[3] = __uint_as_float(x.w);
+          db = b;
+        } else {
+          g[0] += __uint_as_float(x.x), g[1] += __uint_as_float(x.y), g[2] += __uint_as_float(x.z), g[3] += __uint_as_float(x.w);
+          db += b;
+        }
+      }
+    }
+  }
+  TSTAMP(bx, 6);
+  if (slab_live) {
+    reg = adam_slab_finish(a.ad, AL, p_mirror, slab, g, k8, bj, lane, step_now, img[wave & 3]);
+  }
+  TSTAMP(bx, 7);
+  if (bias_lane) {
+    const float t = (float)(step_now + (a.ad.late ? 0 : 1) + a.ad.step_ahead);
+    const float alpha = a.ad.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.ad.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.ad.log2_b1));
+    adam_one(bw, db, bm, bv, bl2, a.ad, alpha, reg);
+    a.ad.w[be] = bw;
+    a.ad.m[be] = bm;
+    a.ad.v[be] = bv;
+  }
+  TSTAMP(bx, 4);
+  // the block's share of the regulariser cost of the NEW weights, for the next launch's epilogue (the other half of ws)
+  reg = wave_sum(reg);
+  if (lane == 0 && wave < 4) rreg[wave] = reg;
+  __syncthreads();
+  float* const wsn = a.ad.ws + ((step_now + 1) & 1) * EMX_REDUCE_WS;
+  if (tid == 0) wsn[blk] = (rreg[0] + rreg[1]) + (rreg[2] + rreg[3]);
+  if (blk == 0)
+    for (int i = n_blocks + tid; i < EMX_REDUCE_WS; i += NTL) wsn[i] = 0.f;
+  TSTAMP(bx, 5);
+}
+
 // g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
 __global__ __launch_bounds__(NT) void mlp_wgrad_reduce_kernel(const float* __restrict__ partial, long n_params, int n_slices, long lo,
                                                               long hi, float* __restrict__ g) {
@@ -2019,6 +2345,140 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
   hipLaunchKernelGGL(mlp_wgrad_adam_kernel, dim3(tiles, slices + extra_rows), dim3(NT), 0, (hipStream_t)stream, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4],
                      tbw[5], tbw[6], row_begin / 16, (row_end + 15) / 16, wgrad_slice_rows(nrows) / 16, tiles, slices, ws, (long)n_params, a);
   return emx::check_launch("mlp_wgrad_adam_kernel");
+}
+
+
+// 32 x 32 blocks of all kernels; 0 if the launch is not made for this network / batch
+static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* blocks_out, int* gather_out, int* splits_out) {
+  static const int max_rows = getenv("EMX_WGRAD_LOCAL_MAX_ROWS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_ROWS")) : 4096;
+  static const int max_blocks = getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS")) : 255;
+  if (n_rows > max_rows) return 0;
+  int blocks = 0;
+  for (int l = 0; l < desc->n_layers; ++l) blocks += ((desc->width[l] + 31) / 32) * ((desc->width[l + 1] + 31) / 32);
+  if (blocks > std::min(max_blocks, (int)EMX_REDUCE_WS)) return 0;
+  int gather = 0;
+  if (next) {
+    if (next->adc_head) return 0;
+    if (gather_vec4(next)) gather = (next->B + 2 * 4 * (NTL / 64) - 1) / (2 * 4 * (NTL / 64));   // four row pairs per wave, one pass
+    else gather = std::min((next->B + NTL / 64 - 1) / (NTL / 64), 512);                            // a row per wave and pass
+  }
+  // the rows of a block over several workgroups: what bounds the launch is the bytes in flight, i.e. the number of CUs at work --
+  // as many parts as fit the device beside the epilogue, at least 32 row blocks (four per wave) each, at most two (C2, 72 blocks:
+  // 0.0735 / 0.0714 / 0.0725-0.0732 ms per step with 1 / 2 / 3 parts -- every part's share goes through memory)
+  static const int max_splits = getenv("EMX_WGRAD_LOCAL_SPLITS") ? atoi(getenv("EMX_WGRAD_LOCAL_SPLITS")) : 2;
+  const int nrb = (n_rows + 15) / 16;
+  int splits = std::min(std::min(max_splits, (nrb + 31) / 32), (std::max(device_cus(), 1) - 1) / std::max(blocks, 1));
+  splits = std::max(splits, 1);
+  *blocks_out = blocks;
+  *gather_out = gather;
+  *splits_out = splits;
+  return 1;
+}
+
+size_t emx_mlp_wgrad_adam_local_ws_floats(const emx_mlp_desc* desc, int n_rows) {
+  if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL || n_rows < 1) return 0;
+  int b, g, sp;
+  if (!wgrad_local_shape(desc, n_rows, nullptr, &b, &g, &sp)) return 0;
+  return sp > 1 ? (size_t)sp * (size_t)b * WL_SHARE : 0;
+}
+
+int emx_mlp_wgrad_adam_local_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next) {
+  if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL || n_rows < 1) return 0;
+  int b, g, sp;
+  return wgrad_local_shape(desc, n_rows, next, &b, &g, &sp);
+}
+
+int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_params, const void* aop, int aop_rows, int row_begin, int row_end,
+                             float* ws, size_t ws_floats, const emx_finish_desc* finish, float* m, float* v, const float* l2coef, float lr, float beta1, float beta2, float eps,
+                             float clip, float* reg_ws, float* mirror, const emx_next_batch* next, uint32_t* sync, emx_stream_t stream) {
+  const char* who = "emx_mlp_wgrad_adam_local";
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  EMX_REQUIRE(params && aop && m && v && reg_ws && mirror && sync && finish, "%s: null pointer argument", who);
+  EMX_REQUIRE(finish->hstep && finish->cursor && finish->counter2, "%s: the epilogue's counters (history step, batch cursor, optimizer step) are required", who);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "%s: bad rows", who);
+  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
+  if (rc) return rc;
+  rc = check_next(next, who);
+  if (rc) return rc;
+  const int nrows = row_end - row_begin;
+  int blocks = 0, gather = 0, splits = 1;
+  if (!wgrad_local_shape(desc, nrows, next, &blocks, &gather, &splits))
+    return emx::fail(EMX_EUNSUPPORTED, "%s: not made for this network / batch (emx_mlp_wgrad_adam_local_fits): use emx_mlp_wgrad + emx_adam_step_slices", who);
+  const size_t need = splits > 1 ? (size_t)splits * blocks * WL_SHARE : 0;
+  if (need > 0 && (!ws || ws_floats < need)) return emx::fail(EMX_EWORKSPACE, "%s: workspace %zu < %zu floats", who, ws ? ws_floats : (size_t)0, need);
+  WgradLocalDev a{};
+  rc = fill_finish_args(a.fin, finish->jobs, finish->n_jobs, finish->terms, finish->n_terms, finish->history, finish->term_history, finish->capacity,
+                        finish->hstep, nullptr, nullptr, "emx_mlp_wgrad_adam_local (finish)");
+  if (rc) return rc;
+  a.t.reg_job = -1;
+  for (int j = 0; j < finish->n_jobs; ++j)
+    if (finish->jobs[j].src == reg_ws) a.t.reg_job = j;
+  AopLayout AL;
+  aop_layout(desc, aop_rows, AL);
+  const int n = desc->n_layers;
+  int begin[MAXL + 1], nblk[MAXL];
+  for (int i = 0; i <= MAXL; ++i) begin[i] = 0xffff;
+  int count = 0, largest = 1;
+  for (int l = 0; l < n; ++l) {
+    const AopTensor X = aop_tensor(const_cast<void*>(aop), AL, l);
+    const AopTensor Dl = aop_tensor(const_cast<void*>(aop), AL, 1 + n + l);
+    a.lay[l] = WgLayer{X.frag, X.rscale, Dl.frag, Dl.rscale, (long)desc->w_off[l], (long)desc->b_off[l], desc->width[l], desc->width[l + 1], X.CG, Dl.CG};
+    EMX_REQUIRE(X.CG == (desc->width[l] + 31) / 32 && Dl.CG == (desc->width[l + 1] + 31) / 32, "%s: unexpected fragment layout", who);
+    nblk[l] = X.CG * Dl.CG;
+    a.t.block_begin[l] = (short)count;
+    count += nblk[l];
+    largest = std::max(largest, nblk[l]);
+  }
+  EMX_REQUIRE(count == blocks && blocks < 0x7fff, "%s: %d blocks", who, blocks);
+  // virtual indices: per_xcd slots per XCD (at most the 32 CUs of one), a kernel's blocks in one run, aligned so that a run of up
+  // to per_xcd blocks lies inside one XCD
+  auto pow2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };
+  // (EMX_WGRAD_LOCAL_XCD=1: an experiment -- measured no faster at B = 4096 without splits, slower with them, where the parts of a
+  //  kernel's blocks then crowd one XCD; default: blocks in layer order, workgroup = block)
+  static const int xcd_aware = getenv("EMX_WGRAD_LOCAL_XCD") ? atoi(getenv("EMX_WGRAD_LOCAL_XCD")) : 0;
+  int per_xcd = std::min(32, std::max((blocks + 7) / 8, pow2ceil(largest)));
+  int n_slots = 0;
+  if (!xcd_aware) {
+    per_xcd = 0;
+    n_slots = blocks;
+    for (int l = 0; l < n; ++l) begin[l] = a.t.block_begin[l];
+  }
+  for (; xcd_aware; per_xcd = std::min(per_xcd * 2, 1 << 14)) {
+    int pos = 0;
+    for (int l = 0; l < n; ++l) {
+      const int al = xcd_aware ? std::min(per_xcd, pow2ceil(nblk[l])) : 1;
+      pos = (pos + al - 1) / al * al;
+      begin[l] = pos;
+      pos += nblk[l];
+    }
+    if (pos <= 8 * per_xcd || per_xcd >= (1 << 14)) {
+      n_slots = 8 * per_xcd;
+      break;
+    }
+  }
+  EMX_REQUIRE(n_slots < 0xffff && begin[n - 1] + nblk[n - 1] <= n_slots, "%s: %d block slots", who, n_slots);
+  unsigned tbw[7];
+  for (int i = 0; i < 7; ++i) {
+    auto t16 = [&](int k) { return (unsigned)std::min(begin[std::min(k, MAXL)], 0xffff) & 0xffffu; };
+    tbw[i] = t16(2 * i) | (t16(2 * i + 1) << 16);
+  }
+  a.ad = make_adam(params, nullptr, nullptr, 0, 0, m, v, l2coef, n_params, lr, beta1, beta2, eps, clip, finish->counter2, reg_ws, desc, mirror, next);
+  a.ad.late = 1;          // the regulariser shares left behind are those of the NEW weights ...
+  a.ad.step_ahead = 1;    // ... while *step still counts the updates before this one
+  a.ad.next.batch_step = 1;
+  a.t.sync = sync;
+  a.t.cursor = finish->cursor;
+  a.t.opt_step = finish->counter2;
+  a.t.gather_wgs = gather;
+  a.t.n_counted = splits * blocks + gather;
+  a.t.splits = splits;
+  a.t.shares = ws;
+  static const unsigned spin = getenv("EMX_TAIL_SPIN_LIMIT") ? (unsigned)atol(getenv("EMX_TAIL_SPIN_LIMIT")) : WG_TAIL_SPIN_LIMIT;
+  a.t.spin_limit = spin;
+  hipLaunchKernelGGL(mlp_wgrad_local_kernel, dim3(splits * n_slots + 1 + gather), dim3(NTL), 0, (hipStream_t)stream, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4], tbw[5],
+                     tbw[6], row_begin / 16, (row_end + 15) / 16, blocks, per_xcd, n_slots, (const int64_t*)finish->counter2, (const char*)mirror, a);
+  return emx::check_launch("mlp_wgrad_local_kernel");
 }
 
 }  // extern "C"

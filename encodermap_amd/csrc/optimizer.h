@@ -511,6 +511,89 @@ __device__ __forceinline__ float adam_store_block(const AdamArgs& a, const void 
   return reg;
 }
 
+// One 8 x 32 slab of a kernel with the gradient in REGISTERS (the weight-gradient launch that sums a block over all rows inside one
+// workgroup, mlp.hip mlp_wgrad_local_kernel): the slab's parameters and moments are requested up front (adam_slab_prefetch, at the
+// head of the launch) and consumed when the gradient is there (adam_slab_finish: L2 + clip + Adam, the operand store's pair
+// fragments, the record of the largest |w| -- the arithmetic of adam_store_block, element for element).
+struct AdamSlab {
+  float4 w4, m4, v4, l4;
+  unsigned long long slot0, slot1;
+  long i4;
+  bool vec;      // the lane's four elements are one aligned float4 inside the kernel
+};
+__device__ __forceinline__ AdamSlab adam_slab_prefetch(const AdamArgs& a, const AdamArgs::Layer& L, const char* p_mirror, int k8, int nb, int lane) {
+  AdamSlab s;
+  const int kr = lane >> 3, c4 = lane & 7;
+  const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
+  const bool al = ((reinterpret_cast<uintptr_t>(a.w) | reinterpret_cast<uintptr_t>(a.m) | reinterpret_cast<uintptr_t>(a.v) |
+                    reinterpret_cast<uintptr_t>(a.l2coef)) & 15) == 0;
+  s.vec = al && (L.N & 3) == 0 && (L.w_off & 3) == 0 && k < L.K && c + 3 < L.N;
+  s.i4 = (L.w_off + (long)k * L.N + c) >> 2;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  s.w4 = s.m4 = s.v4 = s.l4 = z;
+  if (s.vec) {
+    s.w4 = reinterpret_cast<const float4*>(a.w)[s.i4];
+    s.m4 = reinterpret_cast<const float4*>(a.m)[s.i4];
+    s.v4 = reinterpret_cast<const float4*>(a.v)[s.i4];
+    if (a.l2coef) s.l4 = reinterpret_cast<const float4*>(a.l2coef)[s.i4];
+  }
+  const WopHeader* hdr = wop_header(const_cast<char*>(p_mirror), L.layer);
+  s.slot0 = hdr->slot[0];
+  s.slot1 = hdr->slot[1];
+  return s;
+}
+__device__ __forceinline__ float adam_slab_finish(const AdamArgs& a, const AdamArgs::Layer& L, const char* p_mirror, AdamSlab& s, const float (&g)[4],
+                                                  int k8, int nb, int lane, long step_now, _Float16* img) {
+  float reg = 0.f;
+  const float t = (float)(step_now + (a.late ? 0 : 1) + a.step_ahead);
+  const float alpha = a.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.log2_b1));
+  const long tcur = step_now + (a.late ? 0 : 1) + a.step_ahead;
+  const int K = L.K, N = L.N;
+  const int kr = lane >> 3, c4 = lane & 7;
+  const int k = 8 * k8 + kr, c = 32 * nb + 4 * c4;
+  float wv[4];
+  if (s.vec) {
+    adam_one(s.w4.x, g[0], s.m4.x, s.v4.x, s.l4.x, a, alpha, reg);
+    adam_one(s.w4.y, g[1], s.m4.y, s.v4.y, s.l4.y, a, alpha, reg);
+    adam_one(s.w4.z, g[2], s.m4.z, s.v4.z, s.l4.z, a, alpha, reg);
+    adam_one(s.w4.w, g[3], s.m4.w, s.v4.w, s.l4.w, a, alpha, reg);
+    reinterpret_cast<float4*>(a.w)[s.i4] = s.w4;
+    reinterpret_cast<float4*>(a.m)[s.i4] = s.m4;
+    reinterpret_cast<float4*>(a.v)[s.i4] = s.v4;
+    wv[0] = s.w4.x, wv[1] = s.w4.y, wv[2] = s.w4.z, wv[3] = s.w4.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float wn = 0.f;
+      if (k < K && c + i < N) {
+        const long e = L.w_off + (long)k * N + c + i;
+        float mm = a.m[e], vv = a.v[e];
+        wn = a.w[e];
+        adam_one(wn, g[i], mm, vv, a.l2coef ? a.l2coef[e] : 0.f, a, alpha, reg);
+        a.w[e] = wn;
+        a.m[e] = mm;
+        a.v[e] = vv;
+      }
+      wv[i] = wn;
+    }
+  }
+  WopHeader* hdr = wop_header(const_cast<char*>(p_mirror), L.layer);
+  WopArgs wl;          // the layer as layer 0 of a one-layer view: static indices, registers
+  wl.n_layers = 1;
+  wl.K[0] = K, wl.N[0] = N, wl.w_off[0] = L.w_off, wl.fwd_unit[0] = L.fwd_unit, wl.bwd_unit[0] = L.bwd_unit;
+  wl.units_begin = a.mir.units_begin;
+  const unsigned long long prev = (tcur & 1) ? s.slot0 : s.slot1, mine_so_far = (tcur & 1) ? s.slot1 : s.slot0;
+  float ws_, wrs_;
+  pow2_scale_bits<WOP_TOP>((unsigned)prev, ws_, wrs_);
+  const unsigned bmax = wop_write_slab(wl, const_cast<char*>(p_mirror), 0, k8, nb, wv, ws_, lane, img);
+  if (lane == 0) {
+    const unsigned long long rec = ((unsigned long long)tcur << 32) | bmax;
+    if (rec > mine_so_far) atomicMax(&hdr->slot[tcur & 1], rec);
+    if (k8 == 0 && nb == 0) hdr->rs = wrs_;
+  }
+  return reg;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 inline bool gather_vec4(const emx_next_batch* next) {
   return next && next->D % 4 == 0 && ((reinterpret_cast<uintptr_t>(next->data) | reinterpret_cast<uintptr_t>(next->xb) |

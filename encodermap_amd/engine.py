@@ -198,7 +198,7 @@ class SequentialEngine:
         self.dY = torch.zeros(B, self.net_dim, dtype=f32, device=dev)
         self.dZ = torch.zeros(B, self.L, dtype=f32, device=dev)
         self.dlat = torch.zeros(B, self.L, dtype=f32, device=dev)   # dh at the latent coming down from the decoder
-        self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.red_ws2 = torch.zeros(2 * _lib.EMX_REDUCE_WS, dtype=f32, device=dev)   # (two halves: emx_mlp_wgrad_adam_local, by step parity)
         self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         # f16 planes + norms of the batch rows for the all-pairs kernel (Euclidean data only), made beside the gather
@@ -216,8 +216,9 @@ class SequentialEngine:
         self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
         self._tiles_ran = False
         # the optimizer as the tail of the weight-gradient launch (emx_mlp_wgrad_adam): its counters, zeroed once
-        self.wg_sync = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.wg_sync = torch.zeros(4 + 256, dtype=torch.int32, device=dev)
         self._tail_ok = None
+        self._local_ok = None
         self._tail_ran = False
 
     # -- data feed -------------------------------------------------------------------------------
@@ -305,6 +306,11 @@ class SequentialEngine:
     _tail_adam = os.environ.get("EMX_TAIL_ADAM", "0") == "1"
     _tail_ran = False
     _tail_ok = None
+    # single process, batches of up to 4096 rows, small networks: the weight gradients WITHOUT slice partials -- a workgroup owns a
+    # 32 x 32 block of a kernel over all rows and updates it itself -- with the epilogue and the next batch's rows in the same launch
+    # (emx_mlp_wgrad_adam_local: the step's last TWO launches in one, nothing waits for anything)
+    _local_wgrad = os.environ.get("EMX_LOCAL_WGRAD", "1") != "0"
+    _local_ok = None
     _tiles_ran = False
 
     def _gather_current(self) -> None:
@@ -484,6 +490,15 @@ class SequentialEngine:
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         self._wgrad()
 
+    def _local_fits(self) -> bool:
+        """whether the step ends with emx_mlp_wgrad_adam_local (decided once per batch shape)"""
+        if self._local_ok is None:
+            self._local_ok = bool(self._local_wgrad and self._prefetch and type(self)._step_post is SequentialEngine._step_post
+                                  and self.red_ws2.numel() >= 2 * _lib.EMX_REDUCE_WS
+                                  and _lib.mlp_wgrad_adam_local_fits(self.plan, self.re - self.rb, self._next_batch())
+                                  and _lib.mlp_wgrad_adam_local_ws_floats(self.plan, self.re - self.rb) <= self.wg_ws.numel())
+        return self._local_ok
+
     def _tail_fits(self) -> bool:
         """whether the step's last two launches run as one (emx_mlp_wgrad_adam; decided once per batch shape)"""
         if self._tail_ok is None:
@@ -517,6 +532,12 @@ class SequentialEngine:
         if self._late_bookkeeping():
             jobs = self._jobs_pre() + [self._reg_job()]
             fin = _lib.make_finish_desc(jobs, self.terms, N_TERMS, self.history, self.term_history, self.hstep, self.cursor, self.step)
+            if self._local_fits():
+                p = self.p
+                _lib.mlp_wgrad_adam_local(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0,
+                                          self.red_ws2, self.wg_sync, next_batch=self._next_batch())
+                self._tail_ran = True
+                return
             if self._tail_fits():
                 p = self.p
                 _lib.mlp_wgrad_adam(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7,
@@ -570,6 +591,8 @@ class SequentialEngine:
         self.plan.refresh_mirror()
         if self._late_bookkeeping() or self._dp_late_bookkeeping():
             _lib.l2_partials(self.w, self.l2coef, self.red_ws2)
+            if self.red_ws2.numel() >= 2 * _lib.EMX_REDUCE_WS:      # (both halves: whichever parity the optimizer step has)
+                _lib.l2_partials(self.w, self.l2coef, self.red_ws2[_lib.EMX_REDUCE_WS:])
 
     def _step_body(self) -> None:
         self._step_pre_a()

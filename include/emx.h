@@ -469,6 +469,30 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
                        float lr, float beta1, float beta2, float eps, float clip, float* reg_ws, float* mirror,
                        const emx_next_batch* next /* may be NULL */, uint32_t* sync, emx_stream_t stream);
 
+/* Small batches: the same step tail -- weight gradients of all layers, the `finish` epilogue, L2 + clip + Adam with the operand store,
+ * the next batch's rows -- in one launch WITHOUT slice partials: a workgroup owns one 32 x 32 block of one kernel over ALL rows
+ * (its four waves a quarter of the row blocks each, summed in LDS in a fixed order) and updates those parameters itself; no
+ * workspace, no workgroup waits for another.  Deterministic; the gradient's summation order differs from emx_mlp_wgrad's, so
+ * results agree with the two launches to float32 rounding of the sums, not bit for bit.
+ *   finish: required, with hstep, cursor and counter2 (= the optimizer's step counter, read as `step`); cursor and optimizer
+ *     step are advanced by the epilogue workgroup once every other workgroup has read them.
+ *   reg_ws: 2 * EMX_REDUCE_WS floats: the regulariser shares of the weights after update t live in half (t & 1) -- the
+ *     epilogue of a launch reads the half its predecessor wrote while the launch writes the other.  A `finish` job whose
+ *     src == reg_ws sums that half.  At start-up (and whenever the weights are set from outside) fill BOTH halves
+ *     (emx_l2_partials on reg_ws and on reg_ws + EMX_REDUCE_WS).
+ *   sync: 4 + 256 uint32 zeroed once by the caller; the launch leaves [1] and [4 ..] zero again, [2] != 0: the epilogue gave up waiting.
+ *   ws: emx_mlp_wgrad_adam_local_ws_floats(desc, n_rows) floats (0 for small batches: ws may be NULL).  Batches of more than 512
+ *     rows split the rows of a block over up to four workgroups (the launch is bound by the bytes a CU can have in flight, so by
+ *     the number of CUs at work): each leaves its share in ws, the LAST to arrive adds them in the order of the parts.
+ * emx_mlp_wgrad_adam_local_fits: 1 if the launch is made for this network / batch (rows <= 4096, at most 255 blocks, a `next`
+ * whose rows allow 16-byte lanes and no ADC head), else 0 -- emx_mlp_wgrad_adam_local fails with EMX_EUNSUPPORTED then. */
+int emx_mlp_wgrad_adam_local_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next /* may be NULL */);
+size_t emx_mlp_wgrad_adam_local_ws_floats(const emx_mlp_desc* desc, int n_rows);
+int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_params, const void* aop, int aop_rows, int row_begin, int row_end,
+                             float* ws, size_t ws_floats, const emx_finish_desc* finish, float* m, float* v, const float* l2coef /* may be NULL */, float lr, float beta1,
+                             float beta2, float eps, float clip, float* reg_ws, float* mirror, const emx_next_batch* next /* may be NULL */,
+                             uint32_t* sync, emx_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------ *
  * ADC path (AngleDihedralCartesianEncoderMap): back-mapping and per-frame pair distances
  * ------------------------------------------------------------------------------------------------ */

@@ -70,8 +70,11 @@ def _oracle_step(D, p, w0, x, dtype):
     return [f(h) for h in hs], [f(a.grad) for a in pres], [f(q.grad) for q in model.params], float(total.detach())
 
 
-def dense_layer_errors(em, name, seed=0):
-    """{quantity: {"engine": (rms, max), "oracle_f32": (rms, max)}} for one step at the shape ``name``"""
+def dense_layer_errors(em, name, seed=0, local=False):
+    """{quantity: {"engine": (rms, max), "oracle_f32": (rms, max)}} for one step at the shape ``name``.
+    ``local``: the weight gradients of emx_mlp_wgrad_adam_local (summed inside the workgroups, consumed by the optimizer in the same
+    launch -- never stored): recovered from Adam's first moment after ONE step from zero moments, m = 0.1 (g + l2coef w) where the
+    clip at 1 is not reached (elements where it is are left out)."""
     from encodermap_amd import _lib
     from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
 
@@ -79,6 +82,9 @@ def dense_layer_errors(em, name, seed=0):
     rng = np.random.default_rng(seed)
     data = maker(rng)
     p = em.Parameters(n_steps=1, **kw)
+    if local:      # every cost scaled down: the gradients -- whose relative error is what is measured -- stay below Adam's clip at 1
+        p = em.Parameters(n_steps=1, **dict(kw, distance_cost_scale=p.distance_cost_scale * 1e-4, auto_cost_scale=p.auto_cost_scale * 1e-4,
+                                            center_cost_scale=p.center_cost_scale * 1e-4, l2_reg_constant=p.l2_reg_constant * 1e-4))
     D = data.shape[1]
     net_dim = 2 * D if p.periodicity < INF else D
     lay = build_layout(p.n_neurons, p.activation_functions, net_dim)
@@ -87,18 +93,31 @@ def dense_layer_errors(em, name, seed=0):
     idx = rng.integers(0, data.shape[0], B)
     e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True, use_graph=False)
     eng = e._engine
-    # the step up to the weight gradients (no optimizer), as run_steps would enqueue it
-    eng.idx_block = torch.zeros(eng._block_capacity() * B, dtype=torch.int64, device=eng.device)
-    eng.idx_block[:B].copy_(torch.from_numpy(idx).to(eng.device))
-    eng.cursor.zero_()
-    eng._gather_current()
-    eng._step_pre()
-    torch.cuda.synchronize()
-    n_sl = _lib.mlp_wgrad_slices(B)
-    g = eng.wg_ws.view(n_sl, -1).double().sum(0).cpu().numpy()
+    if local:
+        w_before = eng.w.double().cpu().numpy()
+        eng.run_steps(1, torch.from_numpy(idx).to(eng.device))
+        torch.cuda.synchronize()
+        assert eng._local_ok and eng._tail_ran, "emx_mlp_wgrad_adam_local is not made for this shape"
+        gt = eng.m.double().cpu().numpy() / (1.0 - 0.9)
+        l2c = eng.l2coef.double().cpu().numpy() if eng.l2coef is not None else 0.0
+        g = gt - l2c * w_before
+        unclipped = np.abs(gt) < 0.999
+    else:
+        # the step up to the weight gradients (no optimizer), as run_steps would enqueue it with the two-launch tail
+        eng._local_ok = eng._tail_ok = False
+        eng.idx_block = torch.zeros(eng._block_capacity() * B, dtype=torch.int64, device=eng.device)
+        eng.idx_block[:B].copy_(torch.from_numpy(idx).to(eng.device))
+        eng.cursor.zero_()
+        eng._gather_current()
+        eng._step_pre()
+        torch.cuda.synchronize()
+        n_sl = _lib.mlp_wgrad_slices(B)
+        g = eng.wg_ws[: n_sl * eng.w.numel()].view(n_sl, -1).double().sum(0).cpu().numpy()
+        unclipped = np.ones(g.shape, bool)
     e_h = [t.cpu().numpy() for t in eng.h]
     e_d = [t.cpu().numpy() for t in eng.delta]
     e_g = unpack_weights(eng.layout, g)
+    keep = unpack_weights(eng.layout, unclipped.astype(np.float64))
     x = data[idx]
     h64, d64, g64, _ = _oracle_step(D, p, w0, x, torch.float64)
     h32, d32, g32, _ = _oracle_step(D, p, w0, x, torch.float32)
@@ -110,8 +129,10 @@ def dense_layer_errors(em, name, seed=0):
         # (the periodic model's last delta is d loss / d output of the last Dense layer, in front of the atan2: both sides)
         out[f"delta[{l}] {d64[l].shape[1]}"] = {"engine": err(e_d[l], d64[l]), "oracle_f32": err(d32[l], d64[l])}
     for l in range(nl):
-        out[f"dW[{l}] {g64[2 * l].shape[0]}x{g64[2 * l].shape[1]}"] = {"engine": err(e_g[2 * l], g64[2 * l]), "oracle_f32": err(g32[2 * l], g64[2 * l])}
-        out[f"db[{l}]"] = {"engine": err(e_g[2 * l + 1], g64[2 * l + 1]), "oracle_f32": err(g32[2 * l + 1], g64[2 * l + 1])}
+        for i, nm in ((2 * l, f"dW[{l}] {g64[2 * l].shape[0]}x{g64[2 * l].shape[1]}"), (2 * l + 1, f"db[{l}]")):
+            k = keep[i] > 0.5
+            assert k.mean() > 0.9, "most gradient elements should be below Adam's clip"
+            out[nm] = {"engine": err(np.where(k, e_g[i], g64[i]), g64[i]), "oracle_f32": err(np.where(k, g32[i], g64[i]), g64[i])}
     return out
 
 

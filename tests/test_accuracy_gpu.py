@@ -36,6 +36,15 @@ def test_dense_layers_are_float32_accurate(em, name):
     _check(table, factor=2.5 if name.startswith("C4") else 2.0)
 
 
+@pytest.mark.parametrize("name", [n for n in A.SHAPES if not n.startswith("C4")])
+def test_weight_gradients_summed_inside_the_workgroups_are_float32_accurate(em, name):
+    """the same bound for the weight gradients of emx_mlp_wgrad_adam_local (small batches: no slice partials), read back from Adam's
+    first moment after one step"""
+    table = {k: v for k, v in A.dense_layer_errors(em, name, local=True).items() if k.startswith("d")}
+    print(A.format_table(name + " -- gradients of the one-launch step tail", table))
+    _check(table, floor=4e-7)      # (m = 0.1 g and g = 10 m: two more roundings than the stored gradient)
+
+
 @pytest.mark.parametrize("B,D", [(4096, 128), (1024, 256)])
 def test_all_pairs_pass_is_float32_accurate_far_from_the_origin(em, B, D):
     table = A.all_pairs_errors(B, D)

@@ -283,6 +283,7 @@ def test_optimizer_as_the_tail_of_the_weight_gradient_launch_changes_nothing(em,
         data = blobs(rng, 6000, D)
     idx = rng.integers(0, 6000, (steps, B))
     out, ran = [], []
+    monkeypatch.setattr(SequentialEngine, "_local_wgrad", False)      # (the engine's default for these shapes: its own test below)
     for tail in (True, False):
         monkeypatch.setattr(SequentialEngine, "_tail_adam", tail)
         kw = dict(n_neurons=neurons, activation_functions=[""] + ["tanh"] * (len(neurons) - 1) + [""]) if neurons else {}
@@ -302,6 +303,58 @@ def test_optimizer_as_the_tail_of_the_weight_gradient_launch_changes_nothing(em,
     for a, b in zip(out[0], out[1]):
         np.testing.assert_array_equal(a, b)
     assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
+
+
+LOCAL_CASES = [
+    # B, D, steps, periodicity, n_neurons
+    (4096, 128, 12, INF, None), (1000, 128, 12, INF, None), (640, 32, 12, INF, None), (256, 10, 12, 2 * math.pi, None), (100, 33, 12, 2 * math.pi, None),
+    (512, 64, 12, INF, [300, 40, 2]), (48, 8, 12, INF, [20, 3]), (16, 4, 6, INF, None), (2048, 100, 8, INF, [128, 128, 128, 2]),
+]
+
+
+@pytest.mark.parametrize("B,D,steps,periodicity,neurons", LOCAL_CASES)
+def test_weight_gradients_without_slice_partials(em, B, D, steps, periodicity, neurons, monkeypatch):
+    """emx_mlp_wgrad_adam_local (a workgroup per 32 x 32 block of a kernel over all rows, the optimizer in the same workgroup, the
+    epilogue and the next batch's rows in the same launch) against emx_mlp_wgrad + emx_adam_step_slices: the gradient is summed in
+    another order, so the runs agree to float32 rounding -- weights after ONE step to 2e-6 (relative to the update), the loss
+    trajectory and every term to 2e-4 -- while everything that does not pass through the sums is identical: the rows gathered for
+    the next step, the counters; and the launch is deterministic (two runs bit for bit)."""
+    from encodermap_amd.engine import SequentialEngine
+
+    rng = np.random.default_rng(B + D)
+    data = rng.uniform(-math.pi, math.pi, (6000, D)).astype(np.float32) if periodicity < INF else blobs(rng, 6000, D)
+    idx = rng.integers(0, 6000, (steps, B))
+    kw = dict(n_neurons=neurons, activation_functions=[""] + ["tanh"] * (len(neurons) - 1) + [""]) if neurons else {}
+
+    def run(local, n):
+        monkeypatch.setattr(SequentialEngine, "_local_wgrad", local)
+        p = em.Parameters(periodicity=periodicity, batch_size=B, dist_sig_parameters=(math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps, **kw)
+        e = em.EncoderMap(p, data, read_only=True, model=_weights(p, 2 * D if periodicity < INF else D))
+        eng = e._engine
+        w0 = eng.w.cpu().numpy().copy()
+        eng.run_steps(n, torch.from_numpy(idx[:n].reshape(-1)).cuda())
+        loss = eng.losses()
+        assert eng._tail_ran == local and (eng.wg_sync.cpu().numpy() == 0).all()
+        return dict(loss=loss, w=eng.w.cpu().numpy(), w0=w0, m=eng.m.cpu().numpy(), v=eng.v.cpu().numpy(), xb=eng.xb.cpu().numpy(), xin=eng.xin.cpu().numpy(),
+                    counters=np.array([int(eng.step), int(eng.cursor), int(eng.hstep)]), terms=eng.loss_terms(), store=eng.plan.mirror.cpu().numpy())
+
+    a1, b1 = run(True, 1), run(False, 1)
+    upd = np.abs(b1["w"] - b1["w0"]).max()
+    assert upd > 0
+    assert np.abs(a1["w"] - b1["w"]).max() <= 2e-3 * upd          # (Adam's first step is lr * g / (|g| + eps): a rounding of g moves it by ~1e-7 / |g|)
+    np.testing.assert_allclose(a1["m"], b1["m"], rtol=2e-5, atol=1e-9 + 5e-6 * np.abs(b1["m"]).max())     # (m = 0.1 clip(g): a sum of B products, rounded in another order)
+    np.testing.assert_array_equal(a1["counters"], b1["counters"])
+    np.testing.assert_array_equal(a1["loss"], b1["loss"])        # (the first step's cost does not see the optimizer)
+    a, b, a2 = run(True, steps), run(False, steps), run(True, steps)
+    for k in ("loss", "w", "m", "v", "xb", "xin", "store"):
+        np.testing.assert_array_equal(a[k], a2[k])                 # deterministic
+    np.testing.assert_array_equal(a["counters"], b["counters"])
+    np.testing.assert_array_equal(a["xb"], b["xb"])
+    np.testing.assert_array_equal(a["xin"], b["xin"])
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=2e-4)
+    for k in a["terms"]:
+        np.testing.assert_allclose(a["terms"][k], b["terms"][k], rtol=2e-4, atol=1e-6)
+    assert np.isfinite(a["loss"]).all() and a["loss"][-1] < a["loss"][0]
 
 
 def test_short_calls_equal_one_long_call(em):

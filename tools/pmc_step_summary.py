@@ -16,7 +16,9 @@ def short(n):
 LABEL = {"chain_kernel<2, 2>": "chain_kernel<FUSED> (forward + cost + decoder backward)", "chain_kernel_c128<2, 2>": "chain_kernel<FUSED> (128-register build)",
          "chain_kernel<1, 2>": "chain_kernel<BWD> (encoder backward)", "chain_kernel_c128<1, 2>": "chain_kernel<BWD> (128-register build)",
          "chain_kernel<0, 2>": "chain_kernel<FWD>", "chain_kernel_c128<0, 2>": "chain_kernel<FWD> (128-register build)",
-         "mlp_wgrad_kernel": "mlp_wgrad_kernel (+ scalar epilogue)", "adam_kernel<false>": "adam_kernel (+ next batch)", "adam_kernel<true>": "adam_kernel (+ next ADC head)"}
+         "mlp_wgrad_kernel": "mlp_wgrad_kernel (+ scalar epilogue)", "adam_kernel<false>": "adam_kernel (+ next batch)", "adam_kernel<true>": "adam_kernel (+ next ADC head)",
+         "mlp_wgrad_local_kernel": "mlp_wgrad_local_kernel (weight gradients + optimizer + scalar epilogue + next batch)",
+         "mlp_wgrad_adam_kernel": "mlp_wgrad_adam_kernel (weight gradients, optimizer as their tail)"}
 vals = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(root + "/*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
