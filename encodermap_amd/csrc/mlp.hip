@@ -1415,7 +1415,8 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   // fabric four times: 72 MB at B = 4096, which bound the launch).  Indices outside every run: nothing to do.
   // (with the rows of a block split over `splits` workgroups: part = bx / n_slots of them takes slot bx % n_slots)
   const int part = bx >= n_slots ? bx / n_slots : 0, bs = bx - part * n_slots;
-  const int v = per_xcd > 0 ? (bs & 7) * per_xcd + (bs >> 3) : bs;
+  // (XCD-aware placement: part p of a kernel's blocks goes 4 p XCDs further, so that the parts do not crowd one XCD)
+  const int v = per_xcd > 0 ? (((bs & 7) + 8 - ((4 * part) & 7)) & 7) * per_xcd + (bs >> 3) : bs;
   int li = 0, tbase = (int)(tbw[0] & 0xffffu);
 #pragma unroll
   for (int i = 1; i < MAXL; ++i) {
