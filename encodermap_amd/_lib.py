@@ -650,7 +650,7 @@ def mlp_wgrad_adam_local(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishD
     EMX_REDUCE_WS floats (the regulariser shares by the parity of the optimizer step)."""
     if plan.aop is None:
         raise EmxError("mlp_wgrad_adam_local: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
-    assert sync.dtype == torch.int32 and sync.numel() >= 4 + 256 and reg_ws.numel() >= 2 * EMX_REDUCE_WS
+    assert sync.dtype == torch.int32 and sync.numel() >= 4 + 1024 and reg_ws.numel() >= 2 * EMX_REDUCE_WS
     nb = C.byref(next_batch) if next_batch is not None else None
     _check(load().emx_mlp_wgrad_adam_local(C.byref(plan.desc), _ptr(plan.params), plan.n_params, plan.aop.data_ptr(), plan.aop_rows, int(row_begin),
                                            int(row_end), _ptr(ws), ws.numel() if ws is not None else 0, C.byref(finish), _ptr(m), _ptr(v), _ptr(l2coef), float(lr), float(beta1), float(beta2),

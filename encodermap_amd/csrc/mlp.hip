@@ -1329,7 +1329,8 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
 //   the only one that waits, at its end -- advances them when all have counted, and clears sync[1].  Regulariser shares: the
 //   epilogue reads the half of ws the previous launch wrote (parity of the optimizer step), this launch writes the other.
 //   The matrix work of a wave grows with the batch (4096 rows: 192 instructions, ~5 us): the host takes this path for batches
-//   of up to EMX_WGRAD_LOCAL_MAX_ROWS rows and networks of up to 255 blocks (emx_mlp_wgrad_adam_local_fits).
+//   of up to EMX_WGRAD_LOCAL_MAX_ROWS (4096) rows and networks of up to 1000 blocks (emx_mlp_wgrad_adam_local_fits;
+//   tools/time_local_sweep.py: -0.2 .. -13 us per step against the two launches up to 4096 rows, a tie or a small loss beyond).
 // ---------------------------------------------------------------------------------------------------------
 struct WlTail {
   unsigned* sync;
@@ -2352,7 +2353,7 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
 // 32 x 32 blocks of all kernels; 0 if the launch is not made for this network / batch
 static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* blocks_out, int* gather_out, int* splits_out) {
   static const int max_rows = getenv("EMX_WGRAD_LOCAL_MAX_ROWS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_ROWS")) : 4096;
-  static const int max_blocks = getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS")) : 255;
+  static const int max_blocks = getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS")) : 1000;
   if (n_rows > max_rows) return 0;
   int blocks = 0;
   for (int l = 0; l < desc->n_layers; ++l) blocks += ((desc->width[l] + 31) / 32) * ((desc->width[l + 1] + 31) / 32);

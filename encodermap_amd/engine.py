@@ -216,7 +216,7 @@ class SequentialEngine:
         self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
         self._tiles_ran = False
         # the optimizer as the tail of the weight-gradient launch (emx_mlp_wgrad_adam): its counters, zeroed once
-        self.wg_sync = torch.zeros(4 + 256, dtype=torch.int32, device=dev)
+        self.wg_sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
         self._tail_ok = None
         self._local_ok = None
         self._tail_ran = False
@@ -306,7 +306,7 @@ class SequentialEngine:
     _tail_adam = os.environ.get("EMX_TAIL_ADAM", "0") == "1"
     _tail_ran = False
     _tail_ok = None
-    # single process, batches of up to 4096 rows, small networks: the weight gradients WITHOUT slice partials -- a workgroup owns a
+    # single process, batches of up to 4096 rows, networks of up to 1000 blocks of 32 x 32: the weight gradients WITHOUT slice partials -- a workgroup owns a
     # 32 x 32 block of a kernel over all rows and updates it itself -- with the epilogue and the next batch's rows in the same launch
     # (emx_mlp_wgrad_adam_local: the step's last TWO launches in one, nothing waits for anything)
     _local_wgrad = os.environ.get("EMX_LOCAL_WGRAD", "1") != "0"

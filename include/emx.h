@@ -480,11 +480,11 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
  *     epilogue of a launch reads the half its predecessor wrote while the launch writes the other.  A `finish` job whose
  *     src == reg_ws sums that half.  At start-up (and whenever the weights are set from outside) fill BOTH halves
  *     (emx_l2_partials on reg_ws and on reg_ws + EMX_REDUCE_WS).
- *   sync: 4 + 256 uint32 zeroed once by the caller; the launch leaves [1] and [4 ..] zero again, [2] != 0: the epilogue gave up waiting.
+ *   sync: 4 + 1024 uint32 zeroed once by the caller; the launch leaves [1] and [4 ..] zero again, [2] != 0: the epilogue gave up waiting.
  *   ws: emx_mlp_wgrad_adam_local_ws_floats(desc, n_rows) floats (0 for small batches: ws may be NULL).  Batches of more than 512
  *     rows split the rows of a block over up to four workgroups (the launch is bound by the bytes a CU can have in flight, so by
  *     the number of CUs at work): each leaves its share in ws, the LAST to arrive adds them in the order of the parts.
- * emx_mlp_wgrad_adam_local_fits: 1 if the launch is made for this network / batch (rows <= 4096, at most 255 blocks, a `next`
+ * emx_mlp_wgrad_adam_local_fits: 1 if the launch is made for this network / batch (rows <= 4096, at most 1000 blocks of 32 x 32 over all kernels, a `next`
  * whose rows allow 16-byte lanes and no ADC head), else 0 -- emx_mlp_wgrad_adam_local fails with EMX_EUNSUPPORTED then. */
 int emx_mlp_wgrad_adam_local_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next /* may be NULL */);
 size_t emx_mlp_wgrad_adam_local_ws_floats(const emx_mlp_desc* desc, int n_rows);

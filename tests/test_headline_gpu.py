@@ -309,6 +309,7 @@ LOCAL_CASES = [
     # B, D, steps, periodicity, n_neurons
     (4096, 128, 12, INF, None), (1000, 128, 12, INF, None), (640, 32, 12, INF, None), (256, 10, 12, 2 * math.pi, None), (100, 33, 12, 2 * math.pi, None),
     (512, 64, 12, INF, [300, 40, 2]), (48, 8, 12, INF, [20, 3]), (16, 4, 6, INF, None), (2048, 100, 8, INF, [128, 128, 128, 2]),
+    (512, 256, 8, INF, [256, 256, 2]),      # 272 blocks: more workgroups than CUs
 ]
 
 
