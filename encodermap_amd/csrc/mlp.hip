@@ -1417,7 +1417,11 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   // (with the rows of a block split over `splits` workgroups: part = bx / n_slots of them takes slot bx % n_slots)
   const int part = bx >= n_slots ? bx / n_slots : 0, bs = bx - part * n_slots;
   // (XCD-aware placement: part p of a kernel's blocks goes 4 p XCDs further, so that the parts do not crowd one XCD)
-  const int v = per_xcd > 0 ? (((bs & 7) + 8 - ((4 * part) & 7)) & 7) * per_xcd + (bs >> 3) : bs;
+  // (per_xcd < 0: groups of G = -per_xcd consecutive blocks -- which share a fragment -- on one XCD, the groups dealt evenly:
+  //  workgroups x, x + 8, .., x + 8 (G - 1) are one XCD's)
+  const int G = -per_xcd;
+  const int v = per_xcd > 0 ? (((bs & 7) + 8 - ((4 * part) & 7)) & 7) * per_xcd + (bs >> 3)
+              : per_xcd < 0 ? G * ((bs / (8 * G)) * 8 + (bs & 7)) + ((bs >> 3) % G) : bs;
   int li = 0, tbase = (int)(tbw[0] & 0xffffu);
 #pragma unroll
   for (int i = 1; i < MAXL; ++i) {
@@ -2436,17 +2440,20 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   // virtual indices: per_xcd slots per XCD (at most the 32 CUs of one), a kernel's blocks in one run, aligned so that a run of up
   // to per_xcd blocks lies inside one XCD
   auto pow2ceil = [](int x) { int p = 1; while (p < x) p *= 2; return p; };
-  // (EMX_WGRAD_LOCAL_XCD=1: an experiment -- measured no faster at B = 4096 without splits, slower with them, where the parts of a
-  //  kernel's blocks then crowd one XCD; default: blocks in layer order, workgroup = block)
-  static const int xcd_aware = getenv("EMX_WGRAD_LOCAL_XCD") ? atoi(getenv("EMX_WGRAD_LOCAL_XCD")) : 0;
+  // EMX_WGRAD_LOCAL_XCD: 0 blocks in layer order, workgroup = block; 2 / 4 (default 4): groups of that many consecutive blocks --
+  // one row of a 128-wide kernel's blocks, which read the same in-feature fragments -- on one XCD, the groups dealt evenly over the
+  // XCDs (C2: 0.0717 -> 0.0713 ms per step; pairs 0.0722); 1: a whole kernel's blocks on one XCD -- half the HBM traffic and a
+  // LONGER launch (profiles/r03_tail_adam_ab.txt)
+  static const int xcd_aware = getenv("EMX_WGRAD_LOCAL_XCD") ? atoi(getenv("EMX_WGRAD_LOCAL_XCD")) : 4;
   int per_xcd = std::min(32, std::max((blocks + 7) / 8, pow2ceil(largest)));
   int n_slots = 0;
-  if (!xcd_aware) {
-    per_xcd = 0;
-    n_slots = blocks;
+  if (xcd_aware != 1) {
+    const int G = (xcd_aware == 2 || xcd_aware == 4) ? xcd_aware : 0;
+    per_xcd = -G;
+    n_slots = G ? (blocks + 8 * G - 1) / (8 * G) * (8 * G) : blocks;
     for (int l = 0; l < n; ++l) begin[l] = a.t.block_begin[l];
   }
-  for (; xcd_aware; per_xcd = std::min(per_xcd * 2, 1 << 14)) {
+  for (; xcd_aware == 1; per_xcd = std::min(per_xcd * 2, 1 << 14)) {
     int pos = 0;
     for (int l = 0; l < n; ++l) {
       const int al = xcd_aware ? std::min(per_xcd, pow2ceil(nblk[l])) : 1;
