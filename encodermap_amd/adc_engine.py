@@ -118,7 +118,10 @@ class ADCEngine(SequentialEngine):
         self.delta = [z(B, l.n_out) for l in lay.layers]
         self.dY = z(B, self.net_dim)
         self.dZ, self.dZ2 = z(B, self.L), z(B, self.L)
-        self.red_ws2 = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
+        self.red_ws2 = torch.zeros(2 * _lib.EMX_REDUCE_WS, dtype=f32, device=dev)   # (two halves: emx_mlp_wgrad_adam_local, by step parity)
+        self.wg_sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
+        self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
+        self._local_ok = self._tail_ok = None
         # batch means of the whole feature block in ONE launch: the mean bond lengths (BackMapLayer, layers.py:971) and -- without
         # backbone angles in the model -- the mean angles (MeanAngles, layers.py:1153-1161) are views into it
         self.feat_mean = z(self.F)

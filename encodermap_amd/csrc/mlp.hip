@@ -33,6 +33,7 @@
 // Lane maps (cdna_hip_programming.md section 3; checked with integer data by tests/test_mlp_gpu.py):
 //   16x16x32: A[m = lane & 15][k = 8 (lane >> 4) + e], B[k][n = lane & 15], D[row = 4 (lane >> 4) + reg][col = lane & 15];
 //   the k labels inside a K-step are free as long as A and B agree -- here kk(g, e) = 4 g + e (e < 4), 16 + 4 g + e - 4.
+#include "adc_head.h"
 #include "aop.h"
 #include "cost.h"
 #include "emx_common.h"
@@ -1365,6 +1366,8 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   __shared__ float red[NTL / 64][32][33];
   __shared__ float bred[NTL / 64][32];
   __shared__ float rreg[4];
+  __shared__ float cm_part[emx::ADC_CM_PH][32];
+  static_assert(emx::ADC_CM_PH * 32 == NTL, "the batch means: 32 columns x 16 row phases per workgroup");
   __shared__ unsigned ticket;
   typedef const char __attribute__((address_space(4))) * KBytes;
   const KBytes kseg = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64;   // (64: the explicit scalars)
@@ -1398,8 +1401,26 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
       TSTAMP(1000, 2);
     } else {
       TSTAMP(512 + e - 1, 0);
-      if (a.ad.next_vec4) gather_rows2_multi<4>(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);
-      else gather_rows_body(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);   // (rows without 16-byte lanes)
+      if (a.ad.next.adc_head != nullptr) {
+        // the head of the next ADC step (emx_next_batch::adc_head; adc_head.h): two virtual workgroups of 256 threads for the rows per
+        // workgroup, then workgroups of 32 columns x 16 row phases for the batch means
+        const emx::AdcHeadArgs& h = *a.ad.next.adc_head;
+        const long batch = *a.ad.next.cursor + a.ad.next.batch_step;
+        if (!(h.n_batches > 0 && batch >= h.n_batches)) {
+          const int64_t* __restrict__ idx = a.ad.next.idx + batch * (long)a.ad.next.B;
+          const int row_wgs = (h.row_blocks + 1) >> 1;
+          if (e - 1 < row_wgs) {
+            const int vb = 2 * (e - 1) + (tid >> 8);
+            if (vb < h.row_blocks) emx::adc_head_rows(h, idx, vb, h.row_blocks, tid & 255, a.ad.next.batch_step);
+          } else if (h.feat_mean != nullptr) {
+            emx::adc_head_means<32>(h, idx, (e - 1 - row_wgs) * 32, tid, cm_part);
+          }
+        }
+      } else if (a.ad.next_vec4) {
+        gather_rows2_multi<4>(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);
+      } else {
+        gather_rows_body(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);   // (rows without 16-byte lanes)
+      }
       TSTAMP(512 + e - 1, 1);
       __syncthreads();   // (every wave has its cursor: the loads that use it are issued)
       if (tid == 0) __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2364,8 +2385,8 @@ static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_nex
   if (blocks > std::min(max_blocks, (int)EMX_REDUCE_WS)) return 0;
   int gather = 0;
   if (next) {
-    if (next->adc_head) return 0;
-    if (gather_vec4(next)) gather = (next->B + 2 * 4 * (NTL / 64) - 1) / (2 * 4 * (NTL / 64));   // four row pairs per wave, one pass
+    if (next->adc_head) gather = (std::min(next->B, 2048) + 1) / 2 + (next->D + 31) / 32;   // (as emx_adam_step: row workgroups, then the means of D columns)
+    else if (gather_vec4(next)) gather = (next->B + 2 * 4 * (NTL / 64) - 1) / (2 * 4 * (NTL / 64));   // four row pairs per wave, one pass
     else gather = std::min((next->B + NTL / 64 - 1) / (NTL / 64), 512);                            // a row per wave and pass
   }
   // the rows of a block over several workgroups: what bounds the launch is the bytes in flight, i.e. the number of CUs at work --

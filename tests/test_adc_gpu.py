@@ -256,3 +256,43 @@ def test_adc_soft_start_with_and_without_folded_bookkeeping(em, fold, monkeypatc
     cart = np.array([t["cartesian"] for t in want_terms])
     assert cart[0] == 0 and cart[1] == 0 and cart[2] > 0 and cart[3] > cart[2]     # the ramp starts inside the run
     np.testing.assert_allclose(terms["cartesian"], cart, rtol=5e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("case", [1, 2])
+def test_adc_step_tail_in_one_launch(em, case, monkeypatch):
+    """The ADC step with its last two launches as one (emx_mlp_wgrad_adam_local: weight gradients without slice partials, optimizer,
+    scalar epilogue -- and the HEAD of the next ADC step on the launch's spare workgroups, soft-start scale included) against the two
+    launches: the head's outputs for the step after the last are the same bits (the same device functions on the same rows), the
+    counters agree, the loss trajectories agree to float32 rounding of the gradient sums, and the one launch is deterministic."""
+    from encodermap_amd.engine import SequentialEngine
+
+    name, kw, n_res, n_side, B = CASES[case]
+    kw = dict(kw, cartesian_cost_scale_soft_start=(2, 7), cartesian_cost_scale=3.0)
+    rng = np.random.default_rng(23)
+    data = R.synthetic_backbone(rng, 700, n_res, n_side)
+    n_steps = 9
+    idx = rng.integers(0, 700, (n_steps, B))
+
+    def run(local):
+        monkeypatch.setattr(SequentialEngine, "_local_wgrad", local)
+        p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
+        e = em.AngleDihedralCartesianEncoderMap(data, p, read_only=True)
+        eng = e._engine
+        torch.manual_seed(3)
+        eng.w.copy_(torch.randn_like(eng.w) * 0.05)
+        eng._sync_derived_state()
+        eng.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+        loss = eng.losses()
+        assert eng._tail_ran == local
+        return dict(loss=loss, feat=eng.feat.cpu().numpy(), cart=eng.cart.cpu().numpy(), xin=eng.xin.cpu().numpy(), scale=eng.cart_scale.cpu().numpy(),
+                    mean=eng.feat_mean.cpu().numpy(), counters=np.array([int(eng.step), int(eng.cursor), int(eng.hstep)]), w=eng.w.cpu().numpy(),
+                    sync=eng.wg_sync.cpu().numpy())
+
+    a, b, a2 = run(True), run(False), run(True)
+    for k in ("feat", "cart", "xin", "scale", "mean", "counters"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    for k in ("loss", "w", "feat", "xin"):
+        np.testing.assert_array_equal(a[k], a2[k], err_msg=k)
+    assert (a["sync"] == 0).all()
+    np.testing.assert_allclose(a["loss"], b["loss"], rtol=3e-4)
+    assert np.isfinite(a["loss"]).all()
