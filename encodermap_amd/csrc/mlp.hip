@@ -1319,13 +1319,16 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
 
 // ---------------------------------------------------------------------------------------------------------
 // Small batches: weight gradients WITHOUT slice partials, the optimizer in the same workgroup (emx_mlp_wgrad_adam_local).
-//   One workgroup owns one 32 x 32 block of one kernel (and, for the blocks of the first 32 in-features, 32 biases) over ALL
-//   rows of the batch: its four waves take a quarter of the row blocks each (v_mfma_f32_32x32x16_f16 on the fragments of aop.h,
-//   two accumulators in turn, groups of four row blocks on a common scale as in mlp_wgrad_kernel), add their quarters in LDS in a
-//   fixed order, and each wave then runs L2 + clip + Adam and the operand-store rewrite for one 8 x 32 slab of the block -- whose
-//   parameters and moments it requested at the head of the launch.  No partials leave the CU (emx_mlp_wgrad writes and re-reads
-//   slices x parameters floats: 8.4 MB at B = 4096), no workgroup waits for another, and a step ends with this launch: spare
-//   workgroups run the scalar epilogue and gather the next batch's rows.
+//   One workgroup of EIGHT waves owns one 32 x 32 block of one kernel (and, for the blocks of the first 32 in-features, 32 biases)
+//   over ALL rows of the batch: each wave takes an eighth of the row blocks (v_mfma_f32_32x32x16_f16 on the fragments of aop.h, two
+//   accumulators in turn, groups of four row blocks on a common scale as in mlp_wgrad_kernel, two groups in flight, every request
+//   unconditional), the waves add their shares in LDS in a fixed order, and the first four then run L2 + clip + Adam and the
+//   operand-store rewrite for one 8 x 32 slab of the block each -- whose parameters and moments they requested at the head of the
+//   launch.  No partials of slices x parameters floats (emx_mlp_wgrad writes and re-reads 8.4 MB at B = 4096), no workgroup waits
+//   for another, and a step ends with this launch: spare workgroups run the scalar epilogue and gather the next batch's rows (or
+//   run the head of the next ADC step).  From 1024 rows on, two workgroups share the rows of a block (what bounds the launch is the
+//   bytes the CUs at work have in flight): each leaves its share of the block in `shares` (sc1), takes a ticket, and the LAST one
+//   adds the shares in the order of the parts -- whoever it is, the same bits.
 //   Counters: every workgroup reads the optimizer step / the batch cursor and then counts in sync[1]; the epilogue workgroup --
 //   the only one that waits, at its end -- advances them when all have counted, and clears sync[1].  Regulariser shares: the
 //   epilogue reads the half of ws the previous launch wrote (parity of the optimizer step), this launch writes the other.
@@ -1431,10 +1434,10 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   TSTAMP(bx, 0);
   const long step_now = *p_step;
   const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
-  // Slot -> XCD: workgroups go to the XCDs in turn, so slot s of XCD x is workgroup 8 s + x; the host gives every kernel a run of
-  // virtual indices v = per_xcd x + s inside as few XCDs as it can: the blocks of a kernel read the same fragments, and each
-  // XCD fetches what its workgroups read through its own L2 (with the blocks dealt round-robin every fragment crossed the
-  // fabric four times: 72 MB at B = 4096, which bound the launch).  Indices outside every run: nothing to do.
+  // Workgroup -> block.  Workgroups go to the XCDs in turn (workgroup x, x + 8, .. are XCD x's): by default groups of four
+  // consecutive blocks -- which read the same in-feature fragments -- share an XCD (per_xcd = -4); per_xcd > 0 is the experiment
+  // that gives every kernel a run of virtual indices inside as few XCDs as possible (half the HBM traffic, a longer launch:
+  // profiles/r03_tail_adam_ab.txt); per_xcd = 0: workgroup = block.  Indices outside every kernel's run: nothing to do.
   // (with the rows of a block split over `splits` workgroups: part = bx / n_slots of them takes slot bx % n_slots)
   const int part = bx >= n_slots ? bx / n_slots : 0, bs = bx - part * n_slots;
   // (XCD-aware placement: part p of a kernel's blocks goes 4 p XCDs further, so that the parts do not crowd one XCD)
