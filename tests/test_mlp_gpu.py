@@ -464,3 +464,80 @@ def test_integer_data_is_exact(L, net_dim, n_neurons, B):
         assert np.abs(dW).max() < 2 ** 24
         assert np.array_equal(gh[l.w_off: l.w_off + l.n_in * l.n_out].reshape(l.n_in, l.n_out), dW), f"dW {i}"
         assert np.array_equal(gh[l.b_off: l.b_off + l.n_out], deltas[i].sum(0)), f"db {i}"
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("net_dim,n_neurons,afs,B", [CASES[i] for i in (0, 1, 2, 4, 5, 7, 8)] + [(128, [128, 128, 2], ["", "tanh", "tanh", ""], 1500)])
+def test_wgrad_adam_local_through_the_abi(L, net_dim, n_neurons, afs, B):
+    """emx_mlp_wgrad_adam_local called as a C consumer would (no engine): against emx_mlp_wgrad + emx_adam_step_slices(bookkeeping_done)
+    on the same fragments -- new weights to 3e-3 of the update (Adam's first step is lr g / (|g| + eps): a rounding of g moves it),
+    first moments to 5e-6 of their largest element, the operand store decodes to the new weights, the epilogue's sums and counters,
+    the regulariser shares of the NEW weights in the half of ws the parity names, the next batch's rows bit for bit, sync left clean."""
+    from encodermap_amd.layout import build_layout, init_parameters, l2_coefficients
+
+    rng = np.random.default_rng(net_dim * 7 + B)
+    lay = build_layout(n_neurons, afs, net_dim)
+    flat = init_parameters(lay, 2)
+    n = len(lay.layers)
+    dev = "cuda"
+    N = 3 * B
+    data = torch.from_numpy(rng.normal(0, 1, (N, net_dim)).astype(np.float32)).to(dev)
+    idx = torch.from_numpy(rng.integers(0, N, 3 * B)).to(dev)
+    dtop = torch.from_numpy((rng.normal(0, 1, (B, net_dim)) * 0.05).astype(np.float32)).to(dev)
+    l2c = torch.from_numpy(l2_coefficients(lay, 0.001)).to(dev)
+    assert L.mlp_wgrad_adam_local_fits(L.MlpPlan(lay, torch.from_numpy(flat).to(dev), [torch.zeros(B, l.n_out, device=dev) for l in lay.layers],
+                                                 [torch.zeros(B, l.n_out, device=dev) for l in lay.layers], train_rows=B), B)
+    out = []
+    for local in (False, True):
+        params = torch.from_numpy(flat).to(dev)
+        h = [torch.zeros(B, l.n_out, device=dev) for l in lay.layers]
+        delta = [torch.zeros(B, l.n_out, device=dev) for l in lay.layers]
+        plan = L.MlpPlan(lay, params, h, delta, train_rows=B)
+        xb = data[idx[:B]].contiguous()
+        L.mlp_forward(plan, 0, n, xb, 0, B)
+        L.mlp_backward(plan, 0, n, dtop, None, lay.n_enc - 1, 0, B)
+        m, v = torch.zeros_like(params), torch.zeros_like(params)
+        step = torch.tensor([4], dtype=torch.int64, device=dev)            # (an even number of updates so far: parity 0)
+        cursor, hstep = torch.tensor([0], dtype=torch.int64, device=dev), torch.tensor([4], dtype=torch.int64, device=dev)
+        reg_ws = torch.zeros(2 * L.EMX_REDUCE_WS, device=dev)
+        L.l2_partials(params, l2c, reg_ws)
+        L.l2_partials(params, l2c, reg_ws[L.EMX_REDUCE_WS:])
+        terms = torch.zeros(8, device=dev)
+        hist, thist = torch.zeros(16, device=dev), torch.zeros(16, 8, device=dev)
+        jobs = [(reg_ws, L.EMX_REDUCE_WS, 1.0, None, 3, False), (dtop, dtop.numel(), 2.0, None, 1, True)]
+        fin = L.make_finish_desc(jobs, terms, 8, hist, thist, hstep, cursor, step)
+        xnext = torch.full((B, net_dim), -7.0, device=dev)
+        nxt = L.make_next_batch(data, idx, cursor, B, float("inf"), xnext, None, None)
+        ws = torch.zeros(max(L.mlp_wgrad_ws_floats(lay.n_params, B), L.mlp_wgrad_adam_local_ws_floats(plan, B)), device=dev)
+        sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
+        w0 = params.clone()
+        if local:
+            L.mlp_wgrad_adam_local(plan, 0, B, ws, fin, m, v, l2c, 1e-3, 0.9, 0.999, 1e-7, 1.0, reg_ws, sync, next_batch=nxt)
+        else:
+            L.mlp_wgrad(plan, 0, n, 0, B, None, ws, finish=fin)
+            L.adam_step_slices(params, ws, L.mlp_wgrad_slices(B), m, v, l2c, 1e-3, 0.9, 0.999, 1e-7, 1.0, step, reg_ws, plan=plan, next_batch=nxt,
+                               bookkeeping_done=True)
+        torch.cuda.synchronize()
+        assert (sync.cpu().numpy() == 0).all()
+        half = reg_ws[L.EMX_REDUCE_WS:] if local else reg_ws[:L.EMX_REDUCE_WS]     # (update 5: parity 1; the two launches always use the first half)
+        dec = decode_operand_store(lay, plan.mirror)
+        out.append(dict(w=params.cpu().numpy(), w0=w0.cpu().numpy(), m=m.cpu().numpy(), v=v.cpu().numpy(), terms=terms.cpu().numpy(), hist=hist.cpu().numpy(),
+                        counters=[int(step), int(cursor), int(hstep)], reg=float(half.double().sum()), xnext=xnext.cpu().numpy(), store=dec))
+    a, b = out
+    upd = np.abs(a["w"] - a["w0"]).max()
+    dw = np.abs(a["w"] - b["w"])
+    # (elements whose gradient all but cancels: there lr g / (|g| + eps) follows the last bits of g -- a handful, bounded separately)
+    assert upd > 0 and np.quantile(dw, 0.999) <= 3e-3 * upd and dw.max() <= 0.1 * upd
+    np.testing.assert_allclose(b["m"], a["m"], rtol=2e-5, atol=1e-9 + 5e-6 * np.abs(a["m"]).max())
+    np.testing.assert_allclose(b["v"], a["v"], rtol=1e-4, atol=1e-12 + 1e-5 * np.abs(a["v"]).max())
+    np.testing.assert_array_equal(a["terms"], b["terms"])
+    np.testing.assert_array_equal(a["hist"], b["hist"])
+    assert a["counters"] == b["counters"] == [5, 1, 5]
+    np.testing.assert_array_equal(a["xnext"], b["xnext"])
+    assert (a["xnext"] != -7.0).all()
+    assert b["reg"] == pytest.approx(a["reg"], rel=1e-5) and a["reg"] > 0
+    # the operand store holds the NEW weights (22-bit pairs: 2^-21 of the layer's largest weight)
+    from encodermap_amd.layout import unpack_weights
+    wn = unpack_weights(lay, b["w"])
+    for l in range(n):
+        np.testing.assert_allclose(b["store"][l][0], wn[2 * l], rtol=0, atol=2.0 ** -20 * np.abs(wn[2 * l]).max())
