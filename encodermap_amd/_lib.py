@@ -100,6 +100,8 @@ SIGNATURES = {
     "emx_mlp_forward_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p]),
     "emx_mlp_forward_backward_tiles": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, C.POINTER(_f), _p, _sz, _p,
                                             _p, _p, _p]),
+    "emx_mlp_forward_backward_tiles_join": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p, _p, _p, _i, _p, _i, _i, _f, _f, C.POINTER(_f), _p, _sz, _p,
+                                                 _p, _p, _i, _p, _p]),
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
@@ -546,6 +548,20 @@ def mlp_forward_backward_tiles(plan: MlpPlan, l0, l1, x, row_begin, row_end, cos
                                                  ap, ar, _ptr(X), X.shape[1], X.stride(0), float(periodicity), float(data_span or 0.0), sig_arr, _ptr(sk_ws),
                                                  sk_ws.numel() * sk_ws.element_size(),
                                                  _ptr(split_ws), _ptr(zpub), _ptr(sync), _stream()), "emx_mlp_forward_backward_tiles")
+
+
+def mlp_forward_backward_tiles_join(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, X, sig, sk_ws, split_ws, zpub, sync,
+                                    latent_layer, latent, periodicity=float("inf"), data_span=None, train: bool = True):
+    """mlp_forward_backward_tiles with the backward units below the latent layer in the same launch (emx.h): ``latent`` = the
+    tiles' latent-gradient description (``sketchmap_describe(...).grad``), ``sync`` 8 x int32 zeroed once."""
+    ap, ar = plan.aop_args(train)
+    sig_arr = (_f * 6)(*[float(v) for v in sig])
+    assert sync.dtype == torch.int32 and sync.numel() >= 8 and zpub.dtype == torch.float32
+    _check(load().emx_mlp_forward_backward_tiles_join(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
+                                                      int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, None,
+                                                      ap, ar, _ptr(X), X.shape[1], X.stride(0), float(periodicity), float(data_span or 0.0), sig_arr,
+                                                      _ptr(sk_ws), sk_ws.numel() * sk_ws.element_size(), _ptr(split_ws), _ptr(zpub), _ptr(sync),
+                                                      int(latent_layer), C.byref(latent), _stream()), "emx_mlp_forward_backward_tiles_join")
 
 
 def clash_count(xyz, clash_distance, counts):

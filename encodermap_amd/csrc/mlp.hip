@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned row16_max(unsigned x) {
 // store: results leave through buffer resources whose bounds check drops what does not exist), so that every s_waitcnt
 // the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
 // ---------------------------------------------------------------------------------------------------------
-enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8 };   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
+enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8, S_WAIT = 16 };   // S_WAIT (PUB builds): the tile workgroups' partial sums are awaited and joined in front of this epilogue   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
 
 struct GemmRec {          // one layer of the range in one direction: P x C regular units (128 columns x 128 k)
   int P, C;               // passes of 128 output columns, chunks of 128 reduction indices
@@ -444,6 +444,63 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   // call issues the same vector-memory sequence: NE + 1 epilogue operands, 8 pieces (two per K-step of matrix work), 7
   // result stores through buffer resources whose bounds check drops what does not exist -- no conditional load, no
   // exec-masked store, so that every wait the compiler inserts is for the oldest package only.
+  // PUB builds, the encoder's backward units in the SAME launch (emx_mlp_forward_backward_tiles_join): in front of the epilogue that
+  // forms dh of the latent layer the workgroup waits -- one lane polls -- until the LAST tile workgroup has reported (sync[3]; the
+  // tile workgroups stored their partial sums with sc1 and drained them), then collects its sixteen rows of the latent gradient
+  // as the backward launch's staging does (one wave per element, lanes over the tiles' slots, the same association: the same
+  // bits), with sc1 loads.  The last chain workgroup through clears sync[3] / sync[4] for the next launch.
+  auto wait_join = [&]() __attribute__((always_inline)) {
+    if constexpr (PUB_OFF > 0) {
+      int off = PUB_OFF;
+      asm volatile("" : "+s"(off));
+      typedef const PubArgs __attribute__((address_space(4))) * KPub;
+      const KPub kp = (KPub)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+      unsigned* const sync = kp->ready;
+      if (tid == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(&sync[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+          if (++spins > emx::sk::TILE_ROLE_SPIN_LIMIT) {
+            __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(4);
+        }
+      }
+      __syncthreads();
+      // (the join's description is fetched from the kernel arguments HERE, through an offset the optimiser cannot see through: held
+      //  in scalar registers over the whole unit loop it costs the loop its registers -- as the two pointers of the publish hook)
+      int o2 = 56;
+      asm volatile("" : "+s"(o2));
+      const KArgs kq = (KArgs)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + o2);
+      const int N = kq->join_n, n_slots = kq->lg.n_slots, row_base = kq->lg.row_base, row_end = kq->row_end;
+      const long slot_stride = kq->lg.slot_stride;
+      const float gscale = kq->lg.gscale, center_grad = kq->lg.center_grad;
+      const float* const Zp = kq->lg.Z;
+      const __amdgpu_buffer_rsrc_t rP = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(kq->lg.partials), 0, 0x7fffffff, 0x00020000);
+      for (int el = wave; el < R * N; el += NWC) {
+        const int r = el / N, c = el - r * N;
+        const bool rok = r0 + r < row_end;
+        float v = 0.f, zz = 0.f;
+        if (rok) {
+          const int s0 = min(lane, n_slots - 1);
+          const long e0 = (long)(r0 + r - row_base) * N + c;
+          v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rP, (int)((e0 + (long)s0 * slot_stride) * 4), 0, 16)) * (lane < n_slots ? 1.f : 0.f);
+          zz = Zp[(long)(r0 + r) * N + c];     // (this workgroup's own rows of the latent layer)
+        }
+        const float sum = wave_sum(v);
+        if (lane == 0) lat[el] = fmaf(center_grad, zz, gscale * sum);
+      }
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned nc = (unsigned)((p_row_end - p_row0 + R - 1) / R);
+        const unsigned c = __hip_atomic_fetch_add(&sync[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c == nc - 1u) {
+          __hip_atomic_store(&sync[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&sync[4], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+    }
+  };
   auto exec = [&](auto RC) __attribute__((always_inline)) {
     constexpr int r = decltype(RC)::value;          // slot being requested into
     constexpr int rx = (r + 1) % NB;                // slot being executed
@@ -537,6 +594,9 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     float v[4] = {0.f, 0.f, 0.f, 0.f};
     half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
     float rsb = TANH_RS;
+    if constexpr (PUB_OFF > 0) {
+      if (last && (sflags & S_WAIT)) wait_join();
+    }
     if (last) {
       const float cmul = wsc[rx] * (dyn ? 1.f : X.src_rs);
       const int colc = min(col, X.n - 1);
@@ -2013,6 +2073,10 @@ struct TilesHost {
   void* split_ws;
   float* zpub;
   unsigned* sync;
+  // join (emx_mlp_forward_backward_tiles_join): the launch also runs the backward units below the latent layer -- the chain workgroups
+  // wait for the tiles' partial sums and add them to dh of layer latent_layer themselves.  latent: NULL = no join
+  int latent_layer;
+  const emx_latent_grad* latent;
 };
 
 template <bool FAST, int NCH, int KIND = 0>
@@ -2063,7 +2127,7 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
     // float32 copy of h_l in LDS: the cost's input (last layer), the activation derivative of the backward units, or the rows
     // the tile workgroups of the launch are waiting for (the latent layer, bwd_begin - 1)
     const bool for_bwd = desc->act[l] && l >= bwd_begin && l < top;
-    const bool for_tiles = tiles != nullptr && l == bwd_begin - 1;
+    const bool for_tiles = tiles != nullptr && l == (tiles->latent ? tiles->latent_layer : bwd_begin - 1);
     if (for_tiles) a.g[gi].sflags |= S_PUB;
     if (last || for_bwd || for_tiles) {
       GemmRec& G = a.g[gi];
@@ -2085,6 +2149,13 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
       if (gi < 0) return gi;
       a.g[gi].h_f32 = hcopy[l - 1];
       a.g[gi].h_f32_pitch = hpitch[l - 1];
+      if (tiles != nullptr && tiles->latent && l - 1 == tiles->latent_layer) {
+        // dh of the latent layer: the all-pairs cost's gradient joins here, once the tile workgroups of the launch have left it
+        a.g[gi].sflags |= S_JOIN | S_WAIT;
+        a.lg = *tiles->latent;
+        a.join_n = desc->width[l];
+        a.lat_off = b.alloc(R * a.join_n * 4);
+      }
     } else {
       gi = b.add_gemm(l, true, st & 1, false, -1, params, 0, dbelow, 0, AopTensor{nullptr, nullptr, 0});
       if (gi < 0) return gi;
@@ -2114,19 +2185,26 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   if (tiles == nullptr)
     return launch_chain<CHAIN_FUSED>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (forward + cost + backward)");
   // ---- the all-pairs tiles as extra workgroups of this launch (sk_tile.h)
-  EMX_REQUIRE(layer_begin == 0 && bwd_begin >= 1 && bwd_begin < layer_end, "%s: the tiles need the encoder's layers in the launch", who);
+  const int latent_layer = tiles->latent ? tiles->latent_layer : bwd_begin - 1;
+  EMX_REQUIRE(layer_begin == 0 && latent_layer >= 0 && latent_layer < layer_end - 1, "%s: the tiles need the encoder's layers in the launch", who);
+  if (tiles->latent) {
+    EMX_REQUIRE(bwd_begin <= latent_layer && tiles->latent->partials && tiles->latent->Z && tiles->latent->n_slots > 0 && tiles->latent->n_slots <= 64,
+                "%s: the join needs the backward range to reach below the latent layer and a latent-gradient description of at most 64 slots", who);
+    EMX_REQUIRE(a.join_n > 0 && !desc->act[latent_layer], "%s: the join is built for a linear latent layer inside the backward range", who);
+  }
   EMX_REQUIRE(row_begin == 0 && row_end == tiles->B, "%s: the tiles run over the whole batch (rows [0, %d))", who, tiles->B);
   EMX_REQUIRE(tiles->zpub && tiles->sync, "%s: null pointer argument (tile role)", who);
   emx::sk::TileRole tr{};
   int vblocks = 0, nch = 0, kind = 0;
   bool fast = false;
-  rc = emx::sk::make_tile_role(tiles->X, tiles->B, tiles->D, tiles->ldx, h[bwd_begin - 1], desc->width[bwd_begin], tiles->periodicity, tiles->data_span,
+  rc = emx::sk::make_tile_role(tiles->X, tiles->B, tiles->D, tiles->ldx, h[latent_layer], desc->width[latent_layer + 1], tiles->periodicity, tiles->data_span,
                                tiles->sig, tiles->sk_ws, tiles->sk_ws_bytes, tiles->split_ws, &tr, &vblocks, &nch, &fast, &kind, who);
   if (rc) return rc;
   const int n_chain = (row_end - row_begin + R - 1) / R;
   tr.zpub = tiles->zpub;
   tr.sync = tiles->sync;
   tr.n_chain = n_chain;
+  tr.join = tiles->latent ? 1 : 0;
   // persistent tile workgroups: one per CU beside its chain workgroup (more would wait for the chain workgroups to leave), each
   // walking its share of the tile pairs -- in the XCD-aware order 32 per XCD list (pairs k, k + 32, ... of the list)
   static const int per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : 32;
@@ -2182,9 +2260,20 @@ int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, cons
                                    float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, float periodicity,
                                    float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub, uint32_t* sync,
                                    emx_stream_t stream) {
-  TilesHost t{X, row_end - row_begin, D, ldx, periodicity, data_span, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync};
+  TilesHost t{X, row_end - row_begin, D, ldx, periodicity, data_span, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync, -1, nullptr};
   return forward_backward_impl(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop,
                                aop_rows, &t, "emx_mlp_forward_backward_tiles", stream);
+}
+
+int emx_mlp_forward_backward_tiles_join(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                                        int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                                        float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, float periodicity,
+                                        float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes, void* split_ws, float* zpub,
+                                        uint32_t* sync, int latent_layer, const emx_latent_grad* latent, emx_stream_t stream) {
+  EMX_REQUIRE(latent, "emx_mlp_forward_backward_tiles_join: null latent-gradient description");
+  TilesHost t{X, row_end - row_begin, D, ldx, periodicity, data_span, sig, sk_ws, sk_ws_bytes, split_ws, zpub, sync, latent_layer, latent};
+  return forward_backward_impl(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop,
+                               aop_rows, &t, "emx_mlp_forward_backward_tiles_join", stream);
 }
 
 // rows per slice: EMX_WGRAD_SLICE_ROWS, doubled until at most EMX_WGRAD_MAX_SLICES slices remain -- every slice costs a

@@ -254,6 +254,8 @@ struct TileRole {
   unsigned* sync;       // [0] chain workgroups that have published, [1] tile workgroups that are done, [2] spin expired (sticky)
   int n_chain;          // chain workgroups of the launch
   int n_tile_wgs;       // tile workgroups of the launch
+  int join;             // the chain workgroups of the launch wait for the tiles' partial sums (sync[3]: all tile workgroups are done;
+                        // sync[4]: chain workgroups that have collected their rows) and run the encoder's backward units themselves
 };
 constexpr int TILE_ROLE_SMEM_FLOATS = 4096 + 4 * 64 + 64 * 2 + 64 * 2 * 2 + 8;   // one tile (sk_tile_f16_kernel<2, ...>: 18976 bytes)
 constexpr int TILE_ROLE_LDS_BYTES = 2 * TILE_ROLE_SMEM_FLOATS * 4;
@@ -544,12 +546,12 @@ __device__ __forceinline__ void tile_pair_role(char* lds, const TileRole& tr, co
           const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
           const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
                           (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-          a.P[((long)ctj * a.nrows_pad + i0 + rl) * L + l] = s;
+          store_sc1(&a.P[((long)ctj * a.nrows_pad + i0 + rl) * L + l], s);
         }
         if (offdiag) {
           for (int e = tid; e < T * LMAX; e += HNT) {
             const int rl = e / LMAX, l = e - rl * LMAX;
-            a.P[((long)cti * a.nrows_pad + j0 + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+            store_sc1(&a.P[((long)cti * a.nrows_pad + j0 + rl) * L + l], cpart[e * 2] + cpart[e * 2 + 1]);
           }
         }
       }
@@ -562,12 +564,18 @@ __device__ __forceinline__ void tile_pair_role(char* lds, const TileRole& tr, co
   }
 report:
   // the last tile workgroup to finish resets the launch's counters (every chain workgroup has published by then: a tile
-  // workgroup with work saw the full count)
+  // workgroup with work saw the full count) -- and, when the chain workgroups wait for the tiles' partial sums (join: stored with
+  // sc1 above, drained here by every wave before the workgroup counts itself done), tells them
+  if (tr.join) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == (unsigned)tr.n_tile_wgs - 1) {
       __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tr.join) __hip_atomic_store(&tr.sync[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }
@@ -734,7 +742,7 @@ __device__ __forceinline__ void tile32_pair_role(char* lds, const TileRole& tr, 
         const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
         const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
                         (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-        a.P[((long)tj * a.nrows_pad + i0 + rl) * L + l] = s;
+        store_sc1(&a.P[((long)tj * a.nrows_pad + i0 + rl) * L + l], s);
       }
       if (offdiag && tid < T * LMAX) {
         const int rl = tid / LMAX, l = tid - rl * LMAX;
@@ -742,15 +750,20 @@ __device__ __forceinline__ void tile32_pair_role(char* lds, const TileRole& tr, 
         const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
         const float s = ((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w)) +
                         (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
-        a.P[((long)ti * a.nrows_pad + j0 + rl) * L + l] = s;
+        store_sc1(&a.P[((long)ti * a.nrows_pad + j0 + rl) * L + l], s);
       }
     }
+  }
+  if (tr.join) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
     const unsigned done = __hip_atomic_fetch_add(&tr.sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (done == (unsigned)tr.n_tile_wgs - 1) {
       __hip_atomic_store(&tr.sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_store(&tr.sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tr.join) __hip_atomic_store(&tr.sync[3], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
 }

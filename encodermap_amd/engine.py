@@ -213,7 +213,7 @@ class SequentialEngine:
         # the all-pairs tiles as workgroups of the fused dense-layer launch (emx_mlp_forward_backward_tiles): the latent rows as the
         # chain workgroups publish them, and the launch's counters (zeroed once; the launch leaves them at zero)
         self.zpub = torch.zeros(B, self.L, dtype=f32, device=dev)
-        self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
+        self.sk_sync = torch.zeros(8, dtype=torch.int32, device=dev)
         self._tiles_ran = False
         # the optimizer as the tail of the weight-gradient launch (emx_mlp_wgrad_adam): its counters, zeroed once
         self.wg_sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
@@ -299,6 +299,10 @@ class SequentialEngine:
     # the all-pairs tiles ride in the fused dense-layer launch, beside the decoder half of it (single process, Euclidean data on
     # split rows, two latent columns; anything else keeps the separate tile launch).  EMX_OVERLAP_TILES=0: always separate.
     _overlap_tiles = os.environ.get("EMX_OVERLAP_TILES", "1") != "0"
+    # ... and, where the tiles ride there, the encoder's backward units too (emx_mlp_forward_backward_tiles_join): the dense-layer
+    # workgroups wait inside the launch for the tiles' partial sums and carry on down the encoder from their LDS images
+    _join_bwd = os.environ.get("EMX_JOIN_BWD", "1") != "0"
+    _bwd_ran = False
     # single process: L2 + clip + Adam, the operand store and the next batch's rows as the tail of the weight-gradient launch
     # (emx_mlp_wgrad_adam: four launches per step instead of five) where every weight-gradient workgroup is resident at once.
     # OFF by default: bit-identical, but measured slower than the two launches (C2: the one launch 27-33 us against 9.9 + 9.6 us,
@@ -332,9 +336,20 @@ class SequentialEngine:
         if p.auto_cost_scale is not None:
             cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
                                        float(p.auto_cost_scale), self.B, self.delta[-1] if fuse else self.dY, self.cost_ws)
-        self._tiles_ran = False
+        self._tiles_ran = self._bwd_ran = False
         if fuse:
             if full and self._overlap_tiles and self._tiles_fit():
+                if self._join_bwd and self._sk is not None and self._sk.grad.n_slots <= 64:
+                    try:      # ... and the encoder's backward units in the same launch: the step's first THREE launches as one
+                        _lib.mlp_forward_backward_tiles_join(self.plan, 0, n, self.xin, 0, self.B, cost, 0, self.xb, p.dist_sig_parameters, self.sk_ws,
+                                                             self.split_ws, self.zpub, self.sk_sync, lay.n_enc - 1, self._sk.grad,
+                                                             periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
+                        self._tiles_ran = self._bwd_ran = True
+                        return True
+                    except _lib.EmxError as exc:
+                        if not exc.unsupported:
+                            raise
+                        self._join_bwd = False
                 try:
                     _lib.mlp_forward_backward_tiles(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
                                                     self.sk_ws, self.split_ws, self.zpub, self.sk_sync,
@@ -482,6 +497,9 @@ class SequentialEngine:
     def _step_pre_b(self) -> None:
         """Encoder backward (the latent gradient joins here) and the weight gradients."""
         lay = self.layout
+        if self._bwd_ran:          # (the encoder's backward units ran in the fused launch)
+            self._wgrad()
+            return
         if self._dealt():
             _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         elif self._use_sketchmap():

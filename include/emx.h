@@ -427,6 +427,23 @@ int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, cons
                                    float* const* delta, float* dbelow, void* aop, int aop_rows, const float* X, int D, int ldx, float periodicity,
                                    float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes, void* split_ws /* NULL for periodic X */,
                                    float* zpub, uint32_t* sync, emx_stream_t stream);
+/* emx_mlp_forward_backward_tiles with the backward units BELOW the latent layer in the same launch as well (batches whose tiles ride in
+ * the fused launch: the training step's first three launches -- dense layers forward + auto cost + decoder backward, all-pairs tiles,
+ * encoder backward -- as ONE): bwd_begin may reach down to layer_begin (0: all of the encoder), latent_layer names the layer whose rows
+ * the tile workgroups wait for, and `latent` describes where they leave the partial sums of the all-pairs cost's gradient
+ * (emx_sketchmap_describe on sk_ws).  In front of the epilogue that forms dh of the latent layer every dense-layer workgroup waits
+ * -- one lane polls -- until the last tile workgroup has reported, collects its rows of that gradient as emx_mlp_backward's `latent`
+ * join does (same order of additions) and carries on down the encoder from the images it still holds in LDS.
+ *   sync: 8 uint32 zeroed once ([3] all tile workgroups done, [4] dense-layer workgroups through: left at zero by the launch).
+ *   Same results as emx_mlp_forward_backward_tiles (bwd_begin = latent_layer + 1, dbelow) followed by emx_mlp_backward(layers
+ *   [layer_begin, latent_layer + 1), dtop = dbelow, latent) to float32 rounding of the latent layer's image (the one launch forms
+ *   it in its epilogue, the two in the second launch's staging). */
+int emx_mlp_forward_backward_tiles_join(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                                        int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
+                                        float* const* delta, float* dbelow /* may be NULL */, void* aop, int aop_rows, const float* X, int D, int ldx,
+                                        float periodicity, float data_span, const float sig[6], void* sk_ws, size_t sk_ws_bytes,
+                                        void* split_ws /* NULL for periodic X */, float* zpub, uint32_t* sync, int latent_layer,
+                                        const emx_latent_grad* latent, emx_stream_t stream);
 /* dtop = d loss / d h[layer_end-1] (row stride ld_top).  For l = layer_end-1 .. layer_begin:
  *   delta[l] = (dh_l + (l == layer_add ? dadd : 0)) * act'(h[l]);  dh_{l-1} = delta[l] W_l^T.   dadd may be NULL.
  *   dbelow (may be NULL): [B, width[layer_begin]] receives dh of the layer below the range, so that the decoder and

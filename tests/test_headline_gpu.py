@@ -245,18 +245,22 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, peri
     idx = rng.integers(0, 6000, (steps, B))
     out = []
     monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
-    for overlap in (True, False):
+    # (overlap, join): the tiles aboard AND the encoder's backward units in the same launch (emx_mlp_forward_backward_tiles_join: the
+    # dense-layer workgroups wait inside the launch for the tiles' partial sums) / the tiles aboard / the separate launches
+    for overlap, join in ((True, True), (False, False), (True, False)):
         monkeypatch.setattr(SequentialEngine, "_overlap_tiles", overlap)
+        monkeypatch.setattr(SequentialEngine, "_join_bwd", join)
         p = em.Parameters(periodicity=periodicity, batch_size=B, dist_sig_parameters=sig or (math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
         e = em.EncoderMap(p, data, model=_weights(p, 2 * D if periodicity < INF else D), read_only=True)
         e._engine.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
         loss = e._engine.losses()
-        assert e._engine._tiles_ran == overlap
+        assert e._engine._tiles_ran == overlap and e._engine._bwd_ran == (overlap and join)
         out.append((loss, e._engine.w.cpu().numpy(), e._engine.loss_terms()["distance"], e._engine.sk_sync.cpu().numpy()))
-    np.testing.assert_array_equal(out[0][0], out[1][0])
-    np.testing.assert_array_equal(out[0][1], out[1][1])
-    np.testing.assert_array_equal(out[0][2], out[1][2])
-    assert (out[0][3] == 0).all()            # the launch left its counters at zero, nobody gave up waiting
+    for k in (1, 2):
+        np.testing.assert_array_equal(out[0][0], out[k][0])
+        np.testing.assert_array_equal(out[0][1], out[k][1])
+        np.testing.assert_array_equal(out[0][2], out[k][2])
+    assert (out[0][3] == 0).all() and (out[2][3] == 0).all()      # the launches left their counters at zero, nobody gave up waiting
     assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
 
 
