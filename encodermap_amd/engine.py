@@ -400,17 +400,18 @@ class SequentialEngine:
 
     def _tiles_fit(self) -> bool:
         """may the all-pairs tiles ride in the fused dense-layer launch?  (the library has the last word: EMX_EUNSUPPORTED)"""
-        # Batches of up to 1024 rows only.  Measured on one MI355X (tools/time_overlap.py, profiles/r03_overlap_ab.txt): fused launch
-        # + tile launch against the fused launch with the tiles aboard -- B = 1024: 30.8 -> 24.2 us (step 54.0 -> 51.4), B = 2048:
-        # 31.1 -> 31.7, B = 4096: 37.8 -> 46.9 us.  A chain workgroup needs 128+ registers per lane, so a CU holds ONE tile
-        # workgroup (two tiles in flight) beside it where the separate launch keeps eight tiles resident per CU; two tile waves
-        # per SIMD run a tile pair in ~7 us (Gram phase 2.4, sigmoid epilogue 2.2, barriers / reductions / stores 2.4), and at
-        # 4.25 pairs per CU that is longer than the decoder half of the chain workgroups it was meant to hide behind.
+        # Batches of up to 1536 rows only.  Measured on one MI355X (tools/time_overlap.py, tools/time_join_mid.py,
+        # profiles/r03_overlap_ab.txt): with the tiles AND the encoder's backward units aboard the step takes 48.3 against 52.3 us at
+        # 1024 rows, 52.2 against 55.6 at 1536, 58.4 against 58.1 at 2048, 74 against 64 at 3072, 83 against 73 at 4096.  A chain
+        # workgroup needs 128+ registers per lane, so a CU holds ONE tile workgroup (two tiles in flight) beside it where the
+        # separate launch keeps eight tiles resident per CU; two tile waves per SIMD run a tile pair in ~7 us (Gram phase 2.4, sigmoid
+        # epilogue 2.2, barriers / reductions / stores 2.4), and at 4.25 pairs per CU (4096 rows) that is longer than the decoder
+        # half of the chain workgroups it was meant to hide behind.
         if not (self._use_sketchmap() and not self.dp.active and self.L == 2 and self.layout.n_enc >= 1):
             return False
         if self.periodic:      # the 32 x 32 VALU tiles of periodic batches (up to 512 rows: the default configuration's 256)
-            return self.B <= min(512, int(os.environ.get("EMX_OVERLAP_MAX_B", "1024")))
-        return self.split_ws is not None and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1024"))
+            return self.B <= min(512, int(os.environ.get("EMX_OVERLAP_MAX_B", "1536")))
+        return self.split_ws is not None and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1536"))
 
     def check_sync(self) -> None:
         """raises if a tile workgroup of a fused launch ever gave up waiting for the latent rows (emx.h: sync[2])"""
