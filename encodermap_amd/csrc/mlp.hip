@@ -485,7 +485,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           const int s0 = min(lane, n_slots - 1);
           const long e0 = (long)(r0 + r - row_base) * N + c;
           v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rP, (int)((e0 + (long)s0 * slot_stride) * 4), 0, 16)) * (lane < n_slots ? 1.f : 0.f);
-          zz = Zp[(long)(r0 + r) * N + c];     // (this workgroup's own rows of the latent layer)
+          zz = emx::sk::load_sc1(Zp + (long)(r0 + r) * N + c);     // (this workgroup's own rows of the latent layer, stored earlier in this launch: past L1)
         }
         const float sum = wave_sum(v);
         if (lane == 0) lat[el] = fmaf(center_grad, zz, gscale * sum);
