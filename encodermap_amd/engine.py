@@ -207,8 +207,10 @@ class SequentialEngine:
             self.split_ws = torch.zeros(_lib.sketchmap_split_bytes(B, self.D), dtype=torch.uint8, device=dev)
         # auto cost per row block (zero: no auto cost); at least EMX_REDUCE_WS long for the stand-alone cost kernel's shares
         self.cost_ws = torch.zeros(max(_lib.mlp_row_blocks(self.re - self.rb), _lib.EMX_REDUCE_WS), dtype=f32, device=dev)
-        self.wg_ws = torch.zeros(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
+        # slice partials of emx_mlp_wgrad, or the workgroups' shares of emx_mlp_wgrad_adam_local (narrow networks: the larger of the two)
+        self.wg_ws = torch.zeros(max(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), _lib.mlp_wgrad_adam_local_ws_floats(self.plan, self.re - self.rb)),
+                                 dtype=f32, device=dev)
         self._sk = self._describe_sketchmap() if self._use_sketchmap() else None
         # the all-pairs tiles as workgroups of the fused dense-layer launch (emx_mlp_forward_backward_tiles): the latent rows as the
         # chain workgroups publish them, and the launch's counters (zeroed once; the launch leaves them at zero)
