@@ -134,7 +134,7 @@ class ADCEngine(SequentialEngine):
         self.ddih_cart, self.dang_cart = z(B, self.n_dih), z(B, self.n_ang)
         self.cart_scale = z(1)
         dmax = max(self.ldp, self.F)
-        self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
+        self.sk_ws = torch.zeros(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)   # (zero once: the split reduction keeps its tickets there)
         self.split_pair = torch.zeros(_lib.sketchmap_split_bytes(B, self.P), dtype=torch.uint8, device=dev)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         # workgroup shares of the row-mean costs, one row per term: cartesian, dihedral, angle, side dihedral

@@ -43,6 +43,7 @@ struct SkArgs {
   // epilogue.  kmode 0: one workgroup per tile does both.
   int ksplit, kmode;
   float* kpart;      // [tiles][ksplit][4 waves][16][64]
+  unsigned* ktickets; // [tiles] kmode 3: the split reduction in ONE launch -- workgroups of a tile that have left their share (zero between launches)
   // data parallel: the upper-triangle tiles are DEALT to the ranks -- tile t (row-major triangle index)
   // belongs to rank t % deal_world; a workgroup of another rank's tile leaves at once (its cost slot zeroed).  0 / 1: off.
   int deal_rank, deal_world;

@@ -606,7 +606,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 
   const int kmode = NCH == 0 ? (p_kmode_ksplit >> 16) : 0;
   const int ksplit_ = p_kmode_ksplit & 0xffff;
-  const int tile_id = kmode == 1 ? (int)blockIdx.x / ksplit_ : (int)blockIdx.x;
+  const int tile_id = (kmode == 1 || kmode == 3) ? (int)blockIdx.x / ksplit_ : (int)blockIdx.x;
   int ti, tj, tslot = tile_id;
   if (p_xcd_nbg > 0) {
     if (!xcd_tile(blockIdx.x, p_xcd_nbg, p_nbc, ti, tj, tslot)) return;
@@ -706,6 +706,32 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 #pragma unroll
     for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
     return;
+  } else if (kmode == 3) {
+    // ONE launch for the split reduction: the workgroup leaves its share of the chunks in kpart (sc1 stores, drained), takes a
+    // ticket of its tile, and the LAST of the tile's workgroups adds the shares in the order of the chunks -- the sums of kmode 2,
+    // the same bits -- and runs the epilogue.  Nobody waits; the last one leaves the ticket word at zero for the next launch.
+    const int sidx = (int)blockIdx.x - tile_id * a.ksplit;
+    const int c0 = (int)((long)sidx * nch / a.ksplit), c1 = (int)((long)(sidx + 1) * nch / a.ksplit);
+    if (c0 < c1) {
+      SK_GLOAD(c0)
+      for (int c = c0; c < c1; ++c) SK_CHUNK(c, true)
+    }
+    float* dst = a.kpart + ((long)blockIdx.x * 4 + wave) * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) emx::sk::store_sc1(dst + 64 * r, acc[r]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) red[0] = __uint_as_float(__hip_atomic_fetch_add(&a.ktickets[tile_id], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __syncthreads();
+    const unsigned ticket = __float_as_uint(red[0]);
+    if (ticket != (unsigned)a.ksplit - 1u) return;
+    if (tid == 0) __hip_atomic_store(&a.ktickets[tile_id], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const float* src = a.kpart + ((long)tile_id * a.ksplit * 4 + wave) * 1024 + lane;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int s2 = 0; s2 < a.ksplit; ++s2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += emx::sk::load_sc1(src + (long)s2 * 4096 + 64 * r);
   } else {
     // the partials of the first launch, added in the order of the chunks
     const float* src = a.kpart + ((long)tile_id * a.ksplit * 4 + wave) * 1024 + lane;
@@ -1212,7 +1238,8 @@ size_t emx_sketchmap_ws_bytes(int B, int L) {
   if (B <= 0 || L <= 0) return 0;
   size_t nb = (size_t)(B + 63) / 64;
   // + the Gram partials of the split reduction (small batches: at most KSPLIT_BLOCKS workgroups x 64 x 64 floats)
-  return (ws_front_floats(B, L) + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 : 0)) * sizeof(float);
+  // + one ticket word per tile of that reduction (ZERO before the first use; the launches leave them at zero)
+  return (ws_front_floats(B, L) + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 + KSPLIT_BLOCKS : 0)) * sizeof(float);
 }
 
 }  // extern "C" (ws_bytes)
@@ -1293,6 +1320,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   {
     const size_t nb = (size_t)(B + 63) / 64;
     a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + ws_front_floats(B, L) : nullptr;
+    a.ktickets = a.kpart ? reinterpret_cast<unsigned*>(a.kpart + (size_t)KSPLIT_BLOCKS * 4096) : nullptr;
   }
   FinArgs& f = pl.f;
   f.P = a.P;
@@ -1339,9 +1367,12 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     const int ksplit = (b.kpart && b.xcd_nbg == 0 && nch >= 16) ? std::min(std::min(ksplit_cap, nch / 4), KSPLIT_BLOCKS / std::max(pl.ntiles, 1)) : 1;
     if (ksplit > 1) {
       b.ksplit = ksplit;
-      for (int mode = 1; mode <= 2; ++mode) {
+      // one launch (kmode 3: the last workgroup of a tile adds the shares and runs the epilogue; the tickets live behind kpart in the
+      // caller's workspace, zero before the first use) -- or, EMX_SK_KSPLIT_TWO=1, the two launches it replaces (kmode 1, 2)
+      static const bool two = getenv("EMX_SK_KSPLIT_TWO") && atoi(getenv("EMX_SK_KSPLIT_TWO")) == 1;
+      for (int mode = two ? 1 : 3; mode <= (two ? 2 : 3); ++mode) {
         b.kmode = mode;
-        const dim3 gk(mode == 1 ? pl.ntiles * ksplit : pl.ntiles);
+        const dim3 gk(mode == 2 ? pl.ntiles : pl.ntiles * ksplit);
         if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), gk, b);
         else if (a.L == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, false, 0>), gk, b);
         else if (pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<0, true, 0>), gk, b);

@@ -199,7 +199,7 @@ class SequentialEngine:
         self.dZ = torch.zeros(B, self.L, dtype=f32, device=dev)
         self.dlat = torch.zeros(B, self.L, dtype=f32, device=dev)   # dh at the latent coming down from the decoder
         self.red_ws2 = torch.zeros(2 * _lib.EMX_REDUCE_WS, dtype=f32, device=dev)   # (two halves: emx_mlp_wgrad_adam_local, by step parity)
-        self.sk_ws = torch.empty(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)
+        self.sk_ws = torch.zeros(max(_lib.sketchmap_ws_bytes(B, self.L) // 4, 16), dtype=f32, device=dev)   # (zero once: the split reduction keeps its tickets there)
         self.red_ws = torch.zeros(_lib.EMX_REDUCE_WS, dtype=f32, device=dev)
         # f16 planes + norms of the batch rows for the all-pairs kernel (Euclidean data only), made beside the gather
         self.split_ws = None

@@ -150,7 +150,7 @@ def all_pairs_errors(B, D, sig=None, offset_sigmas=40.0, seed=0):
     X, Z = torch.from_numpy(x).cuda(), torch.from_numpy(z).cuda()
     split = torch.zeros(L.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")
     L.sketchmap_split(X, split)
-    ws = torch.empty(L.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(L.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
     dist, cen = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
     dZ = torch.full((B, 2), float("nan"), device="cuda")
     L.sketchmap_tiles(X, Z, INF, sig, 0, B, ws, split)

@@ -85,6 +85,7 @@ int main(int argc, char** argv) {
   CHECK_HIP(hipMalloc((void**)&loss, 4));
   CHECK_HIP(hipMalloc((void**)&closs, 4));
   CHECK_HIP(hipMalloc(&ws, wsb));
+  CHECK_HIP(hipMemset(ws, 0, wsb));   /* emx.h: zero once before the first use */
   CHECK_HIP(hipMemcpy(X, xs, sizeof xs, hipMemcpyHostToDevice));
   CHECK_HIP(hipMemcpy(Z, xs, sizeof xs, hipMemcpyHostToDevice));
   CHECK_EMX(emx_sketchmap_fwd_bwd(X, B, D, D, Z, L, INFINITY, 0.f /* data span: unknown */, sig, 500.f, 1e-4f, 0, B, loss, closs, dZ, ws, wsb, st));

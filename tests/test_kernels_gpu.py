@@ -42,7 +42,7 @@ def make_xz(rng, B, Dd, Ld, periodicity, spread=1.0):
 def run_sketchmap(L, x, z, periodicity, sig, scale, center_scale, rb, re, data_span=None):
     B, Ld = z.shape
     X, Z = dev(x), dev(z)
-    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
     dist = torch.zeros(1, device="cuda")
     cen = torch.zeros(1, device="cuda") if center_scale is not None else None
     dZ = torch.full((B, Ld), float("nan"), device="cuda")
@@ -187,7 +187,7 @@ def test_sketchmap_deterministic_and_rejects(L):
     X = dev(x)
     with pytest.raises(L.EmxError, match="workspace"):              # (nine latent columns are fine since round 3 -- with room for them)
         L.sketchmap_fwd_bwd(X, dev(np.zeros((777, 9), np.float32)), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
-                            torch.zeros(777, 9, device="cuda"), torch.empty(L.sketchmap_ws_bytes(777, 2) // 4, device="cuda"))
+                            torch.zeros(777, 9, device="cuda"), torch.zeros(L.sketchmap_ws_bytes(777, 2) // 4, device="cuda"))
     with pytest.raises(L.EmxError, match="workspace"):
         L.sketchmap_fwd_bwd(X, dev(z), INF, DEFAULT_SIG, 1.0, None, 0, 777, torch.zeros(1, device="cuda"), None,
                             torch.zeros(777, 2, device="cuda"), torch.empty(16, device="cuda"))
@@ -557,7 +557,7 @@ def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     X, Z = dev(x), dev(z)
     split = torch.zeros(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
     L.sketchmap_split(X, split)
-    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
     dist, cen = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
     dZ = torch.full((B, Ld), float("nan"), device="cuda")
     L.sketchmap_tiles(X, Z, INF, sig, rb, re, ws, split)
@@ -632,7 +632,7 @@ def test_sketchmap_tiles_then_finish_equals_the_single_call(L, B, periodicity):
     sig = DEFAULT_SIG if periodicity != INF else (3.0, 12, 6, 1, 2, 6)
     loss, cen, g = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
     X, Z = dev(x), dev(z)
-    ws = torch.empty(L.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(L.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
     dist, c2 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
     dZ = torch.full((B, 2), float("nan"), device="cuda")
     L.sketchmap_tiles(X, Z, periodicity, sig, 0, B, ws, None)
@@ -661,7 +661,7 @@ def test_sketchmap_dealt_tiles_sum_to_the_full_pass(L, B, Dd, Ld, periodicity, t
     sig = DEFAULT_SIG if periodicity != INF else (2.0 * math.sqrt(Dd), 12, 6, 1, 2, 6)
     loss_full, cen_full, g_full = run_sketchmap(L, x, z, periodicity, sig, 500.0, 1e-4, 0, B)
     X, Z = dev(x), dev(z)
-    ws = torch.empty(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(L.sketchmap_ws_bytes(B, Ld) // 4, dtype=torch.float32, device="cuda")
     split_ws = None
     if split:
         split_ws = torch.empty(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")

@@ -10,7 +10,7 @@ g = torch.Generator(device="cuda"); g.manual_seed(0)
 cen = torch.randn(16, D, generator=g, device="cuda") * 4
 X = cen[torch.randint(0, 16, (B,), generator=g, device="cuda")] + torch.randn(B, D, generator=g, device="cuda")
 Z = torch.randn(B, 2, generator=g, device="cuda")
-ws = torch.empty(_lib.sketchmap_ws_bytes(B, 2) // 4, device="cuda")
+ws = torch.zeros(_lib.sketchmap_ws_bytes(B, 2) // 4, device="cuda")
 split = None
 if len(sys.argv) > 2 and sys.argv[2] == "split":
     split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")

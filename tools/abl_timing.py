@@ -27,7 +27,7 @@ elif mode == "bwd_latent":   # the same with the latent gradient joined from the
     _lib.mlp_forward(plan, 0, n, x, 0, B)
     Z = h[lay.n_enc - 1]
     sig = (16.0, 12, 6, 1, 2, 6)
-    ws = torch.empty(_lib.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
+    ws = torch.zeros(_lib.sketchmap_ws_bytes(B, 2) // 4, dtype=torch.float32, device="cuda")
     _lib.sketchmap_tiles(x, Z, float("inf"), sig, 0, B, ws, None)
     sk = _lib.sketchmap_describe(x, Z, float("inf"), sig, 500.0, 1e-4, 0, B, ws)
     for _ in range(20): _lib.mlp_backward(plan, 0, lay.n_enc, dlat, None, lay.n_enc - 1, 0, B, latent=sk.grad)

@@ -17,7 +17,7 @@ else:
     X = (torch.rand(B, D, generator=g, device="cuda") - 0.5) * per
     sig = (per * (D ** 0.5) * 0.2, 12, 6, 1, 2, 6)
 Z = torch.randn(B, 2, generator=g, device="cuda")
-ws = torch.empty(_lib.sketchmap_ws_bytes(B, 2) // 4, device="cuda")
+ws = torch.zeros(_lib.sketchmap_ws_bytes(B, 2) // 4, device="cuda")
 split = None
 if per == float("inf") and os.environ.get("EMX_TIME_SK_F32", "0") != "1":   # the engine's path: Gram products on the f16 cores
     split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")

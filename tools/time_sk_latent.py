@@ -12,7 +12,7 @@ split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device=
 _lib.sketchmap_split(X, split)
 for L in (1, 2, 3, 4, 5, 8, 9, 12):
     Z = torch.randn(B, L, generator=g, device="cuda")
-    ws = torch.empty(_lib.sketchmap_ws_bytes(B, L) // 4, device="cuda")
+    ws = torch.zeros(_lib.sketchmap_ws_bytes(B, L) // 4, device="cuda")
     f = lambda: _lib.sketchmap_tiles(X, Z, float("inf"), (16.0, 12, 6, 1, 2, 6), 0, B, ws, split)
     for _ in range(5): f()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
