@@ -84,6 +84,8 @@ SIGNATURES = {
     "emx_adc_head_describe": (_i, [_p, _p, _l, _i, _i, _i, _p, _p, _p, _p, _p, _i, _f, _p, _i, _p, _f, _f, _f, _p, _p, _i, _p]),
     "emx_adc_frame_bwd": (_i, [_p, _p, _i, _i, _f, _p, _p, _p, _p, _f, _p, _i, _i, _i, _i, _i, _p, _i, _p, _p, _p, _p, _i, _p, _i, _p]),
     "emx_adc_frame_fwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p, _p]),
+    "emx_adc_frame_fwd_bwd": (_i, [_p, _i, _i, _f, _i, _i, _p, _p, _i, _i, _p, _p, _f, _i, _p, _p, _p, _i, _i, _i, _p, _p, _i, _p,
+                                   _i, _f, _p, _p, _p, _i, _p, _p, _i, _p, _i, _p]),
     "emx_backbone_features": (_i, [_p, _l, _i, _p, _p, _p, _p]),
     "emx_soft_start_scale": (_i, [_p, _f, _f, _f, _p, _p]),
     "emx_allatom_mask_words": (_i, [_i]),
@@ -726,6 +728,29 @@ def adc_frame_fwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih
                                     _ptr(inp_pair) if inp_pair is not None else None, _ptr(out_pair), out_pair.stride(0),
                                     _ptr(split_ws) if split_ws is not None else None, _stream()),
            "emx_adc_frame_fwd")
+
+
+def adc_frame_fwd_bwd(Y, periodicity, ang_cols, mean_angles, ang_pred, dih_cols, dih_pred, mean_lengths, dihedral_offset, plane, xyz, cart,
+                      start, step, C, inp_pair, out_pair, split_ws, variant, coef, coef_scale, ws, ddihedrals, dplane, jobs=None, dangles=None):
+    """adc_frame_fwd and adc_frame_bwd as one launch (emx_adc_frame_fwd_bwd): a workgroup back-maps its frame and runs the cartesian
+    cost and the way back on what it has just written."""
+    B, A = xyz.shape[0], xyz.shape[1]
+    a_sin, a_cos = ang_cols if ang_cols is not None else (-1, -1)
+    if ang_cols is not None:
+        assert ang_pred.is_contiguous() and ang_pred.shape == (B, A - 2)
+    assert dih_pred.is_contiguous() and dih_pred.shape == (B, A - 3) and out_pair.stride(0) == inp_pair.stride(0)
+    arr = _cost_jobs(jobs) if jobs else None
+    _check(load().emx_adc_frame_fwd_bwd(_ptr(Y), Y.stride(0), B, float(periodicity), int(a_sin), int(a_cos),
+                                        _ptr(mean_angles) if mean_angles is not None else None, _ptr(ang_pred) if ang_cols is not None else None,
+                                        int(dih_cols[0]), int(dih_cols[1]), _ptr(dih_pred), _ptr(mean_lengths), float(dihedral_offset), A,
+                                        _ptr(plane), _ptr(xyz), _ptr(cart), int(start), int(step), int(C), _ptr(inp_pair), _ptr(out_pair),
+                                        out_pair.stride(0), _ptr(split_ws) if split_ws is not None else None,
+                                        VARIANTS[variant] if isinstance(variant, str) else int(variant), float(coef),
+                                        _ptr(coef_scale) if coef_scale is not None else None, _ptr(ws), _ptr(ddihedrals), ddihedrals.stride(0),
+                                        _ptr(dplane), _ptr(dangles) if ang_cols is not None else None,
+                                        dangles.stride(0) if (ang_cols is not None and dangles is not None) else 0,
+                                        _void_p(arr) if arr is not None else None, len(jobs) if jobs else 0, _stream()),
+           "emx_adc_frame_fwd_bwd")
 
 
 def adc_frame_bwd(out_pair, inp_pair, variant, coef, coef_scale, ws, xyz, dihedrals, offset, plane, start, step, C, ddihedrals, dplane,

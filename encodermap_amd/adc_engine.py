@@ -233,6 +233,54 @@ class ADCEngine(SequentialEngine):
             self._head_key = key
         return _lib.make_next_adc_head(self._head_record, self.idx_block, self.cursor, self.B, self.F if self._fuse_frame else 0)
 
+    def _cost_jobs(self, Y: torch.Tensor) -> list:
+        p, per = self.p, self.periodicity
+        # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward): one
+        # launch for all of them (emx_periodic_cost_batch) -- or none: they ride along with the frame backward pass, behind
+        # chain_in_plane's backward pass when the model has backbone angles
+        jobs = []
+        for off, nn, col in self.parts:
+            tgt = self.feat[:, off: off + nn]
+            if off == self.off_dih:
+                sc, var, ref, slot, extra = p.dihedral_cost_scale, p.dihedral_cost_variant, p.dihedral_cost_reference, T_DIH, self.ddih_cart
+            elif off == self.off_ang:
+                sc, var, ref, slot, extra = p.angle_cost_scale, p.angle_cost_variant, p.angle_cost_reference, T_ANG, self.dang_cart
+            else:
+                sc, var, ref, slot, extra = p.side_dihedral_cost_scale, p.side_dihedral_cost_variant, p.side_dihedral_cost_reference, T_SIDE, None
+            coef = 0.0 if sc is None else float(sc) / float(ref)
+            jobs.append(dict(y=Y, off_sin=col, off_cos=col + nn, periodic_output=True, target=tgt, n=nn, periodicity=per, variant=var, coef=coef,
+                             dY=self.dY, ws=self.cost_ws_rows[self._row_of[slot]], dpred_add=extra))
+        if not self.use_ang:   # mean angles carry no gradient, the cost is still reported (models.py:2383)
+            sc = p.angle_cost_scale
+            jobs.append(dict(y=_Bcast(self.ang_pred), off_sin=0, off_cos=0, periodic_output=False,
+                             target=self.feat[:, self.off_ang: self.off_ang + self.n_ang], n=self.n_ang, periodicity=per,
+                             variant=p.angle_cost_variant, coef=0.0 if sc is None else float(sc) / float(p.angle_cost_reference), dY=None,
+                             ws=self.cost_ws_rows[self._row_of[T_ANG]]))
+        return jobs
+
+    def _frame_both(self, Y: torch.Tensor, jobs: list) -> bool:
+        """emx_adc_frame_fwd_bwd: False outside what either half's fused pass is built for (the two launches, or the single stages, follow)"""
+        if not (self._fuse_frame and self._fuse_frame_bwd and self._fuse_cost_jobs and self._frame_both_ok):
+            return False
+        p = self.p
+        cols = {off: (col, col + n) for off, n, col in self.parts}
+        try:
+            _lib.adc_frame_fwd_bwd(Y, self.periodicity, cols[self.off_ang] if self.use_ang else None,
+                                   None if self.use_ang else self.feat_mean[self.off_ang: self.off_ang + self.n_ang],
+                                   self.ang_pred if self.use_ang else None, cols[self.off_dih], self.dih_pred, self.mean_len, math.pi, self.plane,
+                                   self.xyz, self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair, self.out_pair,
+                                   self.split_pair if p.cartesian_distance_cost_scale is not None else None, p.cartesian_cost_variant,
+                                   1.0 / float(p.cartesian_cost_reference), self.cart_scale, self.cost_ws_rows[0], self.ddih_cart, self.dplane,
+                                   jobs=jobs, dangles=self.dang_cart)
+            return True
+        except _lib.EmxError as exc:
+            if not exc.unsupported:
+                raise
+            self._frame_both_ok = False
+            return False
+
+    _frame_both_ok = os.environ.get("EMX_ADC_FRAME_BOTH", "1") != "0"
+
     def _frame_forward(self, Y: torch.Tensor) -> bool:
         """PeriodicOutput, BackMapLayer and both pair-distance blocks of the step as one launch (emx_adc_frame_fwd) behind the
         batch means; False when the frame does not fit the fused pass (or EMX_ADC_FUSE_FRAME=0): the single stages follow."""
@@ -346,7 +394,12 @@ class ADCEngine(SequentialEngine):
             self._encoder_input(self.feat, self.xin)
         _lib.mlp_forward(self.plan, 0, n, self.xin, 0, B)
         Y, Z = self.h[-1], self.h[lay.n_enc - 1]
-        if not self._frame_forward(Y):
+        jobs = self._cost_jobs(Y)
+        batchable = self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS
+        # both halves of the per-frame work -- back-mapping with the pair distances, then the cartesian cost and the way back, the
+        # angle-like costs behind it -- as ONE launch where everything is in place for it (emx_adc_frame_fwd_bwd)
+        both = self._frame_both(Y, jobs) if (batchable and (self._prefetch or self._fused_head)) else False
+        if not both and not self._frame_forward(Y):
             self._backmap(Y, self.feat, B, self.ang_pred, self.dih_pred, self.mean_len, self.plane, self.xyz)
             _lib.pdist_flat_fwd(self.cart, self.pw_start, self.pw_step, self.C, self.inp_pair)
             _lib.pdist_flat_fwd(self.xyz, self.pw_start, self.pw_step, self.C, self.out_pair)
@@ -355,29 +408,7 @@ class ADCEngine(SequentialEngine):
         # cartesian cost with the soft-start scale of this step, and its way back through the back-mapping
         if not self._fused_head:
             _lib.soft_start_scale(self.step, *soft, self.cart_scale)
-        # angle-like costs on the decoder output blocks (gradient of the cartesian path joins before the atan2 backward): one
-        # launch for all of them (emx_periodic_cost_batch) -- or none: they ride along with the frame backward pass, behind
-        # chain_in_plane's backward pass when the model has backbone angles
-        jobs = []
-        for off, nn, col in self.parts:
-            tgt = self.feat[:, off: off + nn]
-            if off == self.off_dih:
-                sc, var, ref, slot, extra = p.dihedral_cost_scale, p.dihedral_cost_variant, p.dihedral_cost_reference, T_DIH, self.ddih_cart
-            elif off == self.off_ang:
-                sc, var, ref, slot, extra = p.angle_cost_scale, p.angle_cost_variant, p.angle_cost_reference, T_ANG, self.dang_cart
-            else:
-                sc, var, ref, slot, extra = p.side_dihedral_cost_scale, p.side_dihedral_cost_variant, p.side_dihedral_cost_reference, T_SIDE, None
-            coef = 0.0 if sc is None else float(sc) / float(ref)
-            jobs.append(dict(y=Y, off_sin=col, off_cos=col + nn, periodic_output=True, target=tgt, n=nn, periodicity=per, variant=var, coef=coef,
-                             dY=self.dY, ws=self.cost_ws_rows[self._row_of[slot]], dpred_add=extra))
-        if not self.use_ang:   # mean angles carry no gradient, the cost is still reported (models.py:2383)
-            sc = p.angle_cost_scale
-            jobs.append(dict(y=_Bcast(self.ang_pred), off_sin=0, off_cos=0, periodic_output=False,
-                             target=self.feat[:, self.off_ang: self.off_ang + self.n_ang], n=self.n_ang, periodicity=per,
-                             variant=p.angle_cost_variant, coef=0.0 if sc is None else float(sc) / float(p.angle_cost_reference), dY=None,
-                             ws=self.cost_ws_rows[self._row_of[T_ANG]]))
-        batchable = self._batched_costs and len(jobs) <= _lib.EMX_MAX_COST_JOBS
-        done = self._frame_backward(jobs if batchable else None)
+        done = 2 if both else self._frame_backward(jobs if batchable else None)
         if done == 0:
             _lib.periodic_cost_fwd_bwd(self.out_pair, 0, 0, False, self.inp_pair, self.P, INF, p.cartesian_cost_variant,
                                        1.0 / float(p.cartesian_cost_reference), 0, B, None, self.dpair, self.cost_ws_rows[0],

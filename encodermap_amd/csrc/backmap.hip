@@ -988,8 +988,7 @@ __host__ __device__ inline long adc_frame_floats(int A, int C, bool split) {
          (split ? 3 * (long)C + emx::split_ld((int)((long)C * (C - 1) / 2)) : 0);
 }
 
-__global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs a) {
-  extern __shared__ float sm[];
+__device__ __forceinline__ void adc_frame_fwd_body(const AdcFrameArgs& a, float* sm) {
   const int A = a.A, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long b = blockIdx.x;
@@ -1152,9 +1151,7 @@ __host__ __device__ inline long adc_frame_bwd_floats(int A, int C) {
 }
 static_assert(AF_NT == PD_NT, "the pair-distance bodies run on the whole workgroup");
 
-__global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdArgs a) {
-  extern __shared__ float sm[];
-  __shared__ float red[AF_NT / 64];
+__device__ __forceinline__ void adc_frame_bwd_body(const AdcFrameBwdArgs& a, float* sm, float* red) {
   const int A = a.A, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const long b = blockIdx.x;
@@ -1264,6 +1261,27 @@ __global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdA
   else if (q == 1 && a.n_jobs > 1) finish(a.job[1]);
   else if (q == 2 && a.n_jobs > 2) finish(a.job[2]);
   else if (q == 3 && a.n_jobs > 3) finish(a.job[3]);
+}
+
+__global__ __launch_bounds__(AF_NT) void adc_frame_fwd_kernel(const AdcFrameArgs a) {
+  extern __shared__ float sm[];
+  adc_frame_fwd_body(a, sm);
+}
+__global__ __launch_bounds__(AF_NT) void adc_frame_bwd_kernel(const AdcFrameBwdArgs a) {
+  extern __shared__ float sm[];
+  __shared__ float red[AF_NT / 64];
+  adc_frame_bwd_body(a, sm, red);
+}
+// Both halves in ONE launch (emx_adc_frame_fwd_bwd): nothing between them depends on another frame -- the workgroup that has
+// back-mapped frame b runs the cartesian cost and the way back for frame b from what it has just written (drained, then a barrier;
+// the lines were never in this CU's L1), and the second launch's ramp and first trips go.
+__global__ __launch_bounds__(AF_NT) void adc_frame_both_kernel(const AdcFrameArgs f, const AdcFrameBwdArgs g) {
+  extern __shared__ float sm[];
+  __shared__ float red[AF_NT / 64];
+  adc_frame_fwd_body(f, sm);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  adc_frame_bwd_body(g, sm, red);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1651,11 +1669,10 @@ int emx_pdist_flat_fwd(const float* xyz, int B, int A, int start, int step, int 
   return emx::check_launch("pdist_fwd_kernel");
 }
 
-int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
-                      int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane, float* xyz,
-                      const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, void* split_ws,
-                      emx_stream_t stream) {
-  const char* who = "emx_adc_frame_fwd";
+static int fill_frame_fwd(const char* who, const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles,
+                          float* ang_pred, int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A,
+                          float* plane, float* xyz, const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo,
+                          void* split_ws, AdcFrameArgs& a, size_t& lds) {
   EMX_REQUIRE(Y && dih_pred && mean_lengths && plane && xyz && out_pair && B > 0 && A >= 4, "%s: bad arguments (A >= 4)", who);
   EMX_REQUIRE((ang_sin >= 0 && ang_cos >= 0 && ang_pred) || (ang_sin < 0 && mean_angles), "%s: the angles come from Y (columns + ang_pred) or from mean_angles", who);
   EMX_REQUIRE(ang_sin < 0 || (ang_sin + A - 2 <= ldy && ang_cos + A - 2 <= ldy), "%s: angle columns outside the row", who);
@@ -1667,9 +1684,8 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
   EMX_REQUIRE(!inp_pair || cart, "%s: the input frames are needed for their pair distances", who);
   EMX_REQUIRE(!split_ws || (inp_pair && (reinterpret_cast<uintptr_t>(split_ws) & 15) == 0 && P < (1L << 30)),
               "%s: the split needs the input pair block and a 16-byte aligned workspace", who);
-  const size_t lds = (size_t)adc_frame_floats(A, C, split_ws != nullptr) * sizeof(float);
+  lds = (size_t)adc_frame_floats(A, C, split_ws != nullptr) * sizeof(float);
   if (lds > 64 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: a frame of %d atoms does not fit the LDS buffers of the fused pass (use the single stages)", who, A);
-  AdcFrameArgs a;
   a.Y = Y;
   a.ldy = ldy;
   a.out_scale = periodicity == TWO_PI_F ? 1.f : periodicity / TWO_PI_F;
@@ -1695,15 +1711,26 @@ int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang
   a.out_pair = out_pair;
   a.sp = split_ws ? emx::split_view(split_ws, B, (int)P) : emx::SplitRows{};
   a.split_wide = P >= 1024 && B <= 8192;   // (the rule of emx_sketchmap_split)
+  return EMX_OK;
+}
+
+int emx_adc_frame_fwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
+                      int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane, float* xyz,
+                      const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, void* split_ws,
+                      emx_stream_t stream) {
+  AdcFrameArgs a;
+  size_t lds = 0;
+  const int rc = fill_frame_fwd("emx_adc_frame_fwd", Y, ldy, B, periodicity, ang_sin, ang_cos, mean_angles, ang_pred, dih_sin, dih_cos, dih_pred,
+                                mean_lengths, dihedral_offset, A, plane, xyz, cart, start, step, C, inp_pair, out_pair, ldo, split_ws, a, lds);
+  if (rc) return rc;
   hipLaunchKernelGGL(adc_frame_fwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
   return emx::check_launch("adc_frame_fwd_kernel");
 }
 
-int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale, float* ws,
-                      const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start, int step, int C,
-                      float* ddihedrals, int ldg, float* dplane, const float* mean_lengths, const float* angles, float* dangles, int ldd,
-                      const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
-  const char* who = "emx_adc_frame_bwd";
+static int fill_frame_bwd(const char* who, const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale,
+                          float* ws, const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start,
+                          int step, int C, float* ddihedrals, int ldg, float* dplane, const float* mean_lengths, const float* angles,
+                          float* dangles, int ldd, const emx_cost_job* jobs, int n_jobs, AdcFrameBwdArgs& a, size_t& lds) {
   EMX_REQUIRE(!angles || (mean_lengths && dangles && ldd >= A - 2), "%s: chain_in_plane's backward pass needs the mean lengths and dangles [B, >= A-2]", who);
   EMX_REQUIRE(out_pair && inp_pair && ws && xyz && dihedrals && plane && ddihedrals && dplane && B > 0 && A >= 4 && ldg >= A - 3, "%s: bad arguments (A >= 4)", who);
   EMX_REQUIRE(C >= 2 && step >= 1 && start >= 0 && start + (long)step * (C - 1) < A, "%s: atom selection outside the frame", who);
@@ -1715,11 +1742,9 @@ int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int
   const bool four = variant != EMX_MEAN_NORM && B <= EMX_REDUCE_WS / 4 && P > 3 * 512;
   if (!four)
     return emx::fail(EMX_EUNSUPPORTED, "%s: B = %d frames x %ld pair distances (variant %d) is outside the fused pass (use the single stages)", who, B, P, variant);
-  const size_t lds = (size_t)adc_frame_bwd_floats(A, C) * sizeof(float);
+  lds = (size_t)adc_frame_bwd_floats(A, C) * sizeof(float);
   if (lds > 160 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: a frame of %d atoms does not fit the LDS buffers of the fused pass (use the single stages)", who, A);
-  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_frame_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
-  AdcFrameBwdArgs a{};
+  a = AdcFrameBwdArgs{};
   a.cost.y = out_pair;
   a.cost.target = inp_pair;
   a.cost.dpred_add = nullptr;
@@ -1779,8 +1804,47 @@ int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int
     c.prescale = 1;
     c.wide = 1;
   }
+  return EMX_OK;
+}
+
+int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int variant, float coef, const float* coef_scale, float* ws,
+                      const float* xyz, const float* dihedrals, float dihedral_offset, const float* plane, int B, int A, int start, int step, int C,
+                      float* ddihedrals, int ldg, float* dplane, const float* mean_lengths, const float* angles, float* dangles, int ldd,
+                      const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
+  const char* who = "emx_adc_frame_bwd";
+  AdcFrameBwdArgs a;
+  size_t lds = 0;
+  const int rc = fill_frame_bwd(who, out_pair, inp_pair, ldo, variant, coef, coef_scale, ws, xyz, dihedrals, dihedral_offset, plane, B, A, start, step, C,
+                                ddihedrals, ldg, dplane, mean_lengths, angles, dangles, ldd, jobs, n_jobs, a, lds);
+  if (rc) return rc;
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_frame_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
   hipLaunchKernelGGL(adc_frame_bwd_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, a);
   return emx::check_launch("adc_frame_bwd_kernel");
+}
+
+int emx_adc_frame_fwd_bwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
+                          int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane,
+                          float* xyz, const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, void* split_ws,
+                          int variant, float coef, const float* coef_scale, float* ws, float* ddihedrals, int ldg, float* dplane, float* dangles,
+                          int ldd, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream) {
+  const char* who = "emx_adc_frame_fwd_bwd";
+  EMX_REQUIRE(inp_pair, "%s: the cartesian cost needs the input frames' pair distances (inp_pair)", who);
+  AdcFrameArgs f;
+  AdcFrameBwdArgs g;
+  size_t lds_f = 0, lds_g = 0;
+  int rc = fill_frame_fwd(who, Y, ldy, B, periodicity, ang_sin, ang_cos, mean_angles, ang_pred, dih_sin, dih_cos, dih_pred, mean_lengths, dihedral_offset,
+                          A, plane, xyz, cart, start, step, C, inp_pair, out_pair, ldo, split_ws, f, lds_f);
+  if (rc) return rc;
+  rc = fill_frame_bwd(who, out_pair, inp_pair, ldo, variant, coef, coef_scale, ws, xyz, dih_pred, dihedral_offset, plane, B, A, start, step, C, ddihedrals,
+                      ldg, dplane, mean_lengths, ang_sin >= 0 ? ang_pred : nullptr, dangles, ldd, jobs, n_jobs, g, lds_g);
+  if (rc) return rc;
+  const size_t lds = std::max(lds_f, lds_g);
+  if (lds > 64 * 1024 && hipFuncSetAttribute(reinterpret_cast<const void*>(&adc_frame_both_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
+  static_assert(sizeof(AdcFrameArgs) + sizeof(AdcFrameBwdArgs) <= 4096, "kernel arguments of adc_frame_both_kernel");
+  hipLaunchKernelGGL(adc_frame_both_kernel, dim3(B), dim3(AF_NT), lds, (hipStream_t)stream, f, g);
+  return emx::check_launch("adc_frame_both_kernel");
 }
 
 int emx_pdist_flat_bwd(const float* xyz, const float* dout, int B, int A, int start, int step, int C, int ldo, float* dxyz, int accumulate,

@@ -580,6 +580,17 @@ int emx_adc_frame_bwd(const float* out_pair, const float* inp_pair, int ldo, int
                       int start, int step, int C, float* ddihedrals, int ldg, float* dplane, const float* mean_lengths,
                       const float* angles, float* dangles, int ldd, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream);
 
+/* emx_adc_frame_fwd and emx_adc_frame_bwd as ONE launch, a workgroup per frame (nothing between the two depends on another frame):
+ * the arguments of the first, then what the second adds -- the cartesian cost (variant, coef, coef_scale, ws), its outputs
+ * (ddihedrals / ldg, dplane, dangles / ldd) and the cost jobs; its out_pair / inp_pair / xyz / dihedrals / plane / angles are the
+ * forward half's out_pair / inp_pair (required) / xyz / dih_pred / plane / ang_pred (when the angles come from Y).  Same values, bit for
+ * bit, as the two launches; EMX_EUNSUPPORTED where either of them is. */
+int emx_adc_frame_fwd_bwd(const float* Y, int ldy, int B, float periodicity, int ang_sin, int ang_cos, const float* mean_angles, float* ang_pred,
+                          int dih_sin, int dih_cos, float* dih_pred, const float* mean_lengths, float dihedral_offset, int A, float* plane,
+                          float* xyz, const float* cart, int start, int step, int C, float* inp_pair, float* out_pair, int ldo, void* split_ws,
+                          int variant, float coef, const float* coef_scale, float* ws, float* ddihedrals, int ldg, float* dplane, float* dangles,
+                          int ldd, const emx_cost_job* jobs, int n_jobs, emx_stream_t stream);
+
 /* Training metrics of the ADC model, evaluated on the back-mapped frames [B, A, 3]:
  *   emx_clash_count  counts[f] = number of atom pairs i < j closer than clash_distance -- ADCClashMetric.update_state,
  *                    count_nonzero(pairwise_dist(y_pred, flat=True) < d, axis=1)      encodermap/callbacks/metrics.py:505-522

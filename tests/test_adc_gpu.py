@@ -296,3 +296,36 @@ def test_adc_step_tail_in_one_launch(em, case, monkeypatch):
     assert (a["sync"] == 0).all()
     np.testing.assert_allclose(a["loss"], b["loss"], rtol=3e-4)
     assert np.isfinite(a["loss"]).all()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2, 3])
+def test_adc_frame_halves_in_one_launch(em, case, monkeypatch):
+    """emx_adc_frame_fwd_bwd -- the back-mapping with its pair distances, the cartesian cost and the way back, the angle-like costs: one
+    workgroup per frame, one launch -- against emx_adc_frame_fwd + emx_adc_frame_bwd: whole training runs bit for bit (losses, every
+    term, weights), soft start included."""
+    from encodermap_amd.adc_engine import ADCEngine
+
+    name, kw, n_res, n_side, B = CASES[case]
+    kw = dict(kw, cartesian_cost_scale_soft_start=(2, 6), cartesian_cost_scale=3.0)
+    rng = np.random.default_rng(31 + case)
+    data = R.synthetic_backbone(rng, 700, n_res, n_side)
+    n_steps = 8
+    idx = torch.from_numpy(rng.integers(0, 700, (n_steps, B)).reshape(-1)).to("cuda:0")
+    out = []
+    for both in (True, False):
+        monkeypatch.setattr(ADCEngine, "_frame_both_ok", both)
+        p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
+        e = em.AngleDihedralCartesianEncoderMap(data, p, read_only=True)
+        eng = e._engine
+        torch.manual_seed(3)
+        eng.w.copy_(torch.randn_like(eng.w) * 0.05)
+        eng._sync_derived_state()
+        eng.run_steps(n_steps, idx)
+        loss, terms = eng.losses(), eng.loss_terms()
+        out.append((loss, eng.w.cpu().numpy(), terms))
+    np.testing.assert_array_equal(out[0][0], out[1][0])
+    np.testing.assert_array_equal(out[0][1], out[1][1])
+    for k in out[0][2]:
+        np.testing.assert_array_equal(out[0][2][k], out[1][2][k], err_msg=k)
+    assert np.isfinite(out[0][0]).all()
+
