@@ -1238,8 +1238,9 @@ size_t emx_sketchmap_ws_bytes(int B, int L) {
   if (B <= 0 || L <= 0) return 0;
   size_t nb = (size_t)(B + 63) / 64;
   // + the Gram partials of the split reduction (small batches: at most KSPLIT_BLOCKS workgroups x 64 x 64 floats)
-  // + one ticket word per tile of that reduction (ZERO before the first use; the launches leave them at zero)
-  return (ws_front_floats(B, L) + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 + KSPLIT_BLOCKS : 0)) * sizeof(float);
+  // in FRONT of everything, wherever (B, L) puts the rest: one ticket word per tile of that reduction (ZERO before the first use; the
+  // launches leave them at zero, and no launch of any shape writes anything else there)
+  return (KSPLIT_BLOCKS + ws_front_floats(B, L) + (nb <= KSPLIT_MAX_NB ? (size_t)KSPLIT_BLOCKS * 4096 : 0)) * sizeof(float);
 }
 
 }  // extern "C" (ws_bytes)
@@ -1310,7 +1311,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   a.sl = make_sig(sig[3], sig[4], sig[5]);
   pl.ntiles = symm ? a.nbc * (a.nbc + 1) / 2 : a.nbr * a.nbc;
   const int nslots = a.nbc;
-  float* wsf = static_cast<float*>(ws);
+  float* wsf = static_cast<float*>(ws) + KSPLIT_BLOCKS;   // (behind the ticket words of the split reduction)
   a.P = wsf;
   a.tile_loss = wsf + (size_t)nslots * a.nrows_pad * L;
   a.ksplit = 1;
@@ -1320,7 +1321,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   {
     const size_t nb = (size_t)(B + 63) / 64;
     a.kpart = nb <= (size_t)KSPLIT_MAX_NB ? wsf + ws_front_floats(B, L) : nullptr;
-    a.ktickets = a.kpart ? reinterpret_cast<unsigned*>(a.kpart + (size_t)KSPLIT_BLOCKS * 4096) : nullptr;
+    a.ktickets = static_cast<unsigned*>(ws);
   }
   FinArgs& f = pl.f;
   f.P = a.P;

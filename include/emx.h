@@ -74,7 +74,7 @@ int64_t emx_launch_count(void);
  *   contribute zero gradient (the reference's mask, distances.py:247-253).
  *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes, ZERO-INITIALISED ONCE by the caller before its first use (small batches
  *   of long rows split a tile's reduction over workgroups of ONE launch: the last of a tile's workgroups adds their shares and runs
- *   the epilogue; their ticket words live at the end of ws and are left at zero by every launch).
+ *   the epilogue; their ticket words are the first 2 KB of ws, whatever (B, L), and are left at zero by every launch).
  * ------------------------------------------------------------------------------------------------ */
 size_t emx_sketchmap_ws_bytes(int B, int L);
 int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L,
