@@ -1252,10 +1252,10 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
 //   (sync[1]) does, and resets the sync words for the next launch.  sync[2]: sticky, a wait ran out (never expected; the
 //   caller checks it when it synchronises).
 // ---------------------------------------------------------------------------------------------------------
-#ifdef EMX_CHAIN_TIMING   // timeline of the fused launch (tools/abl_tail.py): rows of 16 stamps at emx_dbg[6144 + 16 * who]
-#define TSTAMP(who, k) do { if (threadIdx.x == 0) emx_dbg[8 * (who) + (k)] = wall_clock64(); } while (0)
+#ifdef EMX_CHAIN_TIMING   // timeline of the fused launch (tools/abl_tail.py): rows of 8 stamps at emx_dbg[8 * who]
+#define LSTAMP(who, k) do { if (threadIdx.x == 0) emx_dbg[8 * (who) + (k)] = wall_clock64(); } while (0)
 #else
-#define TSTAMP(who, k)
+#define LSTAMP(who, k)
 #endif
 struct WgTail {
   unsigned* sync;
@@ -1294,19 +1294,19 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
   if (by >= n_slices) {
     const int e = (by - n_slices) * n_tiles + bx;   // 0: the scalar epilogue; 1 ..: the next batch's rows
     if (e == 0) {
-      TSTAMP(1000, 0);
+      LSTAMP(1000, 0);
       finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);   // (its cursor / counter2 are null: advanced below)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its reads of the regulariser shares have returned
       __syncthreads();
       if (tid == 0) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      TSTAMP(1000, 1);
+      LSTAMP(1000, 1);
     } else if (e - 1 < a.t.gather_wgs) {
       if (!(a.t.debug & 1)) {
       const int gw = 512 + e - 1;
-      if (gw >= 0) TSTAMP(gw, 0);
+      if (gw >= 0) LSTAMP(gw, 0);
       gather_rows2_multi<8>(a.ad.next, (e - 1) * (NT / 64) + wave, a.t.gather_wgs * (NT / 64), lane);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (gw >= 0) TSTAMP(gw, 1);
+      if (gw >= 0) LSTAMP(gw, 1);
       }
     } else {
       return;   // (padding of the last grid row)
@@ -1315,11 +1315,11 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
     const WgHd hd{rb0, rb_end, rbs_per_slice, 0, partial, n_params};
     const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
     const int ww = by * n_tiles + bx;
-    if (ww >= 0) TSTAMP(ww, 0);
+    if (ww >= 0) LSTAMP(ww, 0);
     wgrad_block<true>(tbw, bx, by, hd, (WgKVec)(kseg + offsetof(WgradAdamDev, lay)));
-    if (ww >= 0) TSTAMP(ww, 1);
+    if (ww >= 0) LSTAMP(ww, 1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ww >= 0) TSTAMP(ww, 2);
+    if (ww >= 0) LSTAMP(ww, 2);
     __syncthreads();
     const int n_wg = n_tiles * n_slices;
     if (tid == 0) {
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
       }
     }
     __syncthreads();
-    if (ww >= 0) TSTAMP(ww, 3);
+    if (ww >= 0) LSTAMP(ww, 3);
     // the optimizer: virtual workgroups of one wave each, the launch's waves in turn
     const long step_now = *a.ad.step;
     const int nblk = a.ad.adam_blocks;
@@ -1359,9 +1359,9 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsig
   asm volatile("" ::: "memory");
 #ifdef EMX_CHAIN_TIMING
   if (by < n_slices) {
-    TSTAMP(by * n_tiles + bx, 4);
+    LSTAMP(by * n_tiles + bx, 4);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    TSTAMP(by * n_tiles + bx, 5);
+    LSTAMP(by * n_tiles + bx, 5);
   }
 #endif
   // leave: the last one advances the counters and clears the sync words
@@ -1443,11 +1443,11 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
     const int e = bx - splits * n_slots;   // 0: the scalar epilogue; 1 ..: the next batch's rows
     if (e == 0) {
       if (tid >= FIN_NT) return;   // (the epilogue is written for FIN_NT threads; a wave that has ended takes no part in barriers)
-      TSTAMP(1000, 0);
+      LSTAMP(1000, 0);
       const long st = *p_step;
       // (its cursor / counter2 are null: advanced below; the regulariser shares: the half of ws the previous launch wrote)
       finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl, a.t.reg_job, (st & 1) * EMX_REDUCE_WS);
-      TSTAMP(1000, 1);
+      LSTAMP(1000, 1);
       if (tid == 0) {
         unsigned spins = 0;
         while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.t.n_counted) {
@@ -1461,9 +1461,9 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
         if (a.t.cursor) *a.t.cursor += 1;
         *a.t.opt_step = st + 1;
       }
-      TSTAMP(1000, 2);
+      LSTAMP(1000, 2);
     } else {
-      TSTAMP(512 + e - 1, 0);
+      LSTAMP(512 + e - 1, 0);
       if (a.ad.next.adc_head != nullptr) {
         // the head of the next ADC step (emx_next_batch::adc_head; adc_head.h): two virtual workgroups of 256 threads for the rows per
         // workgroup, then workgroups of 32 columns x 16 row phases for the batch means
@@ -1484,14 +1484,14 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
       } else {
         gather_rows_body(a.ad.next, (e - 1) * (NTL / 64) + wave, a.t.gather_wgs * (NTL / 64), lane);   // (rows without 16-byte lanes)
       }
-      TSTAMP(512 + e - 1, 1);
+      LSTAMP(512 + e - 1, 1);
       __syncthreads();   // (every wave has its cursor: the loads that use it are issued)
       if (tid == 0) __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return;
   }
   // ---- one 32 x 32 block ----
-  TSTAMP(bx, 0);
+  LSTAMP(bx, 0);
   const long step_now = *p_step;
   const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
   // Workgroup -> block.  Workgroups go to the XCDs in turn (workgroup x, x + 8, .. are XCD x's): by default groups of four
@@ -1646,7 +1646,7 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
       products(g + GB, fb, vxb, vdb);
     }
   }
-  TSTAMP(bx, 2);
+  LSTAMP(bx, 2);
   static_assert(NTL / 64 == 8, "the fixed-order sums below are written for eight waves");
   // the waves' shares: D[row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)][col = lane & 31]
 #pragma unroll
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
     if (lane < 32) bred[wave][lane] = bsum;
   }
   __syncthreads();
-  TSTAMP(bx, 3);
+  LSTAMP(bx, 3);
   // Every wave's step counter -- its first request -- arrived long ago: count the workgroup in (the epilogue workgroup advances
   // the counters when all have).  By a wave that has nothing else left to do: the others do not wait for the atomic.
   if (tid == NTL - 64) __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1707,11 +1707,11 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
       }
     }
   }
-  TSTAMP(bx, 6);
+  LSTAMP(bx, 6);
   if (slab_live) {
     reg = adam_slab_finish(a.ad, AL, p_mirror, slab, g, k8, bj, lane, step_now, img[wave & 3]);
   }
-  TSTAMP(bx, 7);
+  LSTAMP(bx, 7);
   if (bias_lane) {
     const float t = (float)(step_now + (a.ad.late ? 0 : 1) + a.ad.step_ahead);
     const float alpha = a.ad.lr * sqrtf(1.f - __builtin_amdgcn_exp2f(t * a.ad.log2_b2)) / (1.f - __builtin_amdgcn_exp2f(t * a.ad.log2_b1));
@@ -1720,7 +1720,7 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
     a.ad.m[be] = bm;
     a.ad.v[be] = bv;
   }
-  TSTAMP(bx, 4);
+  LSTAMP(bx, 4);
   // the block's share of the regulariser cost of the NEW weights, for the next launch's epilogue (the other half of ws)
   reg = wave_sum(reg);
   if (lane == 0 && wave < 4) rreg[wave] = reg;
@@ -1729,7 +1729,7 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   if (tid == 0) wsn[blk] = (rreg[0] + rreg[1]) + (rreg[2] + rreg[3]);
   if (blk == 0)
     for (int i = n_blocks + tid; i < EMX_REDUCE_WS; i += NTL) wsn[i] = 0.f;
-  TSTAMP(bx, 5);
+  LSTAMP(bx, 5);
 }
 
 // g[e] = sum over slices (fixed order) of partial[s][e] for the parameter ranges of layers [l0, l1)
