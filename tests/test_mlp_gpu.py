@@ -467,6 +467,38 @@ def test_integer_data_is_exact(L, net_dim, n_neurons, B):
 
 
 @pytest.mark.gpu
+def test_wgrad_adam_local_without_next_batch_and_regulariser(L):
+    """the optional arguments of emx_mlp_wgrad_adam_local left out (no next batch: no gather workgroups; no L2 coefficients): the launch
+    still advances the counters, writes the history row and updates every parameter"""
+    from encodermap_amd.layout import build_layout, init_parameters
+
+    lay = build_layout([64, 2], ["", "tanh", ""], 40)
+    B, n, dev = 300, len(lay.layers), "cuda"
+    g = torch.Generator().manual_seed(2)
+    params = torch.from_numpy(init_parameters(lay, 1)).to(dev)
+    h = [torch.zeros(B, l.n_out, device=dev) for l in lay.layers]
+    delta = [torch.zeros(B, l.n_out, device=dev) for l in lay.layers]
+    plan = L.MlpPlan(lay, params, h, delta, train_rows=B)
+    x = torch.randn(B, 40, generator=g).to(dev)
+    L.mlp_forward(plan, 0, n, x, 0, B)
+    L.mlp_backward(plan, 0, n, (torch.randn(B, 40, generator=g) * 0.01).to(dev), None, lay.n_enc - 1, 0, B)
+    m, v = torch.zeros_like(params), torch.zeros_like(params)
+    step, cursor, hstep = (torch.tensor([k], dtype=torch.int64, device=dev) for k in (7, 3, 7))
+    reg_ws = torch.zeros(2 * L.EMX_REDUCE_WS, device=dev)
+    terms, hist, thist = torch.tensor([1.0, 2.0, 0.0, 0.0], device=dev), torch.zeros(16, device=dev), torch.zeros(16, 4, device=dev)
+    fin = L.make_finish_desc([(reg_ws, L.EMX_REDUCE_WS, 1.0, None, 3, False)], terms, 4, hist, thist, hstep, cursor, step)
+    sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
+    w0 = params.clone()
+    ws = torch.zeros(max(L.mlp_wgrad_adam_local_ws_floats(plan, B), 16), device=dev)
+    L.mlp_wgrad_adam_local(plan, 0, B, ws, fin, m, v, None, 1e-3, 0.9, 0.999, 1e-7, 1.0, reg_ws, sync)
+    torch.cuda.synchronize()
+    assert [int(step), int(cursor), int(hstep)] == [8, 4, 8] and (sync.cpu().numpy() == 0).all()
+    assert float(hist[7]) == 3.0 and float(reg_ws.abs().sum()) == 0.0          # (no L2 coefficients: no regulariser shares)
+    changed = (params != w0).float().mean().item()
+    assert changed > 0.95 and torch.isfinite(params).all()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("net_dim,n_neurons,afs,B", [CASES[i] for i in (0, 1, 2, 4, 5, 7, 8)] + [(128, [128, 128, 2], ["", "tanh", "tanh", ""], 1500)])
 def test_wgrad_adam_local_through_the_abi(L, net_dim, n_neurons, afs, B):
     """emx_mlp_wgrad_adam_local called as a C consumer would (no engine): against emx_mlp_wgrad + emx_adam_step_slices(bookkeeping_done)
