@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import encodermap_amd as em
 from encodermap_amd.engine import SequentialEngine
 INF = float("inf")
-for B, D in ((1024, 128), (1280, 128), (1536, 128), (2048, 128), (2048, 64), (3072, 128), (4096, 128)):
+for B, D in ((1024, 256), (1280, 256), (1536, 256), (1536, 64), (1536, 32)) if os.environ.get("MID") == "2" else ((1536, 128), (1792, 128), (2048, 128), (2048, 64), (2048, 256), (2560, 128)) if os.environ.get("MID") else ((1024, 128), (1280, 128), (1536, 128), (2048, 128), (2048, 64), (3072, 128), (4096, 128)):
     rng = np.random.default_rng(1)
     data = (rng.normal(0, 4, (16, D))[rng.integers(0, 16, 100000)] + rng.normal(0, 1, (100000, D))).astype(np.float32)
     res = []
