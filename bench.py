@@ -3,6 +3,8 @@
 
     python bench.py                                    # the headline: C2, one GPU, 300 steps after 30 warm-up steps
     python bench.py --config C5 --steps 100 --warmup 10
+    python bench.py --gpus N --steps K --warmup W      # no launcher: the script starts torch.distributed.run itself (a child
+                                                       # process, before anything touches the GPU) and relays the JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W [--config C4]
 
@@ -88,8 +90,18 @@ DTYPES = {"blobs": "f32 (split-f16 x3 mfma: 2^-22 operand precision, f32 accumul
 
 
 def git_head():
+    """the commit this tree was built from: EMX_COMMIT, git itself, or -- on the GPU box, which has no .git -- the stamp
+    that __graft_entry__.build() leaves beside the library (.build_commit; "-dirty" when the work tree differed from HEAD)"""
+    if os.environ.get("EMX_COMMIT"):
+        return os.environ["EMX_COMMIT"]
     try:
-        return subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=5).stdout.strip() or None
+        head = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True, timeout=5).stdout.strip()
+        if head:
+            return head
+    except Exception:
+        pass
+    try:
+        return open(os.path.join(ROOT, ".build_commit")).read().strip() or None
     except Exception:
         return None
 
@@ -265,28 +277,39 @@ def _time_launches(fn, launches):
 
 def _counters(name, kernel_key):
     """static per-launch counters of the configuration's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh);
-    returns (counters, source)"""
-    for rnd in ("r03", "r02"):
+    returns (counters, source).  The newest round's file wins; its ``commit`` field is written at profile time (EMX_COMMIT or
+    the build stamp: the GPU box has no .git)."""
+    for rnd in ("r04", "r03", "r02"):
         path = os.path.join("profiles", f"{rnd}_step_counters.json" if name == "C2" else f"{rnd}_{name.lower()}_counters.json")
         try:
             blob = json.load(open(os.path.join(ROOT, path)))
             for kname, c in blob["kernels"].items():
                 if kernel_key in kname:
-                    return c, f"{path} (static: PMC passes over this workload, taken at commit {blob.get('commit', 'of that round')})"
+                    commit = blob.get("commit") or f"not recorded (round {rnd[1:]})"
+                    return c, f"{path} (static: PMC passes over this workload, taken at commit {commit})"
         except Exception:
             continue
     return {}, None
 
 
-def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, bound, limiter, note, algorithmic_bytes):
+def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, roof, bound, limiter, note, algorithmic_bytes, flops_8d=None):
+    """One roofline block.  ``bound`` names what the counters say limits the kernel ("issue": instruction issue / dependent
+    latency; "valu": the vector unit's issue ceiling; "mfma" / "hbm" when one of those roofs binds), ``roof`` the roof that
+    ``peak`` / ``achieved`` / ``frac`` are quoted against (ONE basis per kernel family: executed FLOPs against the dense f16
+    matrix peak for the split-f16 kernels, SURVEY 8d's count against the fp32 peak for the VALU tiles);
+    ``frac_survey_8d`` = SURVEY.md section 8d's figure (f W / t / 157.3 TF, f = 3 Euclidean, 5 periodic) for the all-pairs kernels."""
     c, src = _counters(name, kernel_key)
     valu = c.get("SQ_INSTS_VALU")
-    return {"bound": bound, "achieved": flops_exec / t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops_exec / t / peak,
+    return {"bound": bound, "roof": roof, "achieved": flops_exec / t / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops_exec / t / peak,
+            "frac_basis": ("executed FLOPs (6 per float32 multiply-add on split-f16 operands) / dense f16 matrix peak" if roof == "mfma-f16"
+                           else "SURVEY 8d FLOPs / fp32 vector peak"),
+            "frac_survey_8d": (flops_8d / t / FP32_PEAK) if flops_8d else None,
             "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": src,
             "kernel": kernel, "kernel_us": t * 1e6, "algorithmic_bytes": algorithmic_bytes,
             "hbm_frac_algorithmic": algorithmic_bytes / t / HBM_PEAK,
             "fractions": {"fp32_equivalent": flops_alg / t / FP32_PEAK, "executed": flops_exec / t / peak,
-                          "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None},
+                          "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None,
+                          "valu_busy": c.get("VALUBusy"), "mfma_util": c.get("MfmaUtil")},
             "fp32_equiv_tflops": flops_alg / t / 1e12, "limiter": limiter, "note": note}
 
 
@@ -313,22 +336,22 @@ def kernel_rooflines(name, eng, launches):
         W = D * Bt * (Bt - 1) / 2          # pair-elements per launch (i<->j symmetry exploited)
         abytes = 4 * Bt * (D + 2 * eng.L + eng.L) + 4
         if eng.periodic:
-            sk = _record(name, "sk_tile_kernel (VALU, fixed-point phases)", "sk_tile_kernel", t_sk, 5 * W, 5 * W, FP32_PEAK, "mfma",
+            sk = _record(name, "sk_tile_kernel (VALU, fixed-point phases)", "sk_tile_kernel", t_sk, 5 * W, 5 * W, FP32_PEAK, "valu-fp32", "valu",
                          "VALU issue: the pair loop runs at the measured issue ceiling of the vector unit (profiles/r02_tile_counters.json); "
                          "the fp32 vector peak equals the fp32 matrix peak on this chip",
                          "direct wrapped differences on the VALU: sub, convert, fma per pair-element over the upper triangle; 5 FLOP per "
-                         "pair-element by SURVEY.md section 8d's count for the periodic form", abytes)
+                         "pair-element by SURVEY.md section 8d's count for the periodic form", abytes, flops_8d=5 * W)
         else:
-            sk = _record(name, "sk_tile_f16_kernel", "sk_tile_f16", t_sk, 2 * W, 6 * W, F16_PEAK, "mfma", ISSUE,
+            sk = _record(name, "sk_tile_f16_kernel", "sk_tile_f16", t_sk, 2 * W, 6 * W, F16_PEAK, "mfma-f16", "issue", ISSUE,
                          "Gram tiles on rows split into two f16 planes, VALU sigmoid epilogue (~40 instructions per pair); 2 FLOP per "
-                         "pair-element over the upper triangle (SURVEY.md section 8d), executed three times", abytes)
+                         "pair-element over the upper triangle (SURVEY.md section 8d), executed three times", abytes, flops_8d=3 * W)
         recs.append(sk)
     if cfg["model"] == "encodermap" and (eng.rb, eng.re) == (0, Bt):
         fused = eng._forward()
         t_ch = _time_launches(eng._forward, launches)
         mults = Bt * (sum(k * m for k, m in dims) + (sum(k * m for k, m in dims[lay.n_enc:]) if fused else 0))
         recs.append(_record(name, "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>", "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>",
-                            t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma", ISSUE,
+                            t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma-f16", "issue", ISSUE,
                             ("forward of all layers, auto cost and the decoder's backward pass" if fused else "forward of all layers (+ auto cost)")
                             + " in one launch per 16-row block; weights from the pre-split operand store, activations split in the epilogue; "
                             "algorithmic bytes: the batch in, activations + deltas out as f16 fragments for the weight-gradient kernel, one "
@@ -337,7 +360,7 @@ def kernel_rooflines(name, eng, launches):
         n = len(lay.layers)
         t_ch = _time_launches(lambda: _lib.mlp_forward(eng.plan, 0, n, eng.xin, 0, Bt), launches)
         mults = Bt * sum(k * m for k, m in dims)
-        recs.append(_record(name, "chain_kernel<FWD>", "chain_kernel<FWD>", t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma",
+        recs.append(_record(name, "chain_kernel<FWD>", "chain_kernel<FWD>", t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma-f16", "issue",
                             "launch and dependent-trip latency: 256 rows are 16 row blocks on 16 of 256 CUs; the step is priced by its "
                             "launch count (launches_per_step) and the per-launch floors, DESIGN.md section 4",
                             "dense layers forward, the largest single launch of the ADC step", 4 * Bt * dims[0][0] + 4 * n_par))
@@ -366,19 +389,26 @@ def launches_per_step(eng):
     return int(n1 - n0)
 
 
-def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
-    """N > 1: one child process per rank checks, BEFORE this process touches the GPU, whether an RCCL all-reduce captured in
-    a hipGraph works with this many ranks on this machine (encodermap_amd/_probe_graph_allreduce.py).  Passed on every
-    rank: the data-parallel step runs as one graph, eight steps per replay; failed, or hung until the
-    timeout (the child is killed, its queues go with it): the all-reduce stays eager between two graphs."""
+def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0) -> bool:
+    """N >= 1 ranks over RCCL: one child process per rank checks, BEFORE this process touches the GPU, whether the step with its
+    RCCL all-reduce(s) captured in a hipGraph works with this many ranks on this machine
+    (encodermap_amd/_probe_graph_allreduce.py: a synthetic [scale, all-reduce, add] graph replayed 200 times against the host-side
+    recurrence, then the ENGINE's data-parallel step itself -- the benchmark's layer widths at B = 4096 on a small resident set,
+    40 captured steps, finite losses, identical weights on every rank).  Passed on every rank: the data-parallel step runs as one
+    graph, 32 steps per replay; failed, or hung until the timeout (the child is killed, its queues go with
+    it): the all-reduce stays eager between two graphs."""
     # the children rendezvous among themselves: nothing of the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE makes
     # rank 0 a CLIENT of the launcher's store, which does not listen on the probe's port)
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["EMX_PROBE_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 173)
+    env["EMX_PROBE_MODE"] = mode
     env.setdefault("MASTER_ADDR", "127.0.0.1")
+    env.setdefault("RANK", "0")
+    env.setdefault("WORLD_SIZE", str(world))
+    env.setdefault("LOCAL_RANK", "0")
     try:
         proc = subprocess.Popen([sys.executable, "-m", "encodermap_amd._probe_graph_allreduce"], cwd=ROOT, env=env,
-                                stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                                stdout=subprocess.DEVNULL, stderr=sys.stderr)
     except Exception:
         return False
     try:
@@ -387,6 +417,85 @@ def probe_graph_allreduce(world: int, timeout_s: float = 120.0) -> bool:
         proc.kill()
         proc.wait()
         return False
+
+
+def _free_port() -> int:
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(n_gpus: int, argv) -> int:
+    """``python bench.py --gpus N`` WITHOUT a launcher: this process has not touched the GPU (nothing but argparse has run), so it
+    starts ``python -m torch.distributed.run --nproc-per-node N bench.py ...`` as a child, relays the child's JSON line and
+    returns its exit code (never a re-exec: a process that has initialised the GPU must not be replaced, and this one stays
+    around to relay).  Should the run with the captured all-reduce fail or hang until the timeout, it is repeated ONCE with the
+    eager all-reduce (EMX_DP_GRAPH_ALLREDUCE=0); the line says which form ran (config.allreduce)."""
+    import signal
+
+    timeout_s = float(os.environ.get("EMX_BENCH_LAUNCH_TIMEOUT", "1500"))
+    attempts = [dict()]
+    if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") != "0":
+        attempts.append({"EMX_DP_GRAPH_ALLREDUCE": "0"})
+    code = 1
+    for extra in attempts:
+        env = dict(os.environ, **extra)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+        proc = subprocess.Popen(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=sys.stderr, text=True, start_new_session=True)
+        try:
+            out, _ = proc.communicate(timeout=timeout_s)
+            code = proc.returncode
+        except subprocess.TimeoutExpired:
+            try:
+                os.killpg(proc.pid, signal.SIGKILL)     # (the session this call created: the launcher and its ranks, nothing else)
+            except Exception:
+                proc.kill()
+            out, _ = proc.communicate()
+            code = 124
+        all_lines = (out or "").splitlines()
+        lines = [i for i, ln in enumerate(all_lines) if ln.startswith("{") and '"metric"' in ln]
+        if code == 0 and lines:
+            for i, ln in enumerate(all_lines):
+                if i != lines[-1]:
+                    sys.stderr.write(ln + "\n")      # (anything else the ranks printed: not on stdout, which carries ONE line)
+            sys.stdout.write(all_lines[lines[-1]] + "\n")
+            sys.stdout.flush()
+            return 0
+        sys.stderr.write(f"bench.py: the {n_gpus}-rank run ended with code {code}" + (" and no JSON line" if not lines else "") +
+                         (": repeating it with the eager all-reduce\n" if extra is not attempts[-1] else "\n"))
+    return code or 1
+
+
+def launch_check(args) -> int:
+    """the ranks of ``--gpus N`` as the launcher started them, without any GPU work: rendezvous over gloo, one all-reduce, one
+    line from rank 0.  EMX_BENCH_FAIL_CAPTURED=1 (test hook) makes every rank fail unless the eager all-reduce was forced --
+    which is what self_launch's second attempt does."""
+    import torch
+    import torch.distributed as dist
+
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        return 2
+    forced_eager = os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "0"
+    if os.environ.get("EMX_BENCH_FAIL_CAPTURED") == "1" and not forced_eager:
+        return 3
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    if rank == 0:
+        print("a stray line from a rank", flush=True)      # (must not reach the relayed stdout)
+        print(json.dumps({"metric": "launch_check", "value": float(t), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "config": {"ranks_seen": dist.get_world_size(), "allreduce": "eager (forced)" if forced_eager else "probe decides"}}),
+              flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0
 
 
 def facade_timing(em, cfg, data, device, steps):
@@ -435,11 +544,21 @@ def main():
     ap.add_argument("--one-rank-dp", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL code path (probe, RCCL group, all-reduce) with its one rank -- a self-test, "
                          "not a benchmark configuration")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="self-test of the launcher plumbing WITHOUT a GPU: the ranks meet over gloo, all-reduce one number and rank 0 "
+                         "prints a one-line record (tests/test_host_logic.py)")
     args = ap.parse_args()
     name = args.config
     cfg = CONFIGS[name]
     B = cfg["kw"].get("batch_size", 256)
     D = cfg["D"]
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # (no launcher: become one -- before torch or anything else that could touch the GPU is even imported)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
+    if args.launch_check:
+        raise SystemExit(launch_check(args))
 
     import torch
 
@@ -447,8 +566,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     # C4 / C5 are DEFINED on 8 GPUs as ONE global batch: the objective-preserving row-block partition
     dp_mode = args.dp_mode or ("rowblock" if name in ("C4", "C5") else "replica")
     if cfg["model"] == "adc":
@@ -467,13 +585,14 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         os.environ.setdefault("LOCAL_RANK", "0")
-    # The all-reduces run EAGERLY between the step's graphs unless EMX_DP_GRAPH_ALLREDUCE=1 asks for the captured form (one graph
-    # per step, eight steps per replay): that form has only ever run with a one-rank RCCL group, so it is opt-in until a run
-    # on two or more GPUs has validated it; asked for, it is still taken only if the child-process probe passes on every rank.
+    # The RCCL all-reduce(s) of the step are CAPTURED inside the step's graph (one graph per step, 32 steps per replay) whenever the
+    # child-process probe -- the synthetic graph AND the engine's own data-parallel step, run by one child per rank before this
+    # process touches its GPU -- passes on every rank; otherwise they run eagerly between the step's graphs.
+    # EMX_DP_GRAPH_ALLREDUCE=0 forces the eager form (no probe).  The line records which form ran and the probe's result.
     probe = None
     graph_allreduce = False
-    if multi and backend == "nccl" and os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "1":
-        probe = probe_graph_allreduce(world)
+    if multi and backend == "nccl" and os.environ.get("EMX_DP_GRAPH_ALLREDUCE") != "0":
+        probe = probe_graph_allreduce(world, dp_mode)
         graph_allreduce = probe
     torch.cuda.set_device(device)
     import torch.distributed as dist

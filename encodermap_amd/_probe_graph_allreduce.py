@@ -1,10 +1,13 @@
 """Probe: does an RCCL all-reduce captured inside a hipGraph work on THIS machine with THIS many ranks?
 
 Run as a child process by ``bench.py`` (one child per rank, before the parent touches the GPU; RANK / WORLD_SIZE /
-LOCAL_RANK / MASTER_ADDR come from the launcher, the children meet on their own port).  Exit code 0: a graph holding
-[scale, all_reduce(AVG), add] was captured and replayed 200 times with the right result on every rank.  Anything else --
-an exception, a wrong number, or a hang that the parent ends with its timeout -- means: keep the all-reduce eager
-(engine default).  A hang costs only this child: its queues die with it.
+LOCAL_RANK / MASTER_ADDR come from the launcher, the children meet on their own port).  Exit code 0:
+  (1) a graph holding [scale, all_reduce(AVG), add] was captured and replayed 200 times with the right result on every rank, and
+  (2) the ENGINE's own data-parallel step (EMX_PROBE_MODE: "replica" -- one all-reduce of [gradient | terms] -- or "rowblock" --
+      the latent-gradient all-reduce as well), captured with its collectives inside the step's graphs, ran 40 steps at the
+      benchmark's layer widths and batch with finite losses and bit-identical weights on every rank.
+Anything else -- an exception, a wrong number, or a hang that the parent ends with its timeout -- means: keep the all-reduce
+eager.  A hang costs only this child: its queues die with it.
 """
 import os
 import sys
@@ -56,11 +59,46 @@ def main() -> int:
         ref = [0.5 * m + (r + 1) for r in range(world)]
     torch.cuda.synchronize()
     ok = abs(float(y[0]) - ref[rank]) < 1e-3 * max(1.0, abs(ref[rank])) and bool((y == y[0]).all())
+    if ok and os.environ.get("EMX_PROBE_ENGINE", "1") != "0":
+        ok = engine_stage(rank, world, os.environ.get("EMX_PROBE_MODE", "replica"))
     flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     torch.cuda.synchronize()
     dist.destroy_process_group()
     return 0 if float(flag) == 1.0 else 3
+
+
+def engine_stage(rank: int, world: int, mode: str) -> bool:
+    """the engine's data-parallel step with its collectives captured (bench.py's C2 shape on a small resident set)"""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import encodermap_amd as em
+    from encodermap_amd.engine import DataParallel, SequentialEngine
+
+    class _Ranks(DataParallel):      # (a one-rank group still takes the data-parallel path: the self-test of a one-GPU box)
+        active = True
+
+    SequentialEngine._dp_graph_allreduce = True
+    B, D, rows = 4096, 128, 32768
+    g = torch.Generator(device="cuda")
+    g.manual_seed(17)
+    data = torch.randn(rows, D, generator=g, device="cuda") * 3.0
+    p = em.Parameters(n_steps=40, seed=7, periodicity=float("inf"), batch_size=B, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6))
+    e = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=f"cuda:{torch.cuda.current_device()}", dp=_Ranks(rank, world, mode))
+    eng = e._engine
+    eng.set_data(data)
+    eng.run_steps(40)
+    losses = eng.losses()
+    if not eng._dp_graph_allreduce or len(eng._graph) != 1:      # (the capture itself fell back to the eager form)
+        return False
+    w = eng.w.double()
+    lo, hi = w.clone(), w.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    torch.cuda.synchronize()
+    return bool(np.isfinite(losses).all()) and len(losses) == 40 and bool((lo == hi).all())
 
 
 if __name__ == "__main__":

@@ -487,6 +487,11 @@ class ADCEngine(SequentialEngine):
             _lib.periodic_cost_fwd_bwd(_Bcast(pd_mean), 0, 0, False, self.inp_pair, self.P, INF, "mean_abs", 1.0, 0, B, out[i, 2:3], None,
                                        self.red_ws, B=B)
         o = out.cpu().numpy()
+        # the loop above used the step's batch buffers (feat / cart / inp_pair).  Between two train() calls those hold the HEAD of the
+        # next step -- rows, encoder input, soft-start scale, batch means -- left there by the last optimizer launch (append mode:
+        # run_steps no longer starts with a head launch): put it back
+        if self._prefetch and self.idx_block is not None and self._ring_filled > self._ring_pos:
+            self._gather_current()
         return {"dihedral_cost": o[:, 0], "angle_cost": o[:, 1], "cartesian_cost": o[:, 2]}
 
     # -- inference -------------------------------------------------------------------------------------------

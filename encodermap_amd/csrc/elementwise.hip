@@ -1,6 +1,9 @@
 // Data feed, periodic transforms, row-mean costs, center cost, fused Adam and step bookkeeping (gfx950).
 // Every kernel here is HBM- or launch-latency-bound: rows are walked by whole waves with 16-byte lanes
 // where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
+#include <mutex>
+#include <unordered_map>
+
 #include "emx_common.h"
 #include "cost.h"
 #include "wop.h"
@@ -24,7 +27,37 @@ long long& launch_counter() {
   static long long n = 0;
   return n;
 }
+
+namespace {
+std::mutex g_counters_mu;
+std::unordered_map<const void*, size_t> g_counters_seen;   // pointer -> bytes zeroed
+}  // namespace
+
+int ensure_counters_zeroed(void* words, size_t bytes, hipStream_t stream, const char* who) {
+  if (words == nullptr || bytes == 0) return EMX_OK;
+  std::lock_guard<std::mutex> lock(g_counters_mu);
+  auto it = g_counters_seen.find(words);
+  if (it != g_counters_seen.end() && it->second >= bytes) return EMX_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone)
+    return fail(EMX_EINVAL, "%s: the counter words at %p are new to the library and the stream is capturing -- run the call once outside the "
+                "capture first (a warm-up step), so that the words are zeroed in front of a launch and not on every replay", who, words);
+  if (hipMemsetAsync(words, 0, bytes, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(EMX_EINVAL, "%s: could not zero the counter words at %p (%zu bytes): not device memory?", who, words, bytes);
+  }
+  if (g_counters_seen.size() > 65536) g_counters_seen.clear();   // (a long-lived process that keeps allocating: start over, a memset each)
+  g_counters_seen[words] = bytes;
+  return EMX_OK;
+}
 }  // namespace emx
+
+extern "C" void emx_forget_counters(void* words) {
+  std::lock_guard<std::mutex> lock(emx::g_counters_mu);
+  if (words == nullptr) emx::g_counters_seen.clear();
+  else emx::g_counters_seen.erase(words);
+}
 
 namespace {
 

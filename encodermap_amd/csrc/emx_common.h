@@ -30,6 +30,15 @@ inline int check_launch(const char* what) {
   return EMX_OK;
 }
 
+// Counter words through which workgroups of ONE launch hand work to one another (tickets of a split reduction, arrival counts, the
+// sticky give-up flag): they must be zero before the first launch that uses them, and every launch leaves them at zero again.  The
+// library does not trust its caller with the first part: the first time an entry point is handed a pointer -- per process -- it
+// zeroes the words on the caller's stream in front of its launch (hipMemsetAsync; later calls cost a hash lookup).  Seen for the
+// first time INSIDE a stream capture the memset would become a node of the graph and clear the give-up flag on every replay:
+// that is refused (EMX_EINVAL: call once outside the capture first -- a warm-up step does).  A caller that recycles such memory for
+// something else and hands it back later must zero it again (emx_forget_counters drops the library's note).
+int ensure_counters_zeroed(void* words, size_t bytes, hipStream_t stream, const char* who);
+
 #define EMX_REQUIRE(cond, ...)                             \
   do {                                                     \
     if (!(cond)) return emx::fail(EMX_EINVAL, __VA_ARGS__); \

@@ -494,7 +494,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       if (tid == 0) {
         const unsigned nc = (unsigned)((p_row_end - p_row0 + R - 1) / R);
         const unsigned c = __hip_atomic_fetch_add(&sync[4], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (c == nc - 1u) {
+        if (c == nc - 1u && __hip_atomic_load(&sync[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {   // (after a give-up nothing is reset)
           __hip_atomic_store(&sync[3], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           __hip_atomic_store(&sync[4], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1450,14 +1450,19 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
       LSTAMP(1000, 1);
       if (tid == 0) {
         unsigned spins = 0;
+        bool gave_up = false;
         while (__hip_atomic_load(&sync[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)a.t.n_counted) {
           if (++spins > a.t.spin_limit) {
             __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gave_up = true;
             break;
           }
           __builtin_amdgcn_s_sleep(8);
         }
-        __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (after a give-up the count is left alone: stragglers are still adding to it, and a count that is wrong from now on keeps
+        //  every later launch of a captured run from looking healthy -- sync[2] is sticky and the host checks it wherever a
+        //  result leaves the engine)
+        if (!gave_up) __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (a.t.cursor) *a.t.cursor += 1;
         *a.t.opt_step = st + 1;
       }
@@ -2079,10 +2084,32 @@ struct TilesHost {
   const emx_latent_grad* latent;
 };
 
+int device_cus();
+
 template <bool FAST, int NCH, int KIND = 0>
 int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
   int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND>), lds, b.who);
   if (rc) return rc;
+  // The launch holds in-launch waits: a tile workgroup waits until ALL chain workgroups have published the latent rows, and (join)
+  // every chain workgroup waits until ALL tile workgroups have reported.  Chain workgroups are dispatched first (lower indices), so
+  // progress needs every chain workgroup AND at least one tile workgroup resident at once -- asked of the runtime for THIS
+  // instantiation with THIS launch's LDS, on THIS device (a partitioned device, a larger batch through the C ABI): otherwise the
+  // caller gets EMX_EUNSUPPORTED and keeps the separate launches.
+  {
+    static thread_local const void* cached_fn = nullptr;
+    static thread_local size_t cached_lds = 0;
+    static thread_local int cached_blocks = 0;
+    const void* fn = reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND>);
+    if (cached_fn != fn || cached_lds != lds) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_tiles_kernel<2, FAST, NCH, KIND>, NTC, lds) != hipSuccess) nb = 0;
+      cached_fn = fn, cached_lds = lds, cached_blocks = nb;
+    }
+    const long capacity = (long)cached_blocks * device_cus();
+    if ((long)tr.n_chain + 1 > capacity)
+      return emx::fail(EMX_EUNSUPPORTED, "%s: %d dense-layer workgroups + one tile workgroup do not fit the device at once (%d per CU x %d CUs): "
+                       "the tiles cannot ride in this launch", b.who, tr.n_chain, cached_blocks, device_cus());
+  }
   hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH, KIND>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
                      b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a, tr);
   return emx::check_launch("mlp chain kernel (forward + cost + backward, all-pairs tiles aboard)");
@@ -2194,6 +2221,8 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   }
   EMX_REQUIRE(row_begin == 0 && row_end == tiles->B, "%s: the tiles run over the whole batch (rows [0, %d))", who, tiles->B);
   EMX_REQUIRE(tiles->zpub && tiles->sync, "%s: null pointer argument (tile role)", who);
+  rc = emx::ensure_counters_zeroed(tiles->sync, (tiles->latent ? 8 : 4) * sizeof(unsigned), (hipStream_t)stream, who);
+  if (rc) return rc;
   emx::sk::TileRole tr{};
   int vblocks = 0, nch = 0, kind = 0;
   bool fast = false;
@@ -2207,7 +2236,7 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   tr.join = tiles->latent ? 1 : 0;
   // persistent tile workgroups: one per CU beside its chain workgroup (more would wait for the chain workgroups to leave), each
   // walking its share of the tile pairs -- in the XCD-aware order 32 per XCD list (pairs k, k + 32, ... of the list)
-  static const int per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : 32;
+  static const int per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : std::max(1, device_cus() / 8);
   if (tr.a.xcd_nbg > 0) tr.n_tile_wgs = 8 * std::min(per_xcd, tr.a.xcd_nbg * (tr.a.xcd_nbg + 1) / 2);
   else tr.n_tile_wgs = std::min(8 * per_xcd, (vblocks + 1) / 2);
   const size_t lds = std::max((size_t)b.lds, (size_t)emx::sk::TILE_ROLE_LDS_BYTES);
@@ -2361,7 +2390,8 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 }
 
 
-static int device_cus() {
+namespace {
+int device_cus() {
   static int n = [] {
     int dev = 0, v = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
@@ -2369,6 +2399,7 @@ static int device_cus() {
   }();
   return n;
 }
+}  // namespace
 
 // weight-gradient workgroups of the launch, spare workgroups for the gather; 0 if the tail does not fit
 static int wgrad_adam_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* tiles_out, int* slices_out, int* gather_out) {
@@ -2408,6 +2439,10 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
   int rc = check_desc(desc, who);
   if (rc) return rc;
   EMX_REQUIRE(params && aop && ws && m && v && reg_ws && mirror && sync && finish, "%s: null pointer argument", who);
+  {
+    const int rz = emx::ensure_counters_zeroed(sync, 4 * sizeof(unsigned), (hipStream_t)stream, who);
+    if (rz) return rz;
+  }
   EMX_REQUIRE(finish->hstep && finish->cursor && finish->counter2, "%s: the epilogue's counters (history step, batch cursor, optimizer step) are required", who);
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "%s: bad rows", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);
@@ -2514,6 +2549,10 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   int rc = check_desc(desc, who);
   if (rc) return rc;
   EMX_REQUIRE(params && aop && m && v && reg_ws && mirror && sync && finish, "%s: null pointer argument", who);
+  {
+    const int rz = emx::ensure_counters_zeroed(sync, (4 + 1024) * sizeof(unsigned), (hipStream_t)stream, who);
+    if (rz) return rz;
+  }
   EMX_REQUIRE(finish->hstep && finish->cursor && finish->counter2, "%s: the epilogue's counters (history step, batch cursor, optimizer step) are required", who);
   EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "%s: bad rows", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);

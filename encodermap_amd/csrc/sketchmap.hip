@@ -1371,6 +1371,10 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       // one launch (kmode 3: the last workgroup of a tile adds the shares and runs the epilogue; the tickets live behind kpart in the
       // caller's workspace, zero before the first use) -- or, EMX_SK_KSPLIT_TWO=1, the two launches it replaces (kmode 1, 2)
       static const bool two = getenv("EMX_SK_KSPLIT_TWO") && atoi(getenv("EMX_SK_KSPLIT_TWO")) == 1;
+      if (!two) {   // (the tickets of the one-launch form: zeroed by the library in front of the first launch that sees this workspace)
+        const int rz = emx::ensure_counters_zeroed(b.ktickets, (size_t)KSPLIT_BLOCKS * sizeof(unsigned), st, "emx_sketchmap_tiles (split reduction)");
+        if (rz) return rz;
+      }
       for (int mode = two ? 1 : 3; mode <= (two ? 2 : 3); ++mode) {
         b.kmode = mode;
         const dim3 gk(mode == 2 ? pl.ntiles : pl.ntiles * ksplit);

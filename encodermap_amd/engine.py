@@ -253,6 +253,8 @@ class SequentialEngine:
         self._perm_pos = 0                                                   # ... and how much of it is used up
         self._pending = None
         self._ring_pos = self._ring_filled = 0                               # (the index block starts over: run_steps)
+        if self.idx_block is not None:
+            self.idx_block.zero_()     # (indices of the OLD set must not be dereferenced by a warm replay that runs ahead of the filled part)
 
     def draw_index_block(self, n_batches: int) -> torch.Tensor:
         """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes.  Every pass is one
@@ -346,7 +348,7 @@ class SequentialEngine:
                         _lib.mlp_forward_backward_tiles_join(self.plan, 0, n, self.xin, 0, self.B, cost, 0, self.xb, p.dist_sig_parameters, self.sk_ws,
                                                              self.split_ws, self.zpub, self.sk_sync, lay.n_enc - 1, self._sk.grad,
                                                              periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
-                        self._tiles_ran = self._bwd_ran = True
+                        self._tiles_ran = self._bwd_ran = self._waits_used = True
                         return True
                     except _lib.EmxError as exc:
                         if not exc.unsupported:
@@ -356,7 +358,7 @@ class SequentialEngine:
                     _lib.mlp_forward_backward_tiles(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
                                                     self.sk_ws, self.split_ws, self.zpub, self.sk_sync,
                                                     periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
-                    self._tiles_ran = True
+                    self._tiles_ran = self._waits_used = True
                     return True
                 except _lib.EmxError as exc:
                     if not exc.unsupported:
@@ -416,13 +418,24 @@ class SequentialEngine:
         return self.split_ws is not None and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1536"))
 
     def check_sync(self) -> None:
-        """raises if a tile workgroup of a fused launch ever gave up waiting for the latent rows (emx.h: sync[2])"""
-        if int(self.wg_sync[2].item()) != 0:
-            raise _lib.EmxError("a weight-gradient workgroup gave up waiting for the others inside emx_mlp_wgrad_adam: the results of this "
-                                "run are invalid (set EMX_TAIL_ADAM=0 and report)")
-        if int(self.sk_sync[2].item()) != 0:
-            raise _lib.EmxError("a tile workgroup of the fused dense-layer launch gave up waiting for the latent rows: the results of "
-                                "this run are invalid (set EMX_OVERLAP_TILES=0 and report)")
+        """Raises if a wait inside one of the merged launches ever gave up (include/emx.h: the sticky word 2 of their counters): the
+        tile / dense-layer workgroups of emx_mlp_forward_backward_tiles[_join] (``sk_sync``), the epilogue workgroup of
+        emx_mlp_wgrad_adam_local or the slice workgroups of emx_mlp_wgrad_adam (``wg_sync``).  A give-up never hangs, but the step it
+        happened in -- and every step after it -- worked on incomplete sums.  Called wherever a result leaves the engine (losses,
+        weights, encodings, checkpoints); one small device read, and only for engines whose step plan contains such a wait."""
+        if not self._waits_used:
+            return
+        wg, sk = (int(v) for v in torch.stack([self.wg_sync[2], self.sk_sync[2]]).tolist())
+        if wg != 0:
+            raise _lib.EmxError("a workgroup of the step's last launch (emx_mlp_wgrad_adam_local / emx_mlp_wgrad_adam) gave up waiting for the "
+                                "others: the results of this run are invalid (set EMX_LOCAL_WGRAD=0 and EMX_TAIL_ADAM=0 for the separate "
+                                "launches and report)")
+        if sk != 0:
+            raise _lib.EmxError("a workgroup of the fused dense-layer launch gave up waiting (tile workgroups for the latent rows, or "
+                                "dense-layer workgroups for the tiles' sums): the results of this run are invalid (set EMX_OVERLAP_TILES=0 / "
+                                "EMX_JOIN_BWD=0 for the separate launches and report)")
+
+    _waits_used = False   # a launch with an in-launch wait has been issued by this engine (check_sync has something to check)
 
     def _dealt(self) -> bool:
         """data parallel over row blocks with the all-pairs tiles dealt to the ranks (DataParallel mode "rowblock")"""
@@ -557,13 +570,13 @@ class SequentialEngine:
                 p = self.p
                 _lib.mlp_wgrad_adam_local(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0,
                                           self.red_ws2, self.wg_sync, next_batch=self._next_batch())
-                self._tail_ran = True
+                self._tail_ran = self._waits_used = True
                 return
             if self._tail_fits():
                 p = self.p
                 _lib.mlp_wgrad_adam(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7,
                                     1.0, self.red_ws2, self.wg_sync, next_batch=self._next_batch())
-                self._tail_ran = True
+                self._tail_ran = self._waits_used = True
                 return
         elif self._dp_late_bookkeeping():
             # the rank's shares of the cost terms, summed by the extra workgroup: they travel in the same all-reduce as the
@@ -639,6 +652,12 @@ class SequentialEngine:
         on the same stream, one graph for Adam + bookkeeping."""
         self._graph_multi = None
         self._graph_wrap = None
+        # the capture replays its largest graph once (below): up to _graph_steps steps from the current position, restored afterwards.
+        # Those replays WRITE history rows and READ the index block that far ahead -- make both exist: room in the history, and
+        # valid row indices in the part of the index block this call has not filled (a smaller training set after set_data)
+        ahead = max(self._multi_sizes(), default=1) + 2
+        if int(self.hstep_host()) + ahead > self.history_capacity:
+            self._grow_history(int(self.hstep_host()) + ahead)
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream())
         saved = [t.clone() for t in self._state_tensors()]
@@ -890,18 +909,19 @@ class SequentialEngine:
     def losses(self, start: int = 0) -> np.ndarray:
         """Total loss per executed step from step ``start`` on (synchronises; only that tail crosses PCIe)."""
         torch.cuda.synchronize(self.device)
-        if self._tiles_ran or self._tail_ran:
-            self.check_sync()
+        self.check_sync()
         return self.history[start: self._hstep_host].cpu().numpy()
 
     def last_loss(self) -> float:
         """Loss of the last executed step: ONE float crosses PCIe (what a summary step needs, autoencoder.train)."""
         if self._hstep_host <= 0:
             raise Exception("no step has run yet")
+        self.check_sync()
         return float(self.history[self._hstep_host - 1].item())   # (.item() synchronises with the stream)
 
     def loss_terms(self, start: int = 0) -> dict:
         torch.cuda.synchronize(self.device)
+        self.check_sync()
         th = self.term_history[start: self._hstep_host].cpu().numpy()
         return {name: th[:, i] for i, name in enumerate(self.TERM_NAMES)}
 
@@ -913,6 +933,7 @@ class SequentialEngine:
         """Layers [l0, l1) on an arbitrary number of rows (temporary activation buffers)."""
         lay = self.layout
         n = x_dev.shape[0]
+        self.check_sync()      # (the weights this pass reads are a result of the training run)
         h = [torch.empty(n, l.n_out, dtype=torch.float32, device=self.device) if l0 <= i < l1 else None
              for i, l in enumerate(lay.layers)]
         plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers), mirror=self.plan.mirror)
@@ -977,6 +998,7 @@ class SequentialEngine:
 
     # -- state ---------------------------------------------------------------------------------------
     def get_weights(self) -> list:
+        self.check_sync()
         return unpack_weights(self.layout, self.w.cpu().numpy())
 
     def set_weights(self, arrays: Sequence[np.ndarray]) -> None:
@@ -985,6 +1007,7 @@ class SequentialEngine:
 
     def state_dict(self) -> dict:
         torch.cuda.synchronize(self.device)
+        self.check_sync()
         return {"w": self.w.cpu().numpy(), "m": self.m.cpu().numpy(), "v": self.v.cpu().numpy(),
                 "step": np.int64(self.step.item())}
 

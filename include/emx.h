@@ -10,10 +10,11 @@
  *   - every pointer is a DEVICE pointer owned by the caller (row-major float32 unless stated), except
  *     `const float sig[6]` / scalars, which are host values copied at launch;
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued asynchronously on it, nothing
- *     synchronises, allocates or frees, so every entry point is legal inside a hipGraph capture;
+ *     synchronises, allocates or frees, so every entry point is legal inside a hipGraph capture (one exception: the FIRST call
+ *     that hands the library a set of counter words must run outside a capture, see "counter words");
  *   - return value 0 = launched, negative = rejected before any launch (bad argument, unsupported shape);
  *     emx_last_error() returns the thread-local message of the last rejection;
- *   - re-entrant, no global mutable state; one host thread per GPU/rank is the intended use;
+ *   - re-entrant; the only global mutable state are the launch count and the note of which counter words were zeroed (mutex); one host thread per GPU/rank is the intended use;
  *   - results are deterministic run to run: no float atomics, fixed-order two-pass reductions.
  *
  * Row-block arguments (`row_begin`, `row_end`) implement the data-parallel partition of SURVEY.md section
@@ -52,6 +53,15 @@ const char* emx_target_arch(void);
  * launch-bound configuration is priced by (bench.py: launches_per_step; the reference's train_step, models.py:3367-3401, is
  * ~10^2 TensorFlow op launches) */
 int64_t emx_launch_count(void);
+/* Counter words.  Some launches hand work from workgroup to workgroup INSIDE the launch (tickets of a split reduction, arrival
+ * counts, a sticky give-up flag): the `sync` arguments below and the first 2 KB of the all-pairs workspace.  They must be zero before
+ * the first such launch and every launch leaves them at zero (the give-up flag excepted).  The library does not rely on the caller
+ * for that: the first time an entry point is handed such a pointer -- per process -- it zeroes the words itself on the caller's
+ * stream, in front of its launch.  That first sight must not happen inside a stream capture (EMX_EINVAL: the memset would become a
+ * graph node and clear the give-up flag on every replay) -- run the call once eagerly first, as a warm-up step does.  A caller
+ * that recycles such memory for something else and hands it back later zeroes it itself or calls emx_forget_counters(ptr)
+ * (NULL: forget all), after which the next call zeroes it again. */
+void emx_forget_counters(void* words);
 
 /* ------------------------------------------------------------------------------------------------ *
  * K1/K2  sketch-map sigmoid pairwise-distance cost, forward + gradient wrt the latent
@@ -72,9 +82,10 @@ int64_t emx_launch_count(void);
  *   *center_loss = center_scale / (B*L) * sum_{i in rows} sum_l z_il^2      (skipped if center_loss == NULL)
  *   dZ[i,:] (rows in the block only) = d(dist + center)/dz_i of the FULL-batch loss; pairs with dl == 0
  *   contribute zero gradient (the reference's mask, distances.py:247-253).
- *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes, ZERO-INITIALISED ONCE by the caller before its first use (small batches
- *   of long rows split a tile's reduction over workgroups of ONE launch: the last of a tile's workgroups adds their shares and runs
- *   the epilogue; their ticket words are the first 2 KB of ws, whatever (B, L), and are left at zero by every launch).
+ *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes.  Small batches of long rows split a tile's reduction over workgroups
+ *   of ONE launch: the last of a tile's workgroups adds their shares and runs the epilogue; their ticket words are the first 2 KB of
+ *   ws, whatever (B, L).  The LIBRARY zeroes them in front of the first launch that sees this pointer (see "counter words" below)
+ *   and every launch leaves them at zero.
  * ------------------------------------------------------------------------------------------------ */
 size_t emx_sketchmap_ws_bytes(int B, int L);
 int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L,
@@ -420,8 +431,10 @@ int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const floa
  *   rows [row_begin, row_end) must be the whole batch [0, B); X / D / ldx describe the batch rows, periodicity / data_span as for
  *   emx_sketchmap_tiles.  Euclidean X (periodicity INFINITY): split_ws = their split planes (emx_sketchmap_split / emx_next_batch),
  *   the Gram tiles of the f16 matrix cores.  Periodic X: the 32 x 32 VALU tiles on the rows themselves (batches of up to 512 rows); zpub: B x 2 floats of scratch for the published latent rows; sync: 4
- *   uint32, ZEROED ONCE by the caller (the launch leaves [0] and [1] at zero; [2] != 0 afterwards: a tile workgroup gave up waiting
- *   for the latent -- the results of that launch are invalid).
+ *   uint32 counter words (zeroed by the library at first sight, see "counter words"; the launch leaves [0] and [1] at zero; [2] != 0
+ *   afterwards: a tile workgroup gave up waiting for the latent -- the results of that launch and of every later one are invalid).
+ *   Every dense-layer workgroup and at least one tile workgroup must be resident at once (asked of the runtime for the launch's
+ *   instantiation and LDS on the current device): EMX_EUNSUPPORTED otherwise.
  * EMX_EUNSUPPORTED outside what the tile role is built for (latent width 2; Euclidean rows of 32 / 64 / 128 / 256 features -- up to 128
  * with sigmoid exponents outside the (a, b) = (12, 6 | 2, 6) family; periodic batches of up to 512 rows; LDS) -- then use emx_mlp_forward_backward + emx_sketchmap_tiles. */
 int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
@@ -436,7 +449,8 @@ int emx_mlp_forward_backward_tiles(const emx_mlp_desc* desc, float* params, cons
  * (emx_sketchmap_describe on sk_ws).  In front of the epilogue that forms dh of the latent layer every dense-layer workgroup waits
  * -- one lane polls -- until the last tile workgroup has reported, collects its rows of that gradient as emx_mlp_backward's `latent`
  * join does (same order of additions) and carries on down the encoder from the images it still holds in LDS.
- *   sync: 8 uint32 zeroed once ([3] all tile workgroups done, [4] dense-layer workgroups through: left at zero by the launch).
+ *   sync: 8 uint32 counter words, zeroed by the library at first sight ([3] all tile workgroups done, [4] dense-layer workgroups
+ *   through: left at zero by the launch; [2] sticky: a wait gave up).
  *   Same results as emx_mlp_forward_backward_tiles (bwd_begin = latent_layer + 1, dbelow) followed by emx_mlp_backward(layers
  *   [layer_begin, latent_layer + 1), dtop = dbelow, latent) to float32 rounding of the latent layer's image (the one launch forms
  *   it in its epilogue, the two in the second launch's staging). */
@@ -477,7 +491,7 @@ int emx_mlp_wgrad_slices(int n_rows);
  *   finish: required, with hstep, cursor and counter2 (= the optimizer's step counter, read as `step`); the cursor and the
  *     optimizer step are advanced by the launch's last workgroup.
  *   reg_ws: >= EMX_REDUCE_WS floats, receives the regulariser shares of the NEW weights (as bookkeeping_done = 1).
- *   sync: four uint32, zeroed ONCE by the caller; the launch leaves [0], [1], [3] zero again.  [2] != 0: a wait inside the
+ *   sync: four uint32 counter words (zeroed by the library at first sight); the launch leaves [0], [1], [3] zero again.  [2] != 0: a wait inside the
  *     launch ran out (results of that step are undefined; never expected).
  * Every weight-gradient workgroup must be resident at once: emx_mlp_wgrad_adam_fits says whether that holds on the current
  * device for this network, batch and `next` (1) or the caller has to use the two launches (0); emx_mlp_wgrad_adam itself fails
@@ -499,7 +513,8 @@ int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params
  *     epilogue of a launch reads the half its predecessor wrote while the launch writes the other.  A `finish` job whose
  *     src == reg_ws sums that half.  At start-up (and whenever the weights are set from outside) fill BOTH halves
  *     (emx_l2_partials on reg_ws and on reg_ws + EMX_REDUCE_WS).
- *   sync: 4 + 1024 uint32 zeroed once by the caller; the launch leaves [1] and [4 ..] zero again, [2] != 0: the epilogue gave up waiting.
+ *   sync: 4 + 1024 uint32 counter words (zeroed by the library at first sight); the launch leaves [1] and [4 ..] zero again, [2] != 0
+ *     (sticky): the epilogue gave up waiting -- the count is then left as it is, and this and every later step are invalid.
  *   ws: emx_mlp_wgrad_adam_local_ws_floats(desc, n_rows) floats (0 for small batches: ws may be NULL).  Batches of more than 512
  *     rows split the rows of a block over up to four workgroups (the launch is bound by the bytes a CU can have in flight, so by
  *     the number of CUs at work): each leaves its share in ws, the LAST to arrive adds them in the order of the parts.

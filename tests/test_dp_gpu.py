@@ -178,3 +178,30 @@ def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
     assert line["value"] == pytest.approx(batch * line["steps_per_sec"], rel=1e-6)
     assert line["dtype"].startswith("f32") and line["roofline_all_pairs"]["kernel"] == "sk_tile_f16_kernel"
     assert all(np.isfinite(v) for v in line["loss_first_last"]) and "cpu_baseline" not in line
+
+
+def test_bench_without_a_launcher_and_the_probe_decides(tmp_path):
+    """(1) ``python bench.py --gpus 2`` with NO launcher and no rank environment -- the form the driver uses for one GPU -- starts its
+    own ranks (two on this one GPU through the self-test hooks) and relays one line.  (2) The data-parallel path over RCCL with the
+    one rank this box allows: the child-process probe (synthetic graph + the engine's captured data-parallel step) decides by
+    itself that the all-reduce is captured in the step's graph -- no environment variable asks for it."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    clean = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "EMX_DP_GRAPH_ALLREDUCE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8"], cwd=str(tmp_path),
+                       env=dict(clean, EMX_BENCH_ONE_DEVICE="1", EMX_BENCH_BACKEND="gloo"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["config"]["global_batch"] == 2 * 4096
+    assert line["roofline"]["bound"] in ("issue", "valu", "hbm", "mfma") and line["roofline"]["limiter"]
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--one-rank-dp", "--steps", "64", "--warmup", "32", "--no-cpu-baseline"],
+                       cwd=str(tmp_path), env=dict(clean, MASTER_PORT=str(_free_port())), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["graph_allreduce_probe"] is True and line["config"]["allreduce"] == "captured in the step graph"
+    assert line["config"]["backend"] == "nccl" and all(np.isfinite(v) for v in line["loss_first_last"])

@@ -276,7 +276,7 @@ def test_library_exports_every_declared_symbol():
     from encodermap_amd import _lib
 
     header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "emx.h")).read(), flags=re.S)
-    declared = set(re.findall(r"^(?:int|int64_t|size_t|const char\*)\s+(emx_\w+)\s*\(", header, re.M))
+    declared = set(re.findall(r"^(?:int|int64_t|size_t|void|const char\*)\s+(emx_\w+)\s*\(", header, re.M))
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     if not os.path.isfile(_lib.LIB_PATH):
         pytest.skip("libemx.so not built (run __graft_entry__.build())")
@@ -324,3 +324,36 @@ def test_torsion_table_far_sides_and_bit_layout():
         TorsionTable(A, bonds[1:], cq[:1])
     top = AllAtomTopology(xyz, bonds, cq, sq)
     assert (top.n_central, top.n_side) == (len(cq), len(sq)) and top.table.n_torsions == len(cq) + len(sq)
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """``python bench.py --gpus 2`` the way the driver calls it for one GPU -- no launcher, no environment: the script must start
+    torch.distributed.run itself (a child process; nothing has touched a GPU), relay exactly ONE JSON line on stdout and the exit
+    code, and repeat the run once with the eager all-reduce when the first attempt fails (--launch-check: the ranks meet over gloo
+    and do no GPU work, so this runs on the build box)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "EMX_DP_GRAPH_ALLREDUCE")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check", "--steps", "7", "--warmup", "3"],
+                       cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 3 and line["value"] == 3.0
+    assert line["config"]["ranks_seen"] == 2 and line["config"]["allreduce"] == "probe decides"
+    assert "a stray line from a rank" in r.stderr          # (relayed, but not on stdout)
+    # first attempt fails on every rank -> second attempt with the eager all-reduce forced
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], cwd=str(tmp_path),
+                       env=dict(env, EMX_BENCH_FAIL_CAPTURED="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["config"]["allreduce"] == "eager (forced)" and "repeating it with the eager all-reduce" in r.stderr
+    # both attempts fail: the exit code is relayed, stdout stays empty
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], cwd=str(tmp_path),
+                       env=dict(env, EMX_BENCH_FAIL_CAPTURED="1", EMX_DP_GRAPH_ALLREDUCE="0", WORLD_SIZE="3", RANK="0"), capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode != 0 and r.stdout.strip() == ""

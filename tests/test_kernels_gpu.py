@@ -569,6 +569,62 @@ def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
 
 
+def test_counter_words_are_zeroed_by_the_library(L):
+    """The split reduction of the all-pairs pass keeps one ticket word per tile in the first 2 KB of the caller's workspace
+    (include/emx.h, "counter words").  The library does not trust the caller to have zeroed them: a workspace FULL OF GARBAGE must
+    give the same result as a zeroed one -- the library zeroes the words in front of the first launch that sees the pointer and
+    every launch leaves them at zero -- also on the second and third call; a pointer the library has been told to forget is
+    zeroed again; and a first sight inside a stream capture is refused, not silently turned into a per-replay memset."""
+    from encodermap_amd import _lib
+
+    B, Dd, Ld, sig = 256, 2850, 2, (80.0, 10, 5, 1, 2, 5)      # the ADC model's pair-distance rows: 10 tiles x 16 workgroups
+    rng = np.random.default_rng(3)
+    x, z = make_xz(rng, B, Dd, Ld, INF, sig[0] / math.sqrt(2 * Dd))
+    X, Z = dev(x), dev(z)
+    split = torch.zeros(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
+    L.sketchmap_split(X, split)
+    n_ws = L.sketchmap_ws_bytes(B, Ld) // 4
+
+    def run(ws):
+        dist, cen = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+        dZ = torch.full((B, Ld), float("nan"), device="cuda")
+        L.sketchmap_tiles(X, Z, INF, sig, 0, B, ws, split)
+        L.sketchmap_finish(B, Dd, Z, sig, 500.0, 1e-4, 0, B, dist, cen, dZ, ws)
+        return float(dist), dZ.cpu().numpy()
+
+    clean = run(torch.zeros(n_ws, dtype=torch.float32, device="cuda"))
+    loss_o, _ = D.sketchmap_fwd_bwd(x, z, INF, sig, 500.0, 0, B)
+    assert clean[0] == pytest.approx(loss_o, rel=1e-5)
+    dirty_ws = torch.randint(1, 2 ** 31 - 1, (n_ws,), dtype=torch.int32, device="cuda").view(torch.float32)
+    for _ in range(3):
+        got = run(dirty_ws)
+        assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
+    assert int(dirty_ws[:512].view(torch.int32).abs().max()) == 0          # the tickets are back at zero
+    # recycled memory: garbage again at the same address, the library told to forget it
+    dirty_ws.view(torch.int32).fill_(12345)
+    _lib.load().emx_forget_counters(dirty_ws.data_ptr())
+    got = run(dirty_ws)
+    assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
+    # first sight inside a capture: refused
+    fresh = torch.randint(1, 1000, (n_ws,), dtype=torch.int32, device="cuda").view(torch.float32)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    dummy = torch.zeros(4, device="cuda")
+    refused = None
+    with torch.cuda.stream(s):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            dummy.add_(1.0)
+            try:
+                L.sketchmap_tiles(X, Z, INF, sig, 0, B, fresh, split)
+                refused = False
+            except _lib.EmxError as exc:
+                refused = "capturing" in str(exc)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    assert refused is True
+
+
 def test_periodic_cost_batch_equals_separate_calls(L):
     """emx_periodic_cost_batch == one emx_periodic_cost_fwd_bwd per job (partials, gradients: bit for bit), jobs of different
     widths, variants and modes (atan2 output with a joined gradient, broadcast prediction without a gradient, long rows)."""

@@ -46,7 +46,12 @@ try:
     commit = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
 except Exception:
     commit = None
-doc = {"workload": f"bench.py --config {cfg}: one training step = the launches below", "commit": commit or os.environ.get("EMX_COMMIT"),
+if not commit:      # (the GPU box has no .git: the stamp __graft_entry__.build() left beside the library)
+    try:
+        commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip() or None
+    except Exception:
+        commit = None
+doc = {"workload": f"bench.py --config {cfg}: one training step = the launches below", "commit": os.environ.get("EMX_COMMIT") or commit,
        "command": f"bash tools/run_pmc_step.sh <tag> {cfg}: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --config {cfg} "
                   "--steps 40 --warmup 8 --no-cpu-baseline --no-facade (one pass per counter set; medians over the launches)",
        "corrections": "FETCH_SIZE (KB) doubled, WRITE_SIZE (KB) as reported (MI355X_MICROARCH.md, HBM section); durations are those under "
