@@ -182,7 +182,8 @@ class Autoencoder:
         if loss == "emap_cost":
             return list(self._loss_names)
         if loss in ("reconstruction_loss", "mse"):
-            raise NotImplementedError(f"loss '{loss}' is not part of the HIP engine; use 'emap_cost'.")
+            # (autoencoder.py:948-958: the plain mean-square reconstruction error, nothing else -- engine._PlainReconstruction)
+            return ["reconstruction_loss"]
         raise ValueError(f"loss argument needs to be `reconstruction_loss`, `mse` or `emap_cost`. You provided '{loss}'.")
 
     @classmethod

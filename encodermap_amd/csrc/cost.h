@@ -32,9 +32,12 @@ inline void fill_cost_scalars(CostArgs& a, int B, int n, int ldy, int ldt, int o
   a.periodic_output = periodic_output;
   a.n = n;
   a.variant = variant;
-  a.wrap = std::isfinite(periodicity);
-  a.period = periodicity;
-  a.out_scale = (a.wrap && periodicity != COST_TWO_PI) ? periodicity / COST_TWO_PI : 1.f;
+  // periodicity < 0 (finite): the OUTPUT's period is |periodicity| (the atan2 of a periodic output is scaled to it) but the
+  // differences are plain, not wrapped -- reconstruction_loss / "mse" behind PeriodicOutput (loss_functions.py:541-547)
+  const float per = std::fabs(periodicity);
+  a.wrap = std::isfinite(periodicity) && periodicity > 0.f;
+  a.period = per;
+  a.out_scale = (std::isfinite(per) && per != COST_TWO_PI) ? per / COST_TWO_PI : 1.f;
   const double denom = (variant == EMX_MEAN_NORM) ? (double)B : (double)B * n;
   a.gnorm = (float)(coef / denom);
 }

@@ -122,6 +122,26 @@ class DataParallel:
         return seed if self.mode == "rowblock" else seed * 1000003 + self.rank
 
 
+class _PlainReconstruction:
+    """``Parameters.loss`` = "reconstruction_loss" / "mse" (parameters.py:560-566: "will try to train output == input";
+    loss_functions.py:541-547: ``reduce_mean(square(y_pred - y_true))``, nothing else -- SequentialModel.train_step,
+    models.py:3385-3386, sums the compiled loss functions only, so neither the L2 regulariser nor the center / distance terms take
+    part): the engine's parameter view with the auto cost as the plain mean square at scale 1 and every other term switched off."""
+
+    _OVERRIDES = dict(auto_cost_scale=1.0, auto_cost_variant="mean_square", center_cost_scale=None, distance_cost_scale=None, l2_reg_constant=0.0)
+
+    def __init__(self, p):
+        object.__setattr__(self, "_p", p)
+
+    def __getattr__(self, name):
+        if name in _PlainReconstruction._OVERRIDES:
+            return _PlainReconstruction._OVERRIDES[name]
+        return getattr(object.__getattribute__(self, "_p"), name)
+
+    def __setattr__(self, name, value):
+        setattr(object.__getattribute__(self, "_p"), name, value)
+
+
 class SequentialEngine:
     """Weights, optimizer state, buffers and the captured step of Autoencoder / EncoderMap."""
 
@@ -131,9 +151,15 @@ class SequentialEngine:
     def __init__(self, input_dim: int, p, *, with_distance: bool, device: str = "cuda:0",
                  weights: Optional[Sequence[np.ndarray]] = None, dp: Optional[DataParallel] = None,
                  use_graph: bool = True, history_capacity: Optional[int] = None):
+        self.plain_loss = getattr(p, "loss", "emap_cost") in ("reconstruction_loss", "mse")
+        if self.plain_loss:
+            p, with_distance = _PlainReconstruction(p), False
         self.with_distance = bool(with_distance)
         self.periodicity = float(p.periodicity)
         self.periodic = self.periodicity < INF
+        # the auto cost's differences: wrapped into the period -- or, for the plain reconstruction loss behind PeriodicOutput, NOT
+        # (include/emx.h, emx_auto_cost: a negative periodicity scales the atan2 to the period and leaves the differences alone)
+        self._cost_periodicity = (-self.periodicity if self.plain_loss else self.periodicity) if self.periodic else INF
         self.D = int(input_dim)
         self._init_common(2 * self.D if self.periodic else self.D, p, device, weights, dp, use_graph, history_capacity)
 
@@ -338,7 +364,7 @@ class SequentialEngine:
         fuse = p.auto_cost_scale is not None and self._fuse_decoder and not self._fork
         cost = None
         if p.auto_cost_scale is not None:
-            cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self.periodicity, p.auto_cost_variant,
+            cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self._cost_periodicity, p.auto_cost_variant,
                                        float(p.auto_cost_scale), self.B, self.delta[-1] if fuse else self.dY, self.cost_ws)
         self._tiles_ran = self._bwd_ran = False
         if fuse:
@@ -395,7 +421,7 @@ class SequentialEngine:
         else:
             _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
             _lib.mlp_forward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re)
-        _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self.periodicity if self.periodic else INF,
+        _lib.periodic_cost_fwd_bwd(self.h[-1], 0, self.D, self.periodic, self.xb, self.D, self._cost_periodicity,
                                    p.auto_cost_variant, float(p.auto_cost_scale), self.rb, self.re, None, self.dY, self.cost_ws, B=self.B)
         return False
 

@@ -400,7 +400,8 @@ typedef struct {
   int n;                  /* compared columns */
   int off_sin, off_cos;   /* column windows of the prediction inside the output row (off_cos only for periodic_output) */
   int periodic_output;    /* the output row holds [sin | cos] pairs that are turned into angles first */
-  float periodicity;      /* INFINITY: plain differences */
+  float periodicity;      /* INFINITY: plain differences; < 0 (finite): the periodic output's period is |periodicity| but the
+                             differences are plain, not wrapped (reconstruction_loss / "mse" behind PeriodicOutput) */
   int variant;            /* EMX_MEAN_ABS / EMX_MEAN_SQUARE / EMX_MEAN_NORM */
   float coef;
   int B;                  /* global batch size of the normalisation */

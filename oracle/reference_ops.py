@@ -259,6 +259,16 @@ def encodermap_loss(model: SequentialOracle, x: torch.Tensor, p: dict, with_dist
     return total, terms
 
 
+def reconstruction_loss(model: SequentialOracle, x: torch.Tensor):
+    """``Parameters.loss`` = "reconstruction_loss" / "mse" (loss_functions/loss_functions.py:541-547, autoencoder.py:948-958):
+    ``reduce_mean(square(model(x) - x))`` and nothing else -- the differences are plain also behind PeriodicOutput, and the
+    train step (models.py:3385-3386) adds neither the L2 regulariser nor any other term.  Returns (total, terms)."""
+    y = model.decoder(model.encoder(x))
+    total = torch.mean(torch.square(y - x))
+    zero = torch.zeros((), dtype=x.dtype)
+    return total, {"auto": total, "reg": zero, "center": zero}
+
+
 # --------------------------------------------------------------------------- #
 # a15: Keras Adam with clipvalue (SURVEY.md appendix C; Keras 2.13-2.15 optimizer semantics)
 # --------------------------------------------------------------------------- #
@@ -292,8 +302,12 @@ def train_steps(model: SequentialOracle, data: np.ndarray, batch_indices: Sequen
     losses, terms_all = [], []
     for idx in batch_indices:
         xb = X[torch.as_tensor(np.asarray(idx), dtype=torch.long)]
-        total, terms = encodermap_loss(model, xb, p, with_distance)
-        grads = torch.autograd.grad(total, model.params)
+        if p.get("loss", "emap_cost") in ("reconstruction_loss", "mse"):
+            total, terms = reconstruction_loss(model, xb)
+        else:
+            total, terms = encodermap_loss(model, xb, p, with_distance)
+        grads = torch.autograd.grad(total, model.params, allow_unused=True)
+        grads = [g if g is not None else torch.zeros_like(q) for g, q in zip(grads, model.params)]
         opt.apply_gradients(model.params, grads)
         losses.append(float(total.detach()))
         terms_all.append({k: float(v.detach()) if torch.is_tensor(v) else float(v) for k, v in terms.items()})

@@ -403,3 +403,75 @@ def test_short_calls_equal_one_long_call(em):
     d.run_steps(13, torch.from_numpy(np.concatenate([own[:5], inj, own[5:]]).reshape(-1)).cuda())
     np.testing.assert_array_equal(c.losses(), d.losses())
     np.testing.assert_array_equal(c.w.cpu().numpy(), d.w.cpu().numpy())
+
+
+def _golden_module():
+    import importlib.util
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_full_size_allpairs.py")
+    spec = importlib.util.spec_from_file_location("make_full_size_allpairs", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("name", ["C4", "C5"])
+def test_full_size_all_pairs_pass_against_committed_float64_numbers(em, name):
+    """The all-pairs (sketch-map) pass at the FULL batch of BASELINE configurations 4 (8192 x 512, periodic) and 5 (16384 x 256):
+    cost, |dZ|, and 384 rows of d cost / d z against float64 numbers computed once in the build container by the direct-difference
+    oracle (tests/golden/make_full_size_allpairs.py -> full_size_allpairs.npz; the seeded batch is re-generated here bit for
+    bit), for every form of the pass that runs at this size: C5 -- 128 x 128 macro-tiles on split rows (the single process) and
+    the dealt 64 x 64 Gram tiles of two row-block ranks; C4 -- VALU tiles on 32-bit phases, the float form, and dealt tiles.
+    Tolerances: cost 1e-5 relative, gradient 2e-5 of its largest entry (the kernels' bounds at every other size)."""
+    from encodermap_amd import _lib as L
+    from encodermap_amd.engine import DataParallel
+
+    G = _golden_module()
+    B, Dd, Ld, per, sig, scale, _ = G.CONFIGS[name]
+    x, z, rows = G.make_batch(name)
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "full_size_allpairs.npz"))
+    assert np.array_equal(gold[f"{name}_rows"], rows)
+    cost_o, norm_o, g_o, gmax = float(gold[f"{name}_cost"]), float(gold[f"{name}_dz_norm"]), gold[f"{name}_dz_rows"], float(gold[f"{name}_dz_absmax"])
+    X, Z = torch.from_numpy(x).cuda(), torch.from_numpy(z).cuda()
+    split = None
+    if per == INF:
+        split = torch.zeros(L.sketchmap_split_bytes(B, Dd), dtype=torch.uint8, device="cuda")
+        L.sketchmap_split(X, split)
+    n_ws = L.sketchmap_ws_bytes(B, Ld) // 4
+
+    def check(label, cost, g):
+        assert cost == pytest.approx(cost_o, rel=1e-5), label
+        assert np.isfinite(g).all(), label
+        np.testing.assert_allclose(g[rows], g_o, rtol=0, atol=2e-5 * gmax, err_msg=label)
+        assert float(np.sqrt((g.astype(np.float64) ** 2).sum())) == pytest.approx(norm_o, rel=2e-5), label
+        assert np.abs(g.astype(np.float64).sum(0)).max() < 2e-5 * gmax * math.sqrt(B), label     # zero net gradient
+
+    def single(span):
+        ws = torch.zeros(n_ws, dtype=torch.float32, device="cuda")
+        dist, dZ = torch.zeros(1, device="cuda"), torch.full((B, Ld), float("nan"), device="cuda")
+        L.sketchmap_tiles(X, Z, per, sig, 0, B, ws, split, data_span=span)
+        L.sketchmap_finish(B, Dd, Z, sig, scale, 0.0, 0, B, dist, None, dZ, ws, periodicity=per)
+        return float(dist), dZ.cpu().numpy()
+
+    if per == INF:
+        check("macro-tiles", *single(None))
+    else:
+        span = float(x.max() - x.min())
+        assert span < 1.5 * per
+        check("phase tiles", *single(span))
+        check("float tiles", *single(None))
+    # two row-block ranks: the dealt 64 x 64 tiles, shares summed
+    loss_sum, g_sum = 0.0, np.zeros((B, Ld))
+    for rank in range(2):
+        dp = DataParallel(rank, 2, "rowblock")
+        rb, re = dp.row_block(B)
+        ws = torch.zeros(n_ws, dtype=torch.float32, device="cuda")
+        dZ = torch.full((B, Ld), float("nan"), device="cuda")
+        L.sketchmap_tiles_dealt(X, Z, per, sig, ws, split, rank, 2, data_span=(float(x.max() - x.min()) if per != INF else None))
+        L.sketchmap_reduce_dealt(B, Dd, Z, per, sig, scale, 0.0, rb, re, rank, 2, dZ, ws)
+        sk = L.sketchmap_describe(X, Z, per, sig, scale, 0.0, 0, B, ws)
+        torch.cuda.synchronize()
+        off = (sk.tile_loss - ws.data_ptr()) // 4
+        loss_sum += float(ws[off:off + sk.n_tiles].double().sum()) * sk.loss_scale
+        g_sum += dZ.cpu().numpy().astype(np.float64)
+    check("dealt tiles, two ranks", loss_sum, g_sum)

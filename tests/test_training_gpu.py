@@ -164,6 +164,56 @@ def test_autoencoder_without_distance(em):
     np.testing.assert_allclose(got, want, rtol=2e-2)
 
 
+@pytest.mark.parametrize("loss,periodicity,cls", [("reconstruction_loss", 2 * PI, "Autoencoder"), ("mse", INF, "EncoderMap"),
+                                                  ("reconstruction_loss", 360.0, "EncoderMap")])
+def test_plain_reconstruction_loss(em, loss, periodicity, cls):
+    """``Parameters(loss="reconstruction_loss" | "mse")`` (autoencoder.py:948-958, 1281-1301; loss_functions.py:541-547):
+    mean((model(x) - x)^2) and nothing else -- plain differences also behind PeriodicOutput, no regulariser, no center or
+    distance term -- against the oracle's statement of it, teacher-forced step by step (loss 1e-5, weights after the step) and
+    free-running over 10 steps (1e-4: mean-square gradients are smooth, unlike mean_abs)."""
+    from encodermap_amd.layout import pack_weights
+
+    rng = np.random.default_rng(9)
+    if periodicity < INF:
+        data = rng.uniform(-periodicity / 2, periodicity / 2, (3000, 9)).astype(np.float32)
+    else:
+        data = (rng.normal(0, 2, (6, 20))[rng.integers(0, 6, 3000)] + rng.normal(0, 1, (3000, 20))).astype(np.float32)
+    D = data.shape[1]
+    p = em.Parameters(n_steps=10, batch_size=192, loss=loss, periodicity=periodicity, learning_rate=0.003)
+    net = 2 * D if periodicity < INF else D
+    w0 = initial_weights(em, p, net)
+    e = getattr(em, cls)(p, data, model=[w.copy() for w in w0], read_only=True)
+    assert e.loss == ["reconstruction_loss"]
+    eng = e._engine
+    model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    opt = R.KerasAdam(model.params, learning_rate=p.learning_rate, clipvalue=1.0)
+    X = torch.tensor(data, dtype=torch.float64)
+    idx = rng.integers(0, 3000, (10, 192))
+    for t in range(4):
+        eng.load_state_dict({
+            "w": pack_weights(eng.layout, [q.detach().numpy() for q in model.params]),
+            "m": pack_weights(eng.layout, [q.numpy() for q in opt.m]),
+            "v": pack_weights(eng.layout, [q.numpy() for q in opt.v]),
+            "step": t})
+        eng.run_steps(1, torch.from_numpy(idx[t]).to("cuda:0"))
+        total, _ = R.reconstruction_loss(model, X[torch.as_tensor(idx[t])])
+        grads = torch.autograd.grad(total, model.params)
+        opt.apply_gradients(model.params, grads)
+        assert eng.losses()[-1] == pytest.approx(float(total.detach()), rel=1e-5)
+        tm = eng.loss_terms()
+        assert tm["reg"][-1] == 0 and tm["center"][-1] == 0 and tm["distance"][-1] == 0 and tm["auto"][-1] == pytest.approx(float(total.detach()), rel=1e-5)
+        for a, b in zip(eng.get_weights(), model.params):
+            diff = np.abs(a - b.detach().numpy())
+            assert (diff > 2e-6).mean() < 0.02 and diff.max() < 2.1e-3 * 3, (t, diff.max(), (diff > 2e-6).mean())
+    e2 = getattr(em, cls)(p, data, model=[w.copy() for w in w0], read_only=True)
+    e2._engine.run_steps(10, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    m2 = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    want, _ = R.train_steps(m2, data, idx, p.to_dict())
+    np.testing.assert_allclose(e2._engine.losses(), want, rtol=1e-4)
+    with pytest.raises(ValueError, match="loss argument needs to be"):
+        em.Autoencoder(em.Parameters(loss="nope"), data, read_only=True)
+
+
 def test_graph_replay_equals_eager(em):
     rng = np.random.default_rng(6)
     data = rng.uniform(-PI, PI, (3000, 16)).astype(np.float32)
