@@ -53,6 +53,33 @@ int ensure_counters_zeroed(void* words, size_t bytes, hipStream_t stream, const 
 }
 }  // namespace emx
 
+namespace emx {
+namespace {
+std::unordered_map<const void*, std::pair<unsigned*, size_t>> g_tickets;   // scratch address -> (library-owned block, bytes)
+}
+unsigned* owned_tickets(const void* scratch, size_t bytes, hipStream_t stream, const char* who, int* rc) {
+  *rc = EMX_OK;
+  std::lock_guard<std::mutex> lock(g_counters_mu);
+  auto it = g_tickets.find(scratch);
+  if (it != g_tickets.end() && it->second.second >= bytes) return it->second.first;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) != hipSuccess) (void)hipGetLastError();
+  if (cs != hipStreamCaptureStatusNone) {
+    *rc = fail(EMX_EINVAL, "%s: the scratch buffer at %p is new to the library and the stream is capturing -- run the call once outside the "
+               "capture first (a warm-up step): its ticket words are allocated at first sight", who, scratch);
+    return nullptr;
+  }
+  unsigned* block = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&block), bytes) != hipSuccess || hipMemsetAsync(block, 0, bytes, stream) != hipSuccess) {
+    (void)hipGetLastError();
+    *rc = fail(EMX_EWORKSPACE, "%s: could not allocate %zu bytes of ticket words", who, bytes);
+    return nullptr;
+  }
+  g_tickets[scratch] = std::make_pair(block, bytes);   // (an older, smaller block of this address stays allocated: a launch may still use it)
+  return block;
+}
+}  // namespace emx
+
 extern "C" void emx_forget_counters(void* words) {
   std::lock_guard<std::mutex> lock(emx::g_counters_mu);
   if (words == nullptr) emx::g_counters_seen.clear();

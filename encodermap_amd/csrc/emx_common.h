@@ -38,6 +38,11 @@ inline int check_launch(const char* what) {
 // that is refused (EMX_EINVAL: call once outside the capture first -- a warm-up step does).  A caller that recycles such memory for
 // something else and hands it back later must zero it again (emx_forget_counters drops the library's note).
 int ensure_counters_zeroed(void* words, size_t bytes, hipStream_t stream, const char* who);
+// Ticket words that belong to a caller's SCRATCH buffer (the split reduction of the all-pairs pass): kept in memory the LIBRARY
+// owns, one zeroed block per scratch address it has seen -- scratch buffers come and go through caching allocators, and a
+// recycled address must not bring stale or foreign bits back as ticket counts; a block of the library's is only ever written by
+// launches that leave it at zero.  Allocated at first sight (not inside a stream capture: EMX_EINVAL, as above).
+unsigned* owned_tickets(const void* scratch, size_t bytes, hipStream_t stream, const char* who, int* rc);
 
 #define EMX_REQUIRE(cond, ...)                             \
   do {                                                     \

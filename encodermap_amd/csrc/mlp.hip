@@ -167,21 +167,34 @@ struct PubArgs {
 // The kernel's body as a function, so that chain_kernel and chain_tiles_kernel (below) share it.  PUB_OFF > 0: the forward GEMM
 // flagged S_PUB hands its rows (two columns) to the tile workgroups of the same launch (sk_tile.h); the offset is that of a
 // PubArgs record in the kernel's arguments.
-template <int MODE, int NB, int PUB_OFF>
+template <int MODE, int NB, int PUB_OFF, int KS = 1, bool SMALL = false>
 __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
                                            int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
                                            const ChainArgs& a) {
+  // KS: waves per 16-column tile.  1: eight waves, a wave runs all four K-steps of a unit.  2: SIXTEEN waves (four per SIMD) --
+  // wave (tile tw, kh) runs K-steps 2 kh, 2 kh + 1 and, after an exchange of accumulators through LDS, the epilogue of rows
+  // 4 g + 2 kh, 4 g + 2 kh + 1 of the tile: half the matrix instructions, LDS fragments, piece loads and epilogue elements per
+  // wave, twice the waves to hide the unit's dependent trips behind.  Built for SMALL launches only.
+  // SMALL: every GEMM of the launch is ONE unit (all widths of the range <= 128): no pass / chunk bookkeeping, every unit ends
+  // a layer.
+  static_assert(KS == 1 || (KS == 2 && SMALL && PUB_OFF == 0), "sixteen-wave row blocks: SMALL launches of the plain kernel only");
   constexpr bool BWD = MODE == CHAIN_BWD;
-  constexpr int NE = BWD ? 4 : 1;   // epilogue operands per lane: h of 4 rows (backward) or the bias of its column
+  constexpr int NW_ = NWC * KS, NT_ = NTC * KS;   // waves / threads of the workgroup
+  constexpr int NS = 4 / KS;                      // K-steps of a unit per wave
+  constexpr int NR = 4 / KS;                      // rows of its tile column per lane in the epilogue
+  constexpr int NE = BWD ? NR : 1;   // epilogue operands per lane: h of its rows (backward) or the bias of its column
   extern __shared__ __align__(16) char lds[];
-  __shared__ float cred[NWC];
-  __shared__ __align__(16) unsigned mxbuf[NWC][R];   // row maxima of the waves' tiles (dynamic-scale epilogues)
+  __shared__ float cred[NW_];
+  __shared__ __align__(16) unsigned mxbuf[2][NWC][R];   // row maxima of the waves' tiles (dynamic-scale epilogues), two copies by unit parity
+  __shared__ __align__(16) float xch[KS == 2 ? 2 * NW_ * 64 * 2 : 4];   // KS = 2: the accumulator halves the waves of a tile hand to each other
 #ifdef EMX_CHAIN_TIMING
-  __shared__ long long dbg_lds[NTC];
+  __shared__ long long dbg_lds[NT_];
   int tcount = 0;
 #endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tw = KS == 2 ? (wave & 7) : wave;   // the wave's 16-column tile
+  const int kh = KS == 2 ? (wave >> 3) : 0;     // its half of the reduction and of the rows
   const int n = lane & 15, g = lane >> 4;
   TSTAMP(0);
   const int r0 = p_row0 + blockIdx.x * R;
@@ -276,22 +289,25 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   };
 
   // ---- the register ring
-  half8 wp[NB][4][2];   // [slot][K-step][plane]
+  half8 wp[NB][NS][2];   // [slot][K-step of this wave][plane]
   float ep[NB][NE];
   float wsc[NB];
 
   // per-GEMM state of a unit stream, wave-uniform (scalar registers); the request stream runs NB - 1 units ahead of the
-  // execution stream.  Units are regular (wop.h): the next unit's package is 64 KB behind this one's.
+  // execution stream.  Units are regular (wop.h): the next unit's package is 64 KB behind this one's.  SMALL launches (every
+  // layer of the range at most 128 wide in both dimensions): a GEMM is ONE unit, the stream is the GEMM index.
   struct Stream {
     int gi, g_end;          // current GEMM, end of the segment
     int p, c;               // pass, chunk
     int P, C;
   };
   auto stream_next = [&](Stream& st) __attribute__((always_inline)) -> bool {   // returns true when the GEMM changed
-    if (++st.c < st.C) return false;
-    st.c = 0;
-    if (++st.p < st.P) return false;
-    st.p = 0;
+    if constexpr (!SMALL) {
+      if (++st.c < st.C) return false;
+      st.c = 0;
+      if (++st.p < st.P) return false;
+      st.p = 0;
+    }
     ++st.gi;
     return true;
   };
@@ -305,8 +321,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   bool rq_live;
   auto rq_load_gemm = [&]() __attribute__((always_inline)) {
     const auto& G = ka->g[rq.gi];
-    rq.P = G.P;
-    rq.C = G.C;
+    if constexpr (!SMALL) {
+      rq.P = G.P;
+      rq.C = G.C;
+    }
     rq_aux = G.aux;
     rq_aux_rs = G.aux_rs;
     rq_n = G.n;
@@ -315,10 +333,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   auto request = [&](auto RC, const int ln) __attribute__((always_inline)) {   // the package of the request stream's unit into ring slot r, then advance
     constexpr int r = decltype(RC)::value;
     const int n = ln & 15, g = ln >> 4;
-    const int ccol = min(128 * rq.p + 16 * wave + n, rq_n - 1);
+    const int ccol = min((SMALL ? 0 : 128 * rq.p) + 16 * tw + n, rq_n - 1);
     if (BWD) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) ep[r][reg] = rq_aux[(long)min(r0 + 4 * g + reg, a.row_end - 1) * rq_aux_rs + ccol];
+      for (int rr = 0; rr < NR; ++rr) ep[r][rr] = rq_aux[(long)min(r0 + 4 * g + kh * NR + rr, a.row_end - 1) * rq_aux_rs + ccol];
     } else {
       ep[r][0] = rq_aux[ccol];
     }
@@ -358,8 +376,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   } X;
   auto load_gx = [&](int gi, int g_end, GX& x, int& P, int& C) __attribute__((always_inline)) {
     const auto& G = ka->g[min(gi, g_end - 1)];
-    P = G.P;
-    C = G.C;
+    if constexpr (!SMALL) {
+      P = G.P;
+      C = G.C;
+    }
     x.n = G.n;
     x.sflags = G.sflags;
     x.src_rs = G.src_rs;
@@ -436,12 +456,18 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     else cost_body(IC_<0>{});
   };
 
-  f32x4 acc = {0.f, 0.f, 0.f, 0.f};   // the tile's accumulator in units of 1 / (weight scale [x source scale])
+  // The tile's accumulator in units of 1 / (weight scale [x source scale]), in TWO halves of the reduction: K-steps 0, 1 and
+  // K-steps 2, 3 of every chunk accumulate separately and are added once, in front of the epilogue.  With sixteen waves (KS = 2)
+  // the halves live in the two waves that share a tile -- wave (tile, kh) runs K-steps 2 kh, 2 kh + 1 -- and the waves exchange
+  // them through LDS; the eight-wave builds keep both halves and add them in the same order, so every build of this kernel forms
+  // the same bits.
+  f32x4 accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+  int uparity = 0;   // units executed so far, mod 2: which copy of the exchange areas this unit uses
 
   const float* const wsf = reinterpret_cast<const float*>(a.units);
 
   // Executes the execution stream's unit from ring slot rx while the request stream's unit is requested into slot r.  Every
-  // call issues the same vector-memory sequence: NE + 1 epilogue operands, 8 pieces (two per K-step of matrix work), 7
+  // call issues the same vector-memory sequence: NE + 1 epilogue operands, 2 NS pieces (two per K-step of matrix work), the
   // result stores through buffer resources whose bounds check drops what does not exist -- no conditional load, no
   // exec-masked store, so that every wait the compiler inserts is for the oldest package only.
   // PUB builds, the encoder's backward units in the SAME launch (emx_mlp_forward_backward_tiles_join): in front of the epilogue that
@@ -505,17 +531,20 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     constexpr int r = decltype(RC)::value;          // slot being requested into
     constexpr int rx = (r + 1) % NB;                // slot being executed
     // The lane-dependent address parts.  Where the kernel must fit 128 registers (PUB_OFF != 0: chain_tiles_kernel shares its CUs
-    // with the tile workgroups, chain_kernel_c128 with a second chain workgroup) they are re-derived from the work-item id in every unit instead of living in registers across
-    // the unit loop: there the allocator spilled them to scratch, and a scratch reload sits in the same in-order memory counter
-    // as the weight packages -- every unit then waited for its NEXT package.
+    // with the tile workgroups, chain_kernel_c128 with a second chain workgroup; KS = 2: sixteen waves are four per SIMD) they are
+    // re-derived from the work-item id in every unit instead of living in registers across the unit loop: there the allocator
+    // spilled them to scratch, and a scratch reload sits in the same in-order memory counter as the weight packages -- every unit
+    // then waited for its NEXT package.
     int ln = lane;
-    if constexpr (PUB_OFF != 0) {
+    if constexpr (PUB_OFF != 0 || KS == 2) {
       ln = (int)(threadIdx.x & 63u);
       asm volatile("" : "+v"(ln));
     }
     const int lane = ln, n = ln & 15, g = ln >> 4;
     const int lane8 = ln * 8;
-    const unsigned fvoff = (unsigned)((32 * (g >> 1) + 16 * (wave & 1) + n) * 16 + (g & 1) * 8);   // this lane's 8 bytes inside a fragment
+    // this lane's bytes inside a fragment: lane (n, g) of tile t = tw & 1 holds rows 4 g .. 4 g + 3 (KS = 2: two of them) of
+    // column 16 t + n = fragment lane 32 (g >> 1) + 16 t + n, elements 4 (g & 1) + ..
+    const unsigned fvoff = (unsigned)((32 * (g >> 1) + 16 * (tw & 1) + n) * 16 + (g & 1) * 8 + kh * (2 * NR));
     const bool dyn = X.src_rs == 0.f;
 #ifdef EMX_CHAIN_TIMING
     const int ui = tcount++;
@@ -529,14 +558,15 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     GX Xn = X;
     if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
 
-    if (ex.c == 0) acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    // A fragments of the chunk's four K-steps up front (one LDS latency per unit) -- or, where the backward kernel is held to 128
+    const int exc = SMALL ? 0 : ex.c, exp_ = SMALL ? 0 : ex.p;
+    if (exc == 0) accA = accB = f32x4{0.f, 0.f, 0.f, 0.f};
+    // A fragments of the wave's K-steps up front (one LDS latency per unit) -- or, where the backward kernel is held to 128
     // registers (chain_kernel_c128: a second workgroup on the CU runs in this one's gaps), two K-steps at a time
-    constexpr int AF = (BWD && PUB_OFF != 0) ? 2 : 4;
+    constexpr int AF = (BWD && PUB_OFF != 0) ? 2 : NS;
     half8 ah[AF], al[AF];
     f32x4 rsa[AF];
-    const char* apl = lds + X.src_pl + ex.c * 4096 + lane8;
-    const char* asc = lds + X.src_sc + ex.c * 256 + g * 16;
+    const char* apl = lds + X.src_pl + exc * 4096 + kh * (NS * 1024) + lane8;
+    const char* asc = lds + X.src_sc + exc * 256 + kh * (NS * 64) + g * 16;
     auto fragments = [&](const int s0) __attribute__((always_inline)) {
 #pragma unroll
       for (int s = 0; s < AF; ++s) {
@@ -556,24 +586,31 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     if (dyn) {
       // per-(row, 32 columns) source scales: each K-step's product is unscaled as it is added
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (AF < 4 && s == AF) fragments(AF);
+      for (int s = 0; s < NS; ++s) {
+        if (AF < NS && s == AF) fragments(AF);
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], d, 0, 0, 0);
         d = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], d, 0, 0, 0);
-        acc = d * rsa[s % AF] + acc;
+        if (KS == 2 || s < 2) accA = d * rsa[s % AF] + accA;
+        else accB = d * rsa[s % AF] + accB;
         request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
-      // tanh outputs at their fixed scale: the whole reduction accumulates inside the matrix instruction
+      // tanh outputs at their fixed scale: a whole half of the reduction accumulates inside the matrix instruction
 #pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        if (AF < 4 && s == AF) fragments(AF);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], acc, 0, 0, 0);
+      for (int s = 0; s < NS; ++s) {
+        if (AF < NS && s == AF) fragments(AF);
+        if (KS == 2 || s < 2) {
+          accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], accA, 0, 0, 0);
+          accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], accA, 0, 0, 0);
+          accA = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], accA, 0, 0, 0);
+        } else {
+          accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][1], accB, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(al[s % AF], wp[rx][s][0], accB, 0, 0, 0);
+          accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], accB, 0, 0, 0);
+        }
         request_pieces(RC, s, ln);
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -585,94 +622,160 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     // ---- epilogue (last chunk of a pass).  Columns beyond the layer and rows beyond the batch are NOT masked: their
     //      values are finite (clamped addresses, zero-padded weights), they never reach HBM (buffer bounds), a later layer
     //      multiplies such columns with zero weights, and such rows enter the weight-gradient fragments with factor 0.
-    const bool last = ex.c == ex.C - 1;
+    //      A lane owns NR rows of its column: rows 4 g + kh NR + rr.
+    const bool last = SMALL || ex.c == ex.C - 1;
     const int sflags = X.sflags;
     const bool ubwd = (sflags & S_BWD) != 0;
     const bool bounded = !ubwd && (sflags & S_ACT);            // tanh outputs: fixed scale
     const bool has_img = X.dst_pl >= 0;
-    const int col = 128 * ex.p + 16 * wave + n;
-    float v[4] = {0.f, 0.f, 0.f, 0.f};
-    half4 hi = {0, 0, 0, 0}, lo = {0, 0, 0, 0};
+    const int col = 128 * exp_ + 16 * tw + n;
+    const int row0l = 4 * g + kh * NR;                          // first of the lane's rows inside the row block
+    float v[NR];
+    typedef _Float16 halfR __attribute__((ext_vector_type(NR)));
+    halfR hi, lo;
+#pragma unroll
+    for (int rr = 0; rr < NR; ++rr) v[rr] = 0.f, hi[rr] = (_Float16)0.f, lo[rr] = (_Float16)0.f;
     float rsb = TANH_RS;
     if constexpr (PUB_OFF > 0) {
       if (last && (sflags & S_WAIT)) wait_join();
     }
     if (last) {
+      // the two halves of the reduction, added once
+      float tot[NR];
+      if constexpr (KS == 2) {
+        // wave (tile, kh) keeps rows kh NR .. of the tile and hands the other wave's rows over: one 8-byte LDS write per lane,
+        // a barrier, one 8-byte read of what the other wave left for this one (two copies of the area, by unit parity: a wave may
+        // be a whole unit ahead of its partner's read, not two -- the barrier of the unit in between orders them)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2* const xarea = reinterpret_cast<f32x2*>(xch) + uparity * (NW_ * 64);
+        const f32x2 give = kh ? f32x2{accA[0], accA[1]} : f32x2{accA[2], accA[3]};
+        xarea[wave * 64 + lane] = give;
+        __syncthreads();
+        const f32x2 got = xarea[(wave ^ 8) * 64 + lane];
+        tot[0] = (kh ? accA[2] : accA[0]) + got[0];
+        tot[1] = (kh ? accA[3] : accA[1]) + got[1];
+      } else {
+        const f32x4 t4 = accA + accB;
+#pragma unroll
+        for (int rr = 0; rr < NR; ++rr) tot[rr] = t4[rr];
+      }
       const float cmul = wsc[rx] * (dyn ? 1.f : X.src_rs);
       const int colc = min(col, X.n - 1);
+      // The unit's kind -- forward / backward, with or without an activation (its derivative), with or without joined rows -- is
+      // wave-uniform: ONE scalar switch in front of straight-line code per kind.  (Left as tests inside the loop over the lane's
+      // rows the compiler branched per ELEMENT, and waited for each element's LDS operand before it asked for the next one's.)
+      auto values = [&](auto UB_, auto AC_, auto JN_) __attribute__((always_inline)) {
+        constexpr bool UB = decltype(UB_)::value != 0, AC = decltype(AC_)::value != 0, JN = decltype(JN_)::value != 0;
+        if constexpr (!UB) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        float x;
-        if (!ubwd) {
-          x = fmaf(acc[reg], cmul, ep[rx][0]);
-          if (sflags & S_ACT) x = tanh_f32(x);
+          for (int rr = 0; rr < NR; ++rr) {
+            float x = fmaf(tot[rr], cmul, ep[rx][0]);
+            if constexpr (AC) x = tanh_f32(x);
+            v[rr] = x;
+          }
         } else {
-          x = acc[reg] * cmul;
-          if (sflags & S_JOIN) x += lat[(4 * g + reg) * X.n + colc];
-          if (sflags & S_ACT) {
-            float hv;
-            if (MODE == CHAIN_FUSED)
-              hv = reinterpret_cast<const float*>(lds + X.h_f32)[(4 * g + reg) * X.h_f32_pitch + colc];
-            else
-              hv = ep[rx][BWD ? reg : 0];
-            x *= fmaf(-hv, hv, 1.f);
+          float jn[NR], hv[NR];
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) {
+            jn[rr] = hv[rr] = 0.f;
+            if constexpr (JN) jn[rr] = lat[(row0l + rr) * X.n + colc];
+            if constexpr (AC) {
+              if (MODE == CHAIN_FUSED) hv[rr] = reinterpret_cast<const float*>(lds + X.h_f32)[(row0l + rr) * X.h_f32_pitch + colc];
+              else hv[rr] = ep[rx][BWD ? rr : 0];
+            }
+          }
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) {
+            float x = tot[rr] * cmul;
+            if constexpr (JN) x += jn[rr];
+            if constexpr (AC) x *= fmaf(-hv[rr], hv[rr], 1.f);
+            v[rr] = x;
           }
         }
-        v[reg] = x;
+      };
+      switch (sflags & (S_ACT | S_JOIN | S_BWD)) {
+        case 0: values(IC_<0>{}, IC_<0>{}, IC_<0>{}); break;
+        case S_ACT: values(IC_<0>{}, IC_<1>{}, IC_<0>{}); break;
+        case S_BWD: values(IC_<1>{}, IC_<0>{}, IC_<0>{}); break;
+        case S_BWD | S_ACT: values(IC_<1>{}, IC_<1>{}, IC_<0>{}); break;
+        case S_BWD | S_JOIN: values(IC_<1>{}, IC_<0>{}, IC_<1>{}); break;
+        case S_BWD | S_JOIN | S_ACT: values(IC_<1>{}, IC_<1>{}, IC_<1>{}); break;
+        default: values(IC_<0>{}, IC_<0>{}, IC_<0>{}); break;   // (forward units carry no join)
       }
       if (X.dst_f32 >= 0) {   // (the copy's rows are padded to whole passes: every lane has a slot)
-        float* f = reinterpret_cast<float*>(lds + X.dst_f32) + 4 * g * X.dst_f32_pitch + col;
+        float* f = reinterpret_cast<float*>(lds + X.dst_f32) + row0l * X.dst_f32_pitch + col;
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) f[reg * X.dst_f32_pitch] = v[reg];
+        for (int rr = 0; rr < NR; ++rr) f[rr * X.dst_f32_pitch] = v[rr];
       }
       if (has_img) {
-        float s[4], rs[4];
+        float s[NR], rs[NR];
         unsigned bm = 0;
         if (bounded) {
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) s[reg] = 16384.f, rs[reg] = TANH_RS;
+          for (int rr = 0; rr < NR; ++rr) s[rr] = 16384.f, rs[rr] = TANH_RS;
         } else {
-          // per-row scale over the 32 columns of the tile PAIR (the K-step of the consumer): the two waves of a pair
-          // exchange their tiles' row maxima through LDS (all eight waves are here: the condition is workgroup-uniform)
-          unsigned m[4];
-#pragma unroll
-          for (int reg = 0; reg < 4; ++reg) m[reg] = row16_max(abs_bits(v[reg]));
+          // per-row scale over the 32 columns of the tile PAIR (the K-step of the consumer): the waves of a pair (and, KS = 2, of
+          // both halves of the rows) exchange their tiles' row maxima through LDS (all waves are here: the condition is
+          // workgroup-uniform); two copies of the area by unit parity, as above
           typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-          *reinterpret_cast<u32x4*>(&mxbuf[wave][4 * g]) = u32x4{m[0], m[1], m[2], m[3]};
-          __syncthreads();
-          const u32x4 pm = *reinterpret_cast<const u32x4*>(&mxbuf[wave ^ 1][4 * g]);
+          typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+          unsigned m[NR];
 #pragma unroll
-          for (int reg = 0; reg < 4; ++reg) {
-            m[reg] = max(m[reg], pm[reg]);
-            pow2_scale_bits<ACT_TOP>(m[reg], s[reg], rs[reg]);
-            bm = max(bm, m[reg]);
+          for (int rr = 0; rr < NR; ++rr) m[rr] = row16_max(abs_bits(v[rr]));
+          unsigned (*const mxa)[R] = mxbuf[uparity];
+          u32x4 own;
+          if constexpr (KS == 2) {
+            *reinterpret_cast<u32x2*>(&mxa[tw][row0l]) = u32x2{m[0], m[1]};
+            __syncthreads();
+            own = *reinterpret_cast<const u32x4*>(&mxa[tw][4 * g]);
+          } else {
+            own = u32x4{m[0], m[1], m[2], m[3]};
+            *reinterpret_cast<u32x4*>(&mxa[tw][4 * g]) = own;
+            __syncthreads();
           }
-          // (both waves of the pair and the 16 lanes of a row group write the same 16 bytes: no branch)
-          *reinterpret_cast<f32x4*>(lds + X.dst_sc + (4 * ex.p + (wave >> 1)) * 64 + g * 16) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+          const u32x4 pm = *reinterpret_cast<const u32x4*>(&mxa[tw ^ 1][4 * g]);
+          unsigned mm[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            mm[q] = max(own[q], pm[q]);
+            bm = max(bm, mm[q]);
+          }
+#pragma unroll
+          for (int rr = 0; rr < NR; ++rr) {
+            const unsigned mr = KS == 2 ? (kh ? mm[2 + rr] : mm[rr]) : mm[rr];
+            pow2_scale_bits<ACT_TOP>(mr, s[rr], rs[rr]);
+          }
+          // (both waves of the pair and the 16 lanes of a row group write the same bytes: no branch)
+          float* const scp = reinterpret_cast<float*>(lds + X.dst_sc + (4 * exp_ + (tw >> 1)) * 64 + g * 16) + kh * NR;
+          if constexpr (KS == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(scp) = f32x2{rs[0], rs[1]};
+          } else {
+            *reinterpret_cast<f32x4*>(scp) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+          }
         }
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-          const float x = v[reg] * s[reg];
-          hi[reg] = (_Float16)x;
-          lo[reg] = (_Float16)(x - (float)hi[reg]);
+        for (int rr = 0; rr < NR; ++rr) {
+          const float x = v[rr] * s[rr];
+          hi[rr] = (_Float16)x;
+          lo[rr] = (_Float16)(x - (float)hi[rr]);
         }
-        char* dp = lds + X.dst_pl + col * 32 + 8 * g;
-        *reinterpret_cast<half4*>(dp) = hi;
-        *reinterpret_cast<half4*>(dp + X.dst_lo) = lo;
+        char* dp = lds + X.dst_pl + col * 32 + 8 * g + kh * (2 * NR);
+        *reinterpret_cast<halfR*>(dp) = hi;
+        *reinterpret_cast<halfR*>(dp + X.dst_lo) = lo;
         if (X.frag != nullptr) {
           // the weight-gradient fragment: the image's pair under the block's scale (16 rows x 32 columns); rows beyond
           // the batch get factor 0
-          half4 ratio;
+          halfR ratio;
           if (bounded) {
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(4 * g + reg < rows_valid ? 1.f : 0.f);
+            for (int rr = 0; rr < NR; ++rr) ratio[rr] = (_Float16)(row0l + rr < rows_valid ? 1.f : 0.f);
           } else {
-            bm = max(bm, (unsigned)__shfl_xor((int)bm, 16, 64));
-            bm = max_xor32(bm);
+            bm = max_xor32(max_xor16(bm));   // (lane swaps, not ds_bpermute: no trip through the LDS crossbar)
             float sb;
             pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) ratio[reg] = (_Float16)(4 * g + reg < rows_valid ? sb * rs[reg] : 0.f);
+            for (int rr = 0; rr < NR; ++rr) ratio[rr] = (_Float16)(row0l + rr < rows_valid ? sb * rs[rr] : 0.f);
           }
           hi = hi * ratio;
           lo = lo * ratio;
@@ -680,31 +783,35 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       }
     }
     {
-      // float32 rows: column col of rows 4 g + reg; a column beyond n would alias the next row inside the buffer's
+      // float32 rows: column col of rows 4 g + ..; a column beyond n would alias the next row inside the buffer's
       // bounds, so such a lane's offset is pushed out of them
+      // (a tensor that is not kept: the same address arithmetic on its null pointer and a buffer of ZERO bytes, which drops every
+      //  store -- a select of the size instead of a branch around the 64-bit arithmetic)
       const bool keep = last && X.out != nullptr;
-      const float* ob = keep ? X.out + (long)r0 * X.n : wsf;
-      __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(ob), 0, keep ? max(0, rows_valid) * X.n * 4 : 0, 0x00020000);
-      const unsigned vo = col < X.n ? (unsigned)((4 * g * X.n + col) * 4) : 0x80000000u;
+      __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(X.out + (long)r0 * X.n, 0, keep ? max(0, rows_valid) * X.n * 4 : 0, 0x00020000);
+      const unsigned vo = col < X.n ? (unsigned)((row0l * X.n + col) * 4) : 0x80000000u;
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[reg]), ro, vo + reg * X.n * 4, 0, 0);
-      // weight-gradient fragment of the tile pair: lane (n, g) of tile t = wave & 1 holds rows 4 g .. 4 g + 3 of column
-      // 16 t + n = fragment lane 32 (g >> 1) + 16 t + n, elements 4 (g & 1) ..; column groups beyond the tensor do not exist
-      const int grp = 4 * ex.p + (wave >> 1);
+      for (int rr = 0; rr < NR; ++rr) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[rr]), ro, vo + rr * X.n * 4, 0, 0);
+      // weight-gradient fragment of the tile pair; column groups beyond the tensor do not exist
+      const int grp = 4 * exp_ + (tw >> 1);
       const bool keepf = last && X.frag != nullptr && has_img && grp < X.CG;
-      const char* fb = keepf ? X.frag + ((long)rb * X.CG + grp) * 2048 : a.units;
-      __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(fb), 0, keepf ? 2048 : 0, 0x00020000);
-      typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rf, fvoff, 0, 0);
-      __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rf, fvoff + 1024, 0, 0);
-      const bool keeps = keepf && (wave & 1) == 0;
-      const float* rsp = keeps ? X.rscale + (long)rb * X.CG + grp : wsf;
-      __amdgpu_buffer_rsrc_t rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(rsp), 0, keeps ? 4 : 0, 0x00020000);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rsb), rr, lane == 0 ? 0u : 0x80000000u, 0, 0);
+      const long fblk = (long)rb * X.CG + grp;
+      __amdgpu_buffer_rsrc_t rf = __builtin_amdgcn_make_buffer_rsrc(X.frag + fblk * 2048, 0, keepf ? 2048 : 0, 0x00020000);
+      if constexpr (KS == 2) {
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, hi), rf, fvoff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, lo), rf, fvoff + 1024, 0, 0);
+      } else {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, hi), rf, fvoff, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, lo), rf, fvoff + 1024, 0, 0);
+      }
+      const bool keeps = keepf && (tw & 1) == 0 && kh == 0;
+      __amdgpu_buffer_rsrc_t rr_ = __builtin_amdgcn_make_buffer_rsrc(X.rscale + fblk, 0, keeps ? 4 : 0, 0x00020000);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, rsb), rr_, lane == 0 ? 0u : 0x80000000u, 0, 0);
     }
     TSTAMP(6 + 5 * ui);
     // the layer's rows are complete in the destination image when its last unit is done
-    const bool layer_end = last && ex.p == ex.P - 1;
+    const bool layer_end = SMALL || (last && ex.p == ex.P - 1);
     if (layer_end) __syncthreads();
     if constexpr (PUB_OFF > 0) {
       if (layer_end && (sflags & S_PUB) && wave == 0) {
@@ -724,6 +831,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       }
     }
     TSTAMP(7 + 5 * ui);
+    uparity ^= 1;
     ex = exn;
     X = Xn;
   };
@@ -732,21 +840,21 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   // `between` runs while they are in flight (staging the row block; the cost phase of the fused launch), then every
   // iteration executes one unit and requests the one NB - 1 ahead.
   auto pipeline = [&](const int g0, const int g1, const char* units, auto between) __attribute__((always_inline)) {
-    rq = Stream{g0, g1, 0, 0, 0, 0};
+    rq = Stream{g0, g1, 0, 0, 1, 1};
     rq_live = true;
-    rq_ptr = units + wave * 8192;
+    rq_ptr = units + tw * 8192 + kh * (NS * 2048);
     rq_load_gemm();
     request(IC_<0>{}, lane);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) request_pieces(IC_<0>{}, s, lane);
+    for (int s = 0; s < NS; ++s) request_pieces(IC_<0>{}, s, lane);
     rq_advance();
     if constexpr (NB >= 3) {
       request(IC_<1>{}, lane);
 #pragma unroll
-      for (int s = 0; s < 4; ++s) request_pieces(IC_<1>{}, s, lane);
+      for (int s = 0; s < NS; ++s) request_pieces(IC_<1>{}, s, lane);
       rq_advance();
     }
-    ex = Stream{g0, g1, 0, 0, 0, 0};
+    ex = Stream{g0, g1, 0, 0, 1, 1};
     ex_load_gemm();
     between();
     // iteration k executes the k-th unit from slot k % NB and requests the (k + NB - 1)-th into slot (k + NB - 1) % NB
@@ -903,6 +1011,22 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
                                                     int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
                                                     const ChainArgs a) {
   chain_body<MODE, NB, 0>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
+}
+
+// SMALL launches (every GEMM of the launch one unit: all layer widths of the range <= 128 -- the default network [128, 128, 2] on up
+// to 128 input columns): sixteen waves per 16-row block, two per 16-column tile (chain_body: KS = 2) -- and, for A/B runs, the
+// eight-wave build with the same simplifications (EMX_CHAIN_W16=0).
+template <int MODE, int NB>
+__global__ __launch_bounds__(2 * NTC) void chain_kernel_w16(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
+                                                            int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
+                                                            const ChainArgs a) {
+  chain_body<MODE, NB, 0, 2, true>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
+}
+template <int MODE, int NB>
+__global__ __launch_bounds__(NTC) void chain_kernel_small(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
+                                                          int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
+                                                          const ChainArgs a) {
+  chain_body<MODE, NB, 0, 1, true>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
 }
 
 // The same kernels held to 128 registers per lane: TWO workgroups per CU (four waves per SIMD) where the plain build has room
@@ -1762,8 +1886,9 @@ int check_desc(const emx_mlp_desc* desc, const char* who) {
   return EMX_OK;
 }
 
-int set_lds(const void* fn, size_t bytes, const char* who) {
-  if (bytes > 160 * 1024) return emx::fail(EMX_EUNSUPPORTED, "%s: layer width too large for the LDS row block (%zu bytes)", who, bytes);
+int set_lds(const void* fn, size_t bytes, const char* who, size_t static_bytes = 1280) {   // (static: the chain kernels' exchange areas)
+  if (bytes + static_bytes > 160 * 1024)
+    return emx::fail(EMX_EUNSUPPORTED, "%s: layer width too large for the LDS row block (%zu + %zu bytes)", who, bytes, static_bytes);
   if (bytes > 64 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, bytes, hipGetErrorString(e));
@@ -1869,6 +1994,27 @@ int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStr
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_c128<MODE, 2>), lds, b.who);
     if (rc) return rc;
     hipLaunchKernelGGL((chain_kernel_c128<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
+                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
+    return emx::check_launch(what);
+  }
+  // every GEMM one unit (all widths of the range <= 128) and at most a row block per CU or so: sixteen waves per row block
+  bool small = true;
+  for (int i = 0; i < b.ng; ++i) small = small && b.a.g[i].P == 1 && b.a.g[i].C == 1;
+  // 0 (default): eight waves, SMALL build; 1: sixteen waves (EXPERIMENT: measured slower -- every wave repeats the unit's scalar
+  // bookkeeping, and the exchange costs a barrier -- and its cost phase is not adapted to 1024 threads: wrong cost shares); -1: the general build
+  static const int w16 = getenv("EMX_CHAIN_W16") ? atoi(getenv("EMX_CHAIN_W16")) : 0;
+  if (!deep && small && w16 >= 0) {
+    if (w16 >= 1) {
+      rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_w16<MODE, 2>), lds, b.who, 18 * 1024);   // (the accumulator exchange areas are static)
+      if (rc == EMX_OK) {
+        hipLaunchKernelGGL((chain_kernel_w16<MODE, 2>), dim3(grid), dim3(2 * NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
+                           b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
+        return emx::check_launch(what);
+      }
+    }
+    rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_small<MODE, 2>), lds, b.who);
+    if (rc) return rc;
+    hipLaunchKernelGGL((chain_kernel_small<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
                        b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
     return emx::check_launch(what);
   }

@@ -1371,8 +1371,9 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       // one launch (kmode 3: the last workgroup of a tile adds the shares and runs the epilogue; the tickets live behind kpart in the
       // caller's workspace, zero before the first use) -- or, EMX_SK_KSPLIT_TWO=1, the two launches it replaces (kmode 1, 2)
       static const bool two = getenv("EMX_SK_KSPLIT_TWO") && atoi(getenv("EMX_SK_KSPLIT_TWO")) == 1;
-      if (!two) {   // (the tickets of the one-launch form: zeroed by the library in front of the first launch that sees this workspace)
-        const int rz = emx::ensure_counters_zeroed(b.ktickets, (size_t)KSPLIT_BLOCKS * sizeof(unsigned), st, "emx_sketchmap_tiles (split reduction)");
+      if (!two) {   // (the tickets of the one-launch form live in memory of the library's, one zeroed block per workspace address: emx_common.h)
+        int rz = EMX_OK;
+        b.ktickets = emx::owned_tickets(b.ktickets, (size_t)KSPLIT_BLOCKS * sizeof(unsigned), st, "emx_sketchmap_tiles (split reduction)", &rz);
         if (rz) return rz;
       }
       for (int mode = two ? 1 : 3; mode <= (two ? 2 : 3); ++mode) {

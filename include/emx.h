@@ -53,13 +53,14 @@ const char* emx_target_arch(void);
  * launch-bound configuration is priced by (bench.py: launches_per_step; the reference's train_step, models.py:3367-3401, is
  * ~10^2 TensorFlow op launches) */
 int64_t emx_launch_count(void);
-/* Counter words.  Some launches hand work from workgroup to workgroup INSIDE the launch (tickets of a split reduction, arrival
- * counts, a sticky give-up flag): the `sync` arguments below and the first 2 KB of the all-pairs workspace.  They must be zero before
+/* Counter words.  Some launches hand work from workgroup to workgroup INSIDE the launch (arrival counts, a sticky give-up flag):
+ * the `sync` arguments below.  They must be zero before
  * the first such launch and every launch leaves them at zero (the give-up flag excepted).  The library does not rely on the caller
  * for that: the first time an entry point is handed such a pointer -- per process -- it zeroes the words itself on the caller's
  * stream, in front of its launch.  That first sight must not happen inside a stream capture (EMX_EINVAL: the memset would become a
- * graph node and clear the give-up flag on every replay) -- run the call once eagerly first, as a warm-up step does.  A caller
- * that recycles such memory for something else and hands it back later zeroes it itself or calls emx_forget_counters(ptr)
+ * graph node and clear the give-up flag on every replay) -- run the call once eagerly first, as a warm-up step does.  The note is
+ * by ADDRESS: a caller that frees such memory and gets the same address back from its allocator (or recycles it for something
+ * else) must hand it over zeroed -- allocate these few words zeroed, as you would a lock -- or call emx_forget_counters(ptr)
  * (NULL: forget all), after which the next call zeroes it again. */
 void emx_forget_counters(void* words);
 
@@ -82,10 +83,10 @@ void emx_forget_counters(void* words);
  *   *center_loss = center_scale / (B*L) * sum_{i in rows} sum_l z_il^2      (skipped if center_loss == NULL)
  *   dZ[i,:] (rows in the block only) = d(dist + center)/dz_i of the FULL-batch loss; pairs with dl == 0
  *   contribute zero gradient (the reference's mask, distances.py:247-253).
- *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes.  Small batches of long rows split a tile's reduction over workgroups
- *   of ONE launch: the last of a tile's workgroups adds their shares and runs the epilogue; their ticket words are the first 2 KB of
- *   ws, whatever (B, L).  The LIBRARY zeroes them in front of the first launch that sees this pointer (see "counter words" below)
- *   and every launch leaves them at zero.
+ *   ws: scratch of at least emx_sketchmap_ws_bytes(B, L) bytes; its contents need no initialisation and mean nothing between calls
+ *   of the tiles / finish pair.  (Small batches of long rows split a tile's reduction over workgroups of ONE launch: the last of a
+ *   tile's workgroups adds their shares and runs the epilogue.  Their ticket words live in memory of the LIBRARY's, one zeroed
+ *   block per workspace address it has seen -- so the first such call for a workspace must run outside a stream capture.)
  * ------------------------------------------------------------------------------------------------ */
 size_t emx_sketchmap_ws_bytes(int B, int L);
 int emx_sketchmap_fwd_bwd(const float* X, int B, int D, int ldx, const float* Z, int L,

@@ -569,12 +569,12 @@ def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
     np.testing.assert_allclose(g, g_o, rtol=0, atol=2e-5 * np.abs(g_o).max() + 1e-12)
 
 
-def test_counter_words_are_zeroed_by_the_library(L):
-    """The split reduction of the all-pairs pass keeps one ticket word per tile in the first 2 KB of the caller's workspace
-    (include/emx.h, "counter words").  The library does not trust the caller to have zeroed them: a workspace FULL OF GARBAGE must
-    give the same result as a zeroed one -- the library zeroes the words in front of the first launch that sees the pointer and
-    every launch leaves them at zero -- also on the second and third call; a pointer the library has been told to forget is
-    zeroed again; and a first sight inside a stream capture is refused, not silently turned into a per-replay memset."""
+def test_scratch_of_the_all_pairs_pass_needs_no_initialisation(L):
+    """The split reduction of the all-pairs pass hands a tile's Gram shares to the last of its workgroups through ticket words.
+    They used to live in the caller's workspace ("zero-initialised once by the caller").  Now the library keeps them in memory of
+    its own, one zeroed block per workspace address (include/emx.h): a workspace FULL OF GARBAGE -- also one whose address a
+    caching allocator has handed out before, zeroed then -- gives the same bits as a zeroed one, call after call; and the first
+    call for a workspace inside a stream capture is refused (the block is allocated at first sight), not silently wrong."""
     from encodermap_amd import _lib
 
     B, Dd, Ld, sig = 256, 2850, 2, (80.0, 10, 5, 1, 2, 5)      # the ADC model's pair-distance rows: 10 tiles x 16 workgroups
@@ -592,20 +592,16 @@ def test_counter_words_are_zeroed_by_the_library(L):
         L.sketchmap_finish(B, Dd, Z, sig, 500.0, 1e-4, 0, B, dist, cen, dZ, ws)
         return float(dist), dZ.cpu().numpy()
 
-    clean = run(torch.zeros(n_ws, dtype=torch.float32, device="cuda"))
+    clean = run(torch.zeros(n_ws, dtype=torch.float32, device="cuda"))      # (freed here: the allocator hands the address out again)
     loss_o, _ = D.sketchmap_fwd_bwd(x, z, INF, sig, 500.0, 0, B)
     assert clean[0] == pytest.approx(loss_o, rel=1e-5)
     dirty_ws = torch.randint(1, 2 ** 31 - 1, (n_ws,), dtype=torch.int32, device="cuda").view(torch.float32)
     for _ in range(3):
         got = run(dirty_ws)
         assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
-    assert int(dirty_ws[:512].view(torch.int32).abs().max()) == 0          # the tickets are back at zero
-    # recycled memory: garbage again at the same address, the library told to forget it
-    dirty_ws.view(torch.int32).fill_(12345)
-    _lib.load().emx_forget_counters(dirty_ws.data_ptr())
-    got = run(dirty_ws)
-    assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
+        dirty_ws.view(torch.int32).fill_(0x7fc12345)                         # garbage again between the calls (NaN patterns)
     # first sight inside a capture: refused
+    keep = [torch.empty(n_ws, dtype=torch.float32, device="cuda") for _ in range(4)]      # (addresses the library has not seen)
     fresh = torch.randint(1, 1000, (n_ws,), dtype=torch.int32, device="cuda").view(torch.float32)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
@@ -623,6 +619,7 @@ def test_counter_words_are_zeroed_by_the_library(L):
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
     assert refused is True
+    del keep
 
 
 def test_periodic_cost_batch_equals_separate_calls(L):

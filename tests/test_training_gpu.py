@@ -211,7 +211,7 @@ def test_plain_reconstruction_loss(em, loss, periodicity, cls):
     want, _ = R.train_steps(m2, data, idx, p.to_dict())
     np.testing.assert_allclose(e2._engine.losses(), want, rtol=1e-4)
     with pytest.raises(ValueError, match="loss argument needs to be"):
-        em.Autoencoder(em.Parameters(loss="nope"), data, read_only=True)
+        em.Autoencoder(em.Parameters(loss="nope"), np.zeros((300, 4), np.float32), read_only=True)
 
 
 def test_graph_replay_equals_eager(em):
