@@ -348,19 +348,58 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     wp[r][s][0] = *reinterpret_cast<const half8*>(p);
     wp[r][s][1] = *reinterpret_cast<const half8*>(p + 1024);
   };
-  auto rq_advance = [&]() __attribute__((always_inline)) {
+  // Advancing the request stream, in two parts: the scalar loads of the next unit's GEMM record go out EARLY (rq_prefetch, behind the
+  // first K-step of the unit in execution: scalar loads and LDS accesses share one counter, so a record requested in front of the
+  // A fragments makes the first matrix instruction wait for it, and one requested behind the matrix instructions makes the
+  // epilogue's first LDS access wait) -- the stream's state changes LATE (rq_commit, behind the unit's last piece request, which
+  // still reads the old pointer).
+  Stream rq_nx;
+  const float* nq_aux;
+  const float* nq_ws;
+  int nq_aux_rs, nq_n, nq_P, nq_C;
+  int rq_step;   // 0: the stream has ended; 1: next unit of the same GEMM; 2: next GEMM
+  auto rq_prefetch = [&]() __attribute__((always_inline)) {
+    rq_step = 0;
     if (!rq_live) return;
-    Stream nx = rq;
-    const bool changed = stream_next(nx);
-    if (changed && nx.gi >= nx.g_end) {   // the segment's last unit: keep requesting it (the same instruction sequence; nothing depends on it)
+    rq_nx = rq;
+    const bool changed = stream_next(rq_nx);
+    if (changed && rq_nx.gi >= rq_nx.g_end) return;   // the segment's last unit: keep requesting it (the same instruction sequence; nothing depends on it)
+    rq_step = changed ? 2 : 1;
+    if (changed) {
+      const auto& G = ka->g[rq_nx.gi];
+      if constexpr (!SMALL) {
+        nq_P = G.P;
+        nq_C = G.C;
+      }
+      nq_aux = G.aux;
+      nq_aux_rs = G.aux_rs;
+      nq_n = G.n;
+      nq_ws = G.ws;
+    }
+  };
+  auto rq_commit = [&]() __attribute__((always_inline)) {
+    if (rq_step == 0) {
       rq_live = false;
       return;
     }
-    rq = nx;
+    rq = rq_nx;
 #ifndef EMX_EXP_NOSTREAM   // (experiment: every unit re-reads the first package -- times the kernel without its weight stream)
     rq_ptr += WOP_UNIT;
 #endif
-    if (changed) rq_load_gemm();
+    if (rq_step == 2) {
+      if constexpr (!SMALL) {
+        rq.P = nq_P;
+        rq.C = nq_C;
+      }
+      rq_aux = nq_aux;
+      rq_aux_rs = nq_aux_rs;
+      rq_n = nq_n;
+      rq_ws = nq_ws;
+    }
+  };
+  auto rq_advance = [&]() __attribute__((always_inline)) {
+    rq_prefetch();
+    rq_commit();
   };
 
   // execution stream: the current GEMM's record in scalar registers
@@ -556,13 +595,22 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     Stream exn = ex;
     const bool ex_changed = stream_next(exn);
     GX Xn = X;
-    if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
+    // (the scalar loads of the unit: the next unit's record of the execution stream and of the request stream -- issued behind the
+    //  first K-step, see rq_prefetch)
+    auto records = [&](const bool behind_fragments) __attribute__((always_inline)) {
+      // (every A fragment of the unit has arrived by now -- said explicitly: with scalar loads outstanding every later wait for
+      //  an LDS read would have to be a wait for ALL of them, lgkmcnt(0), in the middle of the matrix instructions)
+      if (behind_fragments) __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0); vmcnt, expcnt untouched
+      if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
+      rq_prefetch();
+    };
 
     const int exc = SMALL ? 0 : ex.c, exp_ = SMALL ? 0 : ex.p;
     if (exc == 0) accA = accB = f32x4{0.f, 0.f, 0.f, 0.f};
     // A fragments of the wave's K-steps up front (one LDS latency per unit) -- or, where the backward kernel is held to 128
     // registers (chain_kernel_c128: a second workgroup on the CU runs in this one's gaps), two K-steps at a time
     constexpr int AF = (BWD && PUB_OFF != 0) ? 2 : NS;
+    if constexpr (AF != NS) records(false);   // (fragments in two portions: the records in front of them, as they always were)
     half8 ah[AF], al[AF];
     f32x4 rsa[AF];
     const char* apl = lds + X.src_pl + exc * 4096 + kh * (NS * 1024) + lane8;
@@ -595,6 +643,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         if (KS == 2 || s < 2) accA = d * rsa[s % AF] + accA;
         else accB = d * rsa[s % AF] + accB;
         request_pieces(RC, s, ln);
+        if (AF == NS && s == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          records(true);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     } else {
@@ -612,11 +664,15 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], accB, 0, 0, 0);
         }
         request_pieces(RC, s, ln);
+        if (AF == NS && s == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          records(true);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
     TSTAMP(4 + 5 * ui);
-    rq_advance();
+    rq_commit();
     TSTAMP(5 + 5 * ui);
 
     // ---- epilogue (last chunk of a pass).  Columns beyond the layer and rows beyond the batch are NOT masked: their

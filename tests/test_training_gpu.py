@@ -391,5 +391,9 @@ def test_autoencoder_free_running_drift_envelope(em):
     dev_e, dev_32 = np.abs(got - f64) / f64, np.abs(f32 - f64) / f64
     print("engine rel. deviation", np.array2string(dev_e, precision=1, max_line_width=250))
     print("oracle-f32 deviation ", np.array2string(dev_32, precision=1, max_line_width=250))
-    np.testing.assert_allclose(got[:3], f64[:3], rtol=1e-6)
+    # (round 4: 5e-6 instead of 1e-6 -- the dense layers now add the two halves of every reduction once, another rounding order,
+    #  and this trajectory amplifies a last-bit difference by ~20x per step from the very first: measured 3e-8, 1e-6, 2.4e-6 beside
+    #  8e-8, 5e-8, 9e-7 of the float32 oracle; the step function itself is pinned to 1e-5 with teacher forcing in
+    #  test_autoencoder_without_distance and to 2x the float32 error per quantity in test_accuracy_gpu.py)
+    np.testing.assert_allclose(got[:3], f64[:3], rtol=5e-6)
     assert dev_e.max() <= 2.0 * dev_32.max(), (dev_e.max(), dev_32.max())
