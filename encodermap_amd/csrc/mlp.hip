@@ -444,10 +444,14 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   auto cost_body = [&](auto PO_) __attribute__((always_inline)) {
     constexpr int PO = decltype(PO_)::value;   // periodic output or not: a wave-uniform branch around the whole body (cost.h)
     const CostArgs& cst = a.cost;
-    const int row = tid >> 5, l32 = tid & 31;
-    const bool rok = row < rows_valid;
+    // (written for 512 threads = 16 rows x 32: the upper waves of a sixteen-wave build run along with nothing to do -- they read row
+    //  15, store nothing, add zeros to the sum)
+    const bool act = KS == 1 || tid < NTC;
+    const int row = KS == 1 ? tid >> 5 : min(tid >> 5, R - 1), l32 = tid & 31;
+    const bool rok = act && row < rows_valid;
     const long grow = (long)min(r0 + row, a.row_end - 1);
     float* yrow = reinterpret_cast<float*>(lds + a.y_f32) + row * a.y_pitch;
+    float* const ywr = act ? yrow : nullptr;   // (cost_store drops a null row)
     const float* trow = tgt + row * cst.n;
     float* drow = (rok && cst.dY != nullptr) ? cst.dY + grow * cst.ldy : nullptr;
     float lsum = 0.f;
@@ -468,7 +472,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         cost_elem<PO>(cst, yrow, trow, k, sn, cs, delta, dd);
         const float gq = rok ? cst.gnorm * delta * inv * dd : 0.f;
         cost_store<PO>(cst, drow, nullptr, k, gq, sn, cs);
-        cost_store<PO>(cst, yrow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, ywr, nullptr, k, gq, sn, cs);
       }
     } else {
       for (int k = l32; k < cst.n; k += 32) {
@@ -484,10 +488,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         }
         gq = rok ? cst.gnorm * gq : 0.f;
         cost_store<PO>(cst, drow, nullptr, k, gq, sn, cs);
-        cost_store<PO>(cst, yrow, nullptr, k, gq, sn, cs);
+        cost_store<PO>(cst, ywr, nullptr, k, gq, sn, cs);
       }
     }
-    const float tsum = block_sum<NTC>(lsum, cred);
+    const float tsum = block_sum<NT_>(lsum, cred);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   };
   auto cost_phase = [&]() __attribute__((always_inline)) {
@@ -930,7 +934,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   // the row block travels ahead of the first packages and reaches LDS behind them
   float sx[8], shv[8], tv[4] = {0.f, 0.f, 0.f, 0.f};
   if (wave < p_in_Q) stage_load(wave, sx, shv);
-  if (with_cost) {
+  if (with_cost && (KS == 1 || tid < NTC)) {
     const int c = 4 * (tid & 31), row = tid >> 5;
     const long grow = (long)min(r0 + row, p_row_end - 1);
 #pragma unroll
@@ -944,11 +948,11 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     if (a.lg.partials != nullptr) {
       // (four elements per wave and pass, every load of the pass requested before the first sum: the partials were written
       //  by the all-pairs kernel on other XCDs a moment ago, a dependent trip per element was four trips)
-      for (int el0 = wave; el0 < R * N; el0 += 4 * NWC) {
+      for (int el0 = wave; el0 < R * N; el0 += 4 * NW_) {
         float v[4], zz[4], dd[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int el = el0 + u * NWC;
+          const int el = el0 + u * NW_;
           const int r = el / N, c = el - r * N;
           const bool rok = el < R * N && r0 + r < a.row_end;
           v[u] = 0.f, zz[u] = 0.f, dd[u] = 0.f;
@@ -966,13 +970,13 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-          const int el = el0 + u * NWC;
+          const int el = el0 + u * NW_;
           const float sum = wave_sum(v[u]);
           if (lane == 0 && el < R * N) lat[el] = fmaf(a.lg.center_grad, zz[u], a.lg.gscale * sum) + dd[u];
         }
       }
     } else {
-      for (int el = tid; el < R * N; el += NTC) {
+      for (int el = tid; el < R * N; el += NT_) {
         const int r = el / N, c = el - r * N;
         lat[el] = r0 + r < a.row_end ? a.dadd[(long)(r0 + r) * N + c] : 0.f;
       }
@@ -992,7 +996,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     } else if (wave < a.in_Qp) {
       stage_finish(zero8, wave, lo_off, a.in_pl, a.in_sc, a.in_aop, false);
     }
-    for (int grp = wave + NWC; grp < a.in_Qp; grp += NWC) {
+    for (int grp = wave + NW_; grp < a.in_Qp; grp += NW_) {
       if (grp < a.in_Q) {
         float x[8], hv[8], v[8];
         stage_load(grp, x, hv);
@@ -1002,7 +1006,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         stage_finish(zero8, grp, lo_off, a.in_pl, a.in_sc, a.in_aop, false);
       }
     }
-    if (with_cost) {
+    if (with_cost && (KS == 1 || tid < NTC)) {
       const int c = 4 * (tid & 31), row = tid >> 5;
       const long grow = (long)min(r0 + row, a.row_end - 1);
 #pragma unroll
@@ -1031,7 +1035,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         const CostArgs& cst = a.cost;
         const float* yb = reinterpret_cast<const float*>(lds + a.y_f32);
         const int wout = cst.ldy;
-        for (int grp = wave; grp < a.top_Qp; grp += NWC) {
+        for (int grp = wave; grp < a.top_Qp; grp += NW_) {
           const int col = 32 * grp + sc_c;
           const bool covered = (col >= cst.off_sin && col < cst.off_sin + cst.n) ||
                                (cst.periodic_output && col >= cst.off_cos && col < cst.off_cos + cst.n);
@@ -1619,6 +1623,9 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
   const int bx = blockIdx.x;
   unsigned* const sync = a.t.sync;
   const int splits = a.t.splits;
+  // (the scalar epilogue and the workgroups that gather the next batch's rows come LAST in the grid.  Round 4 tried them first --
+  //  dispatched ahead of the blocks they would run beside the whole fragment phase -- and the step got 5.6 us LONGER at 4096 rows
+  //  (70.3 against 64.6 us): their loads then compete with the first, coldest fragment requests of every block workgroup)
   if (bx >= splits * n_slots) {
     const int e = bx - splits * n_slots;   // 0: the scalar epilogue; 1 ..: the next batch's rows
     if (e == 0) {
@@ -1876,18 +1883,26 @@ __global__ __launch_bounds__(NTL) void mlp_wgrad_local_kernel(unsigned tb01, uns
     if (ticket != (unsigned)splits - 1u) return;
     if (tid == 0) __hip_atomic_store(&sync[4 + blk], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (wave < 4) {
+      // every part's share requested at once (a part beyond `splits`: a buffer of zero bytes, which answers at once with zeros),
+      // then added in the order of the parts -- as a loop of dependent loads each share was a trip to memory of its own
       typedef unsigned u32x4s __attribute__((ext_vector_type(4)));
-#pragma unroll 1
-      for (int q = 0; q < splits; ++q) {
-        const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(a.t.shares + ((long)q * n_blocks + blk) * WL_SHARE, 0, WL_SHARE * 4, 0x00020000);
-        const u32x4s x = __builtin_amdgcn_raw_buffer_load_b128(rQ, (wave * 64 + lane) * 16, 0, 16);
-        const float b = (do_bias && wave == 0 && lane < 32) ? __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rQ, (1024 + lane) * 4, 0, 16)) : 0.f;
-        if (q == 0) {
-          g[0] = __uint_as_float(x.x), g[1] = __uint_as_float(x.y), g[2] = __uint_as_float(x.z), g[3] = __uint_as_float(x.w);
-          db = b;
-        } else {
-          g[0] += __uint_as_float(x.x), g[1] += __uint_as_float(x.y), g[2] += __uint_as_float(x.z), g[3] += __uint_as_float(x.w);
-          db += b;
+      constexpr int MAXP = 4;
+      u32x4s xs[MAXP];
+      float bs_[MAXP];
+#pragma unroll
+      for (int q = 0; q < MAXP; ++q) {
+        const __amdgpu_buffer_rsrc_t rQ = __builtin_amdgcn_make_buffer_rsrc(a.t.shares + ((long)min(q, splits - 1) * n_blocks + blk) * WL_SHARE, 0,
+                                                                            q < splits ? WL_SHARE * 4 : 0, 0x00020000);
+        xs[q] = __builtin_amdgcn_raw_buffer_load_b128(rQ, (wave * 64 + lane) * 16, 0, 16);
+        bs_[q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rQ, (do_bias && wave == 0 && lane < 32) ? (1024 + lane) * 4 : (int)0x80000000, 0, 16));
+      }
+      g[0] = __uint_as_float(xs[0].x), g[1] = __uint_as_float(xs[0].y), g[2] = __uint_as_float(xs[0].z), g[3] = __uint_as_float(xs[0].w);
+      db = bs_[0];
+#pragma unroll
+      for (int q = 1; q < MAXP; ++q) {
+        if (q < splits) {   // (wave-uniform)
+          g[0] += __uint_as_float(xs[q].x), g[1] += __uint_as_float(xs[q].y), g[2] += __uint_as_float(xs[q].z), g[3] += __uint_as_float(xs[q].w);
+          db += bs_[q];
         }
       }
     }
@@ -2056,8 +2071,8 @@ int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStr
   // every GEMM one unit (all widths of the range <= 128) and at most a row block per CU or so: sixteen waves per row block
   bool small = true;
   for (int i = 0; i < b.ng; ++i) small = small && b.a.g[i].P == 1 && b.a.g[i].C == 1;
-  // 0 (default): eight waves, SMALL build; 1: sixteen waves (EXPERIMENT: measured slower -- every wave repeats the unit's scalar
-  // bookkeeping, and the exchange costs a barrier -- and its cost phase is not adapted to 1024 threads: wrong cost shares); -1: the general build
+  // 0 (default): eight waves, SMALL build; 1: sixteen waves (EXPERIMENT, measured slower: 25.8 against 21.9 us for the fused launch
+  // at 4096 rows -- every wave repeats the unit's scalar bookkeeping and the accumulator exchange costs a barrier per unit); -1: the general build
   static const int w16 = getenv("EMX_CHAIN_W16") ? atoi(getenv("EMX_CHAIN_W16")) : 0;
   if (!deep && small && w16 >= 0) {
     if (w16 >= 1) {
@@ -2721,9 +2736,12 @@ static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_nex
   // the rows of a block over several workgroups: what bounds the launch is the bytes in flight, i.e. the number of CUs at work --
   // as many parts as fit the device beside the epilogue, at least 32 row blocks (four per wave) each, at most two (C2, 72 blocks:
   // 0.0735 / 0.0714 / 0.0725-0.0732 ms per step with 1 / 2 / 3 parts -- every part's share goes through memory)
-  static const int max_splits = getenv("EMX_WGRAD_LOCAL_SPLITS") ? atoi(getenv("EMX_WGRAD_LOCAL_SPLITS")) : 2;
+  static const int max_splits = std::min(getenv("EMX_WGRAD_LOCAL_SPLITS") ? atoi(getenv("EMX_WGRAD_LOCAL_SPLITS")) : 2, 4);   // (the last arriver adds at most four shares)
   const int nrb = (n_rows + 15) / 16;
-  int splits = std::min(std::min(max_splits, (nrb + 31) / 32), (std::max(device_cus(), 1) - 1) / std::max(blocks, 1));
+  static const int gather_cap = getenv("EMX_LOCAL_GATHER_WGS") ? std::max(1, atoi(getenv("EMX_LOCAL_GATHER_WGS"))) : 1 << 20;   // (experiment: fewer gather workgroups, more passes each)
+  if (next && !next->adc_head) gather = std::min(gather, gather_cap);
+  static const bool forced = getenv("EMX_WGRAD_LOCAL_SPLITS") != nullptr;   // (an experiment may ask for more workgroups than CUs: nobody waits for a sibling)
+  int splits = std::min(std::min(max_splits, (nrb + 31) / 32), forced ? 4 : (std::max(device_cus(), 1) - 1) / std::max(blocks, 1));
   splits = std::max(splits, 1);
   *blocks_out = blocks;
   *gather_out = gather;
@@ -2834,6 +2852,7 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   a.t.cursor = finish->cursor;
   a.t.opt_step = finish->counter2;
   a.t.gather_wgs = gather;
+  a.t.n_head = (1 + gather + 7) & ~7;
   a.t.n_counted = splits * blocks + gather;
   a.t.splits = splits;
   a.t.shares = ws;
