@@ -2852,7 +2852,6 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   a.t.cursor = finish->cursor;
   a.t.opt_step = finish->counter2;
   a.t.gather_wgs = gather;
-  a.t.n_head = (1 + gather + 7) & ~7;
   a.t.n_counted = splits * blocks + gather;
   a.t.splits = splits;
   a.t.shares = ws;
