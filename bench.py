@@ -40,7 +40,8 @@ N > 1: C2 -- weak scaling, every rank trains on its own mini-batch of 4096 rows 
 RCCL all-reduce per step (engine.DataParallel mode "replica"; ``--dp-mode rowblock`` is the objective-preserving partition
 of ONE global batch, ``--global-batch``).  C4 / C5 -- ALWAYS the row-block partition of the configuration's one global
 batch (the single-process objective exactly; strong scaling): dense layers on runs of 16-row blocks,
-the symmetric all-pairs tiles dealt to the ranks, two all-reduces per step.
+the all-pairs pass either as the rectangle (own rows) x (all rows) with ONE all-reduce per step (small passes: C2-sized) or with
+its symmetric tiles dealt to the ranks and TWO all-reduces (C4, C5) -- ``--collectives``, default: chosen per configuration.
 """
 from __future__ import annotations
 
@@ -541,6 +542,9 @@ def main():
     ap.add_argument("--dp-mode", default=None, choices=["replica", "rowblock"])
     ap.add_argument("--global-batch", type=int, default=-1,
                     help="--dp-mode rowblock: rows of the ONE global batch all ranks share (default: the configuration's batch; 0: that batch per rank)")
+    ap.add_argument("--collectives", type=int, default=0, choices=[0, 1, 2],
+                    help="--dp-mode rowblock: 1 = the rectangle form of the all-pairs pass (one collective per step), 2 = dealt triangle "
+                         "(two); 0 (default): chosen per configuration by engine.DataParallel.one_collective")
     ap.add_argument("--one-rank-dp", action="store_true",
                     help="N = 1 only: run the DATA-PARALLEL code path (probe, RCCL group, all-reduce) with its one rank -- a self-test, "
                          "not a benchmark configuration")
@@ -618,12 +622,12 @@ def main():
     rowblock = dp_mode == "rowblock" and world > 1
     gb = B if args.global_batch < 0 else args.global_batch
     batch = (gb or B * world) if rowblock else B     # rows per engine step: the rank's own batch, or the shared one
-    dp = DataParallel(rank, world, dp_mode) if world > 1 else None
+    dp = DataParallel(rank, world, dp_mode, collectives=args.collectives or None) if world > 1 else None
     if multi and world == 1:
         class _OneRank(DataParallel):      # the data-parallel path with the one rank a single GPU allows
             active = True
 
-        dp = _OneRank(0, 1, dp_mode)
+        dp = _OneRank(0, 1, dp_mode, collectives=args.collectives or None)
     n_rows = args.rows or cfg["rows"]
     kw = dict(cfg["kw"], batch_size=batch)
     if cfg["model"] == "adc":
@@ -659,8 +663,11 @@ def main():
     if rank == 0:
         global_batch = batch if rowblock else B * world
         if rowblock:
+            one = not eng._dealt()
             objective = (f"one sketch-map cost over one global batch of {batch} rows (the single-process objective at that batch size); "
-                         f"dense layers on {world} runs of 16-row blocks, the upper-triangle tiles of the all-pairs pass dealt round-robin")
+                         f"dense layers on {world} runs of 16-row blocks, " +
+                         ("the all-pairs pass as the rectangle (own rows) x (all rows): ONE collective per step" if one else
+                          "the upper-triangle tiles of the all-pairs pass dealt round-robin: TWO collectives per step"))
             scaling = "strong" if batch == B else "weak"
         else:
             objective = (f"mean of {world} independent costs over {B} rows each (gradients averaged)" if world > 1
@@ -681,6 +688,7 @@ def main():
                                                       (f" [batch {B} per GPU]" if world > 1 else "")),
                        "name": name, "rows_resident": int(n_rows), "global_batch": global_batch, "features": D,
                        "parallelism": f"dp{world}-{dp_mode}" if world > 1 else "single", "objective": objective,
+                       "collectives_per_step": (None if not multi else (1 if (not rowblock or not eng._dealt()) else 2)),
                        "ranks_seen": dist.get_world_size() if multi else 1, "backend": backend if multi else None, "rccl_version": rccl,
                        "allreduce": ("captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None,
                        "graph_allreduce_probe": probe,

@@ -50,18 +50,40 @@ class DataParallel:
     """Partition of one step over ranks.  ``mode``:
 
     ``"rowblock"``  every rank sees the same global batch of ``batch_size`` rows and owns a contiguous row block of it for
-                    the dense layers; the all-pairs cost runs symmetrically over the whole batch with its upper-triangle
-                    tiles DEALT to the ranks (1 / G of the pair work each).  Two small SUM all-reduces per step -- the
-                    [B, L] latent gradient in front of the encoder's backward pass, the flat [gradient | cost terms]
-                    buffer in front of the optimizer: the single-process objective exactly.
+                    the dense layers: the single-process objective exactly.  The all-pairs cost comes in two forms
+                    (``collectives``): ONE collective per step -- SURVEY.md section 8e as written: the rank runs the
+                    rectangle (its rows) x (all rows) and has d cost / d z of its own rows by the symmetry of the pair
+                    terms, 2 / G of the pair work, the only collective is the all-reduce of [gradient | cost terms] -- or TWO --
+                    the symmetric pass over the whole batch with its upper-triangle tiles DEALT to the ranks, 1 / G of the
+                    pair work each, and a SUM all-reduce of the [B, L] latent-gradient shares in front of the encoder's
+                    backward pass.  ``collectives=None`` chooses per configuration (``one_collective``): the rectangle
+                    wherever the pair work it adds costs less than a latency-bound collective (C2: ~2 us against ~25),
+                    the dealt triangle for the large all-pairs passes (C4 / C5: hundreds of microseconds per step).
     ``"replica"``   every rank draws its own mini-batch of ``batch_size`` rows and gradients are averaged:
                     classic data parallelism (weak scaling), the objective is the mean of the per-rank costs.
     """
 
-    def __init__(self, rank: int = 0, world_size: int = 1, mode: str = "replica", group=None):
+    # what one more latency-bound collective costs a step, and what a pair-element of the all-pairs pass costs a GPU (measured on
+    # one MI355X: 17 us at 4096 x 4096 x 128 on the f16 matrix cores, 1.30 ms at 8192 x 8192 x 512 on the periodic VALU tiles)
+    COLLECTIVE_SECONDS = 25e-6
+    PAIR_ELEMENT_SECONDS = {False: 17e-6 / (4096.0 * 4096.0 * 128.0 / 2), True: 1.30e-3 / (8192.0 * 8192.0 * 512.0 / 2)}
+
+    def __init__(self, rank: int = 0, world_size: int = 1, mode: str = "replica", group=None, collectives: Optional[int] = None):
         if mode not in ("rowblock", "replica"):
             raise ValueError(f"data-parallel mode {mode!r} not available")
+        if collectives not in (None, 1, 2):
+            raise ValueError(f"collectives must be None (chosen per configuration), 1 or 2, got {collectives!r}")
         self.rank, self.world_size, self.mode, self.group = int(rank), int(world_size), mode, group
+        self.collectives = collectives
+
+    def one_collective(self, batch_size: int, n_features: int, periodic: bool) -> bool:
+        """Row-block ranks: the rectangle form of the all-pairs pass (one collective per step) or the dealt triangle (two)?
+        The rectangle costs every rank 1 / G of the full symmetric pass MORE than the triangle does; it wins where that is less than
+        a collective.  The same answer on every rank (a function of the configuration alone)."""
+        if self.collectives is not None:
+            return self.collectives == 1
+        extra = self.PAIR_ELEMENT_SECONDS[bool(periodic)] * (0.5 * batch_size * batch_size * n_features) / max(self.world_size, 1)
+        return extra < self.COLLECTIVE_SECONDS
 
     @property
     def active(self) -> bool:
@@ -464,8 +486,10 @@ class SequentialEngine:
     _waits_used = False   # a launch with an in-launch wait has been issued by this engine (check_sync has something to check)
 
     def _dealt(self) -> bool:
-        """data parallel over row blocks with the all-pairs tiles dealt to the ranks (DataParallel mode "rowblock")"""
-        return self.dp.active and self.dp.mode == "rowblock" and self._use_sketchmap()
+        """data parallel over row blocks with the all-pairs tiles dealt to the ranks (DataParallel mode "rowblock", two collectives
+        per step); False for the rectangle form (one collective: the rank's rows x all rows through the single-process kernels)"""
+        return (self.dp.active and self.dp.mode == "rowblock" and self._use_sketchmap()
+                and not self.dp.one_collective(self.B, self.D, self.periodic))
 
     def _latent_costs(self) -> None:
         """all-pairs tile pass of the sketch-map cost (its O(B) reduction is folded into the encoder's backward kernel and

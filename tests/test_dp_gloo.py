@@ -44,14 +44,14 @@ def _setup():
     return p, x, w0
 
 
-def _rank_flat(rank, world, mode, p, x, w0, reduce_latent=True):
+def _rank_flat(rank, world, mode, p, x, w0, reduce_latent=True, collectives=2):
     """[grad | auto, center, distance] as rank `rank` computes it, following the engine's scheme (engine.py:
     _step_pre_a, _mid_collective, _step_pre_b): encoder on all rows; this rank's dealt tiles of the symmetric all-pairs
     pass (oracle: direct_ops) give its share of d distance / dz of EVERY row, summed over the ranks by the first
     collective; decoder, auto cost, center cost and the backward pass on its own rows."""
     from encodermap_amd.engine import DataParallel
 
-    dp = DataParallel(rank, world, mode)
+    dp = DataParallel(rank, world, mode, collectives=collectives if mode == "rowblock" else None)
     B = x.shape[0]
     xr = np.roll(x, 7 * rank, axis=0).copy() if mode == "replica" else x     # replica: own mini-batch per rank
     rb, re = dp.row_block(B)
@@ -60,11 +60,17 @@ def _rank_flat(rank, world, mode, p, x, w0, reduce_latent=True):
     z = model.encoder(X)
     y = model.decoder(z[rb:re])
     auto = torch.sum(torch.abs(R.periodic_distance(X[rb:re], y, p.periodicity))) / (B * 5) * p.auto_cost_scale
-    loss_d, dZ = D.sketchmap_tiles_fwd_bwd(xr, z.detach().numpy(), p.periodicity, p.dist_sig_parameters, p.distance_cost_scale,
-                                           dp.dealt_tiles(B, TILE), TILE)
-    dZ = torch.tensor(dZ)
-    if reduce_latent and mode == "rowblock":     # (replica ranks hold whole batches of their own: no exchange here)
-        dp.all_reduce_(dZ, op="sum")
+    if mode == "rowblock" and dp.one_collective(B, 5, True):
+        # ONE collective (SURVEY.md section 8e as written): the rectangle (own rows) x (all rows) -- the rank's share of the cost and,
+        # by the symmetry of the pair terms, the complete d distance / dz of its own rows; nothing to exchange in front of the backward pass
+        loss_d, dZ = D.sketchmap_fwd_bwd(xr, z.detach().numpy(), p.periodicity, p.dist_sig_parameters, p.distance_cost_scale, rb, re)
+        dZ = torch.tensor(dZ)
+    else:
+        loss_d, dZ = D.sketchmap_tiles_fwd_bwd(xr, z.detach().numpy(), p.periodicity, p.dist_sig_parameters, p.distance_cost_scale,
+                                               dp.dealt_tiles(B, TILE), TILE)
+        dZ = torch.tensor(dZ)
+        if reduce_latent and mode == "rowblock":     # (replica ranks hold whole batches of their own: no exchange here)
+            dp.all_reduce_(dZ, op="sum")
     center = torch.sum(z[rb:re] ** 2) / (B * 2) * p.center_cost_scale
     surrogate = auto + center + torch.sum(dZ[rb:re] * z[rb:re])
     grads = torch.autograd.grad(surrogate, model.params)
@@ -72,12 +78,12 @@ def _rank_flat(rank, world, mode, p, x, w0, reduce_latent=True):
     return dp, flat.detach()
 
 
-def _worker(rank, world, port, mode, out_dir):
+def _worker(rank, world, port, mode, out_dir, collectives=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     p, x, w0 = _setup()
-    dp, flat = _rank_flat(rank, world, mode, p, x, w0)
+    dp, flat = _rank_flat(rank, world, mode, p, x, w0, collectives=collectives)
     dp.all_reduce_(flat)
     np.save(os.path.join(out_dir, f"{mode}_{rank}.npy"), flat.numpy())
     dist.destroy_process_group()
@@ -103,9 +109,26 @@ def test_dealt_tiles_partition_the_upper_triangle():
     np.testing.assert_allclose(tiled[1], full[1], rtol=1e-10, atol=1e-14)
 
 
-@pytest.mark.parametrize("mode,world", [("rowblock", 2), ("rowblock", 3), ("replica", 2)])
-def test_ranks(mode, world, tmp_path):
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path)), nprocs=world, join=True)
+def test_the_form_of_the_row_block_step_is_chosen_per_configuration():
+    """one collective (the rectangle: 1 / G more pair work per rank) where that extra work costs less than a latency-bound
+    collective, two (dealt triangle) for the large all-pairs passes; an explicit choice wins; the same answer on every rank"""
+    from encodermap_amd.engine import DataParallel
+
+    for rank in (0, 7):
+        dp = DataParallel(rank, 8, "rowblock")
+        assert dp.one_collective(4096, 128, False)          # C2: ~2 us of pair work against a ~25 us collective
+        assert not dp.one_collective(16384, 256, False)     # C5
+        assert not dp.one_collective(8192, 512, True)       # C4
+        assert dp.one_collective(256, 10, True)             # C1
+    assert DataParallel(0, 8, "rowblock", collectives=2).one_collective(256, 10, True) is False
+    assert DataParallel(0, 8, "rowblock", collectives=1).one_collective(16384, 256, False) is True
+    with pytest.raises(ValueError):
+        DataParallel(0, 2, "rowblock", collectives=3)
+
+
+@pytest.mark.parametrize("mode,world,collectives", [("rowblock", 2, 2), ("rowblock", 3, 2), ("rowblock", 2, 1), ("rowblock", 3, 1), ("replica", 2, 2)])
+def test_ranks(mode, world, collectives, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), collectives), nprocs=world, join=True)
     got = [np.load(tmp_path / f"{mode}_{r}.npy") for r in range(world)]
     for g in got[1:]:
         np.testing.assert_array_equal(got[0], g)                  # every rank holds the same reduced buffer

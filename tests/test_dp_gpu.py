@@ -44,7 +44,7 @@ def _weights(p):
     return unpack_weights(lay, init_parameters(lay, 2))
 
 
-def _worker(rank, world, port, mode, out_dir, euclid=False):
+def _worker(rank, world, port, mode, out_dir, euclid=False, collectives=None):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -55,7 +55,8 @@ def _worker(rank, world, port, mode, out_dir, euclid=False):
 
     data = _data(euclid)
     p = _params(em, euclid)
-    e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=DataParallel(rank, world, mode))
+    e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=DataParallel(rank, world, mode, collectives=collectives))
+    assert e._engine._dealt() == (mode == "rowblock" and collectives == 2)
     if mode == "rowblock":
         idx = np.random.default_rng(5).integers(0, 3000, (6, p.batch_size))
         e._engine.run_steps(6, torch.from_numpy(idx.reshape(-1)).cuda())
@@ -66,16 +67,19 @@ def _worker(rank, world, port, mode, out_dir, euclid=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode,world,euclid", [("rowblock", 2, False), ("rowblock", 3, False), ("rowblock", 2, True), ("rowblock", 3, True),
-                                               ("replica", 2, False)])
-def test_ranks_on_one_gpu(mode, world, euclid, tmp_path):
-    """rowblock: the dense layers on balanced runs of 16-row blocks (ragged at 3 ranks), the all-pairs tiles dealt
-    round-robin, two SUM all-reduces per step (latent gradient, [gradient | terms]) -- the single-process trajectory."""
+@pytest.mark.parametrize("mode,world,euclid,collectives", [("rowblock", 2, False, 2), ("rowblock", 3, False, 2), ("rowblock", 2, True, 2),
+                                                           ("rowblock", 3, True, 2), ("rowblock", 2, False, 1), ("rowblock", 3, True, 1),
+                                                           ("rowblock", 2, True, 1), ("replica", 2, False, None)])
+def test_ranks_on_one_gpu(mode, world, euclid, collectives, tmp_path):
+    """rowblock: the dense layers on balanced runs of 16-row blocks (ragged at 3 ranks) and the all-pairs cost in both forms --
+    two collectives: the tiles of the symmetric pass dealt round-robin, SUM all-reduces of the latent gradient and of
+    [gradient | terms]; one collective: the rank's rows x all rows (SURVEY.md section 8e as written), the gradient of its own rows
+    complete without an exchange -- the single-process trajectory either way."""
     import torch.multiprocessing as mp
 
     import encodermap_amd as em
 
-    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), euclid), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), euclid, collectives), nprocs=world, join=True)
     runs = [np.load(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
     for r in runs[1:]:
         np.testing.assert_array_equal(runs[0]["w"], r["w"])         # replicated optimizer: identical weights on every rank
@@ -94,7 +98,7 @@ def test_ranks_on_one_gpu(mode, world, euclid, tmp_path):
         assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3
 
 
-def _one_rank_rccl_worker(rank, port, out_dir, mode="replica"):
+def _one_rank_rccl_worker(rank, port, out_dir, mode="replica", collectives=None):
     """The data-parallel path over RCCL itself, with the one rank a single GPU allows: two hipGraphs around the eager
     all-reduce, and (EMX_DP_GRAPH_ALLREDUCE=1) the all-reduce captured inside the step's graph."""
     import torch.distributed as dist
@@ -116,7 +120,7 @@ def _one_rank_rccl_worker(rank, port, out_dir, mode="replica"):
     for name, captured in (("eager", False), ("captured", True)):
         SequentialEngine._dp_graph_allreduce = captured
         p = em.Parameters(n_steps=20, batch_size=256, seed=11)
-        e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=OneRank(0, 1, mode))
+        e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=OneRank(0, 1, mode, collectives=collectives))
         e._engine.run_steps(20)
         out[name] = e._engine.losses()
         out[name + "_graphs"] = np.array(len(e._engine._graph))
@@ -129,17 +133,17 @@ def _one_rank_rccl_worker(rank, port, out_dir, mode="replica"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("mode", ["replica", "rowblock"])
-def test_one_rank_over_rccl(mode, tmp_path):
+@pytest.mark.parametrize("mode,collectives", [("replica", None), ("rowblock", 2), ("rowblock", 1)])
+def test_one_rank_over_rccl(mode, collectives, tmp_path):
     """replica: one all-reduce per step; rowblock: the dealt all-pairs tiles (all of them: one rank), the latent-gradient
     all-reduce in front of the encoder backward and the [gradient | terms] all-reduce -- eagerly between three graphs, or both
     captured inside the step's graph."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), str(tmp_path), mode), nprocs=1, join=True)
+    mp.spawn(_one_rank_rccl_worker, args=(_free_port(), str(tmp_path), mode, collectives), nprocs=1, join=True)
     r = np.load(tmp_path / "one_rank.npz")
     assert np.isfinite(r["eager"]).all() and len(r["eager"]) == 20
-    assert int(r["eager_graphs"]) == (3 if mode == "rowblock" else 2) and int(r["captured_graphs"]) == 1
+    assert int(r["eager_graphs"]) == (3 if collectives == 2 else 2) and int(r["captured_graphs"]) == 1
     np.testing.assert_array_equal(r["eager"], r["captured"])          # same kernels, same order: bitwise the same run
     np.testing.assert_array_equal(r["eager_w"], r["captured_w"])
     # one rank averages with itself: the single-process run up to the summation order of the gradient partials (the
@@ -173,6 +177,9 @@ def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
     assert line["n_gpus"] == 2 and line["steps"] == 24 and line["scaling"] == scaling
     cfg = line["config"]
     assert cfg["global_batch"] == batch and cfg["parallelism"] == f"dp2-{mode}" and cfg["ranks_seen"] == 2
+    # (the form of the row-block step is chosen per configuration: C2-sized all-pairs passes as the rectangle with ONE collective,
+    #  C5's as dealt tiles with two; replica ranks always one)
+    assert cfg["collectives_per_step"] == (2 if "C5" in extra else 1)
     assert cfg["allreduce"] == "eager between the step's graphs" and str(batch if mode == "rowblock" else 4096) in cfg["objective"]
     assert cfg["name"] == ("C5" if "C5" in extra else "C2") and cfg["name"] in cfg["workload"]
     assert line["value"] == pytest.approx(batch * line["steps_per_sec"], rel=1e-6)
