@@ -588,6 +588,12 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   //  is stated: 8 tiles resident per CU: <= 64 VGPRs, <= 20 KB LDS)
   constexpr int T = 64;
   constexpr int LMAX = LT ? LT : 4;
+  // LT = 8: latent widths 5 .. 8 (run-time width, zero padded).  Every consumer plans latents beyond four columns on the 32-tile
+  // layout of the workspace (pick_tile: their VALU tiles only fit the static LDS limit at 32 x 32); this 64 x 64 tile therefore
+  // WRITES that layout (OUT32) -- its row sums into slot 2 tj of the 32-row blocks it covers, zeros into slot 2 tj + 1, its cost
+  // into the slot of 32-tile (2 ti, 2 tj) and zeros into its other 32-tiles' -- as the 128 x 128 macro-tiles write the 64-tile
+  // layout (below).  The sums the consumers form over the slots are the 32-tile pass's up to the association of the additions.
+  constexpr bool OUT32 = LT > 4;
   constexpr int RP = 20;                                // 16 pre-reduced column-lane partials per (row, l) + pad
   constexpr int STAGE = 1024 * 4;                       // 2 sides x 2 planes x 64 rows x 32 k f16, as 16-byte pieces
   constexpr int PART = T * LMAX * RP;                   // row partials (reuse the staging area)
@@ -815,6 +821,42 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   KSTAMP(21);
   float tl = block_sum<NT>(lsum, red);   // contains __syncthreads -> partials visible
   KSTAMP(22);
+  if constexpr (OUT32) {
+    // ---- the 32-tile layout (a.nbc, a.nrows_pad, a.P, a.tile_loss are the 32-tile plan's): this tile covers the 32-tiles
+    //      (2 ti + p, 2 tj + q); symmetric pass: those with 2 ti + p <= 2 tj + q
+    const int nbc = a.nbc, nbr = a.nbr;
+    if (tid < 4) {
+      const int si = 2 * ti + (tid >> 1), sj = 2 * tj + (tid & 1);
+      const float val = tid == 0 ? (offdiag ? 2.f * tl : tl) : 0.f;
+      if (p_symm) {
+        if (si <= sj && sj < nbc) a.tile_loss[si * nbc - si * (si - 1) / 2 + (sj - si)] = val;
+      } else if (si < nbr && sj < nbc) {
+        a.tile_loss[si * nbc + sj] = val;
+      }
+    }
+    const int ir = i0 - a.row0;   // first row of the tile among the rows the plan handles
+    for (int e = tid; e < T * LMAX; e += NT) {
+      const int rl = e / LMAX, l = e - rl * LMAX;
+      if (l < L && ir + rl < a.nrows_pad) {
+        const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+        const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+        const float s = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                        (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+        a.P[((long)(2 * tj) * a.nrows_pad + ir + rl) * L + l] = s;
+        if (2 * tj + 1 < nbc) a.P[((long)(2 * tj + 1) * a.nrows_pad + ir + rl) * L + l] = 0.f;
+      }
+    }
+    if (offdiag) {
+      for (int e = tid; e < T * LMAX; e += NT) {
+        const int rl = e / LMAX, l = e - rl * LMAX;
+        if (l < L && j0 - a.row0 + rl < a.nrows_pad) {
+          a.P[((long)(2 * ti) * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+          a.P[((long)(2 * ti + 1) * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = 0.f;
+        }
+      }
+    }
+    return;
+  }
   if (tid == 0) a.tile_loss[tslot] = offdiag ? 2.f * tl : tl;
 
   for (int e = tid; e < T * LMAX; e += NT) {
@@ -1429,6 +1471,29 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       else hipLaunchKernelGGL((sk_tile_mfma_kernel<0, false>), dim3(pl.ntiles), dim3(NT), 0, st, a);
     }
     return emx::check_launch("sk_tile_mfma_kernel");
+  }
+  if (a.split.planes != nullptr && pl.T == 32 && !pl.periodic && a.L > 4 && a.L <= 8 && a.deal_world <= 1 && a.B >= 64) {
+    // latent widths 5 .. 8 on split rows: the Gram tiles of the f16 matrix cores at 64 x 64, writing the 32-tile layout every
+    // consumer of these widths plans with (sk_tile_f16_kernel: OUT32) -- the 32 x 32 VALU tiles they replace cost 7x the two-column
+    // pass at 4096 rows (113-126 us against 17).  Not for dealt tiles: the deal is by 32-tile.
+    const int nch = a.split.ld / SPLIT_KC;
+    const int nbc64 = (a.B + 63) / 64, nbr64 = (a.row_end - a.row0 + 63) / 64;
+    int grid = a.symm ? nbc64 * (nbc64 + 1) / 2 : nbr64 * nbc64;
+    int xnbg = 0;
+    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    if (a.symm && nbc64 >= 16 && xcd_order) {
+      xnbg = (nbc64 + 3) / 4;
+      grid = 8 * xnbg * (xnbg + 1);
+    }
+#define SK_F16_LAUNCH32(kern)                                                                                                                      \
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, st, (const uint16_t*)a.split.planes, (long)a.split.plane_stride, xnbg, nbc64, a.symm, 1, 0, a.row0, \
+                     a.B, a.split.B, a.split.ld, 0, a)
+    if (pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 4>));
+    else if (pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 8>));
+    else if (pl.fast) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 0>));
+    else SK_F16_LAUNCH32((sk_tile_f16_kernel<8, false, 0>));
+#undef SK_F16_LAUNCH32
+    return emx::check_launch("sk_tile_f16_kernel (latent widths 5 .. 8)");
   }
   if (pl.T == 32) {
     if (a.L == 2) dispatch2<32, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);
