@@ -164,6 +164,12 @@ def make_auto_cost(target, n, off_sin, off_cos, periodic_output, periodicity, va
     return c
 
 
+def _activation_code(name) -> int:
+    from .layout import ACTIVATION_CODES      # (layout.py is the one table of names; include/emx.h: emx_mlp_desc::act)
+
+    return ACTIVATION_CODES[name] if name else 0
+
+
 class SketchmapPartials(C.Structure):
     """Mirror of ``emx_sketchmap_partials``."""
 
@@ -227,7 +233,7 @@ class MlpPlan:
         d.width[0] = layout.net_dim
         for i, lyr in enumerate(layout.layers):
             d.width[i + 1] = lyr.n_out
-            d.act[i] = 1 if lyr.activation == "tanh" else 0
+            d.act[i] = _activation_code(lyr.activation)
             d.w_off[i] = lyr.w_off
             d.b_off[i] = lyr.b_off
         self.desc = d

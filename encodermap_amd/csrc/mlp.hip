@@ -96,7 +96,49 @@ __device__ __forceinline__ unsigned row16_max(unsigned x) {
 // store: results leave through buffer resources whose bounds check drops what does not exist), so that every s_waitcnt
 // the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
 // ---------------------------------------------------------------------------------------------------------
-enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8, S_WAIT = 16 };   // S_WAIT (PUB builds): the tile workgroups' partial sums are awaited and joined in front of this epilogue   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
+// Activations of a layer (emx_mlp_desc::act; models.py:3179-3220 hands any Keras activation name to Dense): 1 = tanh is the fast
+// path of every kernel here (fixed-scale images, its own switch cases); 2 .. 8 are the Keras activations whose derivative is a
+// function of the OUTPUT -- so that, like tanh, the backward pass needs h and not the pre-activation -- evaluated with the
+// hardware exp2 / log2 / rcp (absolute error ~1e-7, the float32 resolution of O(1) activations).
+enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_ELU = 4, ACT_SOFTPLUS = 5, ACT_SELU = 6, ACT_SOFTSIGN = 7, ACT_EXP = 8, ACT_LAST = 8 };
+constexpr float SELU_ALPHA = 1.6732632423543772f, SELU_SCALE = 1.0507009873554805f, LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
+__device__ __forceinline__ float act_apply(const int kind, const float x) {   // kind: wave-uniform
+  switch (kind) {
+    case ACT_RELU: return fmaxf(x, 0.f);
+    case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-LOG2E * x));
+    case ACT_ELU: return x > 0.f ? x : __builtin_amdgcn_exp2f(LOG2E * x) - 1.f;
+    case ACT_SOFTPLUS: return fmaxf(x, 0.f) + LN2 * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-LOG2E * fabsf(x)));
+    case ACT_SELU: return SELU_SCALE * (x > 0.f ? x : SELU_ALPHA * (__builtin_amdgcn_exp2f(LOG2E * x) - 1.f));
+    case ACT_SOFTSIGN: return x * __builtin_amdgcn_rcpf(1.f + fabsf(x));
+    case ACT_EXP: return __builtin_amdgcn_exp2f(LOG2E * x);
+    default: return x;
+  }
+}
+__device__ __forceinline__ float act_deriv_from_output(const int kind, const float h) {   // d act / d x as a function of h = act(x)
+  switch (kind) {
+    case ACT_RELU: return h > 0.f ? 1.f : 0.f;
+    case ACT_SIGMOID: return h * (1.f - h);
+    case ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
+    case ACT_SOFTPLUS: return 1.f - __builtin_amdgcn_exp2f(-LOG2E * h);
+    case ACT_SELU: return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
+    case ACT_SOFTSIGN: { const float t = 1.f - fabsf(h); return t * t; }
+    case ACT_EXP: return h;
+    default: return 1.f;
+  }
+}
+// S_ACT: the layer has an activation (its derivative in backward units); S_ACTX: ... and it is not tanh -- its kind sits in bits
+// 8 .. 11; S_BND: a forward layer whose outputs lie in [-1, 1] (tanh, sigmoid, softsign): its image is written at the fixed scale 2^14
+enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8, S_WAIT = 16, S_ACTX = 32, S_BND = 64 };
+constexpr int S_KIND_SHIFT = 8;
+inline int act_flags(int kind) {
+  if (kind == ACT_NONE) return 0;
+  int f = S_ACT | (kind << S_KIND_SHIFT);
+  if (kind != ACT_TANH) f |= S_ACTX;
+  if (kind == ACT_TANH || kind == ACT_SIGMOID || kind == ACT_SOFTSIGN) f |= S_BND;
+  return f;
+}
+inline bool act_bounded(int kind) { return kind == ACT_TANH || kind == ACT_SIGMOID || kind == ACT_SOFTSIGN; }
+// S_WAIT (PUB builds): the tile workgroups' partial sums are awaited and joined in front of this epilogue   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
 
 struct GemmRec {          // one layer of the range in one direction: P x C regular units (128 columns x 128 k)
   int P, C;               // passes of 128 output columns, chunks of 128 reduction indices
@@ -281,7 +323,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       float y = x[e];
       if (BWD) {
         if (a.top_flags & S_JOIN) y += lat[row * sK + cc];
-        if (a.top_flags & S_ACT) y *= fmaf(-hv[e], hv[e], 1.f);
+        if (a.top_flags & S_ACT) y *= (a.top_flags & S_ACTX) ? act_deriv_from_output((a.top_flags >> S_KIND_SHIFT) & 15, hv[e]) : fmaf(-hv[e], hv[e], 1.f);
       }
       v[e] = y * ((col < sK && row < rows_valid) ? 1.f : 0.f);
       if (BWD && a.top_out != nullptr && col < sK && row < rows_valid) a.top_out[(long)(r0 + row) * sK + col] = v[e];
@@ -686,7 +728,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const bool last = SMALL || ex.c == ex.C - 1;
     const int sflags = X.sflags;
     const bool ubwd = (sflags & S_BWD) != 0;
-    const bool bounded = !ubwd && (sflags & S_ACT);            // tanh outputs: fixed scale
+    const bool bounded = !ubwd && (sflags & S_BND);            // outputs in [-1, 1] (tanh, sigmoid, softsign): fixed scale
     const bool has_img = X.dst_pl >= 0;
     const int col = 128 * exp_ + 16 * tw + n;
     const int row0l = 4 * g + kh * NR;                          // first of the lane's rows inside the row block
@@ -725,12 +767,15 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       // wave-uniform: ONE scalar switch in front of straight-line code per kind.  (Left as tests inside the loop over the lane's
       // rows the compiler branched per ELEMENT, and waited for each element's LDS operand before it asked for the next one's.)
       auto values = [&](auto UB_, auto AC_, auto JN_) __attribute__((always_inline)) {
-        constexpr bool UB = decltype(UB_)::value != 0, AC = decltype(AC_)::value != 0, JN = decltype(JN_)::value != 0;
+        constexpr bool UB = decltype(UB_)::value != 0, JN = decltype(JN_)::value != 0;
+        constexpr int AC = decltype(AC_)::value;   // 0: none, 1: tanh, 2: another activation (its kind in the flags)
+        const int akind = (sflags >> S_KIND_SHIFT) & 15;
         if constexpr (!UB) {
 #pragma unroll
           for (int rr = 0; rr < NR; ++rr) {
             float x = fmaf(tot[rr], cmul, ep[rx][0]);
-            if constexpr (AC) x = tanh_f32(x);
+            if constexpr (AC == 1) x = tanh_f32(x);
+            if constexpr (AC == 2) x = act_apply(akind, x);
             v[rr] = x;
           }
         } else {
@@ -748,18 +793,22 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           for (int rr = 0; rr < NR; ++rr) {
             float x = tot[rr] * cmul;
             if constexpr (JN) x += jn[rr];
-            if constexpr (AC) x *= fmaf(-hv[rr], hv[rr], 1.f);
+            if constexpr (AC == 1) x *= fmaf(-hv[rr], hv[rr], 1.f);
+            if constexpr (AC == 2) x *= act_deriv_from_output(akind, hv[rr]);
             v[rr] = x;
           }
         }
       };
-      switch (sflags & (S_ACT | S_JOIN | S_BWD)) {
+      switch (sflags & (S_ACT | S_JOIN | S_BWD | S_ACTX)) {
         case 0: values(IC_<0>{}, IC_<0>{}, IC_<0>{}); break;
         case S_ACT: values(IC_<0>{}, IC_<1>{}, IC_<0>{}); break;
         case S_BWD: values(IC_<1>{}, IC_<0>{}, IC_<0>{}); break;
         case S_BWD | S_ACT: values(IC_<1>{}, IC_<1>{}, IC_<0>{}); break;
         case S_BWD | S_JOIN: values(IC_<1>{}, IC_<0>{}, IC_<1>{}); break;
         case S_BWD | S_JOIN | S_ACT: values(IC_<1>{}, IC_<1>{}, IC_<1>{}); break;
+        case S_ACT | S_ACTX: values(IC_<0>{}, IC_<2>{}, IC_<0>{}); break;
+        case S_BWD | S_ACT | S_ACTX: values(IC_<1>{}, IC_<2>{}, IC_<0>{}); break;
+        case S_BWD | S_JOIN | S_ACT | S_ACTX: values(IC_<1>{}, IC_<2>{}, IC_<1>{}); break;
         default: values(IC_<0>{}, IC_<0>{}, IC_<0>{}); break;   // (forward units carry no join)
       }
       if (X.dst_f32 >= 0) {   // (the copy's rows are padded to whole passes: every lane has a slot)
@@ -1954,6 +2003,9 @@ int check_desc(const emx_mlp_desc* desc, const char* who) {
   EMX_REQUIRE(desc, "%s: null descriptor", who);
   EMX_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= MAXL, "%s: %d layers not supported (1..%d)", who, desc->n_layers, MAXL);
   for (int l = 0; l <= desc->n_layers; ++l) EMX_REQUIRE(desc->width[l] >= 1, "%s: layer width must be >= 1", who);
+  for (int l = 0; l < desc->n_layers; ++l)
+    EMX_REQUIRE(desc->act[l] >= ACT_NONE && desc->act[l] <= ACT_LAST, "%s: activation code %d of layer %d not available (0 .. %d, include/emx.h)", who,
+                desc->act[l], l, (int)ACT_LAST);
   return EMX_OK;
 }
 
@@ -2171,8 +2223,8 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
     const bool last = st == nf - 1;
     // the fragments of h_l are the X operand of layer l + 1's weight gradient: not needed for the network's last layer
     const AopTensor ao = (aop && l + 1 < desc->n_layers) ? aop_tensor(aop, AL, 1 + l) : AopTensor{nullptr, nullptr, 0};
-    const int gi = b.add_gemm(l, false, st & 1, st > 0 && desc->act[l - 1], (!last || tail_frags) ? (st + 1) & 1 : -1, params + desc->b_off[l], 0,
-                              h[l], desc->act[l] ? S_ACT : 0, ao);
+    const int gi = b.add_gemm(l, false, st & 1, st > 0 && act_bounded(desc->act[l - 1]), (!last || tail_frags) ? (st + 1) & 1 : -1, params + desc->b_off[l], 0,
+                              h[l], act_flags(desc->act[l]), ao);
     if (gi < 0) return gi;
   }
   ChainArgs& a = b.a;
@@ -2231,7 +2283,7 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   if (join) a.join_n = desc->width[layer_add + 1];
   a.dadd = dadd;
   for (int l = layer_begin; l < layer_end; ++l) EMX_REQUIRE(!desc->act[l] || h[l], "%s: activations of layer %d are needed for its derivative", who, l);
-  auto sflags = [&](int l) { return (desc->act[l] ? S_ACT : 0) | ((join && l == layer_add) ? S_JOIN : 0); };
+  auto sflags = [&](int l) { return act_flags(desc->act[l]) | ((join && l == layer_add) ? S_JOIN : 0); };
   auto dop = [&](int l) { return aop ? aop_tensor(aop, AL, 1 + n + l) : AopTensor{nullptr, nullptr, 0}; };
   const int top = layer_end - 1;
   a.top_h = h[top];
@@ -2365,8 +2417,8 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
     const bool last = st == nf - 1;
     const AopTensor ao = (aop && l + 1 < n) ? aop_tensor(aop, AL, 1 + l) : AopTensor{nullptr, nullptr, 0};
     EMX_REQUIRE(!(last && ao.frag), "%s: the fused launch ends at the network's last layer", who);
-    const int gi = b.add_gemm(l, false, st & 1, st > 0 && desc->act[l - 1], last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l],
-                              desc->act[l] ? S_ACT : 0, ao);
+    const int gi = b.add_gemm(l, false, st & 1, st > 0 && act_bounded(desc->act[l - 1]), last ? -1 : (st + 1) & 1, params + desc->b_off[l], 0, h[l],
+                              act_flags(desc->act[l]), ao);
     if (gi < 0) return gi;
     // float32 copy of h_l in LDS: the cost's input (last layer), the activation derivative of the backward units, or the rows
     // the tile workgroups of the launch are waiting for (the latent layer, bwd_begin - 1)
@@ -2389,7 +2441,7 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
     if (l > bwd_begin) {
       // delta_{l-1} = (delta_l W_l^T) * act'(h_{l-1}); h_{l-1} is still in its float32 LDS copy
       const AopTensor ao = dop(l - 1);
-      gi = b.add_gemm(l, true, st & 1, false, (!last || ao.frag) ? (st + 1) & 1 : -1, params, 0, delta[l - 1], desc->act[l - 1] ? S_ACT : 0, ao);
+      gi = b.add_gemm(l, true, st & 1, false, (!last || ao.frag) ? (st + 1) & 1 : -1, params, 0, delta[l - 1], act_flags(desc->act[l - 1]), ao);
       if (gi < 0) return gi;
       a.g[gi].h_f32 = hcopy[l - 1];
       a.g[gi].h_f32_pitch = hpitch[l - 1];

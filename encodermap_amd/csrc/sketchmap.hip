@@ -1488,7 +1488,10 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
 #define SK_F16_LAUNCH32(kern)                                                                                                                      \
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, st, (const uint16_t*)a.split.planes, (long)a.split.plane_stride, xnbg, nbc64, a.symm, 1, 0, a.row0, \
                      a.B, a.split.B, a.split.ld, 0, a)
-    if (pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 4>));
+    // (five and six columns: the six-column instantiation -- the epilogue's latent part is a third of its instructions at this width)
+    if (a.L <= 6 && pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<6, true, 4>));
+    else if (a.L <= 6 && pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<6, true, 8>));
+    else if (pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 4>));
     else if (pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 8>));
     else if (pl.fast) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 0>));
     else SK_F16_LAUNCH32((sk_tile_f16_kernel<8, false, 0>));

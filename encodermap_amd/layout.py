@@ -21,7 +21,7 @@ class DenseSpec:
     name: str          # Encoder_i / Latent / Decoder_i (models.py:3142-3150)
     n_in: int
     n_out: int
-    activation: Optional[str]  # "tanh" or None
+    activation: Optional[str]  # a key of ACTIVATION_CODES, or None (linear)
     w_off: int         # offset of the [n_in, n_out] kernel in the flat buffer
     b_off: int         # offset of the [n_out] bias
 
@@ -47,16 +47,23 @@ class NetLayout:
         return self.layers[self.n_enc - 1].n_out
 
 
+# Keras activation names (models.py:3129-3131, 3179-3220: any name goes to Dense) -> the codes of emx_mlp_desc::act (include/emx.h)
+ACTIVATION_CODES = {"tanh": 1, "relu": 2, "sigmoid": 3, "elu": 4, "softplus": 5, "selu": 6, "softsign": 7, "exponential": 8}
+ACTIVATION_ALIASES = {"linear": None, "Tanh": "tanh"}
+
+
 def build_layout(n_neurons: Sequence[int], activation_functions: Sequence[str], net_dim: int) -> NetLayout:
     """[128,128,2] + ['', 'tanh', 'tanh', ''] -> Encoder_0(tanh) Encoder_1(tanh) Latent(linear) |
     Decoder_0(tanh) Decoder_1(tanh) Decoder_2(linear, net_dim)."""
     if len(n_neurons) != len(activation_functions) - 1:
         raise Exception(
             f"Length of `n_neurons` and `activation_functions` (-1) does not match: {n_neurons}, {activation_functions}")
-    acts = [a if a != "" else None for a in activation_functions]
+    acts = [ACTIVATION_ALIASES.get(a, a) if a not in ("", None) else None for a in activation_functions]
     for a in acts:
-        if a not in (None, "tanh"):
-            raise NotImplementedError(f"activation function {a!r} is not available in the HIP engine (tanh or '' only)")
+        if a is not None and a not in ACTIVATION_CODES:
+            raise NotImplementedError(f"activation function {a!r} is not available in the HIP engine: its backward kernels keep a layer's OUTPUT, "
+                                      f"so they take the Keras activations whose derivative is a function of it -- {sorted(ACTIVATION_CODES)} "
+                                      f"or '' (linear); swish / gelu / softmax need the pre-activation")
     units = list(n_neurons) + list(n_neurons[-2::-1]) + [net_dim]
     layer_acts = acts[1:] + acts[-2::-1] + [None]
     n_lat = len(n_neurons)

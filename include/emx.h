@@ -361,7 +361,9 @@ int emx_step_tick(const float* terms, int n_terms, float* history, float* term_h
  *   replaces: tf.keras.layers.Dense forward (y = act(x W + b), W [in,out])  encodermap/models/models.py:3179-3220
  *             and its autodiff (tape.gradient)                              encodermap/models/models.py:3392-3393
  *   The network is described once by an emx_mlp_desc (host struct): width[0] is the input width, width[l+1]
- *   the outputs of layer l, act[l] 0 = linear / 1 = tanh, w_off/b_off the float offsets of the [in,out] kernel
+ *   the outputs of layer l, act[l] the layer's activation -- 0 linear, 1 tanh (the fast path), 2 relu, 3 sigmoid, 4 elu, 5 softplus,
+ *   6 selu, 7 softsign, 8 exponential: the Keras activations (models.py:3179-3220 hands any Keras name to Dense) whose derivative is
+ *   a function of the layer's OUTPUT, which is what the backward kernels keep --, w_off/b_off the float offsets of the [in,out] kernel
  *   and the bias inside the flat parameter buffer `params` (encodermap_amd/layout.py).
  *   h[l] / delta[l] (host arrays of device pointers, [B, width[l+1]] contiguous; an entry may be NULL: not kept) receive
  *   the activations and d loss / d pre-activation of layer l as float32.  Layer ranges let a data-parallel rank run the

@@ -187,15 +187,35 @@ def layer_plan(n_neurons: Sequence[int], activation_functions: Sequence[str], in
     return layer_data[:bottleneck], layer_data[bottleneck:]
 
 
+def keras_activation(name: str, x: torch.Tensor) -> torch.Tensor:
+    """tf.keras.activations.<name> (Keras 2.15; models.py:3179-3220 passes the parameter's string to Dense): the ones the product
+    builds -- tanh and those whose derivative is a function of the output."""
+    if name == "tanh":
+        return torch.tanh(x)
+    if name == "relu":
+        return torch.clamp(x, min=0.0)
+    if name == "sigmoid":
+        return torch.sigmoid(x)
+    if name == "elu":                      # alpha = 1
+        return torch.where(x > 0, x, torch.expm1(x))
+    if name == "softplus":
+        return torch.nn.functional.softplus(x, beta=1.0, threshold=1e9)
+    if name == "selu":                     # scale 1.0507..., alpha 1.6732... (keras.activations.selu)
+        return 1.0507009873554805 * torch.where(x > 0, x, 1.6732632423543772 * torch.expm1(x))
+    if name == "softsign":
+        return x / (1.0 + torch.abs(x))
+    if name == "exponential":
+        return torch.exp(x)
+    raise ValueError(f"activation {name!r} not restated")
+
+
 def dense_stack(x: torch.Tensor, weights: Sequence[torch.Tensor], biases: Sequence[torch.Tensor],
                 acts: Sequence[Optional[str]]) -> torch.Tensor:
     """Keras Dense: act(x @ W + b), W is [in, out]."""
     for W, b, act in zip(weights, biases, acts):
         x = x @ W + b
-        if act == "tanh":
-            x = torch.tanh(x)
-        elif act is not None:
-            raise ValueError(f"activation {act!r} not restated")
+        if act is not None:
+            x = keras_activation(act, x)
     return x
 
 

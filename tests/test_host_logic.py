@@ -109,8 +109,11 @@ def test_layout_default_and_custom():
     assert all(l.w_off % 4 == 0 for l in lay.layers) and lay.n_params % 4 == 0
     small = build_layout([64, 3], ["", "tanh", ""], 7)
     assert [(l.n_in, l.n_out, l.activation) for l in small.layers] == [(7, 64, "tanh"), (64, 3, None), (3, 64, "tanh"), (64, 7, None)]
-    with pytest.raises(NotImplementedError):
-        build_layout([8, 2], ["", "relu", ""], 4)
+    # any Keras activation whose derivative is a function of the layer's output (models.py:3179-3220 hands the name to Dense)
+    assert [l.activation for l in build_layout([8, 4, 2], ["", "relu", "softplus", ""], 4).layers] == ["relu", "softplus", None, "softplus", "relu", None]
+    assert [l.activation for l in build_layout([8, 2], ["", "linear", ""], 4).layers] == [None] * 4
+    with pytest.raises(NotImplementedError, match="pre-activation"):
+        build_layout([8, 2], ["", "gelu", ""], 4)
 
 
 def test_initialisers_and_packing():

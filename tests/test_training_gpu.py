@@ -214,6 +214,57 @@ def test_plain_reconstruction_loss(em, loss, periodicity, cls):
         em.Autoencoder(em.Parameters(loss="nope"), np.zeros((300, 4), np.float32), read_only=True)
 
 
+@pytest.mark.parametrize("acts,periodicity", [(["", "relu", "elu", ""], INF), (["", "sigmoid", "softplus", ""], 2 * PI),
+                                               (["", "selu", "softsign", ""], INF), (["", "exponential", "tanh", "sigmoid"], INF)])
+def test_other_keras_activations(em, acts, periodicity):
+    """``activation_functions`` other than tanh (models.py:3129-3131, 3179-3220: the string goes to keras Dense): relu, sigmoid, elu,
+    softplus, selu, softsign, exponential -- forward values, derivatives (from the layer's output, as the backward kernels keep it),
+    bounded outputs at the fixed image scale and unbounded ones at dynamic scales, a non-linear latent layer -- against the oracle's
+    torch statement: teacher-forced steps (loss 1e-5, every cost term, weights after the step) and encode / decode of the result.
+    Teacher-forced because relu's kink makes free-running float32 trajectories branch where a pre-activation crosses zero."""
+    from encodermap_amd.layout import pack_weights
+
+    rng = np.random.default_rng(17)
+    D = 14
+    if periodicity < INF:
+        data = rng.uniform(-PI, PI, (2000, D)).astype(np.float32)
+    else:
+        data = (rng.normal(0, 1.5, (5, D))[rng.integers(0, 5, 2000)] + rng.normal(0, 0.7, (2000, D))).astype(np.float32)
+    p = em.Parameters(n_steps=6, batch_size=160, periodicity=periodicity, n_neurons=[48, 40, 3], activation_functions=acts,
+                      dist_sig_parameters=(4.0, 12, 6, 1, 2, 6), learning_rate=0.002)
+    net = 2 * D if periodicity < INF else D
+    w0 = initial_weights(em, p, net)
+    e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True)
+    eng = e._engine
+    model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    opt = R.KerasAdam(model.params, learning_rate=p.learning_rate, clipvalue=1.0)
+    X = torch.tensor(data, dtype=torch.float64)
+    idx = rng.integers(0, 2000, (6, 160))
+    for t in range(6):
+        eng.load_state_dict({
+            "w": pack_weights(eng.layout, [q.detach().numpy() for q in model.params]),
+            "m": pack_weights(eng.layout, [q.numpy() for q in opt.m]),
+            "v": pack_weights(eng.layout, [q.numpy() for q in opt.v]),
+            "step": t})
+        eng.run_steps(1, torch.from_numpy(idx[t]).to("cuda:0"))
+        total, terms = R.encodermap_loss(model, X[torch.as_tensor(idx[t])], p.to_dict())
+        grads = torch.autograd.grad(total, model.params)
+        opt.apply_gradients(model.params, grads)
+        assert eng.losses()[-1] == pytest.approx(float(total.detach()), rel=2e-5)
+        got = eng.loss_terms()
+        for k in ("auto", "reg", "center", "distance"):
+            assert got[k][-1] == pytest.approx(float(terms[k].detach()), rel=1e-4, abs=1e-7), k
+        for a, b in zip(eng.get_weights(), model.params):
+            diff = np.abs(a - b.detach().numpy())
+            assert (diff > 4e-6).mean() < 0.02 and diff.max() < 2.1e-3 * 2, (t, diff.max(), (diff > 4e-6).mean())
+    z = e.encode(data[:300])
+    z_o = model.encoder(X[:300]).detach().numpy()
+    np.testing.assert_allclose(z, z_o, atol=2e-4 * max(1.0, np.abs(z_o).max()))
+    y = e.generate(z_o[:100].astype(np.float32))
+    y_o = model.decoder(torch.tensor(z_o[:100])).detach().numpy()
+    np.testing.assert_allclose(y, y_o, atol=2e-4 * max(1.0, np.abs(y_o).max()))
+
+
 def test_graph_replay_equals_eager(em):
     rng = np.random.default_rng(6)
     data = rng.uniform(-PI, PI, (3000, 16)).astype(np.float32)

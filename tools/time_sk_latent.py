@@ -10,7 +10,7 @@ cen = torch.randn(16, D, generator=g, device="cuda") * 4
 X = cen[torch.randint(0, 16, (B,), generator=g, device="cuda")] + torch.randn(B, D, generator=g, device="cuda")
 split = torch.zeros(_lib.sketchmap_split_bytes(B, D), dtype=torch.uint8, device="cuda")
 _lib.sketchmap_split(X, split)
-for L in (1, 2, 3, 4, 5, 8, 9, 12):
+for L in (1, 2, 3, 4, 5, 6, 7, 8, 9, 12):
     Z = torch.randn(B, L, generator=g, device="cuda")
     ws = torch.zeros(_lib.sketchmap_ws_bytes(B, L) // 4, device="cuda")
     f = lambda: _lib.sketchmap_tiles(X, Z, float("inf"), (16.0, 12, 6, 1, 2, 6), 0, B, ws, split)
