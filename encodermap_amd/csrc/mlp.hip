@@ -279,7 +279,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const int k = 32 * grp + sc_c;
     *reinterpret_cast<half8*>(lds + pl + k * 32 + sc_hf * 16) = hi;
     *reinterpret_cast<half8*>(lds + pl + lo_off + k * 32 + sc_hf * 16) = lo;
-    {   // (every lane of a half writes the same 32 bytes: no branch)
+    if (sc_c == 0) {   // (every lane of a half holds the same 32 bytes: one lane writes them -- 32 writes to one address are a 32-way bank conflict)
       float* dst = reinterpret_cast<float*>(lds + sc) + grp * 16 + 8 * sc_hf;
       *reinterpret_cast<f32x4*>(dst) = f32x4{rs[0], rs[1], rs[2], rs[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
@@ -439,10 +439,21 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       rq_ws = nq_ws;
     }
   };
-  auto rq_advance = [&]() __attribute__((always_inline)) {
-    rq_prefetch();
-    rq_commit();
+  auto rq_advance_plain = [&]() __attribute__((always_inline)) {   // both parts at once, no temporaries
+    if (!rq_live) return;
+    Stream nx = rq;
+    const bool changed = stream_next(nx);
+    if (changed && nx.gi >= nx.g_end) {
+      rq_live = false;
+      return;
+    }
+    rq = nx;
+#ifndef EMX_EXP_NOSTREAM
+    rq_ptr += WOP_UNIT;
+#endif
+    if (changed) rq_load_gemm();
   };
+  auto rq_advance = [&]() __attribute__((always_inline)) { rq_advance_plain(); };
 
   // execution stream: the current GEMM's record in scalar registers
   Stream ex;
@@ -536,8 +547,54 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const float tsum = block_sum<NT_>(lsum, cred);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   };
+  // The same for the common shape -- a non-periodic output, mean_abs or mean_square, rows of whole float4s: a thread takes FOUR
+  // CONSECUTIVE columns of its row per pass (one 16-byte LDS read of the output copy and of the targets, one 16-byte write back, one
+  // 16-byte store of d cost / d output) instead of four columns 32 apart through scalar accesses that each wait for their read.
+  // Another assignment of columns to threads than cost_body's, hence another rounding of the workgroup's cost share (the forward
+  // launch with the cost and the fused launch share this code and agree bit for bit).
+  auto cost_body4 = [&]() __attribute__((always_inline)) {
+#pragma clang fp contract(off)
+    const CostArgs& cst = a.cost;
+    const bool act = KS == 1 || tid < NTC;
+    const int row = KS == 1 ? tid >> 5 : min(tid >> 5, R - 1), l32 = tid & 31;
+    const bool rok = act && row < rows_valid;
+    const long grow = (long)min(r0 + row, a.row_end - 1);
+    float* const yrow = reinterpret_cast<float*>(lds + a.y_f32) + row * a.y_pitch + cst.off_sin;
+    const float* const trow = tgt + row * cst.n;
+    float* const drow = (rok && cst.dY != nullptr) ? cst.dY + grow * cst.ldy + cst.off_sin : nullptr;
+    float lsum = 0.f;
+    for (int k = 4 * l32; k < cst.n; k += 128) {
+      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yrow + k), t4 = *reinterpret_cast<const f32x4*>(trow + k);
+      f32x4 g4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float diff = y4[i] - t4[i];
+        const float d = fabsf(diff);
+        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+        float delta = d, dd = sgn;
+        if (cst.wrap) {
+          const float w = cst.period - d;
+          if (!(d <= w)) delta = w, dd = -sgn;
+        }
+        float gq;
+        if (cst.variant == EMX_MEAN_ABS) {
+          if (rok) lsum += fabsf(delta);
+          gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+        } else {
+          if (rok) lsum = fmaf(delta, delta, lsum);
+          gq = 2.f * delta * dd;
+        }
+        g4[i] = rok ? cst.gnorm * gq : 0.f;
+      }
+      if (drow) *reinterpret_cast<f32x4*>(drow + k) = g4;
+      if (act) *reinterpret_cast<f32x4*>(yrow + k) = g4;
+    }
+    const float tsum = block_sum<NT_>(lsum, cred);
+    if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
+  };
   auto cost_phase = [&]() __attribute__((always_inline)) {
     if (a.cost.periodic_output) cost_body(IC_<1>{});
+    else if (a.cost.vec4) cost_body4();
     else cost_body(IC_<0>{});
   };
 
@@ -656,7 +713,14 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     // A fragments of the wave's K-steps up front (one LDS latency per unit) -- or, where the backward kernel is held to 128
     // registers (chain_kernel_c128: a second workgroup on the CU runs in this one's gaps), two K-steps at a time
     constexpr int AF = (BWD && PUB_OFF != 0) ? 2 : NS;
-    if constexpr (AF != NS) records(false);   // (fragments in two portions: the records in front of them, as they always were)
+    // The early records (behind the first K-step) are the SMALL builds': in the general and the 128-register builds the extra live
+    // scalars of the split request stream cost more (17 -> 86 spilled scalar registers in chain_kernel_c128<FUSED>, +6 us at C5's
+    // shape) than the shorter wait saves -- there the records go out in front of the fragments, as they always did, and the request
+    // stream advances behind the matrix instructions.
+    constexpr bool EARLY_REC = SMALL && AF == NS;
+    if constexpr (!EARLY_REC) {
+      if (ex_changed) load_gx(exn.gi, exn.g_end, Xn, exn.P, exn.C);
+    }
     half8 ah[AF], al[AF];
     f32x4 rsa[AF];
     const char* apl = lds + X.src_pl + exc * 4096 + kh * (NS * 1024) + lane8;
@@ -689,7 +753,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         if (KS == 2 || s < 2) accA = d * rsa[s % AF] + accA;
         else accB = d * rsa[s % AF] + accB;
         request_pieces(RC, s, ln);
-        if (AF == NS && s == 0) {
+        if (EARLY_REC && s == 0) {
           __builtin_amdgcn_sched_barrier(0);
           records(true);
         }
@@ -710,7 +774,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           accB = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah[s % AF], wp[rx][s][0], accB, 0, 0, 0);
         }
         request_pieces(RC, s, ln);
-        if (AF == NS && s == 0) {
+        if (EARLY_REC && s == 0) {
           __builtin_amdgcn_sched_barrier(0);
           records(true);
         }
@@ -718,7 +782,8 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       }
     }
     TSTAMP(4 + 5 * ui);
-    rq_commit();
+    if constexpr (EARLY_REC) rq_commit();
+    else rq_advance_plain();
     TSTAMP(5 + 5 * ui);
 
     // ---- epilogue (last chunk of a pass).  Columns beyond the layer and rows beyond the batch are NOT masked: their
@@ -834,12 +899,14 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           unsigned (*const mxa)[R] = mxbuf[uparity];
           u32x4 own;
           if constexpr (KS == 2) {
-            *reinterpret_cast<u32x2*>(&mxa[tw][row0l]) = u32x2{m[0], m[1]};
+            if (n == 0) *reinterpret_cast<u32x2*>(&mxa[tw][row0l]) = u32x2{m[0], m[1]};
             __syncthreads();
             own = *reinterpret_cast<const u32x4*>(&mxa[tw][4 * g]);
           } else {
             own = u32x4{m[0], m[1], m[2], m[3]};
-            *reinterpret_cast<u32x4*>(&mxa[tw][4 * g]) = own;
+            // (ONE lane per row group writes: the sixteen lanes of a group hold the same four maxima, and sixteen writes to one
+            //  address are a sixteen-way bank conflict -- a quarter of this kernel's LDS cycles in round 3's counters)
+            if (n == 0) *reinterpret_cast<u32x4*>(&mxa[tw][4 * g]) = own;
             __syncthreads();
           }
           const u32x4 pm = *reinterpret_cast<const u32x4*>(&mxa[tw ^ 1][4 * g]);
@@ -854,13 +921,15 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
             const unsigned mr = KS == 2 ? (kh ? mm[2 + rr] : mm[rr]) : mm[rr];
             pow2_scale_bits<ACT_TOP>(mr, s[rr], rs[rr]);
           }
-          // (both waves of the pair and the 16 lanes of a row group write the same bytes: no branch)
+          // (both waves of the pair and the 16 lanes of a row group hold the same scales: one lane of the even wave writes them)
           float* const scp = reinterpret_cast<float*>(lds + X.dst_sc + (4 * exp_ + (tw >> 1)) * 64 + g * 16) + kh * NR;
-          if constexpr (KS == 2) {
-            typedef float f32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<f32x2*>(scp) = f32x2{rs[0], rs[1]};
-          } else {
-            *reinterpret_cast<f32x4*>(scp) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+          if (n == 0 && (tw & 1) == 0) {
+            if constexpr (KS == 2) {
+              typedef float f32x2 __attribute__((ext_vector_type(2)));
+              *reinterpret_cast<f32x2*>(scp) = f32x2{rs[0], rs[1]};
+            } else {
+              *reinterpret_cast<f32x4*>(scp) = f32x4{rs[0], rs[1], rs[2], rs[3]};
+            }
           }
         }
 #pragma unroll
@@ -948,6 +1017,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   // GEMMs [g0, g1) through the ring, their units starting at `units`: the packages of the first NB - 1 units are requested,
   // `between` runs while they are in flight (staging the row block; the cost phase of the fused launch), then every
   // iteration executes one unit and requests the one NB - 1 ahead.
+  // (Round 4 tried ONE stream of units over the forward and the backward GEMMs of the fused launch, the cost phase as a hook between
+  //  two units -- the second pipeline's start-up is three dependent trips to the kernel arguments, ~1600 cycles.  With the hook inside
+  //  the unit loop everything the cost phase holds is live across the loop: 142 -> 216 registers for the plain fused kernel and a
+  //  thousand spilled registers in the 128-register builds.  Two pipelines it stays.)
   auto pipeline = [&](const int g0, const int g1, const char* units, auto between) __attribute__((always_inline)) {
     rq = Stream{g0, g1, 0, 0, 1, 1};
     rq_live = true;
@@ -2094,6 +2167,10 @@ int fill_cost(ChainArgs& a, const emx_auto_cost* cost, int wout, float* dY, cons
   a.cost.ws = cost->ws;
   fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
                     cost->variant, cost->coef);
+  a.cost.vec4 = (!cost->periodic_output && cost->variant != EMX_MEAN_NORM && (cost->n & 3) == 0 && (cost->off_sin & 3) == 0 && (wout & 3) == 0 &&
+                 (reinterpret_cast<uintptr_t>(dY) & 15) == 0)
+                    ? 1
+                    : 0;
   return EMX_OK;
 }
 
