@@ -741,6 +741,10 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
       }
     };
     fragments(0);
+    // (Round 4 tried the unit's twelve matrix instructions interleaved over independent accumulators -- the two halves of the
+    //  reduction; the four K-steps' own accumulators behind dynamic scales -- with the next unit's pieces requested behind them:
+    //  same bits, 32 registers fewer, and SLOWER on a same-box A/B: fused launch 21.0 against 19.8 us, step 69.5 against 67.8.  The
+    //  piece requests between the K-steps are worth more than the shorter dependency chains.)
     if (dyn) {
       // per-(row, 32 columns) source scales: each K-step's product is unscaled as it is added
 #pragma unroll
