@@ -1071,7 +1071,29 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     // rows joined into dh of one layer: dadd and / or the latent gradient of the all-pairs cost (one wave per element,
     // lanes over the per-tile slots, fixed order)
     const int N = a.join_n;
-    if (a.lg.partials != nullptr) {
+    const bool vec_join = a.lg.partials != nullptr && a.lg.n_slots <= 64 && rows_valid == R && (a.lg.slot_stride & 3) == 0 &&
+                          (((a.lg.row_base * N) | (r0 * N)) & 3) == 0 &&
+                          ((reinterpret_cast<uintptr_t>(a.lg.partials) | reinterpret_cast<uintptr_t>(a.lg.Z) | reinterpret_cast<uintptr_t>(a.dadd)) & 15) == 0;
+    if (vec_join) {
+      // A slot's 16 x N partial sums of this row block are ONE run of 64 N bytes: lane = slot, a wave takes four consecutive elements
+      // as one 16-byte load (the eight waves share the slots' cache lines), then sums each element over the lanes in the fixed
+      // butterfly order.  As scalar loads -- one element per wave-load, 64 lanes on 64 different lines, 16 N of them per workgroup --
+      // the address unit alone was busy for thousands of cycles (encoder backward at 4096 rows: the row block staged 10 000 cycles
+      // after the wave's start).  Same sums in the same order as the element-wise form below: the same bits.
+      for (int q = wave; 4 * q < R * N; q += NW_) {
+        const int s0 = min(lane, a.lg.n_slots - 1);
+        const float msk = lane < a.lg.n_slots ? 1.f : 0.f;
+        const f32x4 pv = *reinterpret_cast<const f32x4*>(a.lg.partials + (long)(r0 - a.lg.row_base) * N + 4 * q + (long)s0 * a.lg.slot_stride);
+        const f32x4 z4 = *reinterpret_cast<const f32x4*>(a.lg.Z + (long)r0 * N + 4 * q);
+        f32x4 d4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.dadd != nullptr) d4 = *reinterpret_cast<const f32x4*>(a.dadd + (long)r0 * N + 4 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float sum = wave_sum(pv[i] * msk);
+          if (lane == 0) lat[4 * q + i] = fmaf(a.lg.center_grad, z4[i], a.lg.gscale * sum) + d4[i];
+        }
+      }
+    } else if (a.lg.partials != nullptr) {
       // (four elements per wave and pass, every load of the pass requested before the first sum: the partials were written
       //  by the all-pairs kernel on other XCDs a moment ago, a dependent trip per element was four trips)
       for (int el0 = wave; el0 < R * N; el0 += 4 * NW_) {
