@@ -279,7 +279,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const int k = 32 * grp + sc_c;
     *reinterpret_cast<half8*>(lds + pl + k * 32 + sc_hf * 16) = hi;
     *reinterpret_cast<half8*>(lds + pl + lo_off + k * 32 + sc_hf * 16) = lo;
-    if (sc_c == 0) {   // (every lane of a half holds the same 32 bytes: one lane writes them -- 32 writes to one address are a 32-way bank conflict)
+    {   // (every lane of a half writes the same 32 bytes: no branch)
       float* dst = reinterpret_cast<float*>(lds + sc) + grp * 16 + 8 * sc_hf;
       *reinterpret_cast<f32x4*>(dst) = f32x4{rs[0], rs[1], rs[2], rs[3]};
       *reinterpret_cast<f32x4*>(dst + 4) = f32x4{rs[4], rs[5], rs[6], rs[7]};
@@ -903,14 +903,14 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           unsigned (*const mxa)[R] = mxbuf[uparity];
           u32x4 own;
           if constexpr (KS == 2) {
-            if (n == 0) *reinterpret_cast<u32x2*>(&mxa[tw][row0l]) = u32x2{m[0], m[1]};
+            *reinterpret_cast<u32x2*>(&mxa[tw][row0l]) = u32x2{m[0], m[1]};
             __syncthreads();
             own = *reinterpret_cast<const u32x4*>(&mxa[tw][4 * g]);
           } else {
             own = u32x4{m[0], m[1], m[2], m[3]};
-            // (ONE lane per row group writes: the sixteen lanes of a group hold the same four maxima, and sixteen writes to one
-            //  address are a sixteen-way bank conflict -- a quarter of this kernel's LDS cycles in round 3's counters)
-            if (n == 0) *reinterpret_cast<u32x4*>(&mxa[tw][4 * g]) = own;
+            // (all sixteen lanes of a row group write the same four maxima to the same address: the hardware merges them -- writing
+            //  from one lane only changed nothing in SQ_LDS_BANK_CONFLICT and cost an exec-mask sequence: round 4, reverted)
+            *reinterpret_cast<u32x4*>(&mxa[tw][4 * g]) = own;
             __syncthreads();
           }
           const u32x4 pm = *reinterpret_cast<const u32x4*>(&mxa[tw ^ 1][4 * g]);
@@ -925,15 +925,13 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
             const unsigned mr = KS == 2 ? (kh ? mm[2 + rr] : mm[rr]) : mm[rr];
             pow2_scale_bits<ACT_TOP>(mr, s[rr], rs[rr]);
           }
-          // (both waves of the pair and the 16 lanes of a row group hold the same scales: one lane of the even wave writes them)
+          // (both waves of the pair and the 16 lanes of a row group write the same bytes: no branch)
           float* const scp = reinterpret_cast<float*>(lds + X.dst_sc + (4 * exp_ + (tw >> 1)) * 64 + g * 16) + kh * NR;
-          if (n == 0 && (tw & 1) == 0) {
-            if constexpr (KS == 2) {
-              typedef float f32x2 __attribute__((ext_vector_type(2)));
-              *reinterpret_cast<f32x2*>(scp) = f32x2{rs[0], rs[1]};
-            } else {
-              *reinterpret_cast<f32x4*>(scp) = f32x4{rs[0], rs[1], rs[2], rs[3]};
-            }
+          if constexpr (KS == 2) {
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<f32x2*>(scp) = f32x2{rs[0], rs[1]};
+          } else {
+            *reinterpret_cast<f32x4*>(scp) = f32x4{rs[0], rs[1], rs[2], rs[3]};
           }
         }
 #pragma unroll
