@@ -1248,7 +1248,9 @@ __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // The fused launch with the all-pairs tiles aboard (sk_tile.h): workgroups [0, row blocks) are the chain workgroups, the rest run two
 // tiles each.  128 registers per lane: a chain workgroup (two waves per SIMD) and a tile workgroup share a CU.  The role is
 // told from the preloaded scalars alone (the chain workgroups' first loads must not wait for a trip to the arguments).
-template <int NB, bool FASTSIG, int NCH, int KIND>   // KIND 0: Gram tiles on split rows (NCH chunks); 1 / 2: periodic 32 x 32 VALU tiles, float / phase form
+// SMALL: every GEMM of the launch one unit (chain_body) -- the default network on up to 128 input columns, i.e. the default
+// configuration (B = 256, periodic) and every Euclidean batch of up to 1536 rows and 128 features that takes this launch.
+template <int NB, bool FASTSIG, int NCH, int KIND, bool SMALL = false>   // KIND 0: Gram tiles on split rows (NCH chunks); 1 / 2: periodic 32 x 32 VALU tiles, float / phase form
 __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) void chain_tiles_kernel(
     const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols, int p_row0, int p_row_end, int p_ldt, int p_cost_n,
     int p_in_Q, int p_with_cost, const ChainArgs a, const emx::sk::TileRole tr) {
@@ -1260,8 +1262,9 @@ __global__ __launch_bounds__(NTC) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     return;
   }
   static_assert(offsetof(emx::sk::TileRole, sync) == offsetof(emx::sk::TileRole, zpub) + 8 && sizeof(ChainArgs) % 8 == 0, "PubArgs inside TileRole");
-  chain_body<CHAIN_FUSED, NB, 56 + (int)sizeof(ChainArgs) + (int)offsetof(emx::sk::TileRole, zpub)>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0,
-                                                                                                 p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
+  chain_body<CHAIN_FUSED, NB, 56 + (int)sizeof(ChainArgs) + (int)offsetof(emx::sk::TileRole, zpub), 1, SMALL>(p_in, p_top_h, p_target, p_ld_in, p_in_cols,
+                                                                                                           p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q,
+                                                                                                           p_with_cost, a);
 }
 
 // The operand store from the flat parameter buffer (the optimizer keeps it current afterwards).  Two launches: the layers'
@@ -2456,9 +2459,9 @@ struct TilesHost {
 
 int device_cus();
 
-template <bool FAST, int NCH, int KIND = 0>
-int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
-  int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND>), lds, b.who);
+template <bool FAST, int NCH, int KIND, bool SMALL>
+int launch_chain_tiles_impl(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
+  int rc = set_lds(reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>), lds, b.who);
   if (rc) return rc;
   // The launch holds in-launch waits: a tile workgroup waits until ALL chain workgroups have published the latent rows, and (join)
   // every chain workgroup waits until ALL tile workgroups have reported.  Chain workgroups are dispatched first (lower indices), so
@@ -2469,10 +2472,10 @@ int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, s
     static thread_local const void* cached_fn = nullptr;
     static thread_local size_t cached_lds = 0;
     static thread_local int cached_blocks = 0;
-    const void* fn = reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND>);
+    const void* fn = reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>);
     if (cached_fn != fn || cached_lds != lds) {
       int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_tiles_kernel<2, FAST, NCH, KIND>, NTC, lds) != hipSuccess) nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>, NTC, lds) != hipSuccess) nb = 0;
       cached_fn = fn, cached_lds = lds, cached_blocks = nb;
     }
     const long capacity = (long)cached_blocks * device_cus();
@@ -2480,9 +2483,18 @@ int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, s
       return emx::fail(EMX_EUNSUPPORTED, "%s: %d dense-layer workgroups + one tile workgroup do not fit the device at once (%d per CU x %d CUs): "
                        "the tiles cannot ride in this launch", b.who, tr.n_chain, cached_blocks, device_cus());
   }
-  hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH, KIND>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
+  hipLaunchKernelGGL((chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
                      b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a, tr);
   return emx::check_launch("mlp chain kernel (forward + cost + backward, all-pairs tiles aboard)");
+}
+
+template <bool FAST, int NCH, int KIND = 0>
+int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
+  bool small = true;   // every GEMM one unit: the SMALL build of the dense-layer workgroups (EMX_CHAIN_W16=-1: the general build)
+  for (int i = 0; i < b.ng; ++i) small = small && b.a.g[i].P == 1 && b.a.g[i].C == 1;
+  static const bool allow = !(getenv("EMX_CHAIN_W16") && atoi(getenv("EMX_CHAIN_W16")) < 0);
+  if (small && allow) return launch_chain_tiles_impl<FAST, NCH, KIND, true>(b, tr, grid, lds, st);
+  return launch_chain_tiles_impl<FAST, NCH, KIND, false>(b, tr, grid, lds, st);
 }
 
 int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
