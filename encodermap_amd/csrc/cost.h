@@ -19,7 +19,7 @@ struct CostArgs {
   int ldy, ldt, off_sin, off_cos, periodic_output;
   int n, row_begin, row_end, variant, wrap, prescale;
   int wide;   // stand-alone kernel: S >= 1 workgroups per row (long rows, or few rows) instead of one wave per row (0)
-  int vec4;   // row-block kernels (mlp.hip): a non-periodic output with mean_abs / mean_square over rows of whole, aligned float4s
+  int vec4;   // row-block kernels (mlp.hip): a non-periodic output with mean_abs / mean_square -- the column-wise cost phase (cost_cols)
   float period, out_scale, gnorm;  // gnorm = coef / (B*n) (abs, square) or coef / B (norm)
 };
 

@@ -547,28 +547,36 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const float tsum = block_sum<NT_>(lsum, cred);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   };
-  // The same for the common shape -- a non-periodic output, mean_abs or mean_square, rows of whole float4s: a thread takes FOUR
-  // CONSECUTIVE columns of its row per pass (one 16-byte LDS read of the output copy and of the targets, one 16-byte write back, one
-  // 16-byte store of d cost / d output) instead of four columns 32 apart through scalar accesses that each wait for their read.
-  // Another assignment of columns to threads than cost_body's, hence another rounding of the workgroup's cost share (the forward
+  // The same for the common shape -- a non-periodic output with mean_abs or mean_square -- in the STAGING layout: wave w takes the
+  // column groups w, w + 8, ..; lane (c, hf) column 32 grp + c, rows 8 hf .. 8 hf + 7.  In the fused launch the lane then holds
+  // exactly what stage_finish needs: d cost / d output goes straight from registers into the first backward GEMM's image and the
+  // weight-gradient fragments (RESTAGE) -- no write-back of the gradient into the output copy, no barrier, no second pass over
+  // LDS (the cost phase and the re-staging were 2 500 + 3 000 cycles of the fused launch, profiles/r04_chain_timeline.txt).
+  // Another assignment of elements to threads than cost_body's, hence another rounding of the workgroup's cost share (the forward
   // launch with the cost and the fused launch share this code and agree bit for bit).
-  auto cost_body4 = [&]() __attribute__((always_inline)) {
+  auto cost_cols = [&](auto RESTAGE_) __attribute__((always_inline)) {
 #pragma clang fp contract(off)
+    constexpr bool RESTAGE = decltype(RESTAGE_)::value != 0;
     const CostArgs& cst = a.cost;
-    const bool act = KS == 1 || tid < NTC;
-    const int row = KS == 1 ? tid >> 5 : min(tid >> 5, R - 1), l32 = tid & 31;
-    const bool rok = act && row < rows_valid;
-    const long grow = (long)min(r0 + row, a.row_end - 1);
-    float* const yrow = reinterpret_cast<float*>(lds + a.y_f32) + row * a.y_pitch + cst.off_sin;
-    const float* const trow = tgt + row * cst.n;
-    float* const drow = (rok && cst.dY != nullptr) ? cst.dY + grow * cst.ldy + cst.off_sin : nullptr;
+    const float* const yb = reinterpret_cast<const float*>(lds + a.y_f32);
+    const int wout = cst.ldy;
+    const int ngrp = RESTAGE ? a.top_Qp : groups32(wout);
     float lsum = 0.f;
-    for (int k = 4 * l32; k < cst.n; k += 128) {
-      const f32x4 y4 = *reinterpret_cast<const f32x4*>(yrow + k), t4 = *reinterpret_cast<const f32x4*>(trow + k);
-      f32x4 g4;
+    for (int grp = wave; grp < ngrp; grp += NW_) {
+      const int col = 32 * grp + sc_c;
+      const bool covered = col >= cst.off_sin && col < cst.off_sin + cst.n;
+      const int cy = min(col, wout - 1), ct = min(max(col - cst.off_sin, 0), cst.n - 1);
+      float yv[8], tv8[8], g8[8];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float diff = y4[i] - t4[i];
+      for (int e = 0; e < 8; ++e) {
+        yv[e] = yb[(8 * sc_hf + e) * a.y_pitch + cy];
+        tv8[e] = tgt[(8 * sc_hf + e) * cst.n + ct];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int row = 8 * sc_hf + e;
+        const bool live = covered && row < rows_valid;
+        const float diff = yv[e] - tv8[e];
         const float d = fabsf(diff);
         const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
         float delta = d, dd = sgn;
@@ -578,23 +586,28 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         }
         float gq;
         if (cst.variant == EMX_MEAN_ABS) {
-          if (rok) lsum += fabsf(delta);
+          if (live) lsum += fabsf(delta);
           gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
         } else {
-          if (rok) lsum = fmaf(delta, delta, lsum);
+          if (live) lsum = fmaf(delta, delta, lsum);
           gq = 2.f * delta * dd;
         }
-        g4[i] = rok ? cst.gnorm * gq : 0.f;
+        g8[e] = live ? cst.gnorm * gq : 0.f;
+        if (live && cst.dY != nullptr) cst.dY[(long)(r0 + row) * cst.ldy + col] = g8[e];
       }
-      if (drow) *reinterpret_cast<f32x4*>(drow + k) = g4;
-      if (act) *reinterpret_cast<f32x4*>(yrow + k) = g4;
+      if constexpr (RESTAGE) {
+        TSTAMP(51);
+        stage_finish(g8, grp, a.top_Qp * 1024, a.top_pl, a.top_sc, a.top_aop, grp < a.top_Q);
+        TSTAMP(52);
+      }
     }
-    const float tsum = block_sum<NT_>(lsum, cred);
+    const float tsum = block_sum<NT_>(lsum, cred);   // (its barriers also close the re-staging: the image is complete behind it)
+    if constexpr (RESTAGE) TSTAMP(53);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
   };
   auto cost_phase = [&]() __attribute__((always_inline)) {
     if (a.cost.periodic_output) cost_body(IC_<1>{});
-    else if (a.cost.vec4) cost_body4();
+    else if (a.cost.vec4) cost_cols(IC_<0>{});
     else cost_body(IC_<0>{});
   };
 
@@ -1023,7 +1036,8 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
   //  two units -- the second pipeline's start-up is three dependent trips to the kernel arguments, ~1600 cycles.  With the hook inside
   //  the unit loop everything the cost phase holds is live across the loop: 142 -> 216 registers for the plain fused kernel and a
   //  thousand spilled registers in the 128-register builds.  Two pipelines it stays.)
-  auto pipeline = [&](const int g0, const int g1, const char* units, auto between) __attribute__((always_inline)) {
+  auto pipeline = [&](const int g0, const int g1, const char* units, auto between, auto LATE_) __attribute__((always_inline)) {
+    constexpr bool LATE = decltype(LATE_)::value != 0;
     rq = Stream{g0, g1, 0, 0, 1, 1};
     rq_live = true;
     rq_ptr = units + tw * 8192 + kh * (NS * 2048);
@@ -1031,6 +1045,12 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     request(IC_<0>{}, lane);
 #pragma unroll
     for (int s = 0; s < NS; ++s) request_pieces(IC_<0>{}, s, lane);
+    // LATE (the backward pipeline of the fused launch): `between` -- the cost phase -- runs with the first package in flight and
+    // BEFORE the rest of the streams' state exists: the execution stream's GEMM record alone is twenty scalar registers, and with
+    // it live the cost code re-read its own scalars from the kernel arguments again and again (a hundred scalar loads, each waited
+    // for: ~4 000 cycles).  Elsewhere the state is set up first, so that its scalar loads overlap the staging (the encoder backward
+    // loses 1 300 cycles the other way round).
+    if constexpr (LATE) between();
     rq_advance();
     if constexpr (NB >= 3) {
       request(IC_<1>{}, lane);
@@ -1040,7 +1060,7 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     }
     ex = Stream{g0, g1, 0, 0, 1, 1};
     ex_load_gemm();
-    between();
+    if constexpr (!LATE) between();
     // iteration k executes the k-th unit from slot k % NB and requests the (k + NB - 1)-th into slot (k + NB - 1) % NB
     for (;;) {
       exec(IC_<NB - 1>{});
@@ -1167,13 +1187,18 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     TSTAMP(2);
   };
   if (MODE == CHAIN_FUSED) {
-    pipeline(0, a.ng_fwd, a.units, stage_rest);
+    pipeline(0, a.ng_fwd, a.units, stage_rest, IC_<0>{});
     TSTAMP(49);
     if (a.ng_fwd < a.ng) {
       // the forward part is complete.  The first backward packages are requested, then -- while they are in flight -- the
       // cost runs and d cost / d output goes to HBM and, re-staged, into the first backward GEMM's image
       pipeline(a.ng_fwd, a.ng, a.units_bwd, [&]() __attribute__((always_inline)) {
         TSTAMP(50);
+        if (a.cost.vec4 && !a.cost.periodic_output) {   // cost and re-staging in one pass (cost_cols)
+          cost_cols(IC_<1>{});
+          TSTAMP(54);
+          return;
+        }
         cost_phase();
         TSTAMP(51);
         __syncthreads();
@@ -1193,12 +1218,12 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         TSTAMP(53);
         __syncthreads();
         TSTAMP(54);
-      });
+      }, IC_<1>{});
     } else {
       cost_phase();
     }
   } else {
-    pipeline(0, a.ng, a.units, stage_rest);
+    pipeline(0, a.ng, a.units, stage_rest, IC_<0>{});
   }
   TSTAMP(60);
   if (MODE == CHAIN_FWD && with_cost) cost_phase();
@@ -2194,10 +2219,7 @@ int fill_cost(ChainArgs& a, const emx_auto_cost* cost, int wout, float* dY, cons
   a.cost.ws = cost->ws;
   fill_cost_scalars(a.cost, cost->B, cost->n, wout, cost->ldt, cost->off_sin, cost->off_cos, cost->periodic_output, cost->periodicity,
                     cost->variant, cost->coef);
-  a.cost.vec4 = (!cost->periodic_output && cost->variant != EMX_MEAN_NORM && (cost->n & 3) == 0 && (cost->off_sin & 3) == 0 && (wout & 3) == 0 &&
-                 (reinterpret_cast<uintptr_t>(dY) & 15) == 0)
-                    ? 1
-                    : 0;
+  a.cost.vec4 = (!cost->periodic_output && cost->variant != EMX_MEAN_NORM) ? 1 : 0;   // (the column-wise cost phase of the row-block kernels: cost_cols)
   return EMX_OK;
 }
 

@@ -7,4 +7,5 @@ for lib in default build_ab/libemx_prev.so; do
 done
 done
 unset EMX_LIB_PATH
+python tools/abl_timing.py build_ab/libemx_timing.so fused 2>/dev/null | head -12
 python tools/abl_timing.py build_ab/libemx_timing.so bwd_latent 2>/dev/null | head -4
