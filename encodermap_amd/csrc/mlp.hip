@@ -562,7 +562,11 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     const int wout = cst.ldy;
     const int ngrp = RESTAGE ? a.top_Qp : groups32(wout);
     float lsum = 0.f;
-    for (int grp = wave; grp < ngrp; grp += NW_) {
+    // (the first group outside the loop: in front of a LOOP that holds stores the compiler drains the vector-memory counter --
+    //  s_waitcnt vmcnt(0) -- and the first backward package, requested a moment ago from lines the optimizer rewrote on other
+    //  XCDs, is a trip of ~2.5 us: the cost phase then could not start before it had arrived.  Rows of up to 256 columns are one
+    //  group per wave, no loop.)
+    auto group = [&](const int grp) __attribute__((always_inline)) {
       const int col = 32 * grp + sc_c;
       const bool covered = col >= cst.off_sin && col < cst.off_sin + cst.n;
       const int cy = min(col, wout - 1), ct = min(max(col - cst.off_sin, 0), cst.n - 1);
@@ -572,35 +576,59 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
         yv[e] = yb[(8 * sc_hf + e) * a.y_pitch + cy];
         tv8[e] = tgt[(8 * sc_hf + e) * cst.n + ct];
       }
+      // (variant and wrap are wave-uniform: ONE test each in front of straight-line code.  Without a wrap |diff| sgn(diff) IS diff:
+      //  d cost / d y is 2 gnorm diff resp. gnorm sgn(diff), the same bits as the general form below in 10 instead of 45 instructions
+      //  per element -- four waves run this phase alone on their SIMDs, every instruction at its full latency)
+      auto elems = [&](auto WRAP_, auto ABS_) __attribute__((always_inline)) {
+        constexpr bool WRAP = decltype(WRAP_)::value != 0, ABS = decltype(ABS_)::value != 0;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const int row = 8 * sc_hf + e;
-        const bool live = covered && row < rows_valid;
-        const float diff = yv[e] - tv8[e];
-        const float d = fabsf(diff);
-        const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
-        float delta = d, dd = sgn;
-        if (cst.wrap) {
-          const float w = cst.period - d;
-          if (!(d <= w)) delta = w, dd = -sgn;
+        for (int e = 0; e < 8; ++e) {
+          const int row = 8 * sc_hf + e;
+          const bool live = covered && row < rows_valid;
+          const float diff = yv[e] - tv8[e];
+          float gq;
+          if constexpr (!WRAP) {
+            if constexpr (ABS) {
+              if (live) lsum += fabsf(diff);
+              gq = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+            } else {
+              if (live) lsum = fmaf(diff, diff, lsum);
+              gq = 2.f * diff;
+            }
+          } else {
+            const float d = fabsf(diff);
+            const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+            float delta = d, dd = sgn;
+            const float w = cst.period - d;
+            if (!(d <= w)) delta = w, dd = -sgn;
+            if constexpr (ABS) {
+              if (live) lsum += fabsf(delta);
+              gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
+            } else {
+              if (live) lsum = fmaf(delta, delta, lsum);
+              gq = 2.f * delta * dd;
+            }
+          }
+          g8[e] = live ? cst.gnorm * gq : 0.f;
+          if (live && cst.dY != nullptr) cst.dY[(long)(r0 + row) * cst.ldy + col] = g8[e];
         }
-        float gq;
-        if (cst.variant == EMX_MEAN_ABS) {
-          if (live) lsum += fabsf(delta);
-          gq = (delta > 0.f ? 1.f : (delta < 0.f ? -1.f : 0.f)) * dd;
-        } else {
-          if (live) lsum = fmaf(delta, delta, lsum);
-          gq = 2.f * delta * dd;
-        }
-        g8[e] = live ? cst.gnorm * gq : 0.f;
-        if (live && cst.dY != nullptr) cst.dY[(long)(r0 + row) * cst.ldy + col] = g8[e];
+      };
+      if (cst.wrap) {
+        if (cst.variant == EMX_MEAN_ABS) elems(IC_<1>{}, IC_<1>{});
+        else elems(IC_<1>{}, IC_<0>{});
+      } else {
+        if (cst.variant == EMX_MEAN_ABS) elems(IC_<0>{}, IC_<1>{});
+        else elems(IC_<0>{}, IC_<0>{});
       }
       if constexpr (RESTAGE) {
         TSTAMP(51);
         stage_finish(g8, grp, a.top_Qp * 1024, a.top_pl, a.top_sc, a.top_aop, grp < a.top_Q);
         TSTAMP(52);
       }
-    }
+    };
+    if (wave < ngrp) group(wave);
+    if (ngrp > NW_)   // (an explicit guard: the drain sits in the loop's preheader, in front of its own trip-count test)
+      for (int grp = wave + NW_; grp < ngrp; grp += NW_) group(grp);
     const float tsum = block_sum<NT_>(lsum, cred);   // (its barriers also close the re-staging: the image is complete behind it)
     if constexpr (RESTAGE) TSTAMP(53);
     if (tid == 0) cst.ws[blockIdx.x] = tsum * cst.gnorm;
