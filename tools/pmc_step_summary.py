@@ -13,7 +13,9 @@ def short(n):
     return n.split("(")[0]
 
 
-LABEL = {"chain_kernel<2, 2>": "chain_kernel<FUSED> (forward + cost + decoder backward)", "chain_kernel_c128<2, 2>": "chain_kernel<FUSED> (128-register build)",
+LABEL = {"chain_kernel_small<2, 2>": "chain_kernel<FUSED> (forward + cost + decoder backward; SMALL build)",
+         "chain_kernel_small<1, 2>": "chain_kernel<BWD> (encoder backward; SMALL build)", "chain_kernel_small<0, 2>": "chain_kernel<FWD> (SMALL build)",
+         "chain_kernel<2, 2>": "chain_kernel<FUSED> (forward + cost + decoder backward)", "chain_kernel_c128<2, 2>": "chain_kernel<FUSED> (128-register build)",
          "chain_kernel<1, 2>": "chain_kernel<BWD> (encoder backward)", "chain_kernel_c128<1, 2>": "chain_kernel<BWD> (128-register build)",
          "chain_kernel<0, 2>": "chain_kernel<FWD>", "chain_kernel_c128<0, 2>": "chain_kernel<FWD> (128-register build)",
          "mlp_wgrad_kernel": "mlp_wgrad_kernel (+ scalar epilogue)", "adam_kernel<false>": "adam_kernel (+ next batch)", "adam_kernel<true>": "adam_kernel (+ next ADC head)",
