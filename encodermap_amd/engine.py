@@ -347,7 +347,7 @@ class SequentialEngine:
     _graph_steps = max(1, int(os.environ.get("EMX_GRAPH_STEPS", "32")))  # steps per replay of the largest multi-step graph (1: single-step graph only); 8 -> 32: -0.6 .. -1.0 us per step at C2
     _graph_multi = None
     _data_span = None   # periodic data: max - min over the training set (set_data)
-    _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (opt-in)
+    _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (the engine's own default is eager; bench.py sets it after its child-process probe)
     # the all-pairs tiles ride in the fused dense-layer launch, beside the decoder half of it (single process, Euclidean data on
     # split rows, two latent columns; anything else keeps the separate tile launch).  EMX_OVERLAP_TILES=0: always separate.
     _overlap_tiles = os.environ.get("EMX_OVERLAP_TILES", "1") != "0"
@@ -735,9 +735,10 @@ class SequentialEngine:
         try:
             captured = False
             if self.dp.active and self._dp_graph_allreduce:
-                # opt-in (EMX_DP_GRAPH_ALLREDUCE=1): the RCCL all-reduce captured inside the step's graph, so that the step
-                # is one graph again and replays eight at a time.  Measured with a one-rank RCCL group: 113 -> 94 us per
-                # step (tools/bench_dp_structure.py).  Not the default: it could not be run with more than one GPU here.
+                # EMX_DP_GRAPH_ALLREDUCE=1 (bench.py sets it when its probe passes): the RCCL all-reduce captured inside the
+                # step's graph, so that the step is one graph again and replays many at a time.  Measured with a one-rank
+                # RCCL group: 92.7 -> 72.4 us per step (profiles/r04_dp_one_rank_*.json).  Library users opt in themselves:
+                # it could not be run with more than one GPU here.
                 # (thread-local capture mode: the process group's watchdog thread must not invalidate the capture)
                 try:
                     g = torch.cuda.CUDAGraph()

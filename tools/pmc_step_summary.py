@@ -30,6 +30,8 @@ for f in glob.glob(root + "/*/*/*_counter_collection.csv"):
         nm = LABEL.get(k, k)
         if k.startswith("sk_tile"):
             nm = k + " (all-pairs)"
+        if k.startswith("chain_tiles_kernel"):
+            nm = k + " = chain_kernel<FUSED> with the all-pairs tiles beside its decoder half"
         vals[nm][r["Counter_Name"]].append(float(r["Counter_Value"]))
         vals[nm]["_dur_us_under_pmc"].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 out = {}
