@@ -217,17 +217,60 @@ class MlpDesc(C.Structure):
                 ("w_off", _l * EMX_MAX_LAYERS), ("b_off", _l * EMX_MAX_LAYERS)]
 
 
+class _LayerWindow:
+    """consecutive Dense layers of a network, seen as a network of their own (what MlpPlan reads of a layout)"""
+
+    def __init__(self, net_dim, layers, n_enc=None):
+        self.net_dim, self.layers, self.n_enc = int(net_dim), list(layers), n_enc
+
+
+def _window_bounds(n, n_enc):
+    """[begin, end) of the windows of a network of n > EMX_MAX_LAYERS layers: up to EMX_MAX_LAYERS layers each, never across the
+    encoder / decoder boundary (the engines launch the two halves separately)"""
+    cuts, a = [], 0
+    for stop in ([n_enc, n] if n_enc is not None and 0 < n_enc < n else [n]):
+        while a < stop:
+            b = min(a + EMX_MAX_LAYERS, stop)
+            cuts.append((a, b))
+            a = b
+    return cuts
+
+
 class MlpPlan:
     """Descriptor + pointer tables for one network (built once per engine).
 
     ``mirror``: the weight operand store (include/emx.h, emx_mlp_mirror), shared between plans over the same weights.
     ``train_rows``: > 0 allocates the weight-gradient operand store for batches of that many rows (emx_mlp_aop_bytes);
-    forward / backward launches then leave their fragments there and ``mlp_wgrad`` consumes them.  0: inference only."""
+    forward / backward launches then leave their fragments there and ``mlp_wgrad`` consumes them.  0: inference only.
+
+    More than EMX_MAX_LAYERS Dense layers (the reference stacks any number, models/models.py:3133-3160): the plan is a list of
+    WINDOWS -- plans of up to EMX_MAX_LAYERS consecutive layers over the same parameter buffer, each with its own descriptor,
+    operand store and fragment store (``windows``: (begin, end, plan)).  mlp_forward / mlp_backward / mlp_wgrad walk the windows
+    of their layer range (a window's backward launch hands dh of the layer below it to the next through ``dh``); the launches
+    that merge passes (mlp_forward_backward*, mlp_wgrad_adam*) answer EMX_EUNSUPPORTED, which is what makes the engines take
+    their separate-launch step, and the optimizer launches run without a store, which the windows rebuild afterwards."""
+
+    windows = None
 
     def __init__(self, layout, params, h, delta, mirror=None, train_rows: int = 0):
         n = len(layout.layers)
+        self.params = params
+        self.n_params = params.numel()
+        self.keep = (h, delta)
         if n > EMX_MAX_LAYERS:
-            raise EmxError(f"{n} dense layers not supported by the fused MLP kernels (max {EMX_MAX_LAYERS})")
+            bounds = _window_bounds(n, getattr(layout, "n_enc", None))
+            self.windows = []
+            for i, (a, b) in enumerate(bounds):
+                view = _LayerWindow(layout.net_dim if a == 0 else layout.layers[a - 1].n_out, layout.layers[a:b])
+                self.windows.append((a, b, MlpPlan(view, params, list(h[a:b]), list(delta[a:b]), mirror=None if mirror is None else mirror[i],
+                                                   train_rows=train_rows)))
+            self.mirror = tuple(w.mirror for _, _, w in self.windows)
+            self.desc = None
+            self.aop_rows = int(train_rows)
+            self.aop = tuple(w.aop for _, _, w in self.windows) if train_rows > 0 else None
+            # dh of the layer below a window (rows of h[begin - 1]): written by the window's backward launch, read by the next one's
+            self.dh = {a: torch.empty_like(h[a - 1]) for a, _, _ in self.windows[1:] if h[a - 1] is not None and delta[a] is not None}
+            return
         d = MlpDesc()
         d.n_layers = n
         d.width[0] = layout.net_dim
@@ -237,9 +280,6 @@ class MlpPlan:
             d.w_off[i] = lyr.w_off
             d.b_off[i] = lyr.b_off
         self.desc = d
-        self.params = params
-        self.n_params = params.numel()
-        self.keep = (h, delta)
         PtrArr = _p * EMX_MAX_LAYERS
         self.h = PtrArr(*[(t.data_ptr() if t is not None else None) for t in h] + [None] * (EMX_MAX_LAYERS - n))
         self.delta = PtrArr(*[(t.data_ptr() if t is not None else None) for t in delta] + [None] * (EMX_MAX_LAYERS - n))
@@ -253,8 +293,16 @@ class MlpPlan:
         if self.aop_rows > 0:
             self.aop = torch.zeros(load().emx_mlp_aop_bytes(C.byref(d), self.aop_rows), dtype=torch.uint8, device=params.device)
 
+    def overlapping(self, l0, l1):
+        """(window plan, window begin, first layer, end layer) of the windows that hold layers of [l0, l1), in ascending order"""
+        return [(w, a, max(a, l0), min(b, l1)) for a, b, w in self.windows if a < l1 and l0 < b]
+
     def refresh_mirror(self):
         """Rebuild the operand store after `params` was written by anything other than emx_adam_step*."""
+        if self.windows is not None:
+            for _, _, w in self.windows:
+                w.refresh_mirror()
+            return
         _check(load().emx_mlp_mirror(C.byref(self.desc), _ptr(self.params), _ptr(self.mirror), _stream()), "emx_mlp_mirror")
 
     def aop_args(self, train: bool):
@@ -466,9 +514,20 @@ def center_cost_fwd_bwd(Z, scale, row_begin, row_end, loss, dZ, accumulate):
 
 def _mirror_args(plan):
     """(descriptor, operand store) of the network whose kernels live in the parameter buffer, or (NULL, NULL)."""
-    if plan is None:
+    if plan is None or plan.windows is not None:    # (windows: the optimizer runs without a store, _after_optimizer rebuilds them)
         return None, None
     return C.byref(plan.desc), _ptr(plan.mirror)
+
+
+def _after_optimizer(plan):
+    """a plan of windows: its operand stores are rebuilt from the new weights (one launch per window)"""
+    if plan is not None and plan.windows is not None:
+        plan.refresh_mirror()
+
+
+def _no_merged_launch(plan, what):
+    if plan.windows is not None:
+        raise EmxError(f"{what}: more than {EMX_MAX_LAYERS} Dense layers run as windows of separate launches", EMX_EUNSUPPORTED)
 
 
 def l2_partials(w, l2coef, ws):
@@ -481,6 +540,7 @@ def adam_step(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, reg_loss, w
     _check(load().emx_adam_step(_ptr(w), _ptr(g), _ptr(m), _ptr(v), _ptr(l2coef), w.numel(), float(lr), float(beta1), float(beta2),
                                 float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(reg_loss), _ptr(ws), md, mp,
                                 nb, int(bool(bookkeeping_done)), _stream()), "emx_adam_step")
+    _after_optimizer(plan)
 
 
 def adam_step_history(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, terms, n_terms, history, term_history, hstep,
@@ -494,6 +554,7 @@ def adam_step_history(w, g, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws,
                                         float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step), _ptr(ws), md, mp,
                                         nb, _ptr(terms), int(n_terms), _ptr(history), _ptr(term_history), cap, _ptr(hstep), _stream()),
            "emx_adam_step_history")
+    _after_optimizer(plan)
 
 
 def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, step, ws, plan=None, next_batch=None,
@@ -504,6 +565,7 @@ def adam_step_slices(w, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, ep
     _check(load().emx_adam_step_slices(_ptr(w), _ptr(g_partials), int(n_slices), n, _ptr(m), _ptr(v), _ptr(l2coef), n, float(lr),
                                        float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(step),
                                        _ptr(ws), md, mp, nb, int(bool(bookkeeping_done)), _stream()), "emx_adam_step_slices")
+    _after_optimizer(plan)
 
 
 def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, clip, opt_step, terms, n_terms, reg_slot, history,
@@ -514,6 +576,7 @@ def adam_tick(w, g, g_partials, n_slices, m, v, l2coef, lr, beta1, beta2, eps, c
                                 float(beta1), float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(opt_step),
                                 _ptr(terms), int(n_terms), int(reg_slot), _ptr(history), _ptr(term_history), history.numel(),
                                 _ptr(hstep), _ptr(cursor), _ptr(ws), md, mp, _stream()), "emx_adam_tick")
+    _after_optimizer(plan)
 
 
 def mlp_wgrad_slices(n_rows):
@@ -530,6 +593,10 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" =
     """Layers [l0, l1) on rows [row_begin, row_end); ``cost`` evaluates the auto cost on the last layer's rows in the same launch.
     ``train``: leave the weight-gradient fragments in the plan's store (if it has one; the row range must then start at a
     multiple of 16)."""
+    if plan.windows is not None:
+        for w, a, b0, b1 in plan.overlapping(l0, l1):
+            mlp_forward(w, b0 - a, b1 - a, x if b0 == l0 else plan.keep[0][b0 - 1], row_begin, row_end, cost if b1 == l1 else None, train)
+        return
     ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_forward_cost(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
                                        int(row_end), plan.h, C.byref(cost) if cost is not None else None, ap, ar, _stream()),
@@ -538,6 +605,7 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" =
 
 def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None, train: bool = True):
     """Forward [l0, l1), auto cost, backward-data through [bwd_begin, l1) in one launch (delta[l1 - 1] = d cost / d output)."""
+    _no_merged_launch(plan, "emx_mlp_forward_backward")
     ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_forward_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0),
                                            int(row_begin), int(row_end), plan.h, C.byref(cost), int(bwd_begin), plan.delta, _ptr(dbelow),
@@ -549,6 +617,7 @@ def mlp_forward_backward_tiles(plan: MlpPlan, l0, l1, x, row_begin, row_end, cos
     """mlp_forward_backward with the all-pairs tiles of the sketch-map cost as extra workgroups of the same launch (emx.h):
     ``X`` the batch rows [B, D], ``split_ws`` their split planes (None for periodic rows), ``sk_ws`` the tile workspace (as sketchmap_tiles), ``zpub`` [B, 2]
     float32 scratch, ``sync`` 4 x int32 zeroed once."""
+    _no_merged_launch(plan, "emx_mlp_forward_backward_tiles")
     ap, ar = plan.aop_args(train)
     sig_arr = (_f * 6)(*[float(v) for v in sig])
     assert sync.dtype == torch.int32 and sync.numel() >= 4 and zpub.dtype == torch.float32
@@ -563,6 +632,7 @@ def mlp_forward_backward_tiles_join(plan: MlpPlan, l0, l1, x, row_begin, row_end
                                     latent_layer, latent, periodicity=float("inf"), data_span=None, train: bool = True):
     """mlp_forward_backward_tiles with the backward units below the latent layer in the same launch (emx.h): ``latent`` = the
     tiles' latent-gradient description (``sketchmap_describe(...).grad``), ``sync`` 8 x int32 zeroed once."""
+    _no_merged_launch(plan, "emx_mlp_forward_backward_tiles_join")
     ap, ar = plan.aop_args(train)
     sig_arr = (_f * 6)(*[float(v) for v in sig])
     assert sync.dtype == torch.int32 and sync.numel() >= 8 and zpub.dtype == torch.float32
@@ -599,6 +669,14 @@ def mlp_row_blocks(n_rows):
 
 
 def mlp_backward(plan: MlpPlan, l0, l1, dtop, dadd, layer_add, row_begin, row_end, dbelow=None, latent=None, train: bool = True):
+    """delta[l] for l = l1 - 1 .. l0 from ``dtop`` = d loss / d h[l1 - 1]; ``dadd`` / ``latent`` join at ``layer_add``; ``dbelow``
+    receives dh of the layer below the range (emx.h)."""
+    if plan.windows is not None:
+        for w, a, b0, b1 in reversed(plan.overlapping(l0, l1)):
+            joins = (dadd is not None or latent is not None) and b0 <= layer_add < b1
+            mlp_backward(w, b0 - a, b1 - a, dtop if b1 == l1 else plan.dh[b1], dadd if joins else None, layer_add - a if joins else 0,
+                         row_begin, row_end, dbelow if b0 == l0 else plan.dh[b0], latent if joins else None, train)
+        return
     ap, ar = plan.aop_args(train)
     _check(load().emx_mlp_backward(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(dtop), dtop.stride(0), _ptr(dadd),
                                    int(layer_add), C.byref(latent) if latent is not None else None, _ptr(dbelow), int(row_begin),
@@ -633,6 +711,10 @@ def mlp_wgrad(plan: MlpPlan, l0, l1, row_begin, row_end, grad, ws, finish: "Fini
     step's scalar epilogue rides along as one extra workgroup."""
     if plan.aop is None:
         raise EmxError("mlp_wgrad: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
+    if plan.windows is not None:       # (the slices' partials and the gradient are addressed by the layers' offsets in the ONE parameter buffer)
+        for w, a, b0, b1 in plan.overlapping(l0, l1):
+            mlp_wgrad(w, b0 - a, b1 - a, row_begin, row_end, grad, ws, finish if b1 == l1 else None)
+        return
     _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, plan.aop.data_ptr(), plan.aop_rows,
                                 int(row_begin), int(row_end), _ptr(grad), _ptr(ws), ws.numel(),
                                 C.byref(finish) if finish is not None else None, _stream()), "emx_mlp_wgrad")
@@ -640,6 +722,8 @@ def mlp_wgrad(plan: MlpPlan, l0, l1, row_begin, row_end, grad, ws, finish: "Fini
 
 def mlp_wgrad_adam_fits(plan: MlpPlan, n_rows, next_batch=None) -> bool:
     """whether emx_mlp_wgrad_adam can run this network / batch on the current device (every weight-gradient workgroup resident)"""
+    if plan.windows is not None:
+        return False
     nb = C.byref(next_batch) if next_batch is not None else None
     return bool(load().emx_mlp_wgrad_adam_fits(C.byref(plan.desc), int(n_rows), nb))
 
@@ -648,6 +732,7 @@ def mlp_wgrad_adam(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishDesc", 
                    next_batch=None):
     """Weight gradients of all layers, the step's scalar epilogue, L2 + clip + Adam (+ operand store) and the next batch's rows in ONE
     launch (emx.h): the same bits as ``mlp_wgrad(..., finish)`` followed by ``adam_step_slices(..., bookkeeping_done=True)``."""
+    _no_merged_launch(plan, "emx_mlp_wgrad_adam")
     if plan.aop is None:
         raise EmxError("mlp_wgrad_adam: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
     assert sync.dtype == torch.int32 and sync.numel() >= 4
@@ -660,11 +745,15 @@ def mlp_wgrad_adam(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishDesc", 
 
 def mlp_wgrad_adam_local_fits(plan: MlpPlan, n_rows, next_batch=None) -> bool:
     """whether emx_mlp_wgrad_adam_local is made for this network / batch (small batches, small networks)"""
+    if plan.windows is not None:
+        return False
     nb = C.byref(next_batch) if next_batch is not None else None
     return bool(load().emx_mlp_wgrad_adam_local_fits(C.byref(plan.desc), int(n_rows), nb))
 
 
 def mlp_wgrad_adam_local_ws_floats(plan: MlpPlan, n_rows) -> int:
+    if plan.windows is not None:
+        return 0
     return int(load().emx_mlp_wgrad_adam_local_ws_floats(C.byref(plan.desc), int(n_rows)))
 
 
@@ -673,6 +762,7 @@ def mlp_wgrad_adam_local(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishD
     """Weight gradients of all layers without slice partials (a workgroup per 32 x 32 block of a kernel, over all rows), the step's
     scalar epilogue, L2 + clip + Adam (+ operand store) and the next batch's rows in ONE launch (emx.h).  ``reg_ws``: 2 x
     EMX_REDUCE_WS floats (the regulariser shares by the parity of the optimizer step)."""
+    _no_merged_launch(plan, "emx_mlp_wgrad_adam_local")
     if plan.aop is None:
         raise EmxError("mlp_wgrad_adam_local: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
     assert sync.dtype == torch.int32 and sync.numel() >= 4 + 1024 and reg_ws.numel() >= 2 * EMX_REDUCE_WS

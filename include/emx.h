@@ -232,7 +232,12 @@ int emx_center_cost_fwd_bwd(const float* Z, int B, int L, float scale, int row_b
 
 /* description of the dense network (see K12 below); declared here because the optimizer keeps the operand store of the
  * dense-layer kernels current */
-#define EMX_MAX_LAYERS 12   /* Dense layers of one network: n_neurons of up to six entries (encoder + mirrored decoder) */
+#define EMX_MAX_LAYERS 12   /* Dense layers of ONE description: n_neurons of up to six entries (encoder + mirrored decoder).  A deeper
+                             * network is run as WINDOWS of consecutive layers: one description per window over the same parameter
+                             * buffer (w_off / b_off are offsets into it), each with its own operand store and fragment store;
+                             * emx_mlp_forward chains them through h, emx_mlp_backward through dbelow -> dtop, emx_mlp_wgrad writes a
+                             * window's part of the one gradient / partials buffer, the optimizer runs without a store and
+                             * emx_mlp_mirror rebuilds each window's afterwards (host side: encodermap_amd/_lib.py, MlpPlan.windows) */
 #ifndef EMX_WGRAD_SLICE_ROWS
 #define EMX_WGRAD_SLICE_ROWS 128   /* rows per weight-gradient slice; doubled until ... */
 #endif

@@ -36,6 +36,9 @@ CASES = [
     ("sidechains_distance_cost", dict(use_backbone_angles=True, use_sidechains=True, distance_cost_scale=3.0,
                                       dist_sig_parameters=(6.0, 12, 6, 1, 2, 6), cartesian_cost_variant="mean_square",
                                       dihedral_cost_variant="mean_norm", cartesian_dist_sig_parameters=(8.0, 12, 6, 1, 2, 6)), 9, 11, 50),
+    # fourteen Dense layers (the reference stacks any number, models/models.py:3133-3160): windows of <= 12 layers in separate launches
+    ("fourteen_layers", dict(use_backbone_angles=True, n_neurons=[48, 40, 32, 24, 16, 12, 2],
+                             activation_functions=["", "tanh", "tanh", "tanh", "tanh", "tanh", "tanh", ""]), 8, 0, 64),
     ("c3b_shape", dict(cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(20.0, 10, 5, 1, 2, 5),
                        dihedral_cost_reference=0.7, cartesian_cost_reference=3.0), 76, 0, 256),
 ]
@@ -84,6 +87,7 @@ def test_adc_loss_trajectory(em, name, kw, n_res, n_side, B):
         for a, b in zip(eng.get_weights(), model.params):       # weights after the last forced step
             diff = np.abs(a - b.detach().numpy())
             assert (diff > 5e-6).mean() < 0.03 and diff.max() < 2.1e-3
+    assert (e._engine.plan.windows is not None) == (name == "fourteen_layers")
     np.testing.assert_allclose(got, want, rtol=2e-4)
     for k in want_terms[0]:
         np.testing.assert_allclose(terms[k], [t_[k] for t_ in want_terms], rtol=5e-4, atol=1e-7, err_msg=k)

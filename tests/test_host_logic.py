@@ -259,6 +259,21 @@ def test_row_block_partition():
 
 
 # ---- the product path fails loudly without a GPU / library -----------------------------------------------------------
+def test_windows_of_a_deep_network():
+    """more than twelve Dense layers: windows of up to twelve, broken at the encoder / decoder boundary (encodermap_amd/_lib.py)"""
+    from encodermap_amd._lib import EMX_MAX_LAYERS, _window_bounds
+
+    assert EMX_MAX_LAYERS == 12
+    assert _window_bounds(16, 8) == [(0, 8), (8, 16)]
+    assert _window_bounds(28, 14) == [(0, 12), (12, 14), (14, 26), (26, 28)]
+    assert _window_bounds(13, None) == [(0, 12), (12, 13)]
+    assert _window_bounds(26, 1) == [(0, 1), (1, 13), (13, 25), (25, 26)]
+    for n, n_enc in [(13, 6), (40, 20), (25, 24)]:
+        w = _window_bounds(n, n_enc)
+        assert w[0][0] == 0 and w[-1][1] == n and all(a[1] == b[0] for a, b in zip(w, w[1:]))
+        assert all(0 < b - a <= 12 and not (a < n_enc < b) for a, b in w)
+
+
 def test_no_silent_cpu_fallback():
     import torch
 

@@ -361,6 +361,51 @@ def test_widest_nets_fall_back_to_separate_launches(em):
         em.EncoderMap(em.Parameters(batch_size=32), rng.uniform(-3, 3, (64, 1300)).astype(np.float32), read_only=True).train()
 
 
+@pytest.mark.parametrize("n_neurons,windows", [([48, 40, 32, 32, 24, 24, 16, 2], [(0, 8), (8, 16)]),
+                                               ([24] * 13 + [3], [(0, 12), (12, 14), (14, 26), (26, 28)])], ids=["16_layers", "28_layers"])
+@pytest.mark.parametrize("periodicity", [INF, 2 * PI], ids=["euclid", "periodic"])
+def test_more_than_twelve_dense_layers(em, n_neurons, windows, periodicity):
+    """The reference stacks any number of Dense layers (models/models.py:3133-3160).  Beyond twelve the plan is a list of windows
+    of up to twelve layers (never across the encoder / decoder boundary): separate forward / backward / weight-gradient launches per
+    window, dh handed from a window to the one below, the optimizer without the operand store and the stores rebuilt after it.
+    Same oracle, same tolerances as the twelve-layer networks."""
+    rng = np.random.default_rng(23)
+    if periodicity < INF:
+        data = rng.uniform(-PI, PI, (1500, 9)).astype(np.float32)
+        kw = dict(dist_sig_parameters=(3.0, 12, 6, 1, 2, 6))
+    else:
+        data = (rng.normal(0, 3, (6, 20))[rng.integers(0, 6, 1500)] + rng.normal(0, 1, (1500, 20))).astype(np.float32)
+        kw = dict(dist_sig_parameters=(6.0, 12, 6, 1, 2, 6))
+    acts = [""] + ["tanh"] * (len(n_neurons) - 1) + [""]
+    p = em.Parameters(n_steps=5, periodicity=periodicity, n_neurons=n_neurons, activation_functions=acts, batch_size=160, **kw)
+    e, model, got, want, terms, want_terms = run_both(em, em.EncoderMap, p, data, 5)
+    eng = e._engine
+    assert [(a, b) for a, b, _ in eng.plan.windows] == windows
+    assert not eng._fuse_decoder and not eng._local_fits() and not eng._tail_ran      # the separate-launch step
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+    # (28 tanh layers leave the lowest layers gradients at float32 rounding level, which Adam normalises to ~lr per step: the
+    #  criterion of the shallow networks, taken over all elements of the network instead of tensor by tensor)
+    diff = np.concatenate([np.abs(a - b.detach().numpy()).ravel() for a, b in zip(eng.get_weights(), model.params)])
+    assert (diff > 2e-5).mean() < 0.03 and diff.max() < 5e-4, (diff.max(), (diff > 2e-5).mean())
+    # the captured step equals the eager one, bit for bit (the windows' launches are ordinary launches of the graph)
+    e2 = run_both(em, em.EncoderMap, p, data, 5, use_graph=False)[0]
+    assert np.array_equal(e2._engine.losses(), eng.losses())
+    # inference through the windows, on the oracle's weights
+    eng.set_weights([b.detach().numpy() for b in model.params])
+    x = data[:200]
+    z_o = model.encoder(torch.tensor(x, dtype=torch.float64)).detach().numpy()
+    np.testing.assert_allclose(e.encode(x), z_o, atol=1e-4)
+    y_o = model.decoder(torch.tensor(z_o.astype(np.float32), dtype=torch.float64)).detach().numpy()
+    y = e.decode(z_o.astype(np.float32))
+    if periodicity < INF:
+        d = np.abs(y - y_o)
+        assert np.minimum(d, periodicity - d).max() < 2e-4 * periodicity
+    else:
+        np.testing.assert_allclose(y, y_o, atol=1e-4)
+
+
 def drift_ratio(got, f64, f32, rel=1e-4):
     """max over steps t of (|engine - f64|_t - rel |f64|_t) / envelope_t, envelope_t = max_{s <= t} |oracle_f32 - f64|_s: how
     many float32-drifts of the reference formulation itself the engine is away from the float64 trajectory (<= 0: inside
