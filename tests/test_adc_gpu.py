@@ -36,11 +36,11 @@ CASES = [
     ("sidechains_distance_cost", dict(use_backbone_angles=True, use_sidechains=True, distance_cost_scale=3.0,
                                       dist_sig_parameters=(6.0, 12, 6, 1, 2, 6), cartesian_cost_variant="mean_square",
                                       dihedral_cost_variant="mean_norm", cartesian_dist_sig_parameters=(8.0, 12, 6, 1, 2, 6)), 9, 11, 50),
+    ("c3b_shape", dict(cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(20.0, 10, 5, 1, 2, 5),
+                       dihedral_cost_reference=0.7, cartesian_cost_reference=3.0), 76, 0, 256),
     # fourteen Dense layers (the reference stacks any number, models/models.py:3133-3160): windows of <= 12 layers in separate launches
     ("fourteen_layers", dict(use_backbone_angles=True, n_neurons=[48, 40, 32, 24, 16, 12, 2],
                              activation_functions=["", "tanh", "tanh", "tanh", "tanh", "tanh", "tanh", ""]), 8, 0, 64),
-    ("c3b_shape", dict(cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(20.0, 10, 5, 1, 2, 5),
-                       dihedral_cost_reference=0.7, cartesian_cost_reference=3.0), 76, 0, 256),
 ]
 
 
