@@ -242,6 +242,8 @@ class MlpPlan:
     ``mirror``: the weight operand store (include/emx.h, emx_mlp_mirror), shared between plans over the same weights.
     ``train_rows``: > 0 allocates the weight-gradient operand store for batches of that many rows (emx_mlp_aop_bytes);
     forward / backward launches then leave their fragments there and ``mlp_wgrad`` consumes them.  0: inference only.
+    ``aop``: share another plan's store (a second pointer table over the same network: h[l] / delta[l] = None are rows the
+    launches do not write to HBM).
 
     More than EMX_MAX_LAYERS Dense layers (the reference stacks any number, models/models.py:3133-3160): the plan is a list of
     WINDOWS -- plans of up to EMX_MAX_LAYERS consecutive layers over the same parameter buffer, each with its own descriptor,
@@ -252,7 +254,7 @@ class MlpPlan:
 
     windows = None
 
-    def __init__(self, layout, params, h, delta, mirror=None, train_rows: int = 0):
+    def __init__(self, layout, params, h, delta, mirror=None, train_rows: int = 0, aop=None):
         n = len(layout.layers)
         self.params = params
         self.n_params = params.numel()
@@ -289,8 +291,8 @@ class MlpPlan:
             self.refresh_mirror()
         self.mirror = mirror
         self.aop_rows = int(train_rows)
-        self.aop = None
-        if self.aop_rows > 0:
+        self.aop = aop
+        if self.aop_rows > 0 and aop is None:
             self.aop = torch.zeros(load().emx_mlp_aop_bytes(C.byref(d), self.aop_rows), dtype=torch.uint8, device=params.device)
 
     def overlapping(self, l0, l1):

@@ -256,6 +256,16 @@ class SequentialEngine:
         # auto cost per row block (zero: no auto cost); at least EMX_REDUCE_WS long for the stand-alone cost kernel's shares
         self.cost_ws = torch.zeros(max(_lib.mlp_row_blocks(self.re - self.rb), _lib.EMX_REDUCE_WS), dtype=f32, device=dev)
         self.plan = _lib.MlpPlan(lay, self.w, self.h, self.delta, train_rows=B)
+        # The same network with the rows NOBODY reads left out of HBM (``_lean``): where the decoder's backward pass rides in the
+        # forward launch it takes its activation derivatives from the LDS copies, the weight gradients come from the f16 fragments,
+        # and the encoder's backward launch hands nothing but fragments on -- the float32 rows of the decoder's activations and of
+        # every delta would be written and never read (C2: 12 of the fused launch's 41.6 MB, 4 of the encoder backward's 16.7).
+        # A null row pointer makes the launch drop those stores (a zero-sized buffer descriptor).  h / delta keep the rows of
+        # the LAST launch that did write them: diagnostics set ``_lean = False`` (tests/accuracy.py).
+        self.plan_lean = self.plan
+        if self.plan.windows is None:
+            self.plan_lean = _lib.MlpPlan(lay, self.w, [t if i < lay.n_enc else None for i, t in enumerate(self.h)], [None] * len(self.delta),
+                                          mirror=self.plan.mirror, train_rows=B, aop=self.plan.aop)
         # slice partials of emx_mlp_wgrad, or the workgroups' shares of emx_mlp_wgrad_adam_local (narrow networks: the larger of the two)
         self.wg_ws = torch.zeros(max(_lib.mlp_wgrad_ws_floats(lay.n_params, self.re - self.rb), _lib.mlp_wgrad_adam_local_ws_floats(self.plan, self.re - self.rb)),
                                  dtype=f32, device=dev)
@@ -368,6 +378,7 @@ class SequentialEngine:
     _local_wgrad = os.environ.get("EMX_LOCAL_WGRAD", "1") != "0"
     _local_ok = None
     _tiles_ran = False
+    _lean = os.environ.get("EMX_LEAN_ROWS", "1") != "0"   # float32 rows that no launch reads are not written (plan_lean)
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -385,15 +396,17 @@ class SequentialEngine:
         full = (self.rb, self.re) == (0, self.B)
         fuse = p.auto_cost_scale is not None and self._fuse_decoder and not self._fork
         cost = None
+        lean = self._lean and self.plan_lean is not self.plan
+        pf = self.plan_lean if lean else self.plan        # (the fused launches: rows nobody reads stay on chip)
         if p.auto_cost_scale is not None:
             cost = _lib.make_auto_cost(self.xb, self.D, 0, self.D, self.periodic, self._cost_periodicity, p.auto_cost_variant,
-                                       float(p.auto_cost_scale), self.B, self.delta[-1] if fuse else self.dY, self.cost_ws)
+                                       float(p.auto_cost_scale), self.B, (None if lean else self.delta[-1]) if fuse else self.dY, self.cost_ws)
         self._tiles_ran = self._bwd_ran = False
         if fuse:
             if full and self._overlap_tiles and self._tiles_fit():
                 if self._join_bwd and self._sk is not None and self._sk.grad.n_slots <= 64:
                     try:      # ... and the encoder's backward units in the same launch: the step's first THREE launches as one
-                        _lib.mlp_forward_backward_tiles_join(self.plan, 0, n, self.xin, 0, self.B, cost, 0, self.xb, p.dist_sig_parameters, self.sk_ws,
+                        _lib.mlp_forward_backward_tiles_join(pf, 0, n, self.xin, 0, self.B, cost, 0, self.xb, p.dist_sig_parameters, self.sk_ws,
                                                              self.split_ws, self.zpub, self.sk_sync, lay.n_enc - 1, self._sk.grad,
                                                              periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
                         self._tiles_ran = self._bwd_ran = self._waits_used = True
@@ -403,7 +416,7 @@ class SequentialEngine:
                             raise
                         self._join_bwd = False
                 try:
-                    _lib.mlp_forward_backward_tiles(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
+                    _lib.mlp_forward_backward_tiles(pf, 0, n, self.xin, 0, self.B, cost, lay.n_enc, self.dlat, self.xb, p.dist_sig_parameters,
                                                     self.sk_ws, self.split_ws, self.zpub, self.sk_sync,
                                                     periodicity=self.periodicity if self.periodic else INF, data_span=self._data_span)
                     self._tiles_ran = self._waits_used = True
@@ -414,10 +427,10 @@ class SequentialEngine:
                     self._overlap_tiles = False    # outside what the tile role is built for: the separate launches from now on
             try:
                 if full:
-                    _lib.mlp_forward_backward(self.plan, 0, n, self.xin, 0, self.B, cost, lay.n_enc, dbelow=self.dlat)
+                    _lib.mlp_forward_backward(pf, 0, n, self.xin, 0, self.B, cost, lay.n_enc, dbelow=self.dlat)
                 else:
-                    _lib.mlp_forward(self.plan, 0, lay.n_enc, self.xin, 0, self.B)
-                    _lib.mlp_forward_backward(self.plan, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost, lay.n_enc,
+                    _lib.mlp_forward(pf, 0, lay.n_enc, self.xin, 0, self.B)
+                    _lib.mlp_forward_backward(pf, lay.n_enc, n, self.h[lay.n_enc - 1], self.rb, self.re, cost, lay.n_enc,
                                               dbelow=self.dlat)
                 return True
             except _lib.EmxError as exc:
@@ -566,12 +579,13 @@ class SequentialEngine:
         if self._bwd_ran:          # (the encoder's backward units ran in the fused launch)
             self._wgrad()
             return
+        pb = self.plan_lean if self._lean else self.plan      # (the encoder's deltas leave as fragments only)
         if self._dealt():
-            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         elif self._use_sketchmap():
-            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
+            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
         else:
-            _lib.mlp_backward(self.plan, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
         self._wgrad()
 
     def _local_fits(self) -> bool:

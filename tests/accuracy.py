@@ -93,6 +93,7 @@ def dense_layer_errors(em, name, seed=0, local=False):
     idx = rng.integers(0, data.shape[0], B)
     e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True, use_graph=False)
     eng = e._engine
+    eng._lean = False      # (this comparison reads every float32 row of the step: activations and deltas of all layers)
     if local:
         w_before = eng.w.double().cpu().numpy()
         eng.run_steps(1, torch.from_numpy(idx).to(eng.device))
