@@ -306,7 +306,12 @@ def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, roof, boun
                            else "SURVEY 8d FLOPs / fp32 vector peak"),
             "frac_survey_8d": (flops_8d / t / FP32_PEAK) if flops_8d else None,
             "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": src,
-            "kernel": kernel, "kernel_us": t * 1e6, "algorithmic_bytes": algorithmic_bytes,
+            "kernel": kernel, "kernel_us": t * 1e6,
+            "timing": "HIP events around back-to-back launches of the kernel alone on the live batch (torch's current stream = the stream "
+                      "the kernels run on).  Inside the step a launch also pays the first touch of what the previous launch rewrote on other "
+                      "XCDs: the profiler's per-launch trace shows the fused dense-layer launch 2-4 us longer there than alone "
+                      "(profiles/r04_in_step.txt), and its --stats average mixes both kinds of launches of this command",
+            "algorithmic_bytes": algorithmic_bytes,
             "hbm_frac_algorithmic": algorithmic_bytes / t / HBM_PEAK,
             "fractions": {"fp32_equivalent": flops_alg / t / FP32_PEAK, "executed": flops_exec / t / peak,
                           "valu_issue": (valu / (SIMDS * CLOCK * t)) if valu else None,
