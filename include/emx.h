@@ -394,7 +394,11 @@ int emx_mlp_mirror(const emx_mlp_desc* desc, const float* params, float* mirror,
  * kept.  With a store the row range must start at a multiple of 16. */
 size_t emx_mlp_aop_bytes(const emx_mlp_desc* desc, int n_rows);
 
-/* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in) */
+/* layers [layer_begin, layer_end) on rows [row_begin,row_end); `in` [*, width[layer_begin]] (row stride ld_in).
+ * h[l] (and delta[l] of the backward launches below) are tables of row pointers, one per layer of the description: a NULL entry is a
+ * tensor the caller does not keep -- its float32 rows are not written (the launch still forms them on chip and leaves their
+ * fragments in `aop`).  Entries a launch READS must be there: emx_mlp_backward needs h[l] of every layer with an activation in its
+ * range, the inference result is h[layer_end - 1]. */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream);
 /* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch
