@@ -406,6 +406,33 @@ def test_more_than_twelve_dense_layers(em, n_neurons, windows, periodicity):
         np.testing.assert_allclose(y, y_o, atol=1e-4)
 
 
+@pytest.mark.parametrize("B", [256, 2048])
+def test_rows_nobody_reads_are_not_written(em, monkeypatch, B):
+    """engine.plan_lean: the fused step's launches get NULL row pointers for the decoder's activations and for every delta -- those
+    float32 rows stay on chip -- and the step is bit for bit the step that writes them all (EMX_LEAN_ROWS=0)."""
+    from encodermap_amd.engine import SequentialEngine
+
+    rng = np.random.default_rng(31)
+    data = (rng.normal(0, 3, (6, 64))[rng.integers(0, 6, 6000)] + rng.normal(0, 1, (6000, 64))).astype(np.float32)
+    p = em.Parameters(n_steps=8, periodicity=INF, batch_size=B, dist_sig_parameters=(10.0, 12, 6, 1, 2, 6))
+    runs = {}
+    for lean in (True, False):
+        monkeypatch.setattr(SequentialEngine, "_lean", lean)
+        e = em.EncoderMap(p, data, model=[w.copy() for w in initial_weights(em, p, 64)], read_only=True)
+        eng = e._engine
+        eng.run_steps(8, torch.from_numpy(np.random.default_rng(2).integers(0, 6000, 8 * B)).to("cuda:0"))
+        runs[lean] = (eng.losses().copy(), [w.copy() for w in eng.get_weights()], [float(t.abs().max()) for t in eng.h],
+                      [float(t.abs().max()) for t in eng.delta])
+        assert eng._fuse_decoder and eng.plan_lean is not eng.plan
+    n_enc = eng.layout.n_enc
+    assert np.array_equal(runs[True][0], runs[False][0])
+    for a, b in zip(runs[True][1], runs[False][1]):
+        assert np.array_equal(a, b)
+    # what was written: everything without the lean tables; with them the encoder's activations only
+    assert all(v > 0 for v in runs[False][2]) and all(v > 0 for v in runs[False][3])
+    assert all(v > 0 for v in runs[True][2][:n_enc]) and all(v == 0 for v in runs[True][2][n_enc:]) and all(v == 0 for v in runs[True][3])
+
+
 def drift_ratio(got, f64, f32, rel=1e-4):
     """max over steps t of (|engine - f64|_t - rel |f64|_t) / envelope_t, envelope_t = max_{s <= t} |oracle_f32 - f64|_s: how
     many float32-drifts of the reference formulation itself the engine is away from the float64 trajectory (<= 0: inside
