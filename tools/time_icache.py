@@ -18,27 +18,24 @@ eng.run_steps(20)
 torch.cuda.synchronize()
 st = torch.cuda.current_stream().cuda_stream
 N = 300
-def probe(big, wgs=512):
-    assert lib.probe_launch(big, wgs, st) == 0
-def both(big):
-    probe(big); eng._forward()
-t_f = bench._time_launches(eng._forward, N) * 1e6
-for big, name in ((0, "a launch that does nothing"), (1, "a launch that walks 56 KB of code on every CU")):
-    t_p = bench._time_launches(lambda: probe(big), N) * 1e6
-    t_b = bench._time_launches(lambda: both(big), N) * 1e6
-    print(f"fused launch behind {name}: {t_b - t_p:.2f} us  (pair {t_b:.2f}, the other launch alone {t_p:.2f}; fused alone back to back {t_f:.2f})")
-# the same for the encoder's backward launch and the all-pairs launch
+def probe(kb, wgs=512):
+    assert lib.probe_launch(kb, wgs, st) == 0
 from encodermap_amd import _lib
 lay = eng.layout
 def bwd():
     _lib.mlp_backward(eng.plan_lean, 0, lay.n_enc, eng.dlat, None, lay.n_enc - 1, 0, B, latent=eng._sk.grad)
 def sk():
     eng._latent_costs()
-for fn, nm in ((bwd, "encoder backward"), (sk, "all-pairs")):
+def tail():
+    eng._wgrad()
+SIZES = (0, 8, 16, 24, 32, 40, 48, 56)
+t_p = {kb: bench._time_launches(lambda: probe(kb), N) * 1e6 for kb in SIZES}
+print("the launch behind a launch that walks .. KB of straight-line code on every CU (pair minus that launch alone), us:")
+print("                         " + "".join(f"{kb:>8d}" for kb in SIZES) + "   alone, back to back")
+for fn, nm in ((eng._forward, "fused dense layers"), (sk, "all-pairs"), (bwd, "encoder backward"), (tail, "weight gradients + optimizer")):
     t_a = bench._time_launches(fn, N) * 1e6
-    out = [f"{nm}: alone {t_a:.2f} us"]
-    for big in (0, 1):
-        t_p = bench._time_launches(lambda: probe(big), N) * 1e6
-        t_b = bench._time_launches(lambda: (probe(big), fn()), N) * 1e6
-        out.append(f"behind {'big code' if big else 'nothing'} {t_b - t_p:.2f}")
-    print(", ".join(out))
+    row = []
+    for kb in SIZES:
+        t_b = bench._time_launches(lambda: (probe(kb), fn()), N) * 1e6
+        row.append(t_b - t_p[kb])
+    print(f"{nm:<25s}" + "".join(f"{v:8.2f}" for v in row) + f"   {t_a:8.2f}")
