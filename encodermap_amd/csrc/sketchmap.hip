@@ -394,7 +394,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_num_vgpr(64))) void sk_ti
   float* ni_s = smem + MAIN;
   float* nj_s = ni_s + T;
   float* zi_s = nj_s + T;                               // [T][LMAX]
-  float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
+  float* cpart = zi_s + T * LMAX;                       // [T][LC][2]
   float* red = cpart + T * LMAX * 2;
 
   const int L = LT == 2 ? 2 : a.L;   // LT: 2 = exactly two latent columns (compile time); 0 / 8 = up to 4 / 8 columns at run time, zero padded
@@ -581,7 +581,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (HIP's uint
 template <int LT, bool FASTSIG, int NCH>
 // (leading scalars: what the tile decode and the first operand loads need, preloaded into scalar registers at wave launch --
 //  -amdgpu-kernarg-preload-count; 56 bytes, the struct follows)
-__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void sk_tile_f16_kernel(
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 : 8, LT > 8 ? 3 : 8))) void sk_tile_f16_kernel(
     const uint16_t* p_planes, long p_plane_stride, int p_xcd_nbg, int p_nbc, int p_symm, int p_deal_world, int p_deal_rank, int p_row0, int p_B,
     int p_split_B, int p_split_ld, int p_kmode_ksplit, const SkArgs a) {
   // (the compiler sizes its register budget for the occupancy a 64-KB LDS would allow; gfx950 has 160 KB, so the target
@@ -594,16 +594,20 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   // into the slot of 32-tile (2 ti, 2 tj) and zeros into its other 32-tiles' -- as the 128 x 128 macro-tiles write the 64-tile
   // layout (below).  The sums the consumers form over the slots are the 32-tile pass's up to the association of the additions.
   constexpr bool OUT32 = LT > 4;
+  // LT = 12 / 16: latent widths 9 .. 12 / .. 16 (run-time width, zero padded): the epilogue walks the latent EIGHT columns at a time (LC) -- the
+  // squared low-d distances of the lane's sixteen pairs over all columns first, then the pairs' coefficients (they replace the Gram
+  // accumulators), then per chunk of columns the gradient partials through the same reduction area as the eight-column form.
+  constexpr int LC = LT > 8 ? 8 : LMAX;                 // latent columns per epilogue pass
   constexpr int RP = 20;                                // 16 pre-reduced column-lane partials per (row, l) + pad
   constexpr int STAGE = 1024 * 4;                       // 2 sides x 2 planes x 64 rows x 32 k f16, as 16-byte pieces
-  constexpr int PART = T * LMAX * RP;                   // row partials (reuse the staging area)
+  constexpr int PART = T * LC * RP;                     // row partials (reuse the staging area)
   constexpr int MAIN = STAGE > PART ? STAGE : PART;
-  constexpr int SMEM = MAIN + 4 * T + T * LMAX + T * LMAX * 2 + 8;   // + (norm, 1/scale) of 2 T rows + latent rows of the tile + column partials
+  constexpr int SMEM = MAIN + 4 * T + T * LMAX + T * LC * 2 + 8;   // + (norm, 1/scale) of 2 T rows + latent rows of the tile + column partials
   __shared__ __align__(16) float smem[SMEM];
   float2* nr_s = reinterpret_cast<float2*>(smem + MAIN);   // [2 T] (|x|^2, 1/s): rows of the i side, then of the j side
   float* zi_s = smem + MAIN + 4 * T;                    // [T][LMAX]
   float* cpart = zi_s + T * LMAX;                       // [T][LMAX][2]
-  float* red = cpart + T * LMAX * 2;
+  float* red = cpart + T * LC * 2;
 
   const int L = (LT >= 2 && LT <= 4) ? LT : a.L;   // LT: 2 / 3 / 4 = exactly that many latent columns (compile time); 0 = up to 4 columns at run time, zero padded
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -756,6 +760,130 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(8, 8))) void
   const bool jok = jg < a.B;
   const float2 nrj = nr_s[T + jl];
   const float nj = nrj.x, cj = -2.f * nrj.y;
+  if constexpr (LT > 8) {
+    // ---- latent widths 9 .. 16, eight columns at a time
+    const float* zjp = a.Z + (long)min(jg, a.B - 1) * L;   // the latent row of column j (re-read per chunk: a few L2 hits)
+    float* rpart = smem;                                   // [T][LC][RP]
+    const bool edge = (i0 + T > a.row_end) || (j0 + T > a.B) || (i0 == j0);
+    const int ib = wm * 32 + 4 * h;
+    const float2* nr_b = nr_s + ib;
+    const float* zi_b = zi_s + ib * LMAX;
+    float* rp_b = rpart + ib * LC * RP + (jl >> 2);
+    float dl2[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dl2[r] = 0.f;
+#pragma unroll
+    for (int c0 = 0; c0 < LMAX; c0 += LC) {
+      float zj[LC];
+#pragma unroll
+      for (int l = 0; l < LC; ++l) zj[l] = (jok && c0 + l < L) ? zjp[c0 + l] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int l = 0; l < LC; ++l) {
+          if (c0 + l < LMAX) {   // (LT = 12: the second chunk is four columns wide)
+            const float d = zi_b[ro * LMAX + c0 + l] - zj[l];
+            dl2[r] = fmaf(d, d, dl2[r]);
+          }
+        }
+      }
+    }
+    // the pairs' coefficients g = f G (they take the Gram accumulators' registers) and the tile's cost
+    float lsum = 0.f;
+    auto coef = [&](int r, bool masked) {
+      const int ro = (r & 3) + 8 * (r >> 2);
+      const float2 nri = nr_b[ro];
+      float d2 = fmaf(acc[r] * nri.y, cj, nri.x + nj);
+      if (!FASTSIG) d2 = fmaxf(d2, 0.f);
+      if (masked) d2 = (i0 + ib + ro == jg) ? 0.f : d2;
+      const float Eh = sig_E_high<FASTSIG>(d2, a.sh);
+      float El, G;
+      sig_E_low<FASTSIG>(dl2[r], a.sl, El, G);
+      float f = El - Eh;
+      if (masked) f = (i0 + ib + ro < a.row_end && jok) ? f : 0.f;
+      lsum = fmaf(f, f, lsum);
+      acc[r] = f * G;
+    };
+    if (edge) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) coef(r, true);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) coef(r, false);
+    }
+    const float tl = block_sum<NT>(lsum, red);   // (contains __syncthreads: the staging area is free)
+    const int nbc = a.nbc, nbr = a.nbr;
+    if (tid < 4) {   // the 32-tile layout: this tile's cost into the slot of 32-tile (2 ti, 2 tj), zeros into its other 32-tiles'
+      const int si = 2 * ti + (tid >> 1), sj = 2 * tj + (tid & 1);
+      const float val = tid == 0 ? (offdiag ? 2.f * tl : tl) : 0.f;
+      if (p_symm) {
+        if (si <= sj && sj < nbc) a.tile_loss[si * nbc - si * (si - 1) / 2 + (sj - si)] = val;
+      } else if (si < nbr && sj < nbc) {
+        a.tile_loss[si * nbc + sj] = val;
+      }
+    }
+    const int ir = i0 - a.row0;
+    auto chunk = [&](const int c0, auto W_) __attribute__((always_inline)) {
+      constexpr int W = decltype(W_)::value;                                // columns c0 .. c0 + W - 1 (W <= LC)
+      if (c0 >= L) return;                                                  // (workgroup-uniform)
+      float zj[W], gj[W];
+#pragma unroll
+      for (int l = 0; l < W; ++l) {
+        zj[l] = (jok && c0 + l < L) ? zjp[c0 + l] : 0.f;
+        gj[l] = 0.f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ro = (r & 3) + 8 * (r >> 2);
+#pragma unroll
+        for (int l = 0; l < W; ++l) {
+          float v = acc[r] * (zi_b[ro * LMAX + c0 + l] - zj[l]);
+          gj[l] -= v;
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+          v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+          rp_b[(ro * LC + l) * RP] = v;
+        }
+      }
+      if (offdiag) {
+#pragma unroll
+        for (int l = 0; l < W; ++l) {
+          const float sgj = sum_xor32(gj[l]);   // the two row halves of the quadrant
+          if (h == 0) cpart[(jl * LC + l) * 2 + wm] = sgj;
+        }
+      }
+      __syncthreads();
+      for (int e = tid; e < T * LC; e += NT) {
+        const int rl = e / LC, l = c0 + (e - rl * LC);
+        if (l < L && l < c0 + W && ir + rl < a.nrows_pad) {
+          const float4* p = reinterpret_cast<const float4*>(&rpart[e * RP]);
+          const float4 s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+          const float sum = (((s0.x + s0.y) + (s0.z + s0.w)) + ((s1.x + s1.y) + (s1.z + s1.w))) +
+                            (((s2.x + s2.y) + (s2.z + s2.w)) + ((s3.x + s3.y) + (s3.z + s3.w)));
+          a.P[((long)(2 * tj) * a.nrows_pad + ir + rl) * L + l] = sum;
+          if (2 * tj + 1 < nbc) a.P[((long)(2 * tj + 1) * a.nrows_pad + ir + rl) * L + l] = 0.f;
+        }
+      }
+      if (offdiag) {
+        for (int e = tid; e < T * LC; e += NT) {
+          const int rl = e / LC, l = c0 + (e - rl * LC);
+          if (l < L && l < c0 + W && j0 - a.row0 + rl < a.nrows_pad) {
+            a.P[((long)(2 * ti) * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = cpart[e * 2] + cpart[e * 2 + 1];
+            a.P[((long)(2 * ti + 1) * a.nrows_pad + (j0 - a.row0) + rl) * L + l] = 0.f;
+          }
+        }
+      }
+      __syncthreads();   // (the next chunk overwrites the partial areas)
+    };
+    if constexpr (LMAX - LC == LC) {   // two chunks of the same width: ONE copy of the code
+#pragma unroll 1
+      for (int c0 = 0; c0 < LMAX; c0 += LC) chunk(c0, std::integral_constant<int, LC>{});
+    } else {
+      chunk(0, std::integral_constant<int, LC>{});
+      chunk(LC, std::integral_constant<int, LMAX - LC>{});
+    }
+    return;
+  }
   float zj[LMAX];
 #pragma unroll
   for (int l = 0; l < LMAX; ++l) zj[l] = (jok && l < L) ? a.Z[(long)jg * L + l] : 0.f;
@@ -1472,8 +1600,8 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     }
     return emx::check_launch("sk_tile_mfma_kernel");
   }
-  if (a.split.planes != nullptr && pl.T == 32 && !pl.periodic && a.L > 4 && a.L <= 8 && a.deal_world <= 1 && a.B >= 64) {
-    // latent widths 5 .. 8 on split rows: the Gram tiles of the f16 matrix cores at 64 x 64, writing the 32-tile layout every
+  if (a.split.planes != nullptr && pl.T == 32 && !pl.periodic && a.L > 4 && a.L <= 16 && a.deal_world <= 1 && a.B >= 64) {
+    // latent widths 5 .. 16 on split rows: the Gram tiles of the f16 matrix cores at 64 x 64, writing the 32-tile layout every
     // consumer of these widths plans with (sk_tile_f16_kernel: OUT32) -- the 32 x 32 VALU tiles they replace cost 7x the two-column
     // pass at 4096 rows (113-126 us against 17).  Not for dealt tiles: the deal is by 32-tile.
     const int nch = a.split.ld / SPLIT_KC;
@@ -1489,14 +1617,21 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(grid), dim3(NT), 0, st, (const uint16_t*)a.split.planes, (long)a.split.plane_stride, xnbg, nbc64, a.symm, 1, 0, a.row0, \
                      a.B, a.split.B, a.split.ld, 0, a)
     // (five and six columns: the six-column instantiation -- the epilogue's latent part is a third of its instructions at this width)
-    if (a.L <= 6 && pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<6, true, 4>));
+    // (nine to sixteen columns: the epilogue walks the latent eight columns at a time, LT = 16)
+    if (a.L > 8 && a.L <= 12 && pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<12, true, 4>));   // (chunks of eight and four columns)
+    else if (a.L > 8 && a.L <= 12 && pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<12, true, 8>));
+    else if (a.L > 8 && pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<16, true, 4>));
+    else if (a.L > 8 && pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<16, true, 8>));
+    else if (a.L > 8 && pl.fast) SK_F16_LAUNCH32((sk_tile_f16_kernel<16, true, 0>));
+    else if (a.L > 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<16, false, 0>));
+    else if (a.L <= 6 && pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<6, true, 4>));
     else if (a.L <= 6 && pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<6, true, 8>));
     else if (pl.fast && nch == 4) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 4>));
     else if (pl.fast && nch == 8) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 8>));
     else if (pl.fast) SK_F16_LAUNCH32((sk_tile_f16_kernel<8, true, 0>));
     else SK_F16_LAUNCH32((sk_tile_f16_kernel<8, false, 0>));
 #undef SK_F16_LAUNCH32
-    return emx::check_launch("sk_tile_f16_kernel (latent widths 5 .. 8)");
+    return emx::check_launch("sk_tile_f16_kernel (latent widths 5 .. 16)");
   }
   if (pl.T == 32) {
     if (a.L == 2) dispatch2<32, 2>(a, pl.ntiles, pl.periodic, pl.fast, st);

@@ -542,6 +542,10 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     # batches of 8192 rows and more: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); ragged last tiles,
     # an odd number of 64-row blocks, the general sigmoid
     (600, 64, 12, (8.0, 12, 6, 1, 2, 6), 0, 600), (300, 48, 19, (5.0, 3, 6, 1, 2, 6), 100, 300),      # latent widths beyond 8
+    # latent widths 9 .. 16 on the Gram tiles (round 4: the epilogue walks the latent eight columns at a time, sk_tile_f16_kernel<16, ..>):
+    # fast and general sigmoid, a row range, ragged tiles, D of one / four / eight chunks
+    (700, 64, 9, (8.0, 12, 6, 1, 2, 6), 0, 700), (500, 32, 16, (5.0, 3, 6, 1, 2, 6), 200, 500), (1100, 128, 13, (16.0, 12, 6, 1, 2, 6), 0, 1100),
+    (330, 256, 10, (22.0, 12, 6, 1, 2, 6), 0, 330),
     (1100, 128, 3, (16.0, 12, 6, 1, 2, 6), 0, 1100), (700, 256, 4, (22.0, 12, 6, 1, 2, 6), 0, 700), (900, 128, 4, (16.0, 12, 6, 1, 2, 6), 0, 900),   # 3 / 4 columns at compile time
     (8192, 32, 2, (8.0, 12, 6, 1, 2, 6), 0, 8192), (8300, 64, 2, (11.0, 12, 6, 1, 2, 6), 0, 8300), (8256, 40, 2, (9.0, 3, 6, 1, 2, 6), 0, 8256)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
