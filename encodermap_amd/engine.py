@@ -317,11 +317,15 @@ class SequentialEngine:
     def draw_index_block(self, n_batches: int) -> torch.Tensor:
         """Device twin of layout.BatchIndexStream: shuffle(N) -> repeat -> batch(B), batches straddle passes.  Every pass is one
         emx_permute (a keyed bijection evaluated per element: no sort, no host work); torch only owns the buffers."""
-        if self._pending is not None:
-            first, self._pending = self._pending, None
-            if n_batches == 1:
+        if self._pending is not None:      # batches that were drawn ahead of their use and went back to the stream: they come first
+            have = self._pending.numel() // self.B
+            if n_batches < have:
+                first, self._pending = self._pending[: n_batches * self.B], self._pending[n_batches * self.B:]
                 return first
-            return torch.cat([first, self.draw_index_block(n_batches - 1)])
+            first, self._pending = self._pending, None
+            if n_batches == have:
+                return first
+            return torch.cat([first, self.draw_index_block(n_batches - have)])
         need = n_batches * self.B
         N = self.data.shape[0]
         have = self._perm.numel() - self._perm_pos
@@ -891,10 +895,12 @@ class SequentialEngine:
             while done < n_steps:
                 room = cap - 1 - self._ring_pos
                 if room <= 0:
-                    # restart: the batch under the cursor (drawn, its rows already gathered by the last optimizer launch) moves to the front
-                    self.idx_block[:B].copy_(self.idx_block[self._ring_pos * B: (self._ring_pos + 1) * B].clone())
+                    # restart: the batch under the cursor (drawn, its rows already gathered by the last optimizer launch) and whatever
+                    # was drawn behind it move to the front
+                    m = self._ring_filled - self._ring_pos
+                    self.idx_block[: m * B].copy_(self.idx_block[self._ring_pos * B: self._ring_filled * B].clone())
                     self.cursor.zero_()
-                    self._ring_pos, self._ring_filled = 0, 1
+                    self._ring_pos, self._ring_filled = 0, m
                     continue
                 k = min(room, n_steps - done)
                 need = self._ring_pos + k + 1 - self._ring_filled
@@ -909,11 +915,20 @@ class SequentialEngine:
                 self._run_k(k)
                 self._ring_pos += k
                 done += k
+            if self._draw_ahead:
+                # The NEXT call's batches, drawn behind this call's launches: a call of the same size then starts with its graph
+                # launch (the draw and its copy were ~20 us of host time in front of it -- a twentieth of a 20-step call).  The slots
+                # lie behind everything the enqueued steps read; the copy is ordered behind them on the stream.
+                ahead = min(n_steps, 64, cap - 1 - self._ring_pos) + 1 - (self._ring_filled - self._ring_pos)
+                if ahead > 0 and self._ring_filled + ahead <= cap:
+                    self.idx_block[self._ring_filled * B: (self._ring_filled + ahead) * B].copy_(self.draw_index_block(ahead))
+                    self._ring_filled += ahead
         else:
-            # a caller's index block: written at the front of the block, the cursor reset, its first batch gathered.  A batch the
-            # shuffle stream had drawn ahead goes back to the stream.
+            # a caller's index block: written at the front of the block, the cursor reset, its first batch gathered.  The batches the
+            # shuffle stream had drawn ahead go back to the stream.
             if self._ring_filled > self._ring_pos:
-                self._pending = self.idx_block[self._ring_pos * B: (self._ring_pos + 1) * B].clone()
+                back = self.idx_block[self._ring_pos * B: self._ring_filled * B].clone()
+                self._pending = back if self._pending is None else torch.cat([back, self._pending])
             self._ring_pos = self._ring_filled = 0
             done = 0
             while done < n_steps:
@@ -943,6 +958,7 @@ class SequentialEngine:
                 self._step_body()
 
     _append_blocks = os.environ.get("EMX_APPEND_BLOCKS", "1") != "0"
+    _draw_ahead = os.environ.get("EMX_DRAW_AHEAD", "1") != "0"   # the next call's batches drawn behind this call's launches
     _ring_pos = 0        # batches of the index block consumed (= the device cursor)
     _ring_filled = 0     # batches of the index block that hold drawn indices
     _pending = None      # a batch drawn ahead of its use that went back to the stream
