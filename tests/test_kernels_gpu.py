@@ -546,6 +546,7 @@ def test_split_rows_reproduce_the_rows(L, B, Dd):
     # fast and general sigmoid, a row range, ragged tiles, D of one / four / eight chunks
     (700, 64, 9, (8.0, 12, 6, 1, 2, 6), 0, 700), (500, 32, 16, (5.0, 3, 6, 1, 2, 6), 200, 500), (1100, 128, 13, (16.0, 12, 6, 1, 2, 6), 0, 1100),
     (330, 256, 10, (22.0, 12, 6, 1, 2, 6), 0, 330),
+    (700, 128, 1, (16.0, 12, 6, 1, 2, 6), 0, 700), (260, 256, 1, (22.0, 12, 6, 1, 2, 6), 0, 260),     # a one-column latent (compile-time width)
     (1100, 128, 3, (16.0, 12, 6, 1, 2, 6), 0, 1100), (700, 256, 4, (22.0, 12, 6, 1, 2, 6), 0, 700), (900, 128, 4, (16.0, 12, 6, 1, 2, 6), 0, 900),   # 3 / 4 columns at compile time
     (8192, 32, 2, (8.0, 12, 6, 1, 2, 6), 0, 8192), (8300, 64, 2, (11.0, 12, 6, 1, 2, 6), 0, 8300), (8256, 40, 2, (9.0, 3, 6, 1, 2, 6), 0, 8256)])
 def test_sketchmap_on_split_rows(L, B, Dd, Ld, sig, rb, re):
