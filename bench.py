@@ -395,7 +395,43 @@ def launches_per_step(eng):
     return int(n1 - n0)
 
 
-def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0) -> bool:
+def agree_on_port(world: int, rank: int) -> int:
+    """a free port for the probe children's rendezvous, the SAME on every rank: rank 0 asks the kernel for one and the ranks learn it
+    over a short-lived gloo group (CPU only: nothing here touches a GPU; the launcher's MASTER_PORT carries that group, the RCCL
+    group is initialised later on the same store).  One rank: no exchange."""
+    if world <= 1:
+        return _free_port()
+    import torch.distributed as dist
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        box = [_free_port() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+    finally:
+        dist.destroy_process_group()
+    return int(box[0])
+
+
+def start_watchdog(seconds: float, what: str):
+    """Ranks started by a launcher directly (no self_launch above them to repeat the run): if ``what`` is not over after ``seconds``,
+    say so on stderr and leave with code 124 -- the launcher then ends the other ranks, and the caller sees a failure with a reason
+    instead of a hang (never a re-exec: this process has initialised its GPU).  Returns the function that calls the watchdog off."""
+    import threading
+
+    done = threading.Event()
+
+    def watch():
+        if not done.wait(seconds):
+            sys.stderr.write(f"bench.py: {what} did not finish within {seconds:.0f} s (EMX_BENCH_WATCHDOG); if the all-reduce captured in "
+                             "the step's graph is at fault, EMX_DP_GRAPH_ALLREDUCE=0 runs it eagerly\n")
+            sys.stderr.flush()
+            os._exit(124)
+
+    threading.Thread(target=watch, daemon=True).start()
+    return done.set
+
+
+def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0, port: int = 0) -> bool:
     """N >= 1 ranks over RCCL: one child process per rank checks, BEFORE this process touches the GPU, whether the step with its
     RCCL all-reduce(s) captured in a hipGraph works with this many ranks on this machine
     (encodermap_amd/_probe_graph_allreduce.py: a synthetic [scale, all-reduce, add] graph replayed 200 times against the host-side
@@ -406,7 +442,7 @@ def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 
     # the children rendezvous among themselves: nothing of the launcher's agent store (TORCHELASTIC_USE_AGENT_STORE makes
     # rank 0 a CLIENT of the launcher's store, which does not listen on the probe's port)
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
-    env["EMX_PROBE_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 173)
+    env["EMX_PROBE_PORT"] = str(port or _free_port())     # (agreed between the ranks: agree_on_port)
     env["EMX_PROBE_MODE"] = mode
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("RANK", "0")
@@ -491,13 +527,23 @@ def launch_check(args) -> int:
     forced_eager = os.environ.get("EMX_DP_GRAPH_ALLREDUCE") == "0"
     if os.environ.get("EMX_BENCH_FAIL_CAPTURED") == "1" and not forced_eager:
         return 3
+    # as main() does it: the probe's port over a short-lived gloo group, then the run's own group on the same store
+    port = agree_on_port(world, rank)
+    call_off = start_watchdog(float(os.environ.get("EMX_BENCH_WATCHDOG", "900")), f"the {world}-rank launch check")
+    if os.environ.get("EMX_BENCH_HANG") == "1":            # (test hook: a rank that never comes back -- the watchdog's case)
+        time.sleep(3600)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
+    lo, hi = torch.tensor([float(port)]), torch.tensor([float(port)])
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    call_off()
     if rank == 0:
         print("a stray line from a rank", flush=True)      # (must not reach the relayed stdout)
         print(json.dumps({"metric": "launch_check", "value": float(t), "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "config": {"ranks_seen": dist.get_world_size(), "allreduce": "eager (forced)" if forced_eager else "probe decides"}}),
+                          "config": {"ranks_seen": dist.get_world_size(), "allreduce": "eager (forced)" if forced_eager else "probe decides",
+                                     "probe_port_agreed": bool(float(lo) == float(hi) == float(port)) and port > 0}}),
               flush=True)
     dist.barrier()
     dist.destroy_process_group()
@@ -601,7 +647,7 @@ def main():
     probe = None
     graph_allreduce = False
     if multi and backend == "nccl" and os.environ.get("EMX_DP_GRAPH_ALLREDUCE") != "0":
-        probe = probe_graph_allreduce(world, dp_mode)
+        probe = probe_graph_allreduce(world, dp_mode, port=agree_on_port(world, rank))
         graph_allreduce = probe
     torch.cuda.set_device(device)
     import torch.distributed as dist
@@ -652,12 +698,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # (multi-rank runs: a hang -- of the captured all-reduce, of a rank that lost its peers -- ends as a failure with a reason)
+    call_off = start_watchdog(float(os.environ.get("EMX_BENCH_WATCHDOG", "900")), f"the {world}-rank training run") if multi else (lambda: None)
     eng.run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
     eng.run_steps(args.steps)
     barrier()
     dt = time.perf_counter() - t0
+    call_off()
     if multi:
         tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

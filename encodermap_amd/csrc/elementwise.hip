@@ -3,6 +3,7 @@
 // where the layout allows it, scalar losses use fixed-order two-pass sums (no float atomics).
 #include <mutex>
 #include <unordered_map>
+#include <vector>
 
 #include "emx_common.h"
 #include "cost.h"
@@ -55,8 +56,29 @@ int ensure_counters_zeroed(void* words, size_t bytes, hipStream_t stream, const 
 
 namespace emx {
 namespace {
-std::unordered_map<const void*, std::pair<unsigned*, size_t>> g_tickets;   // scratch address -> (library-owned block, bytes)
+// Ticket words of the split reductions (emx_sketchmap_tiles, kmode 3): library-owned device memory, one block per scratch address.
+// Blocks are never handed back to the runtime while the process lives (a launch in flight may still count in one); a block whose
+// scratch address was forgotten (emx_forget_counters) waits in the pool and is ZEROED AGAIN, in stream order, for its next owner.
+std::unordered_map<const void*, std::pair<unsigned*, size_t>> g_tickets;   // scratch address -> (block, bytes)
+std::vector<std::pair<unsigned*, size_t>> g_ticket_pool;                   // blocks without an owner
+constexpr size_t MAX_TICKET_OWNERS = 4096;   // beyond that many live scratch addresses every block goes back to the pool (a memset each)
+
+void retire_tickets_locked(const void* scratch) {
+  if (scratch == nullptr) {
+    for (auto& kv : g_tickets) g_ticket_pool.push_back(kv.second);
+    g_tickets.clear();
+    return;
+  }
+  auto it = g_tickets.find(scratch);
+  if (it == g_tickets.end()) return;
+  g_ticket_pool.push_back(it->second);
+  g_tickets.erase(it);
 }
+}  // namespace
+
+// The ticket block of `scratch`.  First sight of an address (per process, or after emx_forget_counters): a block is taken from the
+// pool -- or allocated with hipMalloc, which is why first sight must not happen inside a stream capture, and should not while
+// ANOTHER thread captures in global mode (hipMalloc is not a capturable call) -- and zeroed on `stream` in front of the launch.
 unsigned* owned_tickets(const void* scratch, size_t bytes, hipStream_t stream, const char* who, int* rc) {
   *rc = EMX_OK;
   std::lock_guard<std::mutex> lock(g_counters_mu);
@@ -69,13 +91,36 @@ unsigned* owned_tickets(const void* scratch, size_t bytes, hipStream_t stream, c
                "capture first (a warm-up step): its ticket words are allocated at first sight", who, scratch);
     return nullptr;
   }
+  if (it != g_tickets.end()) retire_tickets_locked(scratch);            // (too small for this call: back to the pool)
+  if (g_tickets.size() >= MAX_TICKET_OWNERS) retire_tickets_locked(nullptr);
   unsigned* block = nullptr;
-  if (hipMalloc(reinterpret_cast<void**>(&block), bytes) != hipSuccess || hipMemsetAsync(block, 0, bytes, stream) != hipSuccess) {
+  size_t have = 0;
+  for (size_t i = 0; i < g_ticket_pool.size(); ++i)
+    if (g_ticket_pool[i].second >= bytes && (block == nullptr || g_ticket_pool[i].second < have)) {   // smallest block that fits
+      block = g_ticket_pool[i].first;
+      have = g_ticket_pool[i].second;
+    }
+  if (block != nullptr) {
+    for (size_t i = 0; i < g_ticket_pool.size(); ++i)
+      if (g_ticket_pool[i].first == block) {
+        g_ticket_pool.erase(g_ticket_pool.begin() + (long)i);
+        break;
+      }
+  } else {
+    have = bytes;
+    if (hipMalloc(reinterpret_cast<void**>(&block), bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      *rc = fail(EMX_EWORKSPACE, "%s: could not allocate %zu bytes of ticket words", who, bytes);
+      return nullptr;
+    }
+  }
+  if (hipMemsetAsync(block, 0, have, stream) != hipSuccess) {
     (void)hipGetLastError();
-    *rc = fail(EMX_EWORKSPACE, "%s: could not allocate %zu bytes of ticket words", who, bytes);
+    g_ticket_pool.emplace_back(block, have);
+    *rc = fail(EMX_EWORKSPACE, "%s: could not zero %zu bytes of ticket words", who, have);
     return nullptr;
   }
-  g_tickets[scratch] = std::make_pair(block, bytes);   // (an older, smaller block of this address stays allocated: a launch may still use it)
+  g_tickets[scratch] = std::make_pair(block, have);
   return block;
 }
 }  // namespace emx
@@ -84,6 +129,7 @@ extern "C" void emx_forget_counters(void* words) {
   std::lock_guard<std::mutex> lock(emx::g_counters_mu);
   if (words == nullptr) emx::g_counters_seen.clear();
   else emx::g_counters_seen.erase(words);
+  emx::retire_tickets_locked(words);   // (a scratch buffer's ticket block: zeroed again at the address's next sight)
 }
 
 namespace {

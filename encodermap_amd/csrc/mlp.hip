@@ -33,6 +33,7 @@
 // Lane maps (cdna_hip_programming.md section 3; checked with integer data by tests/test_mlp_gpu.py):
 //   16x16x32: A[m = lane & 15][k = 8 (lane >> 4) + e], B[k][n = lane & 15], D[row = 4 (lane >> 4) + reg][col = lane & 15];
 //   the k labels inside a K-step are free as long as A and B agree -- here kk(g, e) = 4 g + e (e < 4), 16 + 4 g + e - 4.
+#include <atomic>
 #include "adc_head.h"
 #include "aop.h"
 #include "cost.h"
@@ -2508,6 +2509,7 @@ struct TilesHost {
 };
 
 int device_cus();
+int current_device();
 
 template <bool FAST, int NCH, int KIND, bool SMALL>
 int launch_chain_tiles_impl(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
@@ -2521,12 +2523,13 @@ int launch_chain_tiles_impl(ChainBuilder& b, const emx::sk::TileRole& tr, int gr
   {
     static thread_local const void* cached_fn = nullptr;
     static thread_local size_t cached_lds = 0;
-    static thread_local int cached_blocks = 0;
+    static thread_local int cached_blocks = 0, cached_dev = -1;
     const void* fn = reinterpret_cast<const void*>(&chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>);
-    if (cached_fn != fn || cached_lds != lds) {
+    const int dev = current_device();
+    if (cached_fn != fn || cached_lds != lds || cached_dev != dev) {
       int nb = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, chain_tiles_kernel<2, FAST, NCH, KIND, SMALL>, NTC, lds) != hipSuccess) nb = 0;
-      cached_fn = fn, cached_lds = lds, cached_blocks = nb;
+      cached_fn = fn, cached_lds = lds, cached_blocks = nb, cached_dev = dev;
     }
     const long capacity = (long)cached_blocks * device_cus();
     if ((long)tr.n_chain + 1 > capacity)
@@ -2668,7 +2671,8 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   tr.join = tiles->latent ? 1 : 0;
   // persistent tile workgroups: one per CU beside its chain workgroup (more would wait for the chain workgroups to leave), each
   // walking its share of the tile pairs -- in the XCD-aware order 32 per XCD list (pairs k, k + 32, ... of the list)
-  static const int per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : std::max(1, device_cus() / 8);
+  static const int forced_per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : 0;
+  const int per_xcd = forced_per_xcd ? forced_per_xcd : std::max(1, device_cus() / 8);
   if (tr.a.xcd_nbg > 0) tr.n_tile_wgs = 8 * std::min(per_xcd, tr.a.xcd_nbg * (tr.a.xcd_nbg + 1) / 2);
   else tr.n_tile_wgs = std::min(8 * per_xcd, (vblocks + 1) / 2);
   const size_t lds = std::max((size_t)b.lds, (size_t)emx::sk::TILE_ROLE_LDS_BYTES);
@@ -2823,13 +2827,31 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 
 
 namespace {
+// compute units of the CURRENT device (a process may drive several devices, or partitions of one: the answer is kept per device
+// ordinal, not per process)
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) {
+    (void)hipGetLastError();
+    dev = 0;
+  }
+  return dev;
+}
 int device_cus() {
-  static int n = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+  constexpr int MAXDEV = 64;
+  static std::atomic<int> cus[MAXDEV];   // 0: not asked yet
+  const int dev = current_device();
+  if (dev < 0 || dev >= MAXDEV) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
     return v;
-  }();
-  return n;
+  }
+  int v = cus[dev].load(std::memory_order_relaxed);
+  if (v == 0) {
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+    cus[dev].store(v, std::memory_order_relaxed);
+  }
+  return v;
 }
 }  // namespace
 

@@ -721,8 +721,9 @@ class SequentialEngine:
         self._graph_multi = None
         self._graph_wrap = None
         # the capture replays its largest graph once (below): up to _graph_steps steps from the current position, restored afterwards.
-        # Those replays WRITE history rows and READ the index block that far ahead -- make both exist: room in the history, and
-        # valid row indices in the part of the index block this call has not filled (a smaller training set after set_data)
+        # Those replays WRITE history rows and READ the index block that far ahead -- make both exist: room in the history here; the
+        # index block ends in _block_slack() zeroed slots (run_steps) and is zeroed by set_data, so whatever lies ahead of the cursor
+        # is a valid row of the current training set, wherever in the block the cursor stands
         ahead = max(self._multi_sizes(), default=1) + 2
         if int(self.hstep_host()) + ahead > self.history_capacity:
             self._grow_history(int(self.hstep_host()) + ahead)
@@ -881,8 +882,12 @@ class SequentialEngine:
             if lo < 0 or hi >= self.data.shape[0]:
                 raise ValueError(f"index block holds rows in [{lo}, {hi}], the data set has {self.data.shape[0]} rows")
         cap = self._block_capacity()
-        if self.idx_block is None or self.idx_block.numel() < cap * self.B:
-            self.idx_block = torch.zeros(cap * self.B, dtype=torch.int64, device=self.device)
+        # ``cap`` slots take batches; behind them lie zeroed slack slots (row 0: always a valid row) that nothing ever fills: a capture
+        # warms up and replays its largest graph from WHEREVER the cursor stands (_capture: up to _graph_steps + 2 batches ahead of it,
+        # each launch gathering one batch further), also two slots in front of the end of the block (a history grown at that point)
+        slots = cap + self._block_slack()
+        if self.idx_block is None or self.idx_block.numel() < slots * self.B:
+            self.idx_block = torch.zeros(slots * self.B, dtype=torch.int64, device=self.device)
             self._graph = None
             self._ring_pos = self._ring_filled = 0
         B = self.B
@@ -965,6 +970,10 @@ class SequentialEngine:
 
     def _block_capacity(self) -> int:
         return 1024
+
+    def _block_slack(self) -> int:
+        """zeroed slots behind the index block's capacity (see run_steps): what a capture's warm replays may read ahead of the cursor"""
+        return max(self._multi_sizes(), default=1) + 4
 
     _hstep_host = 0
 

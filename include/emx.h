@@ -61,7 +61,13 @@ int64_t emx_launch_count(void);
  * graph node and clear the give-up flag on every replay) -- run the call once eagerly first, as a warm-up step does.  The note is
  * by ADDRESS: a caller that frees such memory and gets the same address back from its allocator (or recycles it for something
  * else) must hand it over zeroed -- allocate these few words zeroed, as you would a lock -- or call emx_forget_counters(ptr)
- * (NULL: forget all), after which the next call zeroes it again. */
+ * (NULL: forget all), after which the next call zeroes it again.
+ * The same call releases what the library keeps PER SCRATCH ADDRESS: the ticket words of the one-launch split reduction
+ * (emx_sketchmap_tiles) live in library-owned device memory, one small block per workspace address, allocated with hipMalloc at the
+ * address's first sight -- hence not inside a capture either, and not while another thread captures in global mode.
+ * emx_forget_counters(workspace) hands that block back to the library's pool; the next call with the address gets a block zeroed
+ * anew.  Call it when a workspace is freed, and after a launch was ABORTED (device reset, a give-up) with tickets taken: that is
+ * how a caller re-zeroes them. */
 void emx_forget_counters(void* words);
 
 /* ------------------------------------------------------------------------------------------------ *

@@ -403,6 +403,19 @@ def test_short_calls_equal_one_long_call(em):
     d.run_steps(13, torch.from_numpy(np.concatenate([own[:5], inj, own[5:]]).reshape(-1)).cuda())
     np.testing.assert_array_equal(c.losses(), d.losses())
     np.testing.assert_array_equal(c.w.cpu().numpy(), d.w.cpu().numpy())
+    # (c) a NEW capture two slots in front of the end of the index block (the history outgrown there): the capture's warm replays
+    # run 32 + 2 batches ahead of the cursor -- into the zeroed slack slots behind the block's capacity, never past its end -- and
+    # leave no trace: the run equals the one call of (a) bit for bit
+    e = engine(1130)
+    cap = e._block_capacity()
+    e.run_steps(cap - 3)
+    assert e._ring_pos == cap - 3 and e.idx_block.numel() == (cap + e._block_slack()) * e.B
+    e._grow_history(e.history_capacity + 1)          # (drops the graphs: captured pointers are stale)
+    assert e._graph is None
+    e.run_steps(1130 - (cap - 3))
+    np.testing.assert_array_equal(a.losses(), e.losses())
+    np.testing.assert_array_equal(a.w.cpu().numpy(), e.w.cpu().numpy())
+    assert int(e.idx_block[cap * e.B:].abs().max()) == 0
 
 
 def _golden_module():

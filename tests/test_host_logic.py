@@ -363,7 +363,20 @@ def test_bench_launches_its_own_ranks(tmp_path):
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 3 and line["value"] == 3.0
     assert line["config"]["ranks_seen"] == 2 and line["config"]["allreduce"] == "probe decides"
+    assert line["config"]["probe_port_agreed"] is True      # (rank 0's free port, learnt by every rank over a short-lived gloo group)
     assert "a stray line from a rank" in r.stderr          # (relayed, but not on stdout)
+    # the ranks under the launcher DIRECTLY (the driver's form for N > 1), one of them never coming back: the watchdog ends the run
+    # with a reason and a non-zero code instead of a hang
+    import socket
+
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], cwd=str(tmp_path),
+                       env=dict(env, EMX_BENCH_HANG="1", EMX_BENCH_WATCHDOG="3"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "did not finish within 3 s" in r.stderr and '"metric"' not in r.stdout
     # first attempt fails on every rank -> second attempt with the eager all-reduce forced
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launch-check"], cwd=str(tmp_path),
                        env=dict(env, EMX_BENCH_FAIL_CAPTURED="1"), capture_output=True, text=True, timeout=300)
