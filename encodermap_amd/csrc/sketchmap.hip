@@ -901,6 +901,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 :
   const float2* nr_b = nr_s + ib;
   const float* zi_b = zi_s + ib * LMAX;
   float* rp_b = rpart + ib * LMAX * RP + (jl >> 2);
+  constexpr bool ROWS4 = LMAX <= 3;
+  float vrow[4][LMAX];
   auto pair = [&](int r, bool masked) {
     const int ro = (r & 3) + 8 * (r >> 2);
     float dz[LMAX];
@@ -925,19 +927,49 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 :
     for (int l = 0; l < LMAX; ++l) {
       float v = g * dz[l];
       gj[l] -= v;
-      // four neighbouring columns pre-reduced in registers: DPP quad permutations (lane ^ 1, lane ^ 2), not LDS
-      // bpermutes; the four lanes of a quad then hold the same sum and all store it to the same word -- no exec mask, no branch
-      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
-      v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
-      rp_b[(ro * LMAX + l) * RP] = v;
+      if constexpr (ROWS4) {
+        vrow[r & 3][l] = v;
+      } else {   // (four latent columns: the grouped form costs the kernel a resident tile per CU -- every pair reduced and stored by itself,
+                 //  the four lanes of a quad hold the same sum and all store it to the same word)
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+        v += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+        rp_b[(ro * LMAX + l) * RP] = v;
+      }
+    }
+  };
+  // Row sums: four neighbouring columns are pre-reduced in registers by DPP quad permutations (lane ^ 1, lane ^ 2), not LDS
+  // bpermutes.  The four pairs r = 4 q4 .. 4 q4 + 3 of a lane are four CONSECUTIVE rows: the quad reduces them as a transposing
+  // butterfly -- lane q of the quad ends with the quad's sum for row q (the same additions in the same association as reducing each
+  // pair by itself: (own pair of lanes) + (the other pair)) -- and ONE store per four pairs and latent column leaves the wave
+  // instead of four (a 4-byte LDS store costs the LDS pipe four cycles whatever it carries).
+  const bool odd1 = (lr & 1) != 0, odd2 = (lr & 2) != 0;
+  float* rp_q = rp_b + (lr & 3) * LMAX * RP;
+  auto rows4 = [&](int q4) __attribute__((always_inline)) {
+    if constexpr (!ROWS4) return;
+#pragma unroll
+    for (int l = 0; l < LMAX; ++l) {
+      const float v0 = vrow[0][l], v1 = vrow[1][l], v2 = vrow[2][l], v3 = vrow[3][l];
+      const float s01 = odd1 ? v1 : v0, o01 = odd1 ? v0 : v1, s23 = odd1 ? v3 : v2, o23 = odd1 ? v2 : v3;
+      const float a2 = s01 + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, o01), 0xB1, 0xF, 0xF, true));
+      const float b2 = s23 + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, o23), 0xB1, 0xF, 0xF, true));
+      const float s4 = odd2 ? b2 : a2, o4 = odd2 ? a2 : b2;
+      rp_q[(8 * q4 * LMAX + l) * RP] = s4 + __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, o4), 0x4E, 0xF, 0xF, true));
     }
   };
   if (edge) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pair(r, true);
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+      for (int r = 4 * q4; r < 4 * q4 + 4; ++r) pair(r, true);
+      rows4(q4);
+    }
   } else {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) pair(r, false);
+    for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+      for (int r = 4 * q4; r < 4 * q4 + 4; ++r) pair(r, false);
+      rows4(q4);
+    }
   }
   if (offdiag) {
 #pragma unroll
