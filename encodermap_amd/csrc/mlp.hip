@@ -2153,6 +2153,8 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_reduce_kernel(const float* __res
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
+#include "wide.h"
+
 int check_desc(const emx_mlp_desc* desc, const char* who) {
   EMX_REQUIRE(desc, "%s: null descriptor", who);
   EMX_REQUIRE(desc->n_layers >= 1 && desc->n_layers <= MAXL, "%s: %d layers not supported (1..%d)", who, desc->n_layers, MAXL);
@@ -2171,6 +2173,15 @@ int set_lds(const void* fn, size_t bytes, const char* who, size_t static_bytes =
     if (e != hipSuccess) return emx::fail(EMX_ELAUNCH, "%s: cannot reserve %zu bytes of LDS: %s", who, bytes, hipGetErrorString(e));
   }
   return EMX_OK;
+}
+
+template <bool BWD>
+int launch_wide(const WideArgs& a, hipStream_t st, const char* who) {
+  const int rc = set_lds(reinterpret_cast<const void*>(&wide_layer_kernel<BWD>), WIDE_LDS, who, 0);
+  if (rc) return rc;
+  const int grid = (a.row_end - a.row0 + R - 1) / R;
+  hipLaunchKernelGGL((wide_layer_kernel<BWD>), dim3(grid), dim3(NTC), WIDE_LDS, st, a);
+  return emx::check_launch(BWD ? "wide-layer kernel (backward)" : "wide-layer kernel (forward)");
 }
 
 // Builds the launch description: LDS allocation (two ping-pong images sized per parity, float32 copies, side buffers) and
@@ -2347,17 +2358,19 @@ size_t emx_mlp_aop_bytes(const emx_mlp_desc* desc, int n_rows) {
 
 int emx_mlp_row_blocks(int n_rows) { return std::max((n_rows + R - 1) / R, 1); }
 
-int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
-                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, void* aop, int aop_rows,
-                         emx_stream_t stream) {
+}  // extern "C"
+
+namespace {
+constexpr size_t CHAIN_LDS_STATIC = 1280;   // the chain kernels' static exchange areas (set_lds)
+inline bool chain_lds_fits(size_t dynamic_bytes) { return dynamic_bytes + CHAIN_LDS_STATIC <= 160 * 1024; }
+
+// Layers [layer_begin, layer_end) as ONE launch of the row-block chain kernel.  dry_run: nothing is launched; EMX_OK if the
+// range's LDS images fit, EMX_EUNSUPPORTED (no message) if not -- how the segmented passes below cut a range into launches.
+int forward_chain(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                  int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, void* aop, int aop_rows,
+                  emx_stream_t stream, bool dry_run) {
   const char* who = "emx_mlp_forward";
-  int rc = check_desc(desc, who);
-  if (rc) return rc;
-  EMX_REQUIRE(params && mirror && h && in, "%s: null pointer argument", who);
-  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "%s: bad layer range", who);
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "%s: bad rows / stride", who);
-  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
-  if (rc) return rc;
+  int rc;
   ChainBuilder b(desc, mirror, who);
   AopLayout AL;
   if (aop) aop_layout(desc, aop_rows, AL);
@@ -2405,7 +2418,83 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   a.in_aop = (aop && layer_begin == 0) ? aop_tensor(aop, AL, 0) : AopTensor{nullptr, nullptr, 0};
   a.row0 = row_begin;
   a.row_end = row_end;
+  if (dry_run) return chain_lds_fits((size_t)b.lds) ? EMX_OK : EMX_EUNSUPPORTED;
   return launch_chain<CHAIN_FWD>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (forward)");
+}
+
+// A forward range with a layer whose source rows do not fit the LDS images: cut into the longest runs of layers the chain kernel
+// takes in one launch, and single layers through the streaming kernel (wide.h) where not even one layer fits.  The float32 rows
+// h[l] hand a segment's result to the next one (they must be kept); every segment leaves the weight-gradient fragments of its last
+// layer, the first one those of the range's input -- as the one launch would.
+int forward_segmented(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in, int ld_in,
+                      int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream) {
+  const char* who = "emx_mlp_forward";
+  WopArgs wa;
+  fill_wop_args(desc, wa);
+  const char* wop = reinterpret_cast<const char*>(mirror);
+  AopLayout AL;
+  if (aop) aop_layout(desc, aop_rows, AL);
+  const float* cur = in;
+  int ld = ld_in;
+  int l = layer_begin;
+  while (l < layer_end) {
+    int m = layer_end;
+    while (m > l && forward_chain(desc, params, mirror, l, m, cur, ld, row_begin, row_end, h, nullptr, aop, aop_rows, stream, true) != EMX_OK) --m;
+    if (m > l) {
+      const int rc = forward_chain(desc, params, mirror, l, m, cur, ld, row_begin, row_end, h, nullptr, aop, aop_rows, stream, false);
+      if (rc) return rc;
+    } else {
+      m = l + 1;
+      WideArgs w{};
+      w.src = cur;
+      w.ld_src = ld;
+      w.K = desc->width[l];
+      w.src_aop = (aop && l == 0) ? aop_tensor(aop, AL, 0) : AopTensor{nullptr, nullptr, 0};
+      w.units = wop + wa.units_begin + wa.fwd_unit[l] * WOP_UNIT;
+      w.ws = reinterpret_cast<const float*>(wop + (long)l * sizeof(WopHeader));
+      w.P = groups128(desc->width[l + 1]);
+      w.C = groups128(desc->width[l]);
+      w.N = desc->width[l + 1];
+      w.bias = params + desc->b_off[l];
+      w.act = desc->act[l];
+      w.out = h[l];
+      w.ld_out = desc->width[l + 1];
+      // the fragments of h_l are the X operand of layer l + 1's weight gradient: not needed behind the network's last layer
+      w.out_aop = (aop && l + 1 < desc->n_layers) ? aop_tensor(aop, AL, 1 + l) : AopTensor{nullptr, nullptr, 0};
+      w.row0 = row_begin;
+      w.row_end = row_end;
+      const int rc = launch_wide<false>(w, (hipStream_t)stream, who);
+      if (rc) return rc;
+    }
+    if (m < layer_end && h[m - 1] == nullptr)
+      return emx::fail(EMX_EUNSUPPORTED, "%s: a layer range this wide runs as several launches, which hand the float32 rows of the layers between them "
+                       "on: this plan does not keep h[%d]", who, m - 1);
+    cur = h[m - 1];
+    ld = desc->width[m];
+    l = m;
+  }
+  return EMX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
+                         int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, void* aop, int aop_rows,
+                         emx_stream_t stream) {
+  const char* who = "emx_mlp_forward";
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  EMX_REQUIRE(params && mirror && h && in, "%s: null pointer argument", who);
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "%s: bad layer range", who);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_in >= desc->width[layer_begin], "%s: bad rows / stride", who);
+  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
+  if (rc) return rc;
+  // the whole range in one launch where its LDS images fit; with the auto cost aboard only so (EMX_EUNSUPPORTED tells the caller
+  // to run the cost as a kernel of its own behind the plain forward pass); a range too wide for one launch: in segments
+  rc = forward_chain(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, aop, aop_rows, stream, false);
+  if (rc != EMX_EUNSUPPORTED || cost) return rc;      // (EMX_EUNSUPPORTED is decided in front of the launch: nothing has been issued)
+  return forward_segmented(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, aop, aop_rows, stream);
 }
 
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
@@ -2413,18 +2502,16 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror
   return emx_mlp_forward_cost(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, nullptr, aop, aop_rows, stream);
 }
 
-int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
-                     int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin,
-                     int row_end, float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream) {
+}  // extern "C"
+
+namespace {
+// Layers [layer_begin, layer_end) backward as ONE launch of the row-block chain kernel (dry_run: as forward_chain).
+int backward_chain(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
+                   int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin,
+                   int row_end, float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream, bool dry_run, bool lean = false) {
+  // lean (the segments of backward_segmented): no LDS image is set aside for a result that has none -- dh below the range leaves
+  // through `dbelow` only.  The one-launch path keeps its layout (and with it the builds its launches select).
   const char* who = "emx_mlp_backward";
-  int rc = check_desc(desc, who);
-  if (rc) return rc;
-  EMX_REQUIRE(params && mirror && dtop && h && delta, "%s: null pointer argument", who);
-  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "%s: bad layer range", who);
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "%s: bad rows / stride", who);
-  EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "%s: layer_add outside the layer range", who);
-  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
-  if (rc) return rc;
   ChainBuilder b(desc, mirror, who);
   ChainArgs& a = b.a;
   AopLayout AL;
@@ -2447,7 +2534,8 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   // boundary j = 0 is the top (width[layer_end]); GEMM of layer l: delta_l W_l^T -> dh_{l-1} -> delta_{l-1} (or dbelow)
   const int lo = dbelow ? layer_begin : layer_begin + 1;
   b.need(0, desc->width[layer_end]);
-  for (int l = top; l >= lo; --l) b.need((top - l + 1) & 1, desc->width[l]);
+  for (int l = top; l >= lo; --l)
+    if (!(lean && l == layer_begin)) b.need((top - l + 1) & 1, desc->width[l]);
   b.layout_images();
   for (int l = top; l >= lo; --l) {
     const int Kin = desc->width[l];
@@ -2485,7 +2573,109 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   a.in_aop = dop(top);
   a.row0 = row_begin;
   a.row_end = row_end;
+  if (dry_run) return chain_lds_fits((size_t)b.lds) ? EMX_OK : EMX_EUNSUPPORTED;
   return launch_chain<CHAIN_BWD>(b, row_begin, row_end, (size_t)b.lds, (hipStream_t)stream, "mlp chain kernel (backward)");
+}
+
+// A backward range whose top (or an inner boundary) is too wide for the LDS images: from the top down, the longest runs of layers
+// the chain kernel takes in one launch, and single layers through the streaming kernel (wide.h).  Between two segments the raw
+// d loss / d h of the boundary layer travels in that layer's delta rows (they must be kept): the upper segment leaves it there as
+// its `dbelow`, the lower one takes it as its `dtop` and overwrites it, element by element, with delta = dh * act'(h) [+ join].
+int backward_segmented(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop, int ld_top,
+                       const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin, int row_end,
+                       float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream) {
+  const char* who = "emx_mlp_backward";
+  WopArgs wa;
+  fill_wop_args(desc, wa);
+  const char* wop = reinterpret_cast<const char*>(mirror);
+  AopLayout AL;
+  if (aop) aop_layout(desc, aop_rows, AL);
+  const int n = desc->n_layers;
+  const bool join = dadd || latent;
+  const float* cur = dtop;
+  int ld = ld_top;
+  int top_end = layer_end;                    // the segment in hand ends here (exclusive); cur = d loss / d h_{top_end - 1}
+  while (top_end > layer_begin) {
+    // the hand-over below a segment that starts at layer m > layer_begin: dh of layer m - 1, in delta[m - 1]
+    auto below = [&](int m) -> float* { return m == layer_begin ? dbelow : delta[m - 1]; };
+    auto seg_join = [&](int m) { return join && layer_add >= m && layer_add < top_end; };
+    int m = layer_begin;
+    bool no_room = false;
+    for (; m < top_end; ++m) {
+      if (m > layer_begin && delta[m - 1] == nullptr) {   // (no room for the hand-over at this boundary)
+        no_room = true;
+        continue;
+      }
+      const bool sj = seg_join(m);
+      if (backward_chain(desc, params, mirror, m, top_end, cur, ld, sj ? dadd : nullptr, sj ? layer_add : 0, sj ? latent : nullptr, below(m), row_begin,
+                         row_end, h, delta, aop, aop_rows, stream, true, true) == EMX_OK)
+        break;
+    }
+    if (m < top_end) {
+      const bool sj = seg_join(m);
+      const int rc = backward_chain(desc, params, mirror, m, top_end, cur, ld, sj ? dadd : nullptr, sj ? layer_add : 0, sj ? latent : nullptr, below(m),
+                                    row_begin, row_end, h, delta, aop, aop_rows, stream, false, true);
+      if (rc) return rc;
+    } else {
+      // not even the top layer alone: its source delta_top = dtop * act'(h_top) is streamed
+      const int top = top_end - 1;
+      m = top;
+      float* out = below(top);
+      if (no_room || (top > layer_begin && out == nullptr))
+        return emx::fail(EMX_EUNSUPPORTED, "%s: a layer range this wide runs as several launches, which hand d loss / d h on in the delta rows of "
+                         "the layers between them: this plan keeps none (delta[%d] is null)", who, top - 1);
+      EMX_REQUIRE(!(join && layer_add == top), "%s: rows cannot be joined into a layer %d columns wide (the streaming kernel takes none)", who,
+                  desc->width[top + 1]);
+      EMX_REQUIRE(!desc->act[top] || h[top], "%s: activations of layer %d are needed for its derivative", who, top);
+      WideArgs w{};
+      w.src = cur;
+      w.ld_src = ld;
+      w.K = desc->width[top + 1];
+      w.src_h = desc->act[top] ? h[top] : nullptr;
+      w.src_act = desc->act[top];
+      w.src_out = delta[top];
+      w.src_aop = aop ? aop_tensor(aop, AL, 1 + n + top) : AopTensor{nullptr, nullptr, 0};
+      w.units = wop + wa.units_begin + wa.bwd_unit[top] * WOP_UNIT;
+      w.ws = reinterpret_cast<const float*>(wop + (long)top * sizeof(WopHeader));
+      w.P = groups128(desc->width[top]);
+      w.C = groups128(desc->width[top + 1]);
+      w.N = out ? desc->width[top] : 0;
+      w.out = out;
+      w.ld_out = desc->width[top];
+      w.row0 = row_begin;
+      w.row_end = row_end;
+      const int rc = launch_wide<true>(w, (hipStream_t)stream, who);
+      if (rc) return rc;
+    }
+    if (m > layer_begin) {
+      cur = delta[m - 1];
+      ld = desc->width[m];
+    }
+    top_end = m;
+  }
+  return EMX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop,
+                     int ld_top, const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin,
+                     int row_end, float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream) {
+  const char* who = "emx_mlp_backward";
+  int rc = check_desc(desc, who);
+  if (rc) return rc;
+  EMX_REQUIRE(params && mirror && dtop && h && delta, "%s: null pointer argument", who);
+  EMX_REQUIRE(0 <= layer_begin && layer_begin < layer_end && layer_end <= desc->n_layers, "%s: bad layer range", who);
+  EMX_REQUIRE(0 <= row_begin && row_begin < row_end && ld_top >= desc->width[layer_end], "%s: bad rows / stride", who);
+  EMX_REQUIRE((!dadd && !latent) || (layer_add >= layer_begin && layer_add < layer_end), "%s: layer_add outside the layer range", who);
+  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
+  if (rc) return rc;
+  rc = backward_chain(desc, params, mirror, layer_begin, layer_end, dtop, ld_top, dadd, layer_add, latent, dbelow, row_begin, row_end, h, delta, aop, aop_rows,
+                      stream, false);
+  if (rc != EMX_EUNSUPPORTED) return rc;              // (decided in front of the launch: nothing has been issued)
+  return backward_segmented(desc, params, mirror, layer_begin, layer_end, dtop, ld_top, dadd, layer_add, latent, dbelow, row_begin, row_end, h, delta, aop,
+                            aop_rows, stream);
 }
 
 }  // extern "C"

@@ -584,12 +584,20 @@ class SequentialEngine:
             self._wgrad()
             return
         pb = self.plan_lean if self._lean else self.plan      # (the encoder's deltas leave as fragments only)
-        if self._dealt():
-            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
-        elif self._use_sketchmap():
-            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
-        else:
-            _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        try:
+            if self._dealt():
+                _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+            elif self._use_sketchmap():
+                _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, None, lay.n_enc - 1, self.rb, self.re, latent=self._sk.grad)
+            else:
+                _lib.mlp_backward(pb, 0, lay.n_enc, self.dlat, self.dZ, lay.n_enc - 1, self.rb, self.re)
+        except _lib.EmxError as exc:
+            if not exc.unsupported or pb is self.plan:
+                raise
+            # layers too wide for one launch run as segments that hand their float32 rows on in HBM (csrc/wide.h): the plan that
+            # keeps them, from now on
+            self._lean = False
+            return self._step_pre_b()
         self._wgrad()
 
     def _local_fits(self) -> bool:

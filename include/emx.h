@@ -404,7 +404,15 @@ size_t emx_mlp_aop_bytes(const emx_mlp_desc* desc, int n_rows);
  * h[l] (and delta[l] of the backward launches below) are tables of row pointers, one per layer of the description: a NULL entry is a
  * tensor the caller does not keep -- its float32 rows are not written (the launch still forms them on chip and leaves their
  * fragments in `aop`).  Entries a launch READS must be there: emx_mlp_backward needs h[l] of every layer with an activation in its
- * range, the inference result is h[layer_end - 1]. */
+ * range, the inference result is h[layer_end - 1].
+ * Layer widths.  The row-block kernels keep a layer's source rows on chip (LDS), which bounds a layer they run in ONE launch to
+ * ~2400 source columns.  The reference has no such bound (models/models.py:3133-3160: Dense layers of any width): a range beyond it
+ * runs, behind these same two entry points, as SEGMENTS -- the longest runs of layers one launch takes, and single layers whose
+ * source is streamed (csrc/wide.h) -- with the same arithmetic and the same fragments left in `aop`.  Between two segments the
+ * float32 rows travel through HBM: h[l] of the layers at the cuts (forward), delta[l] of the layers below the cuts (backward: the
+ * upper segment leaves d loss / d h there, the lower one overwrites it with delta) must then be kept -- EMX_EUNSUPPORTED names the
+ * missing one, and a caller whose plan drops rows (NULL entries) falls back to the plan that keeps them.  The launches that merge
+ * passes (emx_mlp_forward_cost with a cost, emx_mlp_forward_backward*) answer EMX_EUNSUPPORTED for such a network. */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream);
 /* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch

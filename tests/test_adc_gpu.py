@@ -41,6 +41,10 @@ CASES = [
     # fourteen Dense layers (the reference stacks any number, models/models.py:3133-3160): windows of <= 12 layers in separate launches
     ("fourteen_layers", dict(use_backbone_angles=True, n_neurons=[48, 40, 32, 24, 16, 12, 2],
                              activation_functions=["", "tanh", "tanh", "tanh", "tanh", "tanh", "tanh", ""]), 8, 0, 64),
+    # a 410-residue backbone: 1227 dihedrals enter and leave the network 2454 columns wide -- beyond the LDS images of the row-block
+    # kernels, so the network's ends run through the streaming kernel (csrc/wide.h); teacher-forced like the 228-atom chain
+    ("wide_protein", dict(cartesian_pwd_start=1, cartesian_pwd_step=3, cartesian_dist_sig_parameters=(40.0, 10, 5, 1, 2, 5),
+                          dihedral_cost_reference=0.7, cartesian_cost_reference=3.0), 410, 0, 16),
 ]
 
 
@@ -48,7 +52,7 @@ CASES = [
 def test_adc_loss_trajectory(em, name, kw, n_res, n_side, B):
     rng = np.random.default_rng(n_res)
     data = R.synthetic_backbone(rng, 700, n_res, n_side)
-    n_steps = 6
+    n_steps = 3 if name == "wide_protein" else 6      # (the float64 oracle of a 1230-atom chain costs ~8 s per step)
     p = em.ADCParameters(n_steps=n_steps, batch_size=B, **kw)
     A = 3 * n_res
     net_dim = 2 * ((A - 2 if p.use_backbone_angles else 0) + (A - 3) + (n_side if p.use_sidechains else 0))
@@ -56,7 +60,7 @@ def test_adc_loss_trajectory(em, name, kw, n_res, n_side, B):
     e = em.AngleDihedralCartesianEncoderMap(data, p, model=[w.copy() for w in w0], read_only=True)
     idx = rng.integers(0, 700, (n_steps, B))
     model = R.ADCOracle(A, n_side, p.to_dict(), w0)
-    if name != "c3b_shape":
+    if name not in ("c3b_shape", "wide_protein"):
         e._engine.run_steps(n_steps, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
         got = e._engine.losses().astype(np.float64)
         terms = e._engine.loss_terms()

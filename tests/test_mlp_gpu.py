@@ -52,6 +52,11 @@ CASES = [
     (40, [32, 2], ["", "tanh", ""], 9000),     # more than 32 x 128 rows: the weight-gradient slices grow to 512 rows, ragged end
     (24, [40, 32, 24, 16, 3], ["", "tanh", "tanh", "tanh", "tanh", ""], 100),   # ten Dense layers (EMX_MAX_LAYERS = 12)
     (260, [300, 130, 2], ["", "tanh", "tanh", ""], 50),   # layers of several 128-column passes and 128-k chunks
+    # source rows beyond the LDS images of the row-block kernels (~2400 columns): the range runs in segments, the wide layers through
+    # the streaming kernel (csrc/wide.h) -- the 2600-wide ends of a 1300-feature periodic model ...
+    (2600, [128, 128, 2], ["", "tanh", "tanh", ""], 70),
+    # ... and wide layers INSIDE the network (every layer has a 2600-wide side; outputs of 21 passes: three pass groups per row block)
+    (40, [2600, 3], ["", "tanh", ""], 50),
 ]
 
 

@@ -357,8 +357,37 @@ def test_widest_nets_fall_back_to_separate_launches(em):
     np.testing.assert_allclose(got, want, rtol=1e-4)
     for k in ("auto", "reg", "center", "distance"):
         np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=1e-4, atol=1e-9)
-    with pytest.raises(Exception, match="emx_mlp_forward: (layer width too large|layer range needs more than)"):   # loud beyond ~2400 columns
-        em.EncoderMap(em.Parameters(batch_size=32), rng.uniform(-3, 3, (64, 1300)).astype(np.float32), read_only=True).train()
+
+
+@pytest.mark.parametrize("periodicity,D,n_neurons,afs", [(2 * PI, 1300, [128, 128, 2], ["", "tanh", "tanh", ""]),
+                                                         (INF, 3000, [96, 2], ["", "tanh", ""]),
+                                                         (INF, 60, [2500, 3], ["", "tanh", ""])], ids=["periodic_1300", "euclid_3000", "wide_inside"])
+def test_layers_beyond_the_lds_row_block(em, periodicity, D, n_neurons, afs):
+    """Source rows of more than ~2400 columns do not fit the row-block kernels' LDS images (1300 periodic features enter and leave
+    the network 2600 wide; the reference stacks Dense layers of any width, models/models.py:3133-3160).  The library then runs a layer
+    range in segments -- the wide layers through the streaming kernel of csrc/wide.h -- behind the same entry points: same oracle,
+    same tolerances as every other network; encode / decode through the wide layers as well."""
+    rng = np.random.default_rng(D)
+    lo, hi = (-np.pi, np.pi) if periodicity < INF else (-3.0, 3.0)
+    data = rng.uniform(lo, hi, (160, D)).astype(np.float32)
+    p = em.Parameters(n_steps=4, batch_size=48, periodicity=periodicity, n_neurons=n_neurons, activation_functions=afs,
+                      dist_sig_parameters=((45.0 if periodicity < INF else 1.7 * D ** 0.5), 12, 6, 1, 2, 6))
+    e, model, got, want, terms, want_terms = run_both(em, em.EncoderMap, p, data, 4)
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+    # inference through the wide layers, against the oracle ON THE ENGINE'S OWN WEIGHTS (Adam's first updates are lr * sign-like:
+    # over a 2600-wide layer the float32- and float64-trained weights differ by more than the 1e-4 asked of an encoding)
+    mine = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, e._engine.get_weights())
+    z = e.encode(data[:50])
+    z_o = mine.encoder(torch.tensor(data[:50], dtype=torch.float64)).detach().numpy()
+    np.testing.assert_allclose(z, z_o, atol=1e-4)
+    y = e.decode(z_o.astype(np.float32))
+    y_o = mine.decoder(torch.tensor(z_o.astype(np.float32), dtype=torch.float64)).detach().numpy()
+    d = np.abs(y - y_o)
+    if periodicity < INF:
+        d = np.minimum(d, periodicity - d)
+    assert d.max() < 2e-4
 
 
 @pytest.mark.parametrize("n_neurons,windows", [([48, 40, 32, 32, 24, 24, 16, 2], [(0, 8), (8, 16)]),
