@@ -280,7 +280,7 @@ def _counters(name, kernel_key):
     """static per-launch counters of the configuration's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh);
     returns (counters, source).  The newest round's file wins; its ``commit`` field is written at profile time (EMX_COMMIT or
     the build stamp: the GPU box has no .git)."""
-    for rnd in ("r04", "r03", "r02"):
+    for rnd in ("r05", "r04", "r03", "r02"):
         path = os.path.join("profiles", f"{rnd}_step_counters.json" if name == "C2" else f"{rnd}_{name.lower()}_counters.json")
         try:
             blob = json.load(open(os.path.join(ROOT, path)))
