@@ -3165,7 +3165,9 @@ static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_nex
   // 0.0735 / 0.0714 / 0.0725-0.0732 ms per step with 1 / 2 / 3 parts -- every part's share goes through memory)
   static const int max_splits = std::min(getenv("EMX_WGRAD_LOCAL_SPLITS") ? atoi(getenv("EMX_WGRAD_LOCAL_SPLITS")) : 2, 4);   // (the last arriver adds at most four shares)
   const int nrb = (n_rows + 15) / 16;
-  static const int gather_cap = getenv("EMX_LOCAL_GATHER_WGS") ? std::max(1, atoi(getenv("EMX_LOCAL_GATHER_WGS"))) : 1 << 20;   // (experiment: fewer gather workgroups, more passes each)
+  // at most 32 gather workgroups, two passes each at 4096 rows: 65.1-65.6 against 65.9-66.1 us per step with 64 (24 the same, 16: 66.0,
+  // 8: 77.5; same box, alternating, profiles/r05_tail_gather_ab.txt) -- their loads compete with the block workgroups' fragment requests
+  static const int gather_cap = getenv("EMX_LOCAL_GATHER_WGS") ? std::max(1, atoi(getenv("EMX_LOCAL_GATHER_WGS"))) : 32;
   if (next && !next->adc_head) gather = std::min(gather, gather_cap);
   static const bool forced = getenv("EMX_WGRAD_LOCAL_SPLITS") != nullptr;   // (an experiment may ask for more workgroups than CUs: nobody waits for a sibling)
   int splits = std::min(std::min(max_splits, (nrb + 31) / 32), forced ? 4 : (std::max(device_cus(), 1) - 1) / std::max(blocks, 1));
