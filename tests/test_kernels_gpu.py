@@ -625,6 +625,22 @@ def test_scratch_of_the_all_pairs_pass_needs_no_initialisation(L):
     torch.cuda.synchronize()
     assert refused is True
     del keep
+    # emx_forget_counters(workspace): the address's ticket block goes back to the library's pool and the next call gets words zeroed
+    # anew -- how a caller recovers after an aborted launch, and what keeps a process that creates many engines from accumulating
+    # blocks; many workspaces one after the other reuse the pooled block (same results throughout)
+    lib = _lib.load()
+    lib.emx_forget_counters(dirty_ws.data_ptr())
+    got = run(dirty_ws)
+    assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
+    for _ in range(6):
+        w = torch.randint(1, 2 ** 31 - 1, (n_ws + 64,), dtype=torch.int32, device="cuda").view(torch.float32)
+        got = run(w)
+        assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
+        torch.cuda.synchronize()
+        lib.emx_forget_counters(w.data_ptr())
+    lib.emx_forget_counters(None)        # (forget everything: the next call starts over)
+    got = run(dirty_ws)
+    assert got[0] == clean[0] and np.array_equal(got[1], clean[1])
 
 
 def test_periodic_cost_batch_equals_separate_calls(L):

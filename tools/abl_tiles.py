@@ -31,9 +31,17 @@ for w in range(4):
           " | ".join(f"chunk{k}: ready {c[2+2*k]-c[0]} mfma-done {c[3+2*k]-c[0]}" for k in range(4)),
           f"| norms+barrier {c[20]-c[0]}  pairs done {c[21]-c[0]}  block_sum {c[22]-c[0]}  end {c[23]-c[0]}")
 
-n = 2080
+n = 2176                      # (the XCD-aware grid: 8 x 16 x 17 workgroups, 96 of which leave at once without a stamp)
 st = buf[128:128 + 3 * n:3].astype(np.float64); en = buf[129:129 + 3 * n:3].astype(np.float64)
-t0 = st.min()
+live = (st > 0) & (en > 0)
+xcd = np.arange(n) % 8
+print("workgroups with a tile:", int(live.sum()), " per XCD:", [int((live & (xcd == x)).sum()) for x in range(8)])
+t0 = st[live].min()
+for x in range(8):
+    m = live & (xcd == x)
+    print(f"XCD {x}: last start {((st[m] - t0) * 10e-3).max():6.2f} us, starts later than 3 us: {int((((st[m] - t0) * 10e-3) > 3).sum()):3d}, "
+          f"median end {np.median((en[m] - t0) * 10e-3):6.2f}, 90 % end {np.percentile((en[m] - t0) * 10e-3, 90):6.2f}, last end {((en[m] - t0) * 10e-3).max():6.2f}")
+st, en = st[live], en[live]
 st = (st - t0) * 10e-3; en = (en - t0) * 10e-3   # us at 100 MHz
 order = np.argsort(st)
 print("kernel span us:", en.max(), " first-wave starts (us) pct 0/50/90/99/100:", np.percentile(st, [0, 50, 90, 99, 100]).round(2))
