@@ -82,10 +82,17 @@ def test_mlp_forward_backward_wgrad(L, net_dim, n_neurons, afs, B):
     delta = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
     plan = L.MlpPlan(lay, params, h, delta, train_rows=B)
     X = torch.from_numpy(x).to(dev)
+    c0 = L.load().emx_launch_count()
     L.mlp_forward(plan, 0, n, X, 0, B)
+    launches = L.load().emx_launch_count() - c0
     torch.cuda.synchronize()
     for i in range(n):
         np.testing.assert_allclose(h[i].cpu().numpy(), hs[i], rtol=2e-6, atol=3e-6, err_msg=f"activation {i}")
+    # one launch per pass wherever the LDS images hold every layer's source; beyond ~2400 columns the range runs in segments: the
+    # 2600-wide autoencoder as [streamed layer 0] [layers 1 .. 5 in one launch] (its wide OUTPUT keeps no image), the network with
+    # 2600-wide layers inside layer by layer
+    widest_source = max(l.n_in for l in lay.layers)
+    assert launches == (1 if widest_source <= 2048 else (2 if net_dim == 2600 else n)), (launches, widest_source)
     # split ranges give the same numbers (encoder on all rows, decoder on a row block)
     h2 = [torch.full((B, l.n_out), float("nan"), device=dev) for l in lay.layers]
     plan2 = L.MlpPlan(lay, params, h2, delta)
