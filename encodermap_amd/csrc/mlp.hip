@@ -2154,6 +2154,7 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_reduce_kernel(const float* __res
 // host side
 // ---------------------------------------------------------------------------------------------------------
 #include "wide.h"
+#include "tchain.h"
 
 int check_desc(const emx_mlp_desc* desc, const char* who) {
   EMX_REQUIRE(desc, "%s: null descriptor", who);
@@ -2740,6 +2741,114 @@ int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, s
   return launch_chain_tiles_impl<FAST, NCH, KIND, false>(b, tr, grid, lds, st);
 }
 
+// The fused launch of a SMALL network as the transposed, register-resident chain (tchain.h).  EMX_EUNSUPPORTED (no message): the
+// network or the cost is not what that kernel is built for -- the row-block chain kernel takes it.  EMX_TCHAIN=0: never.
+int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in, int ld_in, int row_begin,
+               int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin, float* const* delta, float* dbelow, void* aop, int aop_rows,
+               const char* who, emx_stream_t stream) {
+  // OFF unless EMX_TCHAIN=1: correct (tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle), and at 4096 rows slower
+  // than the row-block chain kernel (24.3-24.9 against 19.3-19.7 us for the fused launch, profiles/r05_tchain_ab.txt): the four waves
+  // of a row block stall on the issue of their own weight requests (64 KB per step through the CU's load path, one wave per SIMD:
+  // nobody to run in the gaps) -- DESIGN.md section 8 says what it needs
+  static const bool enabled = getenv("EMX_TCHAIN") && atoi(getenv("EMX_TCHAIN")) == 1;
+  static const int max_rows = getenv("EMX_TCHAIN_MAX_ROWS") ? atoi(getenv("EMX_TCHAIN_MAX_ROWS")) : 1 << 30;
+  const int n = desc->n_layers, top = layer_end - 1;
+  if (!enabled || layer_begin != 0 || layer_end != n || n > TC_MAXL || row_end - row_begin > max_rows) return EMX_EUNSUPPORTED;
+  for (int l = 0; l <= n; ++l)
+    if (desc->width[l] > 128) return EMX_EUNSUPPORTED;
+  for (int l = 0; l < n; ++l)
+    if (desc->act[l] != ACT_NONE && desc->act[l] != ACT_TANH) return EMX_EUNSUPPORTED;
+  if (cost->periodic_output || cost->variant == EMX_MEAN_NORM || (std::isfinite(cost->periodicity) && cost->periodicity > 0.f)) return EMX_EUNSUPPORTED;
+  if (!(cost->target && cost->ws && cost->n > 0 && cost->ldt >= cost->n && cost->B > 0 && cost->off_sin >= 0 && cost->off_sin + cost->n <= desc->width[n]))
+    return EMX_EUNSUPPORTED;   // (the row-block path reports what is wrong with the description)
+  TChainArgs a{};
+  int keep_slot[TC_MAXL];
+  int kept = 0;
+  for (int l = 0; l < n; ++l) {
+    keep_slot[l] = -1;
+    if (l >= bwd_begin && l < top && desc->act[l]) {
+      if (kept == TC_KEEP) return EMX_EUNSUPPORTED;
+      keep_slot[l] = kept++;
+    }
+  }
+  WopArgs wa;
+  fill_wop_args(desc, wa);
+  const char* wop = reinterpret_cast<const char*>(mirror);
+  AopLayout AL;
+  if (aop) aop_layout(desc, aop_rows, AL);
+  auto tensor = [&](int id) { return aop ? aop_tensor(aop, AL, id) : AopTensor{nullptr, nullptr, 0}; };
+  auto rsw_of = [&](int l) { return reinterpret_cast<const float*>(wop + (long)l * sizeof(WopHeader)); };
+  int ns = 0;
+  for (int l = 0; l < n; ++l) {   // forward steps
+    TStep& S = a.steps[ns++];
+    S.bias = params + desc->b_off[l];
+    S.rsw = rsw_of(l);
+    S.width = desc->width[l + 1];
+    S.act = desc->act[l];
+    S.keep = keep_slot[l];
+    if (l < top) {
+      S.kind = TS_FWD;
+      S.rows = h[l];
+      const AopTensor t = tensor(1 + l);               // the fragments of h_l are the X operand of layer l + 1's weight gradient
+      S.frag = t.frag, S.rscale = t.rscale, S.CG = t.CG;
+    } else {
+      S.kind = TS_FWD_TOP;                             // the output rows turn into d cost / d output = delta_top in place
+      S.rows = delta[top];
+      const AopTensor t = tensor(1 + n + top);
+      S.frag = t.frag, S.rscale = t.rscale, S.CG = t.CG;
+      if (h[top] != nullptr) return EMX_EUNSUPPORTED;  // (the output rows themselves are not kept by this kernel)
+    }
+  }
+  a.nl = n;
+  const int lo = dbelow ? bwd_begin : bwd_begin + 1;
+  for (int l = top; l >= lo; --l) {   // backward steps: the unit of layer l, result = delta_{l-1} (or dh below the range)
+    TStep& S = a.steps[ns++];
+    S.rsw = rsw_of(l);
+    S.width = desc->width[l];
+    if (l > bwd_begin) {
+      S.kind = TS_BWD;
+      S.act = desc->act[l - 1];
+      S.keep = keep_slot[l - 1];
+      S.rows = delta[l - 1];
+      const AopTensor t = tensor(1 + n + l - 1);
+      S.frag = t.frag, S.rscale = t.rscale, S.CG = t.CG;
+    } else {
+      S.kind = TS_BWD_BELOW;
+      S.act = ACT_NONE;
+      S.keep = -1;
+      S.rows = dbelow;
+    }
+  }
+  a.nsteps = ns;
+  a.in = in;
+  a.ld_in = ld_in;
+  a.in_cols = desc->width[0];
+  {
+    const AopTensor t = tensor(0);
+    a.in_frag = t.frag, a.in_rscale = t.rscale, a.in_CG = t.CG;
+  }
+  a.units_fwd = wop + wa.units_begin + wa.fwd_unit[0] * WOP_UNIT;
+  a.units_bwd = wop + wa.units_begin + wa.bwd_unit[top] * WOP_UNIT;
+  a.target = cost->target;
+  a.cost_ws = cost->ws;
+  a.ldt = cost->ldt;
+  a.cost_n = cost->n;
+  a.cost_off = cost->off_sin;
+  a.cost_variant = cost->variant;
+  {
+    CostArgs c{};
+    fill_cost_scalars(c, cost->B, cost->n, desc->width[n], cost->ldt, cost->off_sin, cost->off_cos, 0, cost->periodicity, cost->variant, cost->coef);
+    a.gnorm = c.gnorm;
+  }
+  a.row0 = row_begin;
+  a.row_end = row_end;
+  int rc = set_lds(reinterpret_cast<const void*>(&tchain_fused_kernel), TC_LDS, who, 0);
+  if (rc) return rc;
+  const int grid = (row_end - row_begin + R - 1) / R;
+  hipLaunchKernelGGL(tchain_fused_kernel, dim3(grid), dim3(256), TC_LDS, (hipStream_t)stream, a);
+  return emx::check_launch("transposed chain kernel (forward + cost + backward)");
+}
+
 int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                           int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
                           float* const* delta, float* dbelow, void* aop, int aop_rows, const TilesHost* tiles, const char* who,
@@ -2755,6 +2864,10 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   EMX_REQUIRE(cost->dY == delta[top] || cost->dY == nullptr, "%s: d cost / d output is delta[layer_end - 1]; pass that buffer (or NULL) as cost->dY", who);
   rc = check_aop(aop, aop_rows, row_begin, row_end, who);
   if (rc) return rc;
+  if (tiles == nullptr) {
+    rc = try_tchain(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, bwd_begin, delta, dbelow, aop, aop_rows, who, stream);
+    if (rc != EMX_EUNSUPPORTED) return rc;      // (launched, or a real error; EMX_EUNSUPPORTED here only means: not a network for that kernel)
+  }
   ChainBuilder b(desc, mirror, who);
   ChainArgs& a = b.a;
   AopLayout AL;

@@ -1,0 +1,360 @@
+// The fused dense-layer launch (forward + auto cost + decoder backward) of SMALL networks as a TRANSPOSED, register-resident chain
+// (included by mlp.hip, inside its namespace).
+//
+// The row-block chain kernels (chain_body) compute H = X W with the batch rows as the M dimension of v_mfma_f32_16x16x32_f16: a
+// layer's output leaves the matrix unit with lane = FEATURE, the next layer wants lane = ROW, so every layer goes accumulator ->
+// LDS image -> barrier of eight waves -> transposed read (~3 000 cycles per 128 x 128 layer, most of them that round trip).
+// Here H^T = W^T X^T: the weight pieces of the operand store are used AS THEY STAND as the A operand (lane (m, g) of a piece holds
+// the eight k of wop.h's kk(g, e) for out-feature m -- the same registers a B fragment holds for column n), the 16 batch rows of a
+// block are the N dimension, and D comes out as lane (n = row, g) holding out-features 16 t + 4 g .. + 3 of tile t.  With
+// kk(g, e) = 4 g + e, 16 + 4 g + (e - 4) the accumulators of tiles 2 s and 2 s + 1 in lane (n, g) ARE the eight k that lane
+// supplies for K-step s of the next layer: bias, activation and the f16 split happen in place.  FOUR waves carry a row block: wave w
+// runs K-step w of all eight tiles (24 matrix instructions per layer), hands the partial sums of the six tiles it does not own to
+// their owners through LDS (one barrier of four waves per layer, two copies of the area by layer parity) and finalises tiles 2 w,
+// 2 w + 1 -- its own K-step of the next layer, and exactly one 16 x 32 block of the weight-gradient fragments (aop.h), which it
+// transposes through a wave-private LDS area off the critical path.  A wave's 16 pieces of a layer travel a whole layer ahead in a
+// register ring of two.  The backward GEMMs are the same picture on the backward units (delta^T_{l-1} = W_l delta^T_l), the
+// activation derivative taken from the layer's output kept in the SAME register layout.  Measured as a microbenchmark
+// (tools/ubench_tchain.hip, profiles/r05_tchain_ubench.txt): 2 180 cycles per 128 x 128 tanh layer.
+// Built for: every width of the range <= 128 (one unit per layer), tanh / linear layers, a non-periodic output with mean_abs or
+// mean_square, the whole network forward and the backward pass down to bwd_begin.  Arithmetic: three f16 products per float32
+// product on operands split into two planes with a power-of-two scale per (row, 32 features) -- the chain kernels' precision class.
+#pragma once
+
+constexpr int TC_MAXL = EMX_MAX_LAYERS;
+constexpr int TC_KEEP = 4;   // layer outputs kept for the backward pass's activation derivatives (LDS, 8 KB each)
+
+// One step of the chain = one unit of the operand store; everything a step's epilogue needs, as ONE 64-byte record (a single scalar
+// load at the head of the step: fetched field by field from tables, each behind its own wait, the lookups were 1 200 of a step's
+// 5 000 cycles).
+enum { TS_FWD = 0, TS_FWD_TOP = 1, TS_BWD = 2, TS_BWD_BELOW = 3 };
+struct TStep {
+  const float* bias;     // forward: the layer's bias
+  float* rows;           // float32 rows of the step's result (h_l, delta_{l-1}, or dh below the range); NULL: not kept
+  char* frag;            // its weight-gradient fragments; NULL: not kept
+  float* rscale;
+  const float* rsw;      // the layer's reciprocal weight scale (header of the operand store)
+  int width;             // columns of the result that exist
+  int act;               // forward: the layer's activation; backward: the activation whose derivative the result is multiplied with
+  int keep;              // forward: LDS slot the output is kept in for the backward pass (-1: none); backward: the slot to read
+  int CG;                // column groups of the fragment tensor
+  int kind;              // TS_*
+  int pad;
+};
+static_assert(sizeof(TStep) == 64, "TStep is one s_load_dwordx16");
+
+struct TChainArgs {
+  TStep steps[2 * TC_MAXL];
+  int nsteps, nl;
+  const float* in;
+  int ld_in, in_cols;
+  char* in_frag;           // fragments of the input (tensor 0); NULL: not kept
+  float* in_rscale;
+  int in_CG, pad0;
+  const char* units_fwd;   // unit of layer 0; layer l: + l * 64 KB
+  const char* units_bwd;   // unit of the top layer in the backward direction; layer top - j: + j * 64 KB
+  const float* target;
+  float* cost_ws;
+  int ldt, cost_n, cost_off, cost_variant;
+  float gnorm;
+  int row0, row_end, pad1;
+};
+
+constexpr int TC_XCH = 2 * 4 * 4 * 2 * 64 * 16;           // bytes: [parity][owner][source][tile][lane] x 16
+constexpr int TC_KEEP_BYTES = TC_KEEP * 4 * 8 * 64 * 4;   // [slot][wave][e][lane] floats
+constexpr int TC_FRAG = 4 * 2048;                         // a wave's transposition area: two planes [32 features][16 rows] f16
+constexpr int TC_LDS = TC_XCH + TC_KEEP_BYTES + TC_FRAG + 64;
+
+// (the argument record is indexed at run time -- layer tables -- so it is read through the kernel-argument segment itself, scalar
+//  loads from constant memory: indexing the by-value struct makes hipcc copy all of it to scratch)
+typedef const TChainArgs __attribute__((address_space(4))) * TChainK;
+
+// (ONE copy of the body for the four waves -- the wave index is a scalar register; only the accumulator exchange, which indexes
+//  registers by it, is a four-way switch.  Four instantiations of the whole body were ~80 KB of code for a 64-KB instruction cache.)
+__device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
+  const auto& a = *ka;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, g = lane >> 4;
+  const int r0 = a.row0 + blockIdx.x * R;
+  const int rb = r0 >> 4;
+  const int rows_valid = min(R, a.row_end - r0);
+  const bool rok = n < rows_valid;
+  const long grow = (long)min(r0 + n, a.row_end - 1);
+  f32x4* const xch = reinterpret_cast<f32x4*>(lds);
+  float* const keep = reinterpret_cast<float*>(lds + TC_XCH);
+  char* const fstage = lds + TC_XCH + TC_KEEP_BYTES + wave * 2048;
+  float* const red = reinterpret_cast<float*>(lds + TC_XCH + TC_KEEP_BYTES + TC_FRAG);
+  // feature (column) of element e of this lane inside the wave's block of 32: tiles 2 w and 2 w + 1, rows 4 g .. 4 g + 3 of D
+  auto fcol = [&](int e) { return 32 * wave + 16 * (e >> 2) + 4 * g + (e & 3); };
+
+  half8 bh, bl;        // the operand of the wave's K-step: eight k of this lane's row
+  float brs = 1.f;     // its reciprocal scale (per row and 32 features)
+  unsigned bmax = 0;   // bit pattern of the row's largest |value| over those 32 features
+  bool bfixed = false; // the operand holds tanh outputs at the fixed scale 2^14 (no maxima, partial sums need no unscaling)
+  auto make_operand = [&](const float (&v)[8], const bool fixed) __attribute__((always_inline)) {
+    float s = 16384.f;
+    bfixed = fixed;
+    if (fixed) {
+      brs = TANH_RS;
+    } else {
+      unsigned m = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m = max(m, abs_bits(v[e]));
+      m = max_xor32(max_xor16(m));                     // the row's maximum over the four lanes (g) that hold its 32 features
+      bmax = m;
+      pow2_scale_bits<ACT_TOP>(m, s, brs);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float t = v[e] * s;
+      bh[e] = (_Float16)t;
+      bl[e] = (_Float16)(t - (float)bh[e]);
+    }
+  };
+  // The wave's 16 x 32 block of the tensor the CURRENT operand was made from, as weight-gradient fragments (aop.h): the row-scaled
+  // planes shifted to the block's scale (a power of two <= 1 per row: exact while the low plane stays above 2^-24, as in the
+  // chain kernels' stage_finish), written row-major [row][16 features] per tile (one 8-byte LDS store per plane and tile) and read
+  // back TRANSPOSED (ds_read_b64_tr_b16: lane i of a 16-lane group receives feature i of four rows): lane (feature, hh) ends with
+  // rows 8 hh .. 8 hh + 7 of its feature -- one fragment lane.  The wave's own LDS area; nobody else touches it.
+  auto emit_fragments = [&](const AopTensor& ao) __attribute__((always_inline)) {
+    if (ao.frag == nullptr || wave >= ao.CG) return;
+    float rsb = TANH_RS;
+    half8 fh = bh, fl = bl;
+    if (!bfixed) {
+      const unsigned bm = row16_max(bmax);             // the block's maximum: over the 16 rows (lanes n of a DPP row; every g agrees)
+      float sb;
+      pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
+      const _Float16 ratio = (_Float16)(sb * brs);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        fh[e] = bh[e] * ratio;
+        fl[e] = bl[e] * ratio;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {   // tile q of the wave's two: [16 rows][16 features] f16 = 512 bytes per plane
+      *reinterpret_cast<half4*>(fstage + q * 512 + n * 32 + g * 8) = half4{fh[4 * q], fh[4 * q + 1], fh[4 * q + 2], fh[4 * q + 3]};
+      *reinterpret_cast<half4*>(fstage + 1024 + q * 512 + n * 32 + g * 8) = half4{fl[4 * q], fl[4 * q + 1], fl[4 * q + 2], fl[4 * q + 3]};
+    }
+    __builtin_amdgcn_wave_barrier();
+    // group G = lane >> 4 of the wave: tile G & 1, rows 8 (G >> 1) ..; lane 4 qq + p of the group addresses row qq, features 4 p ..
+    const int G = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
+    const char* src = fstage + (G & 1) * 512 + (8 * (G >> 1) + qq) * 32 + p * 8;
+    const half4 h0 = lds_read_tr16(reinterpret_cast<const _Float16*>(src));
+    const half4 h1 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 4 * 32));
+    const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 1024));
+    const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 1024 + 4 * 32));
+    __builtin_amdgcn_wave_barrier();
+    // lane' = lane: feature r32 = 16 (G & 1) + (lane & 15) = lane & 31 for G & 1 = (lane >> 4) & 1, hh = G >> 1 = lane >> 5: the fragment's lane map
+    {
+      char* f = ao.frag + ((long)rb * ao.CG + wave) * 2048 + lane * 16;
+      *reinterpret_cast<half8*>(f) = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+      *reinterpret_cast<half8*>(f + 1024) = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
+      if (lane == 0) ao.rscale[(long)rb * ao.CG + wave] = rsb;
+    }
+  };
+  // the wave's block as float32 rows [*, width]
+  auto store_rows = [&](const float (&v)[8], float* dst, int width) __attribute__((always_inline)) {
+    if (dst == nullptr || !rok) return;
+    // (a tile's four features of a lane are contiguous: one 16-byte store where the row length allows it)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int c = 32 * wave + 16 * q + 4 * g;
+      if (c + 3 < width && (width & 3) == 0) {
+        *reinterpret_cast<f32x4*>(dst + grow * width + c) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          if (c + r < width) dst[grow * width + c + r] = v[4 * q + r];
+      }
+    }
+  };
+
+  // ---- the block's input rows: operand of K-step `wave`, fragments of tensor 0
+  {
+    float x[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = fcol(e);   // (= 32 wave + kk(g, e): operand order and block order agree)
+      x[e] = (rok && c < a.in_cols) ? a.in[grow * a.ld_in + min(c, a.in_cols - 1)] : 0.f;
+    }
+    make_operand(x, false);
+    emit_fragments(AopTensor{a.in_frag, a.in_rscale, a.in_CG});
+  }
+
+  half8 wb[2][8][2];
+  const int nsteps = a.nsteps;
+  auto unit_of = [&](int step) -> const char* {
+    const int s = min(step, nsteps - 1);
+    return s < a.nl ? a.units_fwd + (long)s * WOP_UNIT : a.units_bwd + (long)(s - a.nl) * WOP_UNIT;
+  };
+  // A wave's 16 pieces of the NEXT step, a quarter at a time: the four waves of a workgroup pull 64 KB per step through the CU's
+  // 64-byte-per-clock load path (>= 1 024 cycles) -- requested in one burst at the head of the step the waves stall on issue behind
+  // their own requests (the products phase took 1 200 cycles instead of 400); in quarters between the phases the stream runs beside
+  // the work
+  auto request_q = [&](const int slot, const int step, const int q) __attribute__((always_inline)) {
+    const char* u = unit_of(step) + wave * 2048 + lane * 16;
+#pragma unroll
+    for (int t = 2 * q; t < 2 * q + 2; ++t) {
+      wb[slot][t][0] = *reinterpret_cast<const half8*>(u + t * 8192);
+      wb[slot][t][1] = *reinterpret_cast<const half8*>(u + t * 8192 + 1024);
+    }
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) request_q(0, 0, q);
+  float lsum = 0.f;
+
+  auto step_fn = [&](const int step, auto SLOT_) __attribute__((always_inline)) {
+    constexpr int slot = decltype(SLOT_)::value;
+    if (step >= nsteps) return;                       // (workgroup-uniform)
+    // the step's record, and everything its epilogue reads from memory, IN FRONT of the next layer's pieces: the memory counter is in
+    // order, and a wait for a bias behind sixteen piece requests would be a wait for all of them
+    TStep S;
+    {
+      const auto& K = a.steps[step];                  // (constant address space: field by field, the loads merge into one)
+      S.bias = K.bias, S.rows = K.rows, S.frag = K.frag, S.rscale = K.rscale, S.rsw = K.rsw;
+      S.width = K.width, S.act = K.act, S.keep = K.keep, S.CG = K.CG, S.kind = K.kind;
+    }
+    const float rsw = *S.rsw;
+    float ev[8], tv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ev[e] = tv[e] = 0.f;
+    if (S.kind <= TS_FWD_TOP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ev[e] = S.bias[min(fcol(e), S.width - 1)];
+      if (S.kind == TS_FWD_TOP) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = fcol(e);
+          const bool live = rok && c >= a.cost_off && c < a.cost_off + a.cost_n;
+          tv[e] = live ? a.target[grow * a.ldt + (c - a.cost_off)] : 0.f;
+        }
+      }
+    }
+    request_q(1 - slot, step + 1, 0);
+    f32x4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][0], bl, acc[t], 0, 0, 0);   // small products first
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][1], bh, acc[t], 0, 0, 0);
+      acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][0], bh, acc[t], 0, 0, 0);
+    }
+    // partial sums of the other waves' tiles -> their owners (unscaled by this K-step's row scale first)
+    f32x4* const xc = xch + slot * (4 * 4 * 2 * 64);
+    const bool fixed_in = bfixed;                      // (workgroup-uniform: every wave's operand came from the same layer)
+    if (!fixed_in) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] *= brs;
+    }
+    f32x4 s0, s1;
+    auto give = [&](auto W_) __attribute__((always_inline)) {
+      constexpr int w = decltype(W_)::value;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        if (o == w) continue;
+        xc[((o * 4 + w) * 2 + 0) * 64 + lane] = acc[2 * o];
+        xc[((o * 4 + w) * 2 + 1) * 64 + lane] = acc[2 * o + 1];
+      }
+      s0 = acc[2 * w], s1 = acc[2 * w + 1];
+    };
+    switch (wave) {
+      case 0: give(IC_<0>{}); break;
+      case 1: give(IC_<1>{}); break;
+      case 2: give(IC_<2>{}); break;
+      default: give(IC_<3>{}); break;
+    }
+    request_q(1 - slot, step + 1, 1);
+    __syncthreads();
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {                      // the other three waves' shares, in the order wave + 1, + 2, + 3 (mod 4)
+      const int src = (wave + j) & 3;
+      s0 += xc[((wave * 4 + src) * 2 + 0) * 64 + lane];
+      s1 += xc[((wave * 4 + src) * 2 + 1) * 64 + lane];
+    }
+    request_q(1 - slot, step + 1, 2);
+    float v[8];
+    const float cm = fixed_in ? rsw * TANH_RS : rsw;
+    // (b) a full block of a full-width layer needs no masks
+    const bool full = rows_valid == R && S.width >= 32 * wave + 32;
+    if (S.kind <= TS_FWD_TOP) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = fmaf(e < 4 ? s0[e & 3] : s1[e & 3], cm, ev[e]);
+        if (S.act == ACT_TANH) x = tanh_f32(x);
+        v[e] = x;
+      }
+      if (!full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (rok && fcol(e) < S.width) ? v[e] : 0.f;
+      }
+      if (S.kind == TS_FWD) {
+        store_rows(v, S.rows, S.width);
+        if (S.keep >= 0) {
+          f32x4* k = reinterpret_cast<f32x4*>(keep) + ((S.keep * 4 + wave) * 2) * 64 + lane;
+          k[0] = f32x4{v[0], v[1], v[2], v[3]};
+          k[64] = f32x4{v[4], v[5], v[6], v[7]};
+        }
+      } else {
+        // ---- the auto cost on the output rows (h of the top layer is kept as float32 rows if asked for: S.bias doubles as nothing
+        //      here -- the rows pointer is d cost / d output's); delta_top replaces the output in place
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int c = fcol(e);
+          const bool live = rok && c >= a.cost_off && c < a.cost_off + a.cost_n;
+          const float diff = v[e] - tv[e];
+          float q;
+          if (a.cost_variant == EMX_MEAN_ABS) {
+            if (live) lsum += fabsf(diff);
+            q = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+          } else {
+            if (live) lsum = fmaf(diff, diff, lsum);
+            q = 2.f * diff;
+          }
+          v[e] = live ? a.gnorm * q : 0.f;
+        }
+        {   // the row block's cost share: wave sums, then the four waves in turn
+          const float ws = wave_sum(lsum);
+          if (lane == 0) red[wave] = ws;
+        }
+        store_rows(v, S.rows, S.width);
+      }
+    } else {
+      // backward: dh of the layer below, times the activation derivative of that layer's output (kept in this register layout)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = (e < 4 ? s0[e & 3] : s1[e & 3]) * cm;
+      }
+      if (!full) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (rok && fcol(e) < S.width) ? v[e] : 0.f;
+      }
+      if (S.act == ACT_TANH) {
+        const f32x4* k = reinterpret_cast<const f32x4*>(keep) + ((S.keep * 4 + wave) * 2) * 64 + lane;
+        const f32x4 h0 = k[0], h1 = k[64];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float hv = e < 4 ? h0[e & 3] : h1[e & 3];
+          v[e] *= fmaf(-hv, hv, 1.f);
+        }
+      }
+      store_rows(v, S.rows, S.width);
+    }
+    request_q(1 - slot, step + 1, 3);
+    make_operand(v, S.kind == TS_FWD && S.act == ACT_TANH);
+    emit_fragments(AopTensor{S.frag, S.rscale, S.CG});
+  };
+  for (int step = 0; step < nsteps; step += 2) {
+    step_fn(step, IC_<0>{});
+    step_fn(step + 1, IC_<1>{});
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && a.cost_ws != nullptr) a.cost_ws[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * a.gnorm;
+}
+
+__global__ __launch_bounds__(256) void tchain_fused_kernel(const TChainArgs) {
+  extern __shared__ __align__(16) char lds[];
+  const TChainK ka = (TChainK)__builtin_amdgcn_kernarg_segment_ptr();
+  tchain_wave(ka, lds);
+}

@@ -585,3 +585,19 @@ def test_wgrad_adam_local_through_the_abi(L, net_dim, n_neurons, afs, B):
     wn = unpack_weights(lay, b["w"])
     for l in range(n):
         np.testing.assert_allclose(b["store"][l][0], wn[2 * l], rtol=0, atol=2.0 ** -20 * np.abs(wn[2 * l]).max())
+
+
+@pytest.mark.gpu
+def test_transposed_chain_against_the_oracle(L):
+    """The fused dense-layer launch as the TRANSPOSED, register-resident chain (csrc/tchain.h; opt-in, EMX_TCHAIN=1 -- the switch is
+    read once per process, hence the process of its own): activations, decoder deltas, latent gradient and cost against the separate
+    row-block launches and float64, and the weight gradients formed from the fragments it leaves (tests/tchain_check.py: full and
+    ragged row blocks, narrow inputs, a 3-wide latent)."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "tchain_check.py")], env=dict(os.environ, EMX_TCHAIN="1"), capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "ALL OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
