@@ -2747,7 +2747,7 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
                int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin, float* const* delta, float* dbelow, void* aop, int aop_rows,
                const char* who, emx_stream_t stream) {
   // OFF unless EMX_TCHAIN=1: correct (tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle), and at 4096 rows slower
-  // than the row-block chain kernel (24.3-24.9 against 19.3-19.7 us for the fused launch, profiles/r05_tchain_ab.txt): the four waves
+  // than the row-block chain kernel (22.7-23.0 against 18.6-18.8 us for the fused launch, profiles/r05_tchain_ab.txt): the four waves
   // of a row block stall on the issue of their own weight requests (64 KB per step through the CU's load path, one wave per SIMD:
   // nobody to run in the gaps) -- DESIGN.md section 8 says what it needs
   static const bool enabled = getenv("EMX_TCHAIN") && atoi(getenv("EMX_TCHAIN")) == 1;
