@@ -2747,9 +2747,8 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
                int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin, float* const* delta, float* dbelow, void* aop, int aop_rows,
                const char* who, emx_stream_t stream) {
   // OFF unless EMX_TCHAIN=1: correct (tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle), and at 4096 rows slower
-  // than the row-block chain kernel (22.7-23.0 against 18.6-18.8 us for the fused launch, profiles/r05_tchain_ab.txt): the four waves
-  // of a row block stall on the issue of their own weight requests (64 KB per step through the CU's load path, one wave per SIMD:
-  // nobody to run in the gaps) -- DESIGN.md section 8 says what it needs
+  // than the row-block chain kernel (22.4-22.8 against 19.1-19.6 us for the fused launch, step 67.7-68.2 against 65.2-65.6,
+  // profiles/r05_tchain_ab.txt) -- DESIGN.md section 8 says where its steps' ~4 000 cycles go and what it needs
   static const bool enabled = getenv("EMX_TCHAIN") && atoi(getenv("EMX_TCHAIN")) == 1;
   static const int max_rows = getenv("EMX_TCHAIN_MAX_ROWS") ? atoi(getenv("EMX_TCHAIN_MAX_ROWS")) : 1 << 30;
   const int n = desc->n_layers, top = layer_end - 1;
@@ -2845,7 +2844,7 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
   int rc = set_lds(reinterpret_cast<const void*>(&tchain_fused_kernel), TC_LDS, who, 0);
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
-  hipLaunchKernelGGL(tchain_fused_kernel, dim3(grid), dim3(256), TC_LDS, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(tchain_fused_kernel, dim3(grid), dim3(512), TC_LDS, (hipStream_t)stream, a);
   return emx::check_launch("transposed chain kernel (forward + cost + backward)");
 }
 

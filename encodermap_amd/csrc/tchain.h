@@ -8,12 +8,14 @@
 // the eight k of wop.h's kk(g, e) for out-feature m -- the same registers a B fragment holds for column n), the 16 batch rows of a
 // block are the N dimension, and D comes out as lane (n = row, g) holding out-features 16 t + 4 g .. + 3 of tile t.  With
 // kk(g, e) = 4 g + e, 16 + 4 g + (e - 4) the accumulators of tiles 2 s and 2 s + 1 in lane (n, g) ARE the eight k that lane
-// supplies for K-step s of the next layer: bias, activation and the f16 split happen in place.  FOUR waves carry a row block: wave w
-// runs K-step w of all eight tiles (24 matrix instructions per layer), hands the partial sums of the six tiles it does not own to
-// their owners through LDS (one barrier of four waves per layer, two copies of the area by layer parity) and finalises tiles 2 w,
-// 2 w + 1 -- its own K-step of the next layer, and exactly one 16 x 32 block of the weight-gradient fragments (aop.h), which it
-// transposes through a wave-private LDS area off the critical path.  A wave's 16 pieces of a layer travel a whole layer ahead in a
-// register ring of two.  The backward GEMMs are the same picture on the backward units (delta^T_{l-1} = W_l delta^T_l), the
+// supplies for K-step s of the next layer: bias, activation and the f16 split happen in place.  EIGHT waves carry a row block, two
+// per SIMD (with one the waves stalled on the issue of their own weight requests with nobody to run in the gaps): wave (w, hf) runs
+// K-step w of tiles 4 hf .. 4 hf + 3 (12 matrix instructions per layer) and leaves its partial sums in LDS ([tile][K-step], one
+// barrier per layer, two copies of the area by layer parity); BOTH waves of a pair (w, 0), (w, 1) then add the four K-steps' shares of
+// tiles 2 w, 2 w + 1 -- the operand of their K-step of the next layer, which each of them needs -- and finalise them identically;
+// that 16 x 32 block is exactly one block of the weight-gradient fragments (aop.h): wave hf of the pair leaves plane hf, transposed
+// through a wave-private LDS area (ds_read_b64_tr_b16); the second wave also stores the float32 rows.  A wave's 8 pieces of a layer travel a whole layer ahead in a register ring of two,
+// requested in quarters between the phases of the step.  The backward GEMMs are the same picture on the backward units (delta^T_{l-1} = W_l delta^T_l), the
 // activation derivative taken from the layer's output kept in the SAME register layout.  Measured as a microbenchmark
 // (tools/ubench_tchain.hip, profiles/r05_tchain_ubench.txt): 2 180 cycles per 128 x 128 tanh layer.
 // Built for: every width of the range <= 128 (one unit per layer), tanh / linear layers, a non-periodic output with mean_abs or
@@ -60,9 +62,9 @@ struct TChainArgs {
   int row0, row_end, pad1;
 };
 
-constexpr int TC_XCH = 2 * 4 * 4 * 2 * 64 * 16;           // bytes: [parity][owner][source][tile][lane] x 16
+constexpr int TC_XCH = 2 * 8 * 4 * 64 * 16;               // bytes: [parity][tile][K-step][lane] x 16
 constexpr int TC_KEEP_BYTES = TC_KEEP * 4 * 8 * 64 * 4;   // [slot][wave][e][lane] floats
-constexpr int TC_FRAG = 4 * 2048;                         // a wave's transposition area: two planes [32 features][16 rows] f16
+constexpr int TC_FRAG = 8 * 1024;                         // a wave's transposition area: one plane [32 features][16 rows] f16
 constexpr int TC_LDS = TC_XCH + TC_KEEP_BYTES + TC_FRAG + 64;
 
 // (the argument record is indexed at run time -- layer tables -- so it is read through the kernel-argument segment itself, scalar
@@ -74,7 +76,9 @@ typedef const TChainArgs __attribute__((address_space(4))) * TChainK;
 __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   const auto& a = *ka;
   const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave8 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = wave8 & 3;          // the K-step this wave multiplies, and the pair of tiles (= 32 features) it finalises
+  const int hf = wave8 >> 2;           // its half of the tiles in the products: tiles 4 hf .. 4 hf + 3
   const int n = lane & 15, g = lane >> 4;
   const int r0 = a.row0 + blockIdx.x * R;
   const int rb = r0 >> 4;
@@ -83,7 +87,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   const long grow = (long)min(r0 + n, a.row_end - 1);
   f32x4* const xch = reinterpret_cast<f32x4*>(lds);
   float* const keep = reinterpret_cast<float*>(lds + TC_XCH);
-  char* const fstage = lds + TC_XCH + TC_KEEP_BYTES + wave * 2048;
+  char* const fstage = lds + TC_XCH + TC_KEEP_BYTES + wave8 * 1024;   // the wave's own transposition area: one plane [32 features][16 rows] f16
   float* const red = reinterpret_cast<float*>(lds + TC_XCH + TC_KEEP_BYTES + TC_FRAG);
   // feature (column) of element e of this lane inside the wave's block of 32: tiles 2 w and 2 w + 1, rows 4 g .. 4 g + 3 of D
   auto fcol = [&](int e) { return 32 * wave + 16 * (e >> 2) + 4 * g + (e & 3); };
@@ -119,44 +123,35 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   // rows 8 hh .. 8 hh + 7 of its feature -- one fragment lane.  The wave's own LDS area; nobody else touches it.
   auto emit_fragments = [&](const AopTensor& ao) __attribute__((always_inline)) {
     if (ao.frag == nullptr || wave >= ao.CG) return;
+    // (the pair's two waves hold the same operand: wave hf leaves plane hf)
     float rsb = TANH_RS;
-    half8 fh = bh, fl = bl;
+    half8 fp = hf ? bl : bh;
     if (!bfixed) {
       const unsigned bm = row16_max(bmax);             // the block's maximum: over the 16 rows (lanes n of a DPP row; every g agrees)
       float sb;
       pow2_scale_bits<ACT_TOP>(bm, sb, rsb);
       const _Float16 ratio = (_Float16)(sb * brs);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        fh[e] = bh[e] * ratio;
-        fl[e] = bl[e] * ratio;
-      }
+      for (int e = 0; e < 8; ++e) fp[e] = fp[e] * ratio;
     }
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {   // tile q of the wave's two: [16 rows][16 features] f16 = 512 bytes per plane
-      *reinterpret_cast<half4*>(fstage + q * 512 + n * 32 + g * 8) = half4{fh[4 * q], fh[4 * q + 1], fh[4 * q + 2], fh[4 * q + 3]};
-      *reinterpret_cast<half4*>(fstage + 1024 + q * 512 + n * 32 + g * 8) = half4{fl[4 * q], fl[4 * q + 1], fl[4 * q + 2], fl[4 * q + 3]};
-    }
+    for (int q = 0; q < 2; ++q)   // tile q of the pair's two: [16 rows][16 features] f16 = 512 bytes
+      *reinterpret_cast<half4*>(fstage + q * 512 + n * 32 + g * 8) = half4{fp[4 * q], fp[4 * q + 1], fp[4 * q + 2], fp[4 * q + 3]};
     __builtin_amdgcn_wave_barrier();
     // group G = lane >> 4 of the wave: tile G & 1, rows 8 (G >> 1) ..; lane 4 qq + p of the group addresses row qq, features 4 p ..
     const int G = lane >> 4, qq = (lane & 15) >> 2, p = lane & 3;
     const char* src = fstage + (G & 1) * 512 + (8 * (G >> 1) + qq) * 32 + p * 8;
     const half4 h0 = lds_read_tr16(reinterpret_cast<const _Float16*>(src));
     const half4 h1 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 4 * 32));
-    const half4 l0 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 1024));
-    const half4 l1 = lds_read_tr16(reinterpret_cast<const _Float16*>(src + 1024 + 4 * 32));
     __builtin_amdgcn_wave_barrier();
-    // lane' = lane: feature r32 = 16 (G & 1) + (lane & 15) = lane & 31 for G & 1 = (lane >> 4) & 1, hh = G >> 1 = lane >> 5: the fragment's lane map
-    {
-      char* f = ao.frag + ((long)rb * ao.CG + wave) * 2048 + lane * 16;
-      *reinterpret_cast<half8*>(f) = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
-      *reinterpret_cast<half8*>(f + 1024) = half8{l0[0], l0[1], l0[2], l0[3], l1[0], l1[1], l1[2], l1[3]};
-      if (lane == 0) ao.rscale[(long)rb * ao.CG + wave] = rsb;
-    }
+    // lane' = lane: feature 16 (G & 1) + (lane & 15) = lane & 31, hh = G >> 1 = lane >> 5: the fragment's lane map
+    char* f = ao.frag + ((long)rb * ao.CG + wave) * 2048 + hf * 1024 + lane * 16;
+    *reinterpret_cast<half8*>(f) = half8{h0[0], h0[1], h0[2], h0[3], h1[0], h1[1], h1[2], h1[3]};
+    if (lane == 0 && hf == 0) ao.rscale[(long)rb * ao.CG + wave] = rsb;
   };
   // the wave's block as float32 rows [*, width]
   auto store_rows = [&](const float (&v)[8], float* dst, int width) __attribute__((always_inline)) {
-    if (dst == nullptr || !rok) return;
+    if (dst == nullptr || !rok || hf != 1) return;     // (the pair's second wave stores the rows, its first the fragments)
     // (a tile's four features of a lane are contiguous: one 16-byte store where the row length allows it)
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -183,7 +178,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
     emit_fragments(AopTensor{a.in_frag, a.in_rscale, a.in_CG});
   }
 
-  half8 wb[2][8][2];
+  half8 wb[2][4][2];   // a register ring of two steps: the wave's pieces of its four tiles
   const int nsteps = a.nsteps;
   auto unit_of = [&](int step) -> const char* {
     const int s = min(step, nsteps - 1);
@@ -194,12 +189,9 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   // their own requests (the products phase took 1 200 cycles instead of 400); in quarters between the phases the stream runs beside
   // the work
   auto request_q = [&](const int slot, const int step, const int q) __attribute__((always_inline)) {
-    const char* u = unit_of(step) + wave * 2048 + lane * 16;
-#pragma unroll
-    for (int t = 2 * q; t < 2 * q + 2; ++t) {
-      wb[slot][t][0] = *reinterpret_cast<const half8*>(u + t * 8192);
-      wb[slot][t][1] = *reinterpret_cast<const half8*>(u + t * 8192 + 1024);
-    }
+    const char* u = unit_of(step) + (4 * hf) * 8192 + wave * 2048 + lane * 16;
+    wb[slot][q][0] = *reinterpret_cast<const half8*>(u + q * 8192);
+    wb[slot][q][1] = *reinterpret_cast<const half8*>(u + q * 8192 + 1024);
   };
 #pragma unroll
   for (int q = 0; q < 4; ++q) request_q(0, 0, q);
@@ -233,45 +225,31 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       }
     }
     request_q(1 - slot, step + 1, 0);
-    f32x4 acc[8];
+    f32x4 acc[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 4; ++t) {
       acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][0], bl, acc[t], 0, 0, 0);   // small products first
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][1], bh, acc[t], 0, 0, 0);
       acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[slot][t][0], bh, acc[t], 0, 0, 0);
     }
-    // partial sums of the other waves' tiles -> their owners (unscaled by this K-step's row scale first)
-    f32x4* const xc = xch + slot * (4 * 4 * 2 * 64);
+    // the wave's partial sums of its four tiles (K-step `wave`) -> LDS, [tile][K-step][lane]; unscaled by this K-step's row scale first
+    f32x4* const xc = xch + slot * (8 * 4 * 64);
     const bool fixed_in = bfixed;                      // (workgroup-uniform: every wave's operand came from the same layer)
     if (!fixed_in) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) acc[t] *= brs;
+      for (int t = 0; t < 4; ++t) acc[t] *= brs;
     }
-    f32x4 s0, s1;
-    auto give = [&](auto W_) __attribute__((always_inline)) {
-      constexpr int w = decltype(W_)::value;
 #pragma unroll
-      for (int o = 0; o < 4; ++o) {
-        if (o == w) continue;
-        xc[((o * 4 + w) * 2 + 0) * 64 + lane] = acc[2 * o];
-        xc[((o * 4 + w) * 2 + 1) * 64 + lane] = acc[2 * o + 1];
-      }
-      s0 = acc[2 * w], s1 = acc[2 * w + 1];
-    };
-    switch (wave) {
-      case 0: give(IC_<0>{}); break;
-      case 1: give(IC_<1>{}); break;
-      case 2: give(IC_<2>{}); break;
-      default: give(IC_<3>{}); break;
-    }
+    for (int t = 0; t < 4; ++t) xc[((4 * hf + t) * 4 + wave) * 64 + lane] = acc[t];
     request_q(1 - slot, step + 1, 1);
     __syncthreads();
+    // both waves of a pair finalise tiles 2 wave and 2 wave + 1: the four K-steps' shares in the order 0, 1, 2, 3
+    f32x4 s0 = xc[((2 * wave) * 4 + 0) * 64 + lane], s1 = xc[((2 * wave + 1) * 4 + 0) * 64 + lane];
 #pragma unroll
-    for (int j = 1; j < 4; ++j) {                      // the other three waves' shares, in the order wave + 1, + 2, + 3 (mod 4)
-      const int src = (wave + j) & 3;
-      s0 += xc[((wave * 4 + src) * 2 + 0) * 64 + lane];
-      s1 += xc[((wave * 4 + src) * 2 + 1) * 64 + lane];
+    for (int src = 1; src < 4; ++src) {
+      s0 += xc[((2 * wave) * 4 + src) * 64 + lane];
+      s1 += xc[((2 * wave + 1) * 4 + src) * 64 + lane];
     }
     request_q(1 - slot, step + 1, 2);
     float v[8];
@@ -291,7 +269,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       }
       if (S.kind == TS_FWD) {
         store_rows(v, S.rows, S.width);
-        if (S.keep >= 0) {
+        if (S.keep >= 0 && hf == 1) {
           f32x4* k = reinterpret_cast<f32x4*>(keep) + ((S.keep * 4 + wave) * 2) * 64 + lane;
           k[0] = f32x4{v[0], v[1], v[2], v[3]};
           k[64] = f32x4{v[4], v[5], v[6], v[7]};
@@ -306,17 +284,17 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
           const float diff = v[e] - tv[e];
           float q;
           if (a.cost_variant == EMX_MEAN_ABS) {
-            if (live) lsum += fabsf(diff);
+            if (live && hf == 0) lsum += fabsf(diff);
             q = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
           } else {
-            if (live) lsum = fmaf(diff, diff, lsum);
+            if (live && hf == 0) lsum = fmaf(diff, diff, lsum);
             q = 2.f * diff;
           }
           v[e] = live ? a.gnorm * q : 0.f;
         }
         {   // the row block's cost share: wave sums, then the four waves in turn
           const float ws = wave_sum(lsum);
-          if (lane == 0) red[wave] = ws;
+          if (lane == 0 && hf == 0) red[wave] = ws;
         }
         store_rows(v, S.rows, S.width);
       }
@@ -353,7 +331,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   if (threadIdx.x == 0 && a.cost_ws != nullptr) a.cost_ws[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * a.gnorm;
 }
 
-__global__ __launch_bounds__(256) void tchain_fused_kernel(const TChainArgs) {
+__global__ __launch_bounds__(512) void tchain_fused_kernel(const TChainArgs) {
   extern __shared__ __align__(16) char lds[];
   const TChainK ka = (TChainK)__builtin_amdgcn_kernarg_segment_ptr();
   tchain_wave(ka, lds);
