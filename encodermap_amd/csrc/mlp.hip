@@ -3408,3 +3408,9 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
 #ifdef EMX_CHAIN_TIMING
 extern "C" int emx_debug_read(void* dst) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(emx_dbg), sizeof(emx_dbg)); }
 #endif
+
+#ifdef TC_STAMP
+extern "C" int emx_debug_tc_stamps(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tc_stamps), sizeof(unsigned long long) * 8 * 32 * 8);
+}
+#endif

@@ -65,11 +65,20 @@ struct TChainArgs {
 constexpr int TC_XCH = 2 * 8 * 4 * 64 * 16;               // bytes: [parity][tile][K-step][lane] x 16
 constexpr int TC_KEEP_BYTES = TC_KEEP * 4 * 8 * 64 * 4;   // [slot][wave][e][lane] floats
 constexpr int TC_FRAG = 8 * 1024;                         // a wave's transposition area: one plane [32 features][16 rows] f16
-constexpr int TC_LDS = TC_XCH + TC_KEEP_BYTES + TC_FRAG + 64;
+constexpr int TC_TAB = 2 * TC_MAXL * (128 + 1) * 4;       // every step's bias (128 floats) and reciprocal weight scale
+constexpr int TC_LDS = TC_XCH + TC_KEEP_BYTES + TC_FRAG + 64 + TC_TAB;
 
 // (the argument record is indexed at run time -- layer tables -- so it is read through the kernel-argument segment itself, scalar
 //  loads from constant memory: indexing the by-value struct makes hipcc copy all of it to scratch)
 typedef const TChainArgs __attribute__((address_space(4))) * TChainK;
+#ifdef TC_STAMP
+__device__ unsigned long long g_tc_stamps[8][32][8];
+#define TCS(step, k) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (blockIdx.x == 0 && lane == 0) g_tc_stamps[wave8][step][k] = t_; } while (0)
+#define TCSV(step, k) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); TCS(step, k); } while (0)
+#else
+#define TCSV(step, k) do {} while (0)
+#define TCS(step, k) do {} while (0)
+#endif
 
 // (ONE copy of the body for the four waves -- the wave index is a scalar register; only the accumulator exchange, which indexes
 //  registers by it, is a four-way switch.  Four instantiations of the whole body were ~80 KB of code for a 64-KB instruction cache.)
@@ -89,6 +98,8 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   float* const keep = reinterpret_cast<float*>(lds + TC_XCH);
   char* const fstage = lds + TC_XCH + TC_KEEP_BYTES + wave8 * 1024;   // the wave's own transposition area: one plane [32 features][16 rows] f16
   float* const red = reinterpret_cast<float*>(lds + TC_XCH + TC_KEEP_BYTES + TC_FRAG);
+  float* const btab = red + 16;                        // [step][128]
+  float* const rtab = btab + 2 * TC_MAXL * 128;        // [step]
   // feature (column) of element e of this lane inside the wave's block of 32: tiles 2 w and 2 w + 1, rows 4 g .. 4 g + 3 of D
   auto fcol = [&](int e) { return 32 * wave + 16 * (e >> 2) + 4 * g + (e & 3); };
 
@@ -166,20 +177,72 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
     }
   };
 
-  // ---- the block's input rows: operand of K-step `wave`, fragments of tensor 0
+  // ---- everything the steps' epilogues read from memory, once, side by side at the head of the launch (a row block is a serial
+  //      chain of ~10 steps on one CU: whatever a step asks memory for is a trip to L2 on its critical path).  Thread (step, j) of a
+  //      pass of 16 steps fetches its record's fields as ordinary memory (one trip), then four biases (a second): two trips in all.
+  const int nsteps = a.nsteps;
+  // (the launch's scalars ONCE, here: read at their places of use the compiler fetched them again per element, each fetch a scalar
+  //  load with a full wait inside a branch -- the cost phase alone took 3 800 cycles)
+  const int cost_off = a.cost_off, cost_n = a.cost_n, cost_variant = a.cost_variant, in_cols = a.in_cols;
+  const float gnorm = a.gnorm;
+  TCS(30, 0);
+  {
+    const TStep* const gs = (const TStep*)(const void*)&a.steps[0];
+    for (int s0 = 0; s0 < nsteps; s0 += 16) {
+      const int st = s0 + (threadIdx.x >> 5), j = threadIdx.x & 31;
+      const TStep* K = gs + min(st, nsteps - 1);
+      const float* bp = K->bias;
+      const float* rp = K->rsw;
+      const int kind = K->kind, w = K->width;
+      const bool has = kind <= TS_FWD_TOP && bp != nullptr;
+      const float* b4 = has ? bp : rp;                  // (an address that exists either way: no conditional loads)
+      const int wm = has ? w - 1 : 0;
+      float bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bv[r] = b4[min(4 * j + r, wm)];
+      const float rv = *rp;
+      if (st < nsteps) {
+        *reinterpret_cast<f32x4*>(btab + st * 128 + 4 * j) = has ? f32x4{bv[0], bv[1], bv[2], bv[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j == 0) rtab[st] = rv;
+      }
+    }
+  }
+  // the block's input rows (operand of K-step `wave`, fragments of tensor 0) and the cost's targets: 16 bytes per lane and tile where
+  // the rows allow it (a lane's four features of a tile are contiguous) -- as single floats the 16 requests of a wave touch 16 lines
+  // each, 2 000 cycles of the CU's load path before the first product
+  auto load_block = [&](const float* base, const long ld, const int off, const int ncol, float (&x)[8]) __attribute__((always_inline)) {
+    const bool vec = ((ld | off | ncol) & 3) == 0 && (reinterpret_cast<unsigned long long>(base) & 15) == 0 && ncol >= 4;
+    if (vec) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int c = 32 * wave + 16 * q + 4 * g - off;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(base + grow * ld + min(max(c, 0), ncol - 4));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) x[4 * q + r] = t[r];
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = base[grow * ld + min(max(fcol(e) - off, 0), ncol - 1)];   // (clamped: the VALUES are masked)
+    }
+  };
+  float tv[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) tv[e] = 0.f;
+  if (a.target != nullptr) load_block(a.target, a.ldt, cost_off, cost_n, tv);
   {
     float x[8];
+    load_block(a.in, a.ld_in, 0, in_cols, x);
+    TCSV(30, 3);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int c = fcol(e);   // (= 32 wave + kk(g, e): operand order and block order agree)
-      x[e] = (rok && c < a.in_cols) ? a.in[grow * a.ld_in + min(c, a.in_cols - 1)] : 0.f;
-    }
+    for (int e = 0; e < 8; ++e) x[e] = (rok & (fcol(e) < in_cols)) ? x[e] : 0.f;
+    TCSV(30, 4);
     make_operand(x, false);
+    TCS(30, 5);
     emit_fragments(AopTensor{a.in_frag, a.in_rscale, a.in_CG});
+    TCSV(30, 6);
   }
 
   half8 wb[2][4][2];   // a register ring of two steps: the wave's pieces of its four tiles
-  const int nsteps = a.nsteps;
   auto unit_of = [&](int step) -> const char* {
     const int s = min(step, nsteps - 1);
     return s < a.nl ? a.units_fwd + (long)s * WOP_UNIT : a.units_bwd + (long)(s - a.nl) * WOP_UNIT;
@@ -196,10 +259,14 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) request_q(0, 0, q);
   float lsum = 0.f;
+  TCS(30, 1);
+  __syncthreads();   // the tables
+  TCS(30, 2);
 
   auto step_fn = [&](const int step, auto SLOT_) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOT_)::value;
     if (step >= nsteps) return;                       // (workgroup-uniform)
+    TCS(step, 0);
     // the step's record, and everything its epilogue reads from memory, IN FRONT of the next layer's pieces: the memory counter is in
     // order, and a wait for a bias behind sixteen piece requests would be a wait for all of them
     TStep S;
@@ -208,21 +275,13 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       S.bias = K.bias, S.rows = K.rows, S.frag = K.frag, S.rscale = K.rscale, S.rsw = K.rsw;
       S.width = K.width, S.act = K.act, S.keep = K.keep, S.CG = K.CG, S.kind = K.kind;
     }
-    const float rsw = *S.rsw;
-    float ev[8], tv[8];
+    const float rsw = rtab[step];
+    float ev[8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 4 * g);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 16 + 4 * g);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) ev[e] = tv[e] = 0.f;
-    if (S.kind <= TS_FWD_TOP) {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) ev[e] = S.bias[min(fcol(e), S.width - 1)];
-      if (S.kind == TS_FWD_TOP) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const int c = fcol(e);
-          const bool live = rok && c >= a.cost_off && c < a.cost_off + a.cost_n;
-          tv[e] = live ? a.target[grow * a.ldt + (c - a.cost_off)] : 0.f;
-        }
-      }
+      for (int e = 0; e < 4; ++e) ev[e] = b0[e], ev[4 + e] = b1[e];
     }
     request_q(1 - slot, step + 1, 0);
     f32x4 acc[4];
@@ -243,7 +302,9 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) xc[((4 * hf + t) * 4 + wave) * 64 + lane] = acc[t];
     request_q(1 - slot, step + 1, 1);
+    TCS(step, 1);
     __syncthreads();
+    TCS(step, 2);
     // both waves of a pair finalise tiles 2 wave and 2 wave + 1: the four K-steps' shares in the order 0, 1, 2, 3
     f32x4 s0 = xc[((2 * wave) * 4 + 0) * 64 + lane], s1 = xc[((2 * wave + 1) * 4 + 0) * 64 + lane];
 #pragma unroll
@@ -252,6 +313,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       s1 += xc[((2 * wave + 1) * 4 + src) * 64 + lane];
     }
     request_q(1 - slot, step + 1, 2);
+    TCS(step, 3);
     float v[8];
     const float cm = fixed_in ? rsw * TANH_RS : rsw;
     // (b) a full block of a full-width layer needs no masks
@@ -265,7 +327,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       }
       if (!full) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (rok && fcol(e) < S.width) ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (rok & (fcol(e) < S.width)) ? v[e] : 0.f;
       }
       if (S.kind == TS_FWD) {
         store_rows(v, S.rows, S.width);
@@ -276,21 +338,19 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
         }
       } else {
         // ---- the auto cost on the output rows (h of the top layer is kept as float32 rows if asked for: S.bias doubles as nothing
-        //      here -- the rows pointer is d cost / d output's); delta_top replaces the output in place
+        //      here -- the rows pointer is d cost / d output's); delta_top replaces the output in place.  Selects, no branches: both
+        //      variants' terms are three instructions
+        const bool abs_variant = cost_variant == EMX_MEAN_ABS;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = fcol(e);
-          const bool live = rok && c >= a.cost_off && c < a.cost_off + a.cost_n;
+          const bool live = rok & (c >= cost_off) & (c < cost_off + cost_n);
           const float diff = v[e] - tv[e];
-          float q;
-          if (a.cost_variant == EMX_MEAN_ABS) {
-            if (live && hf == 0) lsum += fabsf(diff);
-            q = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
-          } else {
-            if (live && hf == 0) lsum = fmaf(diff, diff, lsum);
-            q = 2.f * diff;
-          }
-          v[e] = live ? a.gnorm * q : 0.f;
+          const float sgn = (diff > 0.f) ? 1.f : ((diff < 0.f) ? -1.f : 0.f);
+          const float term = abs_variant ? fabsf(diff) : diff * diff;
+          const float q = abs_variant ? sgn : 2.f * diff;
+          lsum += (live & (hf == 0)) ? term : 0.f;
+          v[e] = live ? gnorm * q : 0.f;
         }
         {   // the row block's cost share: wave sums, then the four waves in turn
           const float ws = wave_sum(lsum);
@@ -306,7 +366,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       }
       if (!full) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (rok && fcol(e) < S.width) ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = (rok & (fcol(e) < S.width)) ? v[e] : 0.f;
       }
       if (S.act == ACT_TANH) {
         const f32x4* k = reinterpret_cast<const f32x4*>(keep) + ((S.keep * 4 + wave) * 2) * 64 + lane;
@@ -320,15 +380,19 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       store_rows(v, S.rows, S.width);
     }
     request_q(1 - slot, step + 1, 3);
+    TCS(step, 4);
     make_operand(v, S.kind == TS_FWD && S.act == ACT_TANH);
+    TCS(step, 5);
     emit_fragments(AopTensor{S.frag, S.rscale, S.CG});
+    TCS(step, 6);
   };
   for (int step = 0; step < nsteps; step += 2) {
     step_fn(step, IC_<0>{});
     step_fn(step + 1, IC_<1>{});
   }
+  TCS(31, 0);
   __syncthreads();
-  if (threadIdx.x == 0 && a.cost_ws != nullptr) a.cost_ws[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * a.gnorm;
+  if (threadIdx.x == 0 && a.cost_ws != nullptr) a.cost_ws[blockIdx.x] = (((red[0] + red[1]) + red[2]) + red[3]) * gnorm;
 }
 
 __global__ __launch_bounds__(512) void tchain_fused_kernel(const TChainArgs) {
