@@ -65,7 +65,7 @@ struct TChainArgs {
 constexpr int TC_XCH = 2 * 8 * 4 * 64 * 16;               // bytes: [parity][tile][K-step][lane] x 16
 constexpr int TC_KEEP_BYTES = TC_KEEP * 4 * 8 * 64 * 4;   // [slot][wave][e][lane] floats
 constexpr int TC_FRAG = 8 * 1024;                         // a wave's transposition area: one plane [32 features][16 rows] f16
-constexpr int TC_TAB = 2 * TC_MAXL * (128 + 1) * 4;       // every step's bias (128 floats) and reciprocal weight scale
+constexpr int TC_TAB = 2 * TC_MAXL * (128 + 32) * 4;      // every step's bias (128 floats) and reciprocal weight scale (x 32)
 constexpr int TC_LDS = TC_XCH + TC_KEEP_BYTES + TC_FRAG + 64 + TC_TAB;
 
 // (the argument record is indexed at run time -- layer tables -- so it is read through the kernel-argument segment itself, scalar
@@ -99,7 +99,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   char* const fstage = lds + TC_XCH + TC_KEEP_BYTES + wave8 * 1024;   // the wave's own transposition area: one plane [32 features][16 rows] f16
   float* const red = reinterpret_cast<float*>(lds + TC_XCH + TC_KEEP_BYTES + TC_FRAG);
   float* const btab = red + 16;                        // [step][128]
-  float* const rtab = btab + 2 * TC_MAXL * 128;        // [step]
+  float* const rtab = btab + 2 * TC_MAXL * 128;        // [step][32 copies]
   // feature (column) of element e of this lane inside the wave's block of 32: tiles 2 w and 2 w + 1, rows 4 g .. 4 g + 3 of D
   auto fcol = [&](int e) { return 32 * wave + 16 * (e >> 2) + 4 * g + (e & 3); };
 
@@ -162,18 +162,17 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   };
   // the wave's block as float32 rows [*, width]
   auto store_rows = [&](const float (&v)[8], float* dst, int width) __attribute__((always_inline)) {
-    if (dst == nullptr || !rok || hf != 1) return;     // (the pair's second wave stores the rows, its first the fragments)
-    // (a tile's four features of a lane are contiguous: one 16-byte store where the row length allows it)
+    if (dst == nullptr || !rok) return;
+    // (the pair's two waves hold the same block: wave hf stores tile hf of the two.  A tile's four features of a lane are contiguous:
+    //  one 16-byte store where the row length allows it)
+    const int c = 32 * wave + 16 * hf + 4 * g;
+    const f32x4 t = hf ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{v[0], v[1], v[2], v[3]};
+    if (c + 3 < width && (width & 3) == 0) {
+      *reinterpret_cast<f32x4*>(dst + grow * width + c) = t;
+    } else {
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int c = 32 * wave + 16 * q + 4 * g;
-      if (c + 3 < width && (width & 3) == 0) {
-        *reinterpret_cast<f32x4*>(dst + grow * width + c) = f32x4{v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-      } else {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          if (c + r < width) dst[grow * width + c + r] = v[4 * q + r];
-      }
+      for (int r = 0; r < 4; ++r)
+        if (c + r < width) dst[grow * width + c + r] = t[r];
     }
   };
 
@@ -186,27 +185,20 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   const int cost_off = a.cost_off, cost_n = a.cost_n, cost_variant = a.cost_variant, in_cols = a.in_cols;
   const float gnorm = a.gnorm;
   TCS(30, 0);
-  {
-    const TStep* const gs = (const TStep*)(const void*)&a.steps[0];
-    for (int s0 = 0; s0 < nsteps; s0 += 16) {
-      const int st = s0 + (threadIdx.x >> 5), j = threadIdx.x & 31;
-      const TStep* K = gs + min(st, nsteps - 1);
-      const float* bp = K->bias;
-      const float* rp = K->rsw;
-      const int kind = K->kind, w = K->width;
-      const bool has = kind <= TS_FWD_TOP && bp != nullptr;
-      const float* b4 = has ? bp : rp;                  // (an address that exists either way: no conditional loads)
-      const int wm = has ? w - 1 : 0;
-      float bv[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bv[r] = b4[min(4 * j + r, wm)];
-      const float rv = *rp;
-      if (st < nsteps) {
-        *reinterpret_cast<f32x4*>(btab + st * 128 + 4 * j) = has ? f32x4{bv[0], bv[1], bv[2], bv[3]} : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j == 0) rtab[st] = rv;
-      }
-    }
-  }
+  half8 wb[2][4][2];   // a register ring of two steps: the wave's pieces of its four tiles
+  auto unit_of = [&](int step) -> const char* {
+    const int s = min(step, nsteps - 1);
+    return s < a.nl ? a.units_fwd + (long)s * WOP_UNIT : a.units_bwd + (long)(s - a.nl) * WOP_UNIT;
+  };
+  // A wave's 16 pieces of the NEXT step, a quarter at a time: the four waves of a workgroup pull 64 KB per step through the CU's
+  // 64-byte-per-clock load path (>= 1 024 cycles) -- requested in one burst at the head of the step the waves stall on issue behind
+  // their own requests (the products phase took 1 200 cycles instead of 400); in quarters between the phases the stream runs beside
+  // the work
+  auto request_q = [&](const int slot, const int step, const int q) __attribute__((always_inline)) {
+    const char* u = unit_of(step) + (4 * hf) * 8192 + wave * 2048 + lane * 16;
+    wb[slot][q][0] = *reinterpret_cast<const half8*>(u + q * 8192);
+    wb[slot][q][1] = *reinterpret_cast<const half8*>(u + q * 8192 + 1024);
+  };
   // the block's input rows (operand of K-step `wave`, fragments of tensor 0) and the cost's targets: 16 bytes per lane and tile where
   // the rows allow it (a lane's four features of a tile are contiguous) -- as single floats the 16 requests of a wave touch 16 lines
   // each, 2 000 cycles of the CU's load path before the first product
@@ -225,43 +217,47 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       for (int e = 0; e < 8; ++e) x[e] = base[grow * ld + min(max(fcol(e) - off, 0), ncol - 1)];   // (clamped: the VALUES are masked)
     }
   };
-  float tv[8];
+  // The tables: wave w8 fetches steps w8, w8 + 8, w8 + 16 -- the step is wave-uniform, so the records come through the scalar cache
+  // (the argument segment), ahead of everything; the biases (two per lane and step) and scales are the one vector trip, requested
+  // behind the input rows and the first layer's pieces.  No conditions: indices beyond the last step repeat it (same values, same
+  // places), so that all of it is one basic block and every request is in flight before the first wait.
+  struct Trip { const float* bp; const float* rp; int kind, w, st; float rv; };
+  Trip tr[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int st = min(wave8 + 8 * i, nsteps - 1);
+    const auto& K = a.steps[st];
+    tr[i] = Trip{K.bias, K.rsw, K.kind, K.width, st, 0.f};
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) tr[i].rv = *tr[i].rp;
+  float tv[8], x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) tv[e] = 0.f;
+  load_block(a.in, a.ld_in, 0, in_cols, x);
   if (a.target != nullptr) load_block(a.target, a.ldt, cost_off, cost_n, tv);
-  {
-    float x[8];
-    load_block(a.in, a.ld_in, 0, in_cols, x);
-    TCSV(30, 3);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) x[e] = (rok & (fcol(e) < in_cols)) ? x[e] : 0.f;
-    TCSV(30, 4);
-    make_operand(x, false);
-    TCS(30, 5);
-    emit_fragments(AopTensor{a.in_frag, a.in_rscale, a.in_CG});
-    TCSV(30, 6);
-  }
-
-  half8 wb[2][4][2];   // a register ring of two steps: the wave's pieces of its four tiles
-  auto unit_of = [&](int step) -> const char* {
-    const int s = min(step, nsteps - 1);
-    return s < a.nl ? a.units_fwd + (long)s * WOP_UNIT : a.units_bwd + (long)(s - a.nl) * WOP_UNIT;
-  };
-  // A wave's 16 pieces of the NEXT step, a quarter at a time: the four waves of a workgroup pull 64 KB per step through the CU's
-  // 64-byte-per-clock load path (>= 1 024 cycles) -- requested in one burst at the head of the step the waves stall on issue behind
-  // their own requests (the products phase took 1 200 cycles instead of 400); in quarters between the phases the stream runs beside
-  // the work
-  auto request_q = [&](const int slot, const int step, const int q) __attribute__((always_inline)) {
-    const char* u = unit_of(step) + (4 * hf) * 8192 + wave * 2048 + lane * 16;
-    wb[slot][q][0] = *reinterpret_cast<const half8*>(u + q * 8192);
-    wb[slot][q][1] = *reinterpret_cast<const half8*>(u + q * 8192 + 1024);
-  };
 #pragma unroll
   for (int q = 0; q < 4; ++q) request_q(0, 0, q);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const Trip& t = tr[i];
+    const bool has = t.kind <= TS_FWD_TOP && t.bp != nullptr;
+    const float* b2 = has ? t.bp : t.rp;                // (an address that exists either way: no conditional loads)
+    const int wm = has ? t.w - 1 : 0;
+    const float b0 = b2[min(lane, wm)], b1 = b2[min(64 + lane, wm)];
+    const float rv = t.rv;
+    btab[t.st * 128 + lane] = has ? b0 : 0.f;
+    btab[t.st * 128 + 64 + lane] = has ? b1 : 0.f;
+    rtab[t.st * 32 + (lane & 31)] = rv;
+  }
+  TCS(30, 3);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = (rok & (fcol(e) < in_cols)) ? x[e] : 0.f;
+  TCS(30, 4);
+  make_operand(x, false);
+  TCS(30, 5);
   float lsum = 0.f;
-  TCS(30, 1);
-  __syncthreads();   // the tables
-  TCS(30, 2);
+  // (no barrier here: the tables are read behind the first step's barrier; the input's fragments leave behind its products)
 
   auto step_fn = [&](const int step, auto SLOT_) __attribute__((always_inline)) {
     constexpr int slot = decltype(SLOT_)::value;
@@ -274,14 +270,6 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       const auto& K = a.steps[step];                  // (constant address space: field by field, the loads merge into one)
       S.bias = K.bias, S.rows = K.rows, S.frag = K.frag, S.rscale = K.rscale, S.rsw = K.rsw;
       S.width = K.width, S.act = K.act, S.keep = K.keep, S.CG = K.CG, S.kind = K.kind;
-    }
-    const float rsw = rtab[step];
-    float ev[8];
-    {
-      const f32x4 b0 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 4 * g);
-      const f32x4 b1 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 16 + 4 * g);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) ev[e] = b0[e], ev[4 + e] = b1[e];
     }
     request_q(1 - slot, step + 1, 0);
     f32x4 acc[4];
@@ -302,9 +290,19 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) xc[((4 * hf + t) * 4 + wave) * 64 + lane] = acc[t];
     request_q(1 - slot, step + 1, 1);
+    if (slot == 0 && step == 0) emit_fragments(AopTensor{a.in_frag, a.in_rscale, a.in_CG});   // (the operand is the input's until the epilogue)
     TCS(step, 1);
     __syncthreads();
     TCS(step, 2);
+    // the step's bias and weight scale from the tables of the prologue (written in front of this barrier at the latest)
+    const float rsw = rtab[step * 32];
+    float ev[8];
+    {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 4 * g);
+      const f32x4 b1 = *reinterpret_cast<const f32x4*>(btab + step * 128 + 32 * wave + 16 + 4 * g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ev[e] = b0[e], ev[4 + e] = b1[e];
+    }
     // both waves of a pair finalise tiles 2 wave and 2 wave + 1: the four K-steps' shares in the order 0, 1, 2, 3
     f32x4 s0 = xc[((2 * wave) * 4 + 0) * 64 + lane], s1 = xc[((2 * wave + 1) * 4 + 0) * 64 + lane];
 #pragma unroll
@@ -331,10 +329,9 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       }
       if (S.kind == TS_FWD) {
         store_rows(v, S.rows, S.width);
-        if (S.keep >= 0 && hf == 1) {
+        if (S.keep >= 0) {
           f32x4* k = reinterpret_cast<f32x4*>(keep) + ((S.keep * 4 + wave) * 2) * 64 + lane;
-          k[0] = f32x4{v[0], v[1], v[2], v[3]};
-          k[64] = f32x4{v[4], v[5], v[6], v[7]};
+          k[64 * hf] = hf ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{v[0], v[1], v[2], v[3]};
         }
       } else {
         // ---- the auto cost on the output rows (h of the top layer is kept as float32 rows if asked for: S.bias doubles as nothing

@@ -36,8 +36,7 @@ st = st.astype(np.int64)
 t0 = st[:, 30, 0].min()
 names = ["top", "products+share", "barrier", "sums", "epilogue", "operand", "fragments"]
 print("s_memtime ticks (100 MHz constant clock on gfx9: x ~24 for core cycles) relative to the first wave's entry")
-print("prologue: entry", st[:, 30, 0] - t0, "\n tables arrived", st[:, 30, 3] - t0, "\n input arrived", st[:, 30, 4] - t0, "\n operand", st[:, 30, 5] - t0,
-      "\n fragments stored", st[:, 30, 6] - t0, "\n first pieces requested", st[:, 30, 1] - t0, "\n barrier", st[:, 30, 2] - t0)
+print("prologue: entry", st[:, 30, 0] - t0, "\n tables stored", st[:, 30, 3] - t0, "\n input masked", st[:, 30, 4] - t0, "\n operand", st[:, 30, 5] - t0)
 nsteps = 2 * n - lay.n_enc
 for s in range(nsteps):
     row = st[:, s, :7] - t0
