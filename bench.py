@@ -353,13 +353,18 @@ def kernel_rooflines(name, eng, launches):
                          "pair-element over the upper triangle (SURVEY.md section 8d), executed three times", abytes, flops_8d=3 * W)
         recs.append(sk)
     if cfg["model"] == "encodermap" and (eng.rb, eng.re) == (0, Bt):
+        c0 = _lib.load().emx_transposed_chain_count()
         fused = eng._forward()
+        transposed = _lib.load().emx_transposed_chain_count() > c0      # (csrc/tchain.h took the launch: small non-periodic networks)
         t_ch = _time_launches(eng._forward, launches)
         mults = Bt * (sum(k * m for k, m in dims) + (sum(k * m for k, m in dims[lay.n_enc:]) if fused else 0))
-        recs.append(_record(name, "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>", "chain_kernel<FUSED>" if fused else "chain_kernel<FWD>",
+        kname = "tchain_fused_kernel" if transposed else ("chain_kernel<FUSED>" if fused else "chain_kernel<FWD>")
+        recs.append(_record(name, kname, kname,
                             t_ch, 2 * mults, 6 * mults, F16_PEAK, "mfma-f16", "issue", ISSUE,
                             ("forward of all layers, auto cost and the decoder's backward pass" if fused else "forward of all layers (+ auto cost)")
-                            + " in one launch per 16-row block; weights from the pre-split operand store, activations split in the epilogue; "
+                            + (" in one launch per 16-row block as the transposed chain (H^T = W^T X^T: a layer's accumulators are the next "
+                               "layer's operand registers); weights from the pre-split operand store; " if transposed else
+                               " in one launch per 16-row block; weights from the pre-split operand store, activations split in the epilogue; ")
                             "algorithmic bytes: the batch in, activations + deltas out as f16 fragments for the weight-gradient kernel, one "
                             "pass over the weights", 4 * Bt * dims[0][0] + 4 * Bt * sum(m for _, m in dims) * 2 + 4 * n_par))
     if cfg["model"] == "adc":

@@ -47,6 +47,7 @@ SIGNATURES = {
     "emx_last_error": (C.c_char_p, []),
     "emx_target_arch": (C.c_char_p, []),
     "emx_launch_count": (_l, []),
+    "emx_transposed_chain_count": (_l, []),
     "emx_forget_counters": (None, [_p]),
     "emx_sketchmap_ws_bytes": (_sz, [_i, _i]),
     "emx_sketchmap_fwd_bwd": (_i, [_p, _i, _i, _i, _p, _i, _f, _f, C.POINTER(_f), _f, _f, _i, _i, _p, _p, _p, _p, _sz, _p]),

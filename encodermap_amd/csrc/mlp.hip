@@ -2741,16 +2741,22 @@ int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, s
   return launch_chain_tiles_impl<FAST, NCH, KIND, false>(b, tr, grid, lds, st);
 }
 
+std::atomic<long long> g_tchain_launches{0};
+
 // The fused launch of a SMALL network as the transposed, register-resident chain (tchain.h).  EMX_EUNSUPPORTED (no message): the
-// network or the cost is not what that kernel is built for -- the row-block chain kernel takes it.  EMX_TCHAIN=0: never.
+// network, the cost or the number of row blocks is not what that kernel is built for -- the row-block chain kernel takes it.
 int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in, int ld_in, int row_begin,
                int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin, float* const* delta, float* dbelow, void* aop, int aop_rows,
                const char* who, emx_stream_t stream) {
-  // OFF unless EMX_TCHAIN=1: correct (tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle), and at 4096 rows slower
-  // than the row-block chain kernel (22.4-22.8 against 19.1-19.6 us for the fused launch, step 67.7-68.2 against 65.2-65.6,
-  // profiles/r05_tchain_ab.txt) -- DESIGN.md section 8 says where its steps' ~4 000 cycles go and what it needs
-  static const bool enabled = getenv("EMX_TCHAIN") && atoi(getenv("EMX_TCHAIN")) == 1;
+  // Taken while the launch is ONE round of workgroups (row blocks <= compute units: 117 KB of LDS, one workgroup per unit) -- there
+  // a step with it is 2 us shorter than with the row-block chain kernel (63.6 against 65.6 us at 4096 x 128, profiles/r05_tchain_ab.txt);
+  // beyond, two row-block workgroups share a unit and that kernel wins (8192 rows: 32.7 against 36 us for the launch alone).
+  // EMX_TCHAIN=1: whenever the network qualifies; EMX_TCHAIN=0: never.
+  // (read per call -- a call is one launch recorded into a graph, not a step: tests compare the two kernels inside one process)
+  const char* const env = getenv("EMX_TCHAIN");
+  const int mode = env ? atoi(env) : -1;
   static const int max_rows = getenv("EMX_TCHAIN_MAX_ROWS") ? atoi(getenv("EMX_TCHAIN_MAX_ROWS")) : 1 << 30;
+  const bool enabled = mode == 1 || (mode < 0 && (row_end - row_begin + R - 1) / R <= device_cus());
   const int n = desc->n_layers, top = layer_end - 1;
   if (!enabled || layer_begin != 0 || layer_end != n || n > TC_MAXL || row_end - row_begin > max_rows) return EMX_EUNSUPPORTED;
   for (int l = 0; l <= n; ++l)
@@ -2795,7 +2801,7 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
       S.rows = delta[top];
       const AopTensor t = tensor(1 + n + top);
       S.frag = t.frag, S.rscale = t.rscale, S.CG = t.CG;
-      if (h[top] != nullptr) return EMX_EUNSUPPORTED;  // (the output rows themselves are not kept by this kernel)
+      a.top_rows = h[top];
     }
   }
   a.nl = n;
@@ -2844,6 +2850,7 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
   int rc = set_lds(reinterpret_cast<const void*>(&tchain_fused_kernel), TC_LDS, who, 0);
   if (rc) return rc;
   const int grid = (row_end - row_begin + R - 1) / R;
+  g_tchain_launches.fetch_add(1, std::memory_order_relaxed);
   hipLaunchKernelGGL(tchain_fused_kernel, dim3(grid), dim3(512), TC_LDS, (hipStream_t)stream, a);
   return emx::check_launch("transposed chain kernel (forward + cost + backward)");
 }
@@ -3014,6 +3021,8 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
 }  // namespace
 
 extern "C" {
+
+int64_t emx_transposed_chain_count(void) { return (int64_t)g_tchain_launches.load(std::memory_order_relaxed); }
 
 int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                              int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,

@@ -56,6 +56,7 @@ struct TChainArgs {
   const char* units_fwd;   // unit of layer 0; layer l: + l * 64 KB
   const char* units_bwd;   // unit of the top layer in the backward direction; layer top - j: + j * 64 KB
   const float* target;
+  float* top_rows;         // the output rows h_top as float32 rows; NULL: not kept
   float* cost_ws;
   int ldt, cost_n, cost_off, cost_variant;
   float gnorm;
@@ -184,6 +185,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   //  load with a full wait inside a branch -- the cost phase alone took 3 800 cycles)
   const int cost_off = a.cost_off, cost_n = a.cost_n, cost_variant = a.cost_variant, in_cols = a.in_cols;
   const float gnorm = a.gnorm;
+  float* const top_rows = a.top_rows;
   TCS(30, 0);
   half8 wb[2][4][2];   // a register ring of two steps: the wave's pieces of its four tiles
   auto unit_of = [&](int step) -> const char* {
@@ -334,8 +336,9 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
           k[64 * hf] = hf ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{v[0], v[1], v[2], v[3]};
         }
       } else {
-        // ---- the auto cost on the output rows (h of the top layer is kept as float32 rows if asked for: S.bias doubles as nothing
-        //      here -- the rows pointer is d cost / d output's); delta_top replaces the output in place.  Selects, no branches: both
+        store_rows(v, top_rows, S.width);                // (the output itself, where somebody reads it)
+        // ---- the auto cost on the output rows (the step's rows pointer is d cost / d output's: delta_top replaces the output in
+        //      place).  Selects, no branches: both
         //      variants' terms are three instructions
         const bool abs_variant = cost_variant == EMX_MEAN_ABS;
 #pragma unroll

@@ -448,6 +448,14 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
 int emx_mlp_forward_backward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                              int ld_in, int row_begin, int row_end, float* const* h, const emx_auto_cost* cost, int bwd_begin,
                              float* const* delta, float* dbelow, void* aop, int aop_rows, emx_stream_t stream);
+/* Two kernels stand behind that entry point.  A network whose every width is <= 128, with tanh / linear layers, a non-periodic
+ * output and the mean_abs or mean_square cost, called on the whole layer range with at most one row block per compute unit, runs as
+ * the TRANSPOSED chain (csrc/tchain.h: H^T = W^T X^T, a layer's accumulators are the next layer's operand registers); everything
+ * else as the row-block chain kernel.  Same precision class (split-f16 x 3 products, float32 accumulation), different order of
+ * summation: results agree to float32 rounding, not bit for bit.  Environment EMX_TCHAIN=0 (read per call) keeps the row-block
+ * kernel everywhere, EMX_TCHAIN=1 takes the transposed chain at any number of row blocks.  emx_transposed_chain_count(): launches of
+ * the transposed chain by this process so far (diagnostics, like emx_launch_count). */
+int64_t emx_transposed_chain_count(void);
 /* The same launch with the ALL-PAIRS TILES of the sketch-map cost aboard (emx_sketchmap_tiles on the batch's split rows; replaces the
  * serial order of SequentialModel.train_step, models/models.py:3367-3401, where loss_functions.py:266-296's distance cost is evaluated
  * after the whole forward pass): the tile pass needs the batch rows and the latent only, so its tiles run as extra workgroups of

@@ -1,5 +1,5 @@
-"""Run by tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle in a process of its own with EMX_TCHAIN=1 (the switch is read
-once per process): the fused dense-layer launch as the transposed, register-resident chain (csrc/tchain.h) against the separate
+"""Run by tests/test_mlp_gpu.py::test_transposed_chain_against_the_oracle in a process of its own with EMX_TCHAIN=1 (the kernel at
+any number of row blocks, not only where it is the default): the fused dense-layer launch as the transposed, register-resident chain (csrc/tchain.h) against the separate
 row-block launches and the float64 reference -- activations, deltas, latent gradient, cost, and the weight gradients formed from the
 fragments it leaves.  Prints one line per case; exits non-zero on a mismatch."""
 import os
@@ -27,7 +27,7 @@ for D, n_neurons, B, variant in CASES:
     Ld = lay.layers[lay.n_enc - 1].n_out
 
     def run(fused):
-        h = [torch.zeros(B, l.n_out, device="cuda") if (i < n - 1 or not fused) else None for i, l in enumerate(lay.layers)]
+        h = [torch.zeros(B, l.n_out, device="cuda") for l in lay.layers]
         dl = [torch.full((B, l.n_out), float("nan"), device="cuda") for l in lay.layers]
         dlat = torch.full((B, Ld), float("nan"), device="cuda")
         plan = L.MlpPlan(lay, params, h, dl, train_rows=B)
@@ -60,7 +60,7 @@ for D, n_neurons, B, variant in CASES:
     cost = 0.7 * (diff.abs().mean() if variant == "mean_abs" else (diff * diff).mean())
     grads = torch.autograd.grad(cost, arrays)
     different = False
-    for i in range(n - 1):
+    for i in range(n):
         a, b, r = h1[i].cpu().numpy(), h2[i].cpu().numpy(), hs[i].detach().numpy()
         np.testing.assert_allclose(b, r, rtol=2e-6, atol=3e-6, err_msg=f"activation {i}")
         different |= not np.array_equal(a, b)

@@ -245,6 +245,9 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, peri
     idx = rng.integers(0, 6000, (steps, B))
     out = []
     monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
+    # (bit for bit is a statement about ONE kernel: small non-periodic networks take the transposed chain for the plain fused launch
+    #  -- another order of summation; the row-block kernel everywhere here, the default's agreement to rounding below)
+    monkeypatch.setenv("EMX_TCHAIN", "0")
     # (overlap, join): the tiles aboard AND the encoder's backward units in the same launch (emx_mlp_forward_backward_tiles_join: the
     # dense-layer workgroups wait inside the launch for the tiles' partial sums) / the tiles aboard / the separate launches
     for overlap, join in ((True, True), (False, False), (True, False)):
@@ -262,6 +265,24 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, peri
         np.testing.assert_array_equal(out[0][2], out[k][2])
     assert (out[0][3] == 0).all() and (out[2][3] == 0).all()      # the launches left their counters at zero, nobody gave up waiting
     assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
+    # the default choice of kernel for the separate launches: where it is the transposed chain (csrc/tchain.h), the same run to
+    # float32 rounding -- losses to 2e-5 relative over the whole run, weights to 2e-4 of their scale (Adam's first steps are sign-like:
+    # a gradient that differs in its last bits moves a weight by the full learning rate)
+    from encodermap_amd import _lib as L
+    monkeypatch.delenv("EMX_TCHAIN")
+    monkeypatch.setattr(SequentialEngine, "_overlap_tiles", False)
+    monkeypatch.setattr(SequentialEngine, "_join_bwd", False)
+    c0 = L.load().emx_transposed_chain_count()
+    p = em.Parameters(periodicity=periodicity, batch_size=B, dist_sig_parameters=sig or (math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps)
+    e = em.EncoderMap(p, data, model=_weights(p, 2 * D if periodicity < INF else D), read_only=True)
+    e._engine.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
+    transposed = L.load().emx_transposed_chain_count() > c0
+    assert transposed == (periodicity == INF and D <= 128 and B <= 16 * torch.cuda.get_device_properties(0).multi_processor_count)
+    if transposed:
+        assert not np.array_equal(e._engine.losses(), out[1][0])      # (it did run: another order of summation)
+    np.testing.assert_allclose(e._engine.losses(), out[1][0], rtol=2e-5)
+    w = e._engine.w.cpu().numpy()
+    np.testing.assert_allclose(w, out[1][1], rtol=0, atol=2e-4 * np.abs(out[1][1]).max())
 
 
 TAIL_CASES = [

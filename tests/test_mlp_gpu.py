@@ -589,8 +589,8 @@ def test_wgrad_adam_local_through_the_abi(L, net_dim, n_neurons, afs, B):
 
 @pytest.mark.gpu
 def test_transposed_chain_against_the_oracle(L):
-    """The fused dense-layer launch as the TRANSPOSED, register-resident chain (csrc/tchain.h; opt-in, EMX_TCHAIN=1 -- the switch is
-    read once per process, hence the process of its own): activations, decoder deltas, latent gradient and cost against the separate
+    """The fused dense-layer launch as the TRANSPOSED, register-resident chain (csrc/tchain.h; the default up to one row block per compute unit,
+    EMX_TCHAIN=1: at any size -- a process of its own keeps the switch away from the other tests): activations, the output rows, decoder deltas, latent gradient and cost against the separate
     row-block launches and float64, and the weight gradients formed from the fragments it leaves (tests/tchain_check.py: full and
     ragged row blocks, narrow inputs, a 3-wide latent)."""
     import os
