@@ -365,7 +365,7 @@ def kernel_rooflines(name, eng, launches):
                             + (" in one launch per 16-row block as the transposed chain (H^T = W^T X^T: a layer's accumulators are the next "
                                "layer's operand registers); weights from the pre-split operand store; " if transposed else
                                " in one launch per 16-row block; weights from the pre-split operand store, activations split in the epilogue; ")
-                            "algorithmic bytes: the batch in, activations + deltas out as f16 fragments for the weight-gradient kernel, one "
+                            + "algorithmic bytes: the batch in, activations + deltas out as f16 fragments for the weight-gradient kernel, one "
                             "pass over the weights", 4 * Bt * dims[0][0] + 4 * Bt * sum(m for _, m in dims) * 2 + 4 * n_par))
     if cfg["model"] == "adc":
         n = len(lay.layers)
