@@ -14,13 +14,16 @@
 // barrier per layer, two copies of the area by layer parity); BOTH waves of a pair (w, 0), (w, 1) then add the four K-steps' shares of
 // tiles 2 w, 2 w + 1 -- the operand of their K-step of the next layer, which each of them needs -- and finalise them identically;
 // that 16 x 32 block is exactly one block of the weight-gradient fragments (aop.h): wave hf of the pair leaves plane hf, transposed
-// through a wave-private LDS area (ds_read_b64_tr_b16); the second wave also stores the float32 rows.  A wave's 8 pieces of a layer travel a whole layer ahead in a register ring of two,
+// through a wave-private LDS area (ds_read_b64_tr_b16) and stores tile hf of the pair's two as float32 rows.  A wave's 8 pieces of a layer travel a whole layer ahead in a register ring of two,
 // requested in quarters between the phases of the step.  The backward GEMMs are the same picture on the backward units (delta^T_{l-1} = W_l delta^T_l), the
-// activation derivative taken from the layer's output kept in the SAME register layout.  Measured as a microbenchmark
-// (tools/ubench_tchain.hip, profiles/r05_tchain_ubench.txt): 2 180 cycles per 128 x 128 tanh layer.
-// Built for: every width of the range <= 128 (one unit per layer), tanh / linear layers, a non-periodic output with mean_abs or
-// mean_square, the whole network forward and the backward pass down to bwd_begin.  Arithmetic: three f16 products per float32
-// product on operands split into two planes with a power-of-two scale per (row, 32 features) -- the chain kernels' precision class.
+// activation derivative taken from the layer's output kept in the SAME register layout.  The prologue is written for latency: the
+// step records come through the scalar cache (wave-uniform indices), every memory request of the launch's head -- input rows,
+// targets, the first layer's pieces, all steps' biases and weight scales (-> LDS tables) -- is in flight before the first wait, the
+// launch's scalars are read once (DESIGN.md section 4 round 5 (d) has the stamps that asked for each of these).
+// The default fused launch for: every width of the range <= 128 (one unit per layer), tanh / linear layers, a non-periodic output with
+// mean_abs or mean_square, the whole network forward and the backward pass down to bwd_begin, at most one row block per compute unit
+// (mlp.hip: try_tchain).  Arithmetic: three f16 products per float32 product on operands split into two planes with a power-of-two
+// scale per (row, 32 features) -- the chain kernels' precision class, another order of summation.
 #pragma once
 
 constexpr int TC_MAXL = EMX_MAX_LAYERS;

@@ -383,10 +383,14 @@ def test_adam_gathers_the_next_batch(L, periodicity, D, B):
 @pytest.mark.parametrize("periodicity,variant,D,B,n_neurons", [
     (float("inf"), "mean_square", 128, 4096, [128, 128, 2]), (2 * np.pi, "mean_abs", 10, 256, [128, 128, 2]),
     (360.0, "mean_norm", 37, 100, [64, 48, 3]), (float("inf"), "mean_abs", 150, 40, [136, 20, 2])])
-def test_forward_backward_in_one_launch_equals_two(L, periodicity, variant, D, B, n_neurons):
+def test_forward_backward_in_one_launch_equals_two(L, periodicity, variant, D, B, n_neurons, monkeypatch):
     """emx_mlp_forward_backward (forward, auto cost, decoder backward in one launch, activations kept in LDS) against
-    emx_mlp_forward_cost followed by emx_mlp_backward: the same activations, deltas, latent gradient and cost."""
+    emx_mlp_forward_cost followed by emx_mlp_backward: the same activations, deltas, latent gradient and cost -- a statement about
+    the row-block chain kernel (EMX_TCHAIN=0: the first case's network would otherwise take the transposed chain, whose own
+    comparison with the separate launches -- to rounding, another order of summation -- is test_transposed_chain_against_the_oracle)."""
     from encodermap_amd.layout import build_layout, init_parameters
+
+    monkeypatch.setenv("EMX_TCHAIN", "0")
 
     periodic = np.isfinite(periodicity)
     net_dim = 2 * D if periodic else D
