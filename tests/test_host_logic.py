@@ -362,7 +362,11 @@ def test_bench_launches_its_own_ranks(tmp_path):
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["steps"] == 7 and line["warmup"] == 3 and line["value"] == 3.0
-    assert line["config"]["ranks_seen"] == 2 and line["config"]["allreduce"] == "probe decides"
+    assert line["config"]["ranks_seen"] == 2
+    # (the first attempt, as a rule; a rendezvous that loses its port to another test's lingering socket is exactly what the retry
+    #  is for -- then the launcher must have said so)
+    assert line["config"]["allreduce"] == "probe decides" or (line["config"]["allreduce"] == "eager (forced)"
+                                                              and "repeating it with the eager all-reduce" in r.stderr), r.stderr[-2000:]
     assert line["config"]["probe_port_agreed"] is True      # (rank 0's free port, learnt by every rank over a short-lived gloo group)
     assert "a stray line from a rank" in r.stderr          # (relayed, but not on stdout)
     # the ranks under the launcher DIRECTLY (the driver's form for N > 1), one of them never coming back: the watchdog ends the run
