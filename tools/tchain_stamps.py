@@ -35,7 +35,7 @@ assert lib.emx_debug_tc_stamps(st.ctypes.data) == 0
 st = st.astype(np.int64)
 t0 = st[:, 30, 0].min()
 names = ["top", "products+share", "barrier", "sums", "epilogue", "operand", "fragments"]
-print("s_memtime ticks (100 MHz constant clock on gfx9: x ~24 for core cycles) relative to the first wave's entry")
+print("s_memtime ticks (shader-clock cycles on this part: ~54 000 of them were a 22-us launch) relative to the first wave's entry; min..max over the eight waves")
 print("prologue: entry", st[:, 30, 0] - t0, "\n tables stored", st[:, 30, 3] - t0, "\n input masked", st[:, 30, 4] - t0, "\n operand", st[:, 30, 5] - t0)
 nsteps = 2 * n - lay.n_enc
 for s in range(nsteps):
