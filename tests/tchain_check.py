@@ -15,8 +15,11 @@ from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
 assert os.environ.get("EMX_TCHAIN") == "1"
 L.require_gpu()
 L.load()
-CASES = [(128, [128, 128, 2], 4096, "mean_abs"), (128, [128, 128, 2], 300, "mean_square"), (50, [64, 3], 77, "mean_abs"), (20, [128, 96, 2], 16, "mean_square")]
-for D, n_neurons, B, variant in CASES:
+# D, n_neurons, rows of the buffers (= the batch size of the cost's normalisation), cost, first row of the launch (a data-parallel
+# rank's run of row blocks starts inside the batch)
+CASES = [(128, [128, 128, 2], 4096, "mean_abs", 0), (128, [128, 128, 2], 300, "mean_square", 0), (50, [64, 3], 77, "mean_abs", 0),
+         (20, [128, 96, 2], 16, "mean_square", 0), (128, [128, 128, 2], 1000, "mean_abs", 208), (33, [96, 2], 160, "mean_square", 48)]
+for D, n_neurons, B, variant, rb in CASES:
     afs = [""] + ["tanh"] * (len(n_neurons) - 1) + [""]
     lay = build_layout(n_neurons, afs, D)
     n = len(lay.layers)
@@ -34,14 +37,14 @@ for D, n_neurons, B, variant in CASES:
         cost_ws = torch.zeros(L.mlp_row_blocks(B), device="cuda")
         cost = L.make_auto_cost(xb, D, 0, D, False, float("inf"), variant, 0.7, B, dl[-1], cost_ws)
         if fused:
-            L.mlp_forward_backward(plan, 0, n, xb, 0, B, cost, lay.n_enc, dbelow=dlat)
+            L.mlp_forward_backward(plan, 0, n, xb, rb, B, cost, lay.n_enc, dbelow=dlat)
         else:
-            L.mlp_forward(plan, 0, n, xb, 0, B, cost=cost)
-            L.mlp_backward(plan, lay.n_enc, n, dl[-1], None, 0, 0, B, dbelow=dlat)
-        L.mlp_backward(plan, 0, lay.n_enc, dlat, None, 0, 0, B)          # (encoder: the row-block launch in both runs)
+            L.mlp_forward(plan, 0, n, xb, rb, B, cost=cost)
+            L.mlp_backward(plan, lay.n_enc, n, dl[-1], None, 0, rb, B, dbelow=dlat)
+        L.mlp_backward(plan, 0, lay.n_enc, dlat, None, 0, rb, B)         # (encoder: the row-block launch in both runs)
         gw = torch.full((lay.n_params,), float("nan"), device="cuda")
         ws = torch.zeros(L.mlp_wgrad_ws_floats(lay.n_params, B), device="cuda")
-        L.mlp_wgrad(plan, 0, n, 0, B, gw, ws)
+        L.mlp_wgrad(plan, 0, n, rb, B, gw, ws)
         torch.cuda.synchronize()
         return h, dl, dlat, cost_ws, gw
 
@@ -49,33 +52,34 @@ for D, n_neurons, B, variant in CASES:
     h2, d2, z2, c2, g2 = run(True)
     # float64 reference of the same pass
     arrays = [torch.tensor(a, dtype=torch.float64, requires_grad=True) for a in unpack_weights(lay, flat)]
-    cur = xb.cpu().double()
+    cur = xb.cpu().double()[rb:]
     hs = []
     for i, l in enumerate(lay.layers):
         cur = cur @ arrays[2 * i] + arrays[2 * i + 1]
         if l.activation == "tanh":
             cur = torch.tanh(cur)
         hs.append(cur)
-    diff = hs[-1] - xb.cpu().double()
-    cost = 0.7 * (diff.abs().mean() if variant == "mean_abs" else (diff * diff).mean())
+    diff = hs[-1] - xb.cpu().double()[rb:]
+    cost = 0.7 * (diff.abs().sum() if variant == "mean_abs" else (diff * diff).sum()) / (B * D)      # (normalised by the whole batch)
     grads = torch.autograd.grad(cost, arrays)
     different = False
     for i in range(n):
-        a, b, r = h1[i].cpu().numpy(), h2[i].cpu().numpy(), hs[i].detach().numpy()
+        a, b, r = h1[i].cpu().numpy()[rb:], h2[i].cpu().numpy()[rb:], hs[i].detach().numpy()
+        assert not h2[i][:rb].any(), "rows in front of the launch's range were written"
         np.testing.assert_allclose(b, r, rtol=2e-6, atol=3e-6, err_msg=f"activation {i}")
         different |= not np.array_equal(a, b)
     assert different, "the fused launch gave the row-block kernel's bits: the transposed chain did not run"
-    np.testing.assert_allclose(float(c2.sum()), float(cost), rtol=2e-6)
+    np.testing.assert_allclose(float(c2.sum()), float(cost.detach()), rtol=2e-6)
     np.testing.assert_allclose(float(c2.sum()), float(c1.sum()), rtol=2e-6)
     for l in range(lay.n_enc, n):
-        ref = d1[l].cpu().numpy()
-        np.testing.assert_allclose(d2[l].cpu().numpy(), ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"delta {l}")
-    np.testing.assert_allclose(z2.cpu().numpy(), z1.cpu().numpy(), rtol=0, atol=2e-5 * np.abs(z1.cpu().numpy()).max())
+        ref = d1[l].cpu().numpy()[rb:]
+        np.testing.assert_allclose(d2[l].cpu().numpy()[rb:], ref, rtol=0, atol=2e-5 * np.abs(ref).max(), err_msg=f"delta {l}")
+    np.testing.assert_allclose(z2.cpu().numpy()[rb:], z1.cpu().numpy()[rb:], rtol=0, atol=2e-5 * np.abs(z1.cpu().numpy()[rb:]).max())
     gh = g2.cpu().numpy()
     for i, l in enumerate(lay.layers):
         gw = gh[l.w_off: l.w_off + l.n_in * l.n_out].reshape(l.n_in, l.n_out)
         gb = gh[l.b_off: l.b_off + l.n_out]
         np.testing.assert_allclose(gw, grads[2 * i].numpy(), rtol=0, atol=2e-5 * np.abs(grads[2 * i].numpy()).max(), err_msg=f"dW {i}")
         np.testing.assert_allclose(gb, grads[2 * i + 1].numpy(), rtol=0, atol=2e-5 * np.abs(grads[2 * i + 1].numpy()).max(), err_msg=f"db {i}")
-    print(f"transposed chain ok: D {D} n_neurons {n_neurons} B {B} {variant}", flush=True)
+    print(f"transposed chain ok: D {D} n_neurons {n_neurons} rows {rb}..{B} {variant}", flush=True)
 print("ALL OK")
