@@ -2755,10 +2755,9 @@ int try_tchain(const emx_mlp_desc* desc, float* params, const float* mirror, int
   // (read per call -- a call is one launch recorded into a graph, not a step: tests compare the two kernels inside one process)
   const char* const env = getenv("EMX_TCHAIN");
   const int mode = env ? atoi(env) : -1;
-  static const int max_rows = getenv("EMX_TCHAIN_MAX_ROWS") ? atoi(getenv("EMX_TCHAIN_MAX_ROWS")) : 1 << 30;
   const bool enabled = mode == 1 || (mode < 0 && (row_end - row_begin + R - 1) / R <= device_cus());
   const int n = desc->n_layers, top = layer_end - 1;
-  if (!enabled || layer_begin != 0 || layer_end != n || n > TC_MAXL || row_end - row_begin > max_rows) return EMX_EUNSUPPORTED;
+  if (!enabled || layer_begin != 0 || layer_end != n || n > TC_MAXL) return EMX_EUNSUPPORTED;
   for (int l = 0; l <= n; ++l)
     if (desc->width[l] > 128) return EMX_EUNSUPPORTED;
   for (int l = 0; l < n; ++l)
