@@ -84,8 +84,9 @@ __device__ unsigned long long g_tc_stamps[8][32][8];
 #define TCS(step, k) do {} while (0)
 #endif
 
-// (ONE copy of the body for the four waves -- the wave index is a scalar register; only the accumulator exchange, which indexes
-//  registers by it, is a four-way switch.  Four instantiations of the whole body were ~80 KB of code for a 64-KB instruction cache.)
+// (ONE copy of the body for the eight waves -- the wave index and the pair's half are scalar registers, the exchange goes through LDS
+//  addresses computed from them: 15 KB of code.  The first form instantiated the body per wave, ~80 KB for a 64-KB instruction cache
+//  that the step's other three launches have just used.)
 __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   const auto& a = *ka;
   const int lane = threadIdx.x & 63;
@@ -268,8 +269,8 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
     constexpr int slot = decltype(SLOT_)::value;
     if (step >= nsteps) return;                       // (workgroup-uniform)
     TCS(step, 0);
-    // the step's record, and everything its epilogue reads from memory, IN FRONT of the next layer's pieces: the memory counter is in
-    // order, and a wait for a bias behind sixteen piece requests would be a wait for all of them
+    // the step's record (scalar cache; its biases and weight scale wait in the prologue's LDS tables: nothing of a step's epilogue is
+    // a trip to memory)
     TStep S;
     {
       const auto& K = a.steps[step];                  // (constant address space: field by field, the loads merge into one)
