@@ -3,6 +3,8 @@
 
     python bench.py                                    # the headline: C2, one GPU, 300 steps after 30 warm-up steps
     python bench.py --config C5 --steps 100 --warmup 10
+    python bench.py --mode encode [--config C2|C4]    # encode() of the resident training set (a "step" = one pass over all its rows)
+    python bench.py --mode decode                      # decode() / generate() of as many latent rows
     python bench.py --gpus N --steps K --warmup W      # no launcher: the script starts torch.distributed.run itself (a child
                                                        # process, before anything touches the GPU) and relays the JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
@@ -33,6 +35,8 @@ that is resident in HBM before the timed region starts.  One JSON line is printe
   cpu_baseline the reference formulation (oracle/reference_ops.py in float32: Gram-matrix / [B, B, D] temporaries, autograd,
                per-element clipped Adam) timed on this host: >= 50 steps after 5 warm-up steps at the fastest thread count of a
                one-step probe, and a few steps on ONE thread.  N = 1 only.  kind "port": TensorFlow cannot be installed here.
+  inference    N = 1: encode() and decode() of the resident set as rows/s, each with bytes in + out / time against the 8 TB/s HBM roof
+               (what ``--mode encode|decode`` print as a line of their own, with a CPU baseline of the same pass).
   facade_ms_per_step   C2, N = 1: the same steps through ``em.EncoderMap.train()`` (the user's entry point, callbacks and History
                included), with the defaults and with the progress read-out every ``summary_step`` steps.
 
@@ -586,12 +590,105 @@ def facade_timing(em, cfg, data, device, steps):
     return out
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# inference: encode() / decode() / generate() of whole trajectories (autoencoder.py:1110-1195) against the HBM roof
+# ------------------------------------------------------------------------------------------------------------------
+def inference_pass(eng, which, data, passes, warmup=2):
+    """seconds per pass of ``which`` ("encode": the resident rows -> latent rows; "decode": as many latent rows -> output rows), HIP
+    events around ``passes`` back-to-back passes on the stream the kernels run on; everything stays on the device.  Returns
+    (seconds, rows, bytes in + out, launches per pass, streaming?)."""
+    import torch
+
+    from encodermap_amd import _lib
+
+    n = data.shape[0]
+    lib = _lib.load()
+    if which == "encode":
+        src = data
+        dst = torch.empty(n, eng.L, dtype=torch.float32, device=data.device)
+        fn = lambda: eng.encode_device(src, dst)
+    else:
+        g = torch.Generator(device=data.device)
+        g.manual_seed(11)
+        src = torch.randn(n, eng.L, generator=g, device=data.device)
+        dst = torch.empty(n, eng.D, dtype=torch.float32, device=data.device)
+        fn = lambda: eng.decode_device(src, dst)
+    for _ in range(warmup):
+        fn()
+    c0 = lib.emx_launch_count()
+    fn()
+    launches = int(lib.emx_launch_count() - c0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(passes):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(dst[:: max(1, n // 4096)]).all()), "non-finite rows out of the inference pass"
+    nbytes = 4 * n * (src.shape[1] + dst.shape[1])
+    return e0.elapsed_time(e1) * 1e-3 / passes, n, nbytes, launches, launches == 1
+
+
+def inference_record(eng, which, data, passes, warmup=2):
+    t, n, nbytes, launches, streaming = inference_pass(eng, which, data, passes, warmup)
+    lay = eng.layout
+    layers = lay.layers[: lay.n_enc] if which == "encode" else lay.layers[lay.n_enc:]
+    mults = n * sum(l.n_in * l.n_out for l in layers)
+    return {"rows_per_sec": n / t, "ms_per_pass": t * 1e3, "rows": int(n), "launches_per_pass": launches,
+            "kernel": "infer_kernel (one streaming launch: rows in, result out, operand pieces resident in LDS)" if streaming else
+                      "chain_kernel<FWD> (the training kernels forward-only: a layer wider than 128 or pieces beyond LDS)",
+            "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": nbytes / t / HBM_PEAK,
+                         "traffic": None, "algorithmic_bytes": int(nbytes),
+                         "mfma_f16_frac_executed": 6 * mults / t / F16_PEAK,
+                         "note": "algorithmic bytes = 4 (columns in + columns out) per row; the split-f16 matrix products of the pass (three per float32 "
+                                 "product) against the dense f16 peak beside it: the two roofs are within a factor of two of each other here"}}
+
+
+def cpu_inference_baseline(name, which, budget_s=15.0):
+    """the same pass in float32 torch-CPU (oracle/reference_ops.py's model: Dense layers, sin / cos in, atan2 out) on a bounded sample"""
+    import numpy as np
+    import torch
+
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+    from encodermap_amd.parameters import Parameters
+    from oracle import reference_ops as R
+
+    cfg = CONFIGS[name]
+    D = cfg["D"]
+    p = Parameters(**cfg["kw"])
+    net = 2 * D if p.periodicity < INF else D
+    lay = build_layout(p.n_neurons, p.activation_functions, net)
+    w0 = unpack_weights(lay, init_parameters(lay, 0))
+    model = R.SequentialOracle(D, p.n_neurons, p.activation_functions, p.periodicity, w0, dtype=torch.float32)
+    rng = np.random.default_rng(2)
+    rows = 100_000
+    x = torch.tensor(rng.normal(0, 1, (rows, D if which == "encode" else p.n_neurons[-1])).astype(np.float32))
+    fn = (lambda: model.encoder(x)) if which == "encode" else (lambda: model.decoder(x))
+    cores = os.cpu_count() or torch.get_num_threads()
+    torch.set_num_threads(min(cores, 32))
+    with torch.no_grad():
+        fn()
+        t0 = time.perf_counter()
+        k = 0
+        while k < 3 or (time.perf_counter() - t0 < budget_s and k < 200):
+            fn()
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+    return {"value": rows / dt, "unit": "rows/s", "cores": min(cores, 32), "kind": "port",
+            "sample": f"{k} passes of {which} over {rows} rows x {x.shape[1]} columns (float32 torch-CPU restatement of the reference's "
+                      f"model, oracle/reference_ops.py) with {min(cores, 32)} of {cores} host threads: {dt * 1e3:.1f} ms per pass",
+            "host_cpu": _cpu_model(), "host_threads": cores}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=30)
     ap.add_argument("--config", default="C2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="train", choices=["train", "encode", "decode"],
+                    help="train (default): the training step; encode / decode: one pass of encode() / decode() over the resident rows per step")
     ap.add_argument("--rows", type=int, default=0, help="rows of the resident training set (default: the configuration's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-facade", action="store_true")
@@ -703,6 +800,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if args.mode != "train":
+        if cfg["model"] != "encodermap":
+            raise SystemExit("--mode encode / decode: the EncoderMap configurations (C1, C2, C4, C5)")
+        # a "step" = one pass over the rank's resident rows (N > 1: every rank its own replica of the set -- rows, not a model, are what
+        # inference shards over: no collective); warm-up passes, then K timed passes bracketed as the contract says
+        barrier()
+        t0 = time.perf_counter()
+        rec = inference_record(eng, args.mode, data, max(args.steps, 1), warmup=max(args.warmup, 1))
+        barrier()
+        dt = time.perf_counter() - t0
+        t_pass = rec["ms_per_pass"] * 1e-3
+        if multi:
+            tt = torch.tensor([t_pass], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_pass = float(tt.item())
+        if rank == 0:
+            n = data.shape[0]
+            out = {"metric": f"{args.mode}_rows_per_sec", "value": n * world / t_pass, "unit": "rows/s", "n_gpus": world, "steps": max(args.steps, 1),
+                   "warmup": max(args.warmup, 1), "ms_per_step": t_pass * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                   "dtype": DTYPES[cfg["kind"]].split(";")[0].replace("all-pairs pass", "").strip(), "data": "synthetic",
+                   "config": {"workload": f"{name}: em.EncoderMap.{args.mode}() of {n} rows x {D if args.mode == 'encode' else eng.L} columns resident in HBM "
+                                          f"-> {eng.L if args.mode == 'encode' else D} columns (network {cfg['workload'].split(':')[0]}'s), result left on the device",
+                              "name": name, "rows_resident": int(n), "features": D, "parallelism": f"replicas{world}" if world > 1 else "single",
+                              "commit": git_head(), "wall_s_including_warmup": dt},
+                   "roofline": dict(rec["roofline"], kernel=rec["kernel"], kernel_us=rec["ms_per_pass"] * 1e3, launches_per_pass=rec["launches_per_pass"])}
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_inference_baseline(name, args.mode)
+            print(json.dumps(out), flush=True)
+        if multi:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     # (multi-rank runs: a hang -- of the captured all-reduce, of a rank that lost its peers -- ends as a failure with a reason)
     call_off = start_watchdog(float(os.environ.get("EMX_BENCH_WATCHDOG", "900")), f"the {world}-rank training run") if multi else (lambda: None)
     eng.run_steps(args.warmup)
@@ -760,6 +890,8 @@ def main():
             out["roofline_all_pairs"] = ap_rec
         if not multi:
             out["launches_per_step"] = launches_per_step(eng)
+        if world == 1 and not multi and cfg["model"] == "encodermap" and data is not None:
+            out["inference"] = {w: inference_record(eng, w, data, 10) for w in ("encode", "decode")}
         if world == 1 and not multi and not args.no_facade and name == "C2":
             f = facade_timing(em, cfg, data, device, max(args.steps, 2000))
             out["facade_ms_per_step"] = f["defaults"]

@@ -96,6 +96,7 @@ SIGNATURES = {
     "emx_mlp_mirror": (_i, [_p, _p, _p, _p]),
     "emx_mlp_aop_bytes": (_sz, [_p, _i]),
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
+    "emx_mlp_infer": (_i, [_p, _p, _i, _i, _p, _l, _f, _l, _p, _l, _f, _p]),
     "emx_mlp_row_blocks": (_i, [_i]),
     "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "emx_clash_count": (_i, [_p, _i, _i, _f, _p, _p]),
@@ -604,6 +605,19 @@ def mlp_forward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost" =
     _check(load().emx_mlp_forward_cost(C.byref(plan.desc), _ptr(plan.params), _ptr(plan.mirror), l0, l1, _ptr(x), x.stride(0), int(row_begin),
                                        int(row_end), plan.h, C.byref(cost) if cost is not None else None, ap, ar, _stream()),
            "emx_mlp_forward")
+
+
+def mlp_infer(plan: MlpPlan, l0, l1, x, out, periodicity_in=0.0, periodicity_out=0.0):
+    """Inference: layers [l0, l1) on every row of ``x`` into ``out`` as one streaming launch (include/emx.h, emx_mlp_infer).
+    ``periodicity_in``: ``x`` holds raw angles, the sin / cos input is formed on chip; ``periodicity_out``: ``out`` receives the angles
+    atan2(sin half, cos half).  Raises EmxError with ``.unsupported`` for networks the streaming pass does not take."""
+    if plan.windows is not None:
+        raise EmxError("emx_mlp_infer: more than 12 Dense layers run as windows of separate launches", EMX_EUNSUPPORTED)
+    assert x.dtype == torch.float32 and out.dtype == torch.float32 and x.stride(1) == 1 and out.stride(1) == 1 and x.shape[0] == out.shape[0]
+    pin = float(periodicity_in) if (periodicity_in and periodicity_in != float("inf")) else 0.0
+    pout = float(periodicity_out) if (periodicity_out and periodicity_out != float("inf")) else 0.0
+    _check(load().emx_mlp_infer(C.byref(plan.desc), _ptr(plan.params), int(l0), int(l1), _ptr(x), x.stride(0), pin, x.shape[0], _ptr(out),
+                                out.stride(0), pout, _stream()), "emx_mlp_infer")
 
 
 def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None, train: bool = True):

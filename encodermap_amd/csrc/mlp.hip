@@ -34,6 +34,7 @@
 //   16x16x32: A[m = lane & 15][k = 8 (lane >> 4) + e], B[k][n = lane & 15], D[row = 4 (lane >> 4) + reg][col = lane & 15];
 //   the k labels inside a K-step are free as long as A and B agree -- here kk(g, e) = 4 g + e (e < 4), 16 + 4 g + e - 4.
 #include <atomic>
+#include "act.h"
 #include "adc_head.h"
 #include "aop.h"
 #include "cost.h"
@@ -56,16 +57,6 @@ constexpr int R = 16;              // batch rows per workgroup
 constexpr int MAXL = EMX_MAX_LAYERS;
 constexpr int MAXG = 2 * MAXL + 1;   // GEMMs per launch
 constexpr int MAXU = 120;            // units (128 output columns x 128 k) per launch
-constexpr float TANH_RS = 1.f / 16384.f;   // reciprocal of the fixed scale of tanh outputs
-
-// tanh(x) = 1 - 2 / (e^{2x} + 1): two transcendental + three plain VALU instructions, absolute error <= ~1.5e-7 over the
-// whole range (v_exp_f32 and v_rcp_f32 are 1-ulp; e = inf gives rcp = 0 -> 1, e = 0 gives -1), which is the float32
-// resolution of the activations.
-__device__ __forceinline__ float tanh_f32(float x) {
-  const float e = __builtin_amdgcn_exp2f(2.8853900817779268f * x);        // e^{2x}
-  return fmaf(-2.f, __builtin_amdgcn_rcpf(e + 1.f), 1.f);
-}
-
 template <int CTRL>
 __device__ __forceinline__ unsigned dpp_u32(unsigned x) {
   return (unsigned)__builtin_amdgcn_mov_dpp((int)x, CTRL, 0xF, 0xF, true);
@@ -97,36 +88,6 @@ __device__ __forceinline__ unsigned row16_max(unsigned x) {
 // store: results leave through buffer resources whose bounds check drops what does not exist), so that every s_waitcnt
 // the compiler inserts is for the OLDEST package only (vmcnt is one in-order counter for loads and stores).
 // ---------------------------------------------------------------------------------------------------------
-// Activations of a layer (emx_mlp_desc::act; models.py:3179-3220 hands any Keras activation name to Dense): 1 = tanh is the fast
-// path of every kernel here (fixed-scale images, its own switch cases); 2 .. 8 are the Keras activations whose derivative is a
-// function of the OUTPUT -- so that, like tanh, the backward pass needs h and not the pre-activation -- evaluated with the
-// hardware exp2 / log2 / rcp (absolute error ~1e-7, the float32 resolution of O(1) activations).
-enum { ACT_NONE = 0, ACT_TANH = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_ELU = 4, ACT_SOFTPLUS = 5, ACT_SELU = 6, ACT_SOFTSIGN = 7, ACT_EXP = 8, ACT_LAST = 8 };
-constexpr float SELU_ALPHA = 1.6732632423543772f, SELU_SCALE = 1.0507009873554805f, LOG2E = 1.4426950408889634f, LN2 = 0.6931471805599453f;
-__device__ __forceinline__ float act_apply(const int kind, const float x) {   // kind: wave-uniform
-  switch (kind) {
-    case ACT_RELU: return fmaxf(x, 0.f);
-    case ACT_SIGMOID: return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-LOG2E * x));
-    case ACT_ELU: return x > 0.f ? x : __builtin_amdgcn_exp2f(LOG2E * x) - 1.f;
-    case ACT_SOFTPLUS: return fmaxf(x, 0.f) + LN2 * __builtin_amdgcn_logf(1.f + __builtin_amdgcn_exp2f(-LOG2E * fabsf(x)));
-    case ACT_SELU: return SELU_SCALE * (x > 0.f ? x : SELU_ALPHA * (__builtin_amdgcn_exp2f(LOG2E * x) - 1.f));
-    case ACT_SOFTSIGN: return x * __builtin_amdgcn_rcpf(1.f + fabsf(x));
-    case ACT_EXP: return __builtin_amdgcn_exp2f(LOG2E * x);
-    default: return x;
-  }
-}
-__device__ __forceinline__ float act_deriv_from_output(const int kind, const float h) {   // d act / d x as a function of h = act(x)
-  switch (kind) {
-    case ACT_RELU: return h > 0.f ? 1.f : 0.f;
-    case ACT_SIGMOID: return h * (1.f - h);
-    case ACT_ELU: return h > 0.f ? 1.f : h + 1.f;
-    case ACT_SOFTPLUS: return 1.f - __builtin_amdgcn_exp2f(-LOG2E * h);
-    case ACT_SELU: return h > 0.f ? SELU_SCALE : h + SELU_SCALE * SELU_ALPHA;
-    case ACT_SOFTSIGN: { const float t = 1.f - fabsf(h); return t * t; }
-    case ACT_EXP: return h;
-    default: return 1.f;
-  }
-}
 // S_ACT: the layer has an activation (its derivative in backward units); S_ACTX: ... and it is not tanh -- its kind sits in bits
 // 8 .. 11; S_BND: a forward layer whose outputs lie in [-1, 1] (tanh, sigmoid, softsign): its image is written at the fixed scale 2^14
 enum { S_ACT = 1, S_JOIN = 2, S_BWD = 4, S_PUB = 8, S_WAIT = 16, S_ACTX = 32, S_BND = 64 };
@@ -138,7 +99,6 @@ inline int act_flags(int kind) {
   if (kind == ACT_TANH || kind == ACT_SIGMOID || kind == ACT_SOFTSIGN) f |= S_BND;
   return f;
 }
-inline bool act_bounded(int kind) { return kind == ACT_TANH || kind == ACT_SIGMOID || kind == ACT_SOFTSIGN; }
 // S_WAIT (PUB builds): the tile workgroups' partial sums are awaited and joined in front of this epilogue   // S_PUB: the layer's rows are published to the tile workgroups of the launch (PUB builds)
 
 struct GemmRec {          // one layer of the range in one direction: P x C regular units (128 columns x 128 k)

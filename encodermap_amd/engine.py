@@ -1027,16 +1027,56 @@ class SequentialEngine:
         return int(self.step.item())
 
     # -- inference -----------------------------------------------------------------------------------
-    def _infer(self, x_dev: torch.Tensor, l0: int, l1: int) -> torch.Tensor:
-        """Layers [l0, l1) on an arbitrary number of rows (temporary activation buffers)."""
+    # encode() / decode() / generate() (autoencoder.py:1110-1195): ONE streaming launch per chunk (emx_mlp_infer: input rows in, result
+    # out, sin / cos and atan2 formed on chip).  Networks it does not take (a layer wider than 128, pieces beyond LDS) run the
+    # training kernels forward-only, keeping no rows but the last layer's.
+    _infer_streaming = os.environ.get("EMX_INFER_STREAM", "1") != "0"
+
+    def _infer(self, x_dev: torch.Tensor, l0: int, l1: int, periodic_in: bool = False, periodic_out: bool = False,
+               out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Layers [l0, l1) on an arbitrary number of rows.  ``periodic_in``: ``x_dev`` holds raw angles (PeriodicInput is part of the
+        pass); ``periodic_out``: the result is the angles of PeriodicOutput.  ``out``: where the result goes (a device tensor)."""
         lay = self.layout
         n = x_dev.shape[0]
         self.check_sync()      # (the weights this pass reads are a result of the training run)
-        h = [torch.empty(n, l.n_out, dtype=torch.float32, device=self.device) if l0 <= i < l1 else None
-             for i, l in enumerate(lay.layers)]
-        plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers), mirror=self.plan.mirror)
-        _lib.mlp_forward(plan, l0, l1, x_dev, 0, n, train=False)
-        return h[l1 - 1]
+        width = lay.layers[l1 - 1].n_out // (2 if periodic_out else 1)
+        if out is None:
+            out = torch.empty(n, width, dtype=torch.float32, device=self.device)
+        if n == 0:
+            return out
+        if self._infer_streaming:
+            try:
+                _lib.mlp_infer(self.plan, l0, l1, x_dev, out, self.periodicity if periodic_in else 0.0, self.periodicity if periodic_out else 0.0)
+                return out
+            except _lib.EmxError as err:
+                if not err.unsupported:
+                    raise
+        if periodic_in:
+            xin = torch.empty(n, 2 * x_dev.shape[1], dtype=torch.float32, device=self.device)
+            _lib.periodic_in(x_dev, self.periodicity, xin)
+            x_dev = xin
+        last = out if not periodic_out else torch.empty(n, lay.layers[l1 - 1].n_out, dtype=torch.float32, device=self.device)
+
+        def run(keep_all: bool):
+            h = [None] * len(lay.layers)
+            for i in range(l0, l1):
+                if i == l1 - 1:
+                    h[i] = last
+                elif keep_all:
+                    h[i] = torch.empty(n, lay.layers[i].n_out, dtype=torch.float32, device=self.device)
+            plan = _lib.MlpPlan(lay, self.w, h, [None] * len(lay.layers), mirror=self.plan.mirror)
+            _lib.mlp_forward(plan, l0, l1, x_dev, 0, n, train=False)
+
+        try:
+            run(False)         # only the last layer's rows are written (include/emx.h: NULL entries of h)
+        except _lib.EmxError as err:
+            if not err.unsupported:
+                raise
+            run(True)          # (a range run in segments hands rows over through HBM at the cuts: keep them)
+        if periodic_out:
+            D = lay.layers[l1 - 1].n_out // 2
+            _lib.periodic_out(last, D, 0, D, self.periodicity, out)
+        return out
 
     @torch.no_grad()
     def encode(self, x: np.ndarray, already_transformed: bool = False, chunk: int = 262144) -> np.ndarray:
@@ -1044,28 +1084,29 @@ class SequentialEngine:
         out = np.empty((x.shape[0], self.L), np.float32)
         for s in range(0, x.shape[0], chunk):
             xc = torch.from_numpy(np.ascontiguousarray(x[s: s + chunk], dtype=np.float32)).to(self.device)
-            if self.periodic and not already_transformed:
-                xin = torch.empty(xc.shape[0], self.net_dim, dtype=torch.float32, device=self.device)
-                _lib.periodic_in(xc, self.periodicity, xin)
-                xc = xin
-            out[s: s + chunk] = self._infer(xc, 0, lay.n_enc).cpu().numpy()
+            out[s: s + chunk] = self._infer(xc, 0, lay.n_enc, periodic_in=self.periodic and not already_transformed).cpu().numpy()
         return out
 
     @torch.no_grad()
-    def encode_resident(self, chunk: int = 262144) -> np.ndarray:
+    def encode_device(self, x_dev: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``encode`` of rows that already live on the device, into a device tensor (no PCIe traffic; what bench.py times)."""
+        return self._infer(x_dev, 0, self.layout.n_enc, periodic_in=self.periodic, out=out)
+
+    @torch.no_grad()
+    def decode_device(self, z_dev: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """``decode`` of latent rows on the device into a device tensor."""
+        return self._infer(z_dev, self.layout.n_enc, len(self.layout.layers), periodic_out=self.periodic, out=out)
+
+    @torch.no_grad()
+    def encode_resident(self, chunk: int = 1 << 22) -> np.ndarray:
         """``encode`` of the training set from its HBM-resident copy (``set_data``): no host-to-device transfer, only the
-        [N, L] result crosses PCIe.  Same kernels, same chunking, hence the same numbers as ``encode(train_data)``."""
+        [N, L] result crosses PCIe.  Same kernel, hence the same numbers as ``encode(train_data)``."""
         if self.data is None:
             raise _lib.EmxError("encode_resident: no resident training set (set_data)")
-        lay, N = self.layout, self.data.shape[0]
+        N = self.data.shape[0]
         out = torch.empty(N, self.L, dtype=torch.float32, device=self.device)
         for s in range(0, N, chunk):
-            xc = self.data[s: s + chunk]
-            if self.periodic:
-                xin = torch.empty(xc.shape[0], self.net_dim, dtype=torch.float32, device=self.device)
-                _lib.periodic_in(xc, self.periodicity, xin)
-                xc = xin
-            out[s: s + chunk] = self._infer(xc, 0, lay.n_enc)
+            self.encode_device(self.data[s: s + chunk], out[s: s + chunk])
         return out.cpu().numpy()
 
     @torch.no_grad()
@@ -1081,17 +1122,11 @@ class SequentialEngine:
 
     @torch.no_grad()
     def decode(self, z: np.ndarray, chunk: int = 262144) -> np.ndarray:
-        lay = self.layout
         z = np.asarray(z, np.float32)
         out = np.empty((z.shape[0], self.D), np.float32)
         for s in range(0, z.shape[0], chunk):
             zc = torch.from_numpy(np.ascontiguousarray(z[s: s + chunk])).to(self.device)
-            y = self._infer(zc, lay.n_enc, len(lay.layers))
-            if self.periodic:
-                o = torch.empty(y.shape[0], self.D, dtype=torch.float32, device=self.device)
-                _lib.periodic_out(y, self.D, 0, self.D, self.periodicity, o)
-                y = o
-            out[s: s + chunk] = y.cpu().numpy()
+            out[s: s + chunk] = self.decode_device(zc).cpu().numpy()
         return out
 
     # -- state ---------------------------------------------------------------------------------------

@@ -415,6 +415,22 @@ size_t emx_mlp_aop_bytes(const emx_mlp_desc* desc, int n_rows);
  * passes (emx_mlp_forward_cost with a cost, emx_mlp_forward_backward*) answer EMX_EUNSUPPORTED for such a network. */
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
                     int ld_in, int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream);
+/* INFERENCE: layers [layer_begin, layer_end) on n_rows rows as ONE streaming launch -- nothing but the input rows and the result
+ * touches HBM (csrc/infer.hip).
+ *   replaces: Autoencoder.encode / generate / decode   encodermap/autoencoder/autoencoder.py:1110-1195 (model.encoder / model.decoder on
+ *             whole trajectories), SequentialModel.encoder / decoder  encodermap/models/models.py:3331-3359
+ *   in  [n_rows, width[layer_begin]] (row stride ld_in floats), or -- periodicity_in finite and > 0 -- the RAW angles
+ *       [n_rows, width[layer_begin] / 2]: the network input [sin(x 2 pi / p) | cos(x 2 pi / p)] (PeriodicInput, layers.py:204-215) is
+ *       formed on chip;
+ *   out [n_rows, width[layer_end]] (row stride ld_out), or -- periodicity_out finite and > 0 -- the angles
+ *       atan2(y[:, k], y[:, n + k]) p / 2 pi, [n_rows, n = width[layer_end] / 2] (PeriodicOutput, layers.py:1118-1125);
+ *   0 or INFINITY for either periodicity: plain rows.  No operand store, no fragment store, no workspace: every workgroup builds the
+ *   split-f16 operand pieces of the range in its LDS from `params` (emx_mlp_desc offsets).  Same precision class as emx_mlp_forward,
+ *   another order of summation (agreement to float32 rounding, not bit for bit).
+ * EMX_EUNSUPPORTED (nothing has been launched): a layer of the range wider than 128 on either side, or pieces beyond 160 KB of LDS
+ * (e.g. three 128 x 128 layers) -- run emx_mlp_forward (+ emx_periodic_in / emx_periodic_out) instead. */
+int emx_mlp_infer(const emx_mlp_desc* desc, const float* params, int layer_begin, int layer_end, const float* in, int64_t ld_in,
+                  float periodicity_in, int64_t n_rows, float* out, int64_t ld_out, float periodicity_out, emx_stream_t stream);
 /* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch
  * latency for a few hundred kilobytes): the cost of emx_periodic_cost_fwd_bwd is evaluated on the rows of layer
  * layer_end-1 while they are still on chip.  dY [*, width[layer_end]] receives d cost / d output; ws[g],
