@@ -1068,7 +1068,9 @@ class SequentialEngine:
             _lib.mlp_forward(plan, l0, l1, x_dev, 0, n, train=False)
 
         try:
-            run(False)         # only the last layer's rows are written (include/emx.h: NULL entries of h)
+            # only the last layer's rows are written (include/emx.h: NULL entries of h); a network of more than twelve layers runs as
+            # windows of launches that hand rows over through HBM: keep them
+            run(self.plan.windows is not None)
         except _lib.EmxError as err:
             if not err.unsupported:
                 raise

@@ -29,11 +29,11 @@ st = np.zeros((8, 16, 8), dtype=np.uint64)
 lib.emx_debug_infer_stamps.argtypes = [C.c_void_p]
 assert lib.emx_debug_infer_stamps(st.ctypes.data) == 0
 st = st.astype(np.int64)
-waves = int(os.environ.get("EMX_INFER_WAVES", "4"))
+waves = 8
 t0 = st[:waves, 15, 0].min()
 print(f"{which}, {rows} rows; s_memtime ticks relative to the first wave's entry, per wave")
 print("pieces built after", st[:waves, 15, 1] - t0)
-names = ["top", "operand", "prefetch", "layer0", "layer1", "layer2", "layer3+", "stored"]
+names = ["top", "operand", "layer0", "layer1", "layer2", "layer3", "last", "stored"]
 for it in range(8):
     for w in range(waves):
         row = st[w, it]
