@@ -60,18 +60,23 @@ namespace {
 // Blocks are never handed back to the runtime while the process lives (a launch in flight may still count in one); a block whose
 // scratch address was forgotten (emx_forget_counters) waits in the pool and is ZEROED AGAIN, in stream order, for its next owner.
 std::unordered_map<const void*, std::pair<unsigned*, size_t>> g_tickets;   // scratch address -> (block, bytes)
-std::vector<std::pair<unsigned*, size_t>> g_ticket_pool;                   // blocks without an owner
-constexpr size_t MAX_TICKET_OWNERS = 4096;   // beyond that many live scratch addresses every block goes back to the pool (a memset each)
+std::vector<std::pair<unsigned*, size_t>> g_ticket_pool;                   // blocks without an owner, free to be handed out again
+std::vector<std::pair<unsigned*, size_t>> g_ticket_parked;                 // blocks without an owner that are NEVER handed out again
 
-void retire_tickets_locked(const void* scratch) {
+// A block goes back to the pool only when its OWNER says so (emx_forget_counters(scratch): the caller's statement that no launch in
+// flight and no captured graph still addresses the scratch buffer -- include/emx.h).  A block the LIBRARY takes away from an address
+// on its own -- too small for a later call with the same scratch, or emx_forget_counters(NULL) -- is parked for the life of the
+// process instead: a hipGraph captured earlier, or a launch in flight on another stream, may still hold its pointer, and handed to
+// another scratch address two owners would share ticket words (a few KB per such event; there is no cap on live owners any more).
+void retire_tickets_locked(const void* scratch, bool reusable) {
   if (scratch == nullptr) {
-    for (auto& kv : g_tickets) g_ticket_pool.push_back(kv.second);
+    for (auto& kv : g_tickets) g_ticket_parked.push_back(kv.second);
     g_tickets.clear();
     return;
   }
   auto it = g_tickets.find(scratch);
   if (it == g_tickets.end()) return;
-  g_ticket_pool.push_back(it->second);
+  (reusable ? g_ticket_pool : g_ticket_parked).push_back(it->second);
   g_tickets.erase(it);
 }
 }  // namespace
@@ -91,8 +96,7 @@ unsigned* owned_tickets(const void* scratch, size_t bytes, hipStream_t stream, c
                "capture first (a warm-up step): its ticket words are allocated at first sight", who, scratch);
     return nullptr;
   }
-  if (it != g_tickets.end()) retire_tickets_locked(scratch);            // (too small for this call: back to the pool)
-  if (g_tickets.size() >= MAX_TICKET_OWNERS) retire_tickets_locked(nullptr);
+  if (it != g_tickets.end()) retire_tickets_locked(scratch, false);     // (too small for this call: parked, a graph may still hold it)
   unsigned* block = nullptr;
   size_t have = 0;
   for (size_t i = 0; i < g_ticket_pool.size(); ++i)
@@ -129,7 +133,7 @@ extern "C" void emx_forget_counters(void* words) {
   std::lock_guard<std::mutex> lock(emx::g_counters_mu);
   if (words == nullptr) emx::g_counters_seen.clear();
   else emx::g_counters_seen.erase(words);
-  emx::retire_tickets_locked(words);   // (a scratch buffer's ticket block: zeroed again at the address's next sight)
+  emx::retire_tickets_locked(words, true);   // (the owner's word that nothing addresses the block any more: zeroed again for its next owner)
 }
 
 namespace {

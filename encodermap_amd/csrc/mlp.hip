@@ -2387,8 +2387,10 @@ int forward_chain(const emx_mlp_desc* desc, float* params, const float* mirror, 
 // takes in one launch, and single layers through the streaming kernel (wide.h) where not even one layer fits.  The float32 rows
 // h[l] hand a segment's result to the next one (they must be kept); every segment leaves the weight-gradient fragments of its last
 // layer, the first one those of the range's input -- as the one launch would.
+// plan_only: walk the cuts with dry runs and check every hand-over row, issue nothing -- the callers run this first, so that
+// EMX_EUNSUPPORTED is always "decided in front of the launch: nothing has been issued" (include/emx.h), also inside a stream capture.
 int forward_segmented(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in, int ld_in,
-                      int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream) {
+                      int row_begin, int row_end, float* const* h, void* aop, int aop_rows, emx_stream_t stream, bool plan_only) {
   const char* who = "emx_mlp_forward";
   WopArgs wa;
   fill_wop_args(desc, wa);
@@ -2402,8 +2404,10 @@ int forward_segmented(const emx_mlp_desc* desc, float* params, const float* mirr
     int m = layer_end;
     while (m > l && forward_chain(desc, params, mirror, l, m, cur, ld, row_begin, row_end, h, nullptr, aop, aop_rows, stream, true) != EMX_OK) --m;
     if (m > l) {
-      const int rc = forward_chain(desc, params, mirror, l, m, cur, ld, row_begin, row_end, h, nullptr, aop, aop_rows, stream, false);
+      const int rc = plan_only ? EMX_OK : forward_chain(desc, params, mirror, l, m, cur, ld, row_begin, row_end, h, nullptr, aop, aop_rows, stream, false);
       if (rc) return rc;
+    } else if (plan_only) {
+      m = l + 1;
     } else {
       m = l + 1;
       WideArgs w{};
@@ -2455,7 +2459,9 @@ int emx_mlp_forward_cost(const emx_mlp_desc* desc, float* params, const float* m
   // to run the cost as a kernel of its own behind the plain forward pass); a range too wide for one launch: in segments
   rc = forward_chain(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, cost, aop, aop_rows, stream, false);
   if (rc != EMX_EUNSUPPORTED || cost) return rc;      // (EMX_EUNSUPPORTED is decided in front of the launch: nothing has been issued)
-  return forward_segmented(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, aop, aop_rows, stream);
+  rc = forward_segmented(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, aop, aop_rows, stream, true);
+  if (rc) return rc;                                   // (a missing hand-over row at ANY cut: refused before the first segment is issued)
+  return forward_segmented(desc, params, mirror, layer_begin, layer_end, in, ld_in, row_begin, row_end, h, aop, aop_rows, stream, false);
 }
 
 int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* in,
@@ -2544,8 +2550,8 @@ int backward_chain(const emx_mlp_desc* desc, float* params, const float* mirror,
 // its `dbelow`, the lower one takes it as its `dtop` and overwrites it, element by element, with delta = dh * act'(h) [+ join].
 int backward_segmented(const emx_mlp_desc* desc, float* params, const float* mirror, int layer_begin, int layer_end, const float* dtop, int ld_top,
                        const float* dadd, int layer_add, const emx_latent_grad* latent, float* dbelow, int row_begin, int row_end,
-                       float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream) {
-  const char* who = "emx_mlp_backward";
+                       float* const* h, float* const* delta, void* aop, int aop_rows, emx_stream_t stream, bool plan_only) {
+  const char* who = "emx_mlp_backward";   // (plan_only: as forward_segmented)
   WopArgs wa;
   fill_wop_args(desc, wa);
   const char* wop = reinterpret_cast<const char*>(mirror);
@@ -2574,8 +2580,8 @@ int backward_segmented(const emx_mlp_desc* desc, float* params, const float* mir
     }
     if (m < top_end) {
       const bool sj = seg_join(m);
-      const int rc = backward_chain(desc, params, mirror, m, top_end, cur, ld, sj ? dadd : nullptr, sj ? layer_add : 0, sj ? latent : nullptr, below(m),
-                                    row_begin, row_end, h, delta, aop, aop_rows, stream, false, true);
+      const int rc = plan_only ? EMX_OK : backward_chain(desc, params, mirror, m, top_end, cur, ld, sj ? dadd : nullptr, sj ? layer_add : 0,
+                                                         sj ? latent : nullptr, below(m), row_begin, row_end, h, delta, aop, aop_rows, stream, false, true);
       if (rc) return rc;
     } else {
       // not even the top layer alone: its source delta_top = dtop * act'(h_top) is streamed
@@ -2605,7 +2611,7 @@ int backward_segmented(const emx_mlp_desc* desc, float* params, const float* mir
       w.ld_out = desc->width[top];
       w.row0 = row_begin;
       w.row_end = row_end;
-      const int rc = launch_wide<true>(w, (hipStream_t)stream, who);
+      const int rc = plan_only ? EMX_OK : launch_wide<true>(w, (hipStream_t)stream, who);
       if (rc) return rc;
     }
     if (m > layer_begin) {
@@ -2635,8 +2641,11 @@ int emx_mlp_backward(const emx_mlp_desc* desc, float* params, const float* mirro
   rc = backward_chain(desc, params, mirror, layer_begin, layer_end, dtop, ld_top, dadd, layer_add, latent, dbelow, row_begin, row_end, h, delta, aop, aop_rows,
                       stream, false);
   if (rc != EMX_EUNSUPPORTED) return rc;              // (decided in front of the launch: nothing has been issued)
+  rc = backward_segmented(desc, params, mirror, layer_begin, layer_end, dtop, ld_top, dadd, layer_add, latent, dbelow, row_begin, row_end, h, delta, aop,
+                          aop_rows, stream, true);
+  if (rc) return rc;                                   // (a missing hand-over row at ANY cut: refused before the first segment is issued)
   return backward_segmented(desc, params, mirror, layer_begin, layer_end, dtop, ld_top, dadd, layer_add, latent, dbelow, row_begin, row_end, h, delta, aop,
-                            aop_rows, stream);
+                            aop_rows, stream, false);
 }
 
 }  // extern "C"

@@ -172,7 +172,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
     //  one 16-byte store where the row length allows it)
     const int c = 32 * wave + 16 * hf + 4 * g;
     const f32x4 t = hf ? f32x4{v[4], v[5], v[6], v[7]} : f32x4{v[0], v[1], v[2], v[3]};
-    if (c + 3 < width && (width & 3) == 0) {
+    if (c + 3 < width && (width & 3) == 0 && (reinterpret_cast<unsigned long long>(dst) & 15) == 0) {   // (the C API takes any row pointer)
       *reinterpret_cast<f32x4*>(dst + grow * width + c) = t;
     } else {
 #pragma unroll
@@ -228,6 +228,7 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
   // behind the input rows and the first layer's pieces.  No conditions: indices beyond the last step repeat it (same values, same
   // places), so that all of it is one basic block and every request is in flight before the first wait.
   struct Trip { const float* bp; const float* rp; int kind, w, st; float rv; };
+  static_assert(2 * TC_MAXL <= 8 * 3, "the tables of 2 TC_MAXL steps are filled by 3 trips of the 8 waves");
   Trip tr[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {

@@ -67,7 +67,10 @@ int64_t emx_launch_count(void);
  * address's first sight -- hence not inside a capture either, and not while another thread captures in global mode.
  * emx_forget_counters(workspace) hands that block back to the library's pool; the next call with the address gets a block zeroed
  * anew.  Call it when a workspace is freed, and after a launch was ABORTED (device reset, a give-up) with tickets taken: that is
- * how a caller re-zeroes them. */
+ * how a caller re-zeroes them.  It is the caller's statement that NOTHING addresses the block any more: drop every hipGraph that was
+ * captured with a launch on that workspace first, and let launches in flight on it finish -- the block may be handed to another
+ * workspace address afterwards.  Blocks the library takes away on its own (a later call on the same workspace that needs more
+ * ticket words; emx_forget_counters(NULL)) are never handed out again: graphs captured before stay valid. */
 void emx_forget_counters(void* words);
 
 /* ------------------------------------------------------------------------------------------------ *

@@ -66,6 +66,32 @@ def test_c2_three_steps_against_the_float64_oracle(em):
     assert want_terms[0]["distance"] > 0   # (the sigmoid is not saturated at these parameters)
 
 
+@pytest.mark.parametrize("B,n_neurons,variant", [(2048, [128, 128, 2], "mean_abs"), (4000, [128, 128, 3], "mean_square")])
+def test_transposed_chain_trajectory_against_the_float64_oracle(em, B, n_neurons, variant):
+    """Twelve free-running steps of the kernel C2 actually runs -- the transposed, register-resident chain (csrc/tchain.h) -- against the
+    float64 oracle: a batch of half the C2 size, and a RAGGED one (4000 rows = 250 row blocks, the last all-pairs tile column half
+    empty) with a three-column latent and the mean-square auto cost.  Tolerances as for C2: total loss 1e-4 relative, cost terms 2e-4."""
+    from encodermap_amd import _lib
+
+    rng = np.random.default_rng(B)
+    data = blobs(rng, 20000, 128)
+    p = em.Parameters(periodicity=INF, batch_size=B, n_neurons=n_neurons, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6), n_steps=12,
+                      auto_cost_variant=variant)
+    w0 = _weights(p, 128)
+    idx = rng.integers(0, data.shape[0], (12, B))
+    e = em.EncoderMap(p, data, model=[w.copy() for w in w0], read_only=True)
+    c0 = _lib.load().emx_transposed_chain_count()
+    e._engine.run_steps(12, torch.from_numpy(idx.reshape(-1)).to("cuda:0"))
+    got, terms = e._engine.losses().astype(np.float64), e._engine.loss_terms()
+    assert _lib.load().emx_transposed_chain_count() > c0, "the transposed chain did not take these launches"
+    model = R.SequentialOracle(128, p.n_neurons, p.activation_functions, p.periodicity, w0)
+    want, want_terms = R.train_steps(model, data, idx, p.to_dict())
+    print(f"B={B}: engine", got, "oracle", np.array(want), "rel", np.abs(got - want) / np.abs(want))
+    np.testing.assert_allclose(got, want, rtol=1e-4)
+    for k in ("auto", "reg", "center", "distance"):
+        np.testing.assert_allclose(terms[k], [t[k] for t in want_terms], rtol=2e-4, atol=1e-9)
+
+
 def test_c3a_cube_example(em):
     """encodermap/examples/cube.py:25-38: points on the edges of a cube, Euclidean, sig_h = (0.2, 3, 6) -- a_h = 3 is NOT the
     fast (12, 6) family: the exp2/log2 form of the high-d sigmoid runs."""
