@@ -111,6 +111,20 @@ def git_head():
         return None
 
 
+def source_hash():
+    """first 16 hex digits of the SHA-256 over the kernel sources (encodermap_amd/csrc, include) in name order: what a counters file
+    under profiles/ must carry to be quoted beside a line of THIS build (tools/pmc_step_summary.py writes it)"""
+    import glob
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "encodermap_amd", "csrc", "*")) + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if f.endswith((".hip", ".h")):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # synthetic data, generated ON the device (nothing crosses PCIe inside or in front of the timed region)
 # ------------------------------------------------------------------------------------------------------------------
@@ -280,21 +294,59 @@ def _time_launches(fn, launches):
     return e0.elapsed_time(e1) * 1e-3 / launches
 
 
-def _counters(name, kernel_key):
-    """static per-launch counters of the configuration's kernels (rocprofv3 PMC passes over this script, tools/run_pmc_step.sh);
-    returns (counters, source).  The newest round's file wins; its ``commit`` field is written at profile time (EMX_COMMIT or
-    the build stamp: the GPU box has no .git)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+def _counters_file(name):
+    """(blob, path, reason): the newest per-launch counters of the configuration (rocprofv3 PMC passes over this script,
+    tools/run_pmc_step.sh) IF they were taken on these kernel sources -- a file whose ``source_hash`` is not this build's is refused
+    (None, path, why): numbers of another build are not quoted beside this one's timings."""
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         path = os.path.join("profiles", f"{rnd}_step_counters.json" if name == "C2" else f"{rnd}_{name.lower()}_counters.json")
         try:
             blob = json.load(open(os.path.join(ROOT, path)))
-            for kname, c in blob["kernels"].items():
-                if kernel_key in kname:
-                    commit = blob.get("commit") or f"not recorded (round {rnd[1:]})"
-                    return c, f"{path} (static: PMC passes over this workload, taken at commit {commit})"
         except Exception:
             continue
-    return {}, None
+        have, want = blob.get("source_hash"), source_hash()
+        if have != want:
+            return None, path, (f"refused: {path} was taken on kernel sources {have or 'of an unrecorded build'} "
+                                f"(commit {blob.get('commit') or 'not recorded'}), this build's are {want}")
+        return blob, path, None
+    return None, None, "no counters file for this configuration"
+
+
+def _counters(name, kernel_key):
+    """static per-launch counters of one kernel of the configuration; returns (counters, source)"""
+    blob, path, reason = _counters_file(name)
+    if blob is None:
+        return {}, reason
+    for kname, c in blob["kernels"].items():
+        if kernel_key in kname:
+            return c, f"{path} (static: PMC passes over this workload, commit {blob.get('commit')}, kernel sources {blob.get('source_hash')})"
+    return {}, f"{path}: no kernel matching {kernel_key!r}"
+
+
+def roofline_step(name, eng, live_us):
+    """Every launch of the step on one line: in-step duration (the profiler's, under the counter passes), HBM bytes per launch against
+    8 TB/s, matrix / vector busy, and for the all-pairs kernel SURVEY 8d's fraction (3 W or 5 W / t / 157.3 TF); ``alone_us``: the
+    HIP-event timing of the kernel alone taken by this run, where there is one.  None (+ reason) without counters of this build."""
+    blob, path, reason = _counters_file(name)
+    if blob is None:
+        return None, reason
+    cfg = CONFIGS[name]
+    Bt, D = eng.B, cfg["D"]
+    W = D * Bt * (Bt - 1) / 2
+    out = []
+    for kname, c in blob["kernels"].items():
+        t = c.get("_dur_us_under_pmc")
+        if not t or c.get("_launches_seen", 0) < 8:
+            continue
+        rec = {"kernel": kname, "us_in_step": t, "hbm_bytes": c.get("hbm_bytes_per_launch"),
+               "hbm_frac": (c["hbm_bytes_per_launch"] / (t * 1e-6) / HBM_PEAK) if c.get("hbm_bytes_per_launch") else None,
+               "mfma_util": c.get("MfmaUtil"), "valu_busy": c.get("VALUBusy"), "l2_hit_rate": c.get("l2_hit_rate"), "frac_survey_8d": None,
+               "alone_us": next((v for k, v in live_us.items() if k in kname), None)}
+        if "sk_tile" in kname:
+            rec["frac_survey_8d"] = (5 if eng.periodic else 3) * W / (t * 1e-6) / FP32_PEAK
+        out.append(rec)
+    out.sort(key=lambda r: -r["us_in_step"])
+    return out, f"{path} (commit {blob.get('commit')}, kernel sources {blob.get('source_hash')})"
 
 
 def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, roof, bound, limiter, note, algorithmic_bytes, flops_8d=None):
@@ -310,7 +362,7 @@ def _record(name, kernel, kernel_key, t, flops_alg, flops_exec, peak, roof, boun
                            else "SURVEY 8d FLOPs / fp32 vector peak"),
             "frac_survey_8d": (flops_8d / t / FP32_PEAK) if flops_8d else None,
             "traffic": c.get("hbm_bytes_per_launch"), "traffic_source": src,
-            "kernel": kernel, "kernel_us": t * 1e6,
+            "kernel": kernel, "kernel_us": t * 1e6, "kernel_us_in_step": c.get("_dur_us_under_pmc"),
             "timing": "HIP events around back-to-back launches of the kernel alone on the live batch (torch's current stream = the stream "
                       "the kernels run on).  Inside the step a launch also pays the first touch of what the previous launch rewrote on other "
                       "XCDs: the profiler's per-launch trace shows the fused dense-layer launch 2-4 us longer there than alone "
@@ -882,12 +934,14 @@ def main():
                        "allreduce": ("captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None,
                        "graph_allreduce_probe": probe,
                        **({"self_test": f"backend {backend}, one device: {one_device}"} if (one_device or backend != "nccl") else {}),
-                       "hip_graph": True, "commit": git_head()},
+                       "hip_graph": True, "commit": git_head(), "kernel_sources": source_hash()},
             "loss_first_last": [float(losses[0]), float(losses[-1])],
         }
         out["roofline"], ap_rec = kernel_rooflines(name, eng, max(min(args.steps, 200), 50))
         if ap_rec is not None:
             out["roofline_all_pairs"] = ap_rec
+        live = {r["kernel"].split(" ")[0].split("<")[0]: r["kernel_us"] for r in (out["roofline"], ap_rec) if r}
+        out["roofline_step"], out["roofline_step_source"] = roofline_step(name, eng, live)
         if not multi:
             out["launches_per_step"] = launches_per_step(eng)
         if world == 1 and not multi and cfg["model"] == "encodermap" and data is not None:

@@ -110,11 +110,9 @@ SIGNATURES = {
     "emx_mlp_backward": (_i, [_p, _p, _p, _i, _i, _p, _i, _p, _i, _p, _p, _i, _i, _p, _p, _p, _i, _p]),
     "emx_mlp_wgrad_ws_floats": (_sz, [_l, _i]),
     "emx_mlp_wgrad": (_i, [_p, _p, _l, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p, _p]),
-    "emx_mlp_wgrad_adam_fits": (_i, [_p, _i, _p]),
     "emx_mlp_wgrad_adam_local_fits": (_i, [_p, _i, _p]),
     "emx_mlp_wgrad_adam_local_ws_floats": (_sz, [_p, _i]),
     "emx_mlp_wgrad_adam_local": (_i, [_p, _p, _l, _p, _i, _i, _i, _p, _sz, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
-    "emx_mlp_wgrad_adam": (_i, [_p, _p, _l, _p, _i, _i, _i, _p, _sz, _p, _p, _p, _p, _f, _f, _f, _f, _f, _p, _p, _p, _p, _p]),
 }
 
 EMX_MAX_LAYERS = 12
@@ -735,29 +733,6 @@ def mlp_wgrad(plan: MlpPlan, l0, l1, row_begin, row_end, grad, ws, finish: "Fini
     _check(load().emx_mlp_wgrad(C.byref(plan.desc), _ptr(plan.params), plan.n_params, l0, l1, plan.aop.data_ptr(), plan.aop_rows,
                                 int(row_begin), int(row_end), _ptr(grad), _ptr(ws), ws.numel(),
                                 C.byref(finish) if finish is not None else None, _stream()), "emx_mlp_wgrad")
-
-
-def mlp_wgrad_adam_fits(plan: MlpPlan, n_rows, next_batch=None) -> bool:
-    """whether emx_mlp_wgrad_adam can run this network / batch on the current device (every weight-gradient workgroup resident)"""
-    if plan.windows is not None:
-        return False
-    nb = C.byref(next_batch) if next_batch is not None else None
-    return bool(load().emx_mlp_wgrad_adam_fits(C.byref(plan.desc), int(n_rows), nb))
-
-
-def mlp_wgrad_adam(plan: MlpPlan, row_begin, row_end, ws, finish: "FinishDesc", m, v, l2coef, lr, beta1, beta2, eps, clip, reg_ws, sync,
-                   next_batch=None):
-    """Weight gradients of all layers, the step's scalar epilogue, L2 + clip + Adam (+ operand store) and the next batch's rows in ONE
-    launch (emx.h): the same bits as ``mlp_wgrad(..., finish)`` followed by ``adam_step_slices(..., bookkeeping_done=True)``."""
-    _no_merged_launch(plan, "emx_mlp_wgrad_adam")
-    if plan.aop is None:
-        raise EmxError("mlp_wgrad_adam: the plan has no weight-gradient operand store (MlpPlan(..., train_rows=B))")
-    assert sync.dtype == torch.int32 and sync.numel() >= 4
-    nb = C.byref(next_batch) if next_batch is not None else None
-    _check(load().emx_mlp_wgrad_adam(C.byref(plan.desc), _ptr(plan.params), plan.n_params, plan.aop.data_ptr(), plan.aop_rows, int(row_begin),
-                                     int(row_end), _ptr(ws), ws.numel(), C.byref(finish), _ptr(m), _ptr(v), _ptr(l2coef), float(lr), float(beta1),
-                                     float(beta2), float(eps), float(clip if clip is not None else 0.0), _ptr(reg_ws), _ptr(plan.mirror), nb,
-                                     _ptr(sync), _stream()), "emx_mlp_wgrad_adam")
 
 
 def mlp_wgrad_adam_local_fits(plan: MlpPlan, n_rows, next_batch=None) -> bool:

@@ -39,11 +39,12 @@ def _round4(n: int) -> int:
 
 class ADCEngine(SequentialEngine):
     # The head of step t + 1 (batch rows, encoder input, soft-start scale, batch means) runs on workgroups of the optimizer launch
-    # of step t, as the row gather of the EncoderMap step does (emx_next_batch::adc_head); EMX_ADC_PREFETCH_HEAD=0 or the single
-    # launches of EMX_ADC_HEAD=0: a launch at the head of every step.
-    _prefetch = os.environ.get("EMX_ADC_HEAD", "1") != "0" and os.environ.get("EMX_ADC_PREFETCH_HEAD", "1") != "0"
-    _fused_head = os.environ.get("EMX_ADC_HEAD", "1") != "0"   # gathers + sin/cos + soft start in one launch (A/B switch)
-    _batched_costs = os.environ.get("EMX_ADC_COST_BATCH", "1") != "0"   # the angle-like costs in one launch (A/B switch)
+    # of step t, as the row gather of the EncoderMap step does (emx_next_batch::adc_head).  (Plan attributes: the parity tests set them.)
+    _prefetch = True
+    _fused_head = True      # gathers + sin/cos + soft start in one launch
+    _batched_costs = True   # the angle-like costs in one launch
+    _fuse_frame_default = True   # the per-frame stages of the step as one launch (emx_adc_frame_*)
+    _join_latent = True          # the cartesian-distance cost's latent gradient joins the encoder's backward launch
 
     TERM_NAMES = ADC_TERM_NAMES
     _reg_slot = T_REG
@@ -101,7 +102,7 @@ class ADCEngine(SequentialEngine):
         self.pw_start, self.pw_step, self.C = sel.start, sel.step, len(sel)
         self.P = self.C * (self.C - 1) // 2
         self.ldp = _round4(self.P)
-        self._fuse_frame = os.environ.get("EMX_ADC_FUSE_FRAME", "1") != "0"
+        self._fuse_frame = self._fuse_frame_default
         self._fuse_frame_bwd = self._fuse_frame
         self._fuse_cost_jobs = self._fuse_frame
         self._init_common(col, p, device, weights, dp, use_graph, history_capacity)
@@ -121,7 +122,7 @@ class ADCEngine(SequentialEngine):
         self.red_ws2 = torch.zeros(2 * _lib.EMX_REDUCE_WS, dtype=f32, device=dev)   # (two halves: emx_mlp_wgrad_adam_local, by step parity)
         self.wg_sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
         self.sk_sync = torch.zeros(4, dtype=torch.int32, device=dev)
-        self._local_ok = self._tail_ok = None
+        self._local_ok = None
         # batch means of the whole feature block in ONE launch: the mean bond lengths (BackMapLayer, layers.py:971) and -- without
         # backbone angles in the model -- the mean angles (MeanAngles, layers.py:1153-1161) are views into it
         self.feat_mean = z(self.F)
@@ -149,7 +150,7 @@ class ADCEngine(SequentialEngine):
         # the tile workspace.  EMX_ADC_JOIN_LATENT=0: the stand-alone reduction.
         p = self.p
         self._sk_cart = None
-        if p.cartesian_distance_cost_scale is not None and p.distance_cost_scale is None and os.environ.get("EMX_ADC_JOIN_LATENT", "1") != "0":
+        if p.cartesian_distance_cost_scale is not None and p.distance_cost_scale is None and self._join_latent:
             cs = p.center_cost_scale
             self._sk_cart = _lib.sketchmap_describe(self.inp_pair[:, :self.P], self.h[lay.n_enc - 1], INF, p.cartesian_dist_sig_parameters,
                                                     float(p.cartesian_distance_cost_scale), float(cs) if cs is not None else 0.0, 0, B,
@@ -279,7 +280,7 @@ class ADCEngine(SequentialEngine):
             self._frame_both_ok = False
             return False
 
-    _frame_both_ok = os.environ.get("EMX_ADC_FRAME_BOTH", "1") != "0"
+    _frame_both_ok = True
 
     def _frame_forward(self, Y: torch.Tensor) -> bool:
         """PeriodicOutput, BackMapLayer and both pair-distance blocks of the step as one launch (emx_adc_frame_fwd) behind the

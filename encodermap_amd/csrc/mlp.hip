@@ -1234,14 +1234,8 @@ __global__ __launch_bounds__(NTC) void chain_kernel(const float* p_in, const flo
 }
 
 // SMALL launches (every GEMM of the launch one unit: all layer widths of the range <= 128 -- the default network [128, 128, 2] on up
-// to 128 input columns): sixteen waves per 16-row block, two per 16-column tile (chain_body: KS = 2) -- and, for A/B runs, the
-// eight-wave build with the same simplifications (EMX_CHAIN_W16=0).
-template <int MODE, int NB>
-__global__ __launch_bounds__(2 * NTC) void chain_kernel_w16(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
-                                                            int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
-                                                            const ChainArgs a) {
-  chain_body<MODE, NB, 0, 2, true>(p_in, p_top_h, p_target, p_ld_in, p_in_cols, p_row0, p_row_end, p_ldt, p_cost_n, p_in_Q, p_with_cost, a);
-}
+// to 128 input columns): the eight-wave build with the unit bookkeeping of one-unit GEMMs folded away.  (A sixteen-wave build, two
+// waves per 16-column tile, was measured slower -- 25.8 against 21.9 us for the fused launch at 4096 rows -- and is gone.)
 template <int MODE, int NB>
 __global__ __launch_bounds__(NTC) void chain_kernel_small(const float* p_in, const float* p_top_h, const float* p_target, int p_ld_in, int p_in_cols,
                                                           int p_row0, int p_row_end, int p_ldt, int p_cost_n, int p_in_Q, int p_with_cost,
@@ -1586,143 +1580,15 @@ __global__ __launch_bounds__(NT) void mlp_wgrad_kernel(unsigned tb01, unsigned t
   wgrad_block<false>(tbw, (int)blockIdx.x, (int)blockIdx.y, hd, kv);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// The optimizer as the TAIL of the weight-gradient launch (emx_mlp_wgrad_adam): a step's last two launches in one.
-//   grid = (output blocks, slices + extra rows).  Rows [0, slices): the weight-gradient workgroups, dispatched first -- ALL of
-//   them are resident (the host checks: at most one per CU, one workgroup of this kernel fills a CU), so they may wait for one
-//   another.  Extra rows: workgroup 0 runs the step's scalar epilogue, the others gather the next batch's rows; neither waits.
-//   A weight-gradient workgroup stores its slice partials with sc1, drains them (s_waitcnt vmcnt(0)), and one lane adds to
-//   sync[0] at agent scope; it then waits (one lane polls, bounded) until every slice of every block is there and the epilogue
-//   has read the regulariser shares of the current weights (sync[3]); then its four waves run virtual optimizer workgroups
-//   (adam_store_block: sc1 loads of the partials, fixed order -- the same bits as emx_adam_step_slices behind emx_mlp_wgrad).
-//   Counters: nobody advances the optimizer step or the batch cursor while anyone may read them -- the LAST workgroup to leave
-//   (sync[1]) does, and resets the sync words for the next launch.  sync[2]: sticky, a wait ran out (never expected; the
-//   caller checks it when it synchronises).
-// ---------------------------------------------------------------------------------------------------------
-#ifdef EMX_CHAIN_TIMING   // timeline of the fused launch (tools/abl_tail.py): rows of 8 stamps at emx_dbg[8 * who]
+#ifdef EMX_CHAIN_TIMING   // timeline of the step's last launch (tools/abl_local.py): rows of 8 stamps at emx_dbg[8 * who]
 #define LSTAMP(who, k) do { if (threadIdx.x == 0) emx_dbg[8 * (who) + (k)] = wall_clock64(); } while (0)
 #else
 #define LSTAMP(who, k)
 #endif
-struct WgTail {
-  unsigned* sync;
-  int64_t* cursor;
-  int64_t* opt_step;
-  int n_leavers;       // workgroups that count in sync[1]: weight gradients + epilogue + gather
-  int gather_wgs;
-  unsigned spin_limit;
-  int debug;           // EMX_TAIL_DEBUG (timing experiments only): 1 the gather workgroups do nothing, 2 no optimizer work, 4 no waiting
-};
-struct WgradAdamDev {
-  WgLayer lay[MAXL];   // (the head's fields are explicit scalars: no WgHead here, the arguments are 4 KB at most)
-  FinishArgs fin;
-  WgTail t;
-  AdamArgs ad;
-};
-static_assert(sizeof(WgradAdamDev) + 64 <= 4096, "kernel arguments: 4 KB");
-static_assert(AdamArgs::PLANES == 16, "the tail's wave -> virtual workgroup map");
 constexpr unsigned WG_TAIL_SPIN_LIMIT = 1u << 22;   // x (one sc1 load + s_sleep): seconds -- the waits last microseconds
-
-__global__ __launch_bounds__(NT) void mlp_wgrad_adam_kernel(unsigned tb01, unsigned tb23, unsigned tb45, unsigned tb67, unsigned tb89, unsigned tbab,
-                                                            unsigned tbcd, int rb0, int rb_end, int rbs_per_slice, int n_tiles, int n_slices,
-                                                            float* partial, long n_params, const WgradAdamDev a) {
-  __shared__ float fin_red[EMX_MAX_SUM_JOBS][FIN_NT / 64];
-  __shared__ float fin_tl[64];
-  __shared__ __align__(16) _Float16 img[NT / 64][512];
-  __shared__ float red_dummy;
-  typedef const char __attribute__((address_space(4))) * KBytes;
-  typedef const void __attribute__((address_space(4))) * KArgs;
-  const KBytes kseg = (KBytes)__builtin_amdgcn_kernarg_segment_ptr() + 64;   // (64: the explicit scalars)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int bx = blockIdx.x, by = blockIdx.y;
-  unsigned* const sync = a.t.sync;
-  (void)red_dummy;
-  if (by >= n_slices) {
-    const int e = (by - n_slices) * n_tiles + bx;   // 0: the scalar epilogue; 1 ..: the next batch's rows
-    if (e == 0) {
-      LSTAMP(1000, 0);
-      finish_step_body<emx::FQ_EMBEDDED>(a.fin, fin_red, fin_tl);   // (its cursor / counter2 are null: advanced below)
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // its reads of the regulariser shares have returned
-      __syncthreads();
-      if (tid == 0) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      LSTAMP(1000, 1);
-    } else if (e - 1 < a.t.gather_wgs) {
-      if (!(a.t.debug & 1)) {
-      const int gw = 512 + e - 1;
-      if (gw >= 0) LSTAMP(gw, 0);
-      gather_rows2_multi<8>(a.ad.next, (e - 1) * (NT / 64) + wave, a.t.gather_wgs * (NT / 64), lane);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (gw >= 0) LSTAMP(gw, 1);
-      }
-    } else {
-      return;   // (padding of the last grid row)
-    }
-  } else {
-    const WgHd hd{rb0, rb_end, rbs_per_slice, 0, partial, n_params};
-    const unsigned tbw[7] = {tb01, tb23, tb45, tb67, tb89, tbab, tbcd};
-    const int ww = by * n_tiles + bx;
-    if (ww >= 0) LSTAMP(ww, 0);
-    wgrad_block<true>(tbw, bx, by, hd, (WgKVec)(kseg + offsetof(WgradAdamDev, lay)));
-    if (ww >= 0) LSTAMP(ww, 1);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (ww >= 0) LSTAMP(ww, 2);
-    __syncthreads();
-    const int n_wg = n_tiles * n_slices;
-    if (tid == 0) {
-      __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      // one word to poll (the epilogue counts as one more arrival), and politely: sc1 loads and the arrivals' atomics of the
-      // whole launch meet at ONE memory channel -- a workgroup that still misses many arrivals sleeps longer between looks
-      unsigned spins = 0;
-      while (!(a.t.debug & 4)) {
-        const unsigned seen = __hip_atomic_load(&sync[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (seen >= (unsigned)n_wg + 1u) break;
-        if (++spins > a.t.spin_limit) {
-          __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          break;
-        }
-        if ((unsigned)n_wg + 1u - seen > 16u) __builtin_amdgcn_s_sleep(32);
-        else __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    __syncthreads();
-    if (ww >= 0) LSTAMP(ww, 3);
-    // the optimizer: virtual workgroups of one wave each, the launch's waves in turn
-    const long step_now = *a.ad.step;
-    const int nblk = a.ad.adam_blocks;
-    // (virtual workgroup vb = 64 plane + x; the planes' work sits at their small x: wave w of the launch takes plane w % 16,
-    //  x = w / 16, so that the slabs spread over as many waves as there are)
-    const int n_waves = n_wg * (NT / 64);
-    for (int w = (by * n_tiles + bx) * (NT / 64) + wave; w < 64 * AdamArgs::PLANES; w += n_waves) {
-      const int vb = ((w & (AdamArgs::PLANES - 1)) << 6) | (w >> 4);
-      if (vb >= nblk || (a.t.debug & 2)) continue;   // (fewer planes than 16)
-      float reg = adam_store_block<true>(a.ad, (KArgs)(kseg + offsetof(WgradAdamDev, ad)), a.ad.mirror, vb, lane, step_now, img[wave]);
-      reg = wave_sum(reg);
-      if (lane == 0) a.ad.ws[vb] = reg;
-      if (vb == 0)
-        for (int i = nblk + lane; i < EMX_REDUCE_WS; i += 64) a.ad.ws[i] = 0.f;
-    }
-  }
-  asm volatile("" ::: "memory");
-#ifdef EMX_CHAIN_TIMING
-  if (by < n_slices) {
-    LSTAMP(by * n_tiles + bx, 4);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    LSTAMP(by * n_tiles + bx, 5);
-  }
-#endif
-  // leave: the last one advances the counters and clears the sync words
-  __syncthreads();
-  if (tid == 0) {
-    const unsigned done = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (done == (unsigned)a.t.n_leavers - 1u) {
-      __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (a.t.cursor) *a.t.cursor += 1;
-      if (a.t.opt_step) *a.t.opt_step += 1;
-    }
-  }
-}
+// (The optimizer as the tail of the SLICE workgroups of mlp_wgrad_kernel -- emx_mlp_wgrad_adam, rounds 3-5: every weight-gradient
+//  workgroup resident, waiting inside the launch for all slice partials -- was bit-identical to the two launches and slower, the wait
+//  cost more than the launch it saved (profiles/r03_tail_adam_ab.txt); removed in round 6.)
 
 // ---------------------------------------------------------------------------------------------------------
 // Small batches: weight gradients WITHOUT slice partials, the optimizer in the same workgroup (emx_mlp_wgrad_adam_local).
@@ -2234,51 +2100,32 @@ int check_aop(const void* aop, int aop_rows, int row_begin, int row_end, const c
 template <int MODE>
 int launch_chain(ChainBuilder& b, int row_begin, int row_end, size_t lds, hipStream_t st, const char* what) {
   const int grid = (row_end - row_begin + R - 1) / R;
-  // more than one row block per CU: the two-deep ring (<= 256 registers, two workgroups per CU); else the three-deep one
-  static const int force_nb = getenv("EMX_CHAIN_NB") ? atoi(getenv("EMX_CHAIN_NB")) : 0;
-  const bool deep = force_nb >= 3;   // (measured at C2: the deeper ring buys nothing -- the kernels are bound by instruction issue -- and costs registers)
+  // (the operand ring is two units deep in every build: a three-deep ring bought nothing at C2 -- the kernels are bound by
+  //  instruction issue -- and cost registers; profiles/r04_nb_ab.txt)
   int rc;
   // several row blocks per CU and LDS for two of them: the 128-register build, two workgroups per CU
-  static const int c128_min_blocks = getenv("EMX_CHAIN_C128_MIN_BLOCKS") ? atoi(getenv("EMX_CHAIN_C128_MIN_BLOCKS")) : 512;
-  if (!deep && grid >= c128_min_blocks && 2 * (lds + 1024) <= 160 * 1024) {
+  constexpr int c128_min_blocks = 512;
+  if (grid >= c128_min_blocks && 2 * (lds + 1024) <= 160 * 1024) {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_c128<MODE, 2>), lds, b.who);
     if (rc) return rc;
     hipLaunchKernelGGL((chain_kernel_c128<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
                        b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
     return emx::check_launch(what);
   }
-  // every GEMM one unit (all widths of the range <= 128) and at most a row block per CU or so: sixteen waves per row block
+  // every GEMM one unit (all widths of the range <= 128): the SMALL build
   bool small = true;
   for (int i = 0; i < b.ng; ++i) small = small && b.a.g[i].P == 1 && b.a.g[i].C == 1;
-  // 0 (default): eight waves, SMALL build; 1: sixteen waves (EXPERIMENT, measured slower: 25.8 against 21.9 us for the fused launch
-  // at 4096 rows -- every wave repeats the unit's scalar bookkeeping and the accumulator exchange costs a barrier per unit); -1: the general build
-  static const int w16 = getenv("EMX_CHAIN_W16") ? atoi(getenv("EMX_CHAIN_W16")) : 0;
-  if (!deep && small && w16 >= 0) {
-    if (w16 >= 1) {
-      rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_w16<MODE, 2>), lds, b.who, 18 * 1024);   // (the accumulator exchange areas are static)
-      if (rc == EMX_OK) {
-        hipLaunchKernelGGL((chain_kernel_w16<MODE, 2>), dim3(grid), dim3(2 * NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols,
-                           b.a.row0, b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
-        return emx::check_launch(what);
-      }
-    }
+  if (small) {
     rc = set_lds(reinterpret_cast<const void*>(&chain_kernel_small<MODE, 2>), lds, b.who);
     if (rc) return rc;
     hipLaunchKernelGGL((chain_kernel_small<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
                        b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
     return emx::check_launch(what);
   }
-  if (deep) {
-    rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 3>), lds, b.who);
-    if (rc) return rc;
-    hipLaunchKernelGGL((chain_kernel<MODE, 3>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
-                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
-  } else {
-    rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 2>), lds, b.who);
-    if (rc) return rc;
-    hipLaunchKernelGGL((chain_kernel<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
-                       b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
-  }
+  rc = set_lds(reinterpret_cast<const void*>(&chain_kernel<MODE, 2>), lds, b.who);
+  if (rc) return rc;
+  hipLaunchKernelGGL((chain_kernel<MODE, 2>), dim3(grid), dim3(NTC), lds, st, b.a.in, b.a.top_h, b.a.cost.target, b.a.ld_in, b.a.in_cols, b.a.row0,
+                     b.a.row_end, b.a.cost.ldt, b.a.cost.n, b.a.in_Q, b.a.cost.ws != nullptr ? 1 : 0, b.a);
   return emx::check_launch(what);
 }
 
@@ -2703,10 +2550,9 @@ int launch_chain_tiles_impl(ChainBuilder& b, const emx::sk::TileRole& tr, int gr
 
 template <bool FAST, int NCH, int KIND = 0>
 int launch_chain_tiles(ChainBuilder& b, const emx::sk::TileRole& tr, int grid, size_t lds, hipStream_t st) {
-  bool small = true;   // every GEMM one unit: the SMALL build of the dense-layer workgroups (EMX_CHAIN_W16=-1: the general build)
+  bool small = true;   // every GEMM one unit: the SMALL build of the dense-layer workgroups
   for (int i = 0; i < b.ng; ++i) small = small && b.a.g[i].P == 1 && b.a.g[i].C == 1;
-  static const bool allow = !(getenv("EMX_CHAIN_W16") && atoi(getenv("EMX_CHAIN_W16")) < 0);
-  if (small && allow) return launch_chain_tiles_impl<FAST, NCH, KIND, true>(b, tr, grid, lds, st);
+  if (small) return launch_chain_tiles_impl<FAST, NCH, KIND, true>(b, tr, grid, lds, st);
   return launch_chain_tiles_impl<FAST, NCH, KIND, false>(b, tr, grid, lds, st);
 }
 
@@ -2948,14 +2794,14 @@ int forward_backward_impl(const emx_mlp_desc* desc, float* params, const float* 
   tr.join = tiles->latent ? 1 : 0;
   // persistent tile workgroups: one per CU beside its chain workgroup (more would wait for the chain workgroups to leave), each
   // walking its share of the tile pairs -- in the XCD-aware order 32 per XCD list (pairs k, k + 32, ... of the list)
-  static const int forced_per_xcd = getenv("EMX_TILE_WGS_PER_XCD") ? std::max(1, atoi(getenv("EMX_TILE_WGS_PER_XCD"))) : 0;
+  constexpr int forced_per_xcd = 0;
   const int per_xcd = forced_per_xcd ? forced_per_xcd : std::max(1, device_cus() / 8);
   if (tr.a.xcd_nbg > 0) tr.n_tile_wgs = 8 * std::min(per_xcd, tr.a.xcd_nbg * (tr.a.xcd_nbg + 1) / 2);
   else tr.n_tile_wgs = std::min(8 * per_xcd, (vblocks + 1) / 2);
   const size_t lds = std::max((size_t)b.lds, (size_t)emx::sk::TILE_ROLE_LDS_BYTES);
   int grid = n_chain + tr.n_tile_wgs;
   // (timing experiments only -- wrong results: EMX_TILES_DEBUG=1 launches the chain workgroups alone, =2 tile workgroups that do not wait)
-  static const int dbg = getenv("EMX_TILES_DEBUG") ? atoi(getenv("EMX_TILES_DEBUG")) : 0;
+  constexpr int dbg = 0;
   if (dbg == 1) grid = n_chain;
   if (dbg == 2) tr.n_chain = 0;
   if (dbg == 3) {   // the tile workgroups alone
@@ -3026,7 +2872,7 @@ static int wgrad_slice_rows(int n_rows) {
   int r = EMX_WGRAD_SLICE_ROWS;
   while ((long)r * EMX_WGRAD_MAX_SLICES < n_rows) r *= 2;
   // small batches: shorter slices, so that a few hundred rows still spread over eight slices' worth of workgroups
-  static const int min_rows = getenv("EMX_WGRAD_MIN_SLICE") ? std::max(16, atoi(getenv("EMX_WGRAD_MIN_SLICE")) / 16 * 16) : 32;
+  constexpr int min_rows = 32;
   while (r > min_rows && n_rows < 8 * r) r /= 2;
   return r;
 }
@@ -3134,111 +2980,10 @@ int device_cus() {
 }
 }  // namespace
 
-// weight-gradient workgroups of the launch, spare workgroups for the gather; 0 if the tail does not fit
-static int wgrad_adam_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* tiles_out, int* slices_out, int* gather_out) {
-  int tiles = 0;
-  for (int l = 0; l < desc->n_layers; ++l) tiles += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
-  const int slices = emx_mlp_wgrad_slices(n_rows);
-  const int cus = device_cus();
-  // every weight-gradient workgroup must be resident while it waits for the others: one workgroup of this kernel fills a CU
-  const int spare = cus - tiles * slices - 1;
-  int gather = 0;
-  if (next) {
-    if (next->adc_head || !gather_vec4(next)) return 0;
-    const int want = (next->B + 2 * 8 * (NT / 64) - 1) / (2 * 8 * (NT / 64));   // eight row pairs per wave and pass
-    static const int cap = getenv("EMX_TAIL_GATHER_WGS") ? atoi(getenv("EMX_TAIL_GATHER_WGS")) : 1 << 20;
-    gather = std::min(std::min(want, spare), cap);
-    // (few spare workgroups for a large batch: the gather would outlast the weight gradients)
-    if (gather < 1 || (long)gather * 16 * (NT / 64) * 2 < next->B) return 0;   // (at most two passes)
-  }
-  if (spare < 0 || cus <= 0) return 0;
-  *tiles_out = tiles;
-  *slices_out = slices;
-  *gather_out = gather;
-  return 1;
-}
-
-int emx_mlp_wgrad_adam_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next) {
-  if (!desc || desc->n_layers < 1 || desc->n_layers > MAXL || n_rows < 1) return 0;
-  int t, sl, g;
-  return wgrad_adam_shape(desc, n_rows, next, &t, &sl, &g);
-}
-
-int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params, const void* aop, int aop_rows, int row_begin, int row_end,
-                       float* ws, size_t ws_floats, const emx_finish_desc* finish, float* m, float* v, const float* l2coef, float lr, float beta1,
-                       float beta2, float eps, float clip, float* reg_ws, float* mirror, const emx_next_batch* next, uint32_t* sync,
-                       emx_stream_t stream) {
-  const char* who = "emx_mlp_wgrad_adam";
-  int rc = check_desc(desc, who);
-  if (rc) return rc;
-  EMX_REQUIRE(params && aop && ws && m && v && reg_ws && mirror && sync && finish, "%s: null pointer argument", who);
-  {
-    const int rz = emx::ensure_counters_zeroed(sync, 4 * sizeof(unsigned), (hipStream_t)stream, who);
-    if (rz) return rz;
-  }
-  EMX_REQUIRE(finish->hstep && finish->cursor && finish->counter2, "%s: the epilogue's counters (history step, batch cursor, optimizer step) are required", who);
-  EMX_REQUIRE(0 <= row_begin && row_begin < row_end, "%s: bad rows", who);
-  rc = check_aop(aop, aop_rows, row_begin, row_end, who);
-  if (rc) return rc;
-  rc = check_next(next, who);
-  if (rc) return rc;
-  const int nrows = row_end - row_begin;
-  if (ws_floats < emx_mlp_wgrad_ws_floats(n_params, nrows))
-    return emx::fail(EMX_EWORKSPACE, "%s: workspace %zu < %zu floats", who, ws_floats, emx_mlp_wgrad_ws_floats(n_params, nrows));
-  int tiles = 0, slices = 0, gather = 0;
-  if (!wgrad_adam_shape(desc, nrows, next, &tiles, &slices, &gather))
-    return emx::fail(EMX_EUNSUPPORTED, "%s: the launch does not fit this network / batch on the device (emx_mlp_wgrad_adam_fits): use emx_mlp_wgrad + "
-                     "emx_adam_step_slices", who);
-  EMX_REQUIRE((size_t)slices * (size_t)n_params * 4 < (size_t)1 << 31, "%s: slice partials beyond 2 GB", who);
-  WgradAdamDev a{};
-  // the epilogue: as emx_mlp_wgrad's, but the cursor and the optimizer step are advanced by the launch's last workgroup
-  rc = fill_finish_args(a.fin, finish->jobs, finish->n_jobs, finish->terms, finish->n_terms, finish->history, finish->term_history, finish->capacity,
-                        finish->hstep, nullptr, nullptr, "emx_mlp_wgrad_adam (finish)");
-  if (rc) return rc;
-  AopLayout AL;
-  aop_layout(desc, aop_rows, AL);
-  const int n = desc->n_layers;
-  int tile_begin[MAXL + 1];
-  for (int i = 0; i <= MAXL; ++i) tile_begin[i] = INT_MAX;
-  int tcount = 0;
-  for (int l = 0; l < n; ++l) {
-    const AopTensor X = aop_tensor(const_cast<void*>(aop), AL, l);
-    const AopTensor Dl = aop_tensor(const_cast<void*>(aop), AL, 1 + n + l);
-    a.lay[l] = WgLayer{X.frag, X.rscale, Dl.frag, Dl.rscale, (long)desc->w_off[l], (long)desc->b_off[l], desc->width[l], desc->width[l + 1], X.CG, Dl.CG};
-    tile_begin[l] = tcount;
-    tcount += ((desc->width[l] + 127) / 128) * ((desc->width[l + 1] + 127) / 128);
-  }
-  EMX_REQUIRE(tcount == tiles && tiles < 0xffff, "%s: %d output blocks", who, tiles);
-  unsigned tbw[7];
-  for (int i = 0; i < 7; ++i) {
-    auto t16 = [&](int k) { return (unsigned)std::min(tile_begin[std::min(k, MAXL)], 0xffff) & 0xffffu; };
-    tbw[i] = t16(2 * i) | (t16(2 * i + 1) << 16);
-  }
-  a.ad = make_adam(params, nullptr, ws, slices, n_params, m, v, l2coef, n_params, lr, beta1, beta2, eps, clip, finish->counter2, reg_ws, desc, mirror, next);
-  a.ad.adam_blocks = 64 * a.ad.n_planes;
-  a.ad.late = 1;          // the regulariser shares left behind are those of the NEW weights ...
-  a.ad.step_ahead = 1;    // ... while *step still counts the updates before this one
-  a.ad.next.batch_step = 1;
-  a.t.sync = sync;
-  a.t.cursor = finish->cursor;
-  a.t.opt_step = finish->counter2;
-  a.t.gather_wgs = gather;
-  a.t.n_leavers = tiles * slices + 1 + gather;
-  static const unsigned spin = getenv("EMX_TAIL_SPIN_LIMIT") ? (unsigned)atol(getenv("EMX_TAIL_SPIN_LIMIT")) : WG_TAIL_SPIN_LIMIT;
-  a.t.spin_limit = spin;
-  static const int dbg = getenv("EMX_TAIL_DEBUG") ? atoi(getenv("EMX_TAIL_DEBUG")) : 0;
-  a.t.debug = dbg;
-  const int extra_rows = (1 + gather + tiles - 1) / tiles;
-  hipLaunchKernelGGL(mlp_wgrad_adam_kernel, dim3(tiles, slices + extra_rows), dim3(NT), 0, (hipStream_t)stream, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4],
-                     tbw[5], tbw[6], row_begin / 16, (row_end + 15) / 16, wgrad_slice_rows(nrows) / 16, tiles, slices, ws, (long)n_params, a);
-  return emx::check_launch("mlp_wgrad_adam_kernel");
-}
-
-
 // 32 x 32 blocks of all kernels; 0 if the launch is not made for this network / batch
 static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next, int* blocks_out, int* gather_out, int* splits_out) {
-  static const int max_rows = getenv("EMX_WGRAD_LOCAL_MAX_ROWS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_ROWS")) : 4096;
-  static const int max_blocks = getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS") ? atoi(getenv("EMX_WGRAD_LOCAL_MAX_BLOCKS")) : 1000;
+  constexpr int max_rows = 4096;
+  constexpr int max_blocks = 1000;
   if (n_rows > max_rows) return 0;
   int blocks = 0;
   for (int l = 0; l < desc->n_layers; ++l) blocks += ((desc->width[l] + 31) / 32) * ((desc->width[l + 1] + 31) / 32);
@@ -3252,13 +2997,13 @@ static int wgrad_local_shape(const emx_mlp_desc* desc, int n_rows, const emx_nex
   // the rows of a block over several workgroups: what bounds the launch is the bytes in flight, i.e. the number of CUs at work --
   // as many parts as fit the device beside the epilogue, at least 32 row blocks (four per wave) each, at most two (C2, 72 blocks:
   // 0.0735 / 0.0714 / 0.0725-0.0732 ms per step with 1 / 2 / 3 parts -- every part's share goes through memory)
-  static const int max_splits = std::min(getenv("EMX_WGRAD_LOCAL_SPLITS") ? atoi(getenv("EMX_WGRAD_LOCAL_SPLITS")) : 2, 4);   // (the last arriver adds at most four shares)
+  constexpr int max_splits = 2;   // (the last arriver adds at most four shares)
   const int nrb = (n_rows + 15) / 16;
   // at most 32 gather workgroups, two passes each at 4096 rows: 65.1-65.6 against 65.9-66.1 us per step with 64 (24 the same, 16: 66.0,
   // 8: 77.5; same box, alternating, profiles/r05_tail_gather_ab.txt) -- their loads compete with the block workgroups' fragment requests
-  static const int gather_cap = getenv("EMX_LOCAL_GATHER_WGS") ? std::max(1, atoi(getenv("EMX_LOCAL_GATHER_WGS"))) : 32;
+  constexpr int gather_cap = 32;
   if (next && !next->adc_head) gather = std::min(gather, gather_cap);
-  static const bool forced = getenv("EMX_WGRAD_LOCAL_SPLITS") != nullptr;   // (an experiment may ask for more workgroups than CUs: nobody waits for a sibling)
+  constexpr bool forced = false;   // (an experiment may ask for more workgroups than CUs: nobody waits for a sibling)
   int splits = std::min(std::min(max_splits, (nrb + 31) / 32), forced ? 4 : (std::max(device_cus(), 1) - 1) / std::max(blocks, 1));
   splits = std::max(splits, 1);
   *blocks_out = blocks;
@@ -3334,7 +3079,7 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   // one row of a 128-wide kernel's blocks, which read the same in-feature fragments -- on one XCD, the groups dealt evenly over the
   // XCDs (C2: 0.0717 -> 0.0713 ms per step; pairs 0.0722); 1: a whole kernel's blocks on one XCD -- half the HBM traffic and a
   // LONGER launch (profiles/r03_tail_adam_ab.txt)
-  static const int xcd_aware = getenv("EMX_WGRAD_LOCAL_XCD") ? atoi(getenv("EMX_WGRAD_LOCAL_XCD")) : 4;
+  constexpr int xcd_aware = 4;
   int per_xcd = std::min(32, std::max((blocks + 7) / 8, pow2ceil(largest)));
   int n_slots = 0;
   if (xcd_aware != 1) {
@@ -3373,7 +3118,7 @@ int emx_mlp_wgrad_adam_local(const emx_mlp_desc* desc, float* params, int64_t n_
   a.t.n_counted = splits * blocks + gather;
   a.t.splits = splits;
   a.t.shares = ws;
-  static const unsigned spin = getenv("EMX_TAIL_SPIN_LIMIT") ? (unsigned)atol(getenv("EMX_TAIL_SPIN_LIMIT")) : WG_TAIL_SPIN_LIMIT;
+  constexpr unsigned spin = WG_TAIL_SPIN_LIMIT;
   a.t.spin_limit = spin;
   hipLaunchKernelGGL(mlp_wgrad_local_kernel, dim3(splits * n_slots + 1 + gather), dim3(NTL), 0, (hipStream_t)stream, tbw[0], tbw[1], tbw[2], tbw[3], tbw[4], tbw[5],
                      tbw[6], row_begin / 16, (row_end + 15) / 16, blocks, per_xcd, n_slots, (const int64_t*)finish->counter2, (const char*)mirror, a);

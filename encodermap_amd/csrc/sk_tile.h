@@ -38,9 +38,9 @@ struct SkArgs {
   SigDev sh, sl;
   SplitRows split;   // optional f16 planes + norms of the rows (split.h): selects the f16 Gram kernel
   int xcd_nbg;       // > 0: XCD-aware tile order of the f16 kernel (xcd_tile), tile columns per group
-  // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of a first launch
-  // (kmode 1: Gram partial of its chunks -> kpart), a second launch (kmode 2) adds them up in a fixed order and runs the
-  // epilogue.  kmode 0: one workgroup per tile does both.
+  // few tiles, many features (B <= 640): the reduction of a tile is split over ksplit workgroups of the launch (kmode 3: each leaves
+  // the Gram partial of its chunks in kpart and takes a ticket; the last one adds them up in a fixed order and runs the epilogue).
+  // kmode 0: one workgroup per tile does both.
   int ksplit, kmode;
   float* kpart;      // [tiles][ksplit][4 waves][16][64]
   unsigned* ktickets; // [tiles] kmode 3: the split reduction in ONE launch -- workgroups of a tile that have left their share (zero between launches)

@@ -616,7 +616,7 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 :
 
   const int kmode = NCH == 0 ? (p_kmode_ksplit >> 16) : 0;
   const int ksplit_ = p_kmode_ksplit & 0xffff;
-  const int tile_id = (kmode == 1 || kmode == 3) ? (int)blockIdx.x / ksplit_ : (int)blockIdx.x;
+  const int tile_id = kmode == 3 ? (int)blockIdx.x / ksplit_ : (int)blockIdx.x;
   int ti, tj, tslot = tile_id;
   if (p_xcd_nbg > 0) {
     if (!xcd_tile(blockIdx.x, p_xcd_nbg, p_nbc, ti, tj, tslot)) return;
@@ -704,22 +704,9 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 :
     for (int c = 0; c < NCH; ++c) SK_CHUNK(c, c + 1 < NCH)
   } else if (kmode == 0) {
     for (int c = 0; c < nch; ++c) SK_CHUNK(c, true)   // (the last request re-reads its own chunk)
-  } else if (kmode == 1) {
-    // this workgroup's share of the chunks; its Gram partial goes to kpart and the workgroup is done
-    const int sidx = (int)blockIdx.x - tile_id * a.ksplit;
-    const int c0 = (int)((long)sidx * nch / a.ksplit), c1 = (int)((long)(sidx + 1) * nch / a.ksplit);
-    if (c0 < c1) {
-      SK_GLOAD(c0)
-      for (int c = c0; c < c1; ++c) SK_CHUNK(c, true)
-    }
-    float* dst = a.kpart + ((long)blockIdx.x * 4 + wave) * 1024 + lane;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dst[64 * r] = acc[r];
-    return;
-  } else if (kmode == 3) {
-    // ONE launch for the split reduction: the workgroup leaves its share of the chunks in kpart (sc1 stores, drained), takes a
-    // ticket of its tile, and the LAST of the tile's workgroups adds the shares in the order of the chunks -- the sums of kmode 2,
-    // the same bits -- and runs the epilogue.  Nobody waits; the last one leaves the ticket word at zero for the next launch.
+  } else {
+    // kmode 3, ONE launch for the split reduction: the workgroup leaves its share of the chunks in kpart (sc1 stores, drained), takes a
+    // ticket of its tile, and the LAST of the tile's workgroups adds the shares in the order of the chunks and runs the epilogue.  Nobody waits; the last one leaves the ticket word at zero for the next launch.
     const int sidx = (int)blockIdx.x - tile_id * a.ksplit;
     const int c0 = (int)((long)sidx * nch / a.ksplit), c1 = (int)((long)(sidx + 1) * nch / a.ksplit);
     if (c0 < c1) {
@@ -742,12 +729,6 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(LT > 8 ? 3 :
     for (int s2 = 0; s2 < a.ksplit; ++s2)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += emx::sk::load_sc1(src + (long)s2 * 4096 + 64 * r);
-  } else {
-    // the partials of the first launch, added in the order of the chunks
-    const float* src = a.kpart + ((long)tile_id * a.ksplit * 4 + wave) * 1024 + lane;
-    for (int sidx = 0; sidx < a.ksplit; ++sidx)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] += src[(long)sidx * 4096 + 64 * r];
   }
 #undef SK_CHUNK
 #undef SK_GLOAD
@@ -1471,10 +1452,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   const bool symm = (row_begin == 0 && row_end == B);
   const int nrows = row_end - row_begin;
   pl.periodic = std::isfinite(periodicity);
-  {
-    const char* e = getenv("EMX_SKETCHMAP_DIRECT");   // debugging aid: force the direct-difference VALU tiles
-    pl.gram = !(e && e[0] == '1');
-  }
+  pl.gram = true;
   const bool vec4ok = (D % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
   const bool split_ok = split_ws != nullptr && pl.gram && !pl.periodic;
   const int T = pick_tile(B, nrows, (pl.gram && !pl.periodic && vec4ok) || split_ok, pl.periodic, L);
@@ -1501,7 +1479,7 @@ int make_plan(const float* X, int B, int D, int ldx, const float* Z, int L, floa
   // |x_i - x_j| < 1.5 p, where the reference's min(|d|, p - |d|) squared IS the squared wrapped difference, which the
   // fixed-point tiles compute.  A wider or unknown span (data_span <= 0) keeps the float form, which follows the reference's
   // formula for any |d|.  EMX_SK_PHASE=0 forces the float form.
-  static const bool phase_allowed = !(getenv("EMX_SK_PHASE") && atoi(getenv("EMX_SK_PHASE")) == 0);
+  constexpr bool phase_allowed = true;
   a.phase_ok = (pl.periodic && phase_allowed && data_span > 0.f && data_span < 1.5f * periodicity) ? 1 : 0;
   {
     const double rp = pl.periodic ? 1.0 / (double)periodicity : 0.0;
@@ -1558,7 +1536,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     SkArgs b = a;
     b.xcd_nbg = 0;
     int grid = pl.ntiles;
-    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    constexpr bool xcd_order = true;
     if (a.symm && a.nbc >= 16 && xcd_order) {   // XCD-aware tile order (xcd_tile): 8 x the largest share, the surplus blocks leave at once
       b.xcd_nbg = (a.nbc + 3) / 4;
       grid = 8 * b.xcd_nbg * (b.xcd_nbg + 1);
@@ -1566,21 +1544,20 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     // few tiles, many chunks (a small batch of very long rows, e.g. the pair-distance vectors of the ADC model): the tiles
     // alone would occupy a handful of CUs -- split each tile's reduction over workgroups (first launch), add the partials
     // up and run the epilogue (second launch)
-    static const int ksplit_cap = getenv("EMX_SK_KSPLIT") ? std::max(1, atoi(getenv("EMX_SK_KSPLIT"))) : 16;   // (measured at the ADC shape: 32 -> 180.8, 16 -> 178.3, 8 -> 179.8 us per step)
+    constexpr int ksplit_cap = 16;   // (measured at the ADC shape: 32 -> 180.8, 16 -> 178.3, 8 -> 179.8 us per step)
     const int ksplit = (b.kpart && b.xcd_nbg == 0 && nch >= 16) ? std::min(std::min(ksplit_cap, nch / 4), KSPLIT_BLOCKS / std::max(pl.ntiles, 1)) : 1;
     if (ksplit > 1) {
       b.ksplit = ksplit;
-      // one launch (kmode 3: the last workgroup of a tile adds the shares and runs the epilogue; the tickets live behind kpart in the
-      // caller's workspace, zero before the first use) -- or, EMX_SK_KSPLIT_TWO=1, the two launches it replaces (kmode 1, 2)
-      static const bool two = getenv("EMX_SK_KSPLIT_TWO") && atoi(getenv("EMX_SK_KSPLIT_TWO")) == 1;
-      if (!two) {   // (the tickets of the one-launch form live in memory of the library's, one zeroed block per workspace address: emx_common.h)
+      // one launch (kmode 3: the last workgroup of a tile adds the shares and runs the epilogue; its tickets live in memory of the
+      // library's, one zeroed block per workspace address: emx_common.h)
+      {
         int rz = EMX_OK;
         b.ktickets = emx::owned_tickets(b.ktickets, (size_t)KSPLIT_BLOCKS * sizeof(unsigned), st, "emx_sketchmap_tiles (split reduction)", &rz);
         if (rz) return rz;
       }
-      for (int mode = two ? 1 : 3; mode <= (two ? 2 : 3); ++mode) {
-        b.kmode = mode;
-        const dim3 gk(mode == 2 ? pl.ntiles : pl.ntiles * ksplit);
+      {
+        b.kmode = 3;
+        const dim3 gk(pl.ntiles * ksplit);
         if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), gk, b);
         else if (a.L == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, false, 0>), gk, b);
         else if (pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<0, true, 0>), gk, b);
@@ -1591,7 +1568,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
       return EMX_OK;
     }
     // large batches: 128 x 128 macro-tiles writing the 64-tile layout (sk_tile_f16_big_kernel); not for dealt tiles
-    static const int big_min_b = getenv("EMX_SK_BIG_MIN_B") ? atoi(getenv("EMX_SK_BIG_MIN_B")) : 8192;
+    constexpr int big_min_b = 8192;
     if (a.L == 2 && a.symm && a.deal_world <= 1 && a.B >= big_min_b && a.row0 == 0 && a.row_end == a.B) {
       const int nbc2 = (a.B + 127) / 128;
       int nbg2 = 0, grid2 = nbc2 * (nbc2 + 1) / 2;
@@ -1615,7 +1592,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     else if (a.L == 3 && pl.fast && nch == 8) SK_F16_LAUNCH((sk_tile_f16_kernel<3, true, 8>), dim3(grid), b);   //  width instantiation below needs 102 registers: four tiles per CU)
     else if (a.L == 4 && pl.fast && nch == 4) SK_F16_LAUNCH((sk_tile_f16_kernel<4, true, 4>), dim3(grid), b);
     else if (a.L == 4 && pl.fast && nch == 8) SK_F16_LAUNCH((sk_tile_f16_kernel<4, true, 8>), dim3(grid), b);
-    else if (a.L == 2 && pl.fast && nch == 8 && !getenv("EMX_SK_NO_NCH8")) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 8>), dim3(grid), b);
+    else if (a.L == 2 && pl.fast && nch == 8) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 8>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 2) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 2>), dim3(grid), b);
     else if (a.L == 2 && pl.fast && nch == 1) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 1>), dim3(grid), b);
     else if (a.L == 2 && pl.fast) SK_F16_LAUNCH((sk_tile_f16_kernel<2, true, 0>), dim3(grid), b);
@@ -1642,7 +1619,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
     const int nbc64 = (a.B + 63) / 64, nbr64 = (a.row_end - a.row0 + 63) / 64;
     int grid = a.symm ? nbc64 * (nbc64 + 1) / 2 : nbr64 * nbc64;
     int xnbg = 0;
-    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    constexpr bool xcd_order = true;
     if (a.symm && nbc64 >= 16 && xcd_order) {
       xnbg = (nbc64 + 3) / 4;
       grid = 8 * xnbg * (xnbg + 1);
@@ -1677,7 +1654,7 @@ int launch_tiles_plan(const SkPlan& pl, hipStream_t st) {
   } else {
     SkArgs b = a;
     int grid = pl.ntiles;
-    static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+    constexpr bool xcd_order = true;
     if (a.symm && a.nbc >= 16 && xcd_order) {   // as for the f16 tiles: 8 x the largest share, surplus blocks leave at once
       b.xcd_nbg = (a.nbc + 3) / 4;
       grid = 8 * b.xcd_nbg * (b.xcd_nbg + 1);
@@ -1719,7 +1696,7 @@ int make_tile_role(const float* X, int B, int D, int ldx, const float* Z, int L,
   }
   if (L != 2 || pl.T != 64 || pl.a.split.planes == nullptr) return emx::fail(EMX_EUNSUPPORTED, "%s: the tile role runs two-column latents on split rows", who);
   *kind = 0;
-  static const bool xcd_order = !(getenv("EMX_SK_XCD") && atoi(getenv("EMX_SK_XCD")) == 0);
+  constexpr bool xcd_order = true;
   if (pl.a.nbc >= 16 && xcd_order) {   // (as launch_tiles_plan)
     out->a.xcd_nbg = (pl.a.nbc + 3) / 4;
     *virtual_blocks = 8 * out->a.xcd_nbg * (out->a.xcd_nbg + 1);

@@ -128,7 +128,7 @@ class DataParallel:
         if op == "sum":
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
             return
-        if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl" and os.environ.get("EMX_DP_AVG", "1") != "0":
+        if self.mode == "replica" and flat.is_cuda and dist.get_backend(self.group) == "nccl":
             dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)   # RCCL averages in the collective
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -222,11 +222,8 @@ class SequentialEngine:
         self.hstep = torch.zeros(1, dtype=torch.int64, device=dev)  # write position in history
 
         self.rb, self.re = self.dp.row_block(self.B)
-        self._side_stream = torch.cuda.Stream(device=self.device)
-        # Optional fork/join of the two post-forward branches (all-pairs kernel || auto cost + decoder backward).  Off by
-        # default: on this stack every cross-stream dependency inside a hipGraph costs 5-12 us (measured, rocprofv3
-        # timeline), more than the ~19 us of work the overlap hides.
-        self._fork = os.environ.get("EMX_FORK_STREAMS", "0") == "1"
+        # (one stream: a fork / join of the two post-forward branches -- all-pairs kernel || auto cost + decoder backward -- over two
+        #  streams cost 5-12 us per cross-stream dependency inside a hipGraph, more than the overlap hid; removed in round 6)
         self._alloc_step_buffers(self.B)
         self._sync_derived_state()
         self._graph = None
@@ -275,9 +272,8 @@ class SequentialEngine:
         self.zpub = torch.zeros(B, self.L, dtype=f32, device=dev)
         self.sk_sync = torch.zeros(8, dtype=torch.int32, device=dev)
         self._tiles_ran = False
-        # the optimizer as the tail of the weight-gradient launch (emx_mlp_wgrad_adam): its counters, zeroed once
+        # counters of the step's last launch (emx_mlp_wgrad_adam_local), zeroed once
         self.wg_sync = torch.zeros(4 + 1024, dtype=torch.int32, device=dev)
-        self._tail_ok = None
         self._local_ok = None
         self._tail_ran = False
 
@@ -355,34 +351,29 @@ class SequentialEngine:
 
     # -- forward / backward ------------------------------------------------------------------------
     _prefetch = True   # the rows of batch t+1 are gathered beside the optimizer of step t (emx_next_batch)
-    _fuse_decoder = os.environ.get("EMX_FUSE_DECODER", "1") != "0"   # forward + auto cost + decoder backward in one launch
-    _fold_finish = os.environ.get("EMX_FOLD_FINISH", "1") != "0"     # scalar epilogue inside the weight-gradient launch
+    _fuse_decoder = True   # forward + auto cost + decoder backward in one launch (plan attributes like this one: set by the parity tests)
+    _fold_finish = True    # scalar epilogue inside the weight-gradient launch
     _cost_in_forward = True                                          # auto cost inside the forward launch (False: layers too wide)
     _graph_steps = max(1, int(os.environ.get("EMX_GRAPH_STEPS", "32")))  # steps per replay of the largest multi-step graph (1: single-step graph only); 8 -> 32: -0.6 .. -1.0 us per step at C2
     _graph_multi = None
     _data_span = None   # periodic data: max - min over the training set (set_data)
     _dp_graph_allreduce = os.environ.get("EMX_DP_GRAPH_ALLREDUCE", "0") == "1"   # data parallel: capture the all-reduce too (the engine's own default is eager; bench.py sets it after its child-process probe)
     # the all-pairs tiles ride in the fused dense-layer launch, beside the decoder half of it (single process, Euclidean data on
-    # split rows, two latent columns; anything else keeps the separate tile launch).  EMX_OVERLAP_TILES=0: always separate.
-    _overlap_tiles = os.environ.get("EMX_OVERLAP_TILES", "1") != "0"
+    # split rows, two latent columns; anything else keeps the separate tile launch).
+    _overlap_tiles = True
+    _overlap_max_rows = 1536   # ... up to this batch size (beyond it the separate launches are faster: profiles/r03_overlap_ab.txt)
     # ... and, where the tiles ride there, the encoder's backward units too (emx_mlp_forward_backward_tiles_join): the dense-layer
     # workgroups wait inside the launch for the tiles' partial sums and carry on down the encoder from their LDS images
-    _join_bwd = os.environ.get("EMX_JOIN_BWD", "1") != "0"
+    _join_bwd = True
     _bwd_ran = False
-    # single process: L2 + clip + Adam, the operand store and the next batch's rows as the tail of the weight-gradient launch
-    # (emx_mlp_wgrad_adam: four launches per step instead of five) where every weight-gradient workgroup is resident at once.
-    # OFF by default: bit-identical, but measured slower than the two launches (C2: the one launch 27-33 us against 9.9 + 9.6 us,
-    # profiles/r03_tail_adam_ab.txt -- the workgroups' wait for one another inside the launch costs more than the launch it saves)
-    _tail_adam = os.environ.get("EMX_TAIL_ADAM", "0") == "1"
-    _tail_ran = False
-    _tail_ok = None
+    _tail_ran = False      # the step's last launch ran the optimizer too (emx_mlp_wgrad_adam_local)
     # single process, batches of up to 4096 rows, networks of up to 1000 blocks of 32 x 32: the weight gradients WITHOUT slice partials -- a workgroup owns a
     # 32 x 32 block of a kernel over all rows and updates it itself -- with the epilogue and the next batch's rows in the same launch
     # (emx_mlp_wgrad_adam_local: the step's last TWO launches in one, nothing waits for anything)
-    _local_wgrad = os.environ.get("EMX_LOCAL_WGRAD", "1") != "0"
+    _local_wgrad = True
     _local_ok = None
     _tiles_ran = False
-    _lean = os.environ.get("EMX_LEAN_ROWS", "1") != "0"   # float32 rows that no launch reads are not written (plan_lean)
+    _lean = True   # float32 rows that no launch reads are not written (plan_lean)
 
     def _gather_current(self) -> None:
         """Rows of the batch under the cursor -> xb / xin (head of an index block; afterwards the optimizer launch of every
@@ -395,10 +386,10 @@ class SequentialEngine:
         every row first).  The activations, the decoder's deltas and the latent gradient of the auto cost (``dlat``) go to
         HBM for the kernels that follow; the cost's per-row-block shares stay in ``cost_ws`` for the step's scalar epilogue.
         Returns False when the decoder's backward pass still has to be launched (no auto cost, a non-linear output layer,
-        layers too wide for the LDS images of the fused launch, or forked streams)."""
+        or layers too wide for the LDS images of the fused launch)."""
         lay, n, p = self.layout, len(self.layout.layers), self.p
         full = (self.rb, self.re) == (0, self.B)
-        fuse = p.auto_cost_scale is not None and self._fuse_decoder and not self._fork
+        fuse = p.auto_cost_scale is not None and self._fuse_decoder
         cost = None
         lean = self._lean and self.plan_lean is not self.plan
         pf = self.plan_lean if lean else self.plan        # (the fused launches: rows nobody reads stay on chip)
@@ -479,26 +470,26 @@ class SequentialEngine:
         if not (self._use_sketchmap() and not self.dp.active and self.L == 2 and self.layout.n_enc >= 1):
             return False
         if self.periodic:      # the 32 x 32 VALU tiles of periodic batches (up to 512 rows: the default configuration's 256)
-            return self.B <= min(512, int(os.environ.get("EMX_OVERLAP_MAX_B", "1536")))
-        return self.split_ws is not None and self.B <= int(os.environ.get("EMX_OVERLAP_MAX_B", "1536"))
+            return self.B <= min(512, self._overlap_max_rows)
+        return self.split_ws is not None and self.B <= self._overlap_max_rows
 
     def check_sync(self) -> None:
         """Raises if a wait inside one of the merged launches ever gave up (include/emx.h: the sticky word 2 of their counters): the
         tile / dense-layer workgroups of emx_mlp_forward_backward_tiles[_join] (``sk_sync``), the epilogue workgroup of
-        emx_mlp_wgrad_adam_local or the slice workgroups of emx_mlp_wgrad_adam (``wg_sync``).  A give-up never hangs, but the step it
+        emx_mlp_wgrad_adam_local (``wg_sync``).  A give-up never hangs, but the step it
         happened in -- and every step after it -- worked on incomplete sums.  Called wherever a result leaves the engine (losses,
         weights, encodings, checkpoints); one small device read, and only for engines whose step plan contains such a wait."""
         if not self._waits_used:
             return
         wg, sk = (int(v) for v in torch.stack([self.wg_sync[2], self.sk_sync[2]]).tolist())
         if wg != 0:
-            raise _lib.EmxError("a workgroup of the step's last launch (emx_mlp_wgrad_adam_local / emx_mlp_wgrad_adam) gave up waiting for the "
-                                "others: the results of this run are invalid (set EMX_LOCAL_WGRAD=0 and EMX_TAIL_ADAM=0 for the separate "
+            raise _lib.EmxError("a workgroup of the step's last launch (emx_mlp_wgrad_adam_local) gave up waiting for the "
+                                "others: the results of this run are invalid (SequentialEngine._local_wgrad = False runs the separate "
                                 "launches and report)")
         if sk != 0:
             raise _lib.EmxError("a workgroup of the fused dense-layer launch gave up waiting (tile workgroups for the latent rows, or "
-                                "dense-layer workgroups for the tiles' sums): the results of this run are invalid (set EMX_OVERLAP_TILES=0 / "
-                                "EMX_JOIN_BWD=0 for the separate launches and report)")
+                                "dense-layer workgroups for the tiles' sums): the results of this run are invalid (SequentialEngine._overlap_tiles = "
+                                "False runs the separate launches; please report)")
 
     _waits_used = False   # a launch with an in-launch wait has been issued by this engine (check_sync has something to check)
 
@@ -559,20 +550,12 @@ class SequentialEngine:
     def _step_pre_a(self) -> None:
         """Forward pass, auto cost, decoder backward, all-pairs tiles.  After the forward pass there are two independent
         branches -- the all-pairs kernel (needs only X and the latent) and the auto cost + decoder backward -- which meet at
-        the latent layer; they run back to back on one stream (or forked over two streams with EMX_FORK_STREAMS=1, see __init__)."""
+        the latent layer; they run back to back on one stream."""
         lay, n = self.layout, len(self.layout.layers)
         decoder_done = self._forward()
         if decoder_done:
             if not self._tiles_ran:      # (else the tiles were workgroups of the forward launch)
                 self._latent_costs()
-        elif self._fork:
-            main = torch.cuda.current_stream()
-            side = self._side_stream
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
-            self._latent_costs()
-            main.wait_stream(side)
         else:
             _lib.mlp_backward(self.plan, lay.n_enc, n, self.dY, None, 0, self.rb, self.re, dbelow=self.dlat)
             self._latent_costs()
@@ -609,13 +592,6 @@ class SequentialEngine:
                                   and _lib.mlp_wgrad_adam_local_ws_floats(self.plan, self.re - self.rb) <= self.wg_ws.numel())
         return self._local_ok
 
-    def _tail_fits(self) -> bool:
-        """whether the step's last two launches run as one (emx_mlp_wgrad_adam; decided once per batch shape)"""
-        if self._tail_ok is None:
-            self._tail_ok = bool(self._tail_adam and self._prefetch and type(self)._step_post is SequentialEngine._step_post
-                                 and _lib.mlp_wgrad_adam_fits(self.plan, self.re - self.rb, self._next_batch()))
-        return self._tail_ok
-
     def _late_bookkeeping(self) -> bool:
         """Single process: the step's scalar epilogue rides along with the weight-gradient launch (its inputs are complete
         by then: the regulariser shares of the CURRENT weights were left by the previous optimizer launch, or by
@@ -646,12 +622,6 @@ class SequentialEngine:
                 p = self.p
                 _lib.mlp_wgrad_adam_local(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7, 1.0,
                                           self.red_ws2, self.wg_sync, next_batch=self._next_batch())
-                self._tail_ran = self._waits_used = True
-                return
-            if self._tail_fits():
-                p = self.p
-                _lib.mlp_wgrad_adam(self.plan, self.rb, self.re, self.wg_ws, fin, self.m, self.v, self.l2coef, p.learning_rate, 0.9, 0.999, 1e-7,
-                                    1.0, self.red_ws2, self.wg_sync, next_batch=self._next_batch())
                 self._tail_ran = self._waits_used = True
                 return
         elif self._dp_late_bookkeeping():
@@ -852,7 +822,7 @@ class SequentialEngine:
                 self._graph[0].replay()
             return
         segs = self._dp_segments()
-        wrap = self._graph_wrap if os.environ.get("EMX_DP_WRAP", "1") != "0" else None
+        wrap = self._graph_wrap
         for i in range(k):
             for j, (g, (_, collective)) in enumerate(zip(self._graph, segs)):
                 last = j == len(segs) - 1
@@ -970,8 +940,8 @@ class SequentialEngine:
             for _ in range(k):
                 self._step_body()
 
-    _append_blocks = os.environ.get("EMX_APPEND_BLOCKS", "1") != "0"
-    _draw_ahead = os.environ.get("EMX_DRAW_AHEAD", "1") != "0"   # the next call's batches drawn behind this call's launches
+    _append_blocks = True
+    _draw_ahead = True   # the next call's batches drawn behind this call's launches
     _ring_pos = 0        # batches of the index block consumed (= the device cursor)
     _ring_filled = 0     # batches of the index block that hold drawn indices
     _pending = None      # a batch drawn ahead of its use that went back to the stream

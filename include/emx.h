@@ -536,28 +536,11 @@ int emx_mlp_wgrad(const emx_mlp_desc* desc, float* params, int64_t n_params, int
 /* number of row slices emx_mlp_wgrad leaves in ws for n_rows rows (slice s starts at ws + s * n_params) */
 int emx_mlp_wgrad_slices(int n_rows);
 
-/* A training step's last two launches in one: emx_mlp_wgrad (all layers, with its `finish` epilogue) and
- * emx_adam_step_slices(..., bookkeeping_done = 1) with `next`, i.e. tape.gradient wrt the kernels and biases, Keras History /
- * counters, Adam(lr, clipvalue).apply_gradients and the next tf.data batch (models.py:3392-3401, autoencoder.py:741-743,845-856).
- * The weight-gradient workgroups hand their slice partials to one another inside the launch (sc1 stores, an agent-scope
- * counter) and run the optimizer as their tail; spare workgroups run the epilogue and gather the next batch.  Same results, bit
- * for bit, as the two launches.
- *   finish: required, with hstep, cursor and counter2 (= the optimizer's step counter, read as `step`); the cursor and the
- *     optimizer step are advanced by the launch's last workgroup.
- *   reg_ws: >= EMX_REDUCE_WS floats, receives the regulariser shares of the NEW weights (as bookkeeping_done = 1).
- *   sync: four uint32 counter words (zeroed by the library at first sight); the launch leaves [0], [1], [3] zero again.  [2] != 0: a wait inside the
- *     launch ran out (results of that step are undefined; never expected).
- * Every weight-gradient workgroup must be resident at once: emx_mlp_wgrad_adam_fits says whether that holds on the current
- * device for this network, batch and `next` (1) or the caller has to use the two launches (0); emx_mlp_wgrad_adam itself fails
- * with EMX_EUNSUPPORTED then.  Nothing else may run on the device beside it (a captured step on one stream satisfies that). */
-int emx_mlp_wgrad_adam_fits(const emx_mlp_desc* desc, int n_rows, const emx_next_batch* next /* may be NULL */);
-int emx_mlp_wgrad_adam(const emx_mlp_desc* desc, float* params, int64_t n_params, const void* aop, int aop_rows, int row_begin, int row_end,
-                       float* ws, size_t ws_floats, const emx_finish_desc* finish, float* m, float* v, const float* l2coef /* may be NULL */,
-                       float lr, float beta1, float beta2, float eps, float clip, float* reg_ws, float* mirror,
-                       const emx_next_batch* next /* may be NULL */, uint32_t* sync, emx_stream_t stream);
-
-/* Small batches: the same step tail -- weight gradients of all layers, the `finish` epilogue, L2 + clip + Adam with the operand store,
- * the next batch's rows -- in one launch WITHOUT slice partials: a workgroup owns one 32 x 32 block of one kernel over ALL rows
+/* A training step's last two launches in one, for small batches: emx_mlp_wgrad (all layers, with its `finish` epilogue) and
+ * emx_adam_step_slices(..., bookkeeping_done = 1) with `next`, i.e. tape.gradient wrt the kernels and biases, Keras History / counters,
+ * Adam(lr, clipvalue).apply_gradients and the next tf.data batch (models.py:3392-3401, autoencoder.py:741-743,845-856) -- weight
+ * gradients of all layers, the `finish` epilogue, L2 + clip + Adam with the operand store, the next batch's rows -- in one launch
+ * WITHOUT slice partials: a workgroup owns one 32 x 32 block of one kernel over ALL rows
  * (its four waves a quarter of the row blocks each, summed in LDS in a fixed order) and updates those parameters itself; no
  * workspace, no workgroup waits for another.  Deterministic; the gradient's summation order differs from emx_mlp_wgrad's, so
  * results agree with the two launches to float32 rounding of the sums, not bit for bit.

@@ -105,7 +105,7 @@ def dense_layer_errors(em, name, seed=0, local=False):
         unclipped = np.abs(gt) < 0.999
     else:
         # the step up to the weight gradients (no optimizer), as run_steps would enqueue it with the two-launch tail
-        eng._local_ok = eng._tail_ok = False
+        eng._local_ok = False
         eng.idx_block = torch.zeros(eng._block_capacity() * B, dtype=torch.int64, device=eng.device)
         eng.idx_block[:B].copy_(torch.from_numpy(idx).to(eng.device))
         eng.cursor.zero_()

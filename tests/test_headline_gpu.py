@@ -270,7 +270,7 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, peri
         data = blobs(rng, 6000, D)
     idx = rng.integers(0, 6000, (steps, B))
     out = []
-    monkeypatch.setenv("EMX_OVERLAP_MAX_B", "4096")    # (the engine's own limit is 1024 rows: beyond that the separate launches are faster)
+    monkeypatch.setattr(SequentialEngine, "_overlap_max_rows", 4096)    # (the engine's own limit is 1536 rows: beyond that the separate launches are faster)
     # (bit for bit is a statement about ONE kernel: small non-periodic networks take the transposed chain for the plain fused launch
     #  -- another order of summation; the row-block kernel everywhere here, the default's agreement to rounding below)
     monkeypatch.setenv("EMX_TCHAIN", "0")
@@ -309,51 +309,6 @@ def test_tiles_inside_the_fused_launch_change_nothing(em, B, D, steps, sig, peri
     np.testing.assert_allclose(e._engine.losses(), out[1][0], rtol=2e-5)
     w = e._engine.w.cpu().numpy()
     np.testing.assert_allclose(w, out[1][1], rtol=0, atol=2e-4 * np.abs(out[1][1]).max())
-
-
-TAIL_CASES = [
-    # B, D, steps, periodicity, n_neurons
-    (4096, 128, 40, INF, None), (1000, 128, 24, INF, None), (640, 32, 24, INF, None), (256, 10, 24, 2 * math.pi, None), (100, 33, 16, 2 * math.pi, None),
-    (512, 64, 16, INF, [300, 40, 2]), (2048, 128, 16, INF, None), (96, 7, 12, INF, [20, 3]),     # (D = 7: rows without 16-byte lanes -> two launches)
-]
-
-
-@pytest.mark.parametrize("B,D,steps,periodicity,neurons", TAIL_CASES)
-def test_optimizer_as_the_tail_of_the_weight_gradient_launch_changes_nothing(em, B, D, steps, periodicity, neurons, monkeypatch):
-    """emx_mlp_wgrad_adam: weight gradients, scalar epilogue, L2 + clip + Adam with the operand store and the next batch's rows in ONE
-    launch (slice partials handed over inside the launch, counters advanced by its last workgroup) against emx_mlp_wgrad +
-    emx_adam_step_slices -- whole training runs agree BIT FOR BIT: losses and every loss term per step, weights, Adam moments, the
-    operand store, the rows gathered for the step after the last, the counters."""
-    from encodermap_amd import _lib
-    from encodermap_amd.engine import SequentialEngine
-
-    rng = np.random.default_rng(B + D)
-    if periodicity < INF:
-        data = rng.uniform(-math.pi, math.pi, (6000, D)).astype(np.float32)
-    else:
-        data = blobs(rng, 6000, D)
-    idx = rng.integers(0, 6000, (steps, B))
-    out, ran = [], []
-    monkeypatch.setattr(SequentialEngine, "_local_wgrad", False)      # (the engine's default for these shapes: its own test below)
-    for tail in (True, False):
-        monkeypatch.setattr(SequentialEngine, "_tail_adam", tail)
-        kw = dict(n_neurons=neurons, activation_functions=[""] + ["tanh"] * (len(neurons) - 1) + [""]) if neurons else {}
-        p = em.Parameters(periodicity=periodicity, batch_size=B, dist_sig_parameters=(math.sqrt(2.0 * D), 12, 6, 1, 2, 6), n_steps=steps, **kw)
-        e = em.EncoderMap(p, data, read_only=True, model=_weights(p, 2 * D if periodicity < INF else D))
-        eng = e._engine
-        eng.run_steps(steps, torch.from_numpy(idx.reshape(-1)).cuda())
-        loss = eng.losses()
-        ran.append(eng._tail_ran)
-        terms = eng.loss_terms()
-        out.append([loss, eng.w.cpu().numpy(), eng.m.cpu().numpy(), eng.v.cpu().numpy(), eng.plan.mirror.cpu().numpy().view(np.uint8), eng.xb.cpu().numpy(),
-                    eng.xin.cpu().numpy(), np.array([int(eng.step), int(eng.cursor), int(eng.hstep)]), eng.red_ws2.cpu().numpy()]
-                   + [terms[k] for k in sorted(terms)] + ([eng.split_ws.cpu().numpy()] if eng.split_ws is not None else []))
-        assert (eng.wg_sync.cpu().numpy() == 0).all()
-    assert ran[1] is False
-    assert ran[0] == (D % 4 == 0), "the one-launch tail did not run where it fits"
-    for a, b in zip(out[0], out[1]):
-        np.testing.assert_array_equal(a, b)
-    assert np.isfinite(out[0][0]).all() and out[0][0][-1] < out[0][0][0]
 
 
 LOCAL_CASES = [

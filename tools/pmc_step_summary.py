@@ -55,7 +55,14 @@ if not commit:      # (the GPU box has no .git: the stamp __graft_entry__.build(
         commit = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), ".build_commit")).read().strip() or None
     except Exception:
         commit = None
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+try:
+    from bench import source_hash
+    shash = source_hash()
+except Exception:
+    shash = None
 doc = {"workload": f"bench.py --config {cfg}: one training step = the launches below", "commit": os.environ.get("EMX_COMMIT") or commit,
+       "source_hash": shash,
        "command": f"bash tools/run_pmc_step.sh <tag> {cfg}: rocprofv3 --pmc <set> --kernel-trace --output-format csv -- python3 bench.py --config {cfg} "
                   "--steps 40 --warmup 8 --no-cpu-baseline --no-facade (one pass per counter set; medians over the launches)",
        "corrections": "FETCH_SIZE (KB) doubled, WRITE_SIZE (KB) as reported (MI355X_MICROARCH.md, HBM section); durations are those under "
