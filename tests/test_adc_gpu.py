@@ -1,7 +1,10 @@
 """AngleDihedralCartesianEncoderMap on the GPU against the float64 oracle of ADCFunctionalModel.get_loss /
 train_step (oracle.reference_ops.adc_loss, following models/models.py:2260-2521).  Needs an MI355X.
-Tolerance: total loss and every term 2e-4 relative per step over 6 steps (identical weights and batch indices)."""
+Tolerance: total loss 5e-5, every term 2e-4 relative per step over 6 steps (identical weights and batch indices)."""
 import math
+
+import json
+import os
 
 import numpy as np
 import pytest
@@ -9,6 +12,9 @@ import torch
 
 from oracle import reference_ops as R
 
+# total loss / every cost term per step: the north star's 1e-4 halved for the total; measured worst cases 1.3e-5 / 7.6e-5 (the center
+# cost of the fourteen-layer network after six free-running steps): profiles/r06_adc_measured_errors.json
+TOTAL_RTOL, TERM_RTOL = 5e-5, 2e-4
 pytestmark = pytest.mark.gpu
 PI = math.pi
 
@@ -92,9 +98,18 @@ def test_adc_loss_trajectory(em, name, kw, n_res, n_side, B):
             diff = np.abs(a - b.detach().numpy())
             assert (diff > 5e-6).mean() < 0.03 and diff.max() < 2.1e-3
     assert (e._engine.plan.windows is not None) == (name == "fourteen_layers")
-    np.testing.assert_allclose(got, want, rtol=2e-4)
+    # the MEASURED errors behind the bounds below (profiles/r06_adc_measured_errors.json: EMX_RECORD_ADC_ERRORS=<file> appends a record)
+    measured = {"case": name, "steps": n_steps, "total": float(np.max(np.abs(got - np.array(want)) / np.abs(want)))}
     for k in want_terms[0]:
-        np.testing.assert_allclose(terms[k], [t_[k] for t_ in want_terms], rtol=5e-4, atol=1e-7, err_msg=k)
+        w_ = np.array([t_[k] for t_ in want_terms], np.float64)
+        measured[k] = float(np.max(np.abs(np.asarray(terms[k], np.float64) - w_) / np.maximum(np.abs(w_), 1e-7)))
+    print("ADC measured max relative errors:", measured)
+    if os.environ.get("EMX_RECORD_ADC_ERRORS"):
+        with open(os.environ["EMX_RECORD_ADC_ERRORS"], "a") as fh:
+            fh.write(json.dumps(measured) + "\n")
+    np.testing.assert_allclose(got, want, rtol=TOTAL_RTOL)
+    for k in want_terms[0]:
+        np.testing.assert_allclose(terms[k], [t_[k] for t_ in want_terms], rtol=TERM_RTOL, atol=1e-7, err_msg=k)
     # inference on identical weights
     e._engine.set_weights([q.detach().numpy() for q in model.params])
     enc_in = ([data["central_angles"]] if p.use_backbone_angles else []) + [data["central_dihedrals"]] + \
