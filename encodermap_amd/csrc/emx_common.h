@@ -111,6 +111,25 @@ __device__ __forceinline__ float block_sum(float v, float* smem /* >= NT/64 floa
   return r;
 }
 
+// Two float32 values as the two f16 planes of the split operands, packed (element 0 in the low half): hi = f16(v) (round to nearest
+// even), lo = f16(v - hi).  THREE instructions for the pair where the compiler's form of `(_Float16)(v - (float)h)` is six
+// (v_cvt_f32_f16 + v_sub_f32 per element and a second v_cvt_pk_f16_f32): v_fma_mixlo / mixhi_f16 read an f16 half as a float32
+// source and round the float32 result to f16 once; v - hi is exact in float32 (hi is v rounded to eleven bits), so these are the
+// same two roundings, bit for bit (f16 denormals are kept by both forms).  EMX_SPLIT_PLAIN builds the compiler's form (A/B).
+__device__ __forceinline__ void split_f16_pair(const float v0, const float v1, unsigned& hi, unsigned& lo) {
+#ifdef EMX_SPLIT_PLAIN
+  typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const h2 vh = __builtin_convertvector(f2{v0, v1}, h2);
+  const h2 vl = __builtin_convertvector(f2{v0 - (float)vh[0], v1 - (float)vh[1]}, h2);
+  hi = __builtin_bit_cast(unsigned, vh), lo = __builtin_bit_cast(unsigned, vl);
+#else
+  asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v0), "v"(v1));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "v"(v0));
+  asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "v"(v1));
+#endif
+}
+
 // sin and cos of an angle of moderate size (|x| up to a few thousand: data angles are within a few periods): three-term
 // Cody-Waite reduction by pi/2 and the classic degree-7 / degree-8 minimax polynomials on [-pi/4, pi/4], ~1.5 ulp.  The
 // library sincosf carries a Payne-Hanek path for huge arguments that costs ~3 KB of scratch per lane in every kernel that

@@ -103,8 +103,9 @@ typedef float in2_f2 __attribute__((ext_vector_type(2)));
 
 // two float32 values -> the operand's two f16 planes (elements i, i + 1 of a K-step)
 __device__ __forceinline__ void in2_split2(const float v0, const float v1, half8& oh, half8& ol, const int i) {
-  const half2v vh = __builtin_convertvector(in2_f2{v0, v1}, half2v);
-  const half2v vl = __builtin_convertvector(in2_f2{v0 - (float)vh[0], v1 - (float)vh[1]}, half2v);
+  unsigned ph, pl;
+  split_f16_pair(v0, v1, ph, pl);   // (three instructions a pair: emx_common.h)
+  const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
   oh[i] = vh[0], oh[i + 1] = vh[1], ol[i] = vl[0], ol[i + 1] = vl[1];
 }
 

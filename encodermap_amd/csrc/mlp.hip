@@ -232,10 +232,12 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
     }
     half8 hi, lo;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float t = v[e] * s[e];
-      hi[e] = (_Float16)t;
-      lo[e] = (_Float16)(t - (float)hi[e]);
+    for (int e = 0; e < 8; e += 2) {
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      unsigned ph, pl;
+      split_f16_pair(v[e] * s[e], v[e + 1] * s[e + 1], ph, pl);   // (three instructions a pair: emx_common.h)
+      const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
+      hi[e] = vh[0], hi[e + 1] = vh[1], lo[e] = vl[0], lo[e + 1] = vl[1];
     }
     const int k = 32 * grp + sc_c;
     *reinterpret_cast<half8*>(lds + pl + k * 32 + sc_hf * 16) = hi;
@@ -937,10 +939,12 @@ __device__ __forceinline__ void chain_body(const float* p_in, const float* p_top
           }
         }
 #pragma unroll
-        for (int rr = 0; rr < NR; ++rr) {
-          const float x = v[rr] * s[rr];
-          hi[rr] = (_Float16)x;
-          lo[rr] = (_Float16)(x - (float)hi[rr]);
+        for (int rr = 0; rr < NR; rr += 2) {   // (NR is 2 or 4)
+          typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+          unsigned ph, pl;
+          split_f16_pair(v[rr] * s[rr], v[rr + 1] * s[rr + 1], ph, pl);   // (three instructions a pair: emx_common.h)
+          const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
+          hi[rr] = vh[0], hi[rr + 1] = vh[1], lo[rr] = vl[0], lo[rr + 1] = vl[1];
         }
         char* dp = lds + X.dst_pl + col * 32 + 8 * g + kh * (2 * NR);
         *reinterpret_cast<halfR*>(dp) = hi;

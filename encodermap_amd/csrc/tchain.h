@@ -126,10 +126,12 @@ __device__ __forceinline__ void tchain_wave(const TChainK ka, char* lds) {
       pow2_scale_bits<ACT_TOP>(m, s, brs);
     }
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float t = v[e] * s;
-      bh[e] = (_Float16)t;
-      bl[e] = (_Float16)(t - (float)bh[e]);
+    for (int e = 0; e < 8; e += 2) {
+      typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+      unsigned ph, pl;
+      split_f16_pair(v[e] * s, v[e + 1] * s, ph, pl);   // (three instructions a pair: emx_common.h)
+      const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
+      bh[e] = vh[0], bh[e + 1] = vh[1], bl[e] = vl[0], bl[e + 1] = vl[1];
     }
   };
   // The wave's 16 x 32 block of the tensor the CURRENT operand was made from, as weight-gradient fragments (aop.h): the row-scaled

@@ -15,7 +15,9 @@ flags="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=on -mllvm -amdgp
 objs=""
 for src in "$work"/encodermap_amd/csrc/*.hip; do
   obj="$work/$(basename "${src%.hip}").o"
-  hipcc $flags -c "$src" -o "$obj" &
+  per_file=""
+  [ "$(basename "$src")" = infer.hip ] && per_file="-fno-slp-vectorize"   # (as __graft_entry__.EXTRA_FLAGS)
+  hipcc $flags $per_file -c "$src" -o "$obj" &
   objs="$objs $obj"
 done
 wait
