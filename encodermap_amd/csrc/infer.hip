@@ -36,7 +36,9 @@
 // Arithmetic: the dense layers' precision class (split-f16 x 3 products, float32 accumulation; one operand scale per row), another
 // order of summation than the training kernels: results agree with them to float32 rounding, not bit for bit.
 // Scope: every layer of the range at most 128 wide (2 x 64 raw features for a periodic input / output) and the pieces of the range
-// within LDS; anything else answers EMX_EUNSUPPORTED and the caller runs emx_mlp_forward.
+// within LDS -- or ONE wide end (a first layer of any number of inputs, or a last layer of any number of out-features) on the
+// standard shape [wide, tanh 65..128, tanh 65..128, last]: infer16_wide_kernel below stages the wide layer's pieces chunk by chunk.
+// Anything else answers EMX_EUNSUPPORTED and the caller runs emx_mlp_forward.
 #include <cstdlib>
 #include <mutex>
 #include <set>
@@ -76,6 +78,8 @@ struct InArgs {
   float in_scale, out_scale;         // periodic input: 2 pi / period (0: none); periodic output: period / 2 pi (0: none)
   int bias_tab, scale_tab;           // LDS byte offsets: [layer][128] floats; [layer] floats, then 8 words of scratch
   int vec_in, vec_out;               // floats per memory instruction the input / output rows allow (4, 2 or 1)
+  int wide_in, wide_out;             // the first layer has more than 128 inputs / the last more than 128 out-features: their pieces are STAGED
+  int stage;                         // LDS byte offset of the two stage buffers (infer16_wide_kernel)
 };
 // (the record is indexed at run time -- layer tables -- so it is read through the kernel-argument segment itself: indexing the
 //  by-value struct makes hipcc copy all of it to scratch)
@@ -115,12 +119,8 @@ __device__ __forceinline__ void in2_split2(const float v0, const float v1, half8
 //   kind 0: a hidden tanh layer -- the next operand in place, at the fixed scale 2^14 (bias table and cm carry 2 log2 e)
 //   kind 1: a hidden layer of another activation -- float32 rows, activation, the row's power-of-two scale, the split
 //   kind 2: the last layer -- the activated float32 rows are left in `res` for the caller's stores
-template <int S, int T, int KIND = -1>   // KIND >= 0: the layer's kind at compile time (the run-time argument is ignored)
-__device__ __forceinline__ void in2_layer(const char* __restrict__ pieces /* + lane * 16 */, const float* __restrict__ bt /* bias + 4 g */,
-                                          const float cm, const int kind_rt, const int act, half8 (&bh)[4], half8 (&bl)[4], float& rs_b,
-                                          f32x4 (&res)[8]) {
-  const int kind = KIND >= 0 ? KIND : kind_rt;
-  f32x4 acc[T];
+template <int S, int T>
+__device__ __forceinline__ void in2_products(const char* __restrict__ pieces /* + lane * 16 */, const half8 (&bh)[4], const half8 (&bl)[4], f32x4 (&acc)[T]) {
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int s = 0; s < S; ++s) {
@@ -136,6 +136,13 @@ __device__ __forceinline__ void in2_layer(const char* __restrict__ pieces /* + l
       if (t & 1) __builtin_amdgcn_sched_barrier(0);
     }
   }
+}
+// bias, activation and what follows by the layer's kind, from the raw accumulators of its T tiles
+template <int T, int KIND = -1>
+__device__ __forceinline__ void in2_epilogue(f32x4 (&acc)[T], const float* __restrict__ bt /* bias + 4 g */, const float cm, const int kind_rt,
+                                             const int act, half8 (&bh)[4], half8 (&bl)[4], float& rs_b, f32x4 (&res)[8]) {
+  const int kind = KIND >= 0 ? KIND : kind_rt;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int t = 0; t < T; ++t) {
     const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + 16 * t);
@@ -206,6 +213,14 @@ __device__ __forceinline__ void in2_layer(const char* __restrict__ pieces /* + l
       in2_split2(t < T ? acc[t][i & 3] * sc : 0.f, t < T ? acc[t][(i & 3) + 1] * sc : 0.f, bh[s2], bl[s2], i);
     }
   }
+}
+template <int S, int T, int KIND = -1>   // KIND >= 0: the layer's kind at compile time (the run-time argument is ignored)
+__device__ __forceinline__ void in2_layer(const char* __restrict__ pieces /* + lane * 16 */, const float* __restrict__ bt /* bias + 4 g */,
+                                          const float cm, const int kind_rt, const int act, half8 (&bh)[4], half8 (&bl)[4], float& rs_b,
+                                          f32x4 (&res)[8]) {
+  f32x4 acc[T];
+  in2_products<S, T>(pieces, bh, bl, acc);
+  in2_epilogue<T, KIND>(acc, bt, cm, kind_rt, act, bh, bl, rs_b, res);
 }
 
 // the block's rows as the first layer's operand: lane (n, g) takes the eight k of each of the S0 K-steps (compile time: see in2_layer)
@@ -347,7 +362,8 @@ __device__ __forceinline__ void in2_build(const InK ka, char* lds) {
     pow2_scale_bits<WOP_TOP>(mx, sc, rs);
     if (tid == 0) scale_tab[l] = rs;
     char* const pieces = lds + a.L[l].pieces;
-    for (int task = tid; task < T * S * 64; task += IN2_NT) {
+    const bool staged = (l == 0 && a.wide_in) || (l == nl - 1 && a.wide_out);   // (chunk by chunk, inside the row loop)
+    for (int task = tid; task < (staged ? 0 : T * S * 64); task += IN2_NT) {
       const int ln = task & 63, ts = task >> 6;
       const int t = ts / S, s = ts - t * S;
       const int pm = ln & 15, pg = ln >> 4;
@@ -369,9 +385,9 @@ __device__ __forceinline__ void in2_build(const InK ka, char* lds) {
       *reinterpret_cast<half8*>(p + 1024) = lo;
     }
     const float bscale = (l + 1 < nl && a.L[l].act == ACT_TANH) ? IN_TANH_ARG : 1.f;
-    for (int vf = tid; vf < 128; vf += IN2_NT) {
+    for (int vf = tid; vf < 128; vf += IN2_NT) {   // (a wide last layer reads its biases with the staged chunks)
       const int f = nperm ? in_unperm(vf, N >> 1) : vf;
-      bias_tab[l * 128 + vf] = vf < N ? bias[f] * bscale : 0.f;
+      bias_tab[l * 128 + vf] = vf < N ? bias[min(f, N - 1)] * bscale : 0.f;
     }
     __syncthreads();
   }
@@ -505,6 +521,340 @@ __global__ __launch_bounds__(IN2_NT) void infer16_std_kernel(const InArgs) {
   }
 }
 
+// ---- WIDE ENDS: a first layer of more than 128 inputs and / or a last layer of more than 128 out-features (C4: 2 x 512 sines and
+// cosines in, C5: 256 columns; the decoders mirrored).  Their pieces do not fit beside the others in LDS, and streamed per 16-row
+// block from L2 they are what the training kernels run forward-only are bound by (512 KB per block at C4: 64 GB per pass).  Here
+// the WORKGROUP stages them chunk by chunk -- two K-steps of the first layer, four tiles of the last: 32 KB, built from the float32
+// parameters by all 1024 threads, double-buffered, one barrier per chunk -- and its sixteen waves run the chunk on their own 16-row
+// blocks: a staged chunk serves 256 rows (32 KB of L2 reads per 256 rows and chunk).  Everything between the ends is the resident
+// form above.  The rows of a wide input arrive chunk by chunk as well (the next chunk's 16 values per lane requested under the
+// current chunk's products); a non-periodic row is scaled by the running maximum of the chunks seen so far -- a power of two that only
+// ever falls, so the accumulators are rescaled exactly (x ratio <= 1) when it does.
+constexpr int INW_KC = 2;                    // K-steps of a wide first layer per staged chunk (8 tiles x 2 steps x 2 planes = 32 pieces)
+constexpr int INW_NC = 4;                    // tiles of a wide last layer per staged chunk (4 tiles x 4 steps x 2 planes = 32 pieces)
+constexpr int INW_STAGE = 32 * 1024 + 256;   // a stage buffer: the pieces, then the chunk's 64 biases (wide last layer)
+
+// the 16 values of a lane's row in chunk c of a wide first layer (two K-steps); periodic: 8 raw angles in x[sl][4 j], x[sl][4 j + 1]
+template <bool PER_IN>
+__device__ __forceinline__ void inw_request(const float* __restrict__ rp, const int c, const int g, const int in_cols, const int vec_in,
+                                            float (&x)[INW_KC][8]) {
+  if (vec_in == (PER_IN ? 2 : 4)) {
+#pragma unroll
+    for (int sl = 0; sl < INW_KC; ++sl) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (PER_IN) {
+          const f32x2 v = *reinterpret_cast<const f32x2*>(rp + min(16 * (INW_KC * c + sl) + 8 * j + 2 * g, in_cols - 2));
+          x[sl][4 * j] = v[0], x[sl][4 * j + 1] = v[1], x[sl][4 * j + 2] = 0.f, x[sl][4 * j + 3] = 0.f;
+        } else {
+          const f32x4 v = *reinterpret_cast<const f32x4*>(rp + min(32 * (INW_KC * c + sl) + 16 * j + 4 * g, in_cols - 4));
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[sl][4 * j + e] = v[e];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int sl = 0; sl < INW_KC; ++sl) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (PER_IN) {
+          const int col = 16 * (INW_KC * c + sl) + 8 * j + 2 * g;
+          x[sl][4 * j] = rp[min(col, in_cols - 1)], x[sl][4 * j + 1] = rp[min(col + 1, in_cols - 1)], x[sl][4 * j + 2] = 0.f, x[sl][4 * j + 3] = 0.f;
+        } else {
+          const int col = 32 * (INW_KC * c + sl) + 16 * j + 4 * g;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) x[sl][4 * j + e] = rp[min(col + e, in_cols - 1)];
+        }
+      }
+    }
+  }
+}
+
+// The shape is the standard one (infer16_std_kernel) with ONE end wide, every class a template parameter:
+//   WIDE_IN:  [K0 > 128 -> 65 .. 128, tanh] [-> 65 .. 128, tanh] [-> TL tiles]              (an encoder; SX unused)
+//   WIDE_OUT: [SX K-steps -> 65 .. 128, tanh] [-> 65 .. 128, tanh] [-> N > 128]              (a decoder; TL unused)
+template <bool PER_IN, bool WIDE_IN, bool WIDE_OUT, int SX, int TL>
+__global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
+  static_assert(WIDE_IN != WIDE_OUT, "one staged end per launch: two stage pairs and the resident layers do not fit in LDS");
+  extern __shared__ __align__(16) char lds[];
+  const InK ka = (InK)__builtin_amdgcn_kernarg_segment_ptr();
+  const auto& a = *ka;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = lane & 15, g0 = lane >> 4;
+  constexpr int nl = 3;
+  float* const bias_tab = reinterpret_cast<float*>(lds + a.bias_tab);
+  float* const scale_tab = reinterpret_cast<float*>(lds + a.scale_tab);
+  char* const stage = lds + a.stage;
+  in2_build(ka, lds);
+
+  const long n_rows = a.n_rows, n_iters = (a.n_blocks + IN2_NW - 1) / IN2_NW;
+  int in_cols = a.in_cols, vec_in = a.vec_in, out_cols = a.out_cols, vec_out = a.vec_out;
+  const long ld_in = a.ld_in, ld_out = a.ld_out;
+  const float* const in = a.in;
+  float* const out = a.out;
+  const float in_scale = a.in_scale, out_scale = a.out_scale;
+
+  // the staged layer and this thread's part of a chunk: piece lane (ln = tid & 63) of piece pair ts = tid >> 6
+  const int sl_ = WIDE_IN ? 0 : nl - 1;
+  const int SK = a.L[sl_].K, SNn = a.L[sl_].N;
+  const float* const SW = a.params + a.L[sl_].w_off;
+  const float* const Sbias = a.params + a.L[sl_].b_off;
+  const int s_kperm = a.L[sl_].kperm, s_nperm = a.L[sl_].nperm;
+  const int n_chunks = WIDE_IN ? (a.L[sl_].S + INW_KC - 1) / INW_KC : (a.L[sl_].T + INW_NC - 1) / INW_NC;
+  const int ts = tid >> 6, pm = lane & 15, pg = lane >> 4;
+  float s_sc, s_rs;
+  {
+    // (the layer's scale as in2_build left it: rs in the table; sc = 1 / rs, both powers of two)
+    s_rs = scale_tab[sl_];
+    s_sc = __uint_as_float((254u << 23) - __float_as_uint(s_rs));
+  }
+  float wv[8];
+  auto stage_request = [&](const int c) __attribute__((always_inline)) {
+    // WIDE_IN: piece (tile t = ts >> 1, K-step INW_KC c + (ts & 1)); WIDE_OUT: piece (tile INW_NC c + (ts >> 2), K-step ts & 3)
+    int pg_ = pg, pm_ = pm;
+    asm volatile("" : "+v"(pg_), "+v"(pm_));       // (eight 64-bit addresses per thread would otherwise be hoisted out of the chunk loop)
+    const int t = WIDE_IN ? (ts >> 1) : INW_NC * c + (ts >> 2);
+    const int st = WIDE_IN ? INW_KC * c + (ts & 1) : (ts & 3);
+    const int vf = 16 * t + pm_;
+    const int f = s_nperm ? in_unperm(vf, SNn >> 1) : vf;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int vk = 32 * st + in2_kk(pg_, i);
+      const int k = s_kperm ? in_unperm(vk, SK >> 1) : vk;
+      const bool ok = (vf < SNn) & (vk < SK);
+      const float w = SW[ok ? (long)k * SNn + f : 0];
+      wv[i] = ok ? w : 0.f;
+    }
+  };
+  auto stage_store = [&](const int c, char* const buf) __attribute__((always_inline)) {
+    half8 hi, lo;
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) {
+      unsigned ph, pl;
+      split_f16_pair(wv[i] * s_sc, wv[i + 1] * s_sc, ph, pl);
+      const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
+      hi[i] = vh[0], hi[i + 1] = vh[1], lo[i] = vl[0], lo[i + 1] = vl[1];
+    }
+    char* const p = buf + ts * 2048 + lane * 16;
+    *reinterpret_cast<half8*>(p) = hi;
+    *reinterpret_cast<half8*>(p + 1024) = lo;
+    if constexpr (WIDE_OUT) {
+      if (tid < 16 * INW_NC) {
+        const int vf = 16 * INW_NC * c + tid;
+        const int f = s_nperm ? in_unperm(vf, SNn >> 1) : vf;
+        reinterpret_cast<float*>(buf + 32 * 1024)[tid] = vf < SNn ? Sbias[f] : 0.f;
+      }
+    }
+  };
+
+  for (long wi = blockIdx.x; wi < n_iters; wi += gridDim.x) {
+    asm volatile("" : "+s"(in_cols), "+s"(out_cols), "+s"(vec_in), "+s"(vec_out));
+    int g = g0;
+    asm volatile("" : "+v"(g));
+    const long row = (wi * IN2_NW + wave) * IN2_ROWS + n;
+    const float* rp = in + min(row, n_rows - 1) * ld_in;
+    float* const orow = row < n_rows ? out + row * ld_out : nullptr;
+    half8 bh[4], bl[4];
+    float rs_b;
+    if constexpr (WIDE_IN) {
+      // ---- the wide first layer, chunk by chunk into the eight tiles' accumulators
+      float x[INW_KC][8];
+      inw_request<PER_IN>(rp, 0, g, in_cols, vec_in, x);
+      stage_request(0);
+      stage_store(0, stage);
+      __syncthreads();
+      f32x4 acc[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      unsigned m_run = 0;
+      float rs_prev = 0.f;
+      rs_b = TANH_RS;
+      for (int c = 0; c < n_chunks; ++c) {
+        asm volatile("" : "+s"(in_cols), "+s"(vec_in));
+        asm volatile("" : "+v"(g));
+        // the chunk's operand
+        half8 ch[INW_KC], cl[INW_KC];
+        if constexpr (PER_IN) {
+#pragma unroll
+          for (int sl = 0; sl < INW_KC; ++sl) {
+#pragma unroll
+            for (int pq = 0; pq < 4; ++pq) {
+              const int col = 16 * (INW_KC * c + sl) + 8 * (pq >> 1) + 2 * g + (pq & 1);
+              float sn, cs;
+              sincos_bounded(x[sl][4 * (pq >> 1) + (pq & 1)] * in_scale, &sn, &cs);
+              sn = col < in_cols ? sn * 16384.f : 0.f;
+              cs = col < in_cols ? cs * 16384.f : 0.f;
+              in2_split2(sn, cs, ch[sl], cl[sl], 4 * (pq >> 1) + 2 * (pq & 1));
+            }
+          }
+        } else {
+          if (in_cols < 32 * INW_KC * (c + 1)) {              // (wave-uniform: only the last chunk of a ragged row)
+#pragma unroll
+            for (int sl = 0; sl < INW_KC; ++sl)
+#pragma unroll
+              for (int i = 0; i < 8; ++i) x[sl][i] = (32 * (INW_KC * c + sl) + in2_kk(g, i)) < in_cols ? x[sl][i] : 0.f;
+          }
+          float mf = 0.f;
+#pragma unroll
+          for (int sl = 0; sl < INW_KC; ++sl)
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) mf = __builtin_fmaxf(mf, __builtin_fmaxf(__builtin_fabsf(x[sl][i]), __builtin_fabsf(x[sl][i + 1])));
+          m_run = max(m_run, max_xor32(max_xor16(abs_bits(mf))));   // the row's four lanes; the running maximum over the chunks
+          float sc;
+          pow2_scale_bits<ACT_TOP>(m_run, sc, rs_b);
+          const float ratio = c == 0 ? 1.f : sc * rs_prev;          // <= 1, a power of two
+          rs_prev = rs_b;
+          if (__builtin_amdgcn_ballot_w64(ratio != 1.f) != 0) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[t][e] *= ratio;
+          }
+#pragma unroll
+          for (int sl = 0; sl < INW_KC; ++sl)
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) in2_split2(x[sl][i] * sc, x[sl][i + 1] * sc, ch[sl], cl[sl], i);
+        }
+        // the next chunk's rows and weights under this chunk's products (the row registers are free again)
+        if (c + 1 < n_chunks) {
+          inw_request<PER_IN>(rp, c + 1, g, in_cols, vec_in, x);
+          stage_request(c + 1);
+        }
+        // the chunk's products
+        const char* const pb = stage + (c & 1) * INW_STAGE + lane * 16;
+#pragma unroll
+        for (int sl = 0; sl < INW_KC; ++sl) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const char* p = pb + (t * INW_KC + sl) * 2048;
+            const half8 ah = *reinterpret_cast<const half8*>(p), al = *reinterpret_cast<const half8*>(p + 1024);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, cl[sl], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, ch[sl], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, ch[sl], acc[t], 0, 0, 0);
+            if (t & 1) __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (c + 1 < n_chunks) stage_store(c + 1, stage + ((c + 1) & 1) * INW_STAGE);
+        __syncthreads();
+      }
+      f32x4 unused[8];
+      in2_epilogue<8, 0>(acc, bias_tab + 4 * g, scale_tab[0] * rs_b * IN_TANH_ARG, 0, ACT_TANH, bh, bl, rs_b, unused);
+    } else {
+      f32x4 unused[8];
+      in2_input<PER_IN, SX>(rp, g, in_cols, vec_in, in_scale, bh, bl, rs_b);
+      in2_layer<SX, 8, 0>(lds + a.L[0].pieces + lane * 16, bias_tab + 4 * g, scale_tab[0] * IN_TANH_ARG * rs_b, 0, ACT_TANH, bh, bl, rs_b, unused);
+    }
+    {
+      f32x4 unused[8];
+      in2_layer<4, 8, 0>(lds + a.L[1].pieces + lane * 16, bias_tab + 128 + 4 * g, scale_tab[1] * IN_TANH_ARG * TANH_RS, 0, ACT_TANH, bh, bl, rs_b, unused);
+    }
+    if constexpr (!WIDE_OUT) {
+      f32x4 res[8];
+      in2_layer<4, TL, 2>(lds + a.L[2].pieces + lane * 16, bias_tab + 256 + 4 * g, scale_tab[2] * TANH_RS, 2, a.L[2].act, bh, bl, rs_b, res);
+      in2_store(res, orow, g, out_cols, vec_out, out_scale);
+    } else {
+      // ---- the wide last layer, four tiles at a time: products, bias, activation, (atan2,) stores
+      const int l = nl - 1;
+      const int act = a.L[l].act;
+      const float cm = scale_tab[l] * rs_b;          // (the operand: the four K-steps the tanh layer in front of it wrote)
+      stage_request(0);
+      stage_store(0, stage);
+      __syncthreads();
+      for (int c = 0; c < n_chunks; ++c) {
+        asm volatile("" : "+s"(out_cols), "+s"(vec_out));
+        asm volatile("" : "+v"(g));
+        if (c + 1 < n_chunks) stage_request(c + 1);
+        const char* const pb = stage + (c & 1) * INW_STAGE;
+        f32x4 acc[INW_NC];
+#pragma unroll
+        for (int t = 0; t < INW_NC; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+#pragma unroll
+          for (int t = 0; t < INW_NC; ++t) {
+            const char* p = pb + (t * 4 + s) * 2048 + lane * 16;
+            const half8 ah = *reinterpret_cast<const half8*>(p), al = *reinterpret_cast<const half8*>(p + 1024);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[s], acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[s], acc[t], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const float* const bt = reinterpret_cast<const float*>(pb + 32 * 1024) + 4 * g;
+#pragma unroll
+        for (int t = 0; t < INW_NC; ++t) {
+          const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + 16 * t);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[t][e] = fmaf(acc[t][e], cm, b4[e]);
+        }
+        if (act != ACT_NONE) {
+#define INW_ACT(K_, EXPR_)                                                                       \
+  case K_:                                                                                       \
+    _Pragma("unroll") for (int t = 0; t < INW_NC; ++t)                                           \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) { const float xv = acc[t][e]; acc[t][e] = EXPR_; } \
+    break;
+          switch (act) {
+            INW_ACT(ACT_TANH, tanh_f32(xv))
+            INW_ACT(ACT_RELU, act_apply(ACT_RELU, xv))
+            INW_ACT(ACT_SIGMOID, act_apply(ACT_SIGMOID, xv))
+            INW_ACT(ACT_ELU, act_apply(ACT_ELU, xv))
+            INW_ACT(ACT_SOFTPLUS, act_apply(ACT_SOFTPLUS, xv))
+            INW_ACT(ACT_SELU, act_apply(ACT_SELU, xv))
+            INW_ACT(ACT_SOFTSIGN, act_apply(ACT_SOFTSIGN, xv))
+            INW_ACT(ACT_EXP, act_apply(ACT_EXP, xv))
+            default: break;
+          }
+#undef INW_ACT
+        }
+        if (orow != nullptr) {
+          if (out_scale != 0.f) {
+            // PeriodicOutput: virtual out-features (2 k, 2 k + 1) = (sin, cos) of angle k = 32 c + 8 t + 2 g (+ 1)
+#pragma unroll
+            for (int t = 0; t < INW_NC; ++t) {
+              const int k = 8 * (INW_NC * c + t) + 2 * g;
+              if (8 * (INW_NC * c + t) < out_cols) {     // (wave-uniform)
+                const float a0 = atan2f(acc[t][0], acc[t][1]) * out_scale;
+                const float a1 = atan2f(acc[t][2], acc[t][3]) * out_scale;
+                if (vec_out >= 2) {
+                  if (k < out_cols) *reinterpret_cast<f32x2*>(orow + k) = f32x2{a0, a1};
+                } else {
+                  if (k < out_cols) orow[k] = a0;
+                  if (k + 1 < out_cols) orow[k + 1] = a1;
+                }
+              }
+            }
+          } else if (vec_out == 4) {
+#pragma unroll
+            for (int t = 0; t < INW_NC; ++t) {
+              const int col = 16 * (INW_NC * c + t) + 4 * g;
+              if (col < out_cols) *reinterpret_cast<f32x4*>(orow + col) = acc[t];
+            }
+          } else if (vec_out == 2) {
+#pragma unroll
+            for (int t = 0; t < INW_NC; ++t) {
+              const int col = 16 * (INW_NC * c + t) + 4 * g;
+              if (col < out_cols) *reinterpret_cast<f32x2*>(orow + col) = f32x2{acc[t][0], acc[t][1]};
+              if (col + 2 < out_cols) *reinterpret_cast<f32x2*>(orow + col + 2) = f32x2{acc[t][2], acc[t][3]};
+            }
+          } else {
+#pragma unroll
+            for (int t = 0; t < INW_NC; ++t)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const int col = 16 * (INW_NC * c + t) + 4 * g + e;
+                if (col < out_cols) orow[col] = acc[t][e];
+              }
+          }
+        }
+        if (c + 1 < n_chunks) stage_store(c + 1, stage + ((c + 1) & 1) * INW_STAGE);
+        __syncthreads();
+      }
+    }
+  }
+}
+
 int cu_count() {
   static int cached[64] = {};
   int dev = 0;
@@ -552,25 +902,35 @@ int emx_mlp_infer(const emx_mlp_desc* desc, const float* params, int layer_begin
     const int l = layer_begin + i;
     const int K = desc->width[l], N = desc->width[l + 1];
     EMX_REQUIRE(K >= 1 && N >= 1, "%s: layer %d is %d x %d", who, l, K, N);
-    if (K > 128 || N > 128) return fail(EMX_EUNSUPPORTED, "%s: layer %d is %d x %d: the streaming pass takes layers of up to 128 x 128", who, l, K, N);
+    const bool w_in = i == 0 && K > 128 && N <= 128, w_out = i == nl - 1 && N > 128 && K <= 128;
+    if ((K > 128 || N > 128) && !(w_in || w_out))
+      return fail(EMX_EUNSUPPORTED, "%s: layer %d is %d x %d: the streaming pass takes layers of up to 128 x 128 between a wide first and a wide last layer", who, l, K, N);
+    if (w_in) a.wide_in = 1;
+    if (w_out) a.wide_out = 1;
     EMX_REQUIRE(desc->act[l] >= 0 && desc->act[l] <= ACT_LAST, "%s: layer %d: activation %d", who, l, desc->act[l]);
     InLayer& L = a.L[i];
     L.w_off = desc->w_off[l];
     L.b_off = desc->b_off[l];
     L.K = K;
     L.N = N;
-    L.S = in2_class_S(K);
-    L.T = in2_class_T(N);
+    L.S = w_in ? (K + 31) / 32 : in2_class_S(K);     // (a staged layer: the true counts; INW_KC K-steps / INW_NC tiles per chunk)
+    L.T = w_out ? (N + 15) / 16 : (w_in ? 8 : in2_class_T(N));
     L.act = desc->act[l];
     L.kperm = (i == 0 && per_in) ? 1 : 0;
     L.nperm = (i == nl - 1 && per_out) ? 1 : 0;
     L.pieces = lds;
-    lds += L.S * L.T * 2048;
+    if (!(w_in || w_out)) lds += L.S * L.T * 2048;
   }
+  if (a.wide_in && a.wide_out)
+    return fail(EMX_EUNSUPPORTED, "%s: layers [%d, %d) have a wide first AND a wide last layer: one staged end per launch", who, layer_begin, layer_end);
   a.bias_tab = lds;
   lds += nl * 128 * 4;
   a.scale_tab = lds;
   lds += (IN_MAXL + 16) * 4;   // (16 >= waves of a workgroup)
+  if (a.wide_in || a.wide_out) {
+    a.stage = lds;             // (a multiple of 16: pieces are 2 KB, the tables multiples of 64 bytes)
+    lds += 2 * INW_STAGE;
+  }
   if (lds > IN_LDS_MAX) return fail(EMX_EUNSUPPORTED, "%s: the operand pieces of layers [%d, %d) take %d bytes of LDS (%d at most)", who, layer_begin,
                                     layer_end, lds, IN_LDS_MAX);
   a.params = params;
@@ -591,8 +951,22 @@ int emx_mlp_infer(const emx_mlp_desc* desc, const float* params, int layer_begin
   const int grid = (int)std::min<long>(cu_count(), wb);
   typedef void (*Fn)(const InArgs);
   Fn fn = per_in ? &infer16_kernel<true> : &infer16_kernel<false>;
+  if (a.wide_in || a.wide_out) {
+    // one end wide: the standard shape only (two tanh layers of 65 .. 128 units in front of the last layer)
+    const bool std_shape = nl == 3 && a.L[0].act == ACT_TANH && a.L[1].act == ACT_TANH && a.L[0].N > 64 && a.L[0].N <= 128 && a.L[1].N > 64 &&
+                           a.L[1].N <= 128;
+    if (!std_shape)
+      return fail(EMX_EUNSUPPORTED, "%s: layers [%d, %d) with a wide end: the streaming pass takes [wide, tanh 65..128, tanh 65..128, last] shapes only", who,
+                  layer_begin, layer_end);
+#define INW_IN(P_, T_) (P_ ? (Fn)&infer16_wide_kernel<true, true, false, 4, T_> : (Fn)&infer16_wide_kernel<false, true, false, 4, T_>)
+#define INW_OUT(P_, S_) (P_ ? (Fn)&infer16_wide_kernel<true, false, true, S_, 8> : (Fn)&infer16_wide_kernel<false, false, true, S_, 8>)
+    if (a.wide_in) fn = a.L[2].T == 1 ? INW_IN(per_in, 1) : a.L[2].T == 2 ? INW_IN(per_in, 2) : a.L[2].T == 4 ? INW_IN(per_in, 4) : INW_IN(per_in, 8);
+    else fn = a.L[0].S == 1 ? INW_OUT(per_in, 1) : a.L[0].S == 2 ? INW_OUT(per_in, 2) : INW_OUT(per_in, 4);
+#undef INW_IN
+#undef INW_OUT
+  }
   // the standard shape (two hidden tanh layers of 65 .. 128 units, then the last layer) has a kernel of its own per (S0, TL)
-  if (nl == 3 && a.L[0].T == 8 && a.L[1].S == 4 && a.L[1].T == 8 && a.L[2].S == 4 && a.L[0].act == ACT_TANH && a.L[1].act == ACT_TANH) {
+  if (!a.wide_in && !a.wide_out && nl == 3 && a.L[0].T == 8 && a.L[1].S == 4 && a.L[1].T == 8 && a.L[2].S == 4 && a.L[0].act == ACT_TANH && a.L[1].act == ACT_TANH) {
 #define IN2_STD(P_, S_, T_) (P_ ? (Fn)&infer16_std_kernel<true, S_, T_> : (Fn)&infer16_std_kernel<false, S_, T_>)
 #define IN2_STD_T(P_, S_) (a.L[2].T == 1 ? IN2_STD(P_, S_, 1) : a.L[2].T == 2 ? IN2_STD(P_, S_, 2) : a.L[2].T == 4 ? IN2_STD(P_, S_, 4) : IN2_STD(P_, S_, 8))
     fn = a.L[0].S == 1 ? IN2_STD_T(per_in, 1) : a.L[0].S == 2 ? IN2_STD_T(per_in, 2) : IN2_STD_T(per_in, 4);

@@ -19,7 +19,7 @@
 // activation derivative taken from the layer's output kept in the SAME register layout.  The prologue is written for latency: the
 // step records come through the scalar cache (wave-uniform indices), every memory request of the launch's head -- input rows,
 // targets, the first layer's pieces, all steps' biases and weight scales (-> LDS tables) -- is in flight before the first wait, the
-// launch's scalars are read once (DESIGN.md section 4 round 5 (d) has the stamps that asked for each of these).
+// launch's scalars are read once (docs/LAB_NOTEBOOK.md section 4 round 5 (d) has the stamps that asked for each of these).
 // The default fused launch for: every width of the range <= 128 (one unit per layer), tanh / linear layers, a non-periodic output with
 // mean_abs or mean_square, the whole network forward and the backward pass down to bwd_begin, at most one row block per compute unit
 // (mlp.hip: try_tchain).  Arithmetic: three f16 products per float32 product on operands split into two planes with a power-of-two

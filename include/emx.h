@@ -430,8 +430,12 @@ int emx_mlp_forward(const emx_mlp_desc* desc, float* params, const float* mirror
  *   0 or INFINITY for either periodicity: plain rows.  No operand store, no fragment store, no workspace: every workgroup builds the
  *   split-f16 operand pieces of the range in its LDS from `params` (emx_mlp_desc offsets).  Same precision class as emx_mlp_forward,
  *   another order of summation (agreement to float32 rounding, not bit for bit).
- * EMX_EUNSUPPORTED (nothing has been launched): a layer of the range wider than 128 on either side, or pieces beyond 160 KB of LDS
- * (e.g. three 128 x 128 layers) -- run emx_mlp_forward (+ emx_periodic_in / emx_periodic_out) instead. */
+ * Widths: every layer at most 128 x 128 (pieces of the whole range resident in LDS) -- or ONE wide end, a first layer of any
+ * number of inputs or a last layer of any number of out-features, on the standard shape [wide end, tanh layer of 65..128 units, tanh
+ * layer of 65..128 units, other end] (n_neurons [128, 128, L] of parameters.py:611-639 on wide data: the wide layer's pieces are
+ * staged through LDS chunk by chunk).
+ * EMX_EUNSUPPORTED (nothing has been launched): any other layer wider than 128, or pieces beyond 160 KB of LDS (e.g. three
+ * 128 x 128 layers) -- run emx_mlp_forward (+ emx_periodic_in / emx_periodic_out) instead. */
 int emx_mlp_infer(const emx_mlp_desc* desc, const float* params, int layer_begin, int layer_end, const float* in, int64_t ld_in,
                   float periodicity_in, int64_t n_rows, float* out, int64_t ld_out, float periodicity_out, emx_stream_t stream);
 /* emx_mlp_forward with the auto cost folded into the same launch (a cost kernel of its own is ~5 us of launch and first-touch

@@ -1,4 +1,4 @@
-// The TRANSPOSED, register-resident chain of Dense layers (plan for the dense layers), as a microbenchmark:
+// The TRANSPOSED, register-resident chain of Dense layers (docs/LAB_NOTEBOOK.md section 8, plan for the dense layers), as a microbenchmark:
 // H^T = W^T X^T on v_mfma_f32_16x16x32_f16 with the weights as the A operand and the 16 batch rows of a block as the N dimension.
 // D comes out as lane (n = batch row, g) holding out-features 16 t + 4 g .. + 3 of tile t; with the k order
 //     kk(g, e) = 4 g + e (e < 4), 16 + 4 g + (e - 4) (e >= 4)
