@@ -297,6 +297,30 @@ __device__ __forceinline__ void in2_input(const float* __restrict__ rp, const in
   }
 }
 
+// atan2 for the periodic outputs: a = min / max of the magnitudes in [0, 1] (v_rcp_f32: 1 ulp), atan(a) = a P(a^2) with a degree-8
+// polynomial fitted at Chebyshev nodes (error 1.2e-8 in exact arithmetic), octant and sign by selects -- 24 instructions where the
+// library's atan2f is ~45; the largest error against float64 over the plane and along the unit circle is 3e-7 rad (one ulp of pi),
+// atan2(0, 0) = 0 as numpy has it.
+__device__ __forceinline__ float in_atan2(const float y, const float x) {
+  const float ax = __builtin_fabsf(x), ay = __builtin_fabsf(y);
+  const float mx = __builtin_fmaxf(ax, ay), mn = __builtin_fminf(ax, ay);
+  const float a = mn * __builtin_amdgcn_rcpf(__builtin_fmaxf(mx, 1e-37f));
+  const float z = a * a;
+  float p = 2.8340642988e-03f;
+  p = fmaf(p, z, -1.6005030503e-02f);
+  p = fmaf(p, z, 4.2587607465e-02f);
+  p = fmaf(p, z, -7.4954454434e-02f);
+  p = fmaf(p, z, 1.0636754098e-01f);
+  p = fmaf(p, z, -1.4202570512e-01f);
+  p = fmaf(p, z, 1.9992483579e-01f);
+  p = fmaf(p, z, -3.3333066781e-01f);
+  p = fmaf(p, z, 9.9999998424e-01f);
+  float r = a * p;
+  r = ay > ax ? 1.5707963267948966f - r : r;
+  r = x < 0.f ? 3.14159265358979f - r : r;
+  return __builtin_copysignf(r, y);
+}
+
 // the result rows: lane (n, g) holds out-features 16 t + 4 g + e of row n; tiles the last layer does not have hold zeros and fall to the
 // per-lane column tests.  orow: the lane's output row (nullptr: the row does not exist)
 __device__ __forceinline__ void in2_store(const f32x4 (&res)[8], float* const orow, const int g, const int oc, const int vec_out, const float out_scale) {
@@ -307,8 +331,8 @@ __device__ __forceinline__ void in2_store(const f32x4 (&res)[8], float* const or
     for (int t = 0; t < 8; ++t) {
       if (8 * t < oc) {                                  // (wave-uniform: no atan2 for tiles beyond the row)
         const int k = 8 * t + 2 * g;
-        const float a0 = atan2f(res[t][0], res[t][1]) * out_scale;
-        const float a1 = atan2f(res[t][2], res[t][3]) * out_scale;
+        const float a0 = in_atan2(res[t][0], res[t][1]) * out_scale;
+        const float a1 = in_atan2(res[t][2], res[t][3]) * out_scale;
         if (vec_out >= 2) {
           if (k < oc) *reinterpret_cast<f32x2*>(orow + k) = f32x2{a0, a1};
         } else {
@@ -534,6 +558,23 @@ constexpr int INW_KC = 2;                    // K-steps of a wide first layer pe
 constexpr int INW_NC = 4;                    // tiles of a wide last layer per staged chunk (4 tiles x 4 steps x 2 planes = 32 pieces)
 constexpr int INW_STAGE = 32 * 1024 + 256;   // a stage buffer: the pieces, then the chunk's 64 biases (wide last layer)
 
+// 2^14 (sin, cos) of an angle given in QUARTER TURNS (u = x 4 / period): the reduction is exact -- q = rint(u), f = u - q in [-1/2, 1/2]
+// -- where sincos_bounded (emx_common.h) spends three fused steps on pi / 2 in three pieces, and the fixed scale 2^14 of the operand is
+// folded into the polynomials' constants: 33 instructions a pair with the split against 41.  The same polynomials and quadrant logic;
+// results differ from sincos_bounded's in the last bit or two (the wide first layer only: the resident form keeps sincos_bounded).
+__device__ __forceinline__ void inw_sincos16(const float u, float& s16, float& c16) {
+  const float q = __builtin_rintf(u);
+  const float f = u - q;
+  const float r = f * 1.5707963267948966f, r16 = f * (1.5707963267948966f * 16384.f);
+  const int n = (int)q;
+  const float r2 = r * r;
+  const float sp = fmaf(r16 * r2, fmaf(r2, fmaf(r2, -1.95152959e-4f, 8.33216087e-3f), -1.66666546e-1f), r16);
+  const float cp = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 2.44331571e-5f * 16384.f, -1.38873163e-3f * 16384.f), 4.16666457e-2f * 16384.f), -8192.f), 16384.f);
+  const float sa = (n & 1) ? cp : sp, cb = (n & 1) ? sp : cp;
+  s16 = (n & 2) ? -sa : sa;
+  c16 = ((n + 1) & 2) ? -cb : cb;
+}
+
 // the 16 values of a lane's row in chunk c of a wide first layer (two K-steps); periodic: 8 raw angles in x[sl][4 j], x[sl][4 j + 1]
 template <bool PER_IN>
 __device__ __forceinline__ void inw_request(const float* __restrict__ rp, const int c, const int g, const int in_cols, const int vec_in,
@@ -595,6 +636,7 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
   const float* const in = a.in;
   float* const out = a.out;
   const float in_scale = a.in_scale, out_scale = a.out_scale;
+  const float in_quarter = in_scale * 0.63661977236758134f;   // angle -> quarter turns (4 / period)
 
   // the staged layer and this thread's part of a chunk: piece lane (ln = tid & 63) of piece pair ts = tid >> 6
   const int sl_ = WIDE_IN ? 0 : nl - 1;
@@ -611,29 +653,45 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
     s_sc = __uint_as_float((254u << 23) - __float_as_uint(s_rs));
   }
   float wv[8];
+  // The thread's eight weights of a chunk: rows k_i of the layer's kernel, ONE column f.  With kk(pg, i) = 4 pg + {0, 1, 2, 3, 16, 17, 18,
+  // 19} the rows are a per-thread base plus eight wave-uniform steps (interleaved (sin, cos) inputs: {0, K/2, 1, K/2 + 1, 8, K/2 + 8,
+  // 9, K/2 + 9}), so the requests are eight scalar base pointers and one 32-bit offset register -- formed per thread and chunk they
+  // were 150 of a chunk's 430 vector instructions, kept per thread eight registers too many.
+  const int t0 = WIDE_IN ? (ts >> 1) : (ts >> 2), st0 = WIDE_IN ? (ts & 1) : (ts & 3);
+  const int vf0 = 16 * t0 + pm;                         // virtual out-feature (of chunk 0 where the chunks walk the out-features)
+  const int vkb = 32 * st0 + 4 * pg;                    // virtual k of element 0 (of chunk 0 where the chunks walk the inputs)
+  const int w_off0 = (s_kperm ? (vkb >> 1) : vkb) * SNn + (s_nperm ? in_unperm(vf0, SNn >> 1) : vf0);
+  const int w_step = WIDE_IN ? (s_kperm ? 32 : 64) * SNn : (s_nperm ? 32 : 64);   // a chunk further, in floats
+  // (rows of element i beyond element 0, branch-free: ci = 2 (ci >> 1) + (ci & 1) for plain inputs, (ci >> 1) + (ci & 1) K / 2 for
+  //  interleaved ones -- a test of s_kperm inside the request loop becomes a branch and a full wait around every load)
+  const int row_pair = s_kperm ? 1 : 2, row_odd = s_kperm ? (SK >> 1) : 1;
   auto stage_request = [&](const int c) __attribute__((always_inline)) {
-    // WIDE_IN: piece (tile t = ts >> 1, K-step INW_KC c + (ts & 1)); WIDE_OUT: piece (tile INW_NC c + (ts >> 2), K-step ts & 3)
-    int pg_ = pg, pm_ = pm;
-    asm volatile("" : "+v"(pg_), "+v"(pm_));       // (eight 64-bit addresses per thread would otherwise be hoisted out of the chunk loop)
-    const int t = WIDE_IN ? (ts >> 1) : INW_NC * c + (ts >> 2);
-    const int st = WIDE_IN ? INW_KC * c + (ts & 1) : (ts & 3);
-    const int vf = 16 * t + pm_;
-    const int f = s_nperm ? in_unperm(vf, SNn >> 1) : vf;
+    const float* const Wc = SW + (long)c * w_step;
+    const int klim = WIDE_IN ? SK - 64 * c : SK;        // virtual k of the chunk below this are inside the layer
+    const bool f_ok = (WIDE_IN ? vf0 : vf0 + 64 * c) < SNn;
+    int vkb_ = vkb, off_ = w_off0;
+    asm volatile("" : "+v"(vkb_), "+v"(off_));          // (loop-variant to the compiler: hoisted, the eight addresses are sixteen registers -- spilled)
+    const unsigned off = f_ok ? (unsigned)off_ : 0u;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int vk = 32 * st + in2_kk(pg_, i);
-      const int k = s_kperm ? in_unperm(vk, SK >> 1) : vk;
-      const bool ok = (vf < SNn) & (vk < SK);
-      const float w = SW[ok ? (long)k * SNn + f : 0];
-      wv[i] = ok ? w : 0.f;
+    for (int i = 0; i < 8; ++i) {                        // all eight requests first, unconditionally (inside the kernel: offset 0 where invalid)
+      const int ci = i < 4 ? i : 12 + i;                 // kk(pg, i) - 4 pg
+      const long di = (long)((ci >> 1) * row_pair + (ci & 1) * row_odd) * SNn;   // (wave-uniform)
+      const float* const q = (vkb_ + ci < klim) ? Wc + di + off : SW;   // (a select of addresses, then ONE load: no branch)
+      wv[i] = *q;
     }
+    // (what was requested out of bounds is zeroed in stage_store, behind the chunk's products: a select right here would wait for
+    //  the eight requests in front of them)
   };
   auto stage_store = [&](const int c, char* const buf) __attribute__((always_inline)) {
     half8 hi, lo;
+    const int klim = WIDE_IN ? SK - 64 * c : SK;
+    const bool f_ok = (WIDE_IN ? vf0 : vf0 + 64 * c) < SNn;
 #pragma unroll
     for (int i = 0; i < 8; i += 2) {
+      const int c0 = i < 4 ? i : 12 + i;
+      const float w0 = (f_ok & (vkb + c0 < klim)) ? wv[i] * s_sc : 0.f, w1 = (f_ok & (vkb + c0 + 1 < klim)) ? wv[i + 1] * s_sc : 0.f;
       unsigned ph, pl;
-      split_f16_pair(wv[i] * s_sc, wv[i + 1] * s_sc, ph, pl);
+      split_f16_pair(w0, w1, ph, pl);
       const half2v vh = __builtin_bit_cast(half2v, ph), vl = __builtin_bit_cast(half2v, pl);
       hi[i] = vh[0], hi[i + 1] = vh[1], lo[i] = vl[0], lo[i + 1] = vl[1];
     }
@@ -660,8 +718,8 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
     float rs_b;
     if constexpr (WIDE_IN) {
       // ---- the wide first layer, chunk by chunk into the eight tiles' accumulators
-      float x[INW_KC][8];
-      inw_request<PER_IN>(rp, 0, g, in_cols, vec_in, x);
+      float xn[INW_KC][8];
+      inw_request<PER_IN>(rp, 0, g, in_cols, vec_in, xn);
       stage_request(0);
       stage_store(0, stage);
       __syncthreads();
@@ -674,6 +732,18 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
       for (int c = 0; c < n_chunks; ++c) {
         asm volatile("" : "+s"(in_cols), "+s"(vec_in));
         asm volatile("" : "+v"(g));
+        // the next chunk's rows and weights first: they have this chunk's operand arithmetic AND its products to arrive under (requested
+        // behind the operand -- one set of row registers -- they had the products alone, and every wave of the workgroup met the
+        // barrier waiting for them)
+        float x[INW_KC][8];
+#pragma unroll
+        for (int sl = 0; sl < INW_KC; ++sl)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[sl][i] = xn[sl][i];
+        if (c + 1 < n_chunks) {
+          inw_request<PER_IN>(rp, c + 1, g, in_cols, vec_in, xn);
+          stage_request(c + 1);
+        }
         // the chunk's operand
         half8 ch[INW_KC], cl[INW_KC];
         if constexpr (PER_IN) {
@@ -681,21 +751,14 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
           for (int sl = 0; sl < INW_KC; ++sl) {
 #pragma unroll
             for (int pq = 0; pq < 4; ++pq) {
-              const int col = 16 * (INW_KC * c + sl) + 8 * (pq >> 1) + 2 * g + (pq & 1);
+              // (no column masks: columns beyond the row re-read its last ones -- finite -- and meet zero pieces)
               float sn, cs;
-              sincos_bounded(x[sl][4 * (pq >> 1) + (pq & 1)] * in_scale, &sn, &cs);
-              sn = col < in_cols ? sn * 16384.f : 0.f;
-              cs = col < in_cols ? cs * 16384.f : 0.f;
+              inw_sincos16(x[sl][4 * (pq >> 1) + (pq & 1)] * in_quarter, sn, cs);
               in2_split2(sn, cs, ch[sl], cl[sl], 4 * (pq >> 1) + 2 * (pq & 1));
             }
           }
         } else {
-          if (in_cols < 32 * INW_KC * (c + 1)) {              // (wave-uniform: only the last chunk of a ragged row)
-#pragma unroll
-            for (int sl = 0; sl < INW_KC; ++sl)
-#pragma unroll
-              for (int i = 0; i < 8; ++i) x[sl][i] = (32 * (INW_KC * c + sl) + in2_kk(g, i)) < in_cols ? x[sl][i] : 0.f;
-          }
+          // (no column masks: columns beyond the row re-read its last ones -- no news for the maximum -- and meet zero pieces)
           float mf = 0.f;
 #pragma unroll
           for (int sl = 0; sl < INW_KC; ++sl)
@@ -716,11 +779,6 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
           for (int sl = 0; sl < INW_KC; ++sl)
 #pragma unroll
             for (int i = 0; i < 8; i += 2) in2_split2(x[sl][i] * sc, x[sl][i + 1] * sc, ch[sl], cl[sl], i);
-        }
-        // the next chunk's rows and weights under this chunk's products (the row registers are free again)
-        if (c + 1 < n_chunks) {
-          inw_request<PER_IN>(rp, c + 1, g, in_cols, vec_in, x);
-          stage_request(c + 1);
         }
         // the chunk's products
         const char* const pb = stage + (c & 1) * INW_STAGE + lane * 16;
@@ -815,8 +873,8 @@ __global__ __launch_bounds__(IN2_NT) void infer16_wide_kernel(const InArgs) {
             for (int t = 0; t < INW_NC; ++t) {
               const int k = 8 * (INW_NC * c + t) + 2 * g;
               if (8 * (INW_NC * c + t) < out_cols) {     // (wave-uniform)
-                const float a0 = atan2f(acc[t][0], acc[t][1]) * out_scale;
-                const float a1 = atan2f(acc[t][2], acc[t][3]) * out_scale;
+                const float a0 = in_atan2(acc[t][0], acc[t][1]) * out_scale;
+                const float a1 = in_atan2(acc[t][2], acc[t][3]) * out_scale;
                 if (vec_out >= 2) {
                   if (k < out_cols) *reinterpret_cast<f32x2*>(orow + k) = f32x2{a0, a1};
                 } else {
