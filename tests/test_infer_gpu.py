@@ -197,6 +197,58 @@ def test_streaming_inference_strides_alignment_and_row_independence(L):
         np.testing.assert_allclose(O.cpu().numpy(), want, rtol=5e-6, atol=5e-6 * np.abs(want).max())
 
 
+def test_streaming_inference_random_shapes(L):
+    """Forty networks drawn at random among the shapes the pass takes -- narrow, ragged, periodic or not, one end wide or none --
+    with random row counts, row strides and base alignments, each against float64.  (Every draw is reproducible: seed 2026 + i.)"""
+    from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
+
+    for i in range(40):
+        rng = np.random.default_rng(2026 + i)
+        periodic = bool(rng.integers(0, 2))
+        wide = bool(rng.integers(0, 2))
+        if wide:
+            D = int(rng.integers(129, 700)) if not periodic else int(rng.integers(65, 400))
+            n_neurons = [int(rng.integers(65, 129)), int(rng.integers(65, 129)), int(rng.integers(1, 9))]
+            afs = ["", "tanh", "tanh", ""]
+        else:
+            D = int(rng.integers(1, 129)) if not periodic else int(rng.integers(1, 65))
+            n_neurons = [int(rng.integers(3, 129)), int(rng.integers(3, 129)), int(rng.integers(1, 9))]
+            afs = ["", str(rng.choice(["tanh", "relu", "sigmoid"])), "tanh", str(rng.choice(["", "tanh"]))]
+        rows = int(rng.integers(1, 3000))
+        periodicity = float(rng.choice([2 * PI, 360.0])) if periodic else INF
+        lay = build_layout(n_neurons, afs, 2 * D if periodic else D)
+        if not (streamable(lay.layers[:lay.n_enc]) and streamable(lay.layers[lay.n_enc:])):
+            continue
+        flat = init_parameters(lay, 100 + i)
+        arrays = unpack_weights(lay, flat)
+        acts = [l.activation for l in lay.layers]
+        n, ne = len(lay.layers), lay.n_enc
+        plan = L.MlpPlan(lay, torch.from_numpy(flat).cuda(), [None] * n, [None] * n)
+        x = (rng.uniform(-periodicity, periodicity, (rows, D)) if periodic else rng.normal(0, 1, (rows, D)) * rng.choice([0.02, 1.0, 20.0], (rows, 1))).astype(np.float32)
+        z = rng.normal(0, 1.5, (rows, lay.latent_dim)).astype(np.float32)
+        ld, shift = D + int(rng.integers(0, 4)), int(rng.integers(0, 4))        # row stride and base alignment of the input rows
+        xbuf = torch.zeros(rows * ld + 8, device="cuda")
+        X = xbuf[shift: shift + rows * ld].view(rows, ld)[:, :D]
+        X.copy_(torch.from_numpy(x))
+        ldo = D + int(rng.integers(0, 4))
+        obuf = torch.full((rows * ldo + 8,), float("nan"), device="cuda")
+        O = obuf[shift: shift + rows * ldo].view(rows, ldo)[:, :D]
+        enc = torch.full((rows, lay.latent_dim), float("nan"), device="cuda")
+        L.mlp_infer(plan, 0, ne, X, enc, periodicity if periodic else 0.0, 0.0)
+        L.mlp_infer(plan, ne, n, torch.from_numpy(z).cuda(), O, 0.0, periodicity if periodic else 0.0)
+        torch.cuda.synchronize()
+        what = f"draw {i}: D={D} n_neurons={n_neurons} afs={afs} periodic={periodic} rows={rows} ld={ld}/{ldo} shift={shift}"
+        enc_o = reference(x, arrays, acts, 0, ne, periodicity if periodic else None, None)
+        dec_o = reference(z, arrays, acts, ne, n, None, periodicity if periodic else None)
+        np.testing.assert_allclose(enc.cpu().numpy(), enc_o, rtol=5e-6, atol=5e-6 * max(1.0, np.abs(enc_o).max()), err_msg=what)
+        if periodic:
+            assert angle_close(O.cpu().numpy().astype(np.float64), dec_o, periodicity, 2e-5 * periodicity / (2 * PI), reference.radius), what
+        else:
+            np.testing.assert_allclose(O.cpu().numpy(), dec_o, rtol=5e-6, atol=5e-6 * max(1.0, np.abs(dec_o).max()), err_msg=what)
+        if ldo > D:
+            assert torch.isnan(obuf[shift + D:: ldo][: rows - 1]).all(), what       # nothing written beside the rows
+
+
 def test_streaming_inference_rejects(L):
     from encodermap_amd.layout import build_layout, init_parameters
 
@@ -212,8 +264,9 @@ def test_streaming_inference_rejects(L):
     L.mlp_infer(plan, 0, 3, X[:0], O[:0])                    # no rows: nothing to do, no error
 
 
+@pytest.mark.parametrize("D", [12, 300])
 @pytest.mark.parametrize("periodicity", [INF, 2 * PI])
-def test_facade_encode_decode_use_the_streaming_launch(L, periodicity, tmp_path):
+def test_facade_encode_decode_use_the_streaming_launch(L, periodicity, D, tmp_path):
     """em.EncoderMap.encode() / decode() / generate() against the float64 oracle model (north star: 1e-4), one launch per call,
     and -- EMX_INFER_STREAM=0's path -- the training kernels' forward pass agreeing with it."""
     import encodermap_amd as em
@@ -221,8 +274,7 @@ def test_facade_encode_decode_use_the_streaming_launch(L, periodicity, tmp_path)
     from encodermap_amd.layout import build_layout, init_parameters, unpack_weights
 
     rng = np.random.default_rng(3)
-    D = 12
-    periodic = periodicity != INF
+    periodic = periodicity != INF                            # (D = 300: one wide end, the staged form of the launch)
     x = (rng.uniform(-PI, PI, (5000, D)) if periodic else rng.normal(0, 1, (5000, D))).astype(np.float32)
     p = em.Parameters(periodicity=periodicity, n_steps=1, batch_size=256, main_path=str(tmp_path))
     lay = build_layout(p.n_neurons, p.activation_functions, 2 * D if periodic else D)
@@ -237,8 +289,9 @@ def test_facade_encode_decode_use_the_streaming_launch(L, periodicity, tmp_path)
     assert np.array_equal(e.encode(), z)                     # the resident copy: the same kernel, the same bits
     y = e.decode(z[:777])
     y_o = reference(z[:777], w0, acts, lay.n_enc, len(lay.layers), None, periodicity if periodic else None)
+    radius = getattr(reference, "radius", None)              # (angles behind a short (sin, cos) pair: tolerance / length, see angle_close)
     if periodic:
-        assert angle_close(y.astype(np.float64), y_o, periodicity, 1e-4)
+        assert angle_close(y.astype(np.float64), y_o, periodicity, 1e-4, radius)
     else:
         assert np.abs(y - y_o).max() < 1e-4 * max(1.0, np.abs(y_o).max())
     assert np.array_equal(np.asarray(e.generate(z[:777])), y)
@@ -250,6 +303,6 @@ def test_facade_encode_decode_use_the_streaming_launch(L, periodicity, tmp_path)
         SequentialEngine._infer_streaming = old
     np.testing.assert_allclose(z2, z, rtol=1e-5, atol=1e-5)
     if periodic:
-        assert angle_close(y2.astype(np.float64), y.astype(np.float64), periodicity, 1e-4)
+        assert angle_close(y2.astype(np.float64), y.astype(np.float64), periodicity, 1e-4, radius)
     else:
         np.testing.assert_allclose(y2, y, rtol=1e-5, atol=1e-5)
