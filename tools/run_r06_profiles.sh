@@ -10,6 +10,8 @@ for m in encode decode; do python3 bench.py --mode $m --steps 20 --warmup 3 > $o
 python3 bench.py --mode encode --config C1 --steps 50 --warmup 5 --no-cpu-baseline > $o/infer_encode_C1.json 2> /dev/null
 python3 bench.py --mode encode --config C4 --steps 3 --warmup 1 --no-cpu-baseline > $o/infer_encode_C4.json 2> /dev/null
 python3 bench.py --mode encode --config C5 --steps 10 --warmup 2 --no-cpu-baseline > $o/infer_encode_C5.json 2> /dev/null
+python3 bench.py --mode decode --config C4 --steps 3 --warmup 1 --no-cpu-baseline > $o/infer_decode_C4.json 2> /dev/null
+python3 bench.py --mode decode --config C5 --steps 10 --warmup 2 --no-cpu-baseline > $o/infer_decode_C5.json 2> /dev/null
 for c in C2 C5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $o/prof_$c -- python3 bench.py --config $c --steps 300 --warmup 30 --no-cpu-baseline --no-facade > $o/prof_$c.json 2> $o/prof_$c.err
 done
@@ -20,8 +22,10 @@ EMX_DP_GRAPH_ALLREDUCE=0 python3 bench.py --one-rank-dp --steps 300 --warmup 30 
 bash tools/run_pmc_step.sh ${tag}_c2 C2 > $o/pmc_c2.txt 2>&1
 bash tools/run_pmc_infer.sh ${tag}_encode encode > $o/pmc_encode.txt 2>&1
 bash tools/run_pmc_infer.sh ${tag}_decode decode > $o/pmc_decode.txt 2>&1
+bash tools/run_pmc_infer.sh ${tag}_c4_encode encode C4 > $o/pmc_c4_encode.txt 2>&1
+bash tools/run_pmc_infer.sh ${tag}_c4_decode decode C4 > $o/pmc_c4_decode.txt 2>&1
 for c in C2 C5 encode; do echo "== $c"; python3 tools/prof_summary.py $o/prof_$c | head -7; done
-for f in bench bench_short bench_C1 bench_C3 bench_C4 bench_C5 infer_encode infer_decode infer_encode_C1 infer_encode_C4 infer_encode_C5 dp_one_rank_captured dp_one_rank_eager; do
+for f in bench bench_short bench_C1 bench_C3 bench_C4 bench_C5 infer_encode infer_decode infer_encode_C1 infer_encode_C4 infer_encode_C5 infer_decode_C4 infer_decode_C5 dp_one_rank_captured dp_one_rank_eager; do
   python3 -c "
 import json,sys
 try:
