@@ -682,8 +682,31 @@ def inference_pass(eng, which, data, passes, warmup=2):
     return e0.elapsed_time(e1) * 1e-3 / passes, n, nbytes, launches, launches == 1
 
 
-def inference_record(eng, which, data, passes, warmup=2):
+def _inference_traffic(name, which):
+    """HBM bytes per launch of the inference kernel from the PMC passes (the C2 step file holds them: the default run ends with an
+    encode and a decode pass; other configurations: profiles/r06_infer_counters_<config>_<encode|decode>.json) -- under the rule
+    of _counters_file: only counters taken on these kernel sources.  Returns (bytes or None, source)."""
+    if name == "C2":
+        blob, path, reason = _counters_file(name)
+    else:
+        path = os.path.join("profiles", f"r06_infer_counters_{name.lower()}_{which}.json")
+        try:
+            blob, reason = json.load(open(os.path.join(ROOT, path))), None
+            if blob.get("source_hash") != source_hash():
+                blob, reason = None, f"refused: {path} was taken on kernel sources {blob.get('source_hash')}, this build's are {source_hash()}"
+        except Exception:
+            blob, reason = None, "no counters file for this configuration"
+    if blob is None:
+        return None, reason
+    for kname, c in blob["kernels"].items():
+        if "infer16" in kname and (c.get("FETCH_SIZE", 0) > c.get("WRITE_SIZE", 0)) == (which == "encode"):
+            return int(c["hbm_bytes_per_launch"]), f"{path}: {kname} (static: PMC passes, kernel sources {blob.get('source_hash')})"
+    return None, f"{path}: no inference kernel among its launches"
+
+
+def inference_record(eng, which, data, passes, warmup=2, name="C2"):
     t, n, nbytes, launches, streaming = inference_pass(eng, which, data, passes, warmup)
+    traffic, traffic_source = _inference_traffic(name, which) if streaming else (None, "the training kernels forward-only: not profiled")
     lay = eng.layout
     layers = lay.layers[: lay.n_enc] if which == "encode" else lay.layers[lay.n_enc:]
     mults = n * sum(l.n_in * l.n_out for l in layers)
@@ -691,7 +714,7 @@ def inference_record(eng, which, data, passes, warmup=2):
             "kernel": "infer_kernel (one streaming launch: rows in, result out, operand pieces resident in LDS)" if streaming else
                       "chain_kernel<FWD> (the training kernels forward-only: a layer wider than 128 or pieces beyond LDS)",
             "roofline": {"bound": "hbm", "achieved": nbytes / t / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": nbytes / t / HBM_PEAK,
-                         "traffic": None, "algorithmic_bytes": int(nbytes),
+                         "traffic": traffic, "traffic_source": traffic_source, "algorithmic_bytes": int(nbytes),
                          "mfma_f16_frac_executed": 6 * mults / t / F16_PEAK,
                          "note": "algorithmic bytes = 4 (columns in + columns out) per row; the split-f16 matrix products of the pass (three per float32 "
                                  "product) against the dense f16 peak beside it: the two roofs are within a factor of two of each other here"}}
@@ -859,7 +882,7 @@ def main():
         # inference shards over: no collective); warm-up passes, then K timed passes bracketed as the contract says
         barrier()
         t0 = time.perf_counter()
-        rec = inference_record(eng, args.mode, data, max(args.steps, 1), warmup=max(args.warmup, 1))
+        rec = inference_record(eng, args.mode, data, max(args.steps, 1), warmup=max(args.warmup, 1), name=name)
         barrier()
         dt = time.perf_counter() - t0
         t_pass = rec["ms_per_pass"] * 1e-3
@@ -945,7 +968,7 @@ def main():
         if not multi:
             out["launches_per_step"] = launches_per_step(eng)
         if world == 1 and not multi and cfg["model"] == "encodermap" and data is not None:
-            out["inference"] = {w: inference_record(eng, w, data, 10) for w in ("encode", "decode")}
+            out["inference"] = {w: inference_record(eng, w, data, 10, name=name) for w in ("encode", "decode")}
         if world == 1 and not multi and not args.no_facade and name == "C2":
             f = facade_timing(em, cfg, data, device, max(args.steps, 2000))
             out["facade_ms_per_step"] = f["defaults"]
