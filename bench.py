@@ -336,7 +336,7 @@ def roofline_step(name, eng, live_us):
     out = []
     for kname, c in blob["kernels"].items():
         t = c.get("_dur_us_under_pmc")
-        if not t or c.get("_launches_seen", 0) < 8:
+        if not t or c.get("_launches_seen", 0) < 8 or "infer16" in kname:   # (the run's inference passes: not launches of the step)
             continue
         rec = {"kernel": kname, "us_in_step": t, "hbm_bytes": c.get("hbm_bytes_per_launch"),
                "hbm_frac": (c["hbm_bytes_per_launch"] / (t * 1e-6) / HBM_PEAK) if c.get("hbm_bytes_per_launch") else None,
