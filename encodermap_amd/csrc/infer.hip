@@ -551,8 +551,8 @@ __global__ __launch_bounds__(IN2_NT) void infer16_std_kernel(const InArgs) {
 // the WORKGROUP stages them chunk by chunk -- two K-steps of the first layer, four tiles of the last: 32 KB, built from the float32
 // parameters by all 1024 threads, double-buffered, one barrier per chunk -- and its sixteen waves run the chunk on their own 16-row
 // blocks: a staged chunk serves 256 rows (32 KB of L2 reads per 256 rows and chunk).  Everything between the ends is the resident
-// form above.  The rows of a wide input arrive chunk by chunk as well (the next chunk's 16 values per lane requested under the
-// current chunk's products); a non-periodic row is scaled by the running maximum of the chunks seen so far -- a power of two that only
+// form above.  The rows of a wide input arrive chunk by chunk as well (the next chunk's 16 values per lane and the thread's eight
+// weights requested at the head of the current chunk: its operand arithmetic and its products to arrive under); a non-periodic row is scaled by the running maximum of the chunks seen so far -- a power of two that only
 // ever falls, so the accumulators are rescaled exactly (x ratio <= 1) when it does.
 constexpr int INW_KC = 2;                    // K-steps of a wide first layer per staged chunk (8 tiles x 2 steps x 2 planes = 32 pieces)
 constexpr int INW_NC = 4;                    // tiles of a wide last layer per staged chunk (4 tiles x 4 steps x 2 planes = 32 pieces)

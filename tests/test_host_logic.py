@@ -392,3 +392,31 @@ def test_bench_launches_its_own_ranks(tmp_path):
                        env=dict(env, EMX_BENCH_FAIL_CAPTURED="1", EMX_DP_GRAPH_ALLREDUCE="0", WORLD_SIZE="3", RANK="0"), capture_output=True,
                        text=True, timeout=300)
     assert r.returncode != 0 and r.stdout.strip() == ""
+
+
+def test_bench_quotes_counters_of_this_build_only(monkeypatch):
+    """bench.py takes HBM traffic and in-step durations from the committed PMC passes only when they were taken on THESE kernel sources
+    (sha256 over csrc/* and include/*.h): a counters file of another build is refused with a reason, for the step's launches and for
+    the inference launch alike; the step's listing holds the step's launches only."""
+    import bench
+
+    h = bench.source_hash()
+    assert len(h) == 16 and h == bench.source_hash()
+    blob, path, reason = bench._counters_file("C2")
+    if blob is not None:                                   # (the committed file is this build's: it is quoted)
+        assert blob["source_hash"] == h and reason is None
+        n, src = bench._inference_traffic("C2", "encode")
+        assert n is None or (n > 5e8 and "infer16" in src)     # 1e6 x 128 rows in: at least the algorithmic 520 MB
+
+        class E:
+            B, periodic = 4096, False
+
+        listing, _ = bench.roofline_step("C2", E(), {})
+        assert listing and not any("infer16" in r["kernel"] for r in listing)
+    else:
+        assert reason.startswith("refused") or reason.startswith("no counters")
+    monkeypatch.setattr(bench, "source_hash", lambda: "0123456789abcdef")
+    blob, path, reason = bench._counters_file("C2")
+    assert blob is None and reason.startswith("refused") and "0123456789abcdef" in reason
+    assert bench._inference_traffic("C2", "decode")[0] is None and bench._inference_traffic("C4", "encode")[0] is None
+    assert bench.roofline_step("C2", None, {})[0] is None
