@@ -1,7 +1,8 @@
 """The C ABI from plain C: tests/cabi/cabi_consumer.c is compiled with gcc against include/emx.h and libemx.so -- no torch,
 no C++ -- and run as its own process.  CPU: the symbols resolve, version / target answer, argument validation rejects with a
 message.  GPU: known answers of the reference's tests (tests/test_pairwise_distances.py:140-153, tests/test_losses.py:815-907)
-through the ABI with device memory from the HIP runtime API."""
+through the ABI with device memory from the HIP runtime API, and emx_mlp_infer (encode(): autoencoder.py:1110-1136) on a narrow and
+on a wide-input encoder against the same layers in double."""
 import os
 import shutil
 import subprocess
