@@ -97,6 +97,12 @@ SIGNATURES = {
     "emx_mlp_aop_bytes": (_sz, [_p, _i]),
     "emx_mlp_forward": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _i, _p]),
     "emx_mlp_infer": (_i, [_p, _p, _i, _i, _p, _l, _f, _l, _p, _l, _f, _p]),
+    "emx_p2p_handle_bytes": (_i, []),
+    "emx_p2p_create": (_i, [_i, _i, _l, _i, C.POINTER(_p), _p]),
+    "emx_p2p_connect": (_i, [_p, _p]),
+    "emx_p2p_allreduce": (_i, [_p, _p, _l, _f, _p]),
+    "emx_p2p_status": (_i, [_p, C.POINTER(_i)]),
+    "emx_p2p_destroy": (_i, [_p]),
     "emx_mlp_row_blocks": (_i, [_i]),
     "emx_mlp_forward_cost": (_i, [_p, _p, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p, _i, _p]),
     "emx_clash_count": (_i, [_p, _i, _i, _f, _p, _p]),
@@ -616,6 +622,46 @@ def mlp_infer(plan: MlpPlan, l0, l1, x, out, periodicity_in=0.0, periodicity_out
     pout = float(periodicity_out) if (periodicity_out and periodicity_out != float("inf")) else 0.0
     _check(load().emx_mlp_infer(C.byref(plan.desc), _ptr(plan.params), int(l0), int(l1), _ptr(x), x.stride(0), pin, x.shape[0], _ptr(out),
                                 out.stride(0), pout, _stream()), "emx_mlp_infer")
+
+
+class P2PAllReduce:
+    """The one-shot all-reduce of a small buffer over peer-mapped memory (include/emx.h: emx_p2p_*; csrc/p2p.hip) between the ranks of
+    one node.  ``exchange(handle: bytes) -> list of every rank's handle in rank order`` is the caller's transport (the engine:
+    ``torch.distributed.all_gather_object``).  ``__call__(flat, scale)`` reduces in place on torch's current stream."""
+
+    def __init__(self, world: int, rank: int, n_floats: int, exchange, chunks: int = 32):
+        lib = load()
+        self.world, self.rank, self.n = int(world), int(rank), int(n_floats)
+        hb = lib.emx_p2p_handle_bytes()
+        handle = C.create_string_buffer(hb)
+        ctx = _p()
+        _check(lib.emx_p2p_create(self.world, self.rank, self.n, int(chunks), C.byref(ctx), handle), "emx_p2p_create")
+        self._ctx = ctx
+        handles = exchange(bytes(handle.raw))
+        if len(handles) != self.world or any(len(h) != hb for h in handles):
+            raise EmxError(f"P2PAllReduce: {len(handles)} handles for {self.world} ranks")
+        _check(lib.emx_p2p_connect(self._ctx, C.c_char_p(b"".join(handles))), "emx_p2p_connect")
+
+    def __call__(self, flat, scale: float = 1.0) -> None:
+        assert flat.dtype == torch.float32 and flat.is_contiguous() and flat.numel() <= self.n
+        _check(load().emx_p2p_allreduce(self._ctx, _ptr(flat), flat.numel(), float(scale), _stream()), "emx_p2p_allreduce")
+
+    def gave_up(self) -> bool:
+        """(synchronises) a wait for a peer ended without the peer: every result since is invalid"""
+        v = _i(0)
+        _check(load().emx_p2p_status(self._ctx, C.byref(v)), "emx_p2p_status")
+        return bool(v.value)
+
+    def close(self) -> None:
+        if getattr(self, "_ctx", None):
+            load().emx_p2p_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def mlp_forward_backward(plan: MlpPlan, l0, l1, x, row_begin, row_end, cost: "AutoCost", bwd_begin, dbelow=None, train: bool = True):

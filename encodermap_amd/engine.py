@@ -68,13 +68,37 @@ class DataParallel:
     COLLECTIVE_SECONDS = 25e-6
     PAIR_ELEMENT_SECONDS = {False: 17e-6 / (4096.0 * 4096.0 * 128.0 / 2), True: 1.30e-3 / (8192.0 * 8192.0 * 512.0 / 2)}
 
-    def __init__(self, rank: int = 0, world_size: int = 1, mode: str = "replica", group=None, collectives: Optional[int] = None):
+    def __init__(self, rank: int = 0, world_size: int = 1, mode: str = "replica", group=None, collectives: Optional[int] = None,
+                 p2p: bool = False):
+        """``p2p``: the step's collectives as the library's one-shot all-reduce over peer-mapped memory (include/emx.h: emx_p2p_*) instead
+        of the process group's -- ranks of ONE node; one launch per collective, the sum taken in rank order on every rank (bit-identical
+        results), captured in the step's graph.  The process group is still needed once per buffer size, to exchange the IPC handles."""
         if mode not in ("rowblock", "replica"):
             raise ValueError(f"data-parallel mode {mode!r} not available")
         if collectives not in (None, 1, 2):
             raise ValueError(f"collectives must be None (chosen per configuration), 1 or 2, got {collectives!r}")
         self.rank, self.world_size, self.mode, self.group = int(rank), int(world_size), mode, group
         self.collectives = collectives
+        self.p2p = bool(p2p)
+        self._p2p_ctx = {}
+
+    def _p2p_for(self, flat: torch.Tensor):
+        """the one-shot all-reduce for buffers of this size (made at the buffer's first collective: on every rank alike, outside any
+        stream capture -- the engine's warm-up steps run eagerly)"""
+        ar = self._p2p_ctx.get(flat.numel())
+        if ar is None:
+            import torch.distributed as dist
+
+            def exchange(handle: bytes):
+                got = [None] * self.world_size
+                dist.all_gather_object(got, handle, group=self.group)
+                return got
+
+            ar = self._p2p_ctx[flat.numel()] = _lib.P2PAllReduce(self.world_size, self.rank, flat.numel(), exchange)
+        return ar
+
+    def p2p_gave_up(self) -> bool:
+        return any(ar.gave_up() for ar in self._p2p_ctx.values())
 
     def one_collective(self, batch_size: int, n_features: int, periodic: bool) -> bool:
         """Row-block ranks: the rectangle form of the all-pairs pass (one collective per step) or the dealt triangle (two)?
@@ -122,6 +146,9 @@ class DataParallel:
         """A collective of a step: gradients and loss terms in one flat buffer (replica: averaged; row blocks: summed), or --
         ``op="sum"`` -- the row-block ranks' contributions to the latent gradient."""
         if not self.active:
+            return
+        if self.p2p and flat.is_cuda:
+            self._p2p_for(flat)(flat, 1.0 / self.world_size if (op != "sum" and self.mode == "replica") else 1.0)
             return
         import torch.distributed as dist
 
@@ -479,6 +506,9 @@ class SequentialEngine:
         emx_mlp_wgrad_adam_local (``wg_sync``).  A give-up never hangs, but the step it
         happened in -- and every step after it -- worked on incomplete sums.  Called wherever a result leaves the engine (losses,
         weights, encodings, checkpoints); one small device read, and only for engines whose step plan contains such a wait."""
+        if self.dp.p2p and self.dp.p2p_gave_up():
+            raise _lib.EmxError("a rank's one-shot all-reduce (emx_p2p_allreduce) gave up waiting for a peer: the results of this run are "
+                                "invalid (DataParallel(p2p=False) reduces through the process group)")
         if not self._waits_used:
             return
         wg, sk = (int(v) for v in torch.stack([self.wg_sync[2], self.sk_sync[2]]).tolist())
@@ -731,7 +761,7 @@ class SequentialEngine:
         gc.disable()
         try:
             captured = False
-            if self.dp.active and self._dp_graph_allreduce:
+            if self.dp.active and (self._dp_graph_allreduce or self.dp.p2p):   # (the one-shot all-reduce is a plain launch: always captured)
                 # EMX_DP_GRAPH_ALLREDUCE=1 (bench.py sets it when its probe passes): the RCCL all-reduce captured inside the
                 # step's graph, so that the step is one graph again and replays many at a time.  Measured with a one-rank
                 # RCCL group: 92.7 -> 72.4 us per step (profiles/r04_dp_one_rank_*.json).  Library users opt in themselves:

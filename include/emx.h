@@ -712,6 +712,28 @@ int emx_adc_batch_head(const float* feat_data, const float* cart_data, int64_t N
                        float periodicity, float* xin, int ld_xin, const int64_t* step, float soft_a, float soft_b, float scale_c,
                        float* cart_scale, float* feat_mean, emx_stream_t stream);
 
+/* One-shot all-reduce of a small float buffer between the ranks of one node over peer-mapped memory (csrc/p2p.hip): the data-parallel
+ * step's [gradient | cost terms] buffer (one collective per step; the reference itself is single-process,
+ * autoencoder.py:741-748).  Every rank publishes the buffer in uncached device memory its peers have mapped through the HIP IPC
+ * interface, signals, reads all peers' copies over xGMI and adds them IN RANK ORDER -- bit-identical results on every rank.  One
+ * launch per call, no host synchronisation, capturable in a hipGraph.  Protocol of use, the same on every rank:
+ *   emx_p2p_create   allocates this rank's region for buffers of up to n_floats floats, `chunks` workgroups per launch
+ *                    (1 .. EMX_P2P_MAX_CHUNKS; the same on every rank), and writes its IPC handle (emx_p2p_handle_bytes() bytes);
+ *   (the caller exchanges the handles: any transport -- the engine uses torch.distributed's object all-gather)
+ *   emx_p2p_connect  with the world x handle_bytes handles in rank order (the own entry is ignored);
+ *   emx_p2p_allreduce(ctx, buf, n, scale, stream): buf[i] <- scale * sum over ranks of buf[i], in place; every rank must issue the
+ *                    same sequence of calls (n <= n_floats, 16-byte aligned buf);
+ *   emx_p2p_status   *gave_up != 0 (sticky): a wait for a peer ended after ~20 s of polling -- results from then on are invalid;
+ *   emx_p2p_destroy.
+ * Ranks may share a device (separate processes); ranks of other nodes are not reachable this way. */
+#define EMX_P2P_MAX_CHUNKS 64
+int emx_p2p_handle_bytes(void);
+int emx_p2p_create(int world, int rank, int64_t n_floats, int chunks, void** ctx_out, void* handle_out);
+int emx_p2p_connect(void* ctx, const void* handles);
+int emx_p2p_allreduce(void* ctx, float* buf, int64_t n, float scale, emx_stream_t stream);
+int emx_p2p_status(void* ctx, int* gave_up);
+int emx_p2p_destroy(void* ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,7 @@ def _weights(p):
     return unpack_weights(lay, init_parameters(lay, 2))
 
 
-def _worker(rank, world, port, mode, out_dir, euclid=False, collectives=None):
+def _worker(rank, world, port, mode, out_dir, euclid=False, collectives=None, p2p=False):
     import torch.distributed as dist
 
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -55,16 +55,44 @@ def _worker(rank, world, port, mode, out_dir, euclid=False, collectives=None):
 
     data = _data(euclid)
     p = _params(em, euclid)
-    e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=DataParallel(rank, world, mode, collectives=collectives))
+    e = em.EncoderMap(p, data, model=_weights(p), read_only=True, dp=DataParallel(rank, world, mode, collectives=collectives, p2p=p2p))
     assert e._engine._dealt() == (mode == "rowblock" and collectives == 2)
     if mode == "rowblock":
         idx = np.random.default_rng(5).integers(0, 3000, (6, p.batch_size))
         e._engine.run_steps(6, torch.from_numpy(idx.reshape(-1)).cuda())
     else:
         e._engine.run_steps(6)
-    np.savez(os.path.join(out_dir, f"{mode}_{rank}.npz"), loss=e._engine.losses(), w=e._engine.w.cpu().numpy(),
+    if p2p:
+        assert len(e._engine._graph) == 1 and e._engine.dp._p2p_ctx and not e._engine.dp.p2p_gave_up()   # the collectives inside ONE step graph
+    np.savez(os.path.join(out_dir, f"{mode}{'_p2p' if p2p else ''}_{rank}.npz"), loss=e._engine.losses(), w=e._engine.w.cpu().numpy(),
              terms=np.stack([e._engine.loss_terms()[k] for k in ("auto", "reg", "center", "distance")]))
+    dist.barrier()
     dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode,world,collectives", [("replica", 2, None), ("replica", 3, None), ("rowblock", 2, 2), ("rowblock", 3, 1)])
+def test_ranks_reduce_through_peer_mapped_memory(mode, world, collectives, tmp_path):
+    """DataParallel(p2p=True): the step's collectives as the library's one-shot all-reduce (emx_p2p_*: every rank reads its peers'
+    buffers through IPC mappings and adds them in rank order), captured inside the step's graph -- against the same ranks reducing
+    through gloo: identical weights on every rank, and the two transports agree (bit for bit with two ranks: one addition either
+    way; to rounding of the sums' order with three)."""
+    import torch.multiprocessing as mp
+
+    for p2p in (False, True):
+        mp.spawn(_worker, args=(world, _free_port(), mode, str(tmp_path), True, collectives, p2p), nprocs=world, join=True)
+    ref = [np.load(tmp_path / f"{mode}_{r}.npz") for r in range(world)]
+    got = [np.load(tmp_path / f"{mode}_p2p_{r}.npz") for r in range(world)]
+    for r in got[1:]:
+        np.testing.assert_array_equal(got[0]["w"], r["w"])
+        np.testing.assert_array_equal(got[0]["loss"], r["loss"])
+    assert np.isfinite(got[0]["loss"]).all()
+    if world == 2:
+        np.testing.assert_array_equal(got[0]["loss"], ref[0]["loss"])
+        np.testing.assert_array_equal(got[0]["w"], ref[0]["w"])
+    else:
+        np.testing.assert_allclose(got[0]["loss"], ref[0]["loss"], rtol=2e-5)
+        diff = np.abs(got[0]["w"] - ref[0]["w"])
+        assert (diff > 2e-5).mean() < 0.02 and diff.max() < 2e-3
 
 
 @pytest.mark.parametrize("mode,world,euclid,collectives", [("rowblock", 2, False, 2), ("rowblock", 3, False, 2), ("rowblock", 2, True, 2),
