@@ -492,7 +492,7 @@ def start_watchdog(seconds: float, what: str):
     return done.set
 
 
-def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0, port: int = 0) -> bool:
+def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0, port: int = 0, p2p: bool = False) -> bool:
     """N >= 1 ranks over RCCL: one child process per rank checks, BEFORE this process touches the GPU, whether the step with its
     RCCL all-reduce(s) captured in a hipGraph works with this many ranks on this machine
     (encodermap_amd/_probe_graph_allreduce.py: a synthetic [scale, all-reduce, add] graph replayed 200 times against the host-side
@@ -505,6 +505,8 @@ def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 
     env = {k: v for k, v in os.environ.items() if not k.startswith("TORCHELASTIC_")}
     env["EMX_PROBE_PORT"] = str(port or _free_port())     # (agreed between the ranks: agree_on_port)
     env["EMX_PROBE_MODE"] = mode
+    env["EMX_PROBE_P2P"] = "1" if p2p else "0"       # (the other question: the library's one-shot all-reduce over peer-mapped memory)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("RANK", "0")
     env.setdefault("WORLD_SIZE", str(world))
@@ -543,7 +545,7 @@ def self_launch(n_gpus: int, argv) -> int:
     timeout_s = float(os.environ.get("EMX_BENCH_LAUNCH_TIMEOUT", "1500"))
     attempts = [dict()]
     if os.environ.get("EMX_DP_GRAPH_ALLREDUCE") != "0":
-        attempts.append({"EMX_DP_GRAPH_ALLREDUCE": "0"})
+        attempts.append({"EMX_DP_GRAPH_ALLREDUCE": "0", "EMX_DP_P2P": "0"})   # (the second attempt: RCCL, eagerly)
     code = 1
     for extra in attempts:
         env = dict(os.environ, **extra)
@@ -826,6 +828,15 @@ def main():
     if multi and backend == "nccl" and os.environ.get("EMX_DP_GRAPH_ALLREDUCE") != "0":
         probe = probe_graph_allreduce(world, dp_mode, port=agree_on_port(world, rank))
         graph_allreduce = probe
+    # The collectives as the library's ONE-SHOT all-reduce over peer-mapped memory (include/emx.h: emx_p2p_*; one launch, every rank reads
+    # its peers' buffers over xGMI and adds them in rank order) instead of RCCL's: where a second child-process probe -- the all-reduce
+    # itself against RCCL on changing data, then the engine's step with it, 40 captured steps against the RCCL run -- passes on every
+    # rank.  EMX_DP_P2P=0: never; EMX_DP_P2P=1: without asking.  Ranks of one node only (which is what this script launches).
+    p2p_probe = None
+    use_p2p = os.environ.get("EMX_DP_P2P") == "1" and multi
+    if multi and world > 1 and backend == "nccl" and os.environ.get("EMX_DP_P2P") is None:
+        p2p_probe = probe_graph_allreduce(world, dp_mode, port=agree_on_port(world, rank), p2p=True)
+        use_p2p = p2p_probe
     torch.cuda.set_device(device)
     import torch.distributed as dist
 
@@ -846,16 +857,19 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         graph_allreduce = bool(float(flag) == 1.0)
         SequentialEngine._dp_graph_allreduce = graph_allreduce
+        flag = torch.tensor([1.0 if use_p2p else 0.0], device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        use_p2p = bool(float(flag) == 1.0)
 
     rowblock = dp_mode == "rowblock" and world > 1
     gb = B if args.global_batch < 0 else args.global_batch
     batch = (gb or B * world) if rowblock else B     # rows per engine step: the rank's own batch, or the shared one
-    dp = DataParallel(rank, world, dp_mode, collectives=args.collectives or None) if world > 1 else None
+    dp = DataParallel(rank, world, dp_mode, collectives=args.collectives or None, p2p=use_p2p) if world > 1 else None
     if multi and world == 1:
         class _OneRank(DataParallel):      # the data-parallel path with the one rank a single GPU allows
             active = True
 
-        dp = _OneRank(0, 1, dp_mode, collectives=args.collectives or None)
+        dp = _OneRank(0, 1, dp_mode, collectives=args.collectives or None, p2p=use_p2p)
     n_rows = args.rows or cfg["rows"]
     kw = dict(cfg["kw"], batch_size=batch)
     if cfg["model"] == "adc":
@@ -954,8 +968,9 @@ def main():
                        "parallelism": f"dp{world}-{dp_mode}" if world > 1 else "single", "objective": objective,
                        "collectives_per_step": (None if not multi else (1 if (not rowblock or not eng._dealt()) else 2)),
                        "ranks_seen": dist.get_world_size() if multi else 1, "backend": backend if multi else None, "rccl_version": rccl,
-                       "allreduce": ("captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None,
-                       "graph_allreduce_probe": probe,
+                       "allreduce": (("one-shot over peer-mapped memory (emx_p2p_allreduce), captured in the step graph" if use_p2p else
+                                      "captured in the step graph" if graph_allreduce else "eager between the step's graphs") if multi else None),
+                       "graph_allreduce_probe": probe, "p2p_allreduce_probe": p2p_probe,
                        **({"self_test": f"backend {backend}, one device: {one_device}"} if (one_device or backend != "nccl") else {}),
                        "hip_graph": True, "commit": git_head(), "kernel_sources": source_hash()},
             "loss_first_last": [float(losses[0]), float(losses[-1])],

@@ -629,7 +629,7 @@ class P2PAllReduce:
     one node.  ``exchange(handle: bytes) -> list of every rank's handle in rank order`` is the caller's transport (the engine:
     ``torch.distributed.all_gather_object``).  ``__call__(flat, scale)`` reduces in place on torch's current stream."""
 
-    def __init__(self, world: int, rank: int, n_floats: int, exchange, chunks: int = 32):
+    def __init__(self, world: int, rank: int, n_floats: int, exchange, chunks: int = 64):
         lib = load()
         self.world, self.rank, self.n = int(world), int(rank), int(n_floats)
         hb = lib.emx_p2p_handle_bytes()

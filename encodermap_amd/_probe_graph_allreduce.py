@@ -8,6 +8,11 @@ LOCAL_RANK / MASTER_ADDR come from the launcher, the children meet on their own 
       benchmark's layer widths and batch with finite losses and bit-identical weights on every rank.
 Anything else -- an exception, a wrong number, or a hang that the parent ends with its timeout -- means: keep the all-reduce
 eager.  A hang costs only this child: its queues die with it.
+
+EMX_PROBE_P2P=1 asks the other question instead: does the library's one-shot all-reduce over peer-mapped memory (emx_p2p_*, csrc/p2p.hip)
+work between THESE ranks -- (1) 60 all-reduces of changing data, eagerly and from a replayed graph, every rank's result bit-identical
+to every other's and equal to RCCL's to rounding; (2) the engine's data-parallel step with DataParallel(p2p=True), 40 captured steps,
+finite losses, identical weights on every rank, the losses equal to the RCCL run's to 1e-4.
 """
 import os
 import sys
@@ -22,6 +27,13 @@ def main() -> int:
     torch.cuda.set_device(local)
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     n = 66700 + 8                                   # the flat [gradient | loss terms] buffer of the benchmark model
+    if os.environ.get("EMX_PROBE_P2P") == "1":
+        ok = p2p_stage(rank, world, n) and engine_stage(rank, world, os.environ.get("EMX_PROBE_MODE", "replica"), p2p=True)
+        flag = torch.tensor([1.0 if ok else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        torch.cuda.synchronize()
+        dist.destroy_process_group()
+        return 0 if float(flag) == 1.0 else 3
     x = torch.full((n,), float(rank + 1), device="cuda")
     for _ in range(3):                              # communicator set-up and warm-up outside any capture
         dist.all_reduce(x, op=dist.ReduceOp.AVG)
@@ -68,7 +80,61 @@ def main() -> int:
     return 0 if float(flag) == 1.0 else 3
 
 
-def engine_stage(rank: int, world: int, mode: str) -> bool:
+def p2p_stage(rank: int, world: int, n: int) -> bool:
+    """the one-shot all-reduce itself against RCCL: changing data, eager launches and a replayed graph"""
+    import torch
+    import torch.distributed as dist
+
+    from encodermap_amd import _lib
+
+    def exchange(h):
+        got = [None] * world
+        dist.all_gather_object(got, h)
+        return got
+
+    ar = _lib.P2PAllReduce(world, rank, n, exchange)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(1000 + rank)
+    ok = True
+    for it in range(40):
+        x = torch.randn(n, generator=g, device="cuda") * (10.0 ** (it % 5 - 2))
+        want = x.clone()
+        dist.all_reduce(want, op=dist.ReduceOp.SUM)
+        ar(x, 1.0)
+        lo, hi = x.clone(), x.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        torch.cuda.synchronize()
+        scale = float(want.abs().max()) + 1e-30
+        ok = ok and bool((lo == hi).all()) and float((x - want).abs().max()) <= 1e-5 * scale
+    # replayed: y <- mean over the ranks of y, then y <- y / 2 + (rank + 1); the host knows the numbers
+    y = torch.full((n,), float(rank + 1), device="cuda")
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        ar(y, 1.0 / world)                           # (a warm-up launch outside the capture; undone below)
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    gy = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(gy, capture_error_mode="thread_local"):
+            ar(y, 1.0 / world)
+            y.mul_(0.5).add_(float(rank + 1))
+    torch.cuda.current_stream().wait_stream(s)
+    y.fill_(float(rank + 1))
+    torch.cuda.synchronize()
+    ref = [float(r + 1) for r in range(world)]
+    for _ in range(20):
+        gy.replay()
+        m = sum(ref) / world
+        ref = [0.5 * m + (r + 1) for r in range(world)]
+    torch.cuda.synchronize()
+    ok = ok and abs(float(y[0]) - ref[rank]) < 1e-4 * max(1.0, abs(ref[rank])) and bool((y == y[0]).all()) and not ar.gave_up()
+    ar.close()
+    return ok
+
+
+def engine_stage(rank: int, world: int, mode: str, p2p: bool = False) -> bool:
     """the engine's data-parallel step with its collectives captured (bench.py's C2 shape on a small resident set)"""
     import numpy as np
     import torch
@@ -86,13 +152,21 @@ def engine_stage(rank: int, world: int, mode: str) -> bool:
     g.manual_seed(17)
     data = torch.randn(rows, D, generator=g, device="cuda") * 3.0
     p = em.Parameters(n_steps=40, seed=7, periodicity=float("inf"), batch_size=B, dist_sig_parameters=(16.0, 12, 6, 1, 2, 6))
-    e = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=f"cuda:{torch.cuda.current_device()}", dp=_Ranks(rank, world, mode))
+    e = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=f"cuda:{torch.cuda.current_device()}", dp=_Ranks(rank, world, mode, p2p=p2p))
     eng = e._engine
     eng.set_data(data)
     eng.run_steps(40)
     losses = eng.losses()
     if not eng._dp_graph_allreduce or len(eng._graph) != 1:      # (the capture itself fell back to the eager form)
         return False
+    if p2p:
+        # the same 40 steps through RCCL: another order of the sums, the same training run to rounding
+        e2 = em.EncoderMap(p, np.zeros((B, D), "float32"), read_only=True, device=f"cuda:{torch.cuda.current_device()}", dp=_Ranks(rank, world, mode))
+        e2._engine.set_data(data)
+        e2._engine.run_steps(40)
+        l2 = e2._engine.losses()
+        if not (np.isfinite(l2).all() and np.allclose(losses, l2, rtol=1e-4, atol=0)):
+            return False
     w = eng.w.double()
     lo, hi = w.clone(), w.clone()
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)

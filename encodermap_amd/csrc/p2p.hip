@@ -67,7 +67,11 @@ __global__ __launch_bounds__(P2P_NT) void p2p_allreduce_kernel(const P2PArgs a) 
       }
     }
   }
+  // (the chunk's stores -- every thread's -- happen before the barrier, the barrier before the flag's release at system scope: the
+  //  release is cumulative.  An explicit __threadfence_system() of all 256 threads in front of it was 5 us of a one-rank launch.)
+#ifdef P2P_EXTRA_FENCES
   __threadfence_system();
+#endif
   __syncthreads();
   if (tid < a.world) {
     unsigned* const f = reinterpret_cast<unsigned*>(a.peer[tid]) + (long)a.rank * a.chunks + c;
@@ -86,8 +90,10 @@ __global__ __launch_bounds__(P2P_NT) void p2p_allreduce_kernel(const P2PArgs a) 
       __builtin_amdgcn_s_sleep(127);
     }
   }
-  __syncthreads();
+  __syncthreads();      // (the polling threads' acquires at system scope happen before everybody's reads of the peers' slots)
+#ifdef P2P_EXTRA_FENCES
   __threadfence_system();
+#endif
   // (3) the sum over the ranks, in rank order
   for (long i = lo + 4 * tid; i < hi; i += 4 * P2P_NT) {
     if (i + 4 <= hi) {

@@ -216,6 +216,26 @@ def test_bench_script_with_two_ranks(mode, extra, batch, scaling, tmp_path):
     assert all(np.isfinite(v) for v in line["loss_first_last"]) and "cpu_baseline" not in line
 
 
+def test_bench_script_with_two_ranks_over_peer_mapped_memory(tmp_path):
+    """bench.py --gpus 2 with EMX_DP_P2P=1 (the one-shot all-reduce without asking the probe; two ranks on this one GPU, gloo for the
+    rendezvous and the timing's MAX): the line names the transport, the run trains."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMX_BENCH_ONE_DEVICE="1", EMX_BENCH_BACKEND="gloo", EMX_DP_P2P="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "24", "--warmup", "8"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and cfg["ranks_seen"] == 2 and cfg["allreduce"].startswith("one-shot over peer-mapped memory")
+    assert cfg["p2p_allreduce_probe"] is None                      # (forced: nobody was asked)
+    assert all(np.isfinite(v) for v in line["loss_first_last"]) and line["loss_first_last"][1] < line["loss_first_last"][0]
+
+
 def test_bench_without_a_launcher_and_the_probe_decides(tmp_path):
     """(1) ``python bench.py --gpus 2`` with NO launcher and no rank environment -- the form the driver uses for one GPU -- starts its
     own ranks (two on this one GPU through the self-test hooks) and relays one line.  (2) The data-parallel path over RCCL with the
