@@ -40,10 +40,14 @@ def _worker(rank, world, port, out_dir, n_max, calls):
     rng = np.random.default_rng(100 + rank)
     outs = []
     ins = []
+    import time
+
     for k, (n, scale) in enumerate(calls):
         x = (rng.normal(0, 1, n) * 10.0 ** rng.integers(-3, 4)).astype(np.float32)
         ins.append(x)
         t = torch.from_numpy(x).cuda()
+        if rng.integers(0, 3) == 0:
+            time.sleep(float(rng.uniform(0, 0.02)))      # ranks out of step: a launch may wait for its peers, or find them two epochs on
         ar(t, scale)
         outs.append(t)                                   # (no synchronisation between the calls: the launches queue up)
     torch.cuda.synchronize()
