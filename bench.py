@@ -492,7 +492,8 @@ def start_watchdog(seconds: float, what: str):
     return done.set
 
 
-def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0, port: int = 0, p2p: bool = False) -> bool:
+def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 300.0, port: int = 0, p2p: bool = False,
+                          rccl_captured: bool = True) -> bool:
     """N >= 1 ranks over RCCL: one child process per rank checks, BEFORE this process touches the GPU, whether the step with its
     RCCL all-reduce(s) captured in a hipGraph works with this many ranks on this machine
     (encodermap_amd/_probe_graph_allreduce.py: a synthetic [scale, all-reduce, add] graph replayed 200 times against the host-side
@@ -506,6 +507,7 @@ def probe_graph_allreduce(world: int, mode: str = "replica", timeout_s: float = 
     env["EMX_PROBE_PORT"] = str(port or _free_port())     # (agreed between the ranks: agree_on_port)
     env["EMX_PROBE_MODE"] = mode
     env["EMX_PROBE_P2P"] = "1" if p2p else "0"       # (the other question: the library's one-shot all-reduce over peer-mapped memory)
+    env["EMX_PROBE_RCCL_CAPTURED"] = "1" if rccl_captured else "0"   # (what it is timed against: RCCL as the run would use it)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("MASTER_ADDR", "127.0.0.1")
     env.setdefault("RANK", "0")
@@ -830,12 +832,12 @@ def main():
         graph_allreduce = probe
     # The collectives as the library's ONE-SHOT all-reduce over peer-mapped memory (include/emx.h: emx_p2p_*; one launch, every rank reads
     # its peers' buffers over xGMI and adds them in rank order) instead of RCCL's: where a second child-process probe -- the all-reduce
-    # itself against RCCL on changing data, then the engine's step with it, 40 captured steps against the RCCL run -- passes on every
-    # rank.  EMX_DP_P2P=0: never; EMX_DP_P2P=1: without asking.  Ranks of one node only (which is what this script launches).
+    # itself against RCCL on changing data AND faster than RCCL's (200 timed calls each), then the engine's step with it, 40 captured
+    # steps against the RCCL run -- passes on every rank.  EMX_DP_P2P=0: never; EMX_DP_P2P=1: without asking.  Ranks of one node only (which is what this script launches).
     p2p_probe = None
     use_p2p = os.environ.get("EMX_DP_P2P") == "1" and multi
     if multi and world > 1 and backend == "nccl" and os.environ.get("EMX_DP_P2P") is None:
-        p2p_probe = probe_graph_allreduce(world, dp_mode, port=agree_on_port(world, rank), p2p=True)
+        p2p_probe = probe_graph_allreduce(world, dp_mode, port=agree_on_port(world, rank), p2p=True, rccl_captured=bool(graph_allreduce))
         use_p2p = p2p_probe
     torch.cuda.set_device(device)
     import torch.distributed as dist

@@ -130,6 +130,41 @@ def p2p_stage(rank: int, world: int, n: int) -> bool:
         ref = [0.5 * m + (r + 1) for r in range(world)]
     torch.cuda.synchronize()
     ok = ok and abs(float(y[0]) - ref[rank]) < 1e-4 * max(1.0, abs(ref[rank])) and bool((y == y[0]).all()) and not ar.gave_up()
+    if ok and (world > 1 or os.environ.get("EMX_PROBE_TIME") == "1"):      # (EMX_PROBE_TIME: the one-rank self-test of this block)
+        # and it has to be the FASTER collective on this machine: 4 x 50 launches each, from graphs where RCCL lets itself be captured
+        # (the question the first probe answers; eagerly otherwise), the slowest rank's time
+        def timed(fn, captured):
+            z = torch.zeros(n, device="cuda")
+            run = lambda: [fn(z) for _ in range(50)]
+            if captured:
+                gz = torch.cuda.CUDAGraph()
+                with torch.cuda.stream(s):
+                    fn(z)
+                    torch.cuda.synchronize()
+                    with torch.cuda.graph(gz, capture_error_mode="thread_local"):
+                        run()
+                torch.cuda.current_stream().wait_stream(s)
+                run = gz.replay
+            run()
+            torch.cuda.synchronize()
+            dist.barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(4):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+            t = torch.tensor([e0.elapsed_time(e1) / 200.0], device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t)
+
+        t_p2p = timed(lambda z: ar(z, 1.0 / world), True)
+        try:
+            t_rccl = timed(lambda z: dist.all_reduce(z, op=dist.ReduceOp.AVG), os.environ.get("EMX_PROBE_RCCL_CAPTURED", "1") == "1")
+        except Exception:
+            t_rccl = timed(lambda z: dist.all_reduce(z, op=dist.ReduceOp.AVG), False)
+        sys.stderr.write(f"probe (rank {rank}): one-shot all-reduce {t_p2p * 1e3:.1f} us, RCCL {t_rccl * 1e3:.1f} us per call of {n} floats\n")
+        ok = t_p2p < t_rccl
     ar.close()
     return ok
 
