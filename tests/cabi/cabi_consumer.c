@@ -113,6 +113,15 @@ int main(int argc, char** argv) {
     if (emx_mlp_infer(&d, dummy, 0, 1, dummy, 3, 0.f, 1, dummy, 2, 0.f, NULL) != EMX_EINVAL || strlen(emx_last_error()) == 0) return 1;
     if (emx_mlp_infer(&d, dummy, 0, 1, NULL, 4, 0.f, 0, NULL, 2, 0.f, NULL) != EMX_OK) return 1;   /* no rows: nothing to do */
   }
+  {
+    /* emx_p2p_*: a rank outside the world and a chunk count beyond EMX_P2P_MAX_CHUNKS are refused before any device call */
+    void* ctx = NULL;
+    char handle[256];
+    if (emx_p2p_handle_bytes() <= 0 || emx_p2p_handle_bytes() > (int)sizeof handle) return 1;
+    if (emx_p2p_create(2, 2, 100, 8, &ctx, handle) != EMX_EINVAL || ctx != NULL) return 1;
+    if (emx_p2p_create(1, 0, 100, EMX_P2P_MAX_CHUNKS + 1, &ctx, handle) != EMX_EINVAL) return 1;
+    if (emx_p2p_allreduce(NULL, NULL, 1, 1.f, NULL) != EMX_EINVAL) return 1;
+  }
   if (argc < 2 || strcmp(argv[1], "--gpu") != 0) {
     printf("ok (no GPU part)\n");
     return 0;
@@ -177,6 +186,32 @@ int main(int argc, char** argv) {
     if (rc) return rc;
     rc = check_infer(300, st);
     if (rc) return rc;
+  }
+  {
+    /* the one-shot all-reduce with the one rank a single process is: out = scale * in, through the whole protocol (region, handle,
+     * connect, publish / flag / read) */
+    enum { NP = 1000 };
+    void* ctx = NULL;
+    char handle[256];
+    float v_h[NP], *v_d;
+    for (int i = 0; i < NP; ++i) v_h[i] = (float)(i - 500) * 0.25f;
+    CHECK_HIP(hipMalloc((void**)&v_d, sizeof v_h));
+    CHECK_HIP(hipMemcpy(v_d, v_h, sizeof v_h, hipMemcpyHostToDevice));
+    CHECK_EMX(emx_p2p_create(1, 0, NP, 4, &ctx, handle));
+    CHECK_EMX(emx_p2p_connect(ctx, handle));
+    CHECK_EMX(emx_p2p_allreduce(ctx, v_d, NP, 0.5f, st));
+    CHECK_EMX(emx_p2p_allreduce(ctx, v_d, NP, 0.5f, st));
+    CHECK_HIP(hipStreamSynchronize(st));
+    int gave_up = -1;
+    CHECK_EMX(emx_p2p_status(ctx, &gave_up));
+    float w_h[NP];
+    CHECK_HIP(hipMemcpy(w_h, v_d, sizeof w_h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < NP; ++i)
+      if (w_h[i] != v_h[i] * 0.25f) return 7;
+    if (gave_up != 0) return 7;
+    CHECK_EMX(emx_p2p_destroy(ctx));
+    hipFree(v_d);
+    printf("emx_p2p_allreduce with one rank: twice 0.5 x\n");
   }
   printf("ok\n");
   return 0;
