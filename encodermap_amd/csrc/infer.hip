@@ -1032,7 +1032,7 @@ int emx_mlp_infer(const emx_mlp_desc* desc, const float* params, int layer_begin
 #undef IN2_STD
   }
   {
-    static std::mutex mu;                                   // (26 kernels, each raised to the full LDS once)
+    static std::mutex mu;                                   // (40 kernels, each raised to the full LDS once)
     static std::set<const void*> attr_done;
     std::lock_guard<std::mutex> lock(mu);
     if (!attr_done.count(reinterpret_cast<const void*>(fn))) {

@@ -15,10 +15,10 @@
 // scope, and so that a flag written by a peer is seen by the spinning reader.
 //
 // One launch, `chunks` workgroups; workgroup c owns floats [c, c + 1) * n / chunks:
-//   (1) copy the chunk of the caller's buffer into the local slot (epoch & 1), fence at system scope, write the epoch into
-//       flags[rank][c] of EVERY peer (and its own);
-//   (2) wait until flags[p][c] >= epoch for every p (the local copy of the flags: peers write, this rank polls its own memory),
-//       acquire at system scope;
+//   (1) copy the chunk of the caller's buffer into the local slot (epoch & 1); behind a barrier, write the epoch into flags[rank][c] of
+//       EVERY peer (and its own) -- a release at system scope;
+//   (2) wait until flags[p][c] >= epoch for every p (the local copy of the flags: peers write, this rank polls its own memory) -- an
+//       acquire at system scope per poll;
 //   (3) out[i] = scale * (((slot_0[i] + slot_1[i]) + slot_2[i]) + ...) over the ranks in order, reading the peers' slots directly.
 // No barrier at the end: slots alternate by epoch parity, and a rank can only publish epoch e + 2 into the slot of epoch e after
 // its own launch e + 1 has seen every peer's flag e + 1 -- which a peer writes at the START of its launch e + 1, behind its launch e,
@@ -26,7 +26,6 @@
 // launch can be captured in a hipGraph and replayed.  A wait that does not end (a peer died) gives up after ~20 s of polling and sets a
 // sticky word the host reads (emx_p2p_status): the results from then on are invalid, nothing hangs.
 #include <cstring>
-#include <mutex>
 
 #include "emx_common.h"
 
@@ -112,7 +111,7 @@ __global__ __launch_bounds__(P2P_NT) void p2p_allreduce_kernel(const P2PArgs a) 
 }
 
 struct P2PCtx {
-  int world, rank, chunks, device;
+  int world, rank, chunks;
   long n, slot_bytes, flags_bytes, bytes;
   char* local;                    // this rank's region
   char* peer[P2P_MAX_WORLD];      // as mapped here
@@ -135,7 +134,9 @@ int emx_p2p_create(int world, int rank, int64_t n_floats, int chunks, void** ctx
   EMX_REQUIRE(chunks >= 1 && chunks <= EMX_P2P_MAX_CHUNKS, "%s: %d chunks (1 .. %d)", who, chunks, EMX_P2P_MAX_CHUNKS);
   P2PCtx* c = new P2PCtx();
   c->world = world, c->rank = rank, c->chunks = chunks, c->n = n_floats, c->connected = false;
-  if (hipGetDevice(&c->device) != hipSuccess) {
+  int device = -1;
+  if (hipGetDevice(&device) != hipSuccess) {
+    (void)hipGetLastError();
     delete c;
     return fail(EMX_ELAUNCH, "%s: no device", who);
   }
